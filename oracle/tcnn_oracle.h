@@ -1,0 +1,185 @@
+/*
+ * tcnn_oracle.h -- CPU restatement of the tiny-cuda-nn HashGrid + FullyFusedMLP hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (tiny-cuda-nn_amd/, include/)
+ * may include, link or call this.  Allowed users: tests/, __graft_entry__.smoke(),
+ * bench.py's cpu_baseline leg.
+ *
+ * Parity pinning status (see DESIGN.md "Oracle"):
+ *   - grid layout / offset table / hash constants: PINNED by the reference's own known-answer
+ *     test (/root/reference/tests/test_grid.cu:55-71) and by the literal constants in
+ *     /root/reference/include/tiny-cuda-nn/common_device.h:787-791, 854-866.
+ *   - MLP / loss / Adam absolute numerics: PARITY UNPINNED.  The reference has no CPU path,
+ *     cannot be compiled here (no nvcc, empty CUTLASS submodule) and its tests hold no stored
+ *     output tensors; only self-consistency invariants exist (tests/test_common.h:124-223).
+ *     This file restates src/cutlass_mlp.cu:162-316 (CutlassMLP semantics) with fp16 storage and
+ *     fp32 accumulation, and is validated by finite differences and the reference's invariants.
+ *
+ * Conventions: "half" values travel as uint16_t bit patterns (IEEE binary16, RNE conversions).
+ * Matrices named AoS are [N][width] (one sample's features contiguous == the reference's
+ * column-major features x batch GPUMatrix, common.h:166-176).
+ */
+#ifndef TCNN_ORACLE_H
+#define TCNN_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_LEVELS 128 /* multi_level_interface.h:84-88 MAX_N_LEVELS */
+#define ORC_MAX_DIMS 4
+
+enum { ORC_GRID_HASH = 0, ORC_GRID_DENSE = 1, ORC_GRID_TILED = 2 };
+enum { ORC_INTERP_NEAREST = 0, ORC_INTERP_LINEAR = 1, ORC_INTERP_SMOOTHSTEP = 2 };
+enum { ORC_ACT_NONE = 0, ORC_ACT_RELU = 1 };
+enum { ORC_LOSS_L2 = 0, ORC_LOSS_RELATIVE_L2 = 1 };
+
+/* ---- fp16 ---- */
+uint16_t orc_f2h(float f);
+float orc_h2f(uint16_t h);
+void orc_f2h_array(const float* in, uint16_t* out, size_t n);
+void orc_h2f_array(const uint16_t* in, float* out, size_t n);
+
+/* ---- pcg32 (dependencies/pcg32/pcg32.h:40-170) ---- */
+typedef struct {
+	uint64_t state;
+	uint64_t inc;
+} orc_pcg32;
+void orc_pcg32_seed(orc_pcg32* r, uint64_t initstate, uint64_t initseq);
+uint32_t orc_pcg32_next_uint(orc_pcg32* r);
+float orc_pcg32_next_float(orc_pcg32* r);
+void orc_pcg32_advance(orc_pcg32* r, int64_t delta);
+/* std::seed_seq{seed}.generate(2 words), first word (trainer.h:53-56) */
+uint32_t orc_seed_seq_first(uint32_t seed);
+/* random.h:39-75: generate_random_uniform with the kernel's idx <-> stream-position mapping */
+void orc_generate_random_uniform(orc_pcg32* rng, size_t n, float* out, float lower, float upper);
+
+/* ---- grid encoding ---- */
+typedef struct {
+	uint32_t n_dims;
+	uint32_t n_levels;
+	uint32_t n_features_per_level;
+	uint32_t log2_hashmap_size;
+	uint32_t base_resolution;
+	float per_level_scale;
+	int grid_type;
+	int interpolation;
+	uint32_t offsets[ORC_MAX_LEVELS + 1]; /* in grid entries (not features) */
+	float scale[ORC_MAX_LEVELS];
+	uint32_t resolution[ORC_MAX_LEVELS];
+	uint32_t n_params; /* offsets[n_levels] * F */
+} orc_grid;
+
+/* grid.h:673-737.  returns 0 on success */
+int orc_grid_init(orc_grid* g, uint32_t n_dims, uint32_t n_levels, uint32_t n_features_per_level,
+                  uint32_t log2_hashmap_size, uint32_t base_resolution, float per_level_scale,
+                  int grid_type, int interpolation);
+
+/* common_device.h:847-884 grid_index for one corner */
+uint32_t orc_grid_index(const orc_grid* g, uint32_t level, const uint32_t* pos_grid);
+
+/* Per (sample, level, corner) entry index [N][L][2^D] and fp32 weight; for bit-exact tests */
+void orc_grid_indices(const orc_grid* g, const float* positions /*[N][D]*/, uint32_t n,
+                      uint32_t* indices /*[N][L][2^D]*/, float* weights /*[N][L][2^D] or NULL*/);
+
+/* grid.h:49-212 forward.  params: half bits [n_params].  out: half bits AoS [N][out_stride],
+ * columns >= L*F are zero (grid.h:757-766).  fp16 fma chain exactly as grid.h:144-163.
+ * dy_dx (optional): fp32 [N][L*F][D] (grid.h:172-211). */
+void orc_grid_forward(const orc_grid* g, const uint16_t* params, const float* positions, uint32_t n,
+                      uint16_t* out, uint32_t out_stride, float* dy_dx);
+
+/* grid.h:215-320 backward.  dL_dy: half bits AoS [N][dy_stride].  grad: double [n_params],
+ * accumulated (+=) with each contribution rounded to half as the reference does
+ * ((GRAD_T)weight * grad, grid.h:254) but summed exactly -- the "ideal" atomics result. */
+void orc_grid_backward(const orc_grid* g, const float* positions, uint32_t n, const uint16_t* dL_dy,
+                       uint32_t dy_stride, double* grad);
+
+/* grid.h:323-349 input gradient: dL_dx [N][D] fp32 */
+void orc_grid_backward_input(const orc_grid* g, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride,
+                             const float* dy_dx, float* dL_dx);
+
+/* ---- MLP (cutlass_mlp.cu:162-316, fully_fused_mlp.cu:635-678 param layout) ---- */
+typedef struct {
+	uint32_t in_width;      /* padded input width (multiple of 16) */
+	uint32_t width;         /* hidden width */
+	uint32_t out_width;     /* real output width */
+	uint32_t padded_out;    /* next multiple of 16 */
+	uint32_t n_hidden;      /* n_hidden_layers >= 1 */
+	int activation;
+	int output_activation;
+	uint32_t n_params;
+} orc_mlp;
+
+int orc_mlp_init(orc_mlp* m, uint32_t in_width, uint32_t width, uint32_t out_width, uint32_t n_hidden,
+                 int activation, int output_activation);
+/* fully_fused_mlp.cu:868-893 + gpu_matrix.h:292-307 (Xavier uniform, row-major draw order) */
+void orc_mlp_init_params(const orc_mlp* m, orc_pcg32* rng, float* params_fp32, float scale);
+
+/* forward: input half AoS [N][in_width]; hidden (optional, may be NULL) half [n_hidden][N][width]
+ * post-activation; output half AoS [N][padded_out].  accum_fp16 != 0 emulates half accumulators
+ * rounded every 16 k-steps (cutlass_matmul.h:67-68) -- used only to bracket the reference's error. */
+void orc_mlp_forward(const orc_mlp* m, const uint16_t* params, const uint16_t* input, uint32_t n,
+                     uint16_t* hidden, uint16_t* output, int accum_fp16);
+
+/* backward: dL_doutput half [N][padded_out]; needs input + hidden from forward.
+ * grad_params: double [n_params] (+=, caller zeroes for Overwrite) -- may be NULL;
+ * dL_dinput half [N][in_width] -- may be NULL. */
+void orc_mlp_backward(const orc_mlp* m, const uint16_t* params, const uint16_t* input, const uint16_t* hidden,
+                      const uint16_t* output, const uint16_t* dL_doutput, uint32_t n, double* grad_params,
+                      uint16_t* dL_dinput);
+
+/* ---- losses (losses/relative_l2.h:40-76, losses/l2.h:40-76) ----
+ * prediction half [N][stride]; target fp32 [N][dims]; values fp32 [N][stride]; gradients half [N][stride].
+ * n_total_override: 0 -> N*dims (reference); else used as n_total (data-parallel global batch). */
+void orc_loss(int loss_type, uint32_t n, uint32_t stride, uint32_t dims, float loss_scale,
+              const uint16_t* prediction, const float* target, const float* data_pdf, float* values,
+              uint16_t* gradients, uint64_t n_total_override);
+
+/* ---- Adam (optimizers/adam.h:48-127) ---- */
+typedef struct {
+	float learning_rate, beta1, beta2, epsilon, l2_reg, non_matrix_l2_reg;
+	float relative_weight_decay, absolute_weight_decay;
+	float weight_clipping_magnitude, gradient_clipping_magnitude;
+	float non_matrix_learning_rate_factor;
+	int adabound;
+	int optimize_matrix_params, optimize_non_matrix_params, skip_zero_grad_non_matrix_params;
+} orc_adam_hparams;
+void orc_adam_defaults(orc_adam_hparams* h);
+/* gradients: half bits; current_step is the optimizer-wide step AFTER increment (adam.h:159) */
+void orc_adam_step(const orc_adam_hparams* h, uint32_t n, uint32_t n_matrix_weights, float loss_scale,
+                   uint32_t current_step, float* weights_fp32, uint16_t* weights_half,
+                   const uint16_t* gradients, float* m1, float* m2, uint32_t* param_steps);
+
+/* ---- identity encoding (encodings/identity.h:46-66): pads with 1.0 ---- */
+void orc_identity_forward(uint32_t n, uint32_t n_dims, uint32_t padded, const float* in /*[N][n_dims]*/,
+                          uint16_t* out /*[N][padded]*/);
+
+/* ---- whole training step of HashGrid+MLP (trainer.h:254-357), used as cpu_baseline ("port") ----
+ * All buffers owned by caller.  grads_half receives the half-rounded gradient buffer
+ * [mlp | grid] (trainer.h:489-495 layout).  Returns summed loss. */
+typedef struct {
+	orc_grid grid;
+	orc_mlp mlp;
+	int loss_type;
+	orc_adam_hparams adam;
+	uint32_t n_params;    /* mlp.n_params + grid.n_params */
+	uint32_t n_out;       /* real output dims */
+} orc_model;
+int orc_model_init(orc_model* md, uint32_t n_in, uint32_t n_out, const orc_grid* g, uint32_t width,
+                   uint32_t n_hidden, int loss_type, const orc_adam_hparams* adam);
+double orc_training_step(const orc_model* md, uint32_t n, const float* positions, const float* targets,
+                         float* params_fp32, uint16_t* params_half, uint16_t* grads_half, float* m1,
+                         float* m2, uint32_t* steps, uint32_t current_step, float loss_scale,
+                         int run_optimizer, uint16_t* out_prediction /*[N][padded_out] or NULL*/);
+void orc_inference(const orc_model* md, uint32_t n, const float* positions, const uint16_t* params_half,
+                   float* out /*[N][n_out]*/);
+
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,200 @@
+"""numpy front-end for the host SIMT emulator build of the gfx950 kernel sources (tests/emu/hip_emu.h).
+
+TEST INFRASTRUCTURE ONLY.  Lets `pytest -m "not gpu"` run the real kernel code (indexing, MFMA fragment
+bookkeeping, LDS tiles, barriers) on a machine without a GPU and compare it with the CPU oracle.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+_CSRC = os.path.join(_ROOT, "tiny-cuda-nn_amd", "csrc")
+_LIB = os.path.join(_HERE, "libtcnn_emu.so")
+_CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("emu_driver.cpp", "hip_emu.h")]
+    srcs += [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < newest:
+        subprocess.check_call([_CLANG, "-x", "c++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared",
+                               "-Wno-pass-failed", "-I" + _HERE, "-I" + _CSRC, os.path.join(_HERE, "emu_driver.cpp"), "-o", _LIB])
+    return _LIB
+
+
+def available():
+    return os.path.exists(_CLANG)
+
+
+class EmuGrid(C.Structure):
+    _fields_ = [("n_dims", C.c_uint32), ("n_levels", C.c_uint32), ("n_feat", C.c_uint32), ("grid_type", C.c_uint32),
+                ("interp", C.c_uint32), ("max_level", C.c_float), ("offset", C.c_void_p), ("scale", C.c_void_p),
+                ("resolution", C.c_void_p)]
+
+
+class EmuMlp(C.Structure):
+    _fields_ = [("in_width", C.c_uint32), ("width", C.c_uint32), ("padded_out", C.c_uint32),
+                ("n_hidden_matmuls", C.c_uint32), ("activation", C.c_uint32)]
+
+
+class EmuAdam(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("learning_rate", "beta1", "beta2", "epsilon", "l2_reg", "non_matrix_l2_reg",
+                                         "relative_weight_decay", "absolute_weight_decay", "weight_clipping_magnitude",
+                                         "gradient_clipping_magnitude", "non_matrix_learning_rate_factor")] + \
+               [(k, C.c_int) for k in ("adabound", "optimize_matrix_params", "optimize_non_matrix_params",
+                                       "skip_zero_grad_non_matrix_params")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Grid:
+    """Wraps an oracle grid description (oracle.Grid) for the emulated kernels."""
+
+    def __init__(self, og, max_level=1.0):
+        self.og = og
+        L = og.n_levels
+        self._off = np.array(og.offsets[: L + 1], dtype=np.uint32)
+        self._scale = np.array(og.scale[:L], dtype=np.float32)
+        self._res = np.array(og.resolution[:L], dtype=np.uint32)
+        self.c = EmuGrid(og.n_dims, L, og.n_features_per_level, og.grid_type, og.interpolation, max_level,
+                         self._off.ctypes.data, self._scale.ctypes.data, self._res.ctypes.data)
+
+
+def grid_forward(g, params_h, positions, soa=True, out_stride=None, want_dy_dx=False):
+    og = g.og
+    positions = np.ascontiguousarray(positions, dtype=np.float32)
+    n = positions.shape[0]
+    k = og.n_levels * og.n_features_per_level
+    if soa:
+        out = np.zeros((k, n), dtype=np.uint16)
+        stride = n
+    else:
+        stride = out_stride or k
+        out = np.zeros((n, stride), dtype=np.uint16)
+    dy_dx = np.zeros((k, n, og.n_dims), dtype=np.float32) if want_dy_dx else None
+    r = lib().emu_grid_forward(C.byref(g.c), _p(positions), C.c_uint32(n), _p(params_h), _p(out), C.c_int(int(soa)),
+                               C.c_uint32(stride), _p(dy_dx))
+    assert r == 0
+    return (out, dy_dx) if want_dy_dx else out
+
+
+def grid_backward(g, positions, dL_dy_h, soa=True, lds_budget=0):
+    og = g.og
+    positions = np.ascontiguousarray(positions, dtype=np.float32)
+    n = positions.shape[0]
+    dL_dy_h = np.ascontiguousarray(dL_dy_h, dtype=np.uint16)
+    F = og.n_features_per_level
+    grad_h = np.zeros(og.n_params, dtype=np.uint16)
+    grad_f = np.zeros(og.n_params, dtype=np.float32) if F == 1 else None
+    stride = dL_dy_h.shape[1] if not soa else n
+    r = lib().emu_grid_backward(C.byref(g.c), _p(positions), C.c_uint32(n), _p(dL_dy_h), C.c_int(int(soa)),
+                                C.c_uint32(stride), _p(grad_h), _p(grad_f), C.c_uint32(lds_budget))
+    assert r == 0
+    return grad_f if F == 1 else grad_h
+
+
+def grid_backward_input(g, dL_dy_soa_h, dy_dx):
+    og = g.og
+    n = dL_dy_soa_h.shape[1]
+    out = np.zeros((n, og.n_dims), dtype=np.float32)
+    lib().emu_grid_backward_input(C.byref(g.c), C.c_uint32(n), _p(np.ascontiguousarray(dL_dy_soa_h)), C.c_int(1),
+                                  C.c_uint32(n), _p(dy_dx), _p(out))
+    return out
+
+
+def grid_indices(g, positions):
+    og = g.og
+    positions = np.ascontiguousarray(positions, dtype=np.float32)
+    n = positions.shape[0]
+    idx = np.zeros((n, og.n_levels, 1 << og.n_dims), dtype=np.uint32)
+    lib().emu_grid_indices(C.byref(g.c), _p(positions), C.c_uint32(n), _p(idx))
+    return idx
+
+
+def mlp_meta(om):
+    """oracle.Mlp -> EmuMlp"""
+    return EmuMlp(om.in_width, om.width, om.padded_out, om.n_hidden - 1, om.activation)
+
+
+def mlp_forward(om, params_h, input_soa_h, save_hidden=True):
+    n = input_soa_h.shape[1]
+    hidden = np.zeros((om.n_hidden, n, om.width), dtype=np.uint16) if save_hidden else None
+    out = np.zeros((n, om.padded_out), dtype=np.uint16)
+    m = mlp_meta(om)
+    r = lib().emu_mlp_forward(C.byref(m), C.c_uint32(n), _p(params_h), _p(np.ascontiguousarray(input_soa_h)), _p(hidden), _p(out))
+    assert r == 0
+    return hidden, out
+
+
+def mlp_backward(om, params_h, input_soa_h, hidden, dL_doutput_h, want_dinput=True, want_grads=True, grads_init=None):
+    n = input_soa_h.shape[1]
+    dinput = np.zeros((om.in_width, n), dtype=np.uint16) if want_dinput else None
+    grads = None
+    if want_grads:
+        grads = np.zeros(om.n_params, dtype=np.uint16) if grads_init is None else grads_init.copy()
+    m = mlp_meta(om)
+    r = lib().emu_mlp_backward(C.byref(m), C.c_uint32(n), _p(params_h), _p(np.ascontiguousarray(input_soa_h)), _p(hidden),
+                               _p(np.ascontiguousarray(dL_doutput_h)), _p(dinput), _p(grads), C.c_int(int(grads_init is not None)))
+    assert r == 0
+    return grads, dinput
+
+
+def loss(loss_type, prediction_h, target, dims, loss_scale=128.0, data_pdf=None, n_total=None):
+    prediction_h = np.ascontiguousarray(prediction_h, dtype=np.uint16)
+    n, stride = prediction_h.shape
+    values = np.zeros((n, stride), dtype=np.float32)
+    grads = np.zeros((n, stride), dtype=np.uint16)
+    s = np.zeros(1, dtype=np.float32)
+    lib().emu_loss(C.c_int(loss_type), C.c_uint32(n), C.c_uint32(stride), C.c_uint32(dims), C.c_float(loss_scale), _p(prediction_h),
+                   _p(np.ascontiguousarray(target, dtype=np.float32)), _p(data_pdf), _p(values), _p(grads), _p(s),
+                   C.c_uint32(n_total if n_total is not None else n * dims))
+    return values, grads, float(s[0])
+
+
+def adam_step(oh, n_matrix, loss_scale, current_step, w32, w16, grads_h, m1, m2, steps):
+    e = EmuAdam(*[getattr(oh, f[0]) for f in EmuAdam._fields_])
+    lib().emu_adam_step(C.byref(e), C.c_uint32(w32.size), C.c_uint32(n_matrix), C.c_float(loss_scale), C.c_uint32(current_step),
+                        _p(w32), _p(w16), _p(grads_h), _p(m1), _p(m2), _p(steps))
+
+
+def generate_random_uniform(rng, n, lower, upper):
+    """rng: oracle.Pcg32 (state, inc) -- advanced in place like the device helper"""
+    st, inc = C.c_uint64(rng.state), C.c_uint64(rng.inc)
+    out = np.zeros(n, dtype=np.float32)
+    lib().emu_generate_random_uniform(C.byref(st), C.byref(inc), C.c_uint64(n), _p(out), C.c_float(lower), C.c_float(upper))
+    rng.state, rng.inc = st.value, inc.value
+    return out
+
+
+def cast_f32_to_f16(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(x.shape, dtype=np.uint16)
+    lib().emu_cast_f32_to_f16(C.c_uint64(x.size), _p(x), _p(out))
+    return out
+
+
+def identity_forward(x, padded):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros((padded, x.shape[0]), dtype=np.uint16)
+    lib().emu_identity_forward(C.c_uint32(x.shape[0]), C.c_uint32(x.shape[1]), C.c_uint32(padded), _p(x), _p(out))
+    return out

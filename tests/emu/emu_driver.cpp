@@ -1,0 +1,173 @@
+// emu_driver.cpp -- builds the gfx950 kernel SOURCES for the host under the SIMT emulator
+// (hip_emu.h) and exposes them to pytest through a flat C interface (host pointers only).
+// TEST INFRASTRUCTURE ONLY -- see hip_emu.h.
+#define TCNN_HOST_EMU 1
+#include "../../tiny-cuda-nn_amd/csrc/grid_kernels.hip"
+#include "../../tiny-cuda-nn_amd/csrc/elementwise_kernels.hip"
+#include "../../tiny-cuda-nn_amd/csrc/mlp_kernels.hip"
+
+using namespace tcnn_hip;
+
+extern "C" {
+
+struct EmuGrid {
+	uint32_t n_dims, n_levels, n_feat, grid_type, interp;
+	float max_level;
+	const uint32_t* offset;      // [L+1]
+	const float* scale;          // [L]
+	const uint32_t* resolution;  // [L]
+};
+
+static GridMeta make_meta(const EmuGrid* e) {
+	GridMeta m = {};
+	m.n_dims = e->n_dims;
+	m.n_levels = e->n_levels;
+	m.n_feat = e->n_feat;
+	m.grid_type = e->grid_type;
+	m.interp = e->interp;
+	m.max_level = e->max_level;
+	for (uint32_t l = 0; l <= e->n_levels; ++l) m.offset[l] = e->offset[l];
+	for (uint32_t l = 0; l < e->n_levels; ++l) {
+		m.scale[l] = e->scale[l];
+		m.resolution[l] = e->resolution[l];
+	}
+	return m;
+}
+
+// positions: [n][D] ; out: feature-major [L*F][n] when soa != 0 else sample-major [n][out_stride]
+int emu_grid_forward(const EmuGrid* e, const float* positions, uint32_t n, const uint16_t* params, uint16_t* out, int soa,
+                     uint32_t out_stride, float* dy_dx) {
+	try {
+		GridIO io = {positions, e->n_dims, 1, n, soa ? n : 1u, soa ? 1u : out_stride};
+		grid_forward(nullptr, make_meta(e), io, (const half_t*)params, (half_t*)out, dy_dx);
+	} catch (const std::exception& ex) {
+		fprintf(stderr, "emu_grid_forward: %s\n", ex.what());
+		return 1;
+	}
+	return 0;
+}
+
+int emu_grid_backward(const EmuGrid* e, const float* positions, uint32_t n, const uint16_t* dL_dy, int soa, uint32_t dy_stride,
+                      uint16_t* grad_half, float* grad_f32, uint32_t lds_budget) {
+	try {
+		GridIO io = {positions, e->n_dims, 1, n, soa ? n : 1u, soa ? 1u : dy_stride};
+		grid_backward(nullptr, make_meta(e), io, (const half_t*)dL_dy, (half_t*)grad_half, grad_f32, lds_budget);
+	} catch (const std::exception& ex) {
+		fprintf(stderr, "emu_grid_backward: %s\n", ex.what());
+		return 1;
+	}
+	return 0;
+}
+
+int emu_grid_backward_input(const EmuGrid* e, uint32_t n, const uint16_t* dL_dy, int soa, uint32_t dy_stride, const float* dy_dx,
+                            float* dL_dx) {
+	GridIO io = {nullptr, e->n_dims, 1, n, soa ? n : 1u, soa ? 1u : dy_stride};
+	grid_backward_input(nullptr, e->n_dims, e->n_levels * e->n_feat, io, (const half_t*)dL_dy, dy_dx, dL_dx, e->n_dims, 1);
+	return 0;
+}
+
+int emu_grid_indices(const EmuGrid* e, const float* positions, uint32_t n, uint32_t* indices) {
+	GridIO io = {positions, e->n_dims, 1, n, n, 1};
+	grid_indices(nullptr, make_meta(e), io, indices);
+	return 0;
+}
+
+struct EmuMlp {
+	uint32_t in_width, width, padded_out, n_hidden_matmuls, activation;
+};
+static MlpMeta make_mlp(const EmuMlp* e) { return MlpMeta{e->in_width, e->width, e->padded_out, e->n_hidden_matmuls, e->activation}; }
+
+int emu_mlp_forward(const EmuMlp* e, uint32_t n, const uint16_t* params, const uint16_t* input_soa, uint16_t* hidden, uint16_t* output) {
+	try {
+		mlp_forward(nullptr, make_mlp(e), n, (const half_t*)params, (const half_t*)input_soa, (half_t*)hidden, (half_t*)output);
+	} catch (const std::exception& ex) {
+		fprintf(stderr, "emu_mlp_forward: %s\n", ex.what());
+		return 1;
+	}
+	return 0;
+}
+
+// grads: half [n_params] (Overwrite unless accumulate); scratch sizes are handled here.
+int emu_mlp_backward(const EmuMlp* e, uint32_t n, const uint16_t* params, const uint16_t* input_soa, const uint16_t* hidden,
+                     const uint16_t* dL_doutput, uint16_t* dL_dinput_soa, uint16_t* grads, int accumulate) {
+	try {
+		const MlpMeta m = make_mlp(e);
+		std::vector<uint16_t> params_t(m.n_params());
+		mlp_transpose_weights(nullptr, m, (const half_t*)params, (half_t*)params_t.data());
+		const uint32_t np = mlp_backward_n_partials(m, n);
+		std::vector<float> partials(grads ? (size_t)np * m.n_params() : 0, -12345.0f);
+		mlp_backward(nullptr, m, n, (const half_t*)params_t.data(), (const half_t*)input_soa, (const half_t*)hidden,
+		             (const half_t*)dL_doutput, (half_t*)dL_dinput_soa, grads ? partials.data() : nullptr);
+		if (grads) mlp_finalize_gradients(nullptr, m.n_params(), np, partials.data(), (half_t*)grads, accumulate != 0);
+	} catch (const std::exception& ex) {
+		fprintf(stderr, "emu_mlp_backward: %s\n", ex.what());
+		return 1;
+	}
+	return 0;
+}
+
+int emu_loss(int type, uint32_t n, uint32_t stride, uint32_t dims, float loss_scale, const uint16_t* prediction, const float* target,
+             const float* data_pdf, float* values, uint16_t* gradients, float* loss_sum, uint32_t n_total) {
+	std::vector<float> block_sums(loss_n_blocks(n, stride));
+	std::vector<float> ws(1024);
+	loss_evaluate(nullptr, (LossType)type, n, stride, dims, loss_scale, (const half_t*)prediction, target, data_pdf, values,
+	              (half_t*)gradients, block_sums.data(), n_total);
+	if (loss_sum) reduce_sum(nullptr, block_sums.data(), block_sums.size(), ws.data(), loss_sum);
+	return 0;
+}
+
+struct EmuAdam {
+	float learning_rate, beta1, beta2, epsilon, l2_reg, non_matrix_l2_reg, relative_weight_decay, absolute_weight_decay;
+	float weight_clipping_magnitude, gradient_clipping_magnitude, non_matrix_learning_rate_factor;
+	int adabound, optimize_matrix_params, optimize_non_matrix_params, skip_zero_grad_non_matrix_params;
+};
+
+int emu_adam_step(const EmuAdam* e, uint32_t n, uint32_t n_matrix, float loss_scale, uint32_t current_step, float* w32, uint16_t* w16,
+                  const uint16_t* grads, float* m1, float* m2, uint32_t* steps) {
+	AdamHyper h;
+	h.learning_rate = e->learning_rate;
+	h.beta1 = e->beta1;
+	h.beta2 = e->beta2;
+	h.epsilon = e->epsilon;
+	h.l2_reg = e->l2_reg;
+	h.non_matrix_l2_reg = e->non_matrix_l2_reg;
+	h.relative_weight_decay = e->relative_weight_decay;
+	h.absolute_weight_decay = e->absolute_weight_decay;
+	h.weight_clipping_magnitude = e->weight_clipping_magnitude;
+	h.gradient_clipping_magnitude = e->gradient_clipping_magnitude;
+	h.non_matrix_learning_rate_factor = e->non_matrix_learning_rate_factor;
+	h.adabound = e->adabound != 0;
+	h.optimize_matrix_params = e->optimize_matrix_params != 0;
+	h.optimize_non_matrix_params = e->optimize_non_matrix_params != 0;
+	h.skip_zero_grad_non_matrix_params = e->skip_zero_grad_non_matrix_params != 0;
+	adam_step(nullptr, h, n, n_matrix, loss_scale, current_step, w32, (half_t*)w16, (const half_t*)grads, m1, m2, steps);
+	return 0;
+}
+
+// rng state is passed in and written back
+int emu_generate_random_uniform(uint64_t* state, uint64_t* inc, uint64_t n, float* out, float lower, float upper) {
+	Pcg32 r;
+	r.state = *state;
+	r.inc = *inc;
+	generate_random_uniform(nullptr, r, (size_t)n, out, lower, upper);
+	*state = r.state;
+	*inc = r.inc;
+	return 0;
+}
+
+int emu_cast_f32_to_f16(uint64_t n, const float* in, uint16_t* out) {
+	cast_f32_to_f16(nullptr, (size_t)n, in, (half_t*)out);
+	return 0;
+}
+
+int emu_identity_forward(uint32_t n, uint32_t n_dims, uint32_t padded, const float* in, uint16_t* out_soa) {
+	identity_forward(nullptr, n, n_dims, padded, 1.0f, 0.0f, in, n_dims, 1, (half_t*)out_soa, n, 1);
+	return 0;
+}
+
+int emu_trim_and_cast(uint32_t n, uint32_t padded, uint32_t dims, const uint16_t* in, float* out) {
+	trim_and_cast(nullptr, n, padded, dims, (const half_t*)in, out, dims, 1);
+	return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// elementwise_kernels.h -- streaming (HBM-bound) kernels of the training step: loss, Adam, casts,
+// PCG32 fills, reductions, identity encoding.  Reference lines restated are cited per function.
+#pragma once
+#include "tcnn_device.h"
+
+namespace tcnn_hip {
+
+enum class LossType : int { L2 = 0, RelativeL2 = 1 };
+
+struct Pcg32 {  // reference dependencies/pcg32/pcg32.h:40-170
+	uint64_t state, inc;
+	TCNN_HOST_DEVICE Pcg32() : state(0x853c49e6748fea9bULL), inc(0xda3e39cb94b95bdbULL) {}
+	TCNN_HOST_DEVICE explicit Pcg32(uint64_t initstate, uint64_t initseq = 1u) { seed(initstate, initseq); }
+	TCNN_HOST_DEVICE void seed(uint64_t initstate, uint64_t initseq = 1) {
+		state = 0U;
+		inc = (initseq << 1u) | 1u;
+		next_uint();
+		state += initstate;
+		next_uint();
+	}
+	TCNN_HOST_DEVICE uint32_t next_uint() {
+		const uint64_t oldstate = state;
+		state = oldstate * 0x5851f42d4c957f2dULL + inc;
+		const uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+		const uint32_t rot = (uint32_t)(oldstate >> 59u);
+		return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+	}
+	TCNN_HOST_DEVICE float next_float() {
+		union { uint32_t u; float f; } x;
+		x.u = (next_uint() >> 9) | 0x3f800000u;
+		return x.f - 1.0f;
+	}
+	TCNN_HOST_DEVICE void advance(int64_t delta_) {
+		uint64_t cur_mult = 0x5851f42d4c957f2dULL, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
+		uint64_t delta = (uint64_t)delta_;
+		while (delta > 0) {
+			if (delta & 1) {
+				acc_mult *= cur_mult;
+				acc_plus = acc_plus * cur_mult + cur_plus;
+			}
+			cur_plus = (cur_mult + 1) * cur_plus;
+			cur_mult *= cur_mult;
+			delta /= 2;
+		}
+		state = acc_mult * state + acc_plus;
+	}
+};
+
+// random.h:39-75 -- fills out[0..n) with U[lower, upper) and advances rng by n (same idx <-> stream map)
+void generate_random_uniform(hipStream_t stream, Pcg32& rng, size_t n, float* out, float lower, float upper);
+
+void cast_f32_to_f16(hipStream_t stream, size_t n, const float* in, half_t* out);  // trainer.h:415-417
+void cast_f16_to_f32(hipStream_t stream, size_t n, const half_t* in, float* out);  // trainer.h:430-432
+void fill_f16(hipStream_t stream, size_t n, half_t* out, float value);
+
+// object.cu:61-67 trim_and_cast_from: in half AoS [n][padded] -> out float element (j, i) at out[i*stride_i + j*stride_j]
+void trim_and_cast(hipStream_t stream, uint32_t n, uint32_t padded, uint32_t dims, const half_t* in, float* out,
+                   uint32_t stride_i, uint32_t stride_j);
+
+// losses/relative_l2.h:40-76, losses/l2.h:40-76.  prediction/gradients: half AoS [n][stride];
+// target/data_pdf: fp32, element (dim j, sample i) at [i*dims + j].  values (fp32 [n][stride]) may be
+// null.  block_sums (may be null): one fp32 partial loss sum per 256-thread block, n_blocks returned.
+// n_total: normalisation count (n*dims on one GPU; the GLOBAL batch*dims under data parallelism).
+uint32_t loss_n_blocks(uint32_t n, uint32_t stride);
+void loss_evaluate(hipStream_t stream, LossType type, uint32_t n, uint32_t stride, uint32_t dims, float loss_scale,
+                   const half_t* prediction, const float* target, const float* data_pdf, float* values,
+                   half_t* gradients, float* block_sums, uint32_t n_total);
+
+// reduce_sum.h:117-156 (deterministic two-pass): *out = sum(in[0..n))
+void reduce_sum(hipStream_t stream, const float* in, size_t n, float* workspace /* >= 1024 floats */, float* out);
+
+struct AdamHyper {  // optimizers/adam.h:330-351 defaults
+	float learning_rate = 1e-3f, beta1 = 0.9f, beta2 = 0.999f, epsilon = 1e-8f, l2_reg = 1e-8f, non_matrix_l2_reg = 0.0f;
+	float relative_weight_decay = 0.0f, absolute_weight_decay = 0.0f;
+	float weight_clipping_magnitude = 0.0f, gradient_clipping_magnitude = 0.0f;
+	float non_matrix_learning_rate_factor = 1.0f;
+	bool adabound = false;
+	bool optimize_matrix_params = true, optimize_non_matrix_params = true, skip_zero_grad_non_matrix_params = true;
+};
+// optimizers/adam.h:48-127, 158-199.  current_step = optimizer step AFTER the increment.
+void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale,
+               uint32_t current_step, float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2,
+               uint32_t* param_steps);
+
+// encodings/identity.h:46-84.  in: fp32 element (dim j, sample i) at in[i*in_stride_i + j*in_stride_j];
+// out: half element (k, i) at out[k*stride_k + i*stride_i], k < padded, padding value 1.
+void identity_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t padded, float scale, float offset,
+                      const float* in, uint32_t in_stride_i, uint32_t in_stride_j, half_t* out, uint32_t stride_k,
+                      uint32_t stride_i);
+void identity_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, float scale, const half_t* dL_dy, uint32_t stride_k,
+                       uint32_t stride_i, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j);
+
+}  // namespace tcnn_hip

@@ -1,0 +1,346 @@
+// elementwise_kernels.hip -- see elementwise_kernels.h.  All kernels here are pure HBM streams:
+// 16-byte accesses per lane, grid-stride where it matters, no host synchronisation.
+// Build with -ffp-contract=off (loss / Adam arithmetic is checked against the CPU oracle).
+#include "elementwise_kernels.h"
+
+#include <stdexcept>
+
+namespace tcnn_hip {
+
+constexpr uint32_t EW_THREADS = 256;
+
+// ------------------------------------------------------------------------------------------ rng
+__global__ void k_generate_random_uniform(size_t n_elements, Pcg32 rng, float* __restrict__ out, float lower, float range) {
+	const size_t i = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
+	const size_t n_threads = (size_t)blockDim.x * gridDim.x;
+	rng.advance((int64_t)(i * 4));
+#pragma unroll
+	for (size_t j = 0; j < 4; ++j) {
+		const size_t idx = i + n_threads * j;
+		if (idx >= n_elements) return;
+		out[idx] = __builtin_fmaf(rng.next_float(), range, lower);
+	}
+}
+
+void generate_random_uniform(hipStream_t stream, Pcg32& rng, size_t n, float* out, float lower, float upper) {
+	if (n > 0) {
+		const size_t n_threads = div_round_up(n, (size_t)4);
+		const uint32_t blocks = (uint32_t)div_round_up(n_threads, (size_t)128);  // N_THREADS_LINEAR = 128 (common.h:247)
+		TCNN_LAUNCH(k_generate_random_uniform, dim3(blocks), dim3(128), 0, stream, n, rng, out, lower, upper - lower);
+	}
+	rng.advance((int64_t)n);
+}
+
+// ------------------------------------------------------------------------------------------ casts
+__global__ void k_cast_f32_to_f16(size_t n, const float* __restrict__ in, half_t* __restrict__ out) {
+	const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+	if (i4 + 3 < n) {
+		const f4 v = *(const f4*)(in + i4);
+		*(h4*)(out + i4) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+	} else {
+		for (size_t i = i4; i < n; ++i) out[i] = (half_t)in[i];
+	}
+}
+__global__ void k_cast_f16_to_f32(size_t n, const half_t* __restrict__ in, float* __restrict__ out) {
+	const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+	if (i4 + 3 < n) {
+		const h4 v = *(const h4*)(in + i4);
+		*(f4*)(out + i4) = f4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+	} else {
+		for (size_t i = i4; i < n; ++i) out[i] = (float)in[i];
+	}
+}
+__global__ void k_fill_f16(size_t n, half_t* __restrict__ out, float value) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = (half_t)value;
+}
+
+void cast_f32_to_f16(hipStream_t stream, size_t n, const float* in, half_t* out) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_cast_f32_to_f16, dim3((uint32_t)div_round_up(div_round_up(n, (size_t)4), (size_t)EW_THREADS)), dim3(EW_THREADS), 0, stream, n, in, out);
+}
+void cast_f16_to_f32(hipStream_t stream, size_t n, const half_t* in, float* out) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_cast_f16_to_f32, dim3((uint32_t)div_round_up(div_round_up(n, (size_t)4), (size_t)EW_THREADS)), dim3(EW_THREADS), 0, stream, n, in, out);
+}
+void fill_f16(hipStream_t stream, size_t n, half_t* out, float value) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_fill_f16, dim3((uint32_t)div_round_up(n, (size_t)EW_THREADS)), dim3(EW_THREADS), 0, stream, n, out, value);
+}
+
+__global__ void k_trim_and_cast(uint32_t n, uint32_t padded, uint32_t dims, const half_t* __restrict__ in, float* __restrict__ out,
+                                uint32_t stride_i, uint32_t stride_j) {
+	const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n * dims) return;
+	const uint32_t i = e / dims, j = e - i * dims;
+	out[(size_t)i * stride_i + (size_t)j * stride_j] = (float)in[(size_t)i * padded + j];
+}
+void trim_and_cast(hipStream_t stream, uint32_t n, uint32_t padded, uint32_t dims, const half_t* in, float* out, uint32_t stride_i,
+                   uint32_t stride_j) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_trim_and_cast, dim3(div_round_up(n * dims, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, padded, dims, in, out, stride_i, stride_j);
+}
+
+// ------------------------------------------------------------------------------------------ loss
+// One thread per 8 consecutive elements of the [n][stride] half prediction matrix (16-byte accesses).
+template <LossType LOSS>
+__global__ void __launch_bounds__(EW_THREADS) k_loss(uint32_t n_groups, uint32_t stride, uint32_t dims, float loss_scale,
+                                                      const half_t* __restrict__ predictions, const float* __restrict__ targets,
+                                                      const float* __restrict__ data_pdf, float* __restrict__ values,
+                                                      half_t* __restrict__ gradients, float* __restrict__ block_sums, uint32_t n_total_u) {
+	__shared__ float red[EW_THREADS];
+	const uint32_t gidx = blockIdx.x * EW_THREADS + threadIdx.x;
+	float local_sum = 0.0f;
+	if (gidx < n_groups) {
+		const uint32_t e0 = gidx * 8;
+		const uint32_t inter = e0 / stride, intra0 = e0 - inter * stride;
+		const h8 p8 = *(const h8*)(predictions + e0);
+		h8 g8;
+		float v8[8];
+		const float n_total = (float)n_total_u;
+#pragma unroll
+		for (uint32_t j = 0; j < 8; ++j) {
+			const uint32_t intra = intra0 + j;
+			if (intra >= dims) {  // relative_l2.h:57-61
+				v8[j] = 0.0f;
+				g8[j] = (half_t)0.0f;
+				continue;
+			}
+			const uint32_t target_idx = inter * dims + intra;
+			const float prediction = (float)p8[j];
+			const float pdf = data_pdf ? data_pdf[target_idx] : 1.0f;
+			const float difference = prediction - targets[target_idx];
+			float value, gradient;
+			if (LOSS == LossType::RelativeL2) {
+				const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
+				value = difference * difference / prediction_sq_plus_epsilon / pdf / n_total;
+				gradient = 2 * difference / prediction_sq_plus_epsilon / pdf;
+			} else {
+				value = difference * difference / pdf / n_total;
+				gradient = 2 * difference / pdf;
+			}
+			v8[j] = value;
+			g8[j] = (half_t)(loss_scale * gradient / n_total);
+			local_sum += value;
+		}
+		*(h8*)(gradients + e0) = g8;
+		if (values) {
+			*(f4*)(values + e0) = f4{v8[0], v8[1], v8[2], v8[3]};
+			*(f4*)(values + e0 + 4) = f4{v8[4], v8[5], v8[6], v8[7]};
+		}
+	}
+	if (block_sums) {
+		red[threadIdx.x] = local_sum;
+		__syncthreads();
+		for (uint32_t s = EW_THREADS / 2; s > 0; s >>= 1) {
+			if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+			__syncthreads();
+		}
+		if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0];
+	}
+}
+
+uint32_t loss_n_blocks(uint32_t n, uint32_t stride) { return div_round_up(n * stride / 8u, EW_THREADS); }
+
+void loss_evaluate(hipStream_t stream, LossType type, uint32_t n, uint32_t stride, uint32_t dims, float loss_scale,
+                   const half_t* prediction, const float* target, const float* data_pdf, float* values, half_t* gradients,
+                   float* block_sums, uint32_t n_total) {
+	if (n == 0) return;
+	if (stride % 8 != 0) throw std::runtime_error("loss: padded output width must be a multiple of 8");
+	const uint32_t n_groups = n * stride / 8u;
+	const uint32_t blocks = div_round_up(n_groups, EW_THREADS);
+	if (type == LossType::RelativeL2) {
+		TCNN_LAUNCH((k_loss<LossType::RelativeL2>), dim3(blocks), dim3(EW_THREADS), 0, stream, n_groups, stride, dims, loss_scale, prediction, target, data_pdf, values, gradients, block_sums, n_total);
+	} else {
+		TCNN_LAUNCH((k_loss<LossType::L2>), dim3(blocks), dim3(EW_THREADS), 0, stream, n_groups, stride, dims, loss_scale, prediction, target, data_pdf, values, gradients, block_sums, n_total);
+	}
+}
+
+// ------------------------------------------------------------------------------------------ reduce
+__global__ void __launch_bounds__(EW_THREADS) k_reduce_partial(const float* __restrict__ in, size_t n, float* __restrict__ out) {
+	__shared__ float red[EW_THREADS];
+	float s = 0.0f;
+	for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * EW_THREADS) s += in[i];
+	red[threadIdx.x] = s;
+	__syncthreads();
+	for (uint32_t k = EW_THREADS / 2; k > 0; k >>= 1) {
+		if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+void reduce_sum(hipStream_t stream, const float* in, size_t n, float* workspace, float* out) {
+	const uint32_t blocks = (uint32_t)(n == 0 ? 1 : (div_round_up(n, (size_t)EW_THREADS) < 1024 ? div_round_up(n, (size_t)EW_THREADS) : 1024));
+	TCNN_LAUNCH(k_reduce_partial, dim3(blocks), dim3(EW_THREADS), 0, stream, in, n, workspace);
+	TCNN_LAUNCH(k_reduce_partial, dim3(1), dim3(EW_THREADS), 0, stream, (const float*)workspace, (size_t)blocks, out);
+}
+
+// ------------------------------------------------------------------------------------------ Adam
+struct AdamArgs {
+	uint32_t n_elements, n_matrix_weights;
+	float relative_weight_decay, absolute_weight_decay, weight_clipping_magnitude, gradient_clipping_magnitude;
+	float loss_scale, learning_rate, non_matrix_learning_rate_factor;
+	int optimize_matrix_params, optimize_non_matrix_params, skip_zero_grad_non_matrix_params;
+	float beta1, beta2, epsilon, lower_lr_bound, upper_lr_bound, l2_reg, non_matrix_l2_reg;
+};
+
+// One parameter, exactly the arithmetic of adam.h:66-126.  Returns false if the parameter is skipped.
+TCNN_DEVICE bool adam_one(const AdamArgs& a, uint32_t i, float gradient_raw, float& weight_fp, float& m1, float& m2, uint32_t& step) {
+	float gradient = gradient_raw / a.loss_scale;
+	if (i >= a.n_matrix_weights) {
+		if (!a.optimize_non_matrix_params || (gradient == 0 && a.skip_zero_grad_non_matrix_params)) return false;
+	} else {
+		if (!a.optimize_matrix_params) return false;
+	}
+	if (i < a.n_matrix_weights) {
+		gradient += a.l2_reg * weight_fp;
+	} else {
+		gradient += a.non_matrix_l2_reg * weight_fp;
+	}
+	if (a.gradient_clipping_magnitude != 0.0f) {
+		gradient = __builtin_copysignf(__builtin_fminf(__builtin_fabsf(gradient), a.gradient_clipping_magnitude), gradient);
+	}
+	const float gradient_sq = gradient * gradient;
+	const float first_moment = m1 = a.beta1 * m1 + (1 - a.beta1) * gradient;
+	const float second_moment = m2 = a.beta2 * m2 + (1 - a.beta2) * gradient_sq;
+	float learning_rate = a.learning_rate;
+	if (i >= a.n_matrix_weights) learning_rate *= a.non_matrix_learning_rate_factor;
+	const uint32_t current_step = ++step;
+	learning_rate *= __builtin_sqrtf(1 - __builtin_powf(a.beta2, (float)current_step)) / (1 - __builtin_powf(a.beta1, (float)current_step));
+	const float effective_learning_rate =
+		__builtin_fminf(__builtin_fmaxf(learning_rate / (__builtin_sqrtf(second_moment) + a.epsilon), a.lower_lr_bound), a.upper_lr_bound);
+	// common_device.h:1045-1048 weight_decay
+	const float rel = a.relative_weight_decay * learning_rate, ab = a.absolute_weight_decay * learning_rate;
+	const float decayed_weight = (1 - rel) * weight_fp - __builtin_copysignf(ab, weight_fp);
+	float new_weight = decayed_weight - effective_learning_rate * first_moment;
+	if (a.weight_clipping_magnitude != 0.0f) {
+		new_weight = __builtin_fminf(__builtin_fmaxf(new_weight, -a.weight_clipping_magnitude), a.weight_clipping_magnitude);
+	}
+	weight_fp = new_weight;
+	return true;
+}
+
+// 4 parameters per lane: 8 B of gradients decide whether the 16-byte state loads happen at all, so
+// untouched hash-table entries cost 2 B/param as in the reference (adam.h:79-82).
+__global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, float* __restrict__ weights_fp32, half_t* __restrict__ weights,
+                                                           const half_t* __restrict__ gradients, float* __restrict__ first_moments,
+                                                           float* __restrict__ second_moments, uint32_t* __restrict__ param_steps) {
+	const uint32_t i0 = (blockIdx.x * EW_THREADS + threadIdx.x) * 4;
+	if (i0 >= a.n_elements) return;
+	if (i0 + 3 < a.n_elements) {
+		const h4 g = *(const h4*)(gradients + i0);
+		const bool all_non_matrix = i0 >= a.n_matrix_weights;
+		if (all_non_matrix && a.skip_zero_grad_non_matrix_params && g[0] == (half_t)0.0f && g[1] == (half_t)0.0f && g[2] == (half_t)0.0f &&
+		    g[3] == (half_t)0.0f) {
+			return;
+		}
+		f4 w = *(const f4*)(weights_fp32 + i0);
+		f4 m1 = *(const f4*)(first_moments + i0);
+		f4 m2 = *(const f4*)(second_moments + i0);
+		u4 st = *(const u4*)(param_steps + i0);
+		h4 wh = *(const h4*)(weights + i0);
+		bool any = false;
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j) {
+			float wj = w[j], m1j = m1[j], m2j = m2[j];
+			uint32_t sj = st[j];
+			if (adam_one(a, i0 + j, (float)g[j], wj, m1j, m2j, sj)) {
+				w[j] = wj;
+				m1[j] = m1j;
+				m2[j] = m2j;
+				st[j] = sj;
+				wh[j] = (half_t)wj;
+				any = true;
+			}
+		}
+		if (any) {
+			*(f4*)(weights_fp32 + i0) = w;
+			*(f4*)(first_moments + i0) = m1;
+			*(f4*)(second_moments + i0) = m2;
+			*(u4*)(param_steps + i0) = st;
+			*(h4*)(weights + i0) = wh;
+		}
+	} else {
+		for (uint32_t i = i0; i < a.n_elements; ++i) {
+			float wj = weights_fp32[i], m1j = first_moments[i], m2j = second_moments[i];
+			uint32_t sj = param_steps[i];
+			if (adam_one(a, i, (float)gradients[i], wj, m1j, m2j, sj)) {
+				weights_fp32[i] = wj;
+				first_moments[i] = m1j;
+				second_moments[i] = m2j;
+				param_steps[i] = sj;
+				weights[i] = (half_t)wj;
+			}
+		}
+	}
+}
+
+void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale, uint32_t current_step,
+               float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2, uint32_t* param_steps) {
+	if (n == 0) return;
+	AdamArgs a;
+	a.n_elements = n;
+	a.n_matrix_weights = n_matrix_weights;
+	a.relative_weight_decay = h.relative_weight_decay;
+	a.absolute_weight_decay = h.absolute_weight_decay;
+	a.weight_clipping_magnitude = h.weight_clipping_magnitude;
+	a.gradient_clipping_magnitude = h.gradient_clipping_magnitude;
+	a.loss_scale = loss_scale;
+	a.learning_rate = h.learning_rate;
+	a.non_matrix_learning_rate_factor = h.non_matrix_learning_rate_factor;
+	a.optimize_matrix_params = h.optimize_matrix_params;
+	a.optimize_non_matrix_params = h.optimize_non_matrix_params;
+	a.skip_zero_grad_non_matrix_params = h.skip_zero_grad_non_matrix_params;
+	a.beta1 = h.beta1;
+	a.beta2 = h.beta2;
+	a.epsilon = h.epsilon;
+	a.lower_lr_bound = 0;
+	a.upper_lr_bound = 3.402823466e+38f;
+	if (h.adabound) {  // adam.h:165-168
+		a.lower_lr_bound = 0.1f - 0.1f / ((1 - h.beta2) * (float)current_step + 1);
+		a.upper_lr_bound = 0.1f + 0.1f / ((1 - h.beta2) * (float)current_step);
+	}
+	a.l2_reg = h.l2_reg;
+	a.non_matrix_l2_reg = h.non_matrix_l2_reg;
+	TCNN_LAUNCH(k_adam_step, dim3(div_round_up(div_round_up(n, 4u), EW_THREADS)), dim3(EW_THREADS), 0, stream, a, weights_fp32, weights, gradients, m1, m2, param_steps);
+}
+
+// ------------------------------------------------------------------------------------------ identity
+__global__ void k_identity_forward(uint32_t n, uint32_t n_dims, uint32_t padded, float scale, float offset, const float* __restrict__ in,
+                                   uint32_t in_stride_i, uint32_t in_stride_j, half_t* __restrict__ out, uint32_t stride_k, uint32_t stride_i) {
+	// thread -> (k, i) with i fastest: coalesced for the feature-major output the MLP kernels read
+	const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n * padded) return;
+	const uint32_t k = e / n, i = e - k * n;
+	half_t v;
+	if (k >= n_dims) {
+		v = (half_t)1.0f;  // identity.h:62-64
+	} else {
+		float t = in[(size_t)i * in_stride_i + (size_t)k * in_stride_j] * scale;
+		t = t + offset;
+		v = (half_t)t;
+	}
+	out[(size_t)k * stride_k + (size_t)i * stride_i] = v;
+}
+__global__ void k_identity_backward(uint32_t n, uint32_t n_dims, float scale, const half_t* __restrict__ dL_dy, uint32_t stride_k,
+                                    uint32_t stride_i, float* __restrict__ dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
+	const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n * n_dims) return;
+	const uint32_t k = e / n, i = e - k * n;
+	// identity.h:83: (T)((float)dL_dy * scale) -- rounded through half, then widened to the fp32 dL_dx
+	dL_dx[(size_t)i * dx_stride_i + (size_t)k * dx_stride_j] = (float)(half_t)((float)dL_dy[(size_t)k * stride_k + (size_t)i * stride_i] * scale);
+}
+
+void identity_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t padded, float scale, float offset, const float* in,
+                      uint32_t in_stride_i, uint32_t in_stride_j, half_t* out, uint32_t stride_k, uint32_t stride_i) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_identity_forward, dim3(div_round_up(n * padded, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, padded, scale, offset, in, in_stride_i, in_stride_j, out, stride_k, stride_i);
+}
+void identity_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, float scale, const half_t* dL_dy, uint32_t stride_k, uint32_t stride_i,
+                       float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_identity_backward, dim3(div_round_up(n * n_dims, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, scale, dL_dy, stride_k, stride_i, dL_dx, dx_stride_i, dx_stride_j);
+}
+
+}  // namespace tcnn_hip

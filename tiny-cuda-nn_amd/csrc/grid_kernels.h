@@ -1,0 +1,62 @@
+// grid_kernels.h -- multiresolution hash/dense/tiled grid encoding on gfx950.
+//
+// Restates the BEHAVIOUR of reference include/tiny-cuda-nn/encodings/grid.h:49-349 (kernel_grid,
+// kernel_grid_backward, kernel_grid_backward_input) and common_device.h:767-895,1000-1043 with an
+// MI355X-first mapping:
+//   * one (level, sample-tile) work item per workgroup, and workgroup -> level chosen so that the
+//     workgroups an XCD receives (block b runs on XCD b%8) all walk the same one or two levels: a
+//     level's table (<= 2^log2_hashmap_size * F * 2 B, 2 MiB at the headline config) then stays in
+//     that XCD's private 4 MiB L2 while it is being gathered / scattered.  Placement only changes
+//     speed, never results.
+//   * the per-level scale/resolution come from a host-computed table (bit-exact indices on any
+//     device), the interpolation is the reference's fp16 fma chain (v_pk_fma_f16) -> bit-exact
+//     encodings versus the CPU oracle.
+//   * backward: packed-half atomics (global_atomic_pk_add_f16) for large levels; levels whose whole
+//     table fits in LDS are accumulated per workgroup in fp32 LDS (ds_add_f32) and flushed once.
+#pragma once
+#include "tcnn_device.h"
+
+namespace tcnn_hip {
+
+struct GridMeta {
+	uint32_t n_dims;      // D
+	uint32_t n_levels;    // L
+	uint32_t n_feat;      // F  (features per level)
+	uint32_t grid_type;   // GridType
+	uint32_t interp;      // InterpolationType
+	float max_level;      // reference MultiLevelEncoding::m_max_level (1.0 = all levels)
+	uint32_t offset[MAX_N_LEVELS + 1];
+	float scale[MAX_N_LEVELS];
+	uint32_t resolution[MAX_N_LEVELS];
+};
+
+struct GridIO {
+	// positions: element (dim d, sample i) at positions[i * pos_stride_i + d * pos_stride_d]
+	const float* positions;
+	uint32_t pos_stride_i, pos_stride_d;
+	uint32_t n;  // samples
+	// encoded output / dL_dy: element (feature k, sample i) at ptr[k * stride_k + i * stride_i]
+	//   SoA (feature-major, the reference's preferred layout grid.h:1070-1072): stride_k = n, stride_i = 1
+	//   AoS (cpp_api.cu:94-95 forces it):                                       stride_k = 1, stride_i = padded width
+	uint32_t stride_k, stride_i;
+};
+
+// Forward: writes n_levels*F features (padding columns are the caller's job). dy_dx may be null;
+// layout [(k * n + i) * D + d] fp32 (grid.h:784, 209).
+void grid_forward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* params, half_t* out,
+                  float* dy_dx);
+
+// Backward into grid_gradient (half, F >= 2) -- caller zeroes for GradientMode::Overwrite
+// (grid.h:865-867).  For F == 1 pass grad_f32 (fp32 accumulation buffer, grid.h:660-671) instead.
+void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy,
+                   half_t* grid_gradient, float* grad_f32, uint32_t lds_level_budget_bytes);
+
+// dL_dx[i][d] = sum_k dL_dy[k][i] * dy_dx[k][i][d]   (grid.h:323-349)
+void grid_backward_input(hipStream_t stream, uint32_t n_dims, uint32_t n_features, const GridIO& io,
+                         const half_t* dL_dy, const float* dy_dx, float* dL_dx, uint32_t dx_stride_i,
+                         uint32_t dx_stride_d);
+
+// Debug/parity helper: entry index per (sample, level, corner) -> indices[(i*L + l)*2^D + c]
+void grid_indices(hipStream_t stream, const GridMeta& meta, const GridIO& io, uint32_t* indices);
+
+}  // namespace tcnn_hip

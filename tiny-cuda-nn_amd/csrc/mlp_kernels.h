@@ -1,0 +1,59 @@
+// mlp_kernels.h -- fully fused MLP (16/32/64/128 wide, fp16 storage, fp32 MFMA accumulation) on gfx950.
+//
+// Restates the BEHAVIOUR of reference src/fully_fused_mlp.cu:499-837 (kernel_mlp_fused,
+// kernel_mlp_fused_backward and the four CUTLASS call sites :786,:820,:829,:835) -- not its tiling.
+// MI355X-first structure (DESIGN.md "MLP kernels"):
+//   * wave64 + v_mfma_f32_16x16x32_f16; a workgroup = WIDTH/16 waves, wave w owns 16 neurons.
+//   * forward:  D[neuron][sample] = W * X   (weights are the A operand in their natural row-major
+//     layout, activations the B operand straight out of a [sample][feature] LDS tile); the
+//     accumulator fragment IS the next layer's [sample][4 features] store -- no shuffles.
+//   * backward: D[sample][neuron] = dA * W  (pre-transposed weights as B operand); the accumulator
+//     fragment (neuron per lane, 4 samples per register) is directly the A operand of the
+//     weight-gradient MFMA  dW[out][in] = sum_s dA[out][s] * A_prev[in][s], whose B operand comes
+//     from feature-major (transposed) LDS tiles of the forward activations.
+//   * weight gradients are accumulated in fp32 MFMA accumulators held in registers across ALL
+//     sample tiles a persistent workgroup processes, written once per workgroup as fp32 partials
+//     and summed by a tiny deterministic finalize kernel (replaces the reference's 64-way split-K
+//     CUTLASS GEMMs and their aux streams).
+// Data layout at the kernel boundary:
+//   input / dL_dinput : half, feature-major  [in_width][n]   (the reference's SoA, grid.h:1070)
+//   output / dL_doutput: half, sample-major  [n][16]         (the reference's CM padded output)
+//   hidden (saved)    : half, [n_hidden][n][WIDTH] post-activation (fully_fused_mlp.cu:841-854)
+#pragma once
+#include "tcnn_device.h"
+
+namespace tcnn_hip {
+
+enum class Activation : int { None = 0, ReLU = 1 };
+
+struct MlpMeta {
+	uint32_t in_width;          // multiple of 16
+	uint32_t width;             // 16 / 32 / 64 / 128
+	uint32_t padded_out;        // 16 (outputs wider than 16 are not fused yet)
+	uint32_t n_hidden_matmuls;  // n_hidden_layers - 1
+	uint32_t activation;        // Activation
+	TCNN_HOST_DEVICE uint32_t n_params() const { return width * in_width + n_hidden_matmuls * width * width + padded_out * width; }
+};
+
+constexpr uint32_t MLP_MAX_HIDDEN_MATMULS_TRAIN = 3;  // backward kernels are instantiated for 0..3
+constexpr uint32_t MLP_MAX_IN_WIDTH = 128;
+
+// Forward.  hidden == nullptr -> inference (nothing saved).
+void mlp_forward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* hidden,
+                 half_t* output);
+
+// weights -> transposed scratch ([in_width][W] | HM x [W][W] | [W][16]); n_params halves
+void mlp_transpose_weights(hipStream_t stream, const MlpMeta& m, const half_t* params, half_t* params_t);
+
+// Number of fp32 partial gradient slabs mlp_backward writes (== its grid size) for batch n.
+uint32_t mlp_backward_n_partials(const MlpMeta& m, uint32_t n);
+
+// Backward.  params_t from mlp_transpose_weights.  dL_dinput may be null.  partials: fp32
+// [mlp_backward_n_partials][n_params] or null (GradientMode::Ignore).
+void mlp_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params_t, const half_t* input, const half_t* hidden,
+                  const half_t* dL_doutput, half_t* dL_dinput, float* partials);
+
+// grads[i] = (accumulate ? grads[i] : 0) + sum_b partials[b][i]   (fully_fused_mlp.cu:770 beta)
+void mlp_finalize_gradients(hipStream_t stream, uint32_t n_params, uint32_t n_partials, const float* partials, half_t* grads, bool accumulate);
+
+}  // namespace tcnn_hip

@@ -1,0 +1,485 @@
+// mlp_kernels.hip -- see mlp_kernels.h for the structure and the reference lines restated.
+//
+// Fragment bookkeeping used throughout (lane l of a wave: lr = l & 15, g = l >> 4):
+//   x32 operand: 8 halves, k = 32*kb + 8*g + j      x16 operand: 4 halves, k = k0 + 4*g + j
+//   accumulator: element r <-> (row = 4*g + r, col = lr)
+// LDS tiles:  "sample-major"  tile[s][ld]   (ld = width + 8 halves: 16-byte aligned, bank-skewed rows)
+//             "feature-major" tile[k][SP]   (SP = S + 8)
+#include "mlp_kernels.h"
+
+#include <stdexcept>
+#include <string>
+
+namespace tcnn_hip {
+
+
+TCNN_DEVICE h8 pack8(h4 a, h4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+TCNN_DEVICE f4 zero4() { return f4{0.0f, 0.0f, 0.0f, 0.0f}; }
+
+constexpr uint32_t mlp_fwd_tile(uint32_t width) { return width == 128 ? 128u : 64u; }
+constexpr uint32_t MLP_BWD_TILE = 64;
+
+// =============================================================================================
+// forward / inference
+// =============================================================================================
+template <uint32_t WIDTH, bool SAVE>
+__global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_forward(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
+                                                                  const half_t* __restrict__ input, half_t* __restrict__ hidden,
+                                                                  half_t* __restrict__ output) {
+	constexpr uint32_t NW = WIDTH / 16, THREADS = NW * 64, S = mlp_fwd_tile(WIDTH), NT = S / 16;
+	TCNN_DYN_LDS(lds_raw);
+	const uint32_t ld = (m.in_width > WIDTH ? m.in_width : WIDTH) + 8;
+	half_t* buf0 = (half_t*)lds_raw;
+	half_t* buf1 = buf0 + S * ld;
+
+	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
+	const bool relu = m.activation == (uint32_t)Activation::ReLU;
+	const uint32_t n_tiles = n / S;
+
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		// ---- stage the feature-major input [in_width][n] into a sample-major LDS tile
+		{
+			const uint32_t n_chunks = m.in_width * (S / 8);
+			for (uint32_t c = tid; c < n_chunks; c += THREADS) {
+				const uint32_t k = c / (S / 8), cc = c % (S / 8);
+				const h8 v = *(const h8*)(input + (size_t)k * n + (size_t)tile * S + 8 * cc);
+#pragma unroll
+				for (uint32_t j = 0; j < 8; ++j) buf0[(8 * cc + j) * ld + k] = v[j];
+			}
+		}
+		__syncthreads();
+
+		half_t* cur = buf0;
+		half_t* nxt = buf1;
+		const half_t* Wl = params;
+		uint32_t K = m.in_width;
+		for (uint32_t layer = 0; layer <= m.n_hidden_matmuls; ++layer) {
+			f4 acc[NT];
+#pragma unroll
+			for (uint32_t t = 0; t < NT; ++t) acc[t] = zero4();
+			const half_t* wrow = Wl + (size_t)(16 * w + lr) * K;  // A operand: this wave's 16 weight rows
+			for (uint32_t kb = 0; kb < K / 32; ++kb) {
+				const h8 a = *(const h8*)(wrow + 32 * kb + 8 * g);
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) {
+					const h8 b = *(const h8*)(cur + (16 * t + lr) * ld + 32 * kb + 8 * g);
+					acc[t] = mfma_16x16x32(a, b, acc[t]);
+				}
+			}
+			if (K & 16u) {
+				const uint32_t k0 = K & ~31u;
+				const h4 a = *(const h4*)(wrow + k0 + 4 * g);
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) {
+					const h4 b = *(const h4*)(cur + (16 * t + lr) * ld + k0 + 4 * g);
+					acc[t] = mfma_16x16x16(a, b, acc[t]);
+				}
+			}
+			// accumulator (neuron 16w+4g+r, sample 16t+lr) -> activation -> sample-major store
+#pragma unroll
+			for (uint32_t t = 0; t < NT; ++t) {
+				h4 o;
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) {
+					float v = acc[t][r];
+					if (relu) v = v > 0.0f ? v : 0.0f;
+					o[r] = (half_t)v;
+				}
+				*(h4*)(nxt + (16 * t + lr) * ld + 16 * w + 4 * g) = o;
+			}
+			__syncthreads();
+			if (SAVE) {  // post-activation hidden state, [layer][n][WIDTH] (fully_fused_mlp.cu:841-854)
+				half_t* dst = hidden + ((size_t)layer * n + (size_t)tile * S) * WIDTH;
+				for (uint32_t c = tid; c < S * WIDTH / 8; c += THREADS) {
+					const uint32_t i = c / (WIDTH / 8), cc = c % (WIDTH / 8);
+					*(h8*)(dst + (size_t)i * WIDTH + 8 * cc) = *(const h8*)(nxt + i * ld + 8 * cc);
+				}
+			}
+			half_t* tmp = cur;
+			cur = nxt;
+			nxt = tmp;
+			Wl += (size_t)WIDTH * K;
+			K = WIDTH;
+		}
+
+		// ---- output layer: 16 (padded) outputs; sample tiles are spread over the waves
+		for (uint32_t t = w; t < NT; t += NW) {
+			f4 acc = zero4();
+			const half_t* wrow = Wl + (size_t)lr * WIDTH;
+#pragma unroll
+			for (uint32_t kb = 0; kb < WIDTH / 32; ++kb) {
+				const h8 a = *(const h8*)(wrow + 32 * kb + 8 * g);
+				const h8 b = *(const h8*)(cur + (16 * t + lr) * ld + 32 * kb + 8 * g);
+				acc = mfma_16x16x32(a, b, acc);
+			}
+			if constexpr (WIDTH % 32 != 0) {
+				constexpr uint32_t k0 = WIDTH & ~31u;
+				const h4 a = *(const h4*)(wrow + k0 + 4 * g);
+				const h4 b = *(const h4*)(cur + (16 * t + lr) * ld + k0 + 4 * g);
+				acc = mfma_16x16x16(a, b, acc);
+			}
+			const h4 o = h4{(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};
+			*(h4*)(output + ((size_t)tile * S + 16 * t + lr) * 16 + 4 * g) = o;  // (output 4g+r, sample 16t+lr)
+		}
+		__syncthreads();
+	}
+}
+
+// =============================================================================================
+// weight transposition (tiny): params [out][in] row-major -> params_t [in][out] per matrix
+// =============================================================================================
+__global__ void k_mlp_transpose_weights(const MlpMeta m, const half_t* __restrict__ params, half_t* __restrict__ params_t) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t W = m.width, IN = m.in_width;
+	const uint32_t n_in = W * IN, n_hid = m.n_hidden_matmuls * W * W, n_out = m.padded_out * W;
+	if (i >= n_in + n_hid + n_out) return;
+	uint32_t dst;
+	if (i < n_in) {
+		const uint32_t o = i / IN, k = i % IN;
+		dst = k * W + o;
+	} else if (i < n_in + n_hid) {
+		const uint32_t local = i - n_in, j = local / (W * W), e = local % (W * W);
+		const uint32_t o = e / W, k = e % W;
+		dst = n_in + j * W * W + k * W + o;
+	} else {
+		const uint32_t local = i - n_in - n_hid;
+		const uint32_t o = local / W, k = local % W;
+		dst = n_in + n_hid + k * m.padded_out + o;
+	}
+	params_t[dst] = params[i];
+}
+
+// =============================================================================================
+// backward (activation gradients + weight gradients)
+// =============================================================================================
+template <uint32_t WIDTH, uint32_t HM>
+__global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params_t,
+                                                                   const half_t* __restrict__ input, const half_t* __restrict__ hidden,
+                                                                   const half_t* __restrict__ dL_doutput, half_t* __restrict__ dL_dinput,
+                                                                   float* __restrict__ partials) {
+	constexpr uint32_t NW = WIDTH / 16, THREADS = NW * 64, S = MLP_BWD_TILE, NT = S / 16, NTP = S / 32;
+	constexpr uint32_t SP = S + 8, LDW = WIDTH + 8, NB = WIDTH / 16, MAX_INB = MLP_MAX_IN_WIDTH / 16;
+	TCNN_DYN_LDS(lds_raw);
+	const uint32_t IN = m.in_width, nb_in = IN / 16;
+	half_t* xT = (half_t*)lds_raw;                 // [IN][SP]           network input, feature-major
+	half_t* hT = xT + IN * SP;                     // [HM+1][WIDTH][SP]  forward activations, feature-major
+	half_t* dact0 = hT + (HM + 1) * WIDTH * SP;    // [S][LDW]           dL/d(pre-activation), sample-major
+	half_t* dact1 = dact0 + S * LDW;
+	half_t* dyT = dact1 + S * LDW;                 // [16][SP]
+	half_t* dxT = dyT + 16 * SP;                   // [IN][SP]
+
+	const half_t* wt_in = params_t;                            // [IN][WIDTH]
+	const half_t* wt_hid = wt_in + (size_t)IN * WIDTH;         // HM x [WIDTH][WIDTH]
+	const half_t* wt_out = wt_hid + (size_t)HM * WIDTH * WIDTH;  // [WIDTH][16]
+
+	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
+	const bool relu = m.activation == (uint32_t)Activation::ReLU;
+	const bool want_grads = partials != nullptr, want_dx = dL_dinput != nullptr;
+	const uint32_t n_tiles = n / S;
+
+	// fp32 weight-gradient accumulators, live across all tiles of this workgroup
+	f4 accI[MAX_INB];
+	f4 accH[HM > 0 ? HM : 1][NB];
+	f4 accO = zero4();
+#pragma unroll
+	for (uint32_t b = 0; b < MAX_INB; ++b) accI[b] = zero4();
+#pragma unroll
+	for (uint32_t j = 0; j < (HM > 0 ? HM : 1); ++j)
+#pragma unroll
+		for (uint32_t b = 0; b < NB; ++b) accH[j][b] = zero4();
+
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		// ---- A. stage tiles -----------------------------------------------------------------
+		for (uint32_t c = tid; c < IN * (S / 8); c += THREADS) {  // input is already feature-major
+			const uint32_t k = c / (S / 8), cc = c % (S / 8);
+			*(h8*)(xT + k * SP + 8 * cc) = *(const h8*)(input + (size_t)k * n + (size_t)tile * S + 8 * cc);
+		}
+#pragma unroll
+		for (uint32_t l = 0; l <= HM; ++l) {  // saved activations are sample-major: transpose on the way in
+			const half_t* src = hidden + ((size_t)l * n + (size_t)tile * S) * WIDTH;
+			for (uint32_t c = tid; c < S * WIDTH / 8; c += THREADS) {
+				const uint32_t i = c / (WIDTH / 8), cc = c % (WIDTH / 8);
+				const h8 v = *(const h8*)(src + (size_t)i * WIDTH + 8 * cc);
+#pragma unroll
+				for (uint32_t j = 0; j < 8; ++j) hT[(l * WIDTH + 8 * cc + j) * SP + i] = v[j];
+			}
+		}
+		for (uint32_t c = tid; c < S * 2; c += THREADS) {
+			const uint32_t i = c / 2, cc = c % 2;
+			const h8 v = *(const h8*)(dL_doutput + ((size_t)tile * S + i) * 16 + 8 * cc);
+#pragma unroll
+			for (uint32_t j = 0; j < 8; ++j) dyT[(8 * cc + j) * SP + i] = v[j];
+		}
+		__syncthreads();
+
+		// ---- B. output matrix:  dA_last[s][k] = sum_o dY[s][o] W_out[o][k], masked -----------
+		h4 da[NT];  // this wave's slice of dL/d(pre-activation): (neuron 16w+lr, samples 16t+4g+r)
+		{
+			const half_t* hlast = hT + HM * WIDTH * SP;
+			const h4 bw = *(const h4*)(wt_out + (size_t)(16 * w + lr) * 16 + 4 * g);
+#pragma unroll
+			for (uint32_t t = 0; t < NT; ++t) {
+				const h4 a = *(const h4*)(dL_doutput + ((size_t)tile * S + 16 * t + lr) * 16 + 4 * g);
+				const f4 acc = mfma_16x16x16(a, bw, zero4());
+				const h4 hv = *(const h4*)(hlast + (16 * w + lr) * SP + 16 * t + 4 * g);
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) {
+					float v = acc[r];
+					if (relu && !(hv[r] > (half_t)0.0f)) v = 0.0f;  // transfer on post-activation values (common_device.h:363-368)
+					da[t][r] = (half_t)v;
+					dact0[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
+				}
+			}
+			if (want_grads) {  // dW_out^T[k][o] += sum_s A_last[k][s] dY[o][s]
+#pragma unroll
+				for (uint32_t tp = 0; tp < NTP; ++tp) {
+					const h8 a = *(const h8*)(hlast + (16 * w + lr) * SP + 32 * tp + 8 * g);
+					const h8 b = *(const h8*)(dyT + lr * SP + 32 * tp + 8 * g);
+					accO = mfma_16x16x32(a, b, accO);
+				}
+			}
+		}
+		__syncthreads();
+
+		half_t* cur = dact0;
+		half_t* nxt = dact1;
+
+		// ---- C. hidden matrices, last to first ----------------------------------------------
+#pragma unroll
+		for (int j = (int)HM - 1; j >= 0; --j) {
+			const half_t* hj = hT + j * WIDTH * SP;  // input activation of hidden matrix j
+			if (want_grads) {  // dW_j[out 16w+..][in 16b+..] += sum_s dA[out][s] A_j[in][s]; A operand = own registers
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b) {
+#pragma unroll
+					for (uint32_t tp = 0; tp < NTP; ++tp) {
+						const h8 a = pack8(da[2 * tp], da[2 * tp + 1]);
+						const h4 b0 = *(const h4*)(hj + (16 * b + lr) * SP + 32 * tp + 4 * g);
+						const h4 b1 = *(const h4*)(hj + (16 * b + lr) * SP + 32 * tp + 16 + 4 * g);
+						accH[j][b] = mfma_16x16x32(a, pack8(b0, b1), accH[j][b]);
+					}
+				}
+			}
+			// dA_j[s][k] = sum_jj dA_{j+1}[s][jj] M_j[jj][k], masked by A_j > 0
+			const half_t* wt = wt_hid + (size_t)j * WIDTH * WIDTH + (size_t)(16 * w + lr) * WIDTH;
+			f4 acc[NT];
+#pragma unroll
+			for (uint32_t t = 0; t < NT; ++t) acc[t] = zero4();
+#pragma unroll
+			for (uint32_t kb = 0; kb < WIDTH / 32; ++kb) {
+				const h8 bw = *(const h8*)(wt + 32 * kb + 8 * g);
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) {
+					const h8 a = *(const h8*)(cur + (16 * t + lr) * LDW + 32 * kb + 8 * g);
+					acc[t] = mfma_16x16x32(a, bw, acc[t]);
+				}
+			}
+			if constexpr (WIDTH % 32 != 0) {
+				constexpr uint32_t k0 = WIDTH & ~31u;
+				const h4 bw = *(const h4*)(wt + k0 + 4 * g);
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) {
+					const h4 a = *(const h4*)(cur + (16 * t + lr) * LDW + k0 + 4 * g);
+					acc[t] = mfma_16x16x16(a, bw, acc[t]);
+				}
+			}
+#pragma unroll
+			for (uint32_t t = 0; t < NT; ++t) {
+				const h4 hv = *(const h4*)(hj + (16 * w + lr) * SP + 16 * t + 4 * g);
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) {
+					float v = acc[t][r];
+					if (relu && !(hv[r] > (half_t)0.0f)) v = 0.0f;
+					da[t][r] = (half_t)v;
+					nxt[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
+				}
+			}
+			__syncthreads();
+			half_t* tmp = cur;
+			cur = nxt;
+			nxt = tmp;
+		}
+
+		// ---- D. input matrix ----------------------------------------------------------------
+		if (want_grads) {
+#pragma unroll
+			for (uint32_t b = 0; b < MAX_INB; ++b) {
+				if (b < nb_in) {
+#pragma unroll
+					for (uint32_t tp = 0; tp < NTP; ++tp) {
+						const h8 a = pack8(da[2 * tp], da[2 * tp + 1]);
+						const h4 b0 = *(const h4*)(xT + (16 * b + lr) * SP + 32 * tp + 4 * g);
+						const h4 b1 = *(const h4*)(xT + (16 * b + lr) * SP + 32 * tp + 16 + 4 * g);
+						accI[b] = mfma_16x16x32(a, pack8(b0, b1), accI[b]);
+					}
+				}
+			}
+		}
+		if (want_dx) {  // dX[s][k] = sum_jj dA_0[s][jj] M_in[jj][k]   (no activation on the network input)
+			for (uint32_t sl = w; sl < nb_in; sl += NW) {
+				const half_t* wt = wt_in + (size_t)(16 * sl + lr) * WIDTH;
+				f4 acc[NT];
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) acc[t] = zero4();
+#pragma unroll
+				for (uint32_t kb = 0; kb < WIDTH / 32; ++kb) {
+					const h8 bw = *(const h8*)(wt + 32 * kb + 8 * g);
+#pragma unroll
+					for (uint32_t t = 0; t < NT; ++t) {
+						const h8 a = *(const h8*)(cur + (16 * t + lr) * LDW + 32 * kb + 8 * g);
+						acc[t] = mfma_16x16x32(a, bw, acc[t]);
+					}
+				}
+				if constexpr (WIDTH % 32 != 0) {
+					constexpr uint32_t k0 = WIDTH & ~31u;
+					const h4 bw = *(const h4*)(wt + k0 + 4 * g);
+#pragma unroll
+					for (uint32_t t = 0; t < NT; ++t) {
+						const h4 a = *(const h4*)(cur + (16 * t + lr) * LDW + k0 + 4 * g);
+						acc[t] = mfma_16x16x16(a, bw, acc[t]);
+					}
+				}
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) {
+					const h4 o = h4{(half_t)acc[t][0], (half_t)acc[t][1], (half_t)acc[t][2], (half_t)acc[t][3]};
+					*(h4*)(dxT + (16 * sl + lr) * SP + 16 * t + 4 * g) = o;  // (feature 16sl+lr, samples 16t+4g+r)
+				}
+			}
+		}
+		__syncthreads();
+		if (want_dx) {
+			for (uint32_t c = tid; c < IN * (S / 8); c += THREADS) {
+				const uint32_t k = c / (S / 8), cc = c % (S / 8);
+				*(h8*)(dL_dinput + (size_t)k * n + (size_t)tile * S + 8 * cc) = *(const h8*)(dxT + k * SP + 8 * cc);
+			}
+		}
+		__syncthreads();
+	}
+
+	// ---- fp32 partial weight gradients of this workgroup, same layout as the parameters -------
+	if (want_grads) {
+		float* P = partials + (size_t)blockIdx.x * m.n_params();
+#pragma unroll
+		for (uint32_t b = 0; b < MAX_INB; ++b) {
+			if (b < nb_in) {
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) P[(size_t)(16 * w + 4 * g + r) * IN + 16 * b + lr] = accI[b][r];
+			}
+		}
+		const size_t off_hid = (size_t)WIDTH * IN;
+#pragma unroll
+		for (uint32_t j = 0; j < HM; ++j)
+#pragma unroll
+			for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) P[off_hid + (size_t)j * WIDTH * WIDTH + (size_t)(16 * w + 4 * g + r) * WIDTH + 16 * b + lr] = accH[j][b][r];
+		const size_t off_out = off_hid + (size_t)HM * WIDTH * WIDTH;
+#pragma unroll
+		for (uint32_t r = 0; r < 4; ++r) P[off_out + (size_t)lr * WIDTH + 16 * w + 4 * g + r] = accO[r];  // accO holds dW_out^T
+	}
+}
+
+__global__ void k_mlp_finalize_gradients(uint32_t n_params, uint32_t n_partials, const float* __restrict__ partials, half_t* __restrict__ grads,
+                                         int accumulate) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_params) return;
+	float s = 0.0f;
+	for (uint32_t b = 0; b < n_partials; ++b) s += partials[(size_t)b * n_params + i];
+	if (accumulate) s += (float)grads[i];
+	grads[i] = (half_t)s;
+}
+
+// =============================================================================================
+// host launchers
+// =============================================================================================
+static void check_meta(const MlpMeta& m, uint32_t n) {
+	if (m.width != 16 && m.width != 32 && m.width != 64 && m.width != 128) {
+		throw std::runtime_error("FullyFusedMLP only supports 16, 32, 64, and 128 neurons, but got " + std::to_string(m.width) + ".");
+	}
+	if (m.in_width % 16 != 0 || m.in_width == 0 || m.in_width > MLP_MAX_IN_WIDTH) {
+		throw std::runtime_error("FullyFusedMLP: input width must be a multiple of 16 and at most " + std::to_string(MLP_MAX_IN_WIDTH) + ".");
+	}
+	if (m.padded_out != 16) throw std::runtime_error("FullyFusedMLP: only up to 16 output dimensions are supported by the fused kernels.");
+	if (n % BATCH_SIZE_GRANULARITY != 0) throw std::runtime_error("Batch size must be a multiple of 256.");
+}
+
+template <uint32_t WIDTH>
+static void launch_forward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* hidden,
+                           half_t* output) {
+	constexpr uint32_t S = mlp_fwd_tile(WIDTH);
+	const uint32_t ld = (m.in_width > WIDTH ? m.in_width : WIDTH) + 8;
+	const uint32_t lds_bytes = 2 * S * ld * (uint32_t)sizeof(half_t);
+	const uint32_t n_tiles = n / S;
+	const uint32_t blocks = n_tiles < 2048 ? n_tiles : 2048;
+	if (hidden) {
+		TCNN_SET_MAX_DYN_LDS((k_mlp_forward<WIDTH, true>), lds_bytes);
+		TCNN_LAUNCH((k_mlp_forward<WIDTH, true>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params, input, hidden, output);
+	} else {
+		TCNN_SET_MAX_DYN_LDS((k_mlp_forward<WIDTH, false>), lds_bytes);
+		TCNN_LAUNCH((k_mlp_forward<WIDTH, false>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params, input, hidden, output);
+	}
+}
+
+void mlp_forward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* hidden, half_t* output) {
+	check_meta(m, n);
+	if (n == 0) return;
+	switch (m.width) {
+		case 16: launch_forward<16>(stream, m, n, params, input, hidden, output); break;
+		case 32: launch_forward<32>(stream, m, n, params, input, hidden, output); break;
+		case 64: launch_forward<64>(stream, m, n, params, input, hidden, output); break;
+		case 128: launch_forward<128>(stream, m, n, params, input, hidden, output); break;
+	}
+}
+
+void mlp_transpose_weights(hipStream_t stream, const MlpMeta& m, const half_t* params, half_t* params_t) {
+	TCNN_LAUNCH(k_mlp_transpose_weights, dim3(div_round_up(m.n_params(), 256u)), dim3(256), 0, stream, m, params, params_t);
+}
+
+uint32_t mlp_backward_n_partials(const MlpMeta& m, uint32_t n) {
+	(void)m;
+	const uint32_t n_tiles = n / MLP_BWD_TILE;
+	return n_tiles < 512 ? n_tiles : 512;
+}
+
+template <uint32_t WIDTH, uint32_t HM>
+static void launch_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params_t, const half_t* input, const half_t* hidden,
+                            const half_t* dL_doutput, half_t* dL_dinput, float* partials) {
+	constexpr uint32_t S = MLP_BWD_TILE, SP = S + 8, LDW = WIDTH + 8;
+	const uint32_t halves = 2 * m.in_width * SP + (HM + 1) * WIDTH * SP + 2 * S * LDW + 16 * SP;
+	const uint32_t lds_bytes = halves * (uint32_t)sizeof(half_t);
+	const uint32_t blocks = mlp_backward_n_partials(m, n);
+	TCNN_SET_MAX_DYN_LDS((k_mlp_backward<WIDTH, HM>), lds_bytes);
+	TCNN_LAUNCH((k_mlp_backward<WIDTH, HM>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials);
+}
+
+template <uint32_t WIDTH>
+static void dispatch_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params_t, const half_t* input, const half_t* hidden,
+                              const half_t* dL_doutput, half_t* dL_dinput, float* partials) {
+	switch (m.n_hidden_matmuls) {
+		case 0: launch_backward<WIDTH, 0>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
+		case 1: launch_backward<WIDTH, 1>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
+		case 2: launch_backward<WIDTH, 2>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
+		case 3: launch_backward<WIDTH, 3>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
+		default:
+			throw std::runtime_error("FullyFusedMLP backward: at most " + std::to_string(MLP_MAX_HIDDEN_MATMULS_TRAIN + 1) +
+			                         " hidden layers are supported by the fused training kernels.");
+	}
+}
+
+void mlp_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params_t, const half_t* input, const half_t* hidden,
+                  const half_t* dL_doutput, half_t* dL_dinput, float* partials) {
+	check_meta(m, n);
+	if (n == 0) return;
+	switch (m.width) {
+		case 16: dispatch_backward<16>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
+		case 32: dispatch_backward<32>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
+		case 64: dispatch_backward<64>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
+		case 128: dispatch_backward<128>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
+	}
+}
+
+void mlp_finalize_gradients(hipStream_t stream, uint32_t n_params, uint32_t n_partials, const float* partials, half_t* grads, bool accumulate) {
+	TCNN_LAUNCH(k_mlp_finalize_gradients, dim3(div_round_up(n_params, 256u)), dim3(256), 0, stream, n_params, n_partials, partials, grads, accumulate ? 1 : 0);
+}
+
+}  // namespace tcnn_hip

@@ -1,0 +1,117 @@
+// tcnn_device.h -- device-side vocabulary shared by all gfx950 kernels of the tiny-cuda-nn_amd hot path.
+//
+// The kernels are written once.  The product build compiles them with hipcc for gfx950.  The test
+// suite can additionally compile the same sources for the host with TCNN_HOST_EMU defined, where
+// tests/emu/hip_emu.h supplies a lock-step SIMT emulator (threads, LDS, barriers, MFMA lane maps,
+// atomics).  The emulator is test infrastructure: nothing under tiny-cuda-nn_amd/ builds it in.
+#pragma once
+
+#include <stdint.h>
+
+#if defined(TCNN_HOST_EMU)
+#include "hip_emu.h"
+#define TCNN_DYN_LDS(name) unsigned char* name = (unsigned char*)::emu::dyn_lds()
+#define TCNN_SET_MAX_DYN_LDS(kernel, bytes) (void)0
+#else
+#include <hip/hip_runtime.h>
+#include <stdexcept>
+#define TCNN_DEVICE __device__ __forceinline__
+#define TCNN_HOST_DEVICE __host__ __device__ __forceinline__
+#define TCNN_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+	hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
+// dynamic LDS: one 16-byte aligned carve base per kernel (cdna_hip_programming.md G17)
+#define TCNN_DYN_LDS(name)                                                        \
+	extern __shared__ __attribute__((aligned(16))) unsigned char tcnn_dyn_lds_[]; \
+	unsigned char* name = tcnn_dyn_lds_
+// kernels may use up to the full 160 KiB of a CU's LDS; HIP needs to be told above 64 KiB
+#define TCNN_SET_MAX_DYN_LDS(kernel, bytes)                                                                                     \
+	do {                                                                                                                        \
+		if (hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != hipSuccess) \
+			throw std::runtime_error("tiny-cuda-nn_amd: could not reserve dynamic LDS for a kernel");                            \
+	} while (0)
+#endif
+
+namespace tcnn_hip {
+
+typedef _Float16 half_t;
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+
+constexpr uint32_t WAVE = 64;                      // CDNA wavefront
+constexpr uint32_t BATCH_SIZE_GRANULARITY = 256;   // reference common.h:246
+constexpr uint32_t MAX_N_LEVELS = 128;             // reference multi_level_interface.h:84-88
+constexpr float LOSS_SCALE_FP16 = 128.0f;          // reference common.h:243
+
+// ---------------------------------------------------------------------------------------------
+// MFMA wrappers.  Fragment maps (cdna_hip_programming.md section 3):
+//   16x16x32 f16:  A[i = lane&15][k = 8*(lane>>4) + j], B[k = 8*(lane>>4) + j][n = lane&15], j<8
+//   16x16x16 f16:  A[i = lane&15][k = 4*(lane>>4) + j], B[k = 4*(lane>>4) + j][n = lane&15], j<4
+//   C/D (both):    row = 4*(lane>>4) + r, col = lane&15, r<4
+// ---------------------------------------------------------------------------------------------
+#if !defined(TCNN_HOST_EMU)
+TCNN_DEVICE f4 mfma_16x16x32(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+TCNN_DEVICE f4 mfma_16x16x16(h4 a, h4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+
+// Packed-half global atomic add (global_atomic_pk_add_f16), no return value.
+TCNN_DEVICE void atomic_add_h2(half_t* addr, h2 v) {
+	__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)addr, v);
+}
+TCNN_DEVICE void atomic_add_f32(float* addr, float v) { unsafeAtomicAdd(addr, v); }
+TCNN_DEVICE void lds_atomic_add_f32(float* addr, float v) { atomicAdd(addr, v); }  // ds_add_f32
+TCNN_DEVICE h2 fma_h2(h2 a, h2 b, h2 c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f16
+TCNN_DEVICE half_t fma_h(half_t a, half_t b, half_t c) { return __builtin_fmaf16(a, b, c); }
+TCNN_DEVICE uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)); }  // HW_REG_XCC_ID
+#endif
+
+TCNN_DEVICE uint32_t lane_id() { return threadIdx.x & 63u; }
+
+template <typename T>
+TCNN_HOST_DEVICE T div_round_up(T a, T b) { return (a + b - 1) / b; }
+template <typename T>
+TCNN_HOST_DEVICE T next_multiple(T a, T b) { return div_round_up(a, b) * b; }
+
+// ---------------------------------------------------------------------------------------------
+// Grid indexing -- reference common_device.h:767-895, 1000-1043.  Integer work: bit-exact.
+// ---------------------------------------------------------------------------------------------
+enum class GridType : int { Hash = 0, Dense = 1, Tiled = 2 };
+enum class InterpolationType : int { Nearest = 0, Linear = 1, Smoothstep = 2 };
+
+struct GridLevelTable {
+	// One entry per level, computed ONCE on the host in fp32 (canonical scale table) and
+	// passed by value; the reference recomputes exp2f per thread (grid.h:97), which is not portable
+	// bit-for-bit across devices.
+	uint32_t offset[MAX_N_LEVELS + 1];  // in grid entries
+};
+
+template <uint32_t D>
+TCNN_HOST_DEVICE uint32_t coherent_prime_hash(const uint32_t (&p)[D]) {
+	constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+	uint32_t r = 0;
+#pragma unroll
+	for (uint32_t i = 0; i < D; ++i) r ^= p[i] * primes[i];
+	return r;
+}
+
+template <uint32_t D>
+TCNN_HOST_DEVICE uint32_t grid_index(bool is_hash, uint32_t hashmap_size, uint32_t resolution, const uint32_t (&p)[D]) {
+	constexpr uint32_t MAX_BASES[11] = {0x0, 0xFFFFFFFF, 0xFFFF, 0x659, 0xFF, 0x54, 0x28, 0x17, 0xF, 0xB, 0x9};
+	uint32_t stride = 1;
+	uint32_t index = 0;
+	if (resolution <= MAX_BASES[D]) {
+#pragma unroll
+		for (uint32_t d = 0; d < D; ++d) {
+			index += p[d] * stride;
+			stride *= resolution;
+		}
+	} else {
+		stride = 0xFFFFFFFFu;
+	}
+	if (is_hash && hashmap_size < stride) index = coherent_prime_hash<D>(p);
+	return index % hashmap_size;
+}
+
+}  // namespace tcnn_hip

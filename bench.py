@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training samples/s of HashGrid + FullyFusedMLP(64, 2 hidden) at batch 2^18 per GPU
+(BASELINE.json `metric`; workload = BASELINE.json configs[2] / SURVEY.md 8d "cfg3").
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = trainer.training_step (grid forward -> fused MLP forward -> RelativeL2 loss -> fused MLP backward
+incl. weight gradients -> grid backward scatter -> Adam) on one batch of synthetic 3-D -> 4 samples that is
+already resident in HBM.  For N > 1 every rank trains on its own 2^18-sample shard of a global batch of
+N * 2^18 (weak scaling), loss gradients are normalised by the global batch, and the fp16 gradient buffer
+[MLP | grid] is all-reduced (RCCL over xGMI) between backward and the optimizer step.
+
+Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
+  roofline     -- the dominant kernel of the step, timed with HIP events on the stream it runs on inside the
+                  timed region (tcnn_trainer_set_profiling), against the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle ("port": the reference has no CPU path and cannot be built here) timed on
+                  this box's host cores on the same workload (rank 0, --gpus 1 only);
+  stages       -- per-stage mean times of a second, fully instrumented pass (not part of `value`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tiny-cuda-nn_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+BATCH = 1 << 18
+N_IN, N_OUT = 3, 4
+CONFIG = {
+    "loss": {"otype": "RelativeL2"},
+    "optimizer": {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6},
+    "encoding": {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19,
+                 "base_resolution": 16, "per_level_scale": 2.0},
+    "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2},
+}
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(n, n_params, n_mlp_params):
+    """ALGORITHMIC bytes per launch of each stage (DESIGN.md "Roofline accounting"; SURVEY.md 8d per-unit figures):
+    what the stage must move at minimum with fp16 params/grads, NOT what the implementation happens to move."""
+    L, F, D, C = 16, 2, 3, 8
+    enc_w, W, H, OUTP = L * F, 64, 2, 16
+    p_grid = n_params - n_mlp_params
+    return {
+        "grid_forward": n * (4 * D + L * C * F * 2 + enc_w * 2),                 # positions + 8-corner gather + encoded write
+        "mlp_forward": n * (enc_w * 2 + H * W * 2 + OUTP * 2) + n_mlp_params * 2,  # encoded read + saved hidden + output
+        "loss": n * (OUTP * 2 + N_OUT * 4 + OUTP * 2),
+        "mlp_backward": n * (enc_w * 2 + H * W * 2 + OUTP * 2 + enc_w * 2) + n_mlp_params * 4,
+        "grid_backward_zero": p_grid * 2,
+        "grid_backward": n * (4 * D + enc_w * 2 + 2 * L * C * F * 2),            # positions + dL/denc + RMW of 8 corners
+        "adam": n_params * 36,                                                   # 2 grad + (4+4)x(master, m, v, steps) + 2 fp16 param
+        # fused-ideal step of SURVEY 8d: per sample 12 + 16 + 512 + 1024 B, per step P_grid*2 + P_total*36
+        "step_ideal": n * (4 * D + 4 * N_OUT + L * C * F * 2 + 2 * L * C * F * 2) + p_grid * 2 + n_params * 36,
+    }
+
+
+def make_batches(n, n_batches, seed, device):
+    """Synthetic 3-D -> 4 regression data, U[0,1)^3 positions, smooth analytic targets."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = []
+    for _ in range(n_batches):
+        x = torch.rand((n, N_IN), generator=g, device=device, dtype=torch.float32)
+        t = torch.stack([0.5 + 0.5 * torch.sin(2 * np.pi * (c + 1) * x[:, 0]) * torch.cos(2 * np.pi * (c + 1) * x[:, 1]) * torch.sin(2 * np.pi * x[:, 2] + c)
+                         for c in range(N_OUT)], dim=1).contiguous()
+        out.append((x.contiguous(), t))
+    return out
+
+
+def cpu_baseline(n_steps=3):
+    """The reference's path has no CPU implementation and cannot be compiled here; the baseline is
+    the CPU oracle restating it (oracle/tcnn_oracle.c, OpenMP), same config, same batch size, fresh random batch."""
+    from oracle import oracle as O
+    g = O.grid_init(3, 16, 2, 19, 16, 2.0)
+    adam = O.adam_defaults(learning_rate=1e-2, beta1=0.9, beta2=0.99, epsilon=1e-15, l2_reg=1e-6)
+    md = O.model_init(N_IN, N_OUT, g, 64, 2, O.LOSS_RELATIVE_L2, adam)
+    st = O.TrainState(md, O.model_init_params(md, 1337))
+    rng = np.random.default_rng(0)
+    pos = rng.random((BATCH, N_IN), dtype=np.float32)
+    tgt = rng.random((BATCH, N_OUT), dtype=np.float32)
+    O.training_step(st, pos, tgt)  # warm-up (page faults, thread pool)
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        O.training_step(st, pos, tgt)
+    dt = time.perf_counter() - t0
+    return {"value": n_steps * BATCH / dt, "unit": "samples/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"{n_steps} full training steps of the same config at batch 2^18 ({dt:.1f} s), after 1 warm-up step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dominant", default="adam", help="stage timed with HIP events inside the timed region")
+    ap.add_argument("--lds-budget", type=int, default=None, help="grid backward: LDS bytes per level table (tuning knob)")
+    args = ap.parse_args()
+
+    import tinycudann as tcnn  # fails loudly if libtcnn_hip.so is missing
+    from tinycudann import parallel as par
+
+    rank, local_rank, world = par.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    tm = tcnn.create_from_config(N_IN, N_OUT, CONFIG, seed=1337)
+    if args.lds_budget is not None:
+        tm.set_lds_level_budget(args.lds_budget)
+    global_batch = BATCH * world
+    if world > 1:
+        tm.set_global_batch_size(global_batch)
+    batches = make_batches(BATCH, 4, seed=1337 + rank, device=device)
+    grads = tm.param_gradients
+
+    def step(i):
+        x, t = batches[i % len(batches)]
+        if world > 1:
+            tm.training_step(x, t, run_optimizer=False, want_context=False)
+            par.all_reduce_gradients(grads)
+            tm.optimizer_step()
+        else:
+            tm.training_step(x, t, want_context=False)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+
+    # ---- timed region: EXACTLY --steps steps, barrier + synchronize on both sides -----------------------
+    tm.set_profiling(True, only_stage=args.dominant)  # 2 HIP events per step around the dominant kernel only
+    par.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    par.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = par.all_reduce_max(elapsed, device=device)
+    dom_ms, dom_cnt = tm.stage_times()[args.dominant]
+
+    # ---- second, fully instrumented pass (breakdown only; not part of `value`) ----------------------------
+    tm.set_profiling(True)
+    n_prof = min(args.steps, 50)
+    for i in range(n_prof):
+        step(i)
+    torch.cuda.synchronize()
+    stages = {k: (ms / max(c, 1)) for k, (ms, c) in tm.stage_times().items()}
+    tm.set_profiling(False)
+
+    # sanity: the run must have trained (loss finite and below the initial loss)
+    ctx = tm.training_step(*batches[0], run_optimizer=False)
+    final_loss = tm.loss(ctx)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = global_batch * args.steps / elapsed
+        ab = algorithmic_bytes(BATCH, tm.n_params, tm.n_mlp_params)
+        dom_avg_s = dom_ms / max(dom_cnt, 1) * 1e-3
+        achieved = ab[args.dominant] / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch, if a pass was recorded
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(args.dominant)
+        line = {
+            "metric": "training samples/s, HashGrid+FullyFusedMLP(64,2) @ batch 2^18",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 (fp16 params/activations/gradients, fp32 MFMA accumulate, fp32 Adam state)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: HashGrid(L=16,F=2,T=2^19,base 16,per_level_scale 2.0) + FullyFusedMLP 64x2 ReLU, "
+                                   "3D->4, RelativeL2, Adam(config_hash.json), training_step incl. optimizer",
+                       "batch_per_gpu": BATCH, "global_batch": global_batch, "n_params": tm.n_params,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "roofline": {"bound": "hbm", "kernel": args.dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": ab[args.dominant], "avg_launch_ms": dom_avg_s * 1e3, "launches_timed": int(dom_cnt)},
+            "stages_ms": stages,
+            "step_ideal_GBps": ab["step_ideal"] / (elapsed / args.steps) / 1e9,
+            "final_loss": final_loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    par.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+/*
+ * tcnn_hip.h -- C ABI of the MI355X-native HashGrid + FullyFusedMLP hot path (libtcnn_hip.so).
+ *
+ * Plain C: opaque handles, raw device pointers, sizes, UTF-8 JSON text.  No C++/torch types cross
+ * this boundary.  Every entry point names the reference interface it replaces (file:line under the
+ * tiny-cuda-nn tree); INTEGRATION.md shows the reference-side bindings (pybind / C++ facade) that a
+ * maintainer would point at these symbols.
+ *
+ * Conventions (identical to the reference's cpp_api, src/cpp_api.cu:72-153):
+ *   - all matrices are "features x batch, column-major" == [batch][features] contiguous;
+ *   - inputs are fp32, params / outputs / gradients are fp16 (TCNN_PRECISION_FP16);
+ *   - n_elements must be a multiple of tcnn_batch_size_granularity() (256); the caller pads;
+ *   - outputs have the PADDED width tcnn_module_n_output_dims() (multiple of 16); the caller slices;
+ *   - dL_doutput arrives pre-multiplied by the loss scale (bindings/torch/tinycudann/modules.py:167);
+ *   - the caller owns input/output/param/gradient buffers, the module owns only hyper-parameters;
+ *     saved activations live in a tcnn_context_t the caller destroys.
+ * Every function returns TCNN_OK (0) or an error code; tcnn_last_error() holds the message of the last
+ * failure on the calling thread (the reference throws std::runtime_error, common_host.h:71-110).
+ * Streams are hipStream_t passed as void*; NULL is the default stream.
+ */
+#ifndef TCNN_HIP_H
+#define TCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TCNN_OK 0
+#define TCNN_ERROR 1             /* std::runtime_error in the reference */
+#define TCNN_ERROR_UNSUPPORTED 2 /* part of the reference surface that is out of this build's scope */
+
+typedef struct tcnn_module tcnn_module_t;                   /* tcnn::cpp::Module, cpp_api.h:91-119 */
+typedef struct tcnn_context tcnn_context_t;                 /* tcnn::cpp::Context, cpp_api.h:87-89 */
+typedef struct tcnn_trainable_model tcnn_trainable_model_t; /* tcnn::TrainableModel, config.h:46-51 */
+typedef struct tcnn_train_context tcnn_train_context_t;     /* Trainer::ForwardContext, trainer.h:89-95 */
+typedef void* tcnn_stream_t;                                /* hipStream_t (cudaStream_t in the reference) */
+
+enum { TCNN_PRECISION_FP32 = 0, TCNN_PRECISION_FP16 = 1 };                  /* cpp_api.h:72-75 */
+enum { TCNN_LOG_INFO = 0, TCNN_LOG_DEBUG, TCNN_LOG_WARNING, TCNN_LOG_ERROR, TCNN_LOG_SUCCESS }; /* cpp_api.h:52-58 */
+enum { TCNN_GRADIENT_IGNORE = 0, TCNN_GRADIENT_OVERWRITE = 1, TCNN_GRADIENT_ACCUMULATE = 2 };  /* common.h:152-156 */
+
+const char* tcnn_last_error(void);
+
+/* ---- free functions, cpp_api.h:62-85 ------------------------------------------------------------- */
+uint32_t tcnn_batch_size_granularity(void);            /* cpp_api.h:62 */
+int tcnn_hip_device(void);                             /* cuda_device(), cpp_api.h:64 */
+int tcnn_set_hip_device(int device);                   /* set_cuda_device(), cpp_api.h:65 */
+void tcnn_free_temporary_memory(void);                 /* cpp_api.h:67 */
+int tcnn_has_networks(void);                           /* cpp_api.h:69 */
+float tcnn_default_loss_scale(int precision);          /* cpp_api.h:77 */
+int tcnn_preferred_precision(void);                    /* cpp_api.h:79 */
+int tcnn_supports_jit_fusion(int device);              /* cpp_api.h:81 -- always 0: no RTC path */
+void tcnn_set_log_callback(void (*callback)(int severity, const char* message)); /* cpp_api.h:85 */
+
+/* ---- module factories, cpp_api.h:121-123 ---------------------------------------------------------- */
+int tcnn_create_network_with_input_encoding(uint32_t n_input_dims, uint32_t n_output_dims, const char* encoding_json,
+                                            const char* network_json, tcnn_module_t** out);
+int tcnn_create_network(uint32_t n_input_dims, uint32_t n_output_dims, const char* network_json, tcnn_module_t** out);
+int tcnn_create_encoding(uint32_t n_input_dims, const char* encoding_json, int requested_precision, tcnn_module_t** out);
+void tcnn_module_destroy(tcnn_module_t* m);
+
+/* ---- tcnn::cpp::Module methods, cpp_api.h:96-114 -------------------------------------------------- */
+int tcnn_module_inference(tcnn_module_t* m, tcnn_stream_t stream, uint32_t n_elements, const float* input, void* output,
+                          void* params);
+int tcnn_module_forward(tcnn_module_t* m, tcnn_stream_t stream, uint32_t n_elements, const float* input, void* output,
+                        void* params, int prepare_input_gradients, tcnn_context_t** ctx);
+int tcnn_module_backward(tcnn_module_t* m, tcnn_stream_t stream, const tcnn_context_t* ctx, uint32_t n_elements,
+                         float* dL_dinput, const void* dL_doutput, void* dL_dparams, const float* input,
+                         const void* output, const void* params);
+int tcnn_module_backward_backward_input(tcnn_module_t* m, tcnn_stream_t stream, const tcnn_context_t* ctx, uint32_t n_elements,
+                                        const float* dL_ddLdinput, const float* input, const void* dL_doutput,
+                                        void* dL_dparams, void* dL_ddLdoutput, float* dL_dinput, const void* params);
+void tcnn_context_destroy(tcnn_context_t* ctx);
+
+uint32_t tcnn_module_n_input_dims(const tcnn_module_t* m);
+uint32_t tcnn_module_n_output_dims(const tcnn_module_t* m); /* PADDED width, cpp_api.cu:137 */
+size_t tcnn_module_n_params(const tcnn_module_t* m);
+int tcnn_module_param_precision(const tcnn_module_t* m);
+int tcnn_module_output_precision(const tcnn_module_t* m);
+int tcnn_module_initialize_params(tcnn_module_t* m, size_t seed, float* params_full_precision, float scale);
+const char* tcnn_module_hyperparams_json(const tcnn_module_t* m); /* valid until the module is destroyed */
+const char* tcnn_module_name(const tcnn_module_t* m);
+int tcnn_module_jit_fusion(const tcnn_module_t* m);               /* always 0 */
+int tcnn_module_set_jit_fusion(tcnn_module_t* m, int val);        /* accepted, ignored (warns if val != 0) */
+
+/* Parity / debug helper (no reference counterpart): hash-grid entry index of every
+ * (sample, level, corner) -> indices[(i * n_levels + level) * 2^D + corner], device uint32. */
+int tcnn_module_grid_indices(tcnn_module_t* m, tcnn_stream_t stream, uint32_t n_elements, const float* input, uint32_t* indices);
+/* Grid layout accessors used by the reference's own known-answer test (tests/test_grid.cu:55-71). */
+int tcnn_module_grid_level_n_params(const tcnn_module_t* m, uint32_t level, size_t* out);
+int tcnn_module_grid_level_params_offset(const tcnn_module_t* m, uint32_t level, size_t* out);
+
+/* ---- create_from_config / Trainer / Network::inference (C++ template API) ------------------------ */
+/* tcnn::create_from_config, config.h:53-63.  config_json holds "loss", "optimizer", "encoding", "network". */
+int tcnn_create_from_config(uint32_t n_input_dims, uint32_t n_output_dims, const char* config_json, uint32_t seed,
+                            tcnn_trainable_model_t** out);
+void tcnn_trainable_model_destroy(tcnn_trainable_model_t* tm);
+
+/* Trainer::training_step, trainer.h:254-357.  input: fp32 [batch][n_input_dims]; target: fp32
+ * [batch][n_output_dims]; data_pdf (nullable) like target; dL_dinput (nullable) like input;
+ * external_dL_dy (nullable): fp16 [batch][padded_output_width].  *ctx (nullable out) must be destroyed
+ * with tcnn_train_context_destroy. */
+int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream, uint32_t batch_size, const float* input,
+                               const float* target, const float* data_pdf, int run_optimizer, float* dL_dinput,
+                               int use_inference_params, int gradient_mode, const void* external_dL_dy,
+                               tcnn_train_context_t** ctx);
+/* Trainer::forward / backward / optimizer_step, trainer.h:97-157 */
+int tcnn_trainer_forward(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale, uint32_t batch_size,
+                         const float* input, const float* target, const float* data_pdf, int use_inference_params,
+                         int prepare_input_gradients, const void* external_dL_dy, tcnn_train_context_t** ctx);
+int tcnn_trainer_backward(tcnn_trainable_model_t* tm, tcnn_stream_t stream, const tcnn_train_context_t* ctx,
+                          uint32_t batch_size, const float* input, float* dL_dinput, int use_inference_params,
+                          int gradient_mode);
+int tcnn_trainer_optimizer_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale);
+/* Trainer::loss, trainer.h:372-374 (synchronises the stream) */
+int tcnn_trainer_loss(tcnn_trainable_model_t* tm, tcnn_stream_t stream, const tcnn_train_context_t* ctx, float* out_loss);
+void tcnn_train_context_destroy(tcnn_train_context_t* ctx);
+/* ForwardContext members, trainer.h:89-95: fp16 [batch][padded_output_width] device pointers */
+const void* tcnn_train_context_output(const tcnn_train_context_t* ctx);
+const void* tcnn_train_context_dL_doutput(const tcnn_train_context_t* ctx);
+
+/* DifferentiableObject::inference, object.h:214-271: fp32 in, fp32 [batch][n_output_dims] out (trimmed) */
+int tcnn_network_inference(tcnn_trainable_model_t* tm, tcnn_stream_t stream, uint32_t batch_size, const float* input,
+                           float* output, int use_inference_params);
+
+/* parameter access, trainer.h:389-440 */
+size_t tcnn_trainer_n_params(const tcnn_trainable_model_t* tm);
+float* tcnn_trainer_params_full_precision(tcnn_trainable_model_t* tm);
+void* tcnn_trainer_params(tcnn_trainable_model_t* tm);
+void* tcnn_trainer_params_inference(tcnn_trainable_model_t* tm);
+void* tcnn_trainer_param_gradients(tcnn_trainable_model_t* tm);
+int tcnn_trainer_set_params_full_precision(tcnn_trainable_model_t* tm, const float* params, size_t n_params, int device_ptr);
+int tcnn_trainer_set_params(tcnn_trainable_model_t* tm, const void* params_fp16, size_t n_params, int device_ptr);
+int tcnn_trainer_update_hyperparams(tcnn_trainable_model_t* tm, const char* json);      /* trainer.h:380-383 */
+const char* tcnn_trainer_hyperparams_json(tcnn_trainable_model_t* tm);                   /* trainer.h:385-391 */
+uint32_t tcnn_trainer_optimizer_step_count(const tcnn_trainable_model_t* tm);            /* Optimizer::step() */
+uint32_t tcnn_trainer_padded_output_width(const tcnn_trainable_model_t* tm);
+uint32_t tcnn_trainer_n_mlp_params(const tcnn_trainable_model_t* tm); /* "matrix" params: leading part of the buffer */
+
+/* Data parallelism (no reference counterpart; the reference is single-GPU).
+ * Loss gradients are normalised by global_batch_size * n_output_dims instead of the local batch, so the
+ * SUM over ranks of the local gradient buffers equals the single-GPU gradient of the global batch.  The
+ * host all-reduces tcnn_trainer_param_gradients() (RCCL) between backward and optimizer_step. */
+int tcnn_trainer_set_global_batch_size(tcnn_trainable_model_t* tm, uint64_t global_batch_size);
+
+/* Measurement hooks (no reference counterpart): HIP events recorded around each stage of the training step
+ * on the stream the kernels are launched on.  only_stage < 0 times every stage, otherwise just that one.
+ * tcnn_trainer_get_stage_times synchronises on the recorded events and returns accumulated totals. */
+int tcnn_trainer_set_profiling(tcnn_trainable_model_t* tm, int enable, int only_stage);
+int tcnn_trainer_n_stages(void);
+const char* tcnn_trainer_stage_name(int stage);
+int tcnn_trainer_get_stage_times(tcnn_trainable_model_t* tm, double* total_ms, uint64_t* counts);
+/* Tuning knob: levels whose fp32 table fits in this many bytes of LDS are accumulated in LDS by grid backward. */
+int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCNN_HIP_H */

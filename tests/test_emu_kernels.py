@@ -1,0 +1,146 @@
+"""Runs the gfx950 kernel SOURCES (tiny-cuda-nn_amd/csrc/*.hip) on the host SIMT emulator
+(tests/emu/hip_emu.h) and compares them with the CPU oracle.  This is host-logic coverage for the
+no-GPU CI leg: indexing, MFMA fragment bookkeeping, LDS tiles and barrier structure of the real kernels.
+The `-m gpu` suite repeats the comparisons on hardware through the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+emu = pytest.importorskip("emu")
+if not emu.available():
+    pytest.skip("ROCm clang++ not available to build the host emulator", allow_module_level=True)
+
+
+def rae(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return np.abs(a - b) / (0.5 * (np.abs(a) + np.abs(b)) + np.abs(b).mean() * 1e-2 + 1e-12)
+
+
+GRID_CASES = [
+    # D, L, F, log2T, base, scale, type, interp
+    (3, 16, 2, 15, 16, 1.5, O.GRID_HASH, O.INTERP_LINEAR),
+    (2, 16, 2, 15, 16, 1.5, O.GRID_HASH, O.INTERP_LINEAR),
+    (3, 8, 4, 12, 8, 2.0, O.GRID_HASH, O.INTERP_SMOOTHSTEP),
+    (3, 6, 1, 12, 4, 1.6, O.GRID_HASH, O.INTERP_LINEAR),
+    (4, 4, 8, 10, 4, 1.5, O.GRID_HASH, O.INTERP_LINEAR),
+    (3, 5, 2, 19, 4, 1.4, O.GRID_DENSE, O.INTERP_LINEAR),
+    (2, 6, 2, 19, 8, 2.0, O.GRID_TILED, O.INTERP_NEAREST),
+]
+
+
+@pytest.mark.parametrize("case", GRID_CASES)
+def test_grid_forward_bit_exact(case):
+    D, L, F, T, base, scale, gtype, interp = case
+    rng = np.random.default_rng(0)
+    og = O.grid_init(D, L, F, T, base, scale, gtype, interp)
+    g = emu.Grid(og)
+    n = 1000  # ragged: not a multiple of the 1024-sample tile
+    pos = rng.random((n, D), dtype=np.float32)
+    pos[0] = 0.0
+    pos[1] = 1.0  # cell coordinate == resolution: wrap-around indexing (common_device.h:1002-1007)
+    params = O.f2h((rng.random(og.n_params, dtype=np.float32) * 2 - 1) * 0.5)
+    assert np.array_equal(emu.grid_indices(g, pos), O.grid_indices(og, pos))
+    ref, ref_dydx = O.grid_forward(og, params, pos, want_dy_dx=True)
+    out, dydx = emu.grid_forward(g, params, pos, soa=True, want_dy_dx=True)
+    assert np.array_equal(out.T, ref)
+    assert np.array_equal(np.transpose(dydx, (1, 0, 2)), ref_dydx)
+    out_aos = emu.grid_forward(g, params, pos, soa=False, out_stride=L * F + 8)
+    assert np.array_equal(out_aos[:, :L * F], ref)
+
+
+@pytest.mark.parametrize("case", GRID_CASES)
+@pytest.mark.parametrize("lds_budget", [0, 48 * 1024])
+def test_grid_backward(case, lds_budget):
+    D, L, F, T, base, scale, gtype, interp = case
+    rng = np.random.default_rng(1)
+    og = O.grid_init(D, L, F, T, base, scale, gtype, interp)
+    g = emu.Grid(og)
+    n = 1500
+    pos = rng.random((n, D), dtype=np.float32)
+    dy = O.f2h(rng.standard_normal((n, L * F)).astype(np.float32))
+    ref = O.grid_backward(og, pos, dy)
+    got = emu.grid_backward(g, pos, np.ascontiguousarray(dy.T), soa=True, lds_budget=lds_budget)
+    gotf = got.astype(np.float64) if F == 1 else O.h2f(got).astype(np.float64)
+    # fp16 atomics round after every add: allow 2^-9 of the accumulated magnitude (+ a little absolute slack)
+    absacc = O.grid_backward(og, pos, O.f2h(np.abs(O.h2f(dy))))
+    assert np.all(np.abs(gotf - ref) <= absacc * 2.0 ** -9 + 2e-3)
+    dl = emu.grid_backward_input(g, np.ascontiguousarray(dy.T), np.ascontiguousarray(np.transpose(O.grid_forward(og, O.f2h(np.zeros(og.n_params, np.float32) + 0.25), pos, want_dy_dx=True)[1], (1, 0, 2))))
+    assert dl.shape == (n, D)
+
+
+MLP_CASES = [(32, 64, 4, 2), (16, 16, 3, 1), (48, 32, 16, 3), (32, 128, 16, 4), (128, 64, 5, 2), (64, 64, 1, 1)]
+
+
+@pytest.mark.parametrize("case", MLP_CASES)
+def test_mlp_forward_backward(case):
+    IN, W, OUT, H = case
+    rng = np.random.default_rng(2)
+    om = O.mlp_init(IN, W, OUT, H)
+    ph = O.f2h(O.mlp_init_params(om, O.pcg32(1337)))
+    n = 256
+    x = O.f2h(rng.random((n, IN), dtype=np.float32))
+    xs = np.ascontiguousarray(x.T)
+    hid_ref, out_ref = O.mlp_forward(om, ph, x)
+    hid, out = emu.mlp_forward(om, ph, xs)
+    assert np.max(np.abs(O.h2f(out) - O.h2f(out_ref))) <= 2e-3
+    assert np.max(np.abs(O.h2f(hid) - O.h2f(hid_ref))) <= 2e-3
+    _, out_inf = emu.mlp_forward(om, ph, xs, save_hidden=False)
+    assert np.array_equal(out_inf, out)  # inference == forward (tests/test_common.h:160-165)
+
+    dy = O.f2h((rng.standard_normal((n, om.padded_out)) * 0.01).astype(np.float32))
+    dy[:, OUT:] = 0
+    gref, dref = O.mlp_backward(om, ph, x, hid_ref, out_ref, dy)
+    gh, dx = emu.mlp_backward(om, ph, xs, hid_ref, dy)
+    assert np.percentile(rae(O.h2f(gh), gref), 99) < 2e-3
+    assert np.max(np.abs(O.h2f(dx).T - O.h2f(dref))) <= 1e-4 + 2e-3 * np.abs(O.h2f(dref)).max()
+    # GradientMode::Accumulate == old + new (fully_fused_mlp.cu:770)
+    gacc, _ = emu.mlp_backward(om, ph, xs, hid_ref, dy, grads_init=gh)
+    assert np.percentile(rae(O.h2f(gacc), 2 * gref), 99) < 3e-3
+    # GradientMode::Ignore: dL_dinput only
+    g_none, dx2 = emu.mlp_backward(om, ph, xs, hid_ref, dy, want_grads=False)
+    assert g_none is None and np.array_equal(dx2, dx)
+
+
+@pytest.mark.parametrize("loss_type", [O.LOSS_L2, O.LOSS_RELATIVE_L2])
+def test_loss_bit_exact(loss_type):
+    rng = np.random.default_rng(3)
+    pred = O.f2h(rng.standard_normal((512, 16)).astype(np.float32))
+    tgt = rng.standard_normal((512, 3)).astype(np.float32)
+    v_ref, g_ref = O.loss(loss_type, pred, tgt, 3)
+    v, g, s = emu.loss(loss_type, pred, tgt, 3)
+    assert np.array_equal(g, g_ref) and np.array_equal(v, v_ref)
+    assert abs(s - v_ref.sum(dtype=np.float64)) < 1e-5 * abs(v_ref.sum(dtype=np.float64)) + 1e-7
+    # data-parallel normalisation: n_total is the GLOBAL count
+    _, g2_ref = O.loss(loss_type, pred, tgt, 3, n_total_override=4 * 512 * 3)
+    _, g2, _ = emu.loss(loss_type, pred, tgt, 3, n_total=4 * 512 * 3)
+    assert np.array_equal(g2, g2_ref)
+
+
+def test_adam_matches_oracle():
+    rng = np.random.default_rng(4)
+    h = O.adam_defaults(learning_rate=1e-2, beta2=0.99, epsilon=1e-15, l2_reg=1e-6)
+    n, nm = 4096 + 3, 1024
+    w = rng.standard_normal(n).astype(np.float32)
+    g = (rng.standard_normal(n) * 20).astype(np.float32)
+    g[2000:3000] = 0  # untouched hash entries are skipped (adam.h:79-82)
+    gh = O.f2h(g)
+    a = [w.copy(), O.f2h(w), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint32)]
+    b = [x.copy() for x in a]
+    for step in (1, 2, 3):
+        O.adam_step(h, nm, 128.0, step, a[0], a[1], gh, a[2], a[3], a[4])
+        emu.adam_step(h, nm, 128.0, step, b[0], b[1], gh, b[2], b[3], b[4])
+    assert np.array_equal(a[4], b[4]) and np.all(a[4][2000:3000] == 0)
+    assert np.allclose(a[0], b[0], rtol=1e-6, atol=1e-9) and np.allclose(a[2], b[2], rtol=1e-6) and np.allclose(a[3], b[3], rtol=1e-6)
+    assert np.mean(a[1] != b[1]) < 1e-3
+
+
+def test_rng_casts_identity():
+    r1, r2 = O.pcg32(1337), O.pcg32(1337)
+    a = O.generate_random_uniform(r1, 5001, -1e-4, 1e-4)
+    b = emu.generate_random_uniform(r2, 5001, -1e-4, 1e-4)
+    assert np.array_equal(a, b) and (r1.state, r1.inc) == (r2.state, r2.inc)
+    x = np.random.default_rng(5).standard_normal(1003).astype(np.float32)
+    assert np.array_equal(emu.cast_f32_to_f16(x), O.f2h(x))
+    xi = np.random.default_rng(6).random((256, 3), dtype=np.float32)
+    assert np.array_equal(emu.identity_forward(xi, 16).T, O.identity_forward(xi, 16))

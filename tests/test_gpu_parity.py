@@ -1,0 +1,410 @@
+"""Parity of the HIP path (through the C ABI / the tinycudann modules) against the CPU oracle, on a real
+MI355X.  Bars:
+  * hash-grid indices and the offset table: bit-exact;
+  * encoded features: bit-exact (the kernel reproduces the reference's fp16 fma chain, grid.h:144-163);
+  * loss gradients: bit-exact given the same fp16 prediction (IEEE fp32 division on both sides);
+  * MLP outputs / gradients: relative absolute error (tests/test_common.h:62-117) p99 <= 1e-2 is the
+    reference's own bar; we require p99 <= 3e-3 against the fp32-accumulate oracle (fp16 tolerance: MFMA
+    and the oracle sum the same fp16 products in a different order, results are rounded to fp16);
+  * grid gradients: |gpu - exact| <= 2^-9 * sum|contributions| + 2e-3 (fp16 atomics round at every add).
+"""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import HASH_ENCODING, HASH_ENCODING_SMALL, MLP_64x2, config_hash
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def tcnn():
+    import tinycudann
+    return tinycudann
+
+
+def h_np(t):
+    return t.detach().contiguous().cpu().view(torch.int16).numpy().view(np.uint16)
+
+
+def h_t(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).view(torch.half).cuda()
+
+
+def rae(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b) / (0.5 * (np.abs(a) + np.abs(b)) + np.abs(b).mean() * 1e-2 + 1e-12)
+
+
+def oracle_grid(enc, n_dims):
+    return O.grid_init(n_dims, enc.get("n_levels", 16), enc.get("n_features_per_level", 2), enc.get("log2_hashmap_size", 19),
+                       enc.get("base_resolution", 16), enc.get("per_level_scale", 2.0),
+                       {"Hash": O.GRID_HASH, "Dense": O.GRID_DENSE, "Tiled": O.GRID_TILED}[enc.get("type", "Hash")],
+                       {"Nearest": O.INTERP_NEAREST, "Linear": O.INTERP_LINEAR, "Smoothstep": O.INTERP_SMOOTHSTEP}[enc.get("interpolation", "Linear")])
+
+
+def positions(n, d, seed=1337):
+    rng = O.pcg32(seed)
+    return O.generate_random_uniform(rng, n * d, 0.0, 1.0).reshape(n, d)
+
+
+def test_native_library_is_loaded():
+    tcnn()
+    maps = open("/proc/self/maps").read()
+    assert "libtcnn_hip.so" in maps, "the HIP extension is not mapped into this process"
+    assert torch.cuda.is_available() and "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+ENCODINGS = [
+    (3, HASH_ENCODING),
+    (3, HASH_ENCODING_SMALL),
+    (2, HASH_ENCODING_SMALL),
+    (3, dict(HASH_ENCODING, n_levels=8, n_features_per_level=4, log2_hashmap_size=14, interpolation="Smoothstep")),
+    (3, dict(HASH_ENCODING, n_levels=6, n_features_per_level=1, log2_hashmap_size=12, base_resolution=4, per_level_scale=1.6)),
+    (4, dict(HASH_ENCODING, n_levels=4, n_features_per_level=8, log2_hashmap_size=10, base_resolution=4, per_level_scale=1.5)),
+    (3, {"otype": "DenseGrid", "n_levels": 5, "base_resolution": 4, "per_level_scale": 1.4}),
+    (2, {"otype": "TiledGrid", "n_levels": 6, "base_resolution": 8, "per_level_scale": 2.0, "interpolation": "Nearest"}),
+]
+
+
+@pytest.mark.parametrize("d,enc", ENCODINGS)
+def test_grid_indices_and_forward_bit_exact(d, enc):
+    C = tcnn()._C
+    m = C.create_encoding(d, enc)
+    og = oracle_grid(enc, d)
+    assert m.n_params() == og.n_params
+    n = 2048
+    pos = positions(n, d)
+    pos[0] = 0.0
+    pos[1] = 1.0  # cell coordinate == resolution -> wrap-around (common_device.h:1002-1007)
+    x = torch.from_numpy(pos).cuda()
+    assert np.array_equal(m.grid_indices(x).cpu().numpy().view(np.uint32), O.grid_indices(og, pos))
+    rng = np.random.default_rng(0)
+    params = O.f2h((rng.random(og.n_params, dtype=np.float32) * 2 - 1) * 0.5)
+    _, y = m.fwd(x, h_t(params))
+    torch.cuda.synchronize()
+    assert y.shape == (n, m.n_output_dims())
+    assert np.array_equal(h_np(y), O.grid_forward(og, params, pos))
+
+
+@pytest.mark.parametrize("d,enc", ENCODINGS)
+def test_grid_backward_and_input_gradient(d, enc):
+    C = tcnn()._C
+    m = C.create_encoding(d, enc)
+    og = oracle_grid(enc, d)
+    n = 4096
+    pos = positions(n, d, seed=7)
+    rng = np.random.default_rng(1)
+    params = O.f2h((rng.random(og.n_params, dtype=np.float32) * 2 - 1) * 0.5)
+    dy = O.f2h(rng.standard_normal((n, m.n_output_dims())).astype(np.float32))
+    x = torch.from_numpy(pos).cuda().requires_grad_(True)
+    p = h_t(params).requires_grad_(True)
+    ctx, y = m.fwd(x, p)
+    dx, dp = m.bwd(ctx, x, p, y, h_t(dy))
+    torch.cuda.synchronize()
+    ref = O.grid_backward(og, pos, dy)
+    absacc = O.grid_backward(og, pos, O.f2h(np.abs(O.h2f(dy))))
+    got = dp.float().cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(got - ref) <= absacc * 2.0 ** -9 + 2e-3)
+    if enc.get("interpolation", "Linear") != "Nearest":
+        _, dy_dx = O.grid_forward(og, params, pos, want_dy_dx=True)
+        dref = O.grid_backward_input(og, dy, dy_dx)
+        assert np.allclose(dx.cpu().numpy(), dref, rtol=1e-4, atol=1e-3 * np.abs(dref).max())
+
+
+def test_grid_forward_full_size_bit_exact_and_checksum():
+    """BASELINE size: N = 2^18, T = 2^19.  Bit-exact against the oracle, plus the size-independent scatter
+    property sum_entries grad[level, f] == sum_i dL_dy[i, level, f] (interpolation weights sum to one)."""
+    C = tcnn()._C
+    m = C.create_encoding(3, HASH_ENCODING)
+    og = oracle_grid(HASH_ENCODING, 3)
+    n = 1 << 18
+    pos = positions(n, 3)
+    rng = np.random.default_rng(2)
+    params = O.f2h((rng.random(og.n_params, dtype=np.float32) * 2 - 1) * 0.5)
+    x = torch.from_numpy(pos).cuda()
+    p = h_t(params).requires_grad_(True)
+    ctx, y = m.fwd(x, p)
+    assert np.array_equal(h_np(y), O.grid_forward(og, params, pos))
+    dy = (torch.randn((n, 32), device="cuda") * 0.01).half()
+    _, dp = m.bwd(ctx, x, p, y, dy)
+    torch.cuda.synchronize()
+    got = dp.float().view(-1, 2)
+    sums = torch.stack([got[og.offsets[l]:og.offsets[l + 1]].double().sum(0) for l in range(16)]).cpu().numpy()  # [L][F]
+    ref = dy.double().sum(0).view(16, 2).cpu().numpy()
+    scale = dy.abs().double().sum(0).view(16, 2).cpu().numpy()
+    assert np.all(np.abs(sums - ref) <= scale * 2.0 ** -8 + 1e-2)
+
+
+MLP_CASES = [(32, 64, 4, 2), (16, 16, 3, 1), (48, 32, 16, 3), (32, 128, 16, 4), (128, 64, 5, 2), (64, 64, 16, 2), (16, 32, 2, 4)]
+
+
+@pytest.mark.parametrize("IN,W,OUT,H", MLP_CASES)
+def test_network_forward_backward(IN, W, OUT, H):
+    """tcnn.Network == identity encoding (padded with 1, identity.h:62-64) + FullyFusedMLP; reference
+    tests/test_networks.cu:38-79 sweeps the same width / depth space."""
+    C = tcnn()._C
+    n_in = IN - 3  # exercises the padding of the identity encoding
+    m = C.create_network(n_in, OUT, dict(MLP_64x2, n_neurons=W, n_hidden_layers=H))
+    om = O.mlp_init(IN, W, OUT, H)
+    assert m.n_params() == om.n_params and m.n_output_dims() == 16
+    p32 = m.initial_params(1337).cpu().numpy()
+    assert np.array_equal(p32, O.mlp_init_params(om, O.pcg32(1337)))  # Xavier draw order, gpu_matrix.h:292-307
+    ph = O.f2h(p32)
+    n = 1024
+    rng = np.random.default_rng(3)
+    xin = rng.random((n, n_in), dtype=np.float32)
+    x = torch.from_numpy(xin).cuda().requires_grad_(True)
+    p = h_t(ph).requires_grad_(True)
+    ctx, y = m.fwd(x, p)
+    _, y_inf = m.fwd(x.detach(), p.detach())
+    torch.cuda.synchronize()
+    enc = O.identity_forward(xin, IN)
+    hid_ref, out_ref = O.mlp_forward(om, ph, enc)
+    assert torch.equal(y, y_inf)                                       # inference == forward (test_common.h:160-165)
+    assert np.percentile(rae(O.h2f(h_np(y)), O.h2f(out_ref)), 99) < 3e-3
+    assert np.max(np.abs(O.h2f(h_np(y)) - O.h2f(out_ref))) < 2e-2 * max(1.0, np.abs(O.h2f(out_ref)).max())
+
+    dy = np.zeros((n, 16), np.float32)
+    dy[:, :OUT] = rng.standard_normal((n, OUT)).astype(np.float32) * 0.05
+    dyh = O.f2h(dy)
+    dx, dp = m.bwd(ctx, x, p, y, h_t(dyh))
+    torch.cuda.synchronize()
+    gref, dref = O.mlp_backward(om, ph, enc, hid_ref, out_ref, dyh)
+    g = dp.float().cpu().numpy()
+    assert np.percentile(rae(g, gref), 99.9) < 1.2e-2                  # the reference's own bar (test_common.h:216-218)
+    assert np.percentile(rae(g, gref), 99) < 3e-3
+    dx_ref = O.h2f(dref)[:, :n_in]
+    assert np.allclose(dx.cpu().numpy(), dx_ref, rtol=2e-2, atol=2e-3 * np.abs(dx_ref).max())
+
+
+@pytest.mark.parametrize("d,enc,net,out", [
+    (3, HASH_ENCODING_SMALL, MLP_64x2, 4),
+    (2, HASH_ENCODING_SMALL, MLP_64x2, 3),
+    (3, dict(HASH_ENCODING, log2_hashmap_size=17, n_levels=20), dict(MLP_64x2, n_neurons=128, n_hidden_layers=4), 16),  # cfg 5 shape
+])
+def test_network_with_input_encoding(d, enc, net, out):
+    C = tcnn()._C
+    m = C.create_network_with_input_encoding(d, out, enc, net)
+    og = oracle_grid(enc, d)
+    md = O.model_init(d, out, og, net["n_neurons"], net["n_hidden_layers"])
+    assert m.n_params() == md.n_params
+    p32 = m.initial_params(1337).cpu().numpy()
+    assert np.array_equal(p32, O.model_init_params(md, 1337))          # MLP Xavier then grid U(-1e-4, 1e-4)
+    p32[md.mlp.n_params:] *= 3.0e3                                      # make the encoding matter numerically
+    ph = O.f2h(p32)
+    n = 2048
+    pos = positions(n, d, seed=11)
+    x = torch.from_numpy(pos).cuda()
+    p = h_t(ph).requires_grad_(True)
+    ctx, y = m.fwd(x, p)
+    torch.cuda.synchronize()
+    enc_ref = O.grid_forward(og, ph[md.mlp.n_params:], pos, out_stride=md.mlp.in_width)
+    hid_ref, out_ref = O.mlp_forward(md.mlp, ph[:md.mlp.n_params], enc_ref)
+    assert np.percentile(rae(O.h2f(h_np(y)), O.h2f(out_ref)), 99) < 3e-3
+    rng = np.random.default_rng(5)
+    dy = np.zeros((n, 16), np.float32)
+    dy[:, :out] = rng.standard_normal((n, out)).astype(np.float32) * 0.05
+    dyh = O.f2h(dy)
+    _, dp = m.bwd(ctx, x, p, y, h_t(dyh))
+    torch.cuda.synchronize()
+    gref, denc = O.mlp_backward(md.mlp, ph[:md.mlp.n_params], enc_ref, hid_ref, out_ref, dyh)
+    g = dp.float().cpu().numpy()
+    assert np.percentile(rae(g[:md.mlp.n_params], gref), 99) < 3e-3
+    ggrid = O.grid_backward(og, pos, denc)
+    absacc = O.grid_backward(og, pos, O.f2h(np.abs(O.h2f(denc))))
+    # dL/d(encoding) itself carries MLP fp16 noise: compare with the exact scatter of the ORACLE's dL/denc
+    assert np.all(np.abs(g[md.mlp.n_params:] - ggrid) <= absacc * 2.0 ** -7 + 1e-3 * np.abs(ggrid).max())
+
+
+def _trainer_and_oracle(cfg, d, out, seed=1337):
+    T = tcnn()
+    tm = T.create_from_config(d, out, cfg, seed=seed)
+    og = oracle_grid(cfg["encoding"], d)
+    adam = O.adam_defaults(**{k: v for k, v in (("learning_rate", 1e-2), ("beta1", 0.9), ("beta2", 0.99), ("epsilon", 1e-15), ("l2_reg", 1e-6))})
+    md = O.model_init(d, out, og, cfg["network"]["n_neurons"], cfg["network"]["n_hidden_layers"],
+                      O.LOSS_RELATIVE_L2 if cfg["loss"]["otype"] == "RelativeL2" else O.LOSS_L2, adam)
+    return tm, md
+
+
+def targets_for(pos, out):
+    return np.stack([0.5 + 0.5 * np.sin(2 * np.pi * (c + 1) * pos[:, 0]) * np.cos(2 * np.pi * pos[:, 1]) for c in range(out)], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("loss", ["RelativeL2", "L2"])
+def test_training_step_matches_oracle(loss):
+    """create_from_config -> trainer.training_step -> trainer.loss -> network.inference against the oracle's
+    whole-step restatement, starting from identical fp32 master parameters."""
+    cfg = config_hash(log2_hashmap_size=15, per_level_scale=1.5, loss=loss)
+    tm, md = _trainer_and_oracle(cfg, 3, 4)
+    # Trainer seed path: std::seed_seq{1337} -> pcg32 (trainer.h:53-56)
+    rng = O.pcg32(O.seed_seq_first(1337))
+    init = np.concatenate([O.mlp_init_params(md.mlp, rng), O.generate_random_uniform(rng, md.grid.n_params, -1e-4, 1e-4)])
+    assert np.array_equal(tm.params_full_precision.cpu().numpy(), init)
+    assert np.array_equal(h_np(tm.params), O.f2h(init))
+    init[md.mlp.n_params:] *= 1.0e3
+    tm.set_params_full_precision(torch.from_numpy(init))
+    st = O.TrainState(md, init)
+    n = 4096
+    pos = positions(n, 3, seed=21)
+    tgt = targets_for(pos, 4)
+    x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(tgt).cuda()
+
+    # step 0 without the optimizer: loss, prediction, gradients
+    ctx = tm.training_step(x, t, run_optimizer=False)
+    loss_ref, pred_ref = O.training_step(st, pos, tgt, run_optimizer=False, want_prediction=True)
+    assert abs(tm.loss(ctx) - loss_ref) <= 2e-3 * abs(loss_ref)
+    assert np.percentile(rae(O.h2f(h_np(ctx.output)), O.h2f(pred_ref)), 99) < 3e-3
+    v_ref, g_ref = O.loss(md.loss_type, h_np(ctx.output), tgt, 4)
+    assert np.array_equal(h_np(ctx.dL_doutput), g_ref)                 # loss gradient: bit-exact on the GPU's own prediction
+    g = tm.param_gradients.float().cpu().numpy()
+    gref = O.h2f(st.grads)
+    nm = md.mlp.n_params
+    assert np.percentile(rae(g[:nm], gref[:nm]), 99) < 5e-3
+    big = np.abs(gref[nm:]) > 1e-2 * np.abs(gref[nm:]).max()
+    assert np.percentile(rae(g[nm:][big], gref[nm:][big]), 99) < 3e-2
+
+    # three optimizer steps: parameters track the oracle, the loss goes down
+    losses, losses_ref = [], []
+    for _ in range(3):
+        ctx = tm.training_step(x, t)
+        losses.append(tm.loss(ctx))
+        losses_ref.append(O.training_step(st, pos, tgt))
+    assert tm.optimizer_step_count == 3
+    assert np.allclose(losses, losses_ref, rtol=2e-2)
+    assert losses[-1] < losses[0]
+    w = tm.params_full_precision.cpu().numpy()
+    # Adam normalises the update to ~lr per step, so after 3 steps |w - w_ref| stays well below 3*lr except
+    # where a near-zero gradient flips sign between the two implementations
+    assert np.mean(np.abs(w - st.w32) > 1e-2) < 2e-3
+    out = tm.inference(x).cpu().numpy()
+    ref = O.inference(md, pos, st.w16)
+    assert out.shape == (n, 4)
+    assert np.percentile(np.abs(out - ref), 99) < 5e-2
+
+
+def test_gradient_modes_and_data_parallel_linearity():
+    """GradientMode::Accumulate adds; and with the global-batch normalisation the gradients of two half
+    batches SUM to the gradient of the whole batch (what the RCCL all-reduce relies on), at BASELINE size."""
+    T = tcnn()
+    cfg = config_hash()
+    tm = T.create_from_config(3, 4, cfg)
+    n = 1 << 18
+    pos = positions(n, 3, seed=3)
+    tgt = targets_for(pos, 4)
+    x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(tgt).cuda()
+    w = tm.params_full_precision.clone()
+    w[tm.n_mlp_params:] *= 1.0e3
+    tm.set_params_full_precision(w)
+    tm.training_step(x, t, run_optimizer=False, want_context=False)
+    full = tm.param_gradients.float().clone()
+    tm.training_step(x, t, run_optimizer=False, gradient_mode=T._C.GradientMode.Accumulate, want_context=False)
+    twice = tm.param_gradients.float().clone()
+    assert torch.allclose(twice, 2 * full, rtol=2e-2, atol=2e-3 * full.abs().max().item())
+    tm.set_global_batch_size(n)
+    h = n // 2
+    tm.training_step(x[:h].contiguous(), t[:h].contiguous(), run_optimizer=False, want_context=False)
+    tm.training_step(x[h:].contiguous(), t[h:].contiguous(), run_optimizer=False, gradient_mode=T._C.GradientMode.Accumulate, want_context=False)
+    halves = tm.param_gradients.float().clone()
+    nm = tm.n_mlp_params
+    assert torch.allclose(halves[:nm], full[:nm], rtol=2e-2, atol=2e-3 * full[:nm].abs().max().item())
+    err = (halves[nm:] - full[nm:]).abs()
+    assert (err > 2e-2 * full[nm:].abs().max()).float().mean().item() < 1e-4
+    assert torch.isfinite(full).all()
+
+
+def test_full_size_training_converges():
+    """BASELINE config 3 at N = 2^18: loss decreases over a short run; inference is deterministic."""
+    T = tcnn()
+    tm = T.create_from_config(3, 4, config_hash())
+    n = 1 << 18
+    pos = positions(n, 3, seed=5)
+    x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(targets_for(pos, 4)).cuda()
+    losses = []
+    for i in range(30):
+        ctx = tm.training_step(x, t)
+        if i % 5 == 0 or i == 29:
+            losses.append(tm.loss(ctx))
+    assert all(np.isfinite(losses)) and losses[-1] < 0.6 * losses[0], losses
+    a, b = tm.inference(x), tm.inference(x)
+    assert torch.equal(a, b)
+
+
+def test_torch_modules_autograd_and_padding():
+    """modules.py surface: batch padding to 256, output slicing, loss-scale handling, two forwards then one
+    backward (scripts/test_torch_bindings.py), pickling."""
+    T = tcnn()
+    model = T.NetworkWithInputEncoding(3, 4, HASH_ENCODING_SMALL, MLP_64x2, seed=1337)
+    assert model.params.dtype == torch.float32 and model.params.shape[0] == model.native_tcnn_module.n_params()
+    n = 1000  # not a multiple of 256
+    pos = positions(n, 3, seed=9)
+    x = torch.from_numpy(pos).cuda()
+    y1 = model(x)
+    y2 = model(x)
+    assert y1.shape == (n, 4) and y1.dtype == torch.half and torch.equal(y1, y2)
+    tgt = torch.from_numpy(targets_for(pos, 4)).cuda()
+    loss = ((y2.float() - tgt) ** 2).mean()
+    loss.backward()
+    g = model.params.grad
+    assert g is not None and g.dtype == torch.float32 and torch.isfinite(g).all() and g.abs().sum() > 0
+    # oracle gradient of the same objective
+    og = oracle_grid(HASH_ENCODING_SMALL, 3)
+    md = O.model_init(3, 4, og, 64, 2)
+    ph = h_np(model.params.detach().half())
+    npad = 1024
+    pos_p = np.zeros((npad, 3), np.float32)
+    pos_p[:n] = pos
+    enc = O.grid_forward(og, ph[md.mlp.n_params:], pos_p, out_stride=32)
+    hid, out = O.mlp_forward(md.mlp, ph[:md.mlp.n_params], enc)
+    dy = np.zeros((npad, 16), np.float32)
+    dy[:n, :4] = (2.0 * (O.h2f(out)[:n, :4] - tgt.cpu().numpy()) / (n * 4)) * 128.0
+    gref, _ = O.mlp_backward(md.mlp, ph[:md.mlp.n_params], enc, hid, out, O.f2h(dy))
+    gm = g[:md.mlp.n_params].cpu().numpy() * 128.0
+    assert np.percentile(rae(gm, gref), 99) < 1e-2
+    # Network and Encoding modules
+    net = T.Network(5, 3, dict(MLP_64x2, n_neurons=32))
+    assert net(torch.rand(300, 5, device="cuda")).shape == (300, 3)
+    enc_m = T.Encoding(3, HASH_ENCODING_SMALL)
+    assert enc_m.n_output_dims == 32 and enc_m(x).shape == (n, 32)
+    clone = pickle.loads(pickle.dumps(model))
+    assert torch.equal(clone(x), y1)
+
+
+def test_golden_fixture():
+    """tests/golden/hotpath_small.npz (made by tests/golden/make_golden.py): the GPU path reproduces the
+    frozen vectors without the oracle library in the loop."""
+    C = tcnn()._C
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hotpath_small.npz"))
+    m = C.create_network_with_input_encoding(3, 4, HASH_ENCODING_SMALL, MLP_64x2)
+    p32 = m.initial_params(1337)
+    assert np.array_equal(p32[:7168].cpu().numpy(), gold["params_fp32"])
+    p32[7168:] *= 1.0e4
+    assert np.array_equal(p32[7168:7168 + 4096].cpu().numpy(), gold["grid_params_first"])
+    p = p32.half()
+    assert int(h_np(p).astype(np.uint64).sum()) == int(gold["params_checksum"][0])
+    x = torch.from_numpy(gold["positions"]).cuda()
+    idx = m.grid_indices(x).cpu().numpy().view(np.uint32)
+    assert np.array_equal(idx[:, 0], gold["indices_level0"]) and np.array_equal(idx[:, 15], gold["indices_level15"])
+    assert int(idx.astype(np.uint64).sum()) == int(gold["indices_checksum"][0])
+    e = C.create_encoding(3, HASH_ENCODING_SMALL)
+    _, enc = e.fwd(x, p[7168:].contiguous())
+    assert np.array_equal(h_np(enc), gold["encoded"])
+    _, y = m.fwd(x, p)
+    torch.cuda.synchronize()
+    assert np.percentile(rae(O.h2f(h_np(y)), O.h2f(gold["output"])), 99) < 3e-3
+
+
+def test_error_behaviour_on_device():
+    C = tcnn()._C
+    m = C.create_network_with_input_encoding(3, 4, HASH_ENCODING_SMALL, MLP_64x2)
+    p = m.initial_params(1).half()
+    with pytest.raises(RuntimeError, match="multiple of 256"):     # object.h:170
+        m.fwd(torch.rand(100, 3, device="cuda"), p)
+    with pytest.raises(RuntimeError, match="wrong size"):
+        m.fwd(torch.rand(256, 2, device="cuda"), p)
+    with pytest.raises(RuntimeError, match="invalid context"):
+        ctx, y = m.fwd(torch.rand(256, 3, device="cuda"), p)          # inference mode: no context
+        m.bwd(ctx, torch.rand(256, 3, device="cuda"), p, y, y)

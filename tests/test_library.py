@@ -1,0 +1,104 @@
+"""The C-ABI shared library: loads without a GPU, exports every symbol include/tcnn_hip.h declares, and its
+host-side logic (config parsing, grid layout, error behaviour) matches the reference.  No compute calls."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    import tinycudann
+    return tinycudann._C
+
+
+def test_library_is_in_tree():
+    assert os.path.dirname(_lib().library_path()) == os.path.join(ROOT, "tiny-cuda-nn_amd", "lib")
+
+
+def test_every_declared_symbol_is_exported():
+    header = open(os.path.join(ROOT, "include", "tcnn_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(tcnn_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 50
+    import ctypes
+    lib = ctypes.CDLL(_lib().library_path())
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, f"declared in include/tcnn_hip.h but not exported: {missing}"
+
+
+def test_free_functions():
+    C = _lib()
+    assert C.batch_size_granularity() == 256                       # common.h:246
+    assert C.default_loss_scale(C.Precision.Fp16) == 128.0         # common.h:243
+    assert C.default_loss_scale(C.Precision.Fp32) == 1.0
+    assert C.preferred_precision() == C.Precision.Fp16
+    assert C.has_networks() and not C.supports_jit_fusion()
+
+
+def test_grid_known_answers_through_c_abi():
+    """reference tests/test_grid.cu:40-71"""
+    C = _lib()
+    e = C.create_encoding(3, {"otype": "Grid", "base_resolution": 32, "log2_hashmap_size": 16, "n_features_per_level": 2,
+                              "n_levels": 20, "otype": "HashGrid", "per_level_scale": 1.5})
+    assert e.n_input_dims() == 3
+    assert e.n_output_dims() == 40
+    assert e.grid_level_n_params(0) == 32 * 32 * 32 and e.grid_level_params_offset(0) == 0
+    assert e.grid_level_n_params(1) == 65536 and e.grid_level_params_offset(1) == 32 * 32 * 32
+    assert e.grid_level_n_params(2) == 65536 and e.grid_level_params_offset(2) == 32 * 32 * 32 + 65536
+    assert e.n_params() == 2555904
+
+
+def test_network_with_input_encoding_layout():
+    from conftest import HASH_ENCODING, MLP_64x2
+    C = _lib()
+    m = C.create_network_with_input_encoding(3, 4, HASH_ENCODING, MLP_64x2)
+    assert m.n_params() == 64 * 32 + 64 * 64 + 16 * 64 + 14229504   # 14 236 672
+    assert m.n_output_dims() == 16                                  # padded width, cpp_api.cu:137
+    hp = m.hyperparams()
+    assert hp["otype"] == "NetworkWithInputEncoding" and hp["network"]["n_neurons"] == 64
+    assert hp["encoding"]["log2_hashmap_size"] == 19 and hp["encoding"]["hash"] == "CoherentPrime"
+    n = C.create_network(5, 3, dict(MLP_64x2, n_neurons=128, n_hidden_layers=4))  # identity encoding padded to 16
+    assert n.n_params() == 128 * 16 + 3 * 128 * 128 + 16 * 128
+    # encoding width is padded to the MLP's alignment of 16 (network_with_input_encoding.h:47): 20*2 = 40 -> 48
+    m2 = C.create_network_with_input_encoding(3, 1, dict(HASH_ENCODING, n_levels=20), MLP_64x2)
+    assert m2.n_params() - C.create_encoding(3, dict(HASH_ENCODING, n_levels=20)).n_params() == 64 * 48 + 64 * 64 + 16 * 64
+
+
+@pytest.mark.parametrize("enc,net,msg", [
+    ({"otype": "HashGrid"}, {"otype": "FullyFusedMLP", "n_neurons": 48}, "only supports 16, 32, 64, and 128 neurons"),
+    ({"otype": "HashGrid"}, {"otype": "FullyFusedMLP", "n_neurons": 64, "n_hidden_layers": 0}, "at least 1 hidden layer"),
+    ({"otype": "HashGrid", "n_features_per_level": 3}, {"n_neurons": 64}, "n_features_per_level must be 1, 2, 4, or 8"),
+    ({"otype": "HashGrid", "n_features": 32, "n_levels": 16}, {"n_neurons": 64}, "may not specify n_features and n_levels"),
+    ({"otype": "Frequency"}, {"n_neurons": 64}, "not found"),
+    ({"otype": "HashGrid"}, {"otype": "Transformer"}, "Invalid network type"),
+])
+def test_config_errors_raise_runtime_error(enc, net, msg):
+    """the reference throws std::runtime_error (-> Python RuntimeError through pybind)"""
+    C = _lib()
+    C.set_log_callback(lambda sev, m: None)
+    try:
+        with pytest.raises(RuntimeError, match=msg):
+            C.create_network_with_input_encoding(3, 4, enc, net)
+    finally:
+        C.set_log_callback(None)
+
+
+def test_log_callback_receives_errors():
+    C = _lib()
+    seen = []
+    C.set_log_callback(lambda sev, m: seen.append((sev, m)))
+    try:
+        with pytest.raises(RuntimeError):
+            C.create_encoding(7, {"otype": "HashGrid"})
+    finally:
+        C.set_log_callback(None)
+    assert seen and seen[-1][0] == C.LogSeverity.Error and "number of input dims" in seen[-1][1]
+
+
+def test_second_order_is_reported_unsupported():
+    C = _lib()
+    e = C.create_encoding(3, {"otype": "HashGrid"})
+    with pytest.raises(RuntimeError, match="not part of"):
+        e.bwd_bwd_input(None, None, None, None, None)

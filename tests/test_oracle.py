@@ -1,0 +1,251 @@
+"""Pins the CPU oracle (oracle/tcnn_oracle.c) against every known answer the reference tree holds for
+the hot path, and checks its internal consistency (finite differences, the reference's invariants).
+Runs without a GPU."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+# ---------------------------------------------------------------- reference known answers
+def test_grid_layout_matches_reference_test_grid_cu():
+    """/root/reference/tests/test_grid.cu:40-71: HashGrid 3-D, L=20, F=2, log2T=16, base 32, scale 1.5."""
+    g = O.grid_init(3, n_levels=20, n_features_per_level=2, log2_hashmap_size=16, base_resolution=32, per_level_scale=1.5)
+    assert g.n_levels * g.n_features_per_level == 40                      # padded_output_width, :55
+    assert g.offsets[1] - g.offsets[0] == 32 * 32 * 32                    # level_n_params(0), :58
+    assert g.offsets[0] == 0                                              # :59
+    assert g.offsets[2] - g.offsets[1] == 65536 and g.offsets[1] == 32768  # :61-62
+    assert g.offsets[3] - g.offsets[2] == 65536 and g.offsets[2] == 32768 + 65536  # :64-65
+    assert g.n_params == 2555904                                          # :70
+
+
+def test_grid_layout_headline_configs():
+    """SURVEY.md appendix A (derived from grid.h:692-737)."""
+    g = O.grid_init(3, 16, 2, 19, 16, 2.0)
+    assert g.offsets[16] == 7114752 and g.n_params == 14229504
+    assert list(g.resolution[:16]) == [16 << i for i in range(16)]
+    assert [g.offsets[i + 1] - g.offsets[i] for i in range(4)] == [4096, 32768, 262144, 524288]
+    g = O.grid_init(3, 16, 2, 19, 16, 1.5)
+    assert list(g.resolution[:16]) == [16, 24, 36, 54, 81, 122, 183, 274, 411, 616, 923, 1384, 2076, 3114, 4671, 7007]
+    assert g.offsets[16] == 6513496
+    g = O.grid_init(2, 16, 2, 15, 16, 1.5)  # data/config_hash.json in 2-D
+    assert g.n_params == 708368
+
+
+def test_hash_constants_and_index():
+    """common_device.h:787-791 (primes) and :847-884 (dense / hashed / wrap-around indexing)."""
+    g = O.grid_init(3, 16, 2, 19, 16, 2.0)
+    import ctypes as C
+    def idx(level, p):
+        return O.lib().orc_grid_index(C.byref(g), level, (C.c_uint32 * 3)(*p))
+    # dense level 0 (res 16): x + 16 y + 256 z, cell coordinate 16 wraps (index % 4096)
+    assert idx(0, (1, 2, 3)) == 1 + 32 + 768
+    assert idx(0, (16, 0, 0)) == 16 and idx(0, (0, 0, 16)) == 0
+    # hashed level 5 (res 512): x*1 ^ y*2654435761 ^ z*805459861 mod 2^19
+    x, y, z = 100, 200, 300
+    h = (x * 1) ^ ((y * 2654435761) & 0xFFFFFFFF) ^ ((z * 805459861) & 0xFFFFFFFF)
+    assert idx(5, (x, y, z)) == h % (1 << 19)
+    # level 12+ : res > MAX_BASES[3] = 0x659 -> always hashed
+    assert g.resolution[7] == 2048 and idx(7, (x, y, z)) == h % (1 << 19)
+
+
+def test_pcg32_known_answer():
+    """pcg32 reference generator demo vector (pcg-random.org pcg32-demo: seed 42, stream 54);
+    dependencies/pcg32/pcg32.h:58-75 is that generator."""
+    r = O.pcg32(42, 54)
+    got = [O.lib().orc_pcg32_next_uint(__import__("ctypes").byref(r)) for _ in range(6)]
+    assert got == [0xa15c02b7, 0x7b47f409, 0xba1d3330, 0x83d2f293, 0xbfa4784b, 0xcbed606e]
+
+
+def test_pcg32_advance_equals_stepping():
+    import ctypes as C
+    a, b = O.pcg32(1337), O.pcg32(1337)
+    for _ in range(1000):
+        O.lib().orc_pcg32_next_uint(C.byref(a))
+    O.lib().orc_pcg32_advance(C.byref(b), C.c_int64(1000))
+    assert (a.state, a.inc) == (b.state, b.inc)
+
+
+def test_seed_seq_matches_libstdcxx():
+    """std::seed_seq{seed}.generate(2 words)[0] (trainer.h:53-56); values produced by g++'s <random>."""
+    expected = {1337: 2150097757, 0: 2061087650, 42: 3788537066, 0xdeadbeef: 4264807581}
+    for s, v in expected.items():
+        assert O.seed_seq_first(s) == v
+
+
+def test_fp16_conversions_match_ieee():
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(100000) * 10.0 ** rng.uniform(-9, 5, 100000)).astype(np.float32)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(O.f2h(x), x.astype(np.float16).view(np.uint16))
+    allh = np.arange(65536, dtype=np.uint16)
+    f, fn = O.h2f(allh), allh.view(np.float16).astype(np.float32)
+    assert np.array_equal(f[~np.isnan(fn)], fn[~np.isnan(fn)])
+
+
+def test_generate_random_uniform_mapping():
+    """random.h:39-65: element idx = i + n_threads*j gets stream position 4*i + j."""
+    import ctypes as C
+    n = 1000
+    rng = O.pcg32(7)
+    out = O.generate_random_uniform(rng, n, 0.0, 1.0)
+    n_threads = ((n + 3) // 4 + 127) // 128 * 128
+    seq = O.pcg32(7)
+    stream = np.array([O.lib().orc_pcg32_next_float(C.byref(seq)) for _ in range(4 * 250)], dtype=np.float32)
+    for i in range(250):
+        for j in range(4):
+            idx = i + n_threads * j
+            if idx < n:
+                assert out[idx] == stream[4 * i + j]
+    ref = O.pcg32(7)
+    O.lib().orc_pcg32_advance(C.byref(ref), C.c_int64(n))
+    assert (rng.state, rng.inc) == (ref.state, ref.inc)
+
+
+# ---------------------------------------------------------------- self-consistency
+def _rand_params(g, rng, amp=0.5):
+    return O.f2h(((rng.random(g.n_params, dtype=np.float32) * 2 - 1) * amp))
+
+
+@pytest.mark.parametrize("interp", [O.INTERP_LINEAR, O.INTERP_SMOOTHSTEP])
+def test_grid_forward_is_interpolation(interp):
+    """At cell corners the interpolation returns the stored entry; weights sum to one."""
+    rng = np.random.default_rng(1)
+    g = O.grid_init(3, 4, 2, 12, 8, 2.0, interpolation=interp)
+    params = _rand_params(g, rng)
+    pos = rng.random((64, 3), dtype=np.float32)
+    idx, w = O.grid_indices(g, pos, with_weights=True)
+    if interp == O.INTERP_LINEAR:
+        assert np.allclose(w.sum(-1), 1.0, atol=1e-6)
+    out = O.h2f(O.grid_forward(g, params, pos))
+    p = O.h2f(params).reshape(-1, 2)
+    for lvl in range(g.n_levels):
+        ref = (w[:, lvl, :, None] * p[g.offsets[lvl] + idx[:, lvl]]).sum(1)
+        assert np.allclose(out[:, 2 * lvl:2 * lvl + 2], ref, atol=4e-3)
+
+
+def test_grid_backward_is_adjoint_of_forward():
+    """<dL_dy, forward(params)> is linear in params: its gradient is what backward scatters."""
+    rng = np.random.default_rng(2)
+    g = O.grid_init(2, 6, 2, 10, 4, 1.7)
+    pos = rng.random((200, 2), dtype=np.float32)
+    dy = O.f2h(rng.standard_normal((200, 12)).astype(np.float32))
+    grad = O.grid_backward(g, pos, dy)
+    idx, w = O.grid_indices(g, pos, with_weights=True)
+    ref = np.zeros((g.n_params // 2, 2))
+    dyf = O.h2f(dy).astype(np.float64)
+    wq = O.h2f(O.f2h(w)).astype(np.float64)
+    for lvl in range(g.n_levels):
+        for c in range(4):
+            np.add.at(ref, g.offsets[lvl] + idx[:, lvl, c], wq[:, lvl, c, None] * dyf[:, 2 * lvl:2 * lvl + 2])
+    assert np.allclose(grad.reshape(-1, 2), ref, rtol=2e-3, atol=5e-3)  # each contribution is rounded to half (grid.h:254)
+
+
+def test_grid_input_gradient_finite_difference():
+    rng = np.random.default_rng(3)
+    g = O.grid_init(3, 2, 2, 14, 4, 1.5)  # two coarse dense levels (scale 3 and 5): wide cells
+    params = _rand_params(g, rng)
+    cand = rng.random((4000, 3), dtype=np.float32)
+    ok = np.ones(len(cand), bool)
+    for lvl in range(g.n_levels):
+        fr = np.modf(cand * g.scale[lvl] + 0.5)[0]
+        ok &= np.all((fr > 0.2) & (fr < 0.8), axis=1)
+    pos = np.ascontiguousarray(cand[ok][:64])
+    assert len(pos) >= 16
+    _, dy_dx = O.grid_forward(g, params, pos, want_dy_dx=True)
+    eps = np.float32(1.0 / 128)  # scale * eps <= 0.04: stays inside the cell, far above fp16 output noise
+    for d in range(3):
+        p1, p0 = pos.copy(), pos.copy()
+        p1[:, d] += eps
+        p0[:, d] -= eps
+        fd = (O.h2f(O.grid_forward(g, params, p1)) - O.h2f(O.grid_forward(g, params, p0))) / (2 * eps)
+        assert np.allclose(dy_dx[:, :, d], fd, atol=0.05, rtol=0.02)
+
+
+def test_mlp_backward_finite_difference():
+    rng = np.random.default_rng(4)
+    m = O.mlp_init(16, 16, 3, 2)
+    p32 = O.mlp_init_params(m, O.pcg32(5))
+    ph = O.f2h(p32)
+    x = O.f2h(rng.random((256, 16), dtype=np.float32))
+    hid, out = O.mlp_forward(m, ph, x)
+    dy = np.zeros((256, 16), np.float32)
+    dy[:, :3] = rng.standard_normal((256, 3)).astype(np.float32)
+    dyh = O.f2h(dy)
+    grad, _ = O.mlp_backward(m, ph, x, hid, out, dyh)
+
+    def objective(p):
+        _, o = O.mlp_forward(m, O.f2h(p), x)
+        return float((O.h2f(o).astype(np.float64) * O.h2f(dyh)).sum())
+
+    pf = O.h2f(ph)
+    worst = 0.0
+    for k in rng.choice(m.n_params, 24, replace=False):
+        step = 2.0 ** -6  # exactly representable around |w| ~ 0.3 in fp16
+        a, b = pf.copy(), pf.copy()
+        a[k] += step
+        b[k] -= step
+        a[k], b[k] = O.h2f(O.f2h(a[k:k + 1]))[0], O.h2f(O.f2h(b[k:k + 1]))[0]
+        fd = (objective(a) - objective(b)) / (a[k] - b[k])
+        worst = max(worst, abs(fd - grad[k]) / (abs(grad[k]) + 2.0))
+    assert worst < 0.15  # fp16 activations + ReLU kinks: loose, but catches a wrong transpose / mask
+
+
+def test_mlp_invariants():
+    """The reference's own checks (tests/test_common.h:150-165): padded output rows of the weight matrix
+    only feed padded outputs; Accumulate == 2 x Overwrite; inference == forward."""
+    rng = np.random.default_rng(6)
+    m = O.mlp_init(32, 64, 4, 2)
+    ph = O.f2h(O.mlp_init_params(m, O.pcg32(1337)))
+    x = O.f2h(rng.random((256, 32), dtype=np.float32))
+    hid, out = O.mlp_forward(m, ph, x)
+    dy = O.f2h((rng.standard_normal((256, 16)) * (np.arange(16) < 4)).astype(np.float32))
+    g1, _ = O.mlp_backward(m, ph, x, hid, out, dy)
+    off_out = 64 * 32 + 64 * 64
+    assert np.all(g1[off_out + 4 * 64:] == 0)  # rows of padded outputs get no gradient
+    import ctypes as C
+    g2 = g1.copy()
+    O.lib().orc_mlp_backward(C.byref(m), O._p(ph), O._p(x), O._p(hid), O._p(out), O._p(dy), C.c_uint32(256), O._p(g2), None)
+    assert np.allclose(g2, 2 * g1)
+    # fp16-accumulate emulation brackets the fp32 result within the reference's own 1e-2 tolerance band
+    _, out16 = O.mlp_forward(m, ph, x, accum_fp16=True)
+    a, b = O.h2f(out)[:, :4], O.h2f(out16)[:, :4]
+    assert np.percentile(np.abs(a - b) / (0.5 * (np.abs(a) + np.abs(b)) + np.abs(a).mean() * 1e-2), 99) < 5e-2
+
+
+def test_loss_and_adam_formulas():
+    rng = np.random.default_rng(7)
+    pred = O.f2h(rng.standard_normal((256, 16)).astype(np.float32))
+    tgt = rng.standard_normal((256, 4)).astype(np.float32)
+    v, gr = O.loss(O.LOSS_RELATIVE_L2, pred, tgt, 4)
+    p = O.h2f(pred)[:, :4].astype(np.float64)
+    d = p - tgt
+    assert np.allclose(v[:, :4], d * d / (p * p + 0.01) / 1024, rtol=1e-5)
+    assert np.all(v[:, 4:] == 0) and np.all(gr[:, 4:] == 0)
+    assert np.allclose(O.h2f(gr)[:, :4], 128 * 2 * d / (p * p + 0.01) / 1024, rtol=2e-3, atol=1e-7)
+    # Adam: first step moves every touched weight by ~lr; zero-gradient hash entries are skipped
+    h = O.adam_defaults(learning_rate=1e-2, beta2=0.99, epsilon=1e-15, l2_reg=1e-6)
+    n, nm = 512, 256
+    w32 = rng.standard_normal(n).astype(np.float32)
+    w0 = w32.copy()
+    w16 = O.f2h(w32)
+    g = (rng.standard_normal(n) * 10).astype(np.float32)
+    g[300:400] = 0
+    gh = O.f2h(g)
+    m1, m2, st = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint32)
+    O.adam_step(h, nm, 128.0, 1, w32, w16, gh, m1, m2, st)
+    assert np.all(w32[300:400] == w0[300:400]) and np.all(st[300:400] == 0)
+    moved = np.r_[0:300, 400:512]
+    assert np.allclose(np.abs(w32[moved] - w0[moved]), 1e-2, rtol=1e-3)
+    assert np.all(st[moved] == 1)
+
+
+def test_training_reduces_loss():
+    rng = np.random.default_rng(8)
+    g = O.grid_init(3, 8, 2, 12, 4, 1.5)
+    md = O.model_init(3, 4, g, 32, 2, O.LOSS_RELATIVE_L2, O.adam_defaults(learning_rate=1e-2, beta2=0.99, epsilon=1e-15, l2_reg=1e-6))
+    st = O.TrainState(md, O.model_init_params(md, 1337))
+    pos = rng.random((2048, 3), dtype=np.float32)
+    tgt = np.stack([np.sin(6.28 * (c + 1) * pos[:, 0]) * np.cos(6.28 * pos[:, 1]) * 0.5 + 0.5 for c in range(4)], 1).astype(np.float32)
+    losses = [O.training_step(st, pos, tgt) for _ in range(30)]
+    assert losses[-1] < 0.5 * losses[0]

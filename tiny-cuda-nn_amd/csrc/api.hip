@@ -1,0 +1,1057 @@
+// api.hip -- host-side object layer (encoding / network / NetworkWithInputEncoding / Trainer) and
+// the C ABI declared in include/tcnn_hip.h.  Mirrors the behaviour of the reference's
+//   src/cpp_api.cu:72-174 (type-erased Module), include/tiny-cuda-nn/config.h:46-63,
+//   trainer.h:51-503, network_with_input_encoding.h:55-130, grid.h:673-737/1725-1852,
+//   src/network.cu:51-138
+// for the HashGrid + FullyFusedMLP hot path only.  Everything heavy happens in the kernel files.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/tcnn_hip.h"
+#include "elementwise_kernels.h"
+#include "grid_kernels.h"
+#include "json_mini.h"
+#include "mlp_kernels.h"
+
+namespace tcnn_hip {
+
+#define HIP_CHECK(x)                                                                                        \
+	do {                                                                                                    \
+		hipError_t e_ = (x);                                                                                \
+		if (e_ != hipSuccess) throw std::runtime_error(std::string(#x " failed: ") + hipGetErrorString(e_)); \
+	} while (0)
+
+// ------------------------------------------------------------------------------------------------
+// logging (common_host.h:46-69) and error state
+// ------------------------------------------------------------------------------------------------
+static void (*g_log_callback)(int, const char*) = nullptr;
+static thread_local std::string g_last_error;
+
+static void log_message(int severity, const std::string& msg) {
+	if (g_log_callback) {
+		g_log_callback(severity, msg.c_str());
+	} else if (severity == TCNN_LOG_WARNING || severity == TCNN_LOG_ERROR) {
+		fprintf(stderr, "tiny-cuda-nn_amd %s: %s\n", severity == TCNN_LOG_WARNING ? "warning" : "error", msg.c_str());
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// stream-keyed scratch cache (stands where the reference's per-stream GPUMemoryArena stands,
+// gpu_memory.h:405-700): blocks are recycled per stream, so steady-state steps allocate nothing
+// (a precondition for hipGraph capture) and a recycled block is only ever reused in stream order.
+// ------------------------------------------------------------------------------------------------
+class ScratchCache {
+public:
+	static void* acquire(hipStream_t stream, size_t bytes, size_t* granted) {
+		bytes = next_multiple(bytes ? bytes : (size_t)1, (size_t)256);
+		{
+			std::lock_guard<std::mutex> lock(mutex());
+			auto& fl = lists()[stream];
+			auto it = fl.lower_bound(bytes);
+			if (it != fl.end() && it->first <= 2 * bytes) {
+				void* p = it->second;
+				*granted = it->first;
+				fl.erase(it);
+				return p;
+			}
+		}
+		void* p = nullptr;
+		HIP_CHECK(hipMalloc(&p, bytes));
+		*granted = bytes;
+		return p;
+	}
+	static void release(hipStream_t stream, void* p, size_t bytes) {
+		std::lock_guard<std::mutex> lock(mutex());
+		lists()[stream].emplace(bytes, p);
+	}
+	static void free_all() {
+		std::lock_guard<std::mutex> lock(mutex());
+		(void)hipDeviceSynchronize();
+		for (auto& kv : lists())
+			for (auto& b : kv.second) (void)hipFree(b.second);
+		lists().clear();
+	}
+
+private:
+	static std::mutex& mutex() {
+		static std::mutex m;
+		return m;
+	}
+	static std::map<hipStream_t, std::multimap<size_t, void*>>& lists() {
+		static std::map<hipStream_t, std::multimap<size_t, void*>> l;
+		return l;
+	}
+};
+
+struct Scratch {
+	void* ptr = nullptr;
+	size_t bytes = 0;
+	hipStream_t stream = nullptr;
+	Scratch() = default;
+	Scratch(hipStream_t s, size_t n_bytes) : stream(s) { ptr = ScratchCache::acquire(s, n_bytes, &bytes); }
+	Scratch(const Scratch&) = delete;
+	Scratch& operator=(const Scratch&) = delete;
+	Scratch(Scratch&& o) noexcept { *this = std::move(o); }
+	Scratch& operator=(Scratch&& o) noexcept {
+		reset();
+		ptr = o.ptr;
+		bytes = o.bytes;
+		stream = o.stream;
+		o.ptr = nullptr;
+		return *this;
+	}
+	~Scratch() { reset(); }
+	void reset() {
+		if (ptr) ScratchCache::release(stream, ptr, bytes);
+		ptr = nullptr;
+	}
+	template <typename T>
+	T* as() const { return (T*)ptr; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// optional per-stage timing with HIP events recorded on the stream the kernels are launched on
+// (bench.py's roofline leg; off by default -- no events are recorded unless a trainer enables it)
+// ------------------------------------------------------------------------------------------------
+enum Stage : int {
+	STAGE_GRID_FWD = 0,
+	STAGE_MLP_FWD,
+	STAGE_LOSS,
+	STAGE_MLP_BWD,       // weight transpose + fused backward + finalize
+	STAGE_GRID_BWD_ZERO, // gradient memset (grid.h:865-867)
+	STAGE_GRID_BWD,      // scatter kernels
+	STAGE_ADAM,
+	N_STAGES
+};
+static const char* const STAGE_NAMES[N_STAGES] = {"grid_forward", "mlp_forward", "loss", "mlp_backward", "grid_backward_zero", "grid_backward", "adam"};
+
+struct Profiler {
+	int only_stage = -1;  // -1: all stages
+	std::vector<hipEvent_t> pool;
+	size_t next = 0;
+	struct Span {
+		int stage;
+		hipEvent_t a, b;
+	};
+	std::vector<Span> spans;
+	double total_ms[N_STAGES] = {};
+	uint64_t count[N_STAGES] = {};
+
+	hipEvent_t get() {
+		if (next == pool.size()) {
+			hipEvent_t e;
+			HIP_CHECK(hipEventCreate(&e));
+			pool.push_back(e);
+		}
+		return pool[next++];
+	}
+	void collect() {
+		for (auto& s : spans) {
+			HIP_CHECK(hipEventSynchronize(s.b));
+			float ms = 0.0f;
+			HIP_CHECK(hipEventElapsedTime(&ms, s.a, s.b));
+			total_ms[s.stage] += ms;
+			count[s.stage]++;
+		}
+		spans.clear();
+		next = 0;
+	}
+	~Profiler() {
+		for (auto e : pool) (void)hipEventDestroy(e);
+	}
+};
+static thread_local Profiler* g_profiler = nullptr;
+
+struct ProfScope {
+	hipStream_t stream;
+	int stage;
+	hipEvent_t a = nullptr;
+	ProfScope(hipStream_t s, int st) : stream(s), stage(st) {
+		if (g_profiler && (g_profiler->only_stage < 0 || g_profiler->only_stage == st)) {
+			a = g_profiler->get();
+			HIP_CHECK(hipEventRecord(a, stream));
+		}
+	}
+	~ProfScope() {
+		if (a) {
+			hipEvent_t b = g_profiler->get();
+			(void)hipEventRecord(b, stream);
+			g_profiler->spans.push_back({stage, a, b});
+		}
+	}
+};
+struct ProfilerGuard {
+	explicit ProfilerGuard(Profiler* p) { g_profiler = p; }
+	~ProfilerGuard() { g_profiler = nullptr; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// model description
+// ------------------------------------------------------------------------------------------------
+static uint32_t powi(uint32_t base, uint32_t exponent) {
+	uint32_t r = 1;
+	for (uint32_t i = 0; i < exponent; ++i) r *= base;
+	return r;
+}
+
+static const char* to_string(GridType t) { return t == GridType::Hash ? "Hash" : t == GridType::Dense ? "Dense" : "Tiled"; }
+static const char* to_string(InterpolationType t) {
+	return t == InterpolationType::Nearest ? "Nearest" : t == InterpolationType::Linear ? "Linear" : "Smoothstep";
+}
+static const char* to_string(Activation a) { return a == Activation::ReLU ? "ReLU" : "None"; }
+
+static GridType string_to_grid_type(const std::string& s) {  // common_host.cu:112-122
+	if (equals_case_insensitive(s, "Hash")) return GridType::Hash;
+	if (equals_case_insensitive(s, "Dense")) return GridType::Dense;
+	if (equals_case_insensitive(s, "Tiled") || equals_case_insensitive(s, "Tile")) return GridType::Tiled;
+	throw std::runtime_error("Invalid grid type: " + s);
+}
+static InterpolationType string_to_interpolation_type(const std::string& s) {  // common_host.cu:160-170
+	if (equals_case_insensitive(s, "Nearest")) return InterpolationType::Nearest;
+	if (equals_case_insensitive(s, "Linear")) return InterpolationType::Linear;
+	if (equals_case_insensitive(s, "Smoothstep")) return InterpolationType::Smoothstep;
+	throw std::runtime_error("Invalid interpolation type: " + s);
+}
+static Activation string_to_activation(const std::string& s) {  // common_host.cu:70-96
+	if (equals_case_insensitive(s, "None")) return Activation::None;
+	if (equals_case_insensitive(s, "ReLU")) return Activation::ReLU;
+	throw std::runtime_error("Activation '" + s + "' is not available in this build (supported: None, ReLU).");
+}
+
+struct EncodingDesc {
+	bool is_grid = false;
+	// grid (grid.h:673-737)
+	GridMeta grid = {};
+	uint32_t log2_hashmap_size = 19, base_resolution = 16;
+	float per_level_scale = 2.0f;
+	// identity (identity.h:88-93)
+	float id_scale = 1.0f, id_offset = 0.0f;
+	uint32_t n_dims = 0;
+	uint32_t n_output_dims = 0;  // before padding
+	uint32_t n_params = 0;
+	uint32_t padded_output_width = 0;
+
+	uint32_t required_output_alignment() const { return is_grid ? grid.n_feat : 1u; }  // grid.h:1066-1068
+	void set_alignment(uint32_t alignment) {  // encoding.h:70-72
+		uint32_t a = alignment, b = required_output_alignment();
+		uint32_t x = a, y = b;
+		while (y) {
+			uint32_t t = x % y;
+			x = y;
+			y = t;
+		}
+		const uint32_t l = a / x * b;
+		padded_output_width = next_multiple(n_output_dims, l);
+	}
+
+	Json hyperparams() const {
+		Json j = Json::object();
+		if (is_grid) {  // grid.h:1115-1132
+			j["otype"] = "Grid";
+			j["type"] = to_string((GridType)grid.grid_type);
+			j["n_levels"] = grid.n_levels;
+			j["n_features_per_level"] = grid.n_feat;
+			j["base_resolution"] = base_resolution;
+			j["per_level_scale"] = per_level_scale;
+			j["interpolation"] = to_string((InterpolationType)grid.interp);
+			j["hash"] = "CoherentPrime";
+			if ((GridType)grid.grid_type == GridType::Hash) j["log2_hashmap_size"] = log2_hashmap_size;
+		} else {
+			j["otype"] = "Identity";
+			j["scale"] = id_scale;
+			j["offset"] = id_offset;
+		}
+		return j;
+	}
+};
+
+static EncodingDesc create_grid_encoding(uint32_t n_dims, const Json& enc) {  // grid.h:1725-1852
+	EncodingDesc e;
+	e.is_grid = true;
+	e.n_dims = n_dims;
+	const std::string hash = enc.value("hash", "CoherentPrime");
+	if (!equals_case_insensitive(hash, "CoherentPrime")) throw std::runtime_error("GridEncoding: compiled without " + hash + " hash support.");
+	const uint32_t F = enc.value("n_features_per_level", 2u);
+	if (F != 1 && F != 2 && F != 4 && F != 8) throw std::runtime_error("GridEncoding: n_features_per_level must be 1, 2, 4, or 8.");
+	const uint32_t log2_hashmap_size = enc.value("log2_hashmap_size", 19u);
+	const std::string otype = enc.value("otype", "Grid");
+	const std::string default_type = equals_case_insensitive(otype, "TiledGrid") ? "Tiled" : (equals_case_insensitive(otype, "DenseGrid") ? "Dense" : "Hash");
+	uint32_t n_features;
+	if (enc.contains("n_features") || enc.contains("n_grid_features")) {
+		n_features = (uint32_t)(enc.contains("n_features") ? enc["n_features"] : enc["n_grid_features"]).as_number();
+		if (enc.contains("n_levels")) throw std::runtime_error("GridEncoding: may not specify n_features and n_levels simultaneously (one determines the other)");
+	} else {
+		n_features = F * enc.value("n_levels", 16u);
+	}
+	const uint32_t n_levels = n_features / F;
+	const GridType grid_type = string_to_grid_type(enc.value("type", default_type));
+	const uint32_t base_resolution = enc.value("base_resolution", 16u);
+	const float default_scale = grid_type == GridType::Dense ? std::exp(std::log(256.0f / (float)base_resolution) / (float)(n_levels - 1)) : 2.0f;
+	const float per_level_scale = enc.value("per_level_scale", default_scale);
+	if (enc.value("stochastic_interpolation", false)) throw std::runtime_error("GridEncoding: stochastic_interpolation is not available in this build.");
+	const InterpolationType interp = string_to_interpolation_type(enc.value("interpolation", "Linear"));
+	if (n_dims < 2 || n_dims > 4) throw std::runtime_error("GridEncoding: number of input dims must be 2, 3 or 4.");
+	if (n_levels > MAX_N_LEVELS) throw std::runtime_error("GridEncoding: m_n_levels=" + std::to_string(n_levels) + " must be at most MAX_N_LEVELS=" + std::to_string(MAX_N_LEVELS));
+	if (n_features % F != 0) throw std::runtime_error("GridEncoding: n_features=" + std::to_string(n_features) + " must be a multiple of N_FEATURES_PER_LEVEL=" + std::to_string(F));
+
+	GridMeta& g = e.grid;
+	g.n_dims = n_dims;
+	g.n_levels = n_levels;
+	g.n_feat = F;
+	g.grid_type = (uint32_t)grid_type;
+	g.interp = (uint32_t)interp;
+	g.max_level = 1.0f;
+	// grid.h:699-727; the scale / resolution table is computed here once (fp32, same expressions as
+	// common_device.h:886-895) and handed to the kernels, see GridMeta.
+	const float log2_per_level_scale = std::log2(per_level_scale);
+	uint32_t offset = 0;
+	for (uint32_t i = 0; i < n_levels; ++i) {
+		const float scale = exp2f((float)i * log2_per_level_scale) * (float)base_resolution - 1.0f;
+		const uint32_t resolution = (uint32_t)ceilf(scale) + 1;
+		g.scale[i] = scale;
+		g.resolution[i] = resolution;
+		const uint32_t max_params = std::numeric_limits<uint32_t>::max() / 2;
+		uint32_t params_in_level = std::pow((float)resolution, (float)n_dims) > (float)max_params ? max_params : powi(resolution, n_dims);
+		params_in_level = next_multiple(params_in_level, 8u);
+		if (grid_type == GridType::Tiled) {
+			params_in_level = std::min(params_in_level, powi(base_resolution, n_dims));
+		} else if (grid_type == GridType::Hash) {
+			params_in_level = std::min(params_in_level, 1u << log2_hashmap_size);
+		}
+		g.offset[i] = offset;
+		offset += params_in_level;
+		log_message(TCNN_LOG_DEBUG, "GridEncoding at level " + std::to_string(i) + ": resolution=" + std::to_string(resolution) +
+		                                " params_in_level=" + std::to_string(params_in_level));
+	}
+	g.offset[n_levels] = offset;
+	e.n_params = offset * F;
+	e.n_output_dims = n_features;
+	e.padded_output_width = n_features;
+	e.log2_hashmap_size = log2_hashmap_size;
+	e.base_resolution = base_resolution;
+	e.per_level_scale = per_level_scale;
+	return e;
+}
+
+static EncodingDesc create_encoding_desc(uint32_t n_dims, const Json& enc, uint32_t alignment) {  // encoding.cu:131-145
+	const std::string name = enc.value("otype", "OneBlob");
+	EncodingDesc e;
+	if (equals_case_insensitive(name, "Grid") || equals_case_insensitive(name, "HashGrid") || equals_case_insensitive(name, "DenseGrid") ||
+	    equals_case_insensitive(name, "TiledGrid")) {
+		e = create_grid_encoding(n_dims, enc);
+	} else if (equals_case_insensitive(name, "Identity")) {
+		e.is_grid = false;
+		e.n_dims = n_dims;
+		e.id_scale = enc.value("scale", 1.0f);
+		e.id_offset = enc.value("offset", 0.0f);
+		e.n_output_dims = n_dims;
+		e.padded_output_width = n_dims;
+	} else {
+		throw std::runtime_error("Encoding '" + name + "' not found (this build provides Grid/HashGrid/DenseGrid/TiledGrid and Identity)");
+	}
+	if (alignment > 0) e.set_alignment(alignment);
+	return e;
+}
+
+struct NetworkDesc {
+	MlpMeta mlp = {};
+	uint32_t n_output_dims = 0;
+	uint32_t n_hidden_layers = 0;
+	std::string otype;
+	Json hyperparams() const {  // fully_fused_mlp.h:139-147
+		Json j = Json::object();
+		j["otype"] = "FullyFusedMLP";
+		j["activation"] = to_string((Activation)mlp.activation);
+		j["output_activation"] = "None";
+		j["n_neurons"] = mlp.width;
+		j["n_hidden_layers"] = n_hidden_layers;
+		return j;
+	}
+};
+
+static NetworkDesc create_network_desc(uint32_t n_input_dims, uint32_t n_output_dims, const Json& net) {  // network.cu:51-138
+	const std::string otype = net.value("otype", "MLP");
+	const bool known = equals_case_insensitive(otype, "MegakernelMLP") || equals_case_insensitive(otype, "FullyFusedMLP") ||
+	                   equals_case_insensitive(otype, "MLP") || equals_case_insensitive(otype, "CutlassMLP");
+	if (!known) throw std::runtime_error("Invalid network type: " + otype);
+	NetworkDesc d;
+	d.otype = otype;
+	const uint32_t n_neurons = net.value("n_neurons", 128u);
+	if (n_neurons != 16 && n_neurons != 32 && n_neurons != 64 && n_neurons != 128) {
+		throw std::runtime_error("FullyFusedMLP only supports 16, 32, 64, and 128 neurons, but got " + std::to_string(n_neurons) +
+		                         ". (CutlassMLP's arbitrary widths are not part of this build.)");
+	}
+	d.n_hidden_layers = net.value("n_hidden_layers", 5u);
+	if (d.n_hidden_layers == 0) throw std::runtime_error("FullyFusedMLP requires at least 1 hidden layer (3 layers in total).");
+	const Activation act = string_to_activation(net.value("activation", "ReLU"));
+	const std::string out_act = net.value("output_activation", "None");
+	if (!equals_case_insensitive(out_act, "None")) throw std::runtime_error("output_activation '" + out_act + "' is not available in this build (supported: None).");
+	d.n_output_dims = n_output_dims;
+	d.mlp.in_width = n_input_dims;
+	d.mlp.width = n_neurons;
+	d.mlp.padded_out = next_multiple(n_output_dims, 16u);  // fully_fused_mlp.cu:656
+	d.mlp.n_hidden_matmuls = d.n_hidden_layers - 1;
+	d.mlp.activation = (uint32_t)act;
+	if (d.mlp.padded_out != 16) throw std::runtime_error("FullyFusedMLP: more than 16 output dimensions are not supported by the fused kernels of this build.");
+	if (n_input_dims % 16 != 0 || n_input_dims > MLP_MAX_IN_WIDTH) {
+		throw std::runtime_error("FullyFusedMLP: input width " + std::to_string(n_input_dims) + " must be a multiple of 16 and at most " + std::to_string(MLP_MAX_IN_WIDTH));
+	}
+	return d;
+}
+
+// A NetworkWithInputEncoding (network_with_input_encoding.h:40-130) or a bare encoding.
+struct Model {
+	uint32_t n_input_dims = 0;
+	EncodingDesc enc;
+	bool has_network = false;
+	NetworkDesc net;
+	std::string hyper_json;
+
+	size_t n_mlp_params() const { return has_network ? net.mlp.n_params() : 0; }
+	size_t n_params() const { return n_mlp_params() + enc.n_params; }  // network first, then encoding (:115-122)
+	uint32_t padded_output_width() const { return has_network ? net.mlp.padded_out : enc.padded_output_width; }
+	uint32_t output_width() const { return has_network ? net.n_output_dims : enc.padded_output_width; }
+	std::string name() const { return has_network ? "NetworkWithInputEncoding" : (enc.is_grid ? "GridEncoding" : "IdentityEncoding"); }
+
+	void finish() {
+		Json j = Json::object();
+		if (has_network) {
+			j["otype"] = "NetworkWithInputEncoding";
+			j["encoding"] = enc.hyperparams();
+			j["network"] = net.hyperparams();
+			hyper_json = j.dump();
+		} else {
+			hyper_json = enc.hyperparams().dump();
+		}
+	}
+
+	// network_with_input_encoding.h:124-130 + fully_fused_mlp.cu:868-893 + grid.h:1076-1079
+	void initialize_params(hipStream_t stream, Pcg32& rng, float* params_full_precision, float scale) const {
+		if (has_network) {
+			std::vector<float> host(n_mlp_params());
+			float* p = host.data();
+			auto xavier = [&](uint32_t rows, uint32_t cols) {  // gpu_matrix.h:292-307
+				const float s = scale * std::sqrt(6.0f / (float)(rows + cols));
+				for (size_t i = 0; i < (size_t)rows * cols; ++i) {
+					float t = rng.next_float() * 2.0f;
+					t = t * s;
+					p[i] = t - s;
+				}
+				p += (size_t)rows * cols;
+			};
+			xavier(net.mlp.width, net.mlp.in_width);
+			for (uint32_t i = 0; i < net.mlp.n_hidden_matmuls; ++i) xavier(net.mlp.width, net.mlp.width);
+			xavier(net.mlp.padded_out, net.mlp.width);
+			HIP_CHECK(hipMemcpyAsync(params_full_precision, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+			HIP_CHECK(hipStreamSynchronize(stream));
+		}
+		if (enc.n_params > 0) {
+			generate_random_uniform(stream, rng, enc.n_params, params_full_precision + n_mlp_params(), -1e-4f * scale, 1e-4f * scale);
+		}
+	}
+};
+
+static void check_batch(uint32_t n) {
+	if (n % BATCH_SIZE_GRANULARITY != 0) {  // object.h:170, 217, 298
+		throw std::runtime_error("Batch size " + std::to_string(n) + " must be a multiple of " + std::to_string(BATCH_SIZE_GRANULARITY) + ".");
+	}
+}
+
+struct ForwardCtx {
+	hipStream_t stream = nullptr;
+	uint32_t n = 0;
+	Scratch enc;     // half, feature-major [enc.padded][n]   (network_with_input_encoding.h:76)
+	Scratch hidden;  // half [n_hidden][n][width]             (fully_fused_mlp.cu:841-854)
+	Scratch dy_dx;   // fp32 [(k*n + i)*D + d]                (grid.h:783-785)
+};
+
+// Encoding forward into a feature-major (SoA) or sample-major (AoS) half matrix.
+static void encoding_forward(hipStream_t stream, const Model& md, uint32_t n, const float* input, const half_t* enc_params, half_t* out,
+                             bool soa, float* dy_dx) {
+	const EncodingDesc& e = md.enc;
+	const uint32_t stride_k = soa ? n : 1u, stride_i = soa ? 1u : e.padded_output_width;
+	ProfScope prof(stream, STAGE_GRID_FWD);
+	if (e.is_grid) {
+		GridIO io = {input, md.n_input_dims, 1u, n, stride_k, stride_i};
+		grid_forward(stream, e.grid, io, enc_params, out, dy_dx);
+		const uint32_t n_to_pad = e.padded_output_width - e.n_output_dims;
+		if (n_to_pad > 0) {  // grid.h:757-766: padded dims are zero
+			if (soa) {
+				HIP_CHECK(hipMemsetAsync(out + (size_t)e.n_output_dims * n, 0, (size_t)n_to_pad * n * sizeof(half_t), stream));
+			} else {
+				HIP_CHECK(hipMemset2DAsync(out + e.n_output_dims, (size_t)e.padded_output_width * sizeof(half_t), 0, (size_t)n_to_pad * sizeof(half_t), n, stream));
+			}
+		}
+	} else {
+		identity_forward(stream, n, e.n_dims, e.padded_output_width, e.id_scale, e.id_offset, input, md.n_input_dims, 1u, out, stride_k, stride_i);
+	}
+}
+
+// NetworkWithInputEncoding::forward_impl / inference_mixed_precision_impl (:60-81).  ctx == nullptr: inference.
+static void model_forward(hipStream_t stream, const Model& md, uint32_t n, const float* input, half_t* output, const half_t* params,
+                          ForwardCtx* ctx, bool prepare_input_gradients) {
+	check_batch(n);
+	if (n == 0) return;
+	if (ctx) {
+		ctx->stream = stream;
+		ctx->n = n;
+	}
+	float* dy_dx = nullptr;
+	if (ctx && prepare_input_gradients && md.enc.is_grid) {
+		ctx->dy_dx = Scratch(stream, (size_t)md.enc.n_output_dims * n * md.n_input_dims * sizeof(float));
+		dy_dx = ctx->dy_dx.as<float>();
+	}
+	if (!md.has_network) {
+		encoding_forward(stream, md, n, input, params, output, /*soa=*/false, dy_dx);
+		return;
+	}
+	Scratch enc_local;
+	Scratch& enc = ctx ? ctx->enc : enc_local;
+	enc = Scratch(stream, (size_t)md.enc.padded_output_width * n * sizeof(half_t));
+	encoding_forward(stream, md, n, input, params + md.n_mlp_params(), enc.as<half_t>(), /*soa=*/true, dy_dx);
+	half_t* hidden = nullptr;
+	if (ctx) {
+		ctx->hidden = Scratch(stream, (size_t)md.net.n_hidden_layers * n * md.net.mlp.width * sizeof(half_t));
+		hidden = ctx->hidden.as<half_t>();
+	}
+	ProfScope prof(stream, STAGE_MLP_FWD);
+	mlp_forward(stream, md.net.mlp, n, params, enc.as<half_t>(), hidden, output);
+}
+
+__global__ void k_add_f32_to_f16(size_t n, const float* __restrict__ in, half_t* __restrict__ out) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = (half_t)((float)out[i] + in[i]);
+}
+
+// NetworkWithInputEncoding::backward_impl (:83-113) / GridEncodingTemplated::backward_impl (grid.h:817-908)
+static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const half_t* dL_doutput,
+                           half_t* dL_dparams, const float* input, const half_t* params, int gradient_mode, uint32_t lds_level_budget) {
+	check_batch(n);
+	if (n == 0) return;
+	if (ctx.n != n) throw std::runtime_error("backward: batch size does not match the forward context");
+	const bool want_grads = gradient_mode != TCNN_GRADIENT_IGNORE && dL_dparams != nullptr;
+	const bool accumulate = gradient_mode == TCNN_GRADIENT_ACCUMULATE;
+	const EncodingDesc& e = md.enc;
+	if (!want_grads && !dL_dinput) return;
+
+	const half_t* dL_denc = dL_doutput;  // bare encoding: gradient of the encoding output, sample-major
+	uint32_t stride_k = 1u, stride_i = e.padded_output_width;
+	Scratch denc;
+	if (md.has_network) {
+		const bool need_denc = (want_grads && e.n_params > 0) || dL_dinput;
+		ProfScope prof(stream, STAGE_MLP_BWD);
+		Scratch params_t(stream, md.n_mlp_params() * sizeof(half_t));
+		mlp_transpose_weights(stream, md.net.mlp, params, params_t.as<half_t>());
+		const uint32_t n_partials = mlp_backward_n_partials(md.net.mlp, n);
+		Scratch partials;
+		if (want_grads) partials = Scratch(stream, (size_t)n_partials * md.n_mlp_params() * sizeof(float));
+		if (need_denc) denc = Scratch(stream, (size_t)e.padded_output_width * n * sizeof(half_t));
+		mlp_backward(stream, md.net.mlp, n, params_t.as<half_t>(), ctx.enc.as<half_t>(), ctx.hidden.as<half_t>(), dL_doutput,
+		             need_denc ? denc.as<half_t>() : nullptr, want_grads ? partials.as<float>() : nullptr);
+		if (want_grads) mlp_finalize_gradients(stream, (uint32_t)md.n_mlp_params(), n_partials, partials.as<float>(), dL_dparams, accumulate);
+		if (!need_denc) return;
+		dL_denc = denc.as<half_t>();
+		stride_k = n;
+		stride_i = 1u;
+	}
+
+	if (e.is_grid) {
+		GridIO io = {input, md.n_input_dims, 1u, n, stride_k, stride_i};
+		if (want_grads && e.n_params > 0) {
+			half_t* grid_grads = dL_dparams + md.n_mlp_params();
+			if (e.grid.n_feat == 1) {  // grad_t == float (grid.h:660-671, 855-863, 890-894)
+				Scratch tmp(stream, (size_t)e.n_params * sizeof(float));
+				HIP_CHECK(hipMemsetAsync(tmp.ptr, 0, (size_t)e.n_params * sizeof(float), stream));
+				grid_backward(stream, e.grid, io, dL_denc, nullptr, tmp.as<float>(), lds_level_budget);
+				if (accumulate) {
+					hipLaunchKernelGGL(k_add_f32_to_f16, dim3((uint32_t)div_round_up((size_t)e.n_params, (size_t)256)), dim3(256), 0, stream, (size_t)e.n_params, tmp.as<float>(), grid_grads);
+				} else {
+					cast_f32_to_f16(stream, e.n_params, tmp.as<float>(), grid_grads);
+				}
+			} else {
+				if (!accumulate) {
+					ProfScope prof(stream, STAGE_GRID_BWD_ZERO);
+					HIP_CHECK(hipMemsetAsync(grid_grads, 0, (size_t)e.n_params * sizeof(half_t), stream));  // grid.h:865-867
+				}
+				ProfScope prof(stream, STAGE_GRID_BWD);
+				grid_backward(stream, e.grid, io, dL_denc, grid_grads, nullptr, lds_level_budget);
+			}
+		}
+		if (dL_dinput) {
+			if (!ctx.dy_dx.ptr) throw std::runtime_error("backward: dL_dinput requested but forward was not run with prepare_input_gradients");
+			grid_backward_input(stream, md.n_input_dims, e.n_output_dims, io, dL_denc, ctx.dy_dx.as<float>(), dL_dinput, md.n_input_dims, 1u);
+		}
+	} else if (dL_dinput) {
+		identity_backward(stream, n, e.n_dims, e.id_scale, dL_denc, stride_k, stride_i, dL_dinput, md.n_input_dims, 1u);
+	}
+}
+
+static Model make_nwie(uint32_t n_input_dims, uint32_t n_output_dims, const Json& encoding, const Json& network) {
+	Model md;
+	md.n_input_dims = n_input_dims;
+	md.enc = create_encoding_desc(n_input_dims, encoding, /*minimum_alignment(network)=*/16);  // network.cu:79-98 -> 16
+	md.has_network = true;
+	md.net = create_network_desc(md.enc.padded_output_width, n_output_dims, network);
+	md.finish();
+	return md;
+}
+
+}  // namespace tcnn_hip
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+using namespace tcnn_hip;
+
+struct tcnn_module {
+	Model md;
+	std::string name;
+	uint32_t lds_level_budget = 48 * 1024;
+};
+struct tcnn_context {
+	ForwardCtx ctx;
+};
+
+struct tcnn_train_context {
+	ForwardCtx model_ctx;
+	Scratch output;       // half [n][padded]
+	Scratch dL_doutput;   // half [n][padded]
+	const half_t* dL_doutput_ptr = nullptr;  // == dL_doutput or the caller's external_dL_dy
+	Scratch block_sums;   // fp32 partial loss sums
+	uint32_t n_block_sums = 0;
+	uint32_t n = 0;
+	hipStream_t stream = nullptr;
+};
+
+struct tcnn_trainable_model {
+	Model md;
+	LossType loss = LossType::RelativeL2;
+	AdamHyper adam;
+	uint32_t optimizer_step = 0;
+	Pcg32 rng;
+	void* buffer = nullptr;  // [fp32 master | half params | half grads], trainer.h:76, 489-495
+	float* master = nullptr;
+	half_t* params = nullptr;
+	half_t* grads = nullptr;
+	float *m1 = nullptr, *m2 = nullptr;
+	uint32_t* steps = nullptr;
+	uint64_t global_batch = 0;
+	uint32_t lds_level_budget = 48 * 1024;
+	std::string hyper_json;
+	float* loss_scratch = nullptr;  // 1024 + 1 floats
+	std::unique_ptr<Profiler> profiler;  // null unless tcnn_trainer_set_profiling enabled it
+};
+
+#define TCNN_API_BEGIN try {
+#define TCNN_API_END                             \
+	}                                            \
+	catch (const std::exception& ex) {           \
+		g_last_error = ex.what();                \
+		log_message(TCNN_LOG_ERROR, ex.what());  \
+		return TCNN_ERROR;                       \
+	}                                            \
+	return TCNN_OK;
+
+extern "C" {
+
+const char* tcnn_last_error(void) { return g_last_error.c_str(); }
+uint32_t tcnn_batch_size_granularity(void) { return BATCH_SIZE_GRANULARITY; }
+int tcnn_hip_device(void) {
+	int d = -1;
+	(void)hipGetDevice(&d);
+	return d;
+}
+int tcnn_set_hip_device(int device) {
+	TCNN_API_BEGIN
+	HIP_CHECK(hipSetDevice(device));
+	TCNN_API_END
+}
+void tcnn_free_temporary_memory(void) { ScratchCache::free_all(); }
+int tcnn_has_networks(void) { return 1; }
+float tcnn_default_loss_scale(int precision) { return precision == TCNN_PRECISION_FP32 ? 1.0f : LOSS_SCALE_FP16; }
+int tcnn_preferred_precision(void) { return TCNN_PRECISION_FP16; }
+int tcnn_supports_jit_fusion(int) { return 0; }
+void tcnn_set_log_callback(void (*callback)(int, const char*)) { g_log_callback = callback; }
+
+int tcnn_create_network_with_input_encoding(uint32_t n_input_dims, uint32_t n_output_dims, const char* encoding_json, const char* network_json,
+                                            tcnn_module_t** out) {
+	TCNN_API_BEGIN
+	auto m = std::make_unique<tcnn_module>();
+	m->md = make_nwie(n_input_dims, n_output_dims, Json::parse(encoding_json), Json::parse(network_json));
+	m->name = m->md.name();
+	*out = m.release();
+	TCNN_API_END
+}
+
+int tcnn_create_network(uint32_t n_input_dims, uint32_t n_output_dims, const char* network_json, tcnn_module_t** out) {
+	return tcnn_create_network_with_input_encoding(n_input_dims, n_output_dims, "{\"otype\": \"Identity\"}", network_json, out);  // cpp_api.cu:160-162
+}
+
+int tcnn_create_encoding(uint32_t n_input_dims, const char* encoding_json, int requested_precision, tcnn_module_t** out) {
+	TCNN_API_BEGIN
+	if (requested_precision != TCNN_PRECISION_FP16) {
+		g_last_error = "create_encoding: only fp16 encodings are available in this build";
+		return TCNN_ERROR_UNSUPPORTED;
+	}
+	auto m = std::make_unique<tcnn_module>();
+	m->md.n_input_dims = n_input_dims;
+	m->md.enc = create_encoding_desc(n_input_dims, Json::parse(encoding_json), /*alignment=*/0);  // cpp_api.cu:165-174
+	m->md.has_network = false;
+	m->md.finish();
+	m->name = m->md.name();
+	*out = m.release();
+	TCNN_API_END
+}
+
+void tcnn_module_destroy(tcnn_module_t* m) { delete m; }
+
+int tcnn_module_inference(tcnn_module_t* m, tcnn_stream_t stream, uint32_t n, const float* input, void* output, void* params) {
+	TCNN_API_BEGIN
+	model_forward((hipStream_t)stream, m->md, n, input, (half_t*)output, (const half_t*)params, nullptr, false);
+	TCNN_API_END
+}
+
+int tcnn_module_forward(tcnn_module_t* m, tcnn_stream_t stream, uint32_t n, const float* input, void* output, void* params,
+                        int prepare_input_gradients, tcnn_context_t** ctx) {
+	TCNN_API_BEGIN
+	auto c = std::make_unique<tcnn_context>();
+	model_forward((hipStream_t)stream, m->md, n, input, (half_t*)output, (const half_t*)params, &c->ctx, prepare_input_gradients != 0);
+	*ctx = c.release();
+	TCNN_API_END
+}
+
+int tcnn_module_backward(tcnn_module_t* m, tcnn_stream_t stream, const tcnn_context_t* ctx, uint32_t n, float* dL_dinput, const void* dL_doutput,
+                         void* dL_dparams, const float* input, const void* output, const void* params) {
+	(void)output;
+	TCNN_API_BEGIN
+	if (!ctx) throw std::runtime_error("backward: missing forward context");
+	model_backward((hipStream_t)stream, m->md, ctx->ctx, n, dL_dinput, (const half_t*)dL_doutput, (half_t*)dL_dparams, input, (const half_t*)params,
+	               dL_dparams ? TCNN_GRADIENT_OVERWRITE : TCNN_GRADIENT_IGNORE, m->lds_level_budget);  // cpp_api.cu:115
+	TCNN_API_END
+}
+
+int tcnn_module_backward_backward_input(tcnn_module_t*, tcnn_stream_t, const tcnn_context_t*, uint32_t, const float*, const float*, const void*,
+                                        void*, void*, float*, const void*) {
+	g_last_error = "backward_backward_input (second-order grid gradients, grid.h:352-655) is not part of this build";
+	return TCNN_ERROR_UNSUPPORTED;
+}
+
+void tcnn_context_destroy(tcnn_context_t* ctx) { delete ctx; }
+
+uint32_t tcnn_module_n_input_dims(const tcnn_module_t* m) { return m->md.n_input_dims; }
+uint32_t tcnn_module_n_output_dims(const tcnn_module_t* m) { return m->md.padded_output_width(); }
+size_t tcnn_module_n_params(const tcnn_module_t* m) { return m->md.n_params(); }
+int tcnn_module_param_precision(const tcnn_module_t*) { return TCNN_PRECISION_FP16; }
+int tcnn_module_output_precision(const tcnn_module_t*) { return TCNN_PRECISION_FP16; }
+
+int tcnn_module_initialize_params(tcnn_module_t* m, size_t seed, float* params_full_precision, float scale) {
+	TCNN_API_BEGIN
+	Pcg32 rng{(uint64_t)seed};  // cpp_api.cu:139-142
+	m->md.initialize_params(nullptr, rng, params_full_precision, scale);
+	HIP_CHECK(hipStreamSynchronize(nullptr));
+	TCNN_API_END
+}
+
+const char* tcnn_module_hyperparams_json(const tcnn_module_t* m) { return m->md.hyper_json.c_str(); }
+const char* tcnn_module_name(const tcnn_module_t* m) { return m->name.c_str(); }
+int tcnn_module_jit_fusion(const tcnn_module_t*) { return 0; }
+int tcnn_module_set_jit_fusion(tcnn_module_t*, int val) {
+	if (val) log_message(TCNN_LOG_WARNING, "JIT fusion was requested but this build has no runtime compilation path; the statically fused kernels are used.");
+	return TCNN_OK;
+}
+
+int tcnn_module_grid_indices(tcnn_module_t* m, tcnn_stream_t stream, uint32_t n, const float* input, uint32_t* indices) {
+	TCNN_API_BEGIN
+	if (!m->md.enc.is_grid) throw std::runtime_error("grid_indices: module has no grid encoding");
+	GridIO io = {input, m->md.n_input_dims, 1u, n, n, 1u};
+	grid_indices((hipStream_t)stream, m->md.enc.grid, io, indices);
+	TCNN_API_END
+}
+int tcnn_module_grid_level_n_params(const tcnn_module_t* m, uint32_t level, size_t* out) {
+	TCNN_API_BEGIN
+	if (!m->md.enc.is_grid || level >= m->md.enc.grid.n_levels) throw std::runtime_error("grid_level_n_params: invalid level");
+	*out = m->md.enc.grid.offset[level + 1] - m->md.enc.grid.offset[level];  // multi_level_interface.h level_n_params
+	TCNN_API_END
+}
+int tcnn_module_grid_level_params_offset(const tcnn_module_t* m, uint32_t level, size_t* out) {
+	TCNN_API_BEGIN
+	if (!m->md.enc.is_grid || level >= m->md.enc.grid.n_levels) throw std::runtime_error("grid_level_params_offset: invalid level");
+	*out = m->md.enc.grid.offset[level];
+	TCNN_API_END
+}
+
+// ------------------------------------------------------------------------------------------------ trainer
+
+static void parse_adam(AdamHyper& h, const Json& p) {  // adam.h:221-281
+	h.beta1 = p.value("beta1", h.beta1);
+	h.beta2 = p.value("beta2", h.beta2);
+	h.epsilon = p.value("epsilon", h.epsilon);
+	h.learning_rate = p.value("learning_rate", h.learning_rate);
+	h.l2_reg = p.value("l2_reg", h.l2_reg);
+	h.adabound = p.value("adabound", h.adabound);
+	h.relative_weight_decay = p.value("relative_decay", h.relative_weight_decay);
+	h.absolute_weight_decay = p.value("absolute_decay", h.absolute_weight_decay);
+	h.weight_clipping_magnitude = p.value("clipping_magnitude", h.weight_clipping_magnitude);
+	h.gradient_clipping_magnitude = p.value("gradient_clipping_magnitude", h.gradient_clipping_magnitude);
+	h.non_matrix_learning_rate_factor = p.value("non_matrix_learning_rate_factor", h.non_matrix_learning_rate_factor);
+	h.non_matrix_l2_reg = p.value("non_matrix_l2_reg", h.non_matrix_l2_reg);
+	h.optimize_matrix_params = p.value("optimize_matrix_params", h.optimize_matrix_params);
+	h.optimize_non_matrix_params = p.value("optimize_non_matrix_params", h.optimize_non_matrix_params);
+	h.skip_zero_grad_non_matrix_params = p.value("skip_zero_grad_non_matrix_params", h.skip_zero_grad_non_matrix_params);
+}
+
+static void refresh_hyper_json(tcnn_trainable_model* tm) {  // trainer.h:385-391, adam.h:283-302
+	Json o = Json::object();
+	o["otype"] = "Adam";
+	o["beta1"] = tm->adam.beta1;
+	o["beta2"] = tm->adam.beta2;
+	o["epsilon"] = tm->adam.epsilon;
+	o["learning_rate"] = tm->adam.learning_rate;
+	o["l2_reg"] = tm->adam.l2_reg;
+	o["adabound"] = tm->adam.adabound;
+	o["relative_decay"] = tm->adam.relative_weight_decay;
+	o["absolute_decay"] = tm->adam.absolute_weight_decay;
+	o["clipping_magnitude"] = tm->adam.weight_clipping_magnitude;
+	o["gradient_clipping_magnitude"] = tm->adam.gradient_clipping_magnitude;
+	o["non_matrix_learning_rate_factor"] = tm->adam.non_matrix_learning_rate_factor;
+	o["non_matrix_l2_reg"] = tm->adam.non_matrix_l2_reg;
+	o["optimize_matrix_params"] = tm->adam.optimize_matrix_params;
+	o["optimize_non_matrix_params"] = tm->adam.optimize_non_matrix_params;
+	o["skip_zero_grad_non_matrix_params"] = tm->adam.skip_zero_grad_non_matrix_params;
+	Json l = Json::object();
+	l["otype"] = tm->loss == LossType::RelativeL2 ? "RelativeL2" : "L2";
+	Json j = Json::object();
+	j["otype"] = "Trainer";
+	j["optimizer"] = o;
+	j["loss"] = l;
+	tm->hyper_json = j.dump();
+}
+
+static void cast_master_to_params(tcnn_trainable_model* tm, hipStream_t stream) {  // trainer.h:409-421
+	cast_f32_to_f16(stream, tm->md.n_params(), tm->master, tm->params);
+}
+
+int tcnn_create_from_config(uint32_t n_input_dims, uint32_t n_output_dims, const char* config_json, uint32_t seed, tcnn_trainable_model_t** out) {
+	TCNN_API_BEGIN
+	const Json config = Json::parse(config_json);
+	auto tm = std::make_unique<tcnn_trainable_model>();
+	// config.h:53-63
+	const Json loss_opts = config.value("loss", Json::object());
+	const Json optimizer_opts = config.value("optimizer", Json::object());
+	const Json network_opts = config.value("network", Json::object());
+	const Json encoding_opts = config.value("encoding", Json::object());
+	const std::string loss_type = loss_opts.value("otype", "RelativeL2");  // loss.cu:81-83
+	if (equals_case_insensitive(loss_type, "RelativeL2")) tm->loss = LossType::RelativeL2;
+	else if (equals_case_insensitive(loss_type, "L2")) tm->loss = LossType::L2;
+	else throw std::runtime_error("Loss '" + loss_type + "' is not available in this build (supported: RelativeL2, L2).");
+	const std::string opt_type = optimizer_opts.value("otype", "Adam");  // optimizer.cu:50
+	if (!equals_case_insensitive(opt_type, "Adam")) throw std::runtime_error("Optimizer '" + opt_type + "' is not available in this build (supported: Adam).");
+	parse_adam(tm->adam, optimizer_opts);
+	tm->md = make_nwie(n_input_dims, n_output_dims, encoding_opts, network_opts);
+	refresh_hyper_json(tm.get());
+
+	// Trainer ctor + initialize_params, trainer.h:51-87
+	const size_t n = tm->md.n_params();
+	HIP_CHECK(hipMalloc(&tm->buffer, n * (sizeof(float) + 2 * sizeof(half_t))));
+	HIP_CHECK(hipMemset(tm->buffer, 0, n * (sizeof(float) + 2 * sizeof(half_t))));
+	tm->master = (float*)tm->buffer;
+	tm->params = (half_t*)((char*)tm->buffer + sizeof(float) * n);
+	tm->grads = tm->params + n;
+	HIP_CHECK(hipMalloc((void**)&tm->m1, n * sizeof(float)));  // adam.h:136-156
+	HIP_CHECK(hipMalloc((void**)&tm->m2, n * sizeof(float)));
+	HIP_CHECK(hipMalloc((void**)&tm->steps, n * sizeof(uint32_t)));
+	HIP_CHECK(hipMemset(tm->m1, 0, n * sizeof(float)));
+	HIP_CHECK(hipMemset(tm->m2, 0, n * sizeof(float)));
+	HIP_CHECK(hipMemset(tm->steps, 0, n * sizeof(uint32_t)));
+	HIP_CHECK(hipMalloc((void**)&tm->loss_scratch, 1032 * sizeof(float)));
+	std::seed_seq seq{seed};
+	std::vector<uint32_t> seeds(2);
+	seq.generate(std::begin(seeds), std::end(seeds));
+	tm->rng = Pcg32{seeds.front()};
+	tm->md.initialize_params(nullptr, tm->rng, tm->master, 1.0f);
+	cast_master_to_params(tm.get(), nullptr);
+	HIP_CHECK(hipDeviceSynchronize());
+	*out = tm.release();
+	TCNN_API_END
+}
+
+void tcnn_trainable_model_destroy(tcnn_trainable_model_t* tm) {
+	if (!tm) return;
+	(void)hipDeviceSynchronize();
+	(void)hipFree(tm->buffer);
+	(void)hipFree(tm->m1);
+	(void)hipFree(tm->m2);
+	(void)hipFree(tm->steps);
+	(void)hipFree(tm->loss_scratch);
+	delete tm;
+}
+
+int tcnn_trainer_forward(tcnn_trainable_model_t* tm, tcnn_stream_t stream_, float loss_scale, uint32_t n, const float* input, const float* target,
+                         const float* data_pdf, int use_inference_params, int prepare_input_gradients, const void* external_dL_dy,
+                         tcnn_train_context_t** ctx_out) {
+	(void)use_inference_params;  // Adam has no custom inference weights: params_inference == params (trainer.h:497-500)
+	TCNN_API_BEGIN
+	ProfilerGuard pg(tm->profiler.get());
+	hipStream_t stream = (hipStream_t)stream_;
+	auto c = std::make_unique<tcnn_train_context>();
+	c->n = n;
+	c->stream = stream;
+	const uint32_t padded = tm->md.padded_output_width();
+	c->output = Scratch(stream, (size_t)padded * n * sizeof(half_t));
+	model_forward(stream, tm->md, n, input, c->output.as<half_t>(), tm->params, &c->model_ctx, prepare_input_gradients != 0);
+	if (external_dL_dy) {  // trainer.h:124-128
+		c->dL_doutput_ptr = (const half_t*)external_dL_dy;
+	} else {
+		if (!target) throw std::runtime_error("Trainer::forward: target must be given unless external_dL_dy is");
+		c->dL_doutput = Scratch(stream, (size_t)padded * n * sizeof(half_t));
+		c->dL_doutput_ptr = c->dL_doutput.as<half_t>();
+		c->n_block_sums = loss_n_blocks(n, padded);
+		c->block_sums = Scratch(stream, (size_t)c->n_block_sums * sizeof(float));
+		const uint64_t n_total = (tm->global_batch ? tm->global_batch : (uint64_t)n) * tm->md.output_width();
+		if (n_total > 0xFFFFFFFFull) throw std::runtime_error("Trainer::forward: batch too large");
+		ProfScope prof(stream, STAGE_LOSS);
+		loss_evaluate(stream, tm->loss, n, padded, tm->md.output_width(), loss_scale, c->output.as<half_t>(), target, data_pdf, nullptr,
+		              c->dL_doutput.as<half_t>(), c->block_sums.as<float>(), (uint32_t)n_total);
+	}
+	*ctx_out = c.release();
+	TCNN_API_END
+}
+
+int tcnn_trainer_backward(tcnn_trainable_model_t* tm, tcnn_stream_t stream, const tcnn_train_context_t* ctx, uint32_t n, const float* input,
+                          float* dL_dinput, int use_inference_params, int gradient_mode) {
+	(void)use_inference_params;
+	TCNN_API_BEGIN
+	if (!ctx) throw std::runtime_error("Trainer::backward: missing forward context");
+	ProfilerGuard pg(tm->profiler.get());
+	model_backward((hipStream_t)stream, tm->md, ctx->model_ctx, n, dL_dinput, ctx->dL_doutput_ptr, tm->grads, input, tm->params, gradient_mode,
+	               tm->lds_level_budget);
+	TCNN_API_END
+}
+
+int tcnn_trainer_optimizer_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale) {
+	TCNN_API_BEGIN
+	++tm->optimizer_step;  // adam.h:159
+	ProfilerGuard pg(tm->profiler.get());
+	ProfScope prof((hipStream_t)stream, STAGE_ADAM);
+	adam_step((hipStream_t)stream, tm->adam, (uint32_t)tm->md.n_params(), (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master,
+	          tm->params, tm->grads, tm->m1, tm->m2, tm->steps);
+	TCNN_API_END
+}
+
+int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream, uint32_t n, const float* input, const float* target,
+                               const float* data_pdf, int run_optimizer, float* dL_dinput, int use_inference_params, int gradient_mode,
+                               const void* external_dL_dy, tcnn_train_context_t** ctx_out) {
+	const float loss_scale = LOSS_SCALE_FP16;  // trainer.h:265
+	tcnn_train_context_t* ctx = nullptr;
+	int r = tcnn_trainer_forward(tm, stream, loss_scale, n, input, target, data_pdf, use_inference_params, dL_dinput != nullptr, external_dL_dy, &ctx);
+	if (r == TCNN_OK) r = tcnn_trainer_backward(tm, stream, ctx, n, input, dL_dinput, use_inference_params, gradient_mode);
+	if (r == TCNN_OK && run_optimizer) r = tcnn_trainer_optimizer_step(tm, stream, loss_scale);
+	if (ctx_out && r == TCNN_OK) {
+		*ctx_out = ctx;
+	} else {
+		delete ctx;
+	}
+	return r;
+}
+
+int tcnn_trainer_loss(tcnn_trainable_model_t* tm, tcnn_stream_t stream_, const tcnn_train_context_t* ctx, float* out_loss) {
+	TCNN_API_BEGIN
+	hipStream_t stream = (hipStream_t)stream_;
+	if (!ctx || !ctx->block_sums.ptr) throw std::runtime_error("Trainer::loss: context holds no loss values (external_dL_dy was used)");
+	reduce_sum(stream, ctx->block_sums.as<float>(), ctx->n_block_sums, tm->loss_scratch, tm->loss_scratch + 1024);
+	HIP_CHECK(hipMemcpyAsync(out_loss, tm->loss_scratch + 1024, sizeof(float), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	TCNN_API_END
+}
+
+void tcnn_train_context_destroy(tcnn_train_context_t* ctx) { delete ctx; }
+const void* tcnn_train_context_output(const tcnn_train_context_t* ctx) { return ctx->output.ptr; }
+const void* tcnn_train_context_dL_doutput(const tcnn_train_context_t* ctx) { return ctx->dL_doutput_ptr; }
+
+int tcnn_network_inference(tcnn_trainable_model_t* tm, tcnn_stream_t stream_, uint32_t n, const float* input, float* output, int use_inference_params) {
+	(void)use_inference_params;
+	TCNN_API_BEGIN
+	hipStream_t stream = (hipStream_t)stream_;
+	const uint32_t padded = tm->md.padded_output_width();
+	Scratch tmp(stream, (size_t)padded * n * sizeof(half_t));  // object.h:260
+	model_forward(stream, tm->md, n, input, tmp.as<half_t>(), tm->params, nullptr, false);
+	trim_and_cast(stream, n, padded, tm->md.output_width(), tmp.as<half_t>(), output, tm->md.output_width(), 1u);  // object.h:269-270
+	TCNN_API_END
+}
+
+size_t tcnn_trainer_n_params(const tcnn_trainable_model_t* tm) { return tm->md.n_params(); }
+float* tcnn_trainer_params_full_precision(tcnn_trainable_model_t* tm) { return tm->master; }
+void* tcnn_trainer_params(tcnn_trainable_model_t* tm) { return tm->params; }
+void* tcnn_trainer_params_inference(tcnn_trainable_model_t* tm) { return tm->params; }
+void* tcnn_trainer_param_gradients(tcnn_trainable_model_t* tm) { return tm->grads; }
+
+int tcnn_trainer_set_params_full_precision(tcnn_trainable_model_t* tm, const float* params, size_t n_params, int device_ptr) {
+	TCNN_API_BEGIN
+	if (n_params != tm->md.n_params()) throw std::runtime_error("Can't set fp params because buffer has the wrong size.");  // trainer.h:410-412
+	HIP_CHECK(hipMemcpy(tm->master, params, sizeof(float) * n_params, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+	cast_master_to_params(tm, nullptr);
+	HIP_CHECK(hipDeviceSynchronize());
+	TCNN_API_END
+}
+
+int tcnn_trainer_set_params(tcnn_trainable_model_t* tm, const void* params_fp16, size_t n_params, int device_ptr) {
+	TCNN_API_BEGIN
+	if (n_params != tm->md.n_params()) throw std::runtime_error("Can't set params because buffer has the wrong size.");  // trainer.h:424-426
+	HIP_CHECK(hipMemcpy(tm->params, params_fp16, sizeof(half_t) * n_params, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+	cast_f16_to_f32(nullptr, n_params, tm->params, tm->master);
+	HIP_CHECK(hipDeviceSynchronize());
+	TCNN_API_END
+}
+
+int tcnn_trainer_update_hyperparams(tcnn_trainable_model_t* tm, const char* json) {
+	TCNN_API_BEGIN
+	const Json j = Json::parse(json);
+	parse_adam(tm->adam, j.value("optimizer", Json::object()));
+	refresh_hyper_json(tm);
+	TCNN_API_END
+}
+const char* tcnn_trainer_hyperparams_json(tcnn_trainable_model_t* tm) { return tm->hyper_json.c_str(); }
+uint32_t tcnn_trainer_optimizer_step_count(const tcnn_trainable_model_t* tm) { return tm->optimizer_step; }
+uint32_t tcnn_trainer_padded_output_width(const tcnn_trainable_model_t* tm) { return tm->md.padded_output_width(); }
+uint32_t tcnn_trainer_n_mlp_params(const tcnn_trainable_model_t* tm) { return (uint32_t)tm->md.n_mlp_params(); }
+
+int tcnn_trainer_set_global_batch_size(tcnn_trainable_model_t* tm, uint64_t global_batch_size) {
+	tm->global_batch = global_batch_size;
+	return TCNN_OK;
+}
+
+int tcnn_trainer_set_profiling(tcnn_trainable_model_t* tm, int enable, int only_stage) {
+	TCNN_API_BEGIN
+	if (!enable) {
+		tm->profiler.reset();
+	} else {
+		tm->profiler = std::make_unique<Profiler>();
+		tm->profiler->only_stage = only_stage;
+	}
+	TCNN_API_END
+}
+int tcnn_trainer_n_stages(void) { return N_STAGES; }
+const char* tcnn_trainer_stage_name(int stage) { return stage >= 0 && stage < N_STAGES ? STAGE_NAMES[stage] : ""; }
+int tcnn_trainer_get_stage_times(tcnn_trainable_model_t* tm, double* total_ms, uint64_t* counts) {
+	TCNN_API_BEGIN
+	if (!tm->profiler) throw std::runtime_error("profiling is not enabled");
+	tm->profiler->collect();
+	for (int i = 0; i < N_STAGES; ++i) {
+		total_ms[i] = tm->profiler->total_ms[i];
+		counts[i] = tm->profiler->count[i];
+	}
+	TCNN_API_END
+}
+int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes) {
+	tm->lds_level_budget = bytes;
+	return TCNN_OK;
+}
+
+}  // extern "C"

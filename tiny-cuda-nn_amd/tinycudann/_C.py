@@ -1,0 +1,343 @@
+"""ctypes binding of libtcnn_hip.so with the surface of the reference's pybind module
+(`tinycudann_bindings._<cc>_C`, reference bindings/torch/tinycudann/bindings.cpp:250-343).
+
+The product path is the HIP library: importing this module fails loudly if the library is missing
+(there is no CPU or eager-PyTorch fallback).  PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+import enum
+import json
+import os
+
+import torch  # must be imported first: libtcnn_hip.so binds to the HIP runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libtcnn_hip.so")
+
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        f"tinycudann (MI355X build): native library {_LIB_PATH} is missing. Build it with "
+        "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C tiny-cuda-nn_amd/csrc` (needs hipcc, gfx950).")
+
+_lib = C.CDLL(_LIB_PATH)
+
+OK = 0
+
+
+class Precision(enum.IntEnum):  # cpp_api.h:72-75
+    Fp32 = 0
+    Fp16 = 1
+
+
+class LogSeverity(enum.IntEnum):  # cpp_api.h:52-58
+    Info = 0
+    Debug = 1
+    Warning = 2
+    Error = 3
+    Success = 4
+
+
+class GradientMode(enum.IntEnum):  # common.h:152-156
+    Ignore = 0
+    Overwrite = 1
+    Accumulate = 2
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(_lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+_vp, _u32, _i, _f, _sz, _cp, _u64 = C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_size_t, C.c_char_p, C.c_uint64
+
+_sig("tcnn_last_error", _cp)
+_sig("tcnn_batch_size_granularity", _u32)
+_sig("tcnn_hip_device", _i)
+_sig("tcnn_set_hip_device", _i, _i)
+_sig("tcnn_free_temporary_memory", None)
+_sig("tcnn_has_networks", _i)
+_sig("tcnn_default_loss_scale", _f, _i)
+_sig("tcnn_preferred_precision", _i)
+_sig("tcnn_supports_jit_fusion", _i, _i)
+_sig("tcnn_set_log_callback", None, _vp)
+_sig("tcnn_create_network_with_input_encoding", _i, _u32, _u32, _cp, _cp, C.POINTER(_vp))
+_sig("tcnn_create_network", _i, _u32, _u32, _cp, C.POINTER(_vp))
+_sig("tcnn_create_encoding", _i, _u32, _cp, _i, C.POINTER(_vp))
+_sig("tcnn_module_destroy", None, _vp)
+_sig("tcnn_module_inference", _i, _vp, _vp, _u32, _vp, _vp, _vp)
+_sig("tcnn_module_forward", _i, _vp, _vp, _u32, _vp, _vp, _vp, _i, C.POINTER(_vp))
+_sig("tcnn_module_backward", _i, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp)
+_sig("tcnn_module_backward_backward_input", _i, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp)
+_sig("tcnn_context_destroy", None, _vp)
+_sig("tcnn_module_n_input_dims", _u32, _vp)
+_sig("tcnn_module_n_output_dims", _u32, _vp)
+_sig("tcnn_module_n_params", _sz, _vp)
+_sig("tcnn_module_param_precision", _i, _vp)
+_sig("tcnn_module_output_precision", _i, _vp)
+_sig("tcnn_module_initialize_params", _i, _vp, _sz, _vp, _f)
+_sig("tcnn_module_hyperparams_json", _cp, _vp)
+_sig("tcnn_module_name", _cp, _vp)
+_sig("tcnn_module_jit_fusion", _i, _vp)
+_sig("tcnn_module_set_jit_fusion", _i, _vp, _i)
+_sig("tcnn_module_grid_indices", _i, _vp, _vp, _u32, _vp, _vp)
+_sig("tcnn_module_grid_level_n_params", _i, _vp, _u32, C.POINTER(_sz))
+_sig("tcnn_module_grid_level_params_offset", _i, _vp, _u32, C.POINTER(_sz))
+_sig("tcnn_create_from_config", _i, _u32, _u32, _cp, _u32, C.POINTER(_vp))
+_sig("tcnn_trainable_model_destroy", None, _vp)
+_sig("tcnn_trainer_training_step", _i, _vp, _vp, _u32, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, C.POINTER(_vp))
+_sig("tcnn_trainer_forward", _i, _vp, _vp, _f, _u32, _vp, _vp, _vp, _i, _i, _vp, C.POINTER(_vp))
+_sig("tcnn_trainer_backward", _i, _vp, _vp, _vp, _u32, _vp, _vp, _i, _i)
+_sig("tcnn_trainer_optimizer_step", _i, _vp, _vp, _f)
+_sig("tcnn_trainer_loss", _i, _vp, _vp, _vp, C.POINTER(_f))
+_sig("tcnn_train_context_destroy", None, _vp)
+_sig("tcnn_train_context_output", _vp, _vp)
+_sig("tcnn_train_context_dL_doutput", _vp, _vp)
+_sig("tcnn_network_inference", _i, _vp, _vp, _u32, _vp, _vp, _i)
+_sig("tcnn_trainer_n_params", _sz, _vp)
+_sig("tcnn_trainer_params_full_precision", _vp, _vp)
+_sig("tcnn_trainer_params", _vp, _vp)
+_sig("tcnn_trainer_params_inference", _vp, _vp)
+_sig("tcnn_trainer_param_gradients", _vp, _vp)
+_sig("tcnn_trainer_set_params_full_precision", _i, _vp, _vp, _sz, _i)
+_sig("tcnn_trainer_set_params", _i, _vp, _vp, _sz, _i)
+_sig("tcnn_trainer_update_hyperparams", _i, _vp, _cp)
+_sig("tcnn_trainer_hyperparams_json", _cp, _vp)
+_sig("tcnn_trainer_optimizer_step_count", _u32, _vp)
+_sig("tcnn_trainer_padded_output_width", _u32, _vp)
+_sig("tcnn_trainer_n_mlp_params", _u32, _vp)
+_sig("tcnn_trainer_set_global_batch_size", _i, _vp, _u64)
+_sig("tcnn_trainer_set_profiling", _i, _vp, _i, _i)
+_sig("tcnn_trainer_n_stages", _i)
+_sig("tcnn_trainer_stage_name", _cp, _i)
+_sig("tcnn_trainer_get_stage_times", _i, _vp, _vp, _vp)
+_sig("tcnn_trainer_set_lds_level_budget", _i, _vp, _u32)
+
+EXPORTED_SYMBOLS = [n for n in dir(_lib) if n.startswith("tcnn_")]
+
+
+def _check(code):
+    if code != OK:
+        raise RuntimeError(_lib.tcnn_last_error().decode())  # the reference throws std::runtime_error -> RuntimeError
+
+
+def library_path():
+    return _LIB_PATH
+
+
+# ---- free functions (bindings.cpp:305-320) ------------------------------------------------------
+def batch_size_granularity():
+    return int(_lib.tcnn_batch_size_granularity())
+
+
+def default_loss_scale(precision):
+    return float(_lib.tcnn_default_loss_scale(int(precision)))
+
+
+def free_temporary_memory():
+    _lib.tcnn_free_temporary_memory()
+
+
+def has_networks():
+    return bool(_lib.tcnn_has_networks())
+
+
+def preferred_precision():
+    return Precision(_lib.tcnn_preferred_precision())
+
+
+def supports_jit_fusion(device=-1):
+    return bool(_lib.tcnn_supports_jit_fusion(device))
+
+
+def rtc_set_cache_dir(_dir):  # no runtime compilation in this build
+    return None
+
+
+def rtc_set_include_dir(_dir):
+    return None
+
+
+_log_cb_keepalive = None
+
+
+def set_log_callback(fn):
+    global _log_cb_keepalive
+    if fn is None:
+        _lib.tcnn_set_log_callback(None)
+        _log_cb_keepalive = None
+        return
+    proto = C.CFUNCTYPE(None, C.c_int, C.c_char_p)
+    _log_cb_keepalive = proto(lambda sev, msg: fn(LogSeverity(sev), msg.decode()))
+    _lib.tcnn_set_log_callback(C.cast(_log_cb_keepalive, C.c_void_p))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _check_input(x):  # bindings.cpp:73 CHECK_INPUT
+    if not x.is_cuda:
+        raise RuntimeError("tensor must live on the GPU")
+    if not x.is_contiguous():
+        raise RuntimeError("tensor must be contiguous")
+
+
+class Context:
+    """tcnn::cpp::Context (cpp_api.h:87-89): owns the saved activations of one forward call."""
+
+    def __init__(self, handle=None):
+        self._h = handle
+
+    @property
+    def valid(self):
+        return self._h is not None
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and _lib is not None:
+            _lib.tcnn_context_destroy(self._h)
+            self._h = None
+
+
+class Module:
+    """Mirror of the pybind `Module` (bindings.cpp:75-248)."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.tcnn_module_destroy(self._h)
+            self._h = None
+
+    def _torch_param_dtype(self):
+        return torch.half if self.param_precision() == Precision.Fp16 else torch.float
+
+    def _torch_output_dtype(self):
+        return torch.half if self.output_precision() == Precision.Fp16 else torch.float
+
+    def fwd(self, input, params):
+        _check_input(input)
+        _check_input(params)
+        if input.dtype != torch.float32:
+            raise RuntimeError("input must be float32")
+        if params.dtype != self._torch_param_dtype():
+            raise RuntimeError("params have the wrong precision")
+        if input.shape[1] != self.n_input_dims() or params.shape[0] != self.n_params():
+            raise RuntimeError("input / params have the wrong size")
+        if input.device != params.device:
+            raise RuntimeError("input and params must be on the same device")
+        with torch.cuda.device(input.device):
+            batch_size = input.shape[0]
+            output = torch.empty((batch_size, self.n_output_dims()), dtype=self._torch_output_dtype(), device=input.device)
+            if not input.requires_grad and not params.requires_grad:
+                _check(_lib.tcnn_module_inference(self._h, _stream(), batch_size, _ptr(input), _ptr(output), _ptr(params)))
+                return Context(None), output
+            h = C.c_void_p()
+            _check(_lib.tcnn_module_forward(self._h, _stream(), batch_size, _ptr(input), _ptr(output), _ptr(params),
+                                            int(input.requires_grad), C.byref(h)))
+            return Context(h), output
+
+    def bwd(self, ctx, input, params, output, dL_doutput):
+        if ctx is None or not ctx.valid:
+            raise RuntimeError("Module::bwd: called with invalid context. fwd likely (mistakenly) ran in inference mode.")
+        for t in (input, params, output, dL_doutput):
+            _check_input(t)
+        if input.dtype != torch.float32 or params.dtype != self._torch_param_dtype() or \
+                output.dtype != self._torch_output_dtype() or dL_doutput.dtype != self._torch_output_dtype():
+            raise RuntimeError("bwd: wrong tensor precision")
+        if input.shape[1] != self.n_input_dims() or output.shape[1] != self.n_output_dims() or \
+                params.shape[0] != self.n_params() or output.shape[0] != input.shape[0] or dL_doutput.shape[0] != input.shape[0]:
+            raise RuntimeError("bwd: wrong tensor size")
+        with torch.cuda.device(input.device):
+            batch_size = input.shape[0]
+            dL_dinput = torch.empty((batch_size, input.shape[1]), dtype=torch.float32, device=input.device) if input.requires_grad else None
+            dL_dparams = torch.empty((self.n_params(),), dtype=self._torch_param_dtype(), device=input.device) if params.requires_grad else None
+            if input.requires_grad or params.requires_grad:
+                _check(_lib.tcnn_module_backward(self._h, _stream(), ctx._h, batch_size, _ptr(dL_dinput), _ptr(dL_doutput),
+                                                 _ptr(dL_dparams), _ptr(input), _ptr(output), _ptr(params)))
+            return dL_dinput, dL_dparams
+
+    def bwd_bwd_input(self, ctx, input, params, dL_ddLdinput, dL_doutput):
+        raise RuntimeError("bwd_bwd_input (second-order gradients) is not part of the MI355X build yet")
+
+    def initial_params(self, seed):  # bindings.cpp:284-289
+        out = torch.zeros((self.n_params(),), dtype=torch.float32, device="cuda")
+        _check(_lib.tcnn_module_initialize_params(self._h, int(seed), _ptr(out), 1.0))
+        return out
+
+    def n_input_dims(self):
+        return int(_lib.tcnn_module_n_input_dims(self._h))
+
+    def n_params(self):
+        return int(_lib.tcnn_module_n_params(self._h))
+
+    def param_precision(self):
+        return Precision(_lib.tcnn_module_param_precision(self._h))
+
+    def n_output_dims(self):
+        return int(_lib.tcnn_module_n_output_dims(self._h))
+
+    def output_precision(self):
+        return Precision(_lib.tcnn_module_output_precision(self._h))
+
+    def hyperparams(self):
+        return json.loads(_lib.tcnn_module_hyperparams_json(self._h).decode())
+
+    def name(self):
+        return _lib.tcnn_module_name(self._h).decode()
+
+    @property
+    def jit_fusion(self):
+        return bool(_lib.tcnn_module_jit_fusion(self._h))
+
+    @jit_fusion.setter
+    def jit_fusion(self, val):
+        _check(_lib.tcnn_module_set_jit_fusion(self._h, int(bool(val))))
+
+    # parity helpers (no reference counterpart)
+    def grid_indices(self, input):
+        _check_input(input)
+        n = input.shape[0]
+        hp = self.hyperparams()
+        enc = hp.get("encoding", hp)
+        out = torch.empty((n, int(enc["n_levels"]), 1 << self.n_input_dims()), dtype=torch.int32, device=input.device)
+        _check(_lib.tcnn_module_grid_indices(self._h, _stream(), n, _ptr(input), _ptr(out)))
+        return out
+
+    def grid_level_n_params(self, level):
+        v = C.c_size_t()
+        _check(_lib.tcnn_module_grid_level_n_params(self._h, level, C.byref(v)))
+        return v.value
+
+    def grid_level_params_offset(self, level):
+        v = C.c_size_t()
+        _check(_lib.tcnn_module_grid_level_params_offset(self._h, level, C.byref(v)))
+        return v.value
+
+
+def _dumps(cfg):
+    return json.dumps(cfg).encode()
+
+
+def create_network_with_input_encoding(n_input_dims, n_output_dims, encoding, network):
+    h = C.c_void_p()
+    _check(_lib.tcnn_create_network_with_input_encoding(n_input_dims, n_output_dims, _dumps(encoding), _dumps(network), C.byref(h)))
+    return Module(h.value)
+
+
+def create_network(n_input_dims, n_output_dims, network):
+    h = C.c_void_p()
+    _check(_lib.tcnn_create_network(n_input_dims, n_output_dims, _dumps(network), C.byref(h)))
+    return Module(h.value)
+
+
+def create_encoding(n_input_dims, encoding, precision=Precision.Fp16):
+    h = C.c_void_p()
+    _check(_lib.tcnn_create_encoding(n_input_dims, _dumps(encoding), int(precision), C.byref(h)))
+    return Module(h.value)

@@ -1,0 +1,178 @@
+"""Python view of the C++ template API the reference's native apps use
+(`tcnn::create_from_config` -> `TrainableModel{loss, optimizer, network, trainer}`, reference
+include/tiny-cuda-nn/config.h:46-63; `Trainer::training_step/forward/backward/optimizer_step/loss`,
+trainer.h:97-374; `network->inference`, object.h:214-271) over the C ABI.
+
+Tensors are torch GPU tensors used as plain device memory: inputs `[batch, n_input_dims]` float32,
+targets `[batch, n_output_dims]` float32 (the reference's column-major features x batch matrices).
+"""
+import ctypes as C
+import json
+
+import torch
+
+from . import _C
+from ._C import GradientMode, _check, _lib, _ptr, _stream
+
+
+class _DeviceView:
+    """Exposes trainer-owned device memory to torch through __cuda_array_interface__ (no copy)."""
+
+    def __init__(self, ptr, n, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+        self._owner = owner
+
+
+class ForwardContext:
+    """Trainer::ForwardContext (trainer.h:89-95)."""
+
+    def __init__(self, handle, batch_size, padded, owner):
+        self._h = handle
+        self.batch_size = batch_size
+        self.padded = padded
+        self._owner = owner
+
+    def _view(self, ptr):
+        return torch.as_tensor(_DeviceView(ptr, self.batch_size * self.padded, "<f2", self), device="cuda").view(self.batch_size, self.padded)
+
+    @property
+    def output(self):
+        return self._view(_lib.tcnn_train_context_output(self._h))
+
+    @property
+    def dL_doutput(self):
+        return self._view(_lib.tcnn_train_context_dL_doutput(self._h))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.tcnn_train_context_destroy(self._h)
+            self._h = None
+
+
+class TrainableModel:
+    """create_from_config(n_input_dims, n_output_dims, config) (config.h:53-63); `seed` is the Trainer seed (trainer.h:51)."""
+
+    def __init__(self, n_input_dims, n_output_dims, config, seed=1337):
+        h = C.c_void_p()
+        _check(_lib.tcnn_create_from_config(n_input_dims, n_output_dims, json.dumps(config).encode(), seed, C.byref(h)))
+        self._h = h
+        self.n_input_dims = n_input_dims
+        self.n_output_dims = n_output_dims
+        self.config = config
+        self.padded_output_width = int(_lib.tcnn_trainer_padded_output_width(h))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.tcnn_trainable_model_destroy(self._h)
+            self._h = None
+
+    # ---- Trainer ------------------------------------------------------------------------------
+    def _check_io(self, input, target):
+        assert input.is_cuda and input.dtype == torch.float32 and input.is_contiguous() and input.shape[1] == self.n_input_dims
+        if target is not None:
+            assert target.is_cuda and target.dtype == torch.float32 and target.is_contiguous()
+            assert target.shape == (input.shape[0], self.n_output_dims)
+
+    def training_step(self, input, target, data_pdf=None, run_optimizer=True, dL_dinput=None, use_inference_params=False,
+                      gradient_mode=GradientMode.Overwrite, external_dL_dy=None, want_context=True):
+        self._check_io(input, target)
+        h = C.c_void_p()
+        _check(_lib.tcnn_trainer_training_step(self._h, _stream(), input.shape[0], _ptr(input), _ptr(target), _ptr(data_pdf),
+                                               int(run_optimizer), _ptr(dL_dinput), int(use_inference_params), int(gradient_mode),
+                                               _ptr(external_dL_dy), C.byref(h) if want_context else None))
+        return ForwardContext(h, input.shape[0], self.padded_output_width, self) if want_context else None
+
+    def forward(self, input, target, loss_scale=128.0, data_pdf=None, prepare_input_gradients=False, external_dL_dy=None):
+        self._check_io(input, target)
+        h = C.c_void_p()
+        _check(_lib.tcnn_trainer_forward(self._h, _stream(), loss_scale, input.shape[0], _ptr(input), _ptr(target), _ptr(data_pdf), 0,
+                                         int(prepare_input_gradients), _ptr(external_dL_dy), C.byref(h)))
+        return ForwardContext(h, input.shape[0], self.padded_output_width, self)
+
+    def backward(self, ctx, input, dL_dinput=None, gradient_mode=GradientMode.Overwrite):
+        _check(_lib.tcnn_trainer_backward(self._h, _stream(), ctx._h, input.shape[0], _ptr(input), _ptr(dL_dinput), 0, int(gradient_mode)))
+
+    def optimizer_step(self, loss_scale=128.0):
+        _check(_lib.tcnn_trainer_optimizer_step(self._h, _stream(), loss_scale))
+
+    def loss(self, ctx):
+        v = C.c_float()
+        _check(_lib.tcnn_trainer_loss(self._h, _stream(), ctx._h, C.byref(v)))
+        return v.value
+
+    # ---- Network::inference --------------------------------------------------------------------
+    def inference(self, input, output=None):
+        self._check_io(input, None)
+        if output is None:
+            output = torch.empty((input.shape[0], self.n_output_dims), dtype=torch.float32, device=input.device)
+        _check(_lib.tcnn_network_inference(self._h, _stream(), input.shape[0], _ptr(input), _ptr(output), 1))
+        return output
+
+    # ---- parameters ----------------------------------------------------------------------------
+    @property
+    def n_params(self):
+        return int(_lib.tcnn_trainer_n_params(self._h))
+
+    @property
+    def n_mlp_params(self):
+        return int(_lib.tcnn_trainer_n_mlp_params(self._h))
+
+    def _tensor(self, ptr, typestr):
+        return torch.as_tensor(_DeviceView(ptr, self.n_params, typestr, self), device="cuda")
+
+    @property
+    def params_full_precision(self):
+        return self._tensor(_lib.tcnn_trainer_params_full_precision(self._h), "<f4")
+
+    @property
+    def params(self):
+        return self._tensor(_lib.tcnn_trainer_params(self._h), "<f2")
+
+    @property
+    def param_gradients(self):
+        return self._tensor(_lib.tcnn_trainer_param_gradients(self._h), "<f2")
+
+    def set_params_full_precision(self, params):
+        if params.is_cuda:
+            _check(_lib.tcnn_trainer_set_params_full_precision(self._h, _ptr(params.contiguous()), params.numel(), 1))
+        else:
+            p = params.contiguous()
+            _check(_lib.tcnn_trainer_set_params_full_precision(self._h, C.c_void_p(p.data_ptr()), p.numel(), 0))
+
+    def update_hyperparams(self, cfg):
+        _check(_lib.tcnn_trainer_update_hyperparams(self._h, json.dumps(cfg).encode()))
+
+    def hyperparams(self):
+        return json.loads(_lib.tcnn_trainer_hyperparams_json(self._h).decode())
+
+    @property
+    def optimizer_step_count(self):
+        return int(_lib.tcnn_trainer_optimizer_step_count(self._h))
+
+    def set_global_batch_size(self, n):
+        _check(_lib.tcnn_trainer_set_global_batch_size(self._h, int(n)))
+
+    # ---- measurement hooks ---------------------------------------------------------------------
+    def set_profiling(self, enable=True, only_stage=None):
+        """HIP events around the stages of the training step, on the stream the kernels run on."""
+        stage = -1 if only_stage is None else self.stage_names().index(only_stage)
+        _check(_lib.tcnn_trainer_set_profiling(self._h, int(enable), stage))
+
+    @staticmethod
+    def stage_names():
+        return [_lib.tcnn_trainer_stage_name(i).decode() for i in range(_lib.tcnn_trainer_n_stages())]
+
+    def stage_times(self):
+        """{stage: (total_ms, launches)} accumulated since profiling was enabled (synchronises)."""
+        n = _lib.tcnn_trainer_n_stages()
+        ms = (C.c_double * n)()
+        cnt = (C.c_uint64 * n)()
+        _check(_lib.tcnn_trainer_get_stage_times(self._h, ms, cnt))
+        return {name: (ms[i], cnt[i]) for i, name in enumerate(self.stage_names())}
+
+    def set_lds_level_budget(self, n_bytes):
+        _check(_lib.tcnn_trainer_set_lds_level_budget(self._h, int(n_bytes)))
+
+
+def create_from_config(n_input_dims, n_output_dims, config, seed=1337):
+    return TrainableModel(n_input_dims, n_output_dims, config, seed)

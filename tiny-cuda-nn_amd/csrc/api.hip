@@ -527,7 +527,7 @@ static void model_forward(hipStream_t stream, const Model& md, uint32_t n, const
 
 __global__ void k_add_f32_to_f16(size_t n, const float* __restrict__ in, half_t* __restrict__ out) {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) out[i] = (half_t)((float)out[i] + in[i]);
+	if (i < n) out[i] = to_half_rn((float)out[i] + in[i]);
 }
 
 // NetworkWithInputEncoding::backward_impl (:83-113) / GridEncodingTemplated::backward_impl (grid.h:817-908)

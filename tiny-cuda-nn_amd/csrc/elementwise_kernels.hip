@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(EW_THREADS) k_loss(uint32_t n_groups, uint32_t
 				gradient = 2 * difference / pdf;
 			}
 			v8[j] = value;
-			g8[j] = (half_t)(loss_scale * gradient / n_total);
+			g8[j] = to_half_rn(loss_scale * gradient / n_total);
 			local_sum += value;
 		}
 		*(h8*)(gradients + e0) = g8;
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 				m1[j] = m1j;
 				m2[j] = m2j;
 				st[j] = sj;
-				wh[j] = (half_t)wj;
+				wh[j] = to_half_rn(wj);
 				any = true;
 			}
 		}
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 				first_moments[i] = m1j;
 				second_moments[i] = m2j;
 				param_steps[i] = sj;
-				weights[i] = (half_t)wj;
+				weights[i] = to_half_rn(wj);
 			}
 		}
 	}
@@ -319,7 +319,7 @@ __global__ void k_identity_forward(uint32_t n, uint32_t n_dims, uint32_t padded,
 	} else {
 		float t = in[(size_t)i * in_stride_i + (size_t)k * in_stride_j] * scale;
 		t = t + offset;
-		v = (half_t)t;
+		v = to_half_rn(t);
 	}
 	out[(size_t)k * stride_k + (size_t)i * stride_i] = v;
 }
@@ -329,7 +329,7 @@ __global__ void k_identity_backward(uint32_t n, uint32_t n_dims, float scale, co
 	if (e >= n * n_dims) return;
 	const uint32_t k = e / n, i = e - k * n;
 	// identity.h:83: (T)((float)dL_dy * scale) -- rounded through half, then widened to the fp32 dL_dx
-	dL_dx[(size_t)i * dx_stride_i + (size_t)k * dx_stride_j] = (float)(half_t)((float)dL_dy[(size_t)k * stride_k + (size_t)i * stride_i] * scale);
+	dL_dx[(size_t)i * dx_stride_i + (size_t)k * dx_stride_j] = (float)to_half_rn((float)dL_dy[(size_t)k * stride_k + (size_t)i * stride_i] * scale);
 }
 
 void identity_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t padded, float scale, float offset, const float* in,

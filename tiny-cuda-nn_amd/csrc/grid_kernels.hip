@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward(const GridMeta me
 					const uint32_t index = grid_index<D>(is_hash, hashmap_size, resolution, local);
 					h2 val[NP];
 					load_features<F>(grid + (size_t)index * F, val);
-					const half_t wh = (half_t)weight;
+					const half_t wh = to_half_rn(weight);
 					const h2 w2 = h2{wh, wh};
 #pragma unroll
 					for (uint32_t p = 0; p < NP; ++p) result[p] = fma_h2(w2, val[p], result[p]);
@@ -196,7 +196,7 @@ TCNN_DEVICE void scatter_add(GRAD_T* grad, uint32_t index, const h2 (&g)[(F + 1)
 		// grad_t == float when F == 1 (grid.h:665): fp32 product, fp32 atomic
 		atomic_add_f32(grad + index, weight * (float)g[0][0]);
 	} else {
-		const half_t wh = (half_t)weight;
+		const half_t wh = to_half_rn(weight);
 		const h2 w2 = h2{wh, wh};
 #pragma unroll
 		for (uint32_t p = 0; p < F / 2; ++p) atomic_add_h2(grad + (size_t)index * F + 2 * p, w2 * g[p]);  // (GRAD_T)weight * grad, grid.h:254
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(GRID_LDS_THREADS) k_grid_backward_lds(const Gr
 			}
 			const uint32_t index = grid_index<D>(is_hash, hashmap_size, resolution, local);
 			// same operand rounding as the atomic path: weight rounded to half first (grid.h:254)
-			const float wq = F == 1 ? weight : (float)(half_t)weight;
+			const float wq = F == 1 ? weight : (float)to_half_rn(weight);
 #pragma unroll
 			for (uint32_t f = 0; f < F; ++f) lds_atomic_add_f32(&lds_table[index * F + f], wq * g[f]);
 		}

@@ -386,7 +386,7 @@ __global__ void k_mlp_finalize_gradients(uint32_t n_params, uint32_t n_partials,
 	float s = 0.0f;
 	for (uint32_t b = 0; b < n_partials; ++b) s += partials[(size_t)b * n_params + i];
 	if (accumulate) s += (float)grads[i];
-	grads[i] = (half_t)s;
+	grads[i] = to_half_rn(s);
 }
 
 // =============================================================================================

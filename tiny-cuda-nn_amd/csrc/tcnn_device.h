@@ -69,6 +69,19 @@ TCNN_DEVICE uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((20) | (0 << 6)
 
 TCNN_DEVICE uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// fp32 -> fp16 with exactly ONE extra rounding (RNE) of an already rounded fp32 value.
+// Without the barrier hipcc folds `(half)(a * b)` / `(half)(a + b)` into v_fma_mixlo_f16, which rounds
+// the exact product/sum once -- a different (double- vs single-rounding) result in rare tie cases, and
+// therefore not bit-identical to the reference's "compute in fp32, then convert" (grid.h:162, 254).
+#if defined(TCNN_HOST_EMU)
+TCNN_DEVICE half_t to_half_rn(float x) { return (half_t)x; }
+#else
+TCNN_DEVICE half_t to_half_rn(float x) {
+	asm volatile("" : "+v"(x));
+	return (half_t)x;
+}
+#endif
+
 template <typename T>
 TCNN_HOST_DEVICE T div_round_up(T a, T b) { return (a + b - 1) / b; }
 template <typename T>

@@ -155,6 +155,9 @@ const char* tcnn_trainer_stage_name(int stage);
 int tcnn_trainer_get_stage_times(tcnn_trainable_model_t* tm, double* total_ms, uint64_t* counts);
 /* Tuning knob: levels whose fp32 table fits in this many bytes of LDS are accumulated in LDS by grid backward. */
 int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes);
+/* Grid backward formulation, process-wide: 0 = owner-computes LDS slices, fp32 accumulation (default),
+ * 1 = same with packed-fp16 accumulation, 2 = the reference's per-corner global atomics (A/B measurements). */
+int tcnn_set_grid_backward_mode(int mode);
 
 #ifdef __cplusplus
 }

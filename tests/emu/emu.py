@@ -98,19 +98,22 @@ def grid_forward(g, params_h, positions, soa=True, out_stride=None, want_dy_dx=F
     return (out, dy_dx) if want_dy_dx else out
 
 
-def grid_backward(g, positions, dL_dy_h, soa=True, lds_budget=0):
+SLICED_F32, SLICED_F16, ATOMIC = 0, 1, 2
+
+
+def grid_backward(g, positions, dL_dy_h, soa=True, mode=SLICED_F32, lds_budget=0, grad_init=None):
+    """grad_init: half bit patterns to accumulate into (GradientMode::Accumulate); None -> Overwrite into a
+    buffer pre-filled with garbage (the kernel must not rely on a zeroed gradient buffer)."""
     og = g.og
     positions = np.ascontiguousarray(positions, dtype=np.float32)
     n = positions.shape[0]
     dL_dy_h = np.ascontiguousarray(dL_dy_h, dtype=np.uint16)
-    F = og.n_features_per_level
-    grad_h = np.zeros(og.n_params, dtype=np.uint16)
-    grad_f = np.zeros(og.n_params, dtype=np.float32) if F == 1 else None
+    grad_h = np.full(og.n_params, 0x3C00, dtype=np.uint16) if grad_init is None else grad_init.copy()
     stride = dL_dy_h.shape[1] if not soa else n
     r = lib().emu_grid_backward(C.byref(g.c), _p(positions), C.c_uint32(n), _p(dL_dy_h), C.c_int(int(soa)),
-                                C.c_uint32(stride), _p(grad_h), _p(grad_f), C.c_uint32(lds_budget))
+                                C.c_uint32(stride), _p(grad_h), C.c_int(int(grad_init is not None)), C.c_int(mode), C.c_uint32(lds_budget))
     assert r == 0
-    return grad_f if F == 1 else grad_h
+    return grad_h
 
 
 def grid_backward_input(g, dL_dy_soa_h, dy_dx):

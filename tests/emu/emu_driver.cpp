@@ -48,10 +48,10 @@ int emu_grid_forward(const EmuGrid* e, const float* positions, uint32_t n, const
 }
 
 int emu_grid_backward(const EmuGrid* e, const float* positions, uint32_t n, const uint16_t* dL_dy, int soa, uint32_t dy_stride,
-                      uint16_t* grad_half, float* grad_f32, uint32_t lds_budget) {
+                      uint16_t* grad_half, int accumulate, int mode, uint32_t lds_budget) {
 	try {
 		GridIO io = {positions, e->n_dims, 1, n, soa ? n : 1u, soa ? 1u : dy_stride};
-		grid_backward(nullptr, make_meta(e), io, (const half_t*)dL_dy, (half_t*)grad_half, grad_f32, lds_budget);
+		grid_backward(nullptr, make_meta(e), io, (const half_t*)dL_dy, (half_t*)grad_half, accumulate != 0, (GridBackwardMode)mode, lds_budget);
 	} catch (const std::exception& ex) {
 		fprintf(stderr, "emu_grid_backward: %s\n", ex.what());
 		return 1;

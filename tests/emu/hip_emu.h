@@ -28,6 +28,12 @@ struct dim3 {
 	dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 typedef void* hipStream_t;
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+inline hipError_t hipMemsetAsync(void* p, int value, size_t bytes, hipStream_t) {
+	memset(p, value, bytes);
+	return hipSuccess;
+}
 
 #define __global__
 #define __device__
@@ -232,6 +238,7 @@ inline void atomic_add_h2(half_t* addr, h2 v) {
 }
 inline void atomic_add_f32(float* addr, float v) { *addr = *addr + v; }
 inline void lds_atomic_add_f32(float* addr, float v) { *addr = *addr + v; }
+inline void lds_atomic_add_h2(h2* addr, h2 v) { atomic_add_h2((half_t*)addr, v); }
 inline h2 fma_h2(h2 a, h2 b, h2 c) {
 	return h2{emu_round_h((double)a[0] * (double)b[0] + (double)c[0]), emu_round_h((double)a[1] * (double)b[1] + (double)c[1])};
 }

@@ -49,10 +49,12 @@ def test_grid_forward_bit_exact(case):
     assert np.array_equal(out_aos[:, :L * F], ref)
 
 
-@pytest.mark.parametrize("case", GRID_CASES)
-@pytest.mark.parametrize("lds_budget", [0, 48 * 1024])
-def test_grid_backward(case, lds_budget):
+@pytest.mark.parametrize("case", GRID_CASES + [(3, 4, 2, 16, 16, 2.0, O.GRID_HASH, O.INTERP_LINEAR)])  # last: > 1 slice per level
+@pytest.mark.parametrize("mode,lds_budget", [(emu.SLICED_F32, 0), (emu.SLICED_F16, 0), (emu.ATOMIC, 0), (emu.ATOMIC, 48 * 1024)])
+def test_grid_backward(case, mode, lds_budget):
     D, L, F, T, base, scale, gtype, interp = case
+    if mode == emu.ATOMIC and F == 1:
+        pytest.skip("the atomic A/B mode needs F >= 2")
     rng = np.random.default_rng(1)
     og = O.grid_init(D, L, F, T, base, scale, gtype, interp)
     g = emu.Grid(og)
@@ -60,11 +62,18 @@ def test_grid_backward(case, lds_budget):
     pos = rng.random((n, D), dtype=np.float32)
     dy = O.f2h(rng.standard_normal((n, L * F)).astype(np.float32))
     ref = O.grid_backward(og, pos, dy)
-    got = emu.grid_backward(g, pos, np.ascontiguousarray(dy.T), soa=True, lds_budget=lds_budget)
-    gotf = got.astype(np.float64) if F == 1 else O.h2f(got).astype(np.float64)
-    # fp16 atomics round after every add: allow 2^-9 of the accumulated magnitude (+ a little absolute slack)
+    dys = np.ascontiguousarray(dy.T)
+    got = emu.grid_backward(g, pos, dys, soa=True, mode=mode, lds_budget=lds_budget)  # Overwrite into a garbage-filled buffer
+    gotf = O.h2f(got).astype(np.float64)
+    # fp16 accumulation rounds after every add: allow 2^-9 of the accumulated magnitude (+ a little absolute slack)
     absacc = O.grid_backward(og, pos, O.f2h(np.abs(O.h2f(dy))))
-    assert np.all(np.abs(gotf - ref) <= absacc * 2.0 ** -9 + 2e-3)
+    tol = absacc * 2.0 ** -9 + 2e-3
+    assert np.all(np.abs(gotf - ref) <= tol)
+    if mode == emu.SLICED_F32:  # fp32 LDS accumulation, one final rounding: much tighter than fp16 atomics
+        assert np.all(np.abs(gotf - ref) <= np.abs(ref) * 2.0 ** -10 + absacc * 2.0 ** -11 + 1e-6)
+    # GradientMode::Accumulate adds to what is there
+    acc = emu.grid_backward(g, pos, dys, soa=True, mode=mode, lds_budget=lds_budget, grad_init=got)
+    assert np.all(np.abs(O.h2f(acc).astype(np.float64) - 2 * ref) <= 2 * tol + np.abs(ref) * 2.0 ** -9)
     dl = emu.grid_backward_input(g, np.ascontiguousarray(dy.T), np.ascontiguousarray(np.transpose(O.grid_forward(og, O.f2h(np.zeros(og.n_params, np.float32) + 0.25), pos, want_dy_dx=True)[1], (1, 0, 2))))
     assert dl.shape == (n, D)
 

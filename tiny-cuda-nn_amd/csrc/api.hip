@@ -6,7 +6,9 @@
 // for the HashGrid + FullyFusedMLP hot path only.  Everything heavy happens in the kernel files.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -168,6 +170,15 @@ struct Profiler {
 	}
 };
 static thread_local Profiler* g_profiler = nullptr;
+
+// grid backward formulation (GridBackwardMode); TCNN_GRID_BACKWARD=sliced_f32|sliced_f16|atomic overrides the default
+static int initial_grid_backward_mode() {
+	const char* e = getenv("TCNN_GRID_BACKWARD");
+	if (e && std::string(e) == "atomic") return (int)GridBackwardMode::Atomic;
+	if (e && std::string(e) == "sliced_f16") return (int)GridBackwardMode::SlicedF16;
+	return (int)GridBackwardMode::SlicedF32;
+}
+static std::atomic<int> g_grid_backward_mode{initial_grid_backward_mode()};
 
 struct ProfScope {
 	hipStream_t stream;
@@ -525,11 +536,6 @@ static void model_forward(hipStream_t stream, const Model& md, uint32_t n, const
 	mlp_forward(stream, md.net.mlp, n, params, enc.as<half_t>(), hidden, output);
 }
 
-__global__ void k_add_f32_to_f16(size_t n, const float* __restrict__ in, half_t* __restrict__ out) {
-	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) out[i] = to_half_rn((float)out[i] + in[i]);
-}
-
 // NetworkWithInputEncoding::backward_impl (:83-113) / GridEncodingTemplated::backward_impl (grid.h:817-908)
 static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const half_t* dL_doutput,
                            half_t* dL_dparams, const float* input, const half_t* params, int gradient_mode, uint32_t lds_level_budget) {
@@ -566,23 +572,10 @@ static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx
 		GridIO io = {input, md.n_input_dims, 1u, n, stride_k, stride_i};
 		if (want_grads && e.n_params > 0) {
 			half_t* grid_grads = dL_dparams + md.n_mlp_params();
-			if (e.grid.n_feat == 1) {  // grad_t == float (grid.h:660-671, 855-863, 890-894)
-				Scratch tmp(stream, (size_t)e.n_params * sizeof(float));
-				HIP_CHECK(hipMemsetAsync(tmp.ptr, 0, (size_t)e.n_params * sizeof(float), stream));
-				grid_backward(stream, e.grid, io, dL_denc, nullptr, tmp.as<float>(), lds_level_budget);
-				if (accumulate) {
-					hipLaunchKernelGGL(k_add_f32_to_f16, dim3((uint32_t)div_round_up((size_t)e.n_params, (size_t)256)), dim3(256), 0, stream, (size_t)e.n_params, tmp.as<float>(), grid_grads);
-				} else {
-					cast_f32_to_f16(stream, e.n_params, tmp.as<float>(), grid_grads);
-				}
-			} else {
-				if (!accumulate) {
-					ProfScope prof(stream, STAGE_GRID_BWD_ZERO);
-					HIP_CHECK(hipMemsetAsync(grid_grads, 0, (size_t)e.n_params * sizeof(half_t), stream));  // grid.h:865-867
-				}
-				ProfScope prof(stream, STAGE_GRID_BWD);
-				grid_backward(stream, e.grid, io, dL_denc, grid_grads, nullptr, lds_level_budget);
-			}
+			// Overwrite vs Accumulate (grid.h:865-867) is handled inside: the owner-computes kernel stores
+			// whole slices, so the reference's full-table memset is only issued for the atomic A/B mode.
+			ProfScope prof(stream, STAGE_GRID_BWD);
+			grid_backward(stream, e.grid, io, dL_denc, grid_grads, accumulate, (GridBackwardMode)g_grid_backward_mode.load(), lds_level_budget);
 		}
 		if (dL_dinput) {
 			if (!ctx.dy_dx.ptr) throw std::runtime_error("backward: dL_dinput requested but forward was not run with prepare_input_gradients");
@@ -613,7 +606,7 @@ using namespace tcnn_hip;
 struct tcnn_module {
 	Model md;
 	std::string name;
-	uint32_t lds_level_budget = 48 * 1024;
+	uint32_t lds_level_budget = 0;  // 0: default LDS slice size of the sliced grid backward
 };
 struct tcnn_context {
 	ForwardCtx ctx;
@@ -643,7 +636,7 @@ struct tcnn_trainable_model {
 	float *m1 = nullptr, *m2 = nullptr;
 	uint32_t* steps = nullptr;
 	uint64_t global_batch = 0;
-	uint32_t lds_level_budget = 48 * 1024;
+	uint32_t lds_level_budget = 0;  // 0: default LDS slice size of the sliced grid backward
 	std::string hyper_json;
 	float* loss_scratch = nullptr;  // 1024 + 1 floats
 	std::unique_ptr<Profiler> profiler;  // null unless tcnn_trainer_set_profiling enabled it
@@ -1051,6 +1044,11 @@ int tcnn_trainer_get_stage_times(tcnn_trainable_model_t* tm, double* total_ms, u
 }
 int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes) {
 	tm->lds_level_budget = bytes;
+	return TCNN_OK;
+}
+int tcnn_set_grid_backward_mode(int mode) {
+	if (mode < 0 || mode > 2) return TCNN_ERROR;
+	g_grid_backward_mode.store(mode);
 	return TCNN_OK;
 }
 

@@ -46,10 +46,16 @@ struct GridIO {
 void grid_forward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* params, half_t* out,
                   float* dy_dx);
 
-// Backward into grid_gradient (half, F >= 2) -- caller zeroes for GradientMode::Overwrite
-// (grid.h:865-867).  For F == 1 pass grad_f32 (fp32 accumulation buffer, grid.h:660-671) instead.
-void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy,
-                   half_t* grid_gradient, float* grad_f32, uint32_t lds_level_budget_bytes);
+// Backward into grid_gradient (half).  accumulate == false overwrites (GradientMode::Overwrite: any zeroing
+// the chosen mode needs is done here, the caller does not memset), true adds to what is there.
+//   SlicedF32 / SlicedF16: owner-computes LDS accumulation (fp32, or packed fp16 like the reference's own
+//                          half2 atomics) -- no global atomics on large levels; the default.
+//   Atomic:                the reference's formulation, global_atomic_pk_add_f16 per corner (F >= 2 only);
+//                          kept for A/B measurements.
+// lds_slice_bytes: LDS bytes one workgroup devotes to its table slice in the sliced modes (0 = default 128 KiB).
+enum class GridBackwardMode : int { SlicedF32 = 0, SlicedF16 = 1, Atomic = 2 };
+void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient, bool accumulate,
+                   GridBackwardMode mode, uint32_t lds_slice_bytes);
 
 // dL_dx[i][d] = sum_k dL_dy[k][i] * dy_dx[k][i][d]   (grid.h:323-349)
 void grid_backward_input(hipStream_t stream, uint32_t n_dims, uint32_t n_features, const GridIO& io,

@@ -3,8 +3,10 @@
 // that indices AND interpolated features are bit-identical to the CPU oracle.
 #include "grid_kernels.h"
 
+#include <algorithm>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 
 namespace tcnn_hip {
 
@@ -14,7 +16,8 @@ constexpr uint32_t GRID_TILE = GRID_THREADS * GRID_SPT;
 
 // Work distribution: block b -> (level, tile) with level % 8 == b % 8.  Blocks are dispatched
 // round-robin over the 8 XCDs (observed, not guaranteed): every XCD then gathers from ceil(L/8)
-// level tables only, in level order, so one table at a time is hot in its private L2.
+// level tables only, in level order, so one table at a time is hot in its private L2
+// (measured: 237 G gathers/s with XCD-local tables vs 67 G/s mixed, profiles/r01_microbench_atomics.txt).
 TCNN_DEVICE bool grid_work_item(uint32_t n_levels, uint32_t tiles, uint32_t& level, uint32_t& tile) {
 	const uint32_t b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
 	if (xcd >= n_levels) return false;
@@ -29,22 +32,96 @@ static uint32_t grid_n_blocks(uint32_t n_levels, uint32_t n) {
 	return 8u * div_round_up(n_levels, 8u) * div_round_up(n, GRID_TILE);
 }
 
+// ---------------------------------------------------------------------------------------------
+// per-level constants and per-sample cell data shared by every kernel below
+// ---------------------------------------------------------------------------------------------
+template <uint32_t D>
+struct Level {
+	uint32_t hashmap_size, resolution, mask;
+	float scale;
+	bool is_hash, smooth, nearest;
+	bool fast;  // hashed level with a power-of-two table: index = coherent_prime_hash & mask
+};
+
+template <uint32_t D>
+TCNN_DEVICE Level<D> make_level(const GridMeta& meta, uint32_t level) {
+	constexpr uint32_t MAX_BASES[11] = {0x0, 0xFFFFFFFF, 0xFFFF, 0x659, 0xFF, 0x54, 0x28, 0x17, 0xF, 0xB, 0x9};
+	Level<D> lv;
+	lv.hashmap_size = meta.offset[level + 1] - meta.offset[level];
+	lv.resolution = meta.resolution[level];
+	lv.mask = lv.hashmap_size - 1u;
+	lv.scale = meta.scale[level];
+	lv.is_hash = meta.grid_type == (uint32_t)GridType::Hash;
+	lv.smooth = meta.interp == (uint32_t)InterpolationType::Smoothstep;
+	lv.nearest = meta.interp == (uint32_t)InterpolationType::Nearest;
+	// same decision as grid_index (common_device.h:868-881): hashed iff hashmap_size < resolution^D
+	uint32_t stride = 0xFFFFFFFFu;
+	if (lv.resolution <= MAX_BASES[D]) {
+		stride = 1;
+#pragma unroll
+		for (uint32_t d = 0; d < D; ++d) stride *= lv.resolution;
+	}
+	lv.fast = lv.is_hash && lv.hashmap_size < stride && (lv.hashmap_size & lv.mask) == 0u;
+	return lv;
+}
+
 TCNN_DEVICE float smoothstep(float v) { return v * v * (3.0f - 2.0f * v); }
 TCNN_DEVICE float smoothstep_derivative(float v) { return 6 * v * (1.0f - v); }
 
-// reference common_device.h:1016-1043
-TCNN_DEVICE void pos_fract(float input, float scale, bool smooth, float& pos, float& pos_derivative, uint32_t& pos_grid) {
-	float p = __builtin_fmaf(scale, input, 0.5f);
-	const float tmp = __builtin_floorf(p);
-	pos_grid = (uint32_t)(int)tmp;
-	p -= tmp;
-	if (smooth) {
-		pos_derivative = smoothstep_derivative(p);
-		pos = smoothstep(p);
-	} else {
-		pos_derivative = 1.0f;
-		pos = p;
+template <uint32_t D>
+struct Cell {
+	uint32_t grid[D];         // integer cell coordinate (may wrap, common_device.h:1002-1007)
+	uint32_t hlo[D], hhi[D];  // grid[d] * prime[d] and (grid[d] + 1) * prime[d]  (mod 2^32)
+	float w[D][2];            // [d][0] = 1 - frac, [d][1] = frac  (after the interpolation function)
+	float derivative[D];
+};
+
+// reference common_device.h:1016-1043 (pos_fract) for every dimension of one sample
+template <uint32_t D, bool FAST>
+TCNN_DEVICE Cell<D> make_cell(const Level<D>& lv, const GridIO& io, uint32_t i) {
+	constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+	Cell<D> c;
+#pragma unroll
+	for (uint32_t d = 0; d < D; ++d) {
+		float p = __builtin_fmaf(lv.scale, io.positions[(size_t)i * io.pos_stride_i + (size_t)d * io.pos_stride_d], 0.5f);
+		const float tmp = __builtin_floorf(p);
+		c.grid[d] = (uint32_t)(int)tmp;
+		p -= tmp;
+		c.derivative[d] = lv.smooth ? smoothstep_derivative(p) : 1.0f;
+		if (lv.smooth) p = smoothstep(p);
+		c.w[d][0] = 1 - p;
+		c.w[d][1] = p;
+		if constexpr (FAST) {
+			c.hlo[d] = c.grid[d] * primes[d];
+			c.hhi[d] = c.hlo[d] + primes[d];
+		}
 	}
+	return c;
+}
+
+// entry index of corner `idx` (bit d of idx selects +1 in dimension d, grid.h:147-160)
+template <uint32_t D, bool FAST>
+TCNN_DEVICE uint32_t corner_index(const Level<D>& lv, const Cell<D>& c, uint32_t idx) {
+	if constexpr (FAST) {
+		uint32_t h = 0;
+#pragma unroll
+		for (uint32_t d = 0; d < D; ++d) h ^= ((idx >> d) & 1u) ? c.hhi[d] : c.hlo[d];
+		return h & lv.mask;
+	} else {
+		uint32_t local[D];
+#pragma unroll
+		for (uint32_t d = 0; d < D; ++d) local[d] = c.grid[d] + ((idx >> d) & 1u);
+		return grid_index<D>(lv.is_hash, lv.hashmap_size, lv.resolution, local);
+	}
+}
+
+// interpolation weight of corner `idx`: ((1 * w0) * w1) * w2 ... in the reference's order (grid.h:148-160)
+template <uint32_t D>
+TCNN_DEVICE float corner_weight(const Cell<D>& c, uint32_t idx) {
+	float weight = ((idx & 1u) ? c.w[0][1] : c.w[0][0]);
+#pragma unroll
+	for (uint32_t d = 1; d < D; ++d) weight *= ((idx >> d) & 1u) ? c.w[d][1] : c.w[d][0];
+	return weight;
 }
 
 // F halves at `p` -> NP packed pairs (F == 1: {x, 0})
@@ -68,282 +145,249 @@ TCNN_DEVICE void load_features(const half_t* p, h2 (&v)[(F + 1) / 2]) {
 	}
 }
 
-template <uint32_t D, uint32_t F>
+// =============================================================================================
+// forward (grid.h:49-212)
+// =============================================================================================
+template <uint32_t D, uint32_t F, bool DYDX, bool FAST>
+TCNN_DEVICE void grid_forward_sample(const Level<D>& lv, const GridIO& io, const half_t* __restrict__ grid, uint32_t level, uint32_t i,
+                                     bool level_off, half_t* __restrict__ out, float* __restrict__ dy_dx) {
+	constexpr uint32_t NP = (F + 1) / 2;
+	h2 result[NP];
+#pragma unroll
+	for (uint32_t p = 0; p < NP; ++p) result[p] = h2{(half_t)0.0f, (half_t)0.0f};
+	float grads[DYDX ? F : 1][D];
+#pragma unroll
+	for (uint32_t f = 0; f < (DYDX ? F : 1); ++f)
+#pragma unroll
+		for (uint32_t d = 0; d < D; ++d) grads[f][d] = 0.0f;
+
+	if (!level_off) {
+		const Cell<D> c = make_cell<D, FAST>(lv, io, i);
+		if (lv.nearest) {
+			load_features<F>(grid + (size_t)corner_index<D, FAST>(lv, c, 0) * F, result);
+		} else {
+			// N-linear interpolation, corner order and fp16 fma chain of grid.h:144-163
+#pragma unroll
+			for (uint32_t idx = 0; idx < (1u << D); ++idx) {
+				h2 val[NP];
+				load_features<F>(grid + (size_t)corner_index<D, FAST>(lv, c, idx) * F, val);
+				const half_t wh = to_half_rn(corner_weight<D>(c, idx));
+				const h2 w2 = h2{wh, wh};
+#pragma unroll
+				for (uint32_t p = 0; p < NP; ++p) result[p] = fma_h2(w2, val[p], result[p]);
+			}
+			if constexpr (DYDX) {  // grid.h:172-211
+#pragma unroll
+				for (uint32_t gd = 0; gd < D; ++gd) {
+#pragma unroll
+					for (uint32_t idx = 0; idx < (1u << (D - 1)); ++idx) {
+						float weight = lv.scale;
+						uint32_t corner = 0;  // corner with the gradient dimension at its low side
+#pragma unroll
+						for (uint32_t ngd = 0; ngd < D - 1; ++ngd) {
+							const uint32_t dim = ngd >= gd ? (ngd + 1) : ngd;
+							const uint32_t bit = (idx >> ngd) & 1u;
+							weight *= bit ? c.w[dim][1] : c.w[dim][0];
+							corner |= bit << dim;
+						}
+						h2 vl[NP], vr[NP];
+						load_features<F>(grid + (size_t)corner_index<D, FAST>(lv, c, corner) * F, vl);
+						load_features<F>(grid + (size_t)corner_index<D, FAST>(lv, c, corner | (1u << gd)) * F, vr);
+#pragma unroll
+						for (uint32_t f = 0; f < F; ++f) {
+							const float diff = (float)vr[f / 2][f % 2] - (float)vl[f / 2][f % 2];
+							float t = weight * diff;
+							t = t * c.derivative[gd];
+							grads[f][gd] = grads[f][gd] + t;
+						}
+					}
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (uint32_t f = 0; f < F; ++f) {
+		const uint32_t k = level * F + f;
+		if (out) out[(size_t)k * io.stride_k + (size_t)i * io.stride_i] = result[f / 2][f % 2];
+		if constexpr (DYDX) {
+#pragma unroll
+			for (uint32_t d = 0; d < D; ++d) dy_dx[((size_t)k * io.n + i) * D + d] = grads[f][d];
+		}
+	}
+}
+
+template <uint32_t D, uint32_t F, bool DYDX>
 __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward(const GridMeta meta, const GridIO io, const half_t* __restrict__ params,
                                                                 half_t* __restrict__ out, float* __restrict__ dy_dx) {
 	uint32_t level, tile;
 	if (!grid_work_item(meta.n_levels, div_round_up(io.n, GRID_TILE), level, tile)) return;
-
-	constexpr uint32_t NP = (F + 1) / 2;
-	const uint32_t hashmap_size = meta.offset[level + 1] - meta.offset[level];
+	const Level<D> lv = make_level<D>(meta, level);
 	const half_t* __restrict__ grid = params + (size_t)meta.offset[level] * F;
-	const float scale = meta.scale[level];
-	const uint32_t resolution = meta.resolution[level];
-	const bool is_hash = meta.grid_type == (uint32_t)GridType::Hash;
-	const bool smooth = meta.interp == (uint32_t)InterpolationType::Smoothstep;
-	const bool nearest = meta.interp == (uint32_t)InterpolationType::Nearest;
 	const uint32_t n_features = meta.n_levels * F;
 	const float max_level = (meta.max_level * (float)n_features) / (float)F;  // grid.h:72
 	const bool level_off = (float)level >= max_level + 1e-3f;               // grid.h:75
-
+	if (lv.fast) {  // wave-uniform: one lean code path per level kind
 #pragma unroll
-	for (uint32_t s = 0; s < GRID_SPT; ++s) {
-		const uint32_t i = tile * GRID_TILE + s * GRID_THREADS + threadIdx.x;
-		if (i >= io.n) continue;
-
-		h2 result[NP];
-#pragma unroll
-		for (uint32_t p = 0; p < NP; ++p) result[p] = h2{(half_t)0.0f, (half_t)0.0f};
-		float grads[F][D];
-#pragma unroll
-		for (uint32_t f = 0; f < F; ++f)
-#pragma unroll
-			for (uint32_t d = 0; d < D; ++d) grads[f][d] = 0.0f;
-
-		if (!level_off) {
-			float pos[D], pos_derivative[D];
-			uint32_t pos_grid[D];
-#pragma unroll
-			for (uint32_t d = 0; d < D; ++d) {
-				pos_fract(io.positions[(size_t)i * io.pos_stride_i + (size_t)d * io.pos_stride_d], scale, smooth, pos[d], pos_derivative[d], pos_grid[d]);
-			}
-
-			if (nearest) {
-				const uint32_t index = grid_index<D>(is_hash, hashmap_size, resolution, pos_grid);
-				load_features<F>(grid + (size_t)index * F, result);
-			} else {
-				// N-linear interpolation, corner order and fp16 fma chain of grid.h:144-163
-#pragma unroll
-				for (uint32_t idx = 0; idx < (1u << D); ++idx) {
-					float weight = 1;
-					uint32_t local[D];
-#pragma unroll
-					for (uint32_t d = 0; d < D; ++d) {
-						if ((idx & (1u << d)) == 0) {
-							weight *= 1 - pos[d];
-							local[d] = pos_grid[d];
-						} else {
-							weight *= pos[d];
-							local[d] = pos_grid[d] + 1;
-						}
-					}
-					const uint32_t index = grid_index<D>(is_hash, hashmap_size, resolution, local);
-					h2 val[NP];
-					load_features<F>(grid + (size_t)index * F, val);
-					const half_t wh = to_half_rn(weight);
-					const h2 w2 = h2{wh, wh};
-#pragma unroll
-					for (uint32_t p = 0; p < NP; ++p) result[p] = fma_h2(w2, val[p], result[p]);
-				}
-
-				if (dy_dx) {  // grid.h:172-211
-#pragma unroll
-					for (uint32_t gd = 0; gd < D; ++gd) {
-#pragma unroll
-						for (uint32_t idx = 0; idx < (1u << (D - 1)); ++idx) {
-							float weight = scale;
-							uint32_t local[D];
-#pragma unroll
-							for (uint32_t ngd = 0; ngd < D - 1; ++ngd) {
-								const uint32_t dim = ngd >= gd ? (ngd + 1) : ngd;
-								if ((idx & (1u << ngd)) == 0) {
-									weight *= 1 - pos[dim];
-									local[dim] = pos_grid[dim];
-								} else {
-									weight *= pos[dim];
-									local[dim] = pos_grid[dim] + 1;
-								}
-							}
-							local[gd] = pos_grid[gd];
-							h2 vl[NP], vr[NP];
-							load_features<F>(grid + (size_t)grid_index<D>(is_hash, hashmap_size, resolution, local) * F, vl);
-							local[gd] = pos_grid[gd] + 1;
-							load_features<F>(grid + (size_t)grid_index<D>(is_hash, hashmap_size, resolution, local) * F, vr);
-#pragma unroll
-							for (uint32_t f = 0; f < F; ++f) {
-								const float diff = (float)vr[f / 2][f % 2] - (float)vl[f / 2][f % 2];
-								float t = weight * diff;
-								t = t * pos_derivative[gd];
-								grads[f][gd] = grads[f][gd] + t;
-							}
-						}
-					}
-				}
-			}
+		for (uint32_t s = 0; s < GRID_SPT; ++s) {
+			const uint32_t i = tile * GRID_TILE + s * GRID_THREADS + threadIdx.x;
+			if (i < io.n) grid_forward_sample<D, F, DYDX, true>(lv, io, grid, level, i, level_off, out, dy_dx);
 		}
-
-#pragma unroll
-		for (uint32_t f = 0; f < F; ++f) {
-			const uint32_t k = level * F + f;
-			if (out) out[(size_t)k * io.stride_k + (size_t)i * io.stride_i] = result[f / 2][f % 2];
-			if (dy_dx) {
-#pragma unroll
-				for (uint32_t d = 0; d < D; ++d) dy_dx[((size_t)k * io.n + i) * D + d] = grads[f][d];
-			}
-		}
-	}
-}
-
-struct SmallLevels {
-	uint32_t mask[4];    // bit l set: level l is handled by the LDS kernel
-	uint32_t count;
-	uint32_t levels[16]; // first `count` small levels
-};
-
-template <uint32_t F, typename GRAD_T>
-TCNN_DEVICE void scatter_add(GRAD_T* grad, uint32_t index, const h2 (&g)[(F + 1) / 2], float weight) {
-	if constexpr (F == 1) {
-		// grad_t == float when F == 1 (grid.h:665): fp32 product, fp32 atomic
-		atomic_add_f32(grad + index, weight * (float)g[0][0]);
 	} else {
-		const half_t wh = to_half_rn(weight);
-		const h2 w2 = h2{wh, wh};
-#pragma unroll
-		for (uint32_t p = 0; p < F / 2; ++p) atomic_add_h2(grad + (size_t)index * F + 2 * p, w2 * g[p]);  // (GRAD_T)weight * grad, grid.h:254
+		for (uint32_t s = 0; s < GRID_SPT; ++s) {
+			const uint32_t i = tile * GRID_TILE + s * GRID_THREADS + threadIdx.x;
+			if (i < io.n) grid_forward_sample<D, F, DYDX, false>(lv, io, grid, level, i, level_off, out, dy_dx);
+		}
 	}
 }
 
-template <uint32_t D, uint32_t F, typename GRAD_T>
-__global__ void __launch_bounds__(GRID_THREADS) k_grid_backward(const GridMeta meta, const GridIO io, const SmallLevels small,
-                                                                 const half_t* __restrict__ dL_dy, GRAD_T* __restrict__ grid_gradient) {
+// =============================================================================================
+// backward, the reference's formulation (grid.h:215-320): one packed-half global atomic per corner.
+// Kept for A/B measurements only (F >= 2): scattered global atomics top out at ~21 G updates/s on
+// MI355X whatever their flavour (profiles/r01_microbench_atomics.txt) -- 1.6 ms for one headline step.
+// =============================================================================================
+template <uint32_t D, uint32_t F>
+__global__ void __launch_bounds__(GRID_THREADS) k_grid_backward_atomic(const GridMeta meta, const GridIO io, const half_t* __restrict__ dL_dy,
+                                                                        half_t* __restrict__ grid_gradient) {
 	uint32_t level, tile;
 	if (!grid_work_item(meta.n_levels, div_round_up(io.n, GRID_TILE), level, tile)) return;
-	if (small.mask[level >> 5] & (1u << (level & 31u))) return;
-
-	constexpr uint32_t NP = (F + 1) / 2;
 	const uint32_t n_features = meta.n_levels * F;
 	const float max_level = (meta.max_level * (float)n_features) / (float)F;
 	if ((float)level > max_level + 1e-3f) return;  // grid.h:242 (sic: '>' here, '>=' in forward)
+	const Level<D> lv = make_level<D>(meta, level);
+	half_t* __restrict__ grad = grid_gradient + (size_t)meta.offset[level] * F;
 
-	const uint32_t hashmap_size = meta.offset[level + 1] - meta.offset[level];
-	GRAD_T* __restrict__ grad = grid_gradient + (size_t)meta.offset[level] * F;
-	const float scale = meta.scale[level];
-	const uint32_t resolution = meta.resolution[level];
-	const bool is_hash = meta.grid_type == (uint32_t)GridType::Hash;
-	const bool smooth = meta.interp == (uint32_t)InterpolationType::Smoothstep;
-	const bool nearest = meta.interp == (uint32_t)InterpolationType::Nearest;
-
-#pragma unroll
 	for (uint32_t s = 0; s < GRID_SPT; ++s) {
 		const uint32_t i = tile * GRID_TILE + s * GRID_THREADS + threadIdx.x;
 		if (i >= io.n) continue;
-
-		float pos[D], pos_derivative[D];
-		uint32_t pos_grid[D];
+		const Cell<D> c = make_cell<D, false>(lv, io, i);
+		h2 g[F / 2];
 #pragma unroll
-		for (uint32_t d = 0; d < D; ++d) {
-			pos_fract(io.positions[(size_t)i * io.pos_stride_i + (size_t)d * io.pos_stride_d], scale, smooth, pos[d], pos_derivative[d], pos_grid[d]);
+		for (uint32_t p = 0; p < F / 2; ++p) {
+			g[p] = h2{dL_dy[(size_t)(level * F + 2 * p) * io.stride_k + (size_t)i * io.stride_i],
+			          dL_dy[(size_t)(level * F + 2 * p + 1) * io.stride_k + (size_t)i * io.stride_i]};
 		}
-		h2 g[NP];
+		const uint32_t n_corners = lv.nearest ? 1u : (1u << D);
+		for (uint32_t idx = 0; idx < n_corners; ++idx) {
+			const half_t wh = lv.nearest ? (half_t)1.0f : to_half_rn(corner_weight<D>(c, idx));
+			const h2 w2 = h2{wh, wh};
+			const uint32_t index = corner_index<D, false>(lv, c, idx);
 #pragma unroll
-		for (uint32_t p = 0; p < NP; ++p) g[p] = h2{(half_t)0.0f, (half_t)0.0f};
-#pragma unroll
-		for (uint32_t f = 0; f < F; ++f) g[f / 2][f % 2] = dL_dy[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i];
-
-		if (nearest) {
-			scatter_add<F, GRAD_T>(grad, grid_index<D>(is_hash, hashmap_size, resolution, pos_grid), g, 1.0f);
-			continue;
-		}
-#pragma unroll
-		for (uint32_t idx = 0; idx < (1u << D); ++idx) {
-			float weight = 1;
-			uint32_t local[D];
-#pragma unroll
-			for (uint32_t d = 0; d < D; ++d) {
-				if ((idx & (1u << d)) == 0) {
-					weight *= 1 - pos[d];
-					local[d] = pos_grid[d];
-				} else {
-					weight *= pos[d];
-					local[d] = pos_grid[d] + 1;
-				}
-			}
-			scatter_add<F, GRAD_T>(grad, grid_index<D>(is_hash, hashmap_size, resolution, local), g, weight);
+			for (uint32_t p = 0; p < F / 2; ++p) atomic_add_h2(grad + (size_t)index * F + 2 * p, w2 * g[p]);  // (GRAD_T)weight * grad, grid.h:254
 		}
 	}
 }
 
-// Small levels: the whole level table lives in LDS as fp32; one flush of packed-half atomics per
-// workgroup.  Removes the atomic hot-spotting of coarse levels (level 0 of the headline config has
-// 4096 entries receiving 2^21 updates per step).
-constexpr uint32_t GRID_LDS_THREADS = 512;
-constexpr uint32_t GRID_LDS_SAMPLES_PER_BLOCK = 16384;
+// =============================================================================================
+// backward, owner-computes form (the default).  No global atomics: a workgroup OWNS a contiguous
+// slice of one level's table, keeps it in LDS, walks all samples, recomputes the corner indices
+// (integer ALU is cheap) and accumulates only the corners that fall into its slice (ds_add_f32 /
+// ds_pk_add_f16); the slice is then written back with plain coalesced stores -- which also makes the
+// reference's per-step gradient memset (grid.h:865-867) unnecessary.  Levels whose whole table fits
+// one slice are instead split over several sample chunks and flushed with a few atomics.
+// =============================================================================================
+constexpr uint32_t SLICED_THREADS = 1024;
+constexpr uint32_t SLICED_LDS_BYTES = 128 * 1024;      // default slice size
+constexpr uint32_t SLICED_LDS_MAX_BYTES = 160 * 1024;  // one CU's LDS
 
-template <uint32_t D, uint32_t F, typename GRAD_T>
-__global__ void __launch_bounds__(GRID_LDS_THREADS) k_grid_backward_lds(const GridMeta meta, const GridIO io, const SmallLevels small,
-                                                                          const half_t* __restrict__ dL_dy, GRAD_T* __restrict__ grid_gradient) {
+struct SlicePlan {
+	uint32_t block_begin[MAX_N_LEVELS + 1];  // first workgroup of each level
+	uint32_t n_slices[MAX_N_LEVELS];
+	uint32_t entries_per_slice;
+};
+
+template <uint32_t D, uint32_t F, bool PACKED, bool FAST>
+TCNN_DEVICE void sliced_accumulate(const Level<D>& lv, const GridIO& io, const half_t* __restrict__ dL_dy, uint32_t level, uint32_t begin,
+                                   uint32_t end, uint32_t slice_begin, uint32_t slice_count, float* tab_f, h2* tab_h) {
+	constexpr uint32_t N_CORNERS = 1u << D;
+	for (uint32_t i = begin + threadIdx.x; i < end; i += SLICED_THREADS) {
+		const Cell<D> c = make_cell<D, FAST>(lv, io, i);
+		// which of this sample's corners live in my slice?
+		uint32_t match = 0;
+#pragma unroll
+		for (uint32_t idx = 0; idx < N_CORNERS; ++idx) {
+			const uint32_t rel = corner_index<D, FAST>(lv, c, idx) - slice_begin;
+			if (rel < slice_count) match |= 1u << idx;
+		}
+		if (lv.nearest) match &= 1u;
+		if (match == 0) continue;
+
+		half_t g[F];
+#pragma unroll
+		for (uint32_t f = 0; f < F; ++f) g[f] = dL_dy[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i];
+
+		while (match) {
+			const uint32_t idx = (uint32_t)__builtin_ctz(match);
+			match &= match - 1;
+			const uint32_t rel = corner_index<D, FAST>(lv, c, idx) - slice_begin;
+			const float weight = lv.nearest ? 1.0f : corner_weight<D>(c, idx);
+			const half_t wh = to_half_rn(weight);  // (GRAD_T)weight, grid.h:254
+			if constexpr (PACKED) {
+				const h2 w2 = h2{wh, wh};
+#pragma unroll
+				for (uint32_t p = 0; p < F / 2; ++p) lds_atomic_add_h2(&tab_h[rel * (F / 2) + p], w2 * h2{g[2 * p], g[2 * p + 1]});
+			} else {
+				const float wq = F == 1 ? weight : (float)wh;  // F == 1: grad_t is float in the reference (grid.h:665)
+#pragma unroll
+				for (uint32_t f = 0; f < F; ++f) lds_atomic_add_f32(&tab_f[rel * F + f], wq * (float)g[f]);
+			}
+		}
+	}
+}
+
+template <uint32_t D, uint32_t F, bool PACKED>
+__global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const GridMeta meta, const GridIO io, const SlicePlan plan,
+                                                                           const half_t* __restrict__ dL_dy, half_t* __restrict__ grid_gradient,
+                                                                           const int accumulate) {
 	TCNN_DYN_LDS(lds_raw);
-	float* lds_table = (float*)lds_raw;
-	const uint32_t chunks = div_round_up(io.n, GRID_LDS_SAMPLES_PER_BLOCK);
-	const uint32_t level = small.levels[blockIdx.x / chunks];
-	const uint32_t chunk = blockIdx.x % chunks;
+	float* tab_f = (float*)lds_raw;  // [entries][F] fp32        (!PACKED)
+	h2* tab_h = (h2*)lds_raw;        // [entries][F/2] half2     (PACKED)
+
+	uint32_t level = 0;
+	while (level + 1 < meta.n_levels && blockIdx.x >= plan.block_begin[level + 1]) ++level;
+	const uint32_t local_block = blockIdx.x - plan.block_begin[level];
+	const uint32_t n_slices = plan.n_slices[level];
+	const uint32_t n_chunks = (plan.block_begin[level + 1] - plan.block_begin[level]) / n_slices;
+	const uint32_t slice = local_block % n_slices, chunk = local_block / n_slices;
 
 	const uint32_t n_features = meta.n_levels * F;
 	const float max_level = (meta.max_level * (float)n_features) / (float)F;
-	if ((float)level > max_level + 1e-3f) return;
+	const bool level_off = (float)level > max_level + 1e-3f;  // grid.h:242
 
-	const uint32_t hashmap_size = meta.offset[level + 1] - meta.offset[level];
-	GRAD_T* __restrict__ grad = grid_gradient + (size_t)meta.offset[level] * F;
-	const float scale = meta.scale[level];
-	const uint32_t resolution = meta.resolution[level];
-	const bool is_hash = meta.grid_type == (uint32_t)GridType::Hash;
-	const bool smooth = meta.interp == (uint32_t)InterpolationType::Smoothstep;
-	const bool nearest = meta.interp == (uint32_t)InterpolationType::Nearest;
+	const Level<D> lv = make_level<D>(meta, level);
+	const uint32_t slice_begin = slice * plan.entries_per_slice;
+	const uint32_t slice_count = min(plan.entries_per_slice, lv.hashmap_size - slice_begin);
+	half_t* __restrict__ grad = grid_gradient + ((size_t)meta.offset[level] + slice_begin) * F;
 
-	for (uint32_t e = threadIdx.x; e < hashmap_size * F; e += GRID_LDS_THREADS) lds_table[e] = 0.0f;
+	const uint32_t lds_words = PACKED ? slice_count * (F / 2) : slice_count * F;
+	for (uint32_t e = threadIdx.x; e < lds_words; e += SLICED_THREADS) tab_f[e] = 0.0f;  // 0.0f == packed (0, 0)
 	__syncthreads();
 
-	const uint32_t begin = chunk * GRID_LDS_SAMPLES_PER_BLOCK;
-	const uint32_t end = min(begin + GRID_LDS_SAMPLES_PER_BLOCK, io.n);
-	for (uint32_t i = begin + threadIdx.x; i < end; i += GRID_LDS_THREADS) {
-		float pos[D], pos_derivative[D];
-		uint32_t pos_grid[D];
-#pragma unroll
-		for (uint32_t d = 0; d < D; ++d) {
-			pos_fract(io.positions[(size_t)i * io.pos_stride_i + (size_t)d * io.pos_stride_d], scale, smooth, pos[d], pos_derivative[d], pos_grid[d]);
-		}
-		float g[F];
-#pragma unroll
-		for (uint32_t f = 0; f < F; ++f) g[f] = (float)dL_dy[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i];
-
-		if (nearest) {
-			const uint32_t index = grid_index<D>(is_hash, hashmap_size, resolution, pos_grid);
-#pragma unroll
-			for (uint32_t f = 0; f < F; ++f) lds_atomic_add_f32(&lds_table[index * F + f], g[f]);
-			continue;
-		}
-#pragma unroll
-		for (uint32_t idx = 0; idx < (1u << D); ++idx) {
-			float weight = 1;
-			uint32_t local[D];
-#pragma unroll
-			for (uint32_t d = 0; d < D; ++d) {
-				if ((idx & (1u << d)) == 0) {
-					weight *= 1 - pos[d];
-					local[d] = pos_grid[d];
-				} else {
-					weight *= pos[d];
-					local[d] = pos_grid[d] + 1;
-				}
-			}
-			const uint32_t index = grid_index<D>(is_hash, hashmap_size, resolution, local);
-			// same operand rounding as the atomic path: weight rounded to half first (grid.h:254)
-			const float wq = F == 1 ? weight : (float)to_half_rn(weight);
-#pragma unroll
-			for (uint32_t f = 0; f < F; ++f) lds_atomic_add_f32(&lds_table[index * F + f], wq * g[f]);
+	if (!level_off) {
+		const uint32_t per_chunk = div_round_up(io.n, n_chunks);
+		const uint32_t begin = chunk * per_chunk;
+		const uint32_t end = min(begin + per_chunk, io.n);
+		if (lv.fast) {
+			sliced_accumulate<D, F, PACKED, true>(lv, io, dL_dy, level, begin, end, slice_begin, slice_count, tab_f, tab_h);
+		} else {
+			sliced_accumulate<D, F, PACKED, false>(lv, io, dL_dy, level, begin, end, slice_begin, slice_count, tab_f, tab_h);
 		}
 	}
 	__syncthreads();
 
-	if constexpr (F == 1) {
-		for (uint32_t e = threadIdx.x; e < hashmap_size; e += GRID_LDS_THREADS) {
-			const float v = lds_table[e];
-			if (v != 0.0f) atomic_add_f32((float*)grad + e, v);
+	// ---- write the slice back: this workgroup is its only writer when n_chunks == 1
+	const uint32_t n_halves = slice_count * F;  // even: level sizes are multiples of 8
+	for (uint32_t e2 = threadIdx.x; e2 < n_halves / 2; e2 += SLICED_THREADS) {
+		h2 v;
+		if constexpr (PACKED) {
+			v = tab_h[e2];
+		} else {
+			v = h2{(half_t)tab_f[2 * e2], (half_t)tab_f[2 * e2 + 1]};
 		}
-	} else {
-		for (uint32_t e = threadIdx.x; e < hashmap_size * F / 2; e += GRID_LDS_THREADS) {
-			const float a = lds_table[2 * e], b = lds_table[2 * e + 1];
-			if (a != 0.0f || b != 0.0f) atomic_add_h2((half_t*)grad + 2 * (size_t)e, h2{(half_t)a, (half_t)b});
+		if (n_chunks == 1) {
+			if (accumulate) v += *(const h2*)(grad + 2 * e2);
+			*(h2*)(grad + 2 * e2) = v;
+		} else if (v[0] != (half_t)0.0f || v[1] != (half_t)0.0f) {
+			atomic_add_h2(grad + 2 * e2, v);  // few: (table size) x (chunks) per level, small tables only
 		}
 	}
 }
@@ -368,19 +412,16 @@ template <uint32_t D>
 __global__ void k_grid_indices(const GridMeta meta, const GridIO io, uint32_t* __restrict__ indices) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= io.n) return;
-	const bool is_hash = meta.grid_type == (uint32_t)GridType::Hash;
-	const bool smooth = meta.interp == (uint32_t)InterpolationType::Smoothstep;
 	for (uint32_t level = 0; level < meta.n_levels; ++level) {
-		const uint32_t hashmap_size = meta.offset[level + 1] - meta.offset[level];
-		float pos[D], pd[D];
-		uint32_t pos_grid[D];
-		for (uint32_t d = 0; d < D; ++d) {
-			pos_fract(io.positions[(size_t)i * io.pos_stride_i + (size_t)d * io.pos_stride_d], meta.scale[level], smooth, pos[d], pd[d], pos_grid[d]);
-		}
+		const Level<D> lv = make_level<D>(meta, level);
 		for (uint32_t idx = 0; idx < (1u << D); ++idx) {
-			uint32_t local[D];
-			for (uint32_t d = 0; d < D; ++d) local[d] = pos_grid[d] + ((idx >> d) & 1u);
-			indices[((size_t)i * meta.n_levels + level) * (1u << D) + idx] = grid_index<D>(is_hash, hashmap_size, meta.resolution[level], local);
+			uint32_t index;
+			if (lv.fast) {
+				index = corner_index<D, true>(lv, make_cell<D, true>(lv, io, i), idx);
+			} else {
+				index = corner_index<D, false>(lv, make_cell<D, false>(lv, io, i), idx);
+			}
+			indices[((size_t)i * meta.n_levels + level) * (1u << D) + idx] = index;
 		}
 	}
 }
@@ -409,44 +450,84 @@ __global__ void k_grid_indices(const GridMeta meta, const GridIO io, uint32_t* _
 void grid_forward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* params, half_t* out, float* dy_dx) {
 	if (io.n == 0) return;
 	const uint32_t blocks = grid_n_blocks(meta.n_levels, io.n);
-#define FWD(D_, F_) TCNN_LAUNCH((k_grid_forward<D_, F_>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, dy_dx)
+#define FWD(D_, F_)                                                                                                                        \
+	if (dy_dx) {                                                                                                                           \
+		TCNN_LAUNCH((k_grid_forward<D_, F_, true>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, dy_dx);            \
+	} else {                                                                                                                               \
+		TCNN_LAUNCH((k_grid_forward<D_, F_, false>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, (float*)nullptr); \
+	}
 	TCNN_GRID_DISPATCH(FWD)
 #undef FWD
 }
 
-void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient,
-                   float* grad_f32, uint32_t lds_level_budget_bytes) {
-	if (io.n == 0) return;
-	SmallLevels small = {};
-	uint32_t max_lds_bytes = 0;
-	for (uint32_t l = 0; l < meta.n_levels && small.count < 16; ++l) {
-		const uint32_t bytes = (meta.offset[l + 1] - meta.offset[l]) * meta.n_feat * (uint32_t)sizeof(float);
-		if (bytes <= lds_level_budget_bytes) {
-			small.mask[l >> 5] |= 1u << (l & 31u);
-			small.levels[small.count++] = l;
-			if (bytes > max_lds_bytes) max_lds_bytes = bytes;
-		}
+static void grid_backward_atomic(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient,
+                                 bool accumulate) {
+	if (meta.n_feat == 1) throw std::runtime_error("grid_backward (atomic mode): n_features_per_level == 1 is only supported by the sliced modes");
+	const size_t n_params = (size_t)meta.offset[meta.n_levels] * meta.n_feat;
+	if (!accumulate) {  // grid.h:865-867
+		if (hipMemsetAsync(grid_gradient, 0, n_params * sizeof(half_t), stream) != hipSuccess) throw std::runtime_error("grid_backward: memset failed");
 	}
 	const uint32_t blocks = grid_n_blocks(meta.n_levels, io.n);
-	const uint32_t lds_blocks = small.count * div_round_up(io.n, GRID_LDS_SAMPLES_PER_BLOCK);
-	if (meta.n_feat == 1) {
-		if (!grad_f32) throw std::runtime_error("grid_backward: F == 1 needs the fp32 gradient accumulation buffer");
-	} else if (!grid_gradient) {
-		throw std::runtime_error("grid_backward: missing gradient buffer");
-	}
-#define BWD(D_, F_)                                                                                                              \
-	{                                                                                                                            \
-		using G = std::conditional_t<F_ == 1, float, half_t>;                                                                    \
-		G* gp = (G*)(F_ == 1 ? (void*)grad_f32 : (void*)grid_gradient);                                                          \
-		if (lds_blocks > 0) TCNN_SET_MAX_DYN_LDS((k_grid_backward_lds<D_, F_, G>), max_lds_bytes);                                \
-		if (lds_blocks > 0)                                                                                                      \
-			TCNN_LAUNCH((k_grid_backward_lds<D_, F_, G>), dim3(lds_blocks), dim3(GRID_LDS_THREADS), max_lds_bytes, stream, meta, \
-			            io, small, dL_dy, gp);                                                                                   \
-		if (small.count < meta.n_levels)                                                                                         \
-			TCNN_LAUNCH((k_grid_backward<D_, F_, G>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, small, dL_dy, gp);  \
+#define BWD(D_, F_)                                                                                                                    \
+	if constexpr (F_ != 1) {                                                                                                           \
+		TCNN_LAUNCH((k_grid_backward_atomic<D_, F_>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, dL_dy, grid_gradient);    \
 	}
 	TCNN_GRID_DISPATCH(BWD)
 #undef BWD
+}
+
+static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient,
+                                 bool accumulate, bool packed, uint32_t lds_slice_bytes) {
+	const uint32_t F = meta.n_feat;
+	packed = packed && (F % 2 == 0);
+	const uint32_t entry_bytes = F * (packed ? (uint32_t)sizeof(half_t) : (uint32_t)sizeof(float));
+	if (lds_slice_bytes == 0 || lds_slice_bytes > SLICED_LDS_MAX_BYTES) lds_slice_bytes = SLICED_LDS_BYTES;
+	lds_slice_bytes = std::max(lds_slice_bytes / entry_bytes, 8u) * entry_bytes;
+	SlicePlan plan = {};
+	plan.entries_per_slice = lds_slice_bytes / entry_bytes;
+	uint32_t blocks = 0;
+	for (uint32_t l = 0; l < meta.n_levels; ++l) {
+		const uint32_t entries = meta.offset[l + 1] - meta.offset[l];
+		const uint32_t n_slices = div_round_up(entries, plan.entries_per_slice);
+		// small tables: split the SAMPLES over a few workgroups instead (flushed with atomics)
+		uint32_t n_chunks = n_slices >= 8 ? 1u : 8u / n_slices;
+		n_chunks = std::max(1u, std::min(n_chunks, div_round_up(io.n, 4096u)));
+		plan.block_begin[l] = blocks;
+		plan.n_slices[l] = n_slices;
+		blocks += n_slices * n_chunks;
+		if (n_chunks > 1 && !accumulate) {  // atomically flushed levels start from zero
+			if (hipMemsetAsync(grid_gradient + (size_t)meta.offset[l] * F, 0, (size_t)entries * F * sizeof(half_t), stream) != hipSuccess) {
+				throw std::runtime_error("grid_backward: memset failed");
+			}
+		}
+	}
+	plan.block_begin[meta.n_levels] = blocks;
+	const int acc = accumulate ? 1 : 0;
+#define BWDS(D_, F_)                                                                                                                    \
+	if (packed) {                                                                                                                       \
+		if constexpr (F_ % 2 == 0) {                                                                                                    \
+			TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, true>), lds_slice_bytes);                                              \
+			TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, true>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io, \
+			            plan, dL_dy, grid_gradient, acc);                                                                               \
+		}                                                                                                                               \
+	} else {                                                                                                                            \
+		TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, false>), lds_slice_bytes);                                                 \
+		TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, false>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io,     \
+		            plan, dL_dy, grid_gradient, acc);                                                                                   \
+	}
+	TCNN_GRID_DISPATCH(BWDS)
+#undef BWDS
+}
+
+void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient, bool accumulate,
+                   GridBackwardMode mode, uint32_t lds_slice_bytes) {
+	if (io.n == 0) return;
+	if (!grid_gradient) throw std::runtime_error("grid_backward: missing gradient buffer");
+	switch (mode) {
+		case GridBackwardMode::SlicedF32: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, false, lds_slice_bytes); break;
+		case GridBackwardMode::SlicedF16: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, true, lds_slice_bytes); break;
+		case GridBackwardMode::Atomic: grid_backward_atomic(stream, meta, io, dL_dy, grid_gradient, accumulate); break;
+	}
 }
 
 void grid_backward_input(hipStream_t stream, uint32_t n_dims, uint32_t n_features, const GridIO& io, const half_t* dL_dy,

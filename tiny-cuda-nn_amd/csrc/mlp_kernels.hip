@@ -381,12 +381,23 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 
 __global__ void k_mlp_finalize_gradients(uint32_t n_params, uint32_t n_partials, const float* __restrict__ partials, half_t* __restrict__ grads,
                                          int accumulate) {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n_params) return;
+	// 256 threads = 32 parameters x 8 slab groups; fixed summation order -> deterministic gradients
+	__shared__ float red[8][32];
+	const uint32_t lane = threadIdx.x & 31u, group = threadIdx.x >> 5;
+	const uint32_t i = blockIdx.x * 32u + lane;
 	float s = 0.0f;
-	for (uint32_t b = 0; b < n_partials; ++b) s += partials[(size_t)b * n_params + i];
-	if (accumulate) s += (float)grads[i];
-	grads[i] = to_half_rn(s);
+	if (i < n_params) {
+		for (uint32_t b = group; b < n_partials; b += 8) s += partials[(size_t)b * n_params + i];
+	}
+	red[group][lane] = s;
+	__syncthreads();
+	if (group == 0 && i < n_params) {
+		float t = red[0][lane];
+#pragma unroll
+		for (uint32_t k = 1; k < 8; ++k) t += red[k][lane];
+		if (accumulate) t += (float)grads[i];
+		grads[i] = to_half_rn(t);
+	}
 }
 
 // =============================================================================================
@@ -479,7 +490,7 @@ void mlp_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t
 }
 
 void mlp_finalize_gradients(hipStream_t stream, uint32_t n_params, uint32_t n_partials, const float* partials, half_t* grads, bool accumulate) {
-	TCNN_LAUNCH(k_mlp_finalize_gradients, dim3(div_round_up(n_params, 256u)), dim3(256), 0, stream, n_params, n_partials, partials, grads, accumulate ? 1 : 0);
+	TCNN_LAUNCH(k_mlp_finalize_gradients, dim3(div_round_up(n_params, 32u)), dim3(256), 0, stream, n_params, n_partials, partials, grads, accumulate ? 1 : 0);
 }
 
 }  // namespace tcnn_hip

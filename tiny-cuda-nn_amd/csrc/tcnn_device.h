@@ -62,6 +62,9 @@ TCNN_DEVICE void atomic_add_h2(half_t* addr, h2 v) {
 }
 TCNN_DEVICE void atomic_add_f32(float* addr, float v) { unsafeAtomicAdd(addr, v); }
 TCNN_DEVICE void lds_atomic_add_f32(float* addr, float v) { atomicAdd(addr, v); }  // ds_add_f32
+TCNN_DEVICE void lds_atomic_add_h2(h2* addr, h2 v) {  // ds_pk_add_f16
+	__builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) h2*)addr, v);
+}
 TCNN_DEVICE h2 fma_h2(h2 a, h2 b, h2 c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f16
 TCNN_DEVICE half_t fma_h(half_t a, half_t b, half_t c) { return __builtin_fmaf16(a, b, c); }
 TCNN_DEVICE uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)); }  // HW_REG_XCC_ID
@@ -124,6 +127,10 @@ TCNN_HOST_DEVICE uint32_t grid_index(bool is_hash, uint32_t hashmap_size, uint32
 		stride = 0xFFFFFFFFu;
 	}
 	if (is_hash && hashmap_size < stride) index = coherent_prime_hash<D>(p);
+	// hashed levels have power-of-two tables (min(dense, 2^log2_hashmap_size)): a mask instead of the
+	// ~15-instruction u32 remainder; the condition is wave-uniform (one level per workgroup)
+	const uint32_t mask = hashmap_size - 1u;
+	if ((hashmap_size & mask) == 0u) return index & mask;
 	return index % hashmap_size;
 }
 

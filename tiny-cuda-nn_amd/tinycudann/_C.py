@@ -113,6 +113,7 @@ _sig("tcnn_trainer_n_stages", _i)
 _sig("tcnn_trainer_stage_name", _cp, _i)
 _sig("tcnn_trainer_get_stage_times", _i, _vp, _vp, _vp)
 _sig("tcnn_trainer_set_lds_level_budget", _i, _vp, _u32)
+_sig("tcnn_set_grid_backward_mode", _i, _i)
 
 EXPORTED_SYMBOLS = [n for n in dir(_lib) if n.startswith("tcnn_")]
 
@@ -149,6 +150,11 @@ def preferred_precision():
 
 def supports_jit_fusion(device=-1):
     return bool(_lib.tcnn_supports_jit_fusion(device))
+
+
+def set_grid_backward_mode(mode):
+    """0: owner-computes LDS slices (fp32 accumulate, default); 1: same, packed fp16; 2: global atomics (A/B)."""
+    _check(_lib.tcnn_set_grid_backward_mode(int(mode)))
 
 
 def rtc_set_cache_dir(_dir):  # no runtime compilation in this build

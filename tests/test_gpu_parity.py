@@ -107,18 +107,19 @@ def test_grid_backward_and_input_gradient(d, enc):
     ref = O.grid_backward(og, pos, dy)
     absacc = O.grid_backward(og, pos, O.f2h(np.abs(O.h2f(dy))))
     try:
-        for mode in (1, 2, 0):  # packed-fp16 LDS slices, the reference's global atomics (A/B), fp32 LDS slices (default, last)
+        for mode in (0, 2, 1):  # fp32 LDS slices, the reference's global atomics (A/B), packed-fp16 LDS slices (default, last)
             if mode == 2 and enc.get("n_features_per_level", 2) == 1:
                 continue
             C.set_grid_backward_mode(mode)
             dx, dp = m.bwd(ctx, x, p, y, h_t(dy))
             torch.cuda.synchronize()
             got = dp.float().cpu().numpy().astype(np.float64)
-            assert np.all(np.abs(got - ref) <= absacc * 2.0 ** -9 + 2e-3), f"grid backward mode {mode}"
+            # modes 1 and 2 add up to hundreds of terms per entry in fp16, in hardware order: 2^-8 of the magnitude
+            assert np.all(np.abs(got - ref) <= absacc * 2.0 ** (-9 if mode == 0 else -8) + 2e-3), f"grid backward mode {mode}"
             if mode == 0:  # fp32 accumulation, one final rounding to half
                 assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -10 + absacc * 2.0 ** -11 + 1e-6)
     finally:
-        C.set_grid_backward_mode(0)
+        C.set_grid_backward_mode(1)
     if enc.get("interpolation", "Linear") != "Nearest":
         _, dy_dx = O.grid_forward(og, params, pos, want_dy_dx=True)
         dref = O.grid_backward_input(og, dy, dy_dx)

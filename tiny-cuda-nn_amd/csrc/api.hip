@@ -175,8 +175,8 @@ static thread_local Profiler* g_profiler = nullptr;
 static int initial_grid_backward_mode() {
 	const char* e = getenv("TCNN_GRID_BACKWARD");
 	if (e && std::string(e) == "atomic") return (int)GridBackwardMode::Atomic;
-	if (e && std::string(e) == "sliced_f16") return (int)GridBackwardMode::SlicedF16;
-	return (int)GridBackwardMode::SlicedF32;
+	if (e && std::string(e) == "sliced_f32") return (int)GridBackwardMode::SlicedF32;
+	return (int)GridBackwardMode::SlicedF16;  // default: fixed-point coarse levels + packed-fp16 slices (the reference's accumulation type)
 }
 static std::atomic<int> g_grid_backward_mode{initial_grid_backward_mode()};
 

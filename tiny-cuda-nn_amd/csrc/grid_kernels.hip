@@ -278,35 +278,54 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_backward_atomic(const Gri
 }
 
 // =============================================================================================
-// backward, owner-computes form (the default).  No global atomics: a workgroup OWNS a contiguous
-// slice of one level's table, keeps it in LDS, walks all samples, recomputes the corner indices
-// (integer ALU is cheap) and accumulates only the corners that fall into its slice (ds_add_f32 /
-// ds_pk_add_f16); the slice is then written back with plain coalesced stores -- which also makes the
-// reference's per-step gradient memset (grid.h:865-867) unnecessary.  Levels whose whole table fits
-// one slice are instead split over several sample chunks and flushed with a few atomics.
+// backward, owner-computes form (the default).  No global atomics on the hot path: a workgroup OWNS a
+// contiguous slice of one level's table, keeps it in LDS, walks the samples, recomputes the corner
+// indices (integer ALU is cheap) and accumulates only the corners that fall into its slice; the slice
+// is then written back with plain coalesced stores -- which also makes the reference's per-step
+// gradient memset (grid.h:865-867) unnecessary.
+//
+// Measured LDS atomic rates that shape this (profiles/r01_microbench_lds_atomics.txt): a dense
+// ds_add_f32 / ds_pk_add_f16 wave instruction costs ~170 clk (floating-point LDS atomics are serialised
+// per lane, ~2.6 clk each), a dense ds_add_u32 / ds_add_u64 7 / 11 clk; with <= 2-3 active lanes all of
+// them cost ~7 clk.  Hence two accumulator kinds, chosen per level on the host:
+//   * small tables (coarse levels, nearly every corner of every sample hits the slice -> dense
+//     atomics): 64-bit fixed point (2^-24 resolution, exact and order-independent, cannot overflow for
+//     any fp16 input), the SAMPLES are additionally split over several workgroups, each flushing its
+//     partial table with a few packed-half global atomics;
+//   * large tables (fine / hashed levels, a slice sees ~1/16 of the corners -> sparse atomics):
+//     packed fp16 (the reference's own accumulation type, vec.h:328-351) or fp32 slices.
 // =============================================================================================
 constexpr uint32_t SLICED_THREADS = 1024;
 constexpr uint32_t SLICED_LDS_BYTES = 128 * 1024;      // default slice size
 constexpr uint32_t SLICED_LDS_MAX_BYTES = 160 * 1024;  // one CU's LDS
+constexpr double FIXED_SCALE = 16777216.0;             // 2^24: below the smallest fp16 subnormal
+
+enum SliceKind : uint32_t { SLICE_FIXED64 = 0, SLICE_FLOAT = 1 };
 
 struct SlicePlan {
 	uint32_t block_begin[MAX_N_LEVELS + 1];  // first workgroup of each level
 	uint32_t n_slices[MAX_N_LEVELS];
-	uint32_t entries_per_slice;
+	uint32_t entries_per_slice[2];           // per SliceKind
+	uint32_t kind_mask[MAX_N_LEVELS / 32];   // bit set: SLICE_FLOAT
 };
 
-template <uint32_t D, uint32_t F, bool PACKED, bool FAST>
+enum class Acc { F32, PK16, FIX64 };
+
+template <uint32_t D, uint32_t F, Acc ACC, bool FAST>
 TCNN_DEVICE void sliced_accumulate(const Level<D>& lv, const GridIO& io, const half_t* __restrict__ dL_dy, uint32_t level, uint32_t begin,
-                                   uint32_t end, uint32_t slice_begin, uint32_t slice_count, float* tab_f, h2* tab_h) {
+                                   uint32_t end, uint32_t slice_begin, uint32_t slice_count, unsigned char* lds_raw) {
 	constexpr uint32_t N_CORNERS = 1u << D;
+	float* tab_f = (float*)lds_raw;                            // [entries][F]
+	h2* tab_h = (h2*)lds_raw;                                  // [entries][F/2]
+	unsigned long long* tab_q = (unsigned long long*)lds_raw;  // [entries][F]
 	for (uint32_t i = begin + threadIdx.x; i < end; i += SLICED_THREADS) {
 		const Cell<D> c = make_cell<D, FAST>(lv, io, i);
-		// which of this sample's corners live in my slice?
+		// which of this sample's corners live in my slice?  (branch-free bit mask)
 		uint32_t match = 0;
 #pragma unroll
 		for (uint32_t idx = 0; idx < N_CORNERS; ++idx) {
 			const uint32_t rel = corner_index<D, FAST>(lv, c, idx) - slice_begin;
-			if (rel < slice_count) match |= 1u << idx;
+			match |= (rel < slice_count ? 1u : 0u) << idx;
 		}
 		if (lv.nearest) match &= 1u;
 		if (match == 0) continue;
@@ -321,15 +340,69 @@ TCNN_DEVICE void sliced_accumulate(const Level<D>& lv, const GridIO& io, const h
 			const uint32_t rel = corner_index<D, FAST>(lv, c, idx) - slice_begin;
 			const float weight = lv.nearest ? 1.0f : corner_weight<D>(c, idx);
 			const half_t wh = to_half_rn(weight);  // (GRAD_T)weight, grid.h:254
-			if constexpr (PACKED) {
+			if constexpr (ACC == Acc::PK16) {
 				const h2 w2 = h2{wh, wh};
 #pragma unroll
 				for (uint32_t p = 0; p < F / 2; ++p) lds_atomic_add_h2(&tab_h[rel * (F / 2) + p], w2 * h2{g[2 * p], g[2 * p + 1]});
 			} else {
 				const float wq = F == 1 ? weight : (float)wh;  // F == 1: grad_t is float in the reference (grid.h:665)
 #pragma unroll
-				for (uint32_t f = 0; f < F; ++f) lds_atomic_add_f32(&tab_f[rel * F + f], wq * (float)g[f]);
+				for (uint32_t f = 0; f < F; ++f) {
+					const float prod = wq * (float)g[f];
+					if constexpr (ACC == Acc::FIX64) {
+						const long long q = (long long)__builtin_rint((double)prod * FIXED_SCALE);
+						lds_atomic_add_u64(&tab_q[rel * F + f], (unsigned long long)q);
+					} else {
+						lds_atomic_add_f32(&tab_f[rel * F + f], prod);
+					}
+				}
 			}
+		}
+	}
+}
+
+template <uint32_t D, uint32_t F, Acc ACC>
+TCNN_DEVICE void sliced_level(const GridMeta& meta, const GridIO& io, const Level<D>& lv, uint32_t level, uint32_t slice, uint32_t chunk,
+                              uint32_t n_chunks, uint32_t entries_per_slice, const half_t* __restrict__ dL_dy, half_t* __restrict__ grid_gradient,
+                              bool accumulate, bool level_off, unsigned char* lds_raw) {
+	const uint32_t slice_begin = slice * entries_per_slice;
+	const uint32_t slice_count = min(entries_per_slice, lv.hashmap_size - slice_begin);
+	half_t* __restrict__ grad = grid_gradient + ((size_t)meta.offset[level] + slice_begin) * F;
+
+	constexpr uint32_t WORDS_PER_VALUE_X2 = ACC == Acc::FIX64 ? 4 : (ACC == Acc::F32 ? 2 : 1);  // 32-bit words per value, times two
+	const uint32_t lds_words = slice_count * F * WORDS_PER_VALUE_X2 / 2;
+	for (uint32_t e = threadIdx.x; e < lds_words; e += SLICED_THREADS) ((uint32_t*)lds_raw)[e] = 0u;  // +0.0f / (0, 0) / 0
+	__syncthreads();
+
+	if (!level_off) {
+		const uint32_t per_chunk = div_round_up(io.n, n_chunks);
+		const uint32_t begin = chunk * per_chunk;
+		const uint32_t end = min(begin + per_chunk, io.n);
+		if (lv.fast) {
+			sliced_accumulate<D, F, ACC, true>(lv, io, dL_dy, level, begin, end, slice_begin, slice_count, lds_raw);
+		} else {
+			sliced_accumulate<D, F, ACC, false>(lv, io, dL_dy, level, begin, end, slice_begin, slice_count, lds_raw);
+		}
+	}
+	__syncthreads();
+
+	// ---- write the slice back: this workgroup is its only writer when n_chunks == 1
+	const uint32_t n_halves = slice_count * F;  // even: level sizes are multiples of 8
+	for (uint32_t e2 = threadIdx.x; e2 < n_halves / 2; e2 += SLICED_THREADS) {
+		h2 v;
+		if constexpr (ACC == Acc::PK16) {
+			v = ((const h2*)lds_raw)[e2];
+		} else if constexpr (ACC == Acc::F32) {
+			v = h2{(half_t)((const float*)lds_raw)[2 * e2], (half_t)((const float*)lds_raw)[2 * e2 + 1]};
+		} else {
+			const long long q0 = ((const long long*)lds_raw)[2 * e2], q1 = ((const long long*)lds_raw)[2 * e2 + 1];
+			v = h2{(half_t)(float)((double)q0 * (1.0 / FIXED_SCALE)), (half_t)(float)((double)q1 * (1.0 / FIXED_SCALE))};
+		}
+		if (n_chunks == 1) {
+			if (accumulate) v += *(const h2*)(grad + 2 * e2);
+			*(h2*)(grad + 2 * e2) = v;
+		} else if (v[0] != (half_t)0.0f || v[1] != (half_t)0.0f) {
+			atomic_add_h2(grad + 2 * e2, v);  // (table size) x (chunks) per level, small tables only
 		}
 	}
 }
@@ -339,56 +412,25 @@ __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const G
                                                                            const half_t* __restrict__ dL_dy, half_t* __restrict__ grid_gradient,
                                                                            const int accumulate) {
 	TCNN_DYN_LDS(lds_raw);
-	float* tab_f = (float*)lds_raw;  // [entries][F] fp32        (!PACKED)
-	h2* tab_h = (h2*)lds_raw;        // [entries][F/2] half2     (PACKED)
-
 	uint32_t level = 0;
 	while (level + 1 < meta.n_levels && blockIdx.x >= plan.block_begin[level + 1]) ++level;
 	const uint32_t local_block = blockIdx.x - plan.block_begin[level];
 	const uint32_t n_slices = plan.n_slices[level];
 	const uint32_t n_chunks = (plan.block_begin[level + 1] - plan.block_begin[level]) / n_slices;
 	const uint32_t slice = local_block % n_slices, chunk = local_block / n_slices;
+	const uint32_t kind = (plan.kind_mask[level >> 5] >> (level & 31u)) & 1u;
 
 	const uint32_t n_features = meta.n_levels * F;
 	const float max_level = (meta.max_level * (float)n_features) / (float)F;
 	const bool level_off = (float)level > max_level + 1e-3f;  // grid.h:242
-
 	const Level<D> lv = make_level<D>(meta, level);
-	const uint32_t slice_begin = slice * plan.entries_per_slice;
-	const uint32_t slice_count = min(plan.entries_per_slice, lv.hashmap_size - slice_begin);
-	half_t* __restrict__ grad = grid_gradient + ((size_t)meta.offset[level] + slice_begin) * F;
 
-	const uint32_t lds_words = PACKED ? slice_count * (F / 2) : slice_count * F;
-	for (uint32_t e = threadIdx.x; e < lds_words; e += SLICED_THREADS) tab_f[e] = 0.0f;  // 0.0f == packed (0, 0)
-	__syncthreads();
-
-	if (!level_off) {
-		const uint32_t per_chunk = div_round_up(io.n, n_chunks);
-		const uint32_t begin = chunk * per_chunk;
-		const uint32_t end = min(begin + per_chunk, io.n);
-		if (lv.fast) {
-			sliced_accumulate<D, F, PACKED, true>(lv, io, dL_dy, level, begin, end, slice_begin, slice_count, tab_f, tab_h);
-		} else {
-			sliced_accumulate<D, F, PACKED, false>(lv, io, dL_dy, level, begin, end, slice_begin, slice_count, tab_f, tab_h);
-		}
-	}
-	__syncthreads();
-
-	// ---- write the slice back: this workgroup is its only writer when n_chunks == 1
-	const uint32_t n_halves = slice_count * F;  // even: level sizes are multiples of 8
-	for (uint32_t e2 = threadIdx.x; e2 < n_halves / 2; e2 += SLICED_THREADS) {
-		h2 v;
-		if constexpr (PACKED) {
-			v = tab_h[e2];
-		} else {
-			v = h2{(half_t)tab_f[2 * e2], (half_t)tab_f[2 * e2 + 1]};
-		}
-		if (n_chunks == 1) {
-			if (accumulate) v += *(const h2*)(grad + 2 * e2);
-			*(h2*)(grad + 2 * e2) = v;
-		} else if (v[0] != (half_t)0.0f || v[1] != (half_t)0.0f) {
-			atomic_add_h2(grad + 2 * e2, v);  // few: (table size) x (chunks) per level, small tables only
-		}
+	if (kind == SLICE_FIXED64) {
+		sliced_level<D, F, Acc::FIX64>(meta, io, lv, level, slice, chunk, n_chunks, plan.entries_per_slice[SLICE_FIXED64], dL_dy, grid_gradient,
+		                               accumulate != 0, level_off, lds_raw);
+	} else {
+		sliced_level<D, F, PACKED ? Acc::PK16 : Acc::F32>(meta, io, lv, level, slice, chunk, n_chunks, plan.entries_per_slice[SLICE_FLOAT], dL_dy,
+		                                                   grid_gradient, accumulate != 0, level_off, lds_raw);
 	}
 }
 
@@ -480,18 +522,22 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
                                  bool accumulate, bool packed, uint32_t lds_slice_bytes) {
 	const uint32_t F = meta.n_feat;
 	packed = packed && (F % 2 == 0);
-	const uint32_t entry_bytes = F * (packed ? (uint32_t)sizeof(half_t) : (uint32_t)sizeof(float));
 	if (lds_slice_bytes == 0 || lds_slice_bytes > SLICED_LDS_MAX_BYTES) lds_slice_bytes = SLICED_LDS_BYTES;
-	lds_slice_bytes = std::max(lds_slice_bytes / entry_bytes, 8u) * entry_bytes;
+	const uint32_t float_entry_bytes = F * (packed ? (uint32_t)sizeof(half_t) : (uint32_t)sizeof(float));
+	const uint32_t fixed_entry_bytes = F * (uint32_t)sizeof(unsigned long long);
+	lds_slice_bytes = std::max(lds_slice_bytes / fixed_entry_bytes, 8u) * fixed_entry_bytes;
 	SlicePlan plan = {};
-	plan.entries_per_slice = lds_slice_bytes / entry_bytes;
+	plan.entries_per_slice[SLICE_FIXED64] = lds_slice_bytes / fixed_entry_bytes;
+	plan.entries_per_slice[SLICE_FLOAT] = lds_slice_bytes / float_entry_bytes;
 	uint32_t blocks = 0;
 	for (uint32_t l = 0; l < meta.n_levels; ++l) {
 		const uint32_t entries = meta.offset[l + 1] - meta.offset[l];
-		const uint32_t n_slices = div_round_up(entries, plan.entries_per_slice);
-		// small tables: split the SAMPLES over a few workgroups instead (flushed with atomics)
-		uint32_t n_chunks = n_slices >= 8 ? 1u : 8u / n_slices;
-		n_chunks = std::max(1u, std::min(n_chunks, div_round_up(io.n, 4096u)));
+		// coarse level (dense LDS atomics): <= 4 fixed-point slices; split the samples over ~32 workgroups
+		const uint32_t n_fixed = div_round_up(entries, plan.entries_per_slice[SLICE_FIXED64]);
+		const bool fixed = n_fixed <= 4;
+		const uint32_t n_slices = fixed ? n_fixed : div_round_up(entries, plan.entries_per_slice[SLICE_FLOAT]);
+		uint32_t n_chunks = fixed ? std::max(1u, std::min(32u / n_slices, div_round_up(io.n, 2048u))) : 1u;
+		if (!fixed) plan.kind_mask[l >> 5] |= 1u << (l & 31u);
 		plan.block_begin[l] = blocks;
 		plan.n_slices[l] = n_slices;
 		blocks += n_slices * n_chunks;
@@ -503,17 +549,17 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 	}
 	plan.block_begin[meta.n_levels] = blocks;
 	const int acc = accumulate ? 1 : 0;
-#define BWDS(D_, F_)                                                                                                                    \
-	if (packed) {                                                                                                                       \
-		if constexpr (F_ % 2 == 0) {                                                                                                    \
-			TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, true>), lds_slice_bytes);                                              \
+#define BWDS(D_, F_)                                                                                                                   \
+	if (packed) {                                                                                                                      \
+		if constexpr (F_ % 2 == 0) {                                                                                                   \
+			TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, true>), lds_slice_bytes);                                             \
 			TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, true>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io, \
-			            plan, dL_dy, grid_gradient, acc);                                                                               \
-		}                                                                                                                               \
-	} else {                                                                                                                            \
-		TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, false>), lds_slice_bytes);                                                 \
-		TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, false>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io,     \
-		            plan, dL_dy, grid_gradient, acc);                                                                                   \
+			            plan, dL_dy, grid_gradient, acc);                                                                              \
+		}                                                                                                                              \
+	} else {                                                                                                                           \
+		TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, false>), lds_slice_bytes);                                                \
+		TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, false>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io,    \
+		            plan, dL_dy, grid_gradient, acc);                                                                                  \
 	}
 	TCNN_GRID_DISPATCH(BWDS)
 #undef BWDS

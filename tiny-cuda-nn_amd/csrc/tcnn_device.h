@@ -62,6 +62,7 @@ TCNN_DEVICE void atomic_add_h2(half_t* addr, h2 v) {
 }
 TCNN_DEVICE void atomic_add_f32(float* addr, float v) { unsafeAtomicAdd(addr, v); }
 TCNN_DEVICE void lds_atomic_add_f32(float* addr, float v) { atomicAdd(addr, v); }  // ds_add_f32
+TCNN_DEVICE void lds_atomic_add_u64(unsigned long long* addr, unsigned long long v) { atomicAdd(addr, v); }  // ds_add_u64
 TCNN_DEVICE void lds_atomic_add_h2(h2* addr, h2 v) {  // ds_pk_add_f16
 	__builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) h2*)addr, v);
 }

@@ -76,14 +76,14 @@ struct Cell {
 	float derivative[D];
 };
 
-// reference common_device.h:1016-1043 (pos_fract) for every dimension of one sample
+// reference common_device.h:1016-1043 (pos_fract) for every dimension of one sample (x = its position)
 template <uint32_t D, bool FAST>
-TCNN_DEVICE Cell<D> make_cell(const Level<D>& lv, const GridIO& io, uint32_t i) {
+TCNN_DEVICE Cell<D> make_cell(const Level<D>& lv, const float (&x)[D]) {
 	constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
 	Cell<D> c;
 #pragma unroll
 	for (uint32_t d = 0; d < D; ++d) {
-		float p = __builtin_fmaf(lv.scale, io.positions[(size_t)i * io.pos_stride_i + (size_t)d * io.pos_stride_d], 0.5f);
+		float p = __builtin_fmaf(lv.scale, x[d], 0.5f);
 		const float tmp = __builtin_floorf(p);
 		c.grid[d] = (uint32_t)(int)tmp;
 		p -= tmp;
@@ -97,6 +97,19 @@ TCNN_DEVICE Cell<D> make_cell(const Level<D>& lv, const GridIO& io, uint32_t i) 
 		}
 	}
 	return c;
+}
+
+template <uint32_t D>
+TCNN_DEVICE void load_position(const GridIO& io, uint32_t i, float (&x)[D]) {
+#pragma unroll
+	for (uint32_t d = 0; d < D; ++d) x[d] = io.positions[(size_t)i * io.pos_stride_i + (size_t)d * io.pos_stride_d];
+}
+
+template <uint32_t D, bool FAST>
+TCNN_DEVICE Cell<D> make_cell(const Level<D>& lv, const GridIO& io, uint32_t i) {
+	float x[D];
+	load_position<D>(io, i, x);
+	return make_cell<D, FAST>(lv, x);
 }
 
 // entry index of corner `idx` (bit d of idx selects +1 in dimension d, grid.h:147-160)
@@ -318,42 +331,53 @@ TCNN_DEVICE void sliced_accumulate(const Level<D>& lv, const GridIO& io, const h
 	float* tab_f = (float*)lds_raw;                            // [entries][F]
 	h2* tab_h = (h2*)lds_raw;                                  // [entries][F/2]
 	unsigned long long* tab_q = (unsigned long long*)lds_raw;  // [entries][F]
-	for (uint32_t i = begin + threadIdx.x; i < end; i += SLICED_THREADS) {
-		const Cell<D> c = make_cell<D, FAST>(lv, io, i);
-		// which of this sample's corners live in my slice?  (branch-free bit mask)
-		uint32_t match = 0;
+	// U samples per lane and iteration: all their position / gradient loads are issued before the first
+	// use (each workgroup streams the whole batch; with one sample in flight the loop is latency-bound).
+	constexpr uint32_t U = 4;
+	for (uint32_t base = begin + threadIdx.x; base < end; base += SLICED_THREADS * U) {
+		float x[U][D];
+		half_t g[U][F];
 #pragma unroll
-		for (uint32_t idx = 0; idx < N_CORNERS; ++idx) {
-			const uint32_t rel = corner_index<D, FAST>(lv, c, idx) - slice_begin;
-			match |= (rel < slice_count ? 1u : 0u) << idx;
+		for (uint32_t u = 0; u < U; ++u) {
+			const uint32_t i = min(base + u * SLICED_THREADS, end - 1);  // clamped: out-of-range lanes are masked below
+			load_position<D>(io, i, x[u]);
+#pragma unroll
+			for (uint32_t f = 0; f < F; ++f) g[u][f] = dL_dy[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i];
 		}
-		if (lv.nearest) match &= 1u;
-		if (match == 0) continue;
+#pragma unroll
+		for (uint32_t u = 0; u < U; ++u) {
+			const Cell<D> c = make_cell<D, FAST>(lv, x[u]);
+			// which of this sample's corners live in my slice?  (branch-free bit mask)
+			uint32_t match = 0;
+#pragma unroll
+			for (uint32_t idx = 0; idx < N_CORNERS; ++idx) {
+				const uint32_t rel = corner_index<D, FAST>(lv, c, idx) - slice_begin;
+				match |= (rel < slice_count ? 1u : 0u) << idx;
+			}
+			if (lv.nearest) match &= 1u;
+			if (base + u * SLICED_THREADS >= end) match = 0;
 
-		half_t g[F];
+			while (match) {
+				const uint32_t idx = (uint32_t)__builtin_ctz(match);
+				match &= match - 1;
+				const uint32_t rel = corner_index<D, FAST>(lv, c, idx) - slice_begin;
+				const float weight = lv.nearest ? 1.0f : corner_weight<D>(c, idx);
+				const half_t wh = to_half_rn(weight);  // (GRAD_T)weight, grid.h:254
+				if constexpr (ACC == Acc::PK16) {
+					const h2 w2 = h2{wh, wh};
 #pragma unroll
-		for (uint32_t f = 0; f < F; ++f) g[f] = dL_dy[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i];
-
-		while (match) {
-			const uint32_t idx = (uint32_t)__builtin_ctz(match);
-			match &= match - 1;
-			const uint32_t rel = corner_index<D, FAST>(lv, c, idx) - slice_begin;
-			const float weight = lv.nearest ? 1.0f : corner_weight<D>(c, idx);
-			const half_t wh = to_half_rn(weight);  // (GRAD_T)weight, grid.h:254
-			if constexpr (ACC == Acc::PK16) {
-				const h2 w2 = h2{wh, wh};
+					for (uint32_t p = 0; p < F / 2; ++p) lds_atomic_add_h2(&tab_h[rel * (F / 2) + p], w2 * h2{g[u][2 * p], g[u][2 * p + 1]});
+				} else {
+					const float wq = F == 1 ? weight : (float)wh;  // F == 1: grad_t is float in the reference (grid.h:665)
 #pragma unroll
-				for (uint32_t p = 0; p < F / 2; ++p) lds_atomic_add_h2(&tab_h[rel * (F / 2) + p], w2 * h2{g[2 * p], g[2 * p + 1]});
-			} else {
-				const float wq = F == 1 ? weight : (float)wh;  // F == 1: grad_t is float in the reference (grid.h:665)
-#pragma unroll
-				for (uint32_t f = 0; f < F; ++f) {
-					const float prod = wq * (float)g[f];
-					if constexpr (ACC == Acc::FIX64) {
-						const long long q = (long long)__builtin_rint((double)prod * FIXED_SCALE);
-						lds_atomic_add_u64(&tab_q[rel * F + f], (unsigned long long)q);
-					} else {
-						lds_atomic_add_f32(&tab_f[rel * F + f], prod);
+					for (uint32_t f = 0; f < F; ++f) {
+						const float prod = wq * (float)g[u][f];
+						if constexpr (ACC == Acc::FIX64) {
+							const long long q = (long long)__builtin_rint((double)prod * FIXED_SCALE);
+							lds_atomic_add_u64(&tab_q[rel * F + f], (unsigned long long)q);
+						} else {
+							lds_atomic_add_f32(&tab_f[rel * F + f], prod);
+						}
 					}
 				}
 			}
@@ -532,11 +556,13 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 	uint32_t blocks = 0;
 	for (uint32_t l = 0; l < meta.n_levels; ++l) {
 		const uint32_t entries = meta.offset[l + 1] - meta.offset[l];
-		// coarse level (dense LDS atomics): <= 4 fixed-point slices; split the samples over ~32 workgroups
+		// Accumulator kind by expected atomic density: with <= 32 fixed-point slices a float slice would see
+		// >= 1 matching corner per sample (dense, serialised float atomics) -> 64-bit fixed point.  Tables of
+		// <= 4 slices additionally split the samples over up to 16 workgroups (few flush atomics).
 		const uint32_t n_fixed = div_round_up(entries, plan.entries_per_slice[SLICE_FIXED64]);
-		const bool fixed = n_fixed <= 4;
+		const bool fixed = n_fixed <= 32;
 		const uint32_t n_slices = fixed ? n_fixed : div_round_up(entries, plan.entries_per_slice[SLICE_FLOAT]);
-		uint32_t n_chunks = fixed ? std::max(1u, std::min(32u / n_slices, div_round_up(io.n, 2048u))) : 1u;
+		uint32_t n_chunks = (fixed && n_slices <= 4) ? std::max(1u, std::min(16u / n_slices, div_round_up(io.n, 2048u))) : 1u;
 		if (!fixed) plan.kind_mask[l >> 5] |= 1u << (l & 31u);
 		plan.block_begin[l] = blocks;
 		plan.n_slices[l] = n_slices;

@@ -318,11 +318,22 @@ enum SliceKind : uint32_t { SLICE_FIXED64 = 0, SLICE_FLOAT = 1 };
 struct SlicePlan {
 	uint32_t block_begin[MAX_N_LEVELS + 1];  // first workgroup of each level
 	uint32_t n_slices[MAX_N_LEVELS];
-	uint32_t entries_per_slice[2];           // per SliceKind
 	uint32_t kind_mask[MAX_N_LEVELS / 32];   // bit set: SLICE_FLOAT
 };
 
 enum class Acc { F32, PK16, FIX64 };
+
+// round(v * 2^24) as a 64-bit integer using fp32 / int32 ops only (no fp64 conversions in the hot loop).
+// v is a product of two halves: |v| <= 2^32 and at most 22 significant bits, so v * 2^8 splits exactly into an
+// integer part (|hi| <= 2^40 would overflow -> clamp to the fp16 range first: |v| <= 65504 < 2^16 -> |hi| < 2^24)
+// and a fraction |r| < 1 that is rounded to 16 bits.
+TCNN_DEVICE long long to_fixed(float v) {
+	v = __builtin_fminf(__builtin_fmaxf(v, -65504.0f), 65504.0f);
+	const float s = v * 256.0f;
+	const float hi = __builtin_truncf(s);
+	const int lo = (int)__builtin_rintf((s - hi) * 65536.0f);
+	return (long long)(int)hi * 65536ll + (long long)lo;
+}
 
 template <uint32_t D, uint32_t F, Acc ACC, bool FAST>
 TCNN_DEVICE void sliced_accumulate(const Level<D>& lv, const GridIO& io, const half_t* __restrict__ dL_dy, uint32_t level, uint32_t begin,
@@ -373,8 +384,7 @@ TCNN_DEVICE void sliced_accumulate(const Level<D>& lv, const GridIO& io, const h
 					for (uint32_t f = 0; f < F; ++f) {
 						const float prod = wq * (float)g[u][f];
 						if constexpr (ACC == Acc::FIX64) {
-							const long long q = (long long)__builtin_rint((double)prod * FIXED_SCALE);
-							lds_atomic_add_u64(&tab_q[rel * F + f], (unsigned long long)q);
+							lds_atomic_add_u64(&tab_q[rel * F + f], (unsigned long long)to_fixed(prod));
 						} else {
 							lds_atomic_add_f32(&tab_f[rel * F + f], prod);
 						}
@@ -390,7 +400,7 @@ TCNN_DEVICE void sliced_level(const GridMeta& meta, const GridIO& io, const Leve
                               uint32_t n_chunks, uint32_t entries_per_slice, const half_t* __restrict__ dL_dy, half_t* __restrict__ grid_gradient,
                               bool accumulate, bool level_off, unsigned char* lds_raw) {
 	const uint32_t slice_begin = slice * entries_per_slice;
-	const uint32_t slice_count = min(entries_per_slice, lv.hashmap_size - slice_begin);
+	const uint32_t slice_count = slice_begin < lv.hashmap_size ? min(entries_per_slice, lv.hashmap_size - slice_begin) : 0u;
 	half_t* __restrict__ grad = grid_gradient + ((size_t)meta.offset[level] + slice_begin) * F;
 
 	constexpr uint32_t WORDS_PER_VALUE_X2 = ACC == Acc::FIX64 ? 4 : (ACC == Acc::F32 ? 2 : 1);  // 32-bit words per value, times two
@@ -449,12 +459,14 @@ __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const G
 	const bool level_off = (float)level > max_level + 1e-3f;  // grid.h:242
 	const Level<D> lv = make_level<D>(meta, level);
 
+	// equal slices of this level's table (level sizes are multiples of 8; the host sized n_slices to fit LDS)
+	const uint32_t entries_per_slice = next_multiple(div_round_up(lv.hashmap_size, n_slices), 8u);
 	if (kind == SLICE_FIXED64) {
-		sliced_level<D, F, Acc::FIX64>(meta, io, lv, level, slice, chunk, n_chunks, plan.entries_per_slice[SLICE_FIXED64], dL_dy, grid_gradient,
-		                               accumulate != 0, level_off, lds_raw);
+		sliced_level<D, F, Acc::FIX64>(meta, io, lv, level, slice, chunk, n_chunks, entries_per_slice, dL_dy, grid_gradient, accumulate != 0,
+		                               level_off, lds_raw);
 	} else {
-		sliced_level<D, F, PACKED ? Acc::PK16 : Acc::F32>(meta, io, lv, level, slice, chunk, n_chunks, plan.entries_per_slice[SLICE_FLOAT], dL_dy,
-		                                                   grid_gradient, accumulate != 0, level_off, lds_raw);
+		sliced_level<D, F, PACKED ? Acc::PK16 : Acc::F32>(meta, io, lv, level, slice, chunk, n_chunks, entries_per_slice, dL_dy, grid_gradient,
+		                                                   accumulate != 0, level_off, lds_raw);
 	}
 }
 
@@ -551,17 +563,18 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 	const uint32_t fixed_entry_bytes = F * (uint32_t)sizeof(unsigned long long);
 	lds_slice_bytes = std::max(lds_slice_bytes / fixed_entry_bytes, 8u) * fixed_entry_bytes;
 	SlicePlan plan = {};
-	plan.entries_per_slice[SLICE_FIXED64] = lds_slice_bytes / fixed_entry_bytes;
-	plan.entries_per_slice[SLICE_FLOAT] = lds_slice_bytes / float_entry_bytes;
+	const uint32_t cap_fixed = lds_slice_bytes / fixed_entry_bytes, cap_float = lds_slice_bytes / float_entry_bytes;  // entries per slice
 	uint32_t blocks = 0;
 	for (uint32_t l = 0; l < meta.n_levels; ++l) {
 		const uint32_t entries = meta.offset[l + 1] - meta.offset[l];
-		// Accumulator kind by expected atomic density: with <= 32 fixed-point slices a float slice would see
-		// >= 1 matching corner per sample (dense, serialised float atomics) -> 64-bit fixed point.  Tables of
-		// <= 4 slices additionally split the samples over up to 16 workgroups (few flush atomics).
-		const uint32_t n_fixed = div_round_up(entries, plan.entries_per_slice[SLICE_FIXED64]);
-		const bool fixed = n_fixed <= 32;
-		const uint32_t n_slices = fixed ? n_fixed : div_round_up(entries, plan.entries_per_slice[SLICE_FLOAT]);
+		// Accumulator kind by expected atomic density.  Tables that cannot be cut into >= 16 float slices of a
+		// useful size (<= 64 Ki entries here) would see dense -- i.e. serialised -- float atomics: they use 64-bit
+		// fixed point, and <= 4 slices of them also split the SAMPLES over up to 16 workgroups (few flush
+		// atomics).  Larger tables use >= 16 float slices (<= 1/16 of the corners match: sparse atomics).
+		const uint32_t n_fixed = div_round_up(entries, cap_fixed);
+		const bool fixed = n_fixed <= 8;
+		uint32_t n_slices = n_fixed;
+		if (!fixed) n_slices = std::max(16u, div_round_up(entries, cap_float));
 		uint32_t n_chunks = (fixed && n_slices <= 4) ? std::max(1u, std::min(16u / n_slices, div_round_up(io.n, 2048u))) : 1u;
 		if (!fixed) plan.kind_mask[l >> 5] |= 1u << (l & 31u);
 		plan.block_begin[l] = blocks;

@@ -7,6 +7,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 namespace tcnn_hip {
 
@@ -313,12 +314,15 @@ constexpr uint32_t SLICED_LDS_BYTES = 128 * 1024;      // default slice size
 constexpr uint32_t SLICED_LDS_MAX_BYTES = 160 * 1024;  // one CU's LDS
 constexpr double FIXED_SCALE = 16777216.0;             // 2^24: below the smallest fp16 subnormal
 
-enum SliceKind : uint32_t { SLICE_FIXED64 = 0, SLICE_FLOAT = 1 };
+enum SliceKind : uint32_t { SLICE_FIXED64 = 0, SLICE_FLOAT = 1, SLICE_GLOBAL_ATOMIC = 2 };
 
+// Work list of one launch, in dispatch order (long slice passes first, short work fills the tail).
 struct SlicePlan {
-	uint32_t block_begin[MAX_N_LEVELS + 1];  // first workgroup of each level
-	uint32_t n_slices[MAX_N_LEVELS];
-	uint32_t kind_mask[MAX_N_LEVELS / 32];   // bit set: SLICE_FLOAT
+	uint32_t n_items;
+	uint32_t block_begin[MAX_N_LEVELS + 1];  // first workgroup of item p
+	uint32_t n_slices[MAX_N_LEVELS];         // slices (FIXED64 / FLOAT) or sample tiles (GLOBAL_ATOMIC) of item p
+	uint8_t level[MAX_N_LEVELS];             // grid level of item p
+	uint8_t kind[MAX_N_LEVELS];              // SliceKind of item p
 };
 
 enum class Acc { F32, PK16, FIX64 };
@@ -446,18 +450,49 @@ __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const G
                                                                            const half_t* __restrict__ dL_dy, half_t* __restrict__ grid_gradient,
                                                                            const int accumulate) {
 	TCNN_DYN_LDS(lds_raw);
-	uint32_t level = 0;
-	while (level + 1 < meta.n_levels && blockIdx.x >= plan.block_begin[level + 1]) ++level;
-	const uint32_t local_block = blockIdx.x - plan.block_begin[level];
-	const uint32_t n_slices = plan.n_slices[level];
-	const uint32_t n_chunks = (plan.block_begin[level + 1] - plan.block_begin[level]) / n_slices;
+	uint32_t item = 0;
+	while (item + 1 < plan.n_items && blockIdx.x >= plan.block_begin[item + 1]) ++item;
+	const uint32_t level = plan.level[item], kind = plan.kind[item];
+	const uint32_t local_block = blockIdx.x - plan.block_begin[item];
+	const uint32_t n_slices = plan.n_slices[item];
+	const uint32_t n_chunks = (plan.block_begin[item + 1] - plan.block_begin[item]) / n_slices;
 	const uint32_t slice = local_block % n_slices, chunk = local_block / n_slices;
-	const uint32_t kind = (plan.kind_mask[level >> 5] >> (level & 31u)) & 1u;
 
 	const uint32_t n_features = meta.n_levels * F;
 	const float max_level = (meta.max_level * (float)n_features) / (float)F;
 	const bool level_off = (float)level > max_level + 1e-3f;  // grid.h:242
 	const Level<D> lv = make_level<D>(meta, level);
+
+	if (kind == SLICE_GLOBAL_ATOMIC) {
+		// Dense-indexed level too large for the fixed-point path: its corners are memory-adjacent, so a float
+		// slice would see all-or-nothing samples (8 serial iterations at 1/16 lane occupancy).  The memory-side
+		// atomic units are otherwise idle during this launch: send this level's updates there (tile = slice).
+		if (level_off) return;
+		half_t* __restrict__ grad = grid_gradient + (size_t)meta.offset[level] * F;
+		const uint32_t per_tile = div_round_up(io.n, n_slices);
+		const uint32_t begin = slice * per_tile, end = min(begin + per_tile, io.n);
+		for (uint32_t i = begin + threadIdx.x; i < end; i += SLICED_THREADS) {
+			const Cell<D> c = make_cell<D, false>(lv, io, i);
+			half_t g[F];
+#pragma unroll
+			for (uint32_t f = 0; f < F; ++f) g[f] = dL_dy[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i];
+			const uint32_t n_corners = lv.nearest ? 1u : (1u << D);
+			for (uint32_t idx = 0; idx < n_corners; ++idx) {
+				const half_t wh = lv.nearest ? (half_t)1.0f : to_half_rn(corner_weight<D>(c, idx));
+				const uint32_t index = corner_index<D, false>(lv, c, idx);
+				if constexpr (F == 1) {
+					// a packed atomic on the aligned pair; the partner half gets +0
+					const h2 v = (index & 1u) ? h2{(half_t)0.0f, wh * g[0]} : h2{wh * g[0], (half_t)0.0f};
+					atomic_add_h2(grad + (index & ~1u), v);
+				} else {
+					const h2 w2 = h2{wh, wh};
+#pragma unroll
+					for (uint32_t p = 0; p < F / 2; ++p) atomic_add_h2(grad + (size_t)index * F + 2 * p, w2 * h2{g[2 * p], g[2 * p + 1]});
+				}
+			}
+		}
+		return;
+	}
 
 	// equal slices of this level's table (level sizes are multiples of 8; the host sized n_slices to fit LDS)
 	const uint32_t entries_per_slice = next_multiple(div_round_up(lv.hashmap_size, n_slices), 8u);
@@ -562,31 +597,56 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 	const uint32_t float_entry_bytes = F * (packed ? (uint32_t)sizeof(half_t) : (uint32_t)sizeof(float));
 	const uint32_t fixed_entry_bytes = F * (uint32_t)sizeof(unsigned long long);
 	lds_slice_bytes = std::max(lds_slice_bytes / fixed_entry_bytes, 8u) * fixed_entry_bytes;
-	SlicePlan plan = {};
 	const uint32_t cap_fixed = lds_slice_bytes / fixed_entry_bytes, cap_float = lds_slice_bytes / float_entry_bytes;  // entries per slice
-	uint32_t blocks = 0;
+	constexpr uint32_t MAX_BASES[11] = {0x0, 0xFFFFFFFF, 0xFFFF, 0x659, 0xFF, 0x54, 0x28, 0x17, 0xF, 0xB, 0x9};
+
+	// Per level: accumulator kind by expected LDS-atomic density (see the comment above the kernel).
+	struct Item {
+		uint32_t level, kind, n_slices, n_chunks;
+	};
+	std::vector<Item> items;
 	for (uint32_t l = 0; l < meta.n_levels; ++l) {
 		const uint32_t entries = meta.offset[l + 1] - meta.offset[l];
-		// Accumulator kind by expected atomic density.  Tables that cannot be cut into >= 16 float slices of a
-		// useful size (<= 64 Ki entries here) would see dense -- i.e. serialised -- float atomics: they use 64-bit
-		// fixed point, and <= 4 slices of them also split the SAMPLES over up to 16 workgroups (few flush
-		// atomics).  Larger tables use >= 16 float slices (<= 1/16 of the corners match: sparse atomics).
+		uint64_t dense = 1;  // resolution^D, saturated
+		for (uint32_t d = 0; d < meta.n_dims; ++d) dense = meta.resolution[l] <= MAX_BASES[meta.n_dims] ? dense * meta.resolution[l] : ~0ull >> 1;
+		const bool hashed = meta.grid_type == (uint32_t)GridType::Hash && (uint64_t)entries < dense;
 		const uint32_t n_fixed = div_round_up(entries, cap_fixed);
-		const bool fixed = n_fixed <= 8;
-		uint32_t n_slices = n_fixed;
-		if (!fixed) n_slices = std::max(16u, div_round_up(entries, cap_float));
-		uint32_t n_chunks = (fixed && n_slices <= 4) ? std::max(1u, std::min(16u / n_slices, div_round_up(io.n, 2048u))) : 1u;
-		if (!fixed) plan.kind_mask[l >> 5] |= 1u << (l & 31u);
-		plan.block_begin[l] = blocks;
-		plan.n_slices[l] = n_slices;
-		blocks += n_slices * n_chunks;
-		if (n_chunks > 1 && !accumulate) {  // atomically flushed levels start from zero
-			if (hipMemsetAsync(grid_gradient + (size_t)meta.offset[l] * F, 0, (size_t)entries * F * sizeof(half_t), stream) != hipSuccess) {
+		Item it = {l, SLICE_FIXED64, n_fixed, 1u};
+		if (n_fixed <= 8) {
+			// small table: every corner of every sample hits the slice(s) -> dense atomics -> fixed point;
+			// <= 4 slices also split the SAMPLES over up to 16 workgroups (few flush atomics)
+			if (n_fixed <= 4) it.n_chunks = std::max(1u, std::min(16u / n_fixed, div_round_up(io.n, 2048u)));
+		} else if (hashed) {
+			// hashed level: corners scatter over the table -> >= 16 float slices see <= 1/16 of them (sparse atomics)
+			it.kind = SLICE_FLOAT;
+			it.n_slices = std::max(16u, div_round_up(entries, cap_float));
+		} else {
+			it.kind = SLICE_GLOBAL_ATOMIC;
+			it.n_slices = std::max(1u, div_round_up(io.n, SLICED_THREADS * 4u));  // sample tiles
+		}
+		items.push_back(it);
+	}
+	// long slice passes first, the short work (fixed-point chunks, atomic tiles) fills the tail
+	std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return (a.kind == SLICE_FLOAT) > (b.kind == SLICE_FLOAT); });
+
+	SlicePlan plan = {};
+	plan.n_items = (uint32_t)items.size();
+	uint32_t blocks = 0;
+	for (uint32_t p = 0; p < plan.n_items; ++p) {
+		const Item& it = items[p];
+		plan.block_begin[p] = blocks;
+		plan.n_slices[p] = it.n_slices;
+		plan.level[p] = (uint8_t)it.level;
+		plan.kind[p] = (uint8_t)it.kind;
+		blocks += it.n_slices * it.n_chunks;
+		if ((it.n_chunks > 1 || it.kind == SLICE_GLOBAL_ATOMIC) && !accumulate) {  // atomically updated levels start from zero
+			const uint32_t entries = meta.offset[it.level + 1] - meta.offset[it.level];
+			if (hipMemsetAsync(grid_gradient + (size_t)meta.offset[it.level] * F, 0, (size_t)entries * F * sizeof(half_t), stream) != hipSuccess) {
 				throw std::runtime_error("grid_backward: memset failed");
 			}
 		}
 	}
-	plan.block_begin[meta.n_levels] = blocks;
+	plan.block_begin[plan.n_items] = blocks;
 	const int acc = accumulate ? 1 : 0;
 #define BWDS(D_, F_)                                                                                                                   \
 	if (packed) {                                                                                                                      \

@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dominant", default="adam", help="stage timed with HIP events inside the timed region")
+    ap.add_argument("--dominant", default="auto", help="stage timed with HIP events inside the timed region (auto: the slowest stage of a short probe pass)")
     ap.add_argument("--lds-budget", type=int, default=None, help="grid backward: LDS bytes per level table (tuning knob)")
     args = ap.parse_args()
 
@@ -139,8 +139,19 @@ def main():
         step(i)
     torch.cuda.synchronize()
 
+    # ---- which stage dominates?  short untimed probe with every stage instrumented -----------------------
+    dominant = args.dominant
+    if dominant == "auto":
+        tm.set_profiling(True)
+        for i in range(5):
+            step(i)
+        torch.cuda.synchronize()
+        probe = tm.stage_times()
+        dominant = max(probe, key=lambda k: probe[k][0])
+        dominant = par.broadcast_object(dominant)
+
     # ---- timed region: EXACTLY --steps steps, barrier + synchronize on both sides -----------------------
-    tm.set_profiling(True, only_stage=args.dominant)  # 2 HIP events per step around the dominant kernel only
+    tm.set_profiling(True, only_stage=dominant)  # 2 HIP events per step around the dominant kernel only
     par.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -150,7 +161,7 @@ def main():
     par.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = par.all_reduce_max(elapsed, device=device)
-    dom_ms, dom_cnt = tm.stage_times()[args.dominant]
+    dom_ms, dom_cnt = tm.stage_times()[dominant]
 
     # ---- second, fully instrumented pass (breakdown only; not part of `value`) ----------------------------
     tm.set_profiling(True)
@@ -170,11 +181,11 @@ def main():
         value = global_batch * args.steps / elapsed
         ab = algorithmic_bytes(BATCH, tm.n_params, tm.n_mlp_params)
         dom_avg_s = dom_ms / max(dom_cnt, 1) * 1e-3
-        achieved = ab[args.dominant] / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
+        achieved = ab[dominant] / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch, if a pass was recorded
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(args.dominant)
+            traffic = json.load(open(tpath)).get(dominant)
         line = {
             "metric": "training samples/s, HashGrid+FullyFusedMLP(64,2) @ batch 2^18",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -184,9 +195,9 @@ def main():
                                    "3D->4, RelativeL2, Adam(config_hash.json), training_step incl. optimizer",
                        "batch_per_gpu": BATCH, "global_batch": global_batch, "n_params": tm.n_params,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": {"bound": "hbm", "kernel": args.dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ab[args.dominant], "avg_launch_ms": dom_avg_s * 1e3, "launches_timed": int(dom_cnt)},
+                         "algorithmic_bytes_per_launch": ab[dominant], "avg_launch_ms": dom_avg_s * 1e3, "launches_timed": int(dom_cnt)},
             "stages_ms": stages,
             "step_ideal_GBps": ab["step_ideal"] / (elapsed / args.steps) / 1e9,
             "final_loss": final_loss,

@@ -51,6 +51,15 @@ def all_reduce_max(value, device="cpu"):
     return float(t.item())
 
 
+def broadcast_object(obj, src=0):
+    """Same Python object on every rank (rank `src`'s)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        box = [obj]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+    return obj
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -134,6 +134,11 @@ void* tcnn_trainer_params_inference(tcnn_trainable_model_t* tm);
 void* tcnn_trainer_param_gradients(tcnn_trainable_model_t* tm);
 int tcnn_trainer_set_params_full_precision(tcnn_trainable_model_t* tm, const float* params, size_t n_params, int device_ptr);
 int tcnn_trainer_set_params(tcnn_trainable_model_t* tm, const void* params_fp16, size_t n_params, int device_ptr);
+/* Trainer::serialize / deserialize, trainer.h:442-481 (+ Adam::serialize, adam.h:304-325).  The snapshot is the
+ * reference's JSON document {n_params, params_type, params_binary[, optimizer{...}]} as MessagePack bytes, i.e. what
+ * nlohmann::json::to_msgpack(trainer->serialize(...)) yields.  Call with buffer == NULL to query *n_bytes. */
+int tcnn_trainer_serialize(tcnn_trainable_model_t* tm, int serialize_optimizer, void* buffer, size_t capacity, size_t* n_bytes);
+int tcnn_trainer_deserialize(tcnn_trainable_model_t* tm, const void* data, size_t n_bytes);
 int tcnn_trainer_update_hyperparams(tcnn_trainable_model_t* tm, const char* json);      /* trainer.h:380-383 */
 const char* tcnn_trainer_hyperparams_json(tcnn_trainable_model_t* tm);                   /* trainer.h:385-391 */
 uint32_t tcnn_trainer_optimizer_step_count(const tcnn_trainable_model_t* tm);            /* Optimizer::step() */
@@ -153,10 +158,11 @@ int tcnn_trainer_set_profiling(tcnn_trainable_model_t* tm, int enable, int only_
 int tcnn_trainer_n_stages(void);
 const char* tcnn_trainer_stage_name(int stage);
 int tcnn_trainer_get_stage_times(tcnn_trainable_model_t* tm, double* total_ms, uint64_t* counts);
-/* Tuning knob: levels whose fp32 table fits in this many bytes of LDS are accumulated in LDS by grid backward. */
+/* Tuning knob: bytes of LDS one grid-backward workgroup uses for the table slice it owns (default 64 KiB). */
 int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes);
-/* Grid backward formulation, process-wide: 0 = owner-computes LDS slices, fp32 accumulation (default),
- * 1 = same with packed-fp16 accumulation, 2 = the reference's per-corner global atomics (A/B measurements). */
+/* Grid backward formulation, process-wide: 0 = owner-computes LDS slices with fp32 accumulation on hashed levels,
+ * 1 = same with packed-fp16 accumulation (default; the reference's accumulation type), 2 = the reference's
+ * per-corner global atomics (A/B measurements).  Also selectable with TCNN_GRID_BACKWARD=sliced_f32|sliced_f16|atomic. */
 int tcnn_set_grid_backward_mode(int mode);
 
 #ifdef __cplusplus

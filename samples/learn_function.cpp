@@ -1,0 +1,88 @@
+// learn_function.cpp -- the hot path through the C++ facade (include/tiny-cuda-nn/config.h), spelled the way a
+// reference application spells it (README.md:40-67 / samples/mlp_learning_an_image.cu:214-311 of the reference):
+//   create_from_config -> trainer->training_step -> trainer->loss -> network->inference.
+// Learns a smooth 3-D -> 4-D function from synthetic samples, prints the loss curve, checks a snapshot round trip.
+// Build: make -C samples      Run (MI355X): samples/learn_function [n_steps] [batch_size]
+#include <tiny-cuda-nn/config.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+static const char* CONFIG = R"({
+	"loss": {"otype": "RelativeL2"},
+	"optimizer": {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6},
+	"encoding": {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 16, "per_level_scale": 2.0},
+	"network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2}
+})";
+
+int main(int argc, char** argv) {
+	try {
+		const uint32_t n_steps = argc > 1 ? uint32_t(atoi(argv[1])) : 200;
+		const uint32_t batch_size = tcnn::next_multiple(argc > 2 ? uint32_t(atoi(argv[2])) : (1u << 16), tcnn::batch_size_granularity());
+		const uint32_t n_input_dims = 3, n_output_dims = 4;
+
+		auto model = tcnn::create_from_config(n_input_dims, n_output_dims, CONFIG);
+
+		std::mt19937 rng(42);
+		std::uniform_real_distribution<float> uni(0.f, 1.f);
+		std::vector<float> xs(size_t(n_input_dims) * batch_size), ys(size_t(n_output_dims) * batch_size);
+		for (uint32_t i = 0; i < batch_size; ++i) {
+			float* x = &xs[size_t(i) * n_input_dims];
+			for (uint32_t d = 0; d < n_input_dims; ++d) x[d] = uni(rng);
+			float* y = &ys[size_t(i) * n_output_dims];
+			y[0] = 0.5f + 0.5f * std::sin(6.2831853f * x[0]) * std::cos(6.2831853f * x[1]);
+			y[1] = x[0] * x[1] + x[2];
+			y[2] = std::exp(-8.f * ((x[0] - .5f) * (x[0] - .5f) + (x[1] - .5f) * (x[1] - .5f) + (x[2] - .5f) * (x[2] - .5f)));
+			y[3] = 1.f;
+		}
+		tcnn::GPUMatrix<float> training_batch(n_input_dims, batch_size), training_target(n_output_dims, batch_size), prediction(n_output_dims, batch_size);
+		training_batch.copy_from_host(xs);
+		training_target.copy_from_host(ys);
+
+		hipStream_t stream;
+		tcnn::hip_check(hipStreamCreate(&stream), "hipStreamCreate");
+		float first_loss = 0.f, last_loss = 0.f;
+		for (uint32_t i = 0; i < n_steps; ++i) {
+			auto ctx = model.trainer->training_step(stream, training_batch, training_target);
+			if (i == 0 || (i + 1) % 50 == 0 || i + 1 == n_steps) {
+				last_loss = model.trainer->loss(stream, *ctx);
+				if (i == 0) first_loss = last_loss;
+				std::printf("step=%u loss=%g\n", i + 1, last_loss);
+			}
+		}
+		model.network->inference(stream, training_batch, prediction);
+		tcnn::hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+		const std::vector<float> pred = prediction.to_cpu_vector();
+		double mse = 0.0;
+		for (size_t k = 0; k < pred.size(); ++k) mse += (pred[k] - ys[k]) * (pred[k] - ys[k]);
+		mse /= double(pred.size());
+		std::printf("inference mse=%g\n", mse);
+
+		// snapshot -> fresh model -> identical inference
+		const std::string snapshot = model.trainer->serialize(true);
+		auto restored = tcnn::create_from_config(n_input_dims, n_output_dims, CONFIG, /*seed=*/7);
+		restored.trainer->deserialize(snapshot);
+		tcnn::GPUMatrix<float> prediction2(n_output_dims, batch_size);
+		restored.network->inference(stream, training_batch, prediction2);
+		tcnn::hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+		const bool same = prediction2.to_cpu_vector() == pred;
+		std::printf("snapshot bytes=%zu restored_inference_identical=%d\n", snapshot.size(), int(same));
+
+		// error behaviour: the reference throws std::runtime_error for a batch that is not a multiple of 256
+		bool threw = false;
+		try {
+			tcnn::GPUMatrix<float> bad_in(n_input_dims, 100), bad_out(n_output_dims, 100);
+			model.network->inference(stream, bad_in, bad_out);
+		} catch (const std::runtime_error& e) { threw = true; std::printf("expected error: %s\n", e.what()); }
+
+		(void)hipStreamDestroy(stream);
+		const bool ok = std::isfinite(last_loss) && last_loss < 0.5f * first_loss && same && threw;
+		std::printf(ok ? "OK\n" : "FAILED\n");
+		return ok ? 0 : 1;
+	} catch (const std::exception& e) {
+		std::fprintf(stderr, "error: %s\n", e.what());
+		return 2;
+	}
+}

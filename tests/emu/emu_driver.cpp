@@ -171,3 +171,49 @@ int emu_trim_and_cast(uint32_t n, uint32_t padded, uint32_t dims, const uint16_t
 }
 
 }  // extern "C"
+
+// ---- trainer snapshot (host-only code of the product: csrc/snapshot_msgpack.h) --------------------------------
+#include "../../tiny-cuda-nn_amd/csrc/snapshot_msgpack.h"
+
+extern "C" {
+
+// Encodes a snapshot from host arrays; returns the byte count (call with out == nullptr to size the buffer).
+long emu_snapshot_encode(uint64_t n_params, const void* params_fp16, int with_optimizer, uint32_t current_step, float base_lr,
+                         const float* m1, const float* m2, const uint32_t* steps, uint8_t* out, size_t capacity) {
+	try {
+		Snapshot s;
+		s.n_params = n_params;
+		s.params.data = (const uint8_t*)params_fp16;
+		s.params.size = n_params * 2;
+		s.has_optimizer = with_optimizer != 0;
+		s.current_step = current_step;
+		s.base_learning_rate = base_lr;
+		s.first_moments.data = (const uint8_t*)m1; s.first_moments.size = n_params * 4;
+		s.second_moments.data = (const uint8_t*)m2; s.second_moments.size = n_params * 4;
+		s.param_steps.data = (const uint8_t*)steps; s.param_steps.size = n_params * 4;
+		const size_t needed = snapshot_encoded_size(s);
+		if (!out) return (long)needed;
+		const std::vector<uint8_t> bytes = snapshot_encode(s);
+		if (bytes.size() != needed || capacity < needed) return -2;
+		std::memcpy(out, bytes.data(), bytes.size());
+		return (long)needed;
+	} catch (const std::exception&) { return -1; }
+}
+
+// Decodes; copies each blob into the caller's array when non-null.  meta = {n_params, has_optimizer, current_step,
+// params_bytes, m1_bytes, m2_bytes, steps_bytes, params_is_float}.
+int emu_snapshot_decode(const uint8_t* data, size_t size, uint64_t* meta, float* base_lr, void* params, void* m1, void* m2, void* steps) {
+	try {
+		const Snapshot s = snapshot_decode(data, size);
+		meta[0] = s.n_params; meta[1] = s.has_optimizer; meta[2] = s.current_step; meta[3] = s.params.size;
+		meta[4] = s.first_moments.size; meta[5] = s.second_moments.size; meta[6] = s.param_steps.size; meta[7] = s.params_type == "float";
+		*base_lr = s.base_learning_rate;
+		if (params) std::memcpy(params, s.params.data, s.params.size);
+		if (m1 && s.first_moments.present()) std::memcpy(m1, s.first_moments.data, s.first_moments.size);
+		if (m2 && s.second_moments.present()) std::memcpy(m2, s.second_moments.data, s.second_moments.size);
+		if (steps && s.param_steps.present()) std::memcpy(steps, s.param_steps.data, s.param_steps.size);
+		return 0;
+	} catch (const std::exception&) { return -1; }
+}
+
+}  // extern "C"

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import HASH_ENCODING, HASH_ENCODING_SMALL, MLP_64x2, config_hash
+from conftest import HASH_ENCODING, HASH_ENCODING_SMALL, MLP_64x2, ROOT, config_hash
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -439,3 +439,52 @@ def test_mlp_keeps_fp16_subnormal_inputs():
     ref = O.h2f(out_ref)[:, :4]
     assert np.abs(ref).max() > 1e-6
     assert np.max(np.abs(O.h2f(h_np(y))[:, :4] - ref)) <= 2.0 ** -23  # within two fp16 subnormal ulps
+
+
+def test_snapshot_round_trip_resumes_training_bit_exactly():
+    """Trainer::serialize/deserialize (trainer.h:442-481, adam.h:304-325): a model restored from a snapshot with
+    optimizer state continues EXACTLY like the original; the bytes decode as the reference's document."""
+    import msgpack
+    T = tcnn()
+    cfg = config_hash(log2_hashmap_size=14)
+    n = 1 << 12
+    pos = positions(n, 3, seed=11)
+    x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(targets_for(pos, 4)).cuda()
+    a = T.create_from_config(3, 4, cfg, seed=7)
+    for _ in range(5):
+        a.training_step(x, t, want_context=False)
+    blob = a.serialize(serialize_optimizer=True)
+    doc = msgpack.unpackb(blob, raw=False)
+    assert doc["n_params"] == a.n_params and doc["params_type"] == "__half"
+    assert doc["params_binary"] == a.params.cpu().numpy().tobytes()
+    assert doc["optimizer"]["current_step"] == 5 and len(doc["optimizer"]["param_steps_binary"]) == 4 * a.n_params
+    assert set(msgpack.unpackb(a.serialize(), raw=False)) == {"n_params", "params_type", "params_binary"}
+
+    b = T.create_from_config(3, 4, cfg, seed=99)  # different init, then restored
+    b.deserialize(blob)
+    assert b.optimizer_step_count == 5 and torch.equal(a.params, b.params)
+    # the fp16 snapshot drops the fp32 master's low bits (as in the reference, which stores params_inference): align a with it
+    a.deserialize(blob)
+    for _ in range(3):
+        a.training_step(x, t, want_context=False)
+        b.training_step(x, t, want_context=False)
+    assert torch.equal(a.params_full_precision, b.params_full_precision)
+    assert torch.equal(a.inference(x), b.inference(x))
+    # fp32 parameter snapshots written by a reference build with fp32 params are accepted too (trainer.h:459-461)
+    p32 = a.params_full_precision.cpu().numpy()
+    b.deserialize(msgpack.packb({"n_params": int(a.n_params), "params_type": "float", "params_binary": p32.tobytes()}, use_bin_type=True))
+    assert torch.equal(b.params_full_precision, a.params_full_precision)
+    with pytest.raises(RuntimeError, match="wrong size"):
+        b.deserialize(msgpack.packb({"n_params": 4, "params_type": "__half", "params_binary": b"12345678"}, use_bin_type=True))
+
+
+def test_cpp_facade_sample():
+    """The header-only C++ facade (include/tiny-cuda-nn/config.h) over the C ABI: the sample application trains,
+    infers, round-trips a snapshot and sees the reference's error for a bad batch size."""
+    import subprocess
+    exe = os.path.join(ROOT, "samples", "learn_function")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "samples"), "-s"])
+    r = subprocess.run([exe, "150", "16384"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    assert "restored_inference_identical=1" in r.stdout

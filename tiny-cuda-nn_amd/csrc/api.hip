@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -21,6 +22,7 @@
 #include "grid_kernels.h"
 #include "json_mini.h"
 #include "mlp_kernels.h"
+#include "snapshot_msgpack.h"
 
 namespace tcnn_hip {
 
@@ -999,6 +1001,83 @@ int tcnn_trainer_set_params(tcnn_trainable_model_t* tm, const void* params_fp16,
 	if (n_params != tm->md.n_params()) throw std::runtime_error("Can't set params because buffer has the wrong size.");  // trainer.h:424-426
 	HIP_CHECK(hipMemcpy(tm->params, params_fp16, sizeof(half_t) * n_params, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
 	cast_f16_to_f32(nullptr, n_params, tm->params, tm->master);
+	HIP_CHECK(hipDeviceSynchronize());
+	TCNN_API_END
+}
+
+// Trainer::serialize / deserialize, trainer.h:442-481 + adam.h:304-325; document layout in snapshot_msgpack.h.
+static Snapshot snapshot_shape(const tcnn_trainable_model* tm, bool with_optimizer) {
+	const size_t n = tm->md.n_params();
+	Snapshot s;
+	s.n_params = n;
+	s.params_type = "__half";
+	s.params.size = n * sizeof(half_t);
+	s.has_optimizer = with_optimizer;
+	s.current_step = tm->optimizer_step;
+	s.base_learning_rate = tm->adam.learning_rate;
+	s.first_moments.size = s.second_moments.size = n * sizeof(float);
+	s.param_steps.size = n * sizeof(uint32_t);
+	return s;
+}
+
+int tcnn_trainer_serialize(tcnn_trainable_model_t* tm, int serialize_optimizer, void* buffer, size_t capacity, size_t* n_bytes) {
+	TCNN_API_BEGIN
+	Snapshot s = snapshot_shape(tm, serialize_optimizer != 0);
+	const size_t needed = snapshot_encoded_size(s);
+	if (n_bytes) *n_bytes = needed;
+	if (buffer) {
+		if (capacity < needed) throw std::runtime_error("tcnn_trainer_serialize: buffer too small (" + std::to_string(capacity) + " < " + std::to_string(needed) + " bytes)");
+		HIP_CHECK(hipDeviceSynchronize());
+		std::vector<uint8_t> host_params(s.params.size), host_m1, host_m2, host_steps;
+		HIP_CHECK(hipMemcpy(host_params.data(), tm->params, s.params.size, hipMemcpyDeviceToHost));
+		s.params.data = host_params.data();
+		if (s.has_optimizer) {
+			host_m1.resize(s.first_moments.size);
+			host_m2.resize(s.second_moments.size);
+			host_steps.resize(s.param_steps.size);
+			HIP_CHECK(hipMemcpy(host_m1.data(), tm->m1, host_m1.size(), hipMemcpyDeviceToHost));
+			HIP_CHECK(hipMemcpy(host_m2.data(), tm->m2, host_m2.size(), hipMemcpyDeviceToHost));
+			HIP_CHECK(hipMemcpy(host_steps.data(), tm->steps, host_steps.size(), hipMemcpyDeviceToHost));
+			s.first_moments.data = host_m1.data();
+			s.second_moments.data = host_m2.data();
+			s.param_steps.data = host_steps.data();
+		}
+		const std::vector<uint8_t> bytes = snapshot_encode(s);
+		std::memcpy(buffer, bytes.data(), bytes.size());
+	}
+	TCNN_API_END
+}
+
+int tcnn_trainer_deserialize(tcnn_trainable_model_t* tm, const void* data, size_t n_bytes) {
+	TCNN_API_BEGIN
+	const Snapshot s = snapshot_decode(static_cast<const uint8_t*>(data), n_bytes);
+	const size_t n = tm->md.n_params();
+	if (s.params_type == "float") {
+		if (s.params.size != n * sizeof(float)) throw std::runtime_error("Can't set fp params because buffer has the wrong size.");  // trainer.h:410-412
+		HIP_CHECK(hipMemcpy(tm->master, s.params.data, s.params.size, hipMemcpyHostToDevice));
+		cast_master_to_params(tm, nullptr);
+	} else if (s.params_type == "__half") {
+		if (s.params.size != n * sizeof(half_t)) throw std::runtime_error("Can't set params because buffer has the wrong size.");  // trainer.h:424-426
+		HIP_CHECK(hipMemcpy(tm->params, s.params.data, s.params.size, hipMemcpyHostToDevice));
+		cast_f16_to_f32(nullptr, n, tm->params, tm->master);
+	} else {
+		throw std::runtime_error("Trainer: snapshot parameters must be of type float of __half");  // trainer.h:473
+	}
+	if (s.has_optimizer) {
+		if (!s.first_moments.present() || !s.second_moments.present() || s.first_moments.size != n * sizeof(float) || s.second_moments.size != n * sizeof(float))
+			throw std::runtime_error("Trainer: optimizer snapshot does not match the number of parameters");
+		HIP_CHECK(hipMemcpy(tm->m1, s.first_moments.data, s.first_moments.size, hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemcpy(tm->m2, s.second_moments.data, s.second_moments.size, hipMemcpyHostToDevice));
+		if (s.param_steps.present()) {  // adam.h:317-322: older snapshots carry no per-parameter steps
+			if (s.param_steps.size != n * sizeof(uint32_t)) throw std::runtime_error("Trainer: optimizer snapshot does not match the number of parameters");
+			HIP_CHECK(hipMemcpy(tm->steps, s.param_steps.data, s.param_steps.size, hipMemcpyHostToDevice));
+		} else {
+			HIP_CHECK(hipMemset(tm->steps, 0, n * sizeof(uint32_t)));
+		}
+		tm->optimizer_step = s.current_step;
+		tm->adam.learning_rate = s.base_learning_rate;
+		refresh_hyper_json(tm);
+	}
 	HIP_CHECK(hipDeviceSynchronize());
 	TCNN_API_END
 }

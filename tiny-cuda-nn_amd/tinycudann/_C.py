@@ -102,6 +102,8 @@ _sig("tcnn_trainer_params_inference", _vp, _vp)
 _sig("tcnn_trainer_param_gradients", _vp, _vp)
 _sig("tcnn_trainer_set_params_full_precision", _i, _vp, _vp, _sz, _i)
 _sig("tcnn_trainer_set_params", _i, _vp, _vp, _sz, _i)
+_sig("tcnn_trainer_serialize", _i, _vp, _i, _vp, _sz, C.POINTER(C.c_size_t))
+_sig("tcnn_trainer_deserialize", _i, _vp, _vp, _sz)
 _sig("tcnn_trainer_update_hyperparams", _i, _vp, _cp)
 _sig("tcnn_trainer_hyperparams_json", _cp, _vp)
 _sig("tcnn_trainer_optimizer_step_count", _u32, _vp)

@@ -139,6 +139,19 @@ class TrainableModel:
             p = params.contiguous()
             _check(_lib.tcnn_trainer_set_params_full_precision(self._h, C.c_void_p(p.data_ptr()), p.numel(), 0))
 
+    def serialize(self, serialize_optimizer=False):
+        """Trainer::serialize (trainer.h:442-455) as the MessagePack bytes of the reference's snapshot document."""
+        n = C.c_size_t(0)
+        _check(_lib.tcnn_trainer_serialize(self._h, int(serialize_optimizer), None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        _check(_lib.tcnn_trainer_serialize(self._h, int(serialize_optimizer), buf, n.value, C.byref(n)))
+        return buf.raw[:n.value]
+
+    def deserialize(self, blob):
+        """Trainer::deserialize (trainer.h:457-481); accepts fp16 or fp32 parameter snapshots, with or without optimizer state."""
+        blob = bytes(blob)
+        _check(_lib.tcnn_trainer_deserialize(self._h, blob, len(blob)))
+
     def update_hyperparams(self, cfg):
         _check(_lib.tcnn_trainer_update_hyperparams(self._h, json.dumps(cfg).encode()))
 

@@ -162,8 +162,11 @@ int tcnn_trainer_get_stage_times(tcnn_trainable_model_t* tm, double* total_ms, u
 int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes);
 /* Grid backward formulation, process-wide: 0 = owner-computes LDS slices with fp32 accumulation on hashed levels,
  * 1 = same with packed-fp16 accumulation (default; the reference's accumulation type), 2 = the reference's
- * per-corner global atomics (A/B measurements).  Also selectable with TCNN_GRID_BACKWARD=sliced_f32|sliced_f16|atomic. */
+ * per-corner global atomics (A/B measurements), 3 = bucket-once: large levels derive each corner once, bin the
+ * records by owning slice in HBM queues and accumulate them exactly (64-bit fixed point) in the owner's LDS.
+ * Also selectable with TCNN_GRID_BACKWARD=sliced_f32|sliced_f16|atomic|bucketed. */
 int tcnn_set_grid_backward_mode(int mode);
+int tcnn_get_grid_backward_mode(void);
 
 #ifdef __cplusplus
 }

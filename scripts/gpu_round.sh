@@ -12,7 +12,7 @@ echo "== smoke" ; timeout 600 python -c "import __graft_entry__ as g; g.smoke()"
 echo "== pytest -m gpu" ; timeout 1500 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider --tb=line > $OUT/pytest_gpu.log 2>&1 ; echo "pytest exit $?" | tee -a $OUT/pytest_gpu.log
 grep -E "^/|passed|failed|Error" $OUT/pytest_gpu.log | cut -c1-400 | tail -30
 echo "== bench" ; timeout 900 python bench.py --steps 100 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err ; echo "bench exit $?" ; cut -c1-1800 $OUT/bench.json; tail -3 $OUT/bench.err
-for MODE in sliced_f32 atomic; do
+for MODE in ${AB_MODES:-bucketed sliced_f16 sliced_f32 atomic}; do
   TCNN_GRID_BACKWARD=$MODE timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_$MODE.json 2>> $OUT/bench.err
   python - <<EOF
 import json

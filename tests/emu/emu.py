@@ -98,7 +98,7 @@ def grid_forward(g, params_h, positions, soa=True, out_stride=None, want_dy_dx=F
     return (out, dy_dx) if want_dy_dx else out
 
 
-SLICED_F32, SLICED_F16, ATOMIC = 0, 1, 2
+SLICED_F32, SLICED_F16, ATOMIC, BUCKETED = 0, 1, 2, 3
 
 
 def grid_backward(g, positions, dL_dy_h, soa=True, mode=SLICED_F32, lds_budget=0, grad_init=None):

@@ -51,7 +51,11 @@ int emu_grid_backward(const EmuGrid* e, const float* positions, uint32_t n, cons
                       uint16_t* grad_half, int accumulate, int mode, uint32_t lds_budget) {
 	try {
 		GridIO io = {positions, e->n_dims, 1, n, soa ? n : 1u, soa ? 1u : dy_stride};
-		grid_backward(nullptr, make_meta(e), io, (const half_t*)dL_dy, (half_t*)grad_half, accumulate != 0, (GridBackwardMode)mode, lds_budget);
+		const GridMeta meta = make_meta(e);
+		const size_t ws_bytes = grid_backward_workspace_bytes(meta, n, (GridBackwardMode)mode, lds_budget);
+		std::vector<unsigned char> ws(ws_bytes + 16, 0xCD);  // garbage-filled: the call must not rely on a clean workspace
+		grid_backward(nullptr, meta, io, (const half_t*)dL_dy, (half_t*)grad_half, accumulate != 0, (GridBackwardMode)mode, lds_budget,
+		              ws_bytes ? ws.data() : nullptr, ws_bytes);
 	} catch (const std::exception& ex) {
 		fprintf(stderr, "emu_grid_backward: %s\n", ex.what());
 		return 1;

@@ -240,6 +240,7 @@ inline void atomic_add_f32(float* addr, float v) { *addr = *addr + v; }
 inline void lds_atomic_add_f32(float* addr, float v) { *addr = *addr + v; }
 inline void lds_atomic_add_u64(unsigned long long* addr, unsigned long long v) { *addr = *addr + v; }
 inline void lds_atomic_add_h2(h2* addr, h2 v) { atomic_add_h2((half_t*)addr, v); }
+inline uint32_t atomic_add_u32(uint32_t* addr, uint32_t v) { const uint32_t old = *addr; *addr = old + v; return old; }
 inline h2 fma_h2(h2 a, h2 b, h2 c) {
 	return h2{emu_round_h((double)a[0] * (double)b[0] + (double)c[0]), emu_round_h((double)a[1] * (double)b[1] + (double)c[1])};
 }

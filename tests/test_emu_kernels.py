@@ -50,7 +50,8 @@ def test_grid_forward_bit_exact(case):
 
 
 @pytest.mark.parametrize("case", GRID_CASES + [(3, 4, 2, 16, 16, 2.0, O.GRID_HASH, O.INTERP_LINEAR)])  # last: > 1 slice per level
-@pytest.mark.parametrize("mode,lds_budget", [(emu.SLICED_F32, 0), (emu.SLICED_F16, 0), (emu.ATOMIC, 0), (emu.ATOMIC, 48 * 1024)])
+@pytest.mark.parametrize("mode,lds_budget", [(emu.SLICED_F32, 0), (emu.SLICED_F16, 0), (emu.ATOMIC, 0), (emu.ATOMIC, 48 * 1024),
+                                             (emu.BUCKETED, 0), (emu.BUCKETED, 1024)])  # 1 KiB slices: every level is bucketed
 def test_grid_backward(case, mode, lds_budget):
     D, L, F, T, base, scale, gtype, interp = case
     if mode == emu.ATOMIC and F == 1:
@@ -71,11 +72,35 @@ def test_grid_backward(case, mode, lds_budget):
     assert np.all(np.abs(gotf - ref) <= tol)
     if mode == emu.SLICED_F32:  # fp32 LDS accumulation, one final rounding: much tighter than fp16 atomics
         assert np.all(np.abs(gotf - ref) <= np.abs(ref) * 2.0 ** -10 + absacc * 2.0 ** -11 + 1e-6)
+    if mode == emu.BUCKETED and lds_budget and F > 1:
+        # bucketed levels (tables > 8 slices) accumulate exactly in fixed point: ONE rounding of the exact sum
+        for l in range(L):
+            lo, hi = og.offsets[l] * F, og.offsets[l + 1] * F
+            if og.offsets[l + 1] - og.offsets[l] > 8 * (lds_budget // (8 * F)):
+                assert np.array_equal(got[lo:hi], O.f2h(ref[lo:hi].astype(np.float32))), f"level {l}"
     # GradientMode::Accumulate adds to what is there
     acc = emu.grid_backward(g, pos, dys, soa=True, mode=mode, lds_budget=lds_budget, grad_init=got)
     assert np.all(np.abs(O.h2f(acc).astype(np.float64) - 2 * ref) <= 2 * tol + np.abs(ref) * 2.0 ** -9)
     dl = emu.grid_backward_input(g, np.ascontiguousarray(dy.T), np.ascontiguousarray(np.transpose(O.grid_forward(og, O.f2h(np.zeros(og.n_params, np.float32) + 0.25), pos, want_dy_dx=True)[1], (1, 0, 2))))
     assert dl.shape == (n, D)
+
+
+def test_grid_backward_bucket_overflow():
+    """Strongly clustered samples overflow their bucket queues; the overflow list + atomic pass keeps the sum right."""
+    D, L, F, T = 3, 3, 2, 14
+    rng = np.random.default_rng(5)
+    og = O.grid_init(D, L, F, T, 16, 2.0, O.GRID_HASH, O.INTERP_LINEAR)
+    g = emu.Grid(og)
+    n = 2048
+    pos = np.tile(np.array([[0.3137, 0.6211, 0.1173]], np.float32), (n, 1))
+    pos[: n // 8] = rng.random((n // 8, D), dtype=np.float32)
+    dy = O.f2h((rng.standard_normal((n, L * F)) * 0.05).astype(np.float32))
+    ref = O.grid_backward(og, pos, dy)
+    absacc = O.grid_backward(og, pos, O.f2h(np.abs(O.h2f(dy))))
+    got = emu.grid_backward(g, pos, np.ascontiguousarray(dy.T), soa=True, mode=emu.BUCKETED, lds_budget=512)
+    # the overflowed share goes through fp16 atomics (rounds after every add)
+    assert np.all(np.abs(O.h2f(got).astype(np.float64) - ref) <= absacc * 2.0 ** -8 + 2e-3)
+    assert np.count_nonzero(ref) > 0
 
 
 MLP_CASES = [(32, 64, 4, 2), (16, 16, 3, 1), (48, 32, 16, 3), (32, 128, 16, 4), (128, 64, 5, 2), (64, 64, 1, 1)]

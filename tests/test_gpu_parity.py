@@ -106,8 +106,9 @@ def test_grid_backward_and_input_gradient(d, enc):
     ctx, y = m.fwd(x, p)
     ref = O.grid_backward(og, pos, dy)
     absacc = O.grid_backward(og, pos, O.f2h(np.abs(O.h2f(dy))))
+    default_mode = C.get_grid_backward_mode()
     try:
-        for mode in (0, 2, 1):  # fp32 LDS slices, the reference's global atomics (A/B), packed-fp16 LDS slices (default, last)
+        for mode in (0, 2, 3, 1):  # fp32 LDS slices, the reference's global atomics (A/B), bucket-once, packed-fp16 LDS slices
             if mode == 2 and enc.get("n_features_per_level", 2) == 1:
                 continue
             C.set_grid_backward_mode(mode)
@@ -117,7 +118,7 @@ def test_grid_backward_and_input_gradient(d, enc):
             # modes 1 and 2 add up to hundreds of terms per entry in fp16, in hardware order: 2^-8 of the magnitude
             assert np.all(np.abs(got - ref) <= absacc * 2.0 ** (-9 if mode == 0 else -8) + 2e-3), f"grid backward mode {mode}"
     finally:
-        C.set_grid_backward_mode(1)
+        C.set_grid_backward_mode(default_mode)
     if enc.get("interpolation", "Linear") != "Nearest":
         _, dy_dx = O.grid_forward(og, params, pos, want_dy_dx=True)
         dref = O.grid_backward_input(og, dy, dy_dx)
@@ -488,3 +489,43 @@ def test_cpp_facade_sample():
     r = subprocess.run([exe, "150", "16384"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
     assert "restored_inference_identical=1" in r.stdout
+
+
+@pytest.mark.parametrize("clustered", [False, True])
+def test_bucketed_grid_backward_full_size(clustered):
+    """Bucket-once backward at BASELINE size (N = 2^18, T = 2^19): every bucketed level equals the exact sum rounded
+    once (fixed-point accumulation) -- checked against the oracle on the levels, and against the fp32-slice
+    formulation everywhere.  Clustered inputs overflow the bucket queues and take the atomic overflow pass."""
+    C = tcnn()._C
+    enc = dict(HASH_ENCODING)
+    m = C.create_encoding(3, enc)
+    og = oracle_grid(enc, 3)
+    n = 1 << 18
+    pos = positions(n, 3, seed=21)
+    if clustered:
+        pos[n // 4:] = pos[:3 * n // 4] * 0.01 + 0.37  # 3/4 of the batch inside a 1% cube
+    rng = np.random.default_rng(3)
+    dy = O.f2h((rng.standard_normal((n, m.n_output_dims())) * 0.02).astype(np.float32))
+    x = torch.from_numpy(pos).cuda()
+    p = torch.zeros(og.n_params, dtype=torch.half, device="cuda").requires_grad_(True)
+    ctx, y = m.fwd(x, p)
+    out = {}
+    default_mode = C.get_grid_backward_mode()
+    try:
+        for mode in (0, 3):
+            C.set_grid_backward_mode(mode)
+            _, dp = m.bwd(ctx, x, p, y, h_t(dy))
+            torch.cuda.synchronize()
+            out[mode] = dp.float().cpu().numpy().astype(np.float64)
+    finally:
+        C.set_grid_backward_mode(default_mode)
+    ref = O.grid_backward(og, pos, dy)
+    absacc = O.grid_backward(og, pos, O.f2h(np.abs(O.h2f(dy))))
+    assert np.all(np.abs(out[3] - ref) <= absacc * 2.0 ** -8 + 1e-3)
+    assert np.all(np.abs(out[3] - out[0]) <= absacc * 2.0 ** -8 + 1e-3)
+    if not clustered:  # no overflow: levels above 65536 entries are exact
+        F = 2
+        for l in range(og.n_levels):
+            lo, hi = og.offsets[l] * F, og.offsets[l + 1] * F
+            if og.offsets[l + 1] - og.offsets[l] > 65536:
+                assert np.array_equal(out[3][lo:hi].astype(np.float32), O.h2f(O.f2h(ref[lo:hi].astype(np.float32)))), f"level {l}"

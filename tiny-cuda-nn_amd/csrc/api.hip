@@ -173,11 +173,12 @@ struct Profiler {
 };
 static thread_local Profiler* g_profiler = nullptr;
 
-// grid backward formulation (GridBackwardMode); TCNN_GRID_BACKWARD=sliced_f32|sliced_f16|atomic overrides the default
+// grid backward formulation (GridBackwardMode); TCNN_GRID_BACKWARD=sliced_f32|sliced_f16|atomic|bucketed overrides the default
 static int initial_grid_backward_mode() {
 	const char* e = getenv("TCNN_GRID_BACKWARD");
 	if (e && std::string(e) == "atomic") return (int)GridBackwardMode::Atomic;
 	if (e && std::string(e) == "sliced_f32") return (int)GridBackwardMode::SlicedF32;
+	if (e && std::string(e) == "bucketed") return (int)GridBackwardMode::Bucketed;
 	return (int)GridBackwardMode::SlicedF16;  // default: fixed-point coarse levels + packed-fp16 slices (the reference's accumulation type)
 }
 static std::atomic<int> g_grid_backward_mode{initial_grid_backward_mode()};
@@ -577,7 +578,11 @@ static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx
 			// Overwrite vs Accumulate (grid.h:865-867) is handled inside: the owner-computes kernel stores
 			// whole slices, so the reference's full-table memset is only issued for the atomic A/B mode.
 			ProfScope prof(stream, STAGE_GRID_BWD);
-			grid_backward(stream, e.grid, io, dL_denc, grid_grads, accumulate, (GridBackwardMode)g_grid_backward_mode.load(), lds_level_budget);
+			const GridBackwardMode mode = (GridBackwardMode)g_grid_backward_mode.load();
+			const size_t ws_bytes = grid_backward_workspace_bytes(e.grid, n, mode, lds_level_budget);
+			Scratch ws;
+			if (ws_bytes) ws = Scratch(stream, ws_bytes);
+			grid_backward(stream, e.grid, io, dL_denc, grid_grads, accumulate, mode, lds_level_budget, ws.ptr, ws.bytes);
 		}
 		if (dL_dinput) {
 			if (!ctx.dy_dx.ptr) throw std::runtime_error("backward: dL_dinput requested but forward was not run with prepare_input_gradients");
@@ -1125,8 +1130,9 @@ int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes
 	tm->lds_level_budget = bytes;
 	return TCNN_OK;
 }
+int tcnn_get_grid_backward_mode(void) { return g_grid_backward_mode.load(); }
 int tcnn_set_grid_backward_mode(int mode) {
-	if (mode < 0 || mode > 2) return TCNN_ERROR;
+	if (mode < 0 || mode > 3) return TCNN_ERROR;
 	g_grid_backward_mode.store(mode);
 	return TCNN_OK;
 }

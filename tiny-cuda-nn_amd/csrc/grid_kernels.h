@@ -52,10 +52,15 @@ void grid_forward(hipStream_t stream, const GridMeta& meta, const GridIO& io, co
 //                          half2 atomics) -- no global atomics on large levels; the default.
 //   Atomic:                the reference's formulation, global_atomic_pk_add_f16 per corner (F >= 2 only);
 //                          kept for A/B measurements.
-// lds_slice_bytes: LDS bytes one workgroup devotes to its table slice in the sliced modes (0 = default 128 KiB).
-enum class GridBackwardMode : int { SlicedF32 = 0, SlicedF16 = 1, Atomic = 2 };
+//   Bucketed:              large levels derive every corner ONCE, bin the records by owning slice in HBM queues
+//                          and let the owner accumulate them in 64-bit fixed point in LDS; small levels as in
+//                          the sliced modes.  Needs `workspace` (grid_backward_workspace_bytes) -- device
+//                          memory the call may scribble on, no state is kept in it between calls.
+// lds_slice_bytes: LDS bytes one workgroup devotes to its table slice (0 = default 128 KiB).
+enum class GridBackwardMode : int { SlicedF32 = 0, SlicedF16 = 1, Atomic = 2, Bucketed = 3 };
+size_t grid_backward_workspace_bytes(const GridMeta& meta, uint32_t n, GridBackwardMode mode, uint32_t lds_slice_bytes);
 void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient, bool accumulate,
-                   GridBackwardMode mode, uint32_t lds_slice_bytes);
+                   GridBackwardMode mode, uint32_t lds_slice_bytes, void* workspace = nullptr, size_t workspace_bytes = 0);
 
 // dL_dx[i][d] = sum_k dL_dy[k][i] * dy_dx[k][i][d]   (grid.h:323-349)
 void grid_backward_input(hipStream_t stream, uint32_t n_dims, uint32_t n_features, const GridIO& io,

@@ -314,7 +314,7 @@ constexpr uint32_t SLICED_LDS_BYTES = 128 * 1024;      // default slice size
 constexpr uint32_t SLICED_LDS_MAX_BYTES = 160 * 1024;  // one CU's LDS
 constexpr double FIXED_SCALE = 16777216.0;             // 2^24: below the smallest fp16 subnormal
 
-enum SliceKind : uint32_t { SLICE_FIXED64 = 0, SLICE_FLOAT = 1, SLICE_GLOBAL_ATOMIC = 2 };
+enum SliceKind : uint32_t { SLICE_FIXED64 = 0, SLICE_FLOAT = 1, SLICE_GLOBAL_ATOMIC = 2, SLICE_BUCKET = 3 };
 
 // Work list of one launch, in dispatch order (long slice passes first, short work fills the tail).
 struct SlicePlan {
@@ -323,6 +323,7 @@ struct SlicePlan {
 	uint32_t n_slices[MAX_N_LEVELS];         // slices (FIXED64 / FLOAT) or sample tiles (GLOBAL_ATOMIC) of item p
 	uint8_t level[MAX_N_LEVELS];             // grid level of item p
 	uint8_t kind[MAX_N_LEVELS];              // SliceKind of item p
+	uint8_t slot[MAX_N_LEVELS];              // SLICE_BUCKET: slot of the level in the BucketPlan
 };
 
 enum class Acc { F32, PK16, FIX64 };
@@ -445,10 +446,277 @@ TCNN_DEVICE void sliced_level(const GridMeta& meta, const GridIO& io, const Leve
 	}
 }
 
+// =============================================================================================
+// backward, bucket-once form for the large levels.  The slice passes above re-derive every corner of every
+// sample once PER SLICE (16 x 13 passes over the batch at the headline config: VALU-bound).  Here each corner
+// is derived ONCE:
+//   pass A (k_grid_bucket_scatter): a workgroup takes one (level, sample tile), computes the corner records
+//     {entry index, (GRAD_T)weight * grad} (grid.h:254), ranks them by table slice ("bucket") with integer LDS
+//     atomics, reorders them by bucket in LDS and appends each bucket's run to that bucket's queue in HBM with
+//     coalesced stores (one global integer atomic per (workgroup, bucket) reserves the run);
+//   pass B (kind SLICE_BUCKET of k_grid_backward_sliced): the workgroup that owns a slice streams its queue and
+//     accumulates in 64-bit fixed point in LDS (dense ds_add_u64: 11 clk per wave instruction vs ~170 for the
+//     floating-point LDS atomics), then stores the slice -- exact, order-independent, no memset, no float atomics;
+//   pass C (k_grid_bucket_overflow): records that did not fit their queue (capacity = 2x the uniform expectation;
+//     only strongly non-uniform inputs get there) are applied with the reference's global atomics afterwards.
+// HBM traffic: 2 x 8 B per corner (F = 2) -- 0.44 GB per headline step, a fraction of the chip's bandwidth.
+// =============================================================================================
+constexpr uint32_t BUCKET_THREADS = 256;
+constexpr uint32_t MAX_BUCKET_LEVELS = 32;
+constexpr uint32_t MAX_BUCKETS_PER_LEVEL = 4096;
+constexpr uint32_t BUCKET_STAGE_BYTES = 64 * 1024;  // LDS staging area of pass A
+
+struct BucketPlan {
+	uint32_t n_levels;  // bucketed levels
+	uint32_t shift;     // log2(entries per bucket)
+	uint32_t tiles;     // sample tiles per level in pass A
+	uint32_t overflow_counter;              // index of the overflow counter (== total number of buckets)
+	uint32_t overflow_capacity;             // records
+	uint8_t level[MAX_BUCKET_LEVELS];       // grid level of slot j
+	uint32_t n_buckets[MAX_BUCKET_LEVELS];
+	uint32_t capacity[MAX_BUCKET_LEVELS];      // records per bucket queue
+	uint32_t counter_base[MAX_BUCKET_LEVELS];  // first counter of slot j
+	uint64_t queue_base[MAX_BUCKET_LEVELS];    // first record of slot j's queues
+};
+
+// record = {entry index within the level, payload}: payload = F halves packed in pairs (F == 1: one fp32, the
+// reference's grad_t for a single feature is float, grid.h:665)
+template <uint32_t F>
+struct BucketRecord {
+	static constexpr uint32_t PAYLOAD_WORDS = (F + 1) / 2;
+	static constexpr uint32_t WORDS = 1 + PAYLOAD_WORDS;
+};
+// samples per thread of pass A: as many as fit the staging area, at least one
+TCNN_HOST_DEVICE constexpr uint32_t bucket_spt(uint32_t D, uint32_t F) {
+	const uint32_t per_sample_bytes = (1u << D) * (1u + (F + 1) / 2) * 4u;
+	const uint32_t spt = BUCKET_STAGE_BYTES / (per_sample_bytes * BUCKET_THREADS);
+	return spt < 1u ? 1u : (spt > 8u ? 8u : spt);
+}
+
+TCNN_DEVICE uint32_t h2_bits(h2 v) { return __builtin_bit_cast(uint32_t, v); }
+TCNN_DEVICE h2 bits_h2(uint32_t v) { return __builtin_bit_cast(h2, v); }
+
+template <uint32_t D, uint32_t F>
+__global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const GridMeta meta, const GridIO io, const BucketPlan plan,
+                                                                         const half_t* __restrict__ dL_dy, uint32_t* __restrict__ counters,
+                                                                         uint32_t* __restrict__ queues, uint32_t* __restrict__ overflow) {
+	constexpr uint32_t N_CORNERS = 1u << D, PW = BucketRecord<F>::PAYLOAD_WORDS, W = BucketRecord<F>::WORDS;
+	constexpr uint32_t SPT = bucket_spt(D, F), TILE = SPT * BUCKET_THREADS, N_REC = TILE * N_CORNERS;
+	constexpr uint32_t INVALID = 0xFFFFFFFFu;
+	TCNN_DYN_LDS(lds_raw);
+	const uint32_t j = blockIdx.x / plan.tiles, tile = blockIdx.x % plan.tiles;
+	const uint32_t level = plan.level[j], nb = plan.n_buckets[j], shift = plan.shift;
+	const uint32_t n_features = meta.n_levels * F;
+	const float max_level = (meta.max_level * (float)n_features) / (float)F;
+	if ((float)level > max_level + 1e-3f) return;  // grid.h:242: no records, the owners store zeros
+	const Level<D> lv = make_level<D>(meta, level);
+
+	uint32_t* stage = (uint32_t*)lds_raw;  // [N_REC][W]
+	uint32_t* cnt = stage + N_REC * W;     // [nb] records of this workgroup per bucket
+	uint32_t* off = cnt + nb;              // [nb] exclusive prefix of cnt
+	uint32_t* gbase = off + nb;            // [nb] position of this workgroup's run in the bucket queue
+	uint32_t* part = gbase + nb;           // [BUCKET_THREADS] scan scratch
+	for (uint32_t b = threadIdx.x; b < nb; b += BUCKET_THREADS) cnt[b] = 0u;
+	__syncthreads();
+
+	// ---- derive the records of my samples; rank each within its bucket
+	float x[SPT][D];
+	half_t g[SPT][F];
+#pragma unroll
+	for (uint32_t s = 0; s < SPT; ++s) {
+		const uint32_t i = min(tile * TILE + s * BUCKET_THREADS + threadIdx.x, io.n - 1u);
+		load_position<D>(io, i, x[s]);
+#pragma unroll
+		for (uint32_t f = 0; f < F; ++f) g[s][f] = dL_dy[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i];
+	}
+	uint32_t ridx[SPT][N_CORNERS], rank[SPT][N_CORNERS], pay[SPT][N_CORNERS][PW];
+	auto derive = [&](auto fast_tag) {
+		constexpr bool FAST = decltype(fast_tag)::value;
+#pragma unroll
+		for (uint32_t s = 0; s < SPT; ++s) {
+			const bool valid = tile * TILE + s * BUCKET_THREADS + threadIdx.x < io.n;
+			const Cell<D> c = make_cell<D, FAST>(lv, x[s]);
+#pragma unroll
+			for (uint32_t idx = 0; idx < N_CORNERS; ++idx) {
+				const bool live = valid && (idx == 0u || !lv.nearest);
+				const uint32_t index = corner_index<D, FAST>(lv, c, idx);
+				const float weight = lv.nearest ? 1.0f : corner_weight<D>(c, idx);
+				if constexpr (F == 1) {
+					pay[s][idx][0] = __builtin_bit_cast(uint32_t, weight * (float)g[s][0]);
+				} else {
+					const half_t wh = to_half_rn(weight);  // (GRAD_T)weight, grid.h:254
+					const h2 w2 = h2{wh, wh};
+#pragma unroll
+					for (uint32_t p = 0; p < PW; ++p) pay[s][idx][p] = h2_bits(w2 * h2{g[s][2 * p], g[s][2 * p + 1]});
+				}
+				ridx[s][idx] = live ? index : INVALID;
+				rank[s][idx] = live ? atomic_add_u32(&cnt[index >> shift], 1u) : 0u;
+			}
+		}
+	};
+	if (lv.fast) derive(std::true_type{}); else derive(std::false_type{});
+	__syncthreads();
+
+	// ---- exclusive scan of the bucket counts; reserve this workgroup's run in every bucket queue
+	const uint32_t per_thread = div_round_up(nb, BUCKET_THREADS);
+	const uint32_t b_begin = min(threadIdx.x * per_thread, nb), b_end = min(b_begin + per_thread, nb);
+	uint32_t sum = 0;
+	for (uint32_t b = b_begin; b < b_end; ++b) sum += cnt[b];
+	part[threadIdx.x] = sum;
+	__syncthreads();
+	for (uint32_t d = 1; d < BUCKET_THREADS; d <<= 1) {
+		const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+		__syncthreads();
+		part[threadIdx.x] += v;
+		__syncthreads();
+	}
+	uint32_t running = part[threadIdx.x] - sum;
+	for (uint32_t b = b_begin; b < b_end; ++b) {
+		const uint32_t c = cnt[b];
+		off[b] = running;
+		running += c;
+		gbase[b] = c ? atomic_add_u32(&counters[plan.counter_base[j] + b], c) : 0u;
+	}
+	const uint32_t total = part[BUCKET_THREADS - 1];
+	__syncthreads();
+
+	// ---- reorder by bucket in LDS
+#pragma unroll
+	for (uint32_t s = 0; s < SPT; ++s) {
+#pragma unroll
+		for (uint32_t idx = 0; idx < N_CORNERS; ++idx) {
+			if (ridx[s][idx] == INVALID) continue;
+			const uint32_t pos = off[ridx[s][idx] >> shift] + rank[s][idx];
+			if constexpr (W == 2) {
+				*(u2*)&stage[pos * 2] = u2{ridx[s][idx], pay[s][idx][0]};
+			} else {
+				stage[pos * W] = ridx[s][idx];
+#pragma unroll
+				for (uint32_t p = 0; p < PW; ++p) stage[pos * W + 1 + p] = pay[s][idx][p];
+			}
+		}
+	}
+	__syncthreads();
+
+	// ---- append the runs to the bucket queues: consecutive threads -> consecutive records
+	const uint32_t cap = plan.capacity[j];
+	uint32_t* __restrict__ q = queues + plan.queue_base[j] * W;
+	for (uint32_t t = threadIdx.x; t < total; t += BUCKET_THREADS) {
+		uint32_t rec[W];
+		if constexpr (W == 2) {
+			const u2 r = *(const u2*)&stage[t * 2];
+			rec[0] = r[0];
+			rec[1] = r[1];
+		} else {
+#pragma unroll
+			for (uint32_t w = 0; w < W; ++w) rec[w] = stage[t * W + w];
+		}
+		const uint32_t b = rec[0] >> shift;
+		const uint32_t pos = gbase[b] + (t - off[b]);
+		if (pos < cap) {
+			uint32_t* dst = q + ((size_t)b * cap + pos) * W;
+			if constexpr (W == 2) {
+				*(u2*)dst = u2{rec[0], rec[1]};
+			} else {
+#pragma unroll
+				for (uint32_t w = 0; w < W; ++w) dst[w] = rec[w];
+			}
+		} else {
+			const uint32_t o = atomic_add_u32(&counters[plan.overflow_counter], 1u);
+			if (o < plan.overflow_capacity) {
+				uint32_t* dst = overflow + (size_t)o * (W + 1);
+				dst[0] = level;
+#pragma unroll
+				for (uint32_t w = 0; w < W; ++w) dst[1 + w] = rec[w];
+			}
+		}
+	}
+}
+
+// pass B: the owner of bucket `bucket` of slot `j` streams its queue into a 64-bit fixed-point LDS table
+template <uint32_t D, uint32_t F>
+TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t level, uint32_t j, uint32_t bucket, const BucketPlan& plan,
+                              const uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues, half_t* __restrict__ grid_gradient,
+                              bool accumulate, unsigned char* lds_raw) {
+	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, W = BucketRecord<F>::WORDS;
+	const uint32_t entries_per_bucket = 1u << plan.shift;
+	const uint32_t slice_begin = bucket * entries_per_bucket;
+	const uint32_t slice_count = slice_begin < lv.hashmap_size ? min(entries_per_bucket, lv.hashmap_size - slice_begin) : 0u;
+	unsigned long long* tab = (unsigned long long*)lds_raw;  // [entries][F]
+	for (uint32_t e = threadIdx.x; e < slice_count * F * 2; e += SLICED_THREADS) ((uint32_t*)lds_raw)[e] = 0u;
+	__syncthreads();
+
+	const uint32_t cap = plan.capacity[j];
+	const uint32_t count = min(counters[plan.counter_base[j] + bucket], cap);
+	const uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)bucket * cap) * W;
+	constexpr uint32_t U = 4;  // records in flight per lane
+	for (uint32_t base = threadIdx.x; base < count; base += SLICED_THREADS * U) {
+		uint32_t rec[U][W];
+#pragma unroll
+		for (uint32_t u = 0; u < U; ++u) {
+			const uint32_t t = min(base + u * SLICED_THREADS, count - 1u);
+			if constexpr (W == 2) {
+				const u2 r = *(const u2*)&q[(size_t)t * 2];
+				rec[u][0] = r[0];
+				rec[u][1] = r[1];
+			} else {
+#pragma unroll
+				for (uint32_t w = 0; w < W; ++w) rec[u][w] = q[(size_t)t * W + w];
+			}
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < U; ++u) {
+			if (base + u * SLICED_THREADS >= count) continue;
+			const uint32_t rel = rec[u][0] & (entries_per_bucket - 1u);
+			if constexpr (F == 1) {
+				lds_atomic_add_u64(&tab[rel], (unsigned long long)to_fixed(__builtin_bit_cast(float, rec[u][1])));
+			} else {
+#pragma unroll
+				for (uint32_t p = 0; p < PW; ++p) {
+					const h2 v = bits_h2(rec[u][1 + p]);
+					lds_atomic_add_u64(&tab[rel * F + 2 * p], (unsigned long long)to_fixed((float)v[0]));
+					lds_atomic_add_u64(&tab[rel * F + 2 * p + 1], (unsigned long long)to_fixed((float)v[1]));
+				}
+			}
+		}
+	}
+	__syncthreads();
+
+	half_t* __restrict__ grad = grid_gradient + ((size_t)meta.offset[level] + slice_begin) * F;
+	const uint32_t n_halves = slice_count * F;  // even: level sizes are multiples of 8
+	for (uint32_t e2 = threadIdx.x; e2 < n_halves / 2; e2 += SLICED_THREADS) {
+		const long long q0 = ((const long long*)lds_raw)[2 * e2], q1 = ((const long long*)lds_raw)[2 * e2 + 1];
+		h2 v = h2{(half_t)(float)((double)q0 * (1.0 / FIXED_SCALE)), (half_t)(float)((double)q1 * (1.0 / FIXED_SCALE))};
+		if (accumulate) v += *(const h2*)(grad + 2 * e2);
+		*(h2*)(grad + 2 * e2) = v;
+	}
+}
+
+// pass C: queue overflow -> the reference's global atomics (runs after pass B stored the slices)
+template <uint32_t F>
+__global__ void __launch_bounds__(256) k_grid_bucket_overflow(const GridMeta meta, const BucketPlan plan, const uint32_t* __restrict__ counters,
+                                                               const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient) {
+	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, W = BucketRecord<F>::WORDS;
+	const uint32_t count = min(counters[plan.overflow_counter], plan.overflow_capacity);
+	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < count; t += gridDim.x * 256u) {
+		const uint32_t* rec = overflow + (size_t)t * (W + 1);
+		half_t* __restrict__ grad = grid_gradient + (size_t)meta.offset[rec[0]] * F;
+		const uint32_t index = rec[1];
+		if constexpr (F == 1) {
+			const half_t v = (half_t)__builtin_bit_cast(float, rec[2]);
+			atomic_add_h2(grad + (index & ~1u), (index & 1u) ? h2{(half_t)0.0f, v} : h2{v, (half_t)0.0f});
+		} else {
+#pragma unroll
+			for (uint32_t p = 0; p < PW; ++p) atomic_add_h2(grad + (size_t)index * F + 2 * p, bits_h2(rec[2 + p]));
+		}
+	}
+}
+
 template <uint32_t D, uint32_t F, bool PACKED>
 __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const GridMeta meta, const GridIO io, const SlicePlan plan,
                                                                            const half_t* __restrict__ dL_dy, half_t* __restrict__ grid_gradient,
-                                                                           const int accumulate) {
+                                                                           const int accumulate, const BucketPlan bplan,
+                                                                           const uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues) {
 	TCNN_DYN_LDS(lds_raw);
 	uint32_t item = 0;
 	while (item + 1 < plan.n_items && blockIdx.x >= plan.block_begin[item + 1]) ++item;
@@ -463,6 +731,10 @@ __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const G
 	const bool level_off = (float)level > max_level + 1e-3f;  // grid.h:242
 	const Level<D> lv = make_level<D>(meta, level);
 
+	if (kind == SLICE_BUCKET) {
+		bucket_level<D, F>(meta, lv, level, plan.slot[item], slice, bplan, counters, queues, grid_gradient, accumulate != 0, lds_raw);
+		return;
+	}
 	if (kind == SLICE_GLOBAL_ATOMIC) {
 		// Dense-indexed level too large for the fixed-point path: its corners are memory-adjacent, so a float
 		// slice would see all-or-nothing samples (8 serial iterations at 1/16 lane occupancy).  The memory-side
@@ -589,8 +861,17 @@ static void grid_backward_atomic(hipStream_t stream, const GridMeta& meta, const
 #undef BWD
 }
 
-static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient,
-                                 bool accumulate, bool packed, uint32_t lds_slice_bytes) {
+// Host-side plan of one sliced / bucketed launch sequence.
+struct BackwardPlan {
+	SlicePlan slices = {};
+	BucketPlan buckets = {};
+	uint32_t lds_slice_bytes = 0, blocks = 0;
+	std::vector<uint32_t> n_chunks;  // per item
+	// workspace layout (bytes from its start)
+	size_t counters_bytes = 0, queues_offset = 0, overflow_offset = 0, workspace_bytes = 0;
+};
+
+static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool packed, bool bucketed, uint32_t lds_slice_bytes) {
 	const uint32_t F = meta.n_feat;
 	packed = packed && (F % 2 == 0);
 	if (lds_slice_bytes == 0 || lds_slice_bytes > SLICED_LDS_MAX_BYTES) lds_slice_bytes = SLICED_LDS_BYTES;
@@ -599,10 +880,22 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 	lds_slice_bytes = std::max(lds_slice_bytes / fixed_entry_bytes, 8u) * fixed_entry_bytes;
 	const uint32_t cap_fixed = lds_slice_bytes / fixed_entry_bytes, cap_float = lds_slice_bytes / float_entry_bytes;  // entries per slice
 	constexpr uint32_t MAX_BASES[11] = {0x0, 0xFFFFFFFF, 0xFFFF, 0x659, 0xFF, 0x54, 0x28, 0x17, 0xF, 0xB, 0x9};
+	uint32_t bucket_shift = 0;  // buckets hold a power-of-two number of entries (bucket = index >> shift)
+	while ((2u << bucket_shift) <= cap_fixed) ++bucket_shift;
+	const uint32_t n_corners = meta.interp == (uint32_t)InterpolationType::Nearest ? 1u : (1u << meta.n_dims);
+	const uint32_t record_words = 1u + (F + 1u) / 2u;
 
-	// Per level: accumulator kind by expected LDS-atomic density (see the comment above the kernel).
+	BackwardPlan bp;
+	bp.lds_slice_bytes = lds_slice_bytes;
+	BucketPlan& bk = bp.buckets;
+	bk.shift = bucket_shift;
+	bk.tiles = div_round_up(n, bucket_spt(meta.n_dims, F) * BUCKET_THREADS);
+	uint32_t n_counters = 0;
+	uint64_t n_queue_records = 0, n_records = 0;
+
+	// Per level: accumulator kind by expected LDS-atomic density (see the comments above the kernels).
 	struct Item {
-		uint32_t level, kind, n_slices, n_chunks;
+		uint32_t level, kind, n_slices, n_chunks, slot;
 	};
 	std::vector<Item> items;
 	for (uint32_t l = 0; l < meta.n_levels; ++l) {
@@ -611,25 +904,52 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 		for (uint32_t d = 0; d < meta.n_dims; ++d) dense = meta.resolution[l] <= MAX_BASES[meta.n_dims] ? dense * meta.resolution[l] : ~0ull >> 1;
 		const bool hashed = meta.grid_type == (uint32_t)GridType::Hash && (uint64_t)entries < dense;
 		const uint32_t n_fixed = div_round_up(entries, cap_fixed);
-		Item it = {l, SLICE_FIXED64, n_fixed, 1u};
+		const uint32_t n_buckets = div_round_up(entries, 1u << bucket_shift);
+		Item it = {l, SLICE_FIXED64, n_fixed, 1u, 0u};
 		if (n_fixed <= 8) {
 			// small table: every corner of every sample hits the slice(s) -> dense atomics -> fixed point;
 			// <= 4 slices also split the SAMPLES over up to 16 workgroups (few flush atomics)
-			if (n_fixed <= 4) it.n_chunks = std::max(1u, std::min(16u / n_fixed, div_round_up(io.n, 2048u)));
+			if (n_fixed <= 4) it.n_chunks = std::max(1u, std::min(16u / n_fixed, div_round_up(n, 2048u)));
+		} else if (bucketed && bk.n_levels < MAX_BUCKET_LEVELS && n_buckets <= MAX_BUCKETS_PER_LEVEL) {
+			// large table: corners are derived once, binned by slice, accumulated by the slice's owner
+			const uint32_t j = bk.n_levels++;
+			const uint64_t expected = (uint64_t)n * n_corners / n_buckets;
+			const uint64_t capacity = next_multiple<uint64_t>(2 * expected + 1024, 64);
+			if (capacity > 0x7FFFFFFFull) throw std::runtime_error("grid_backward: batch too large for the bucketed backward");
+			bk.level[j] = (uint8_t)l;
+			bk.n_buckets[j] = n_buckets;
+			bk.capacity[j] = (uint32_t)capacity;
+			bk.counter_base[j] = n_counters;
+			bk.queue_base[j] = n_queue_records;
+			n_counters += n_buckets;
+			n_queue_records += capacity * n_buckets;
+			n_records += (uint64_t)n * n_corners;
+			it.kind = SLICE_BUCKET;
+			it.n_slices = n_buckets;
+			it.slot = j;
 		} else if (hashed) {
 			// hashed level: corners scatter over the table -> >= 16 float slices see <= 1/16 of them (sparse atomics)
 			it.kind = SLICE_FLOAT;
 			it.n_slices = std::max(16u, div_round_up(entries, cap_float));
 		} else {
 			it.kind = SLICE_GLOBAL_ATOMIC;
-			it.n_slices = std::max(1u, div_round_up(io.n, SLICED_THREADS * 4u));  // sample tiles
+			it.n_slices = std::max(1u, div_round_up(n, SLICED_THREADS * 4u));  // sample tiles
 		}
 		items.push_back(it);
 	}
-	// long slice passes first, the short work (fixed-point chunks, atomic tiles) fills the tail
-	std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return (a.kind == SLICE_FLOAT) > (b.kind == SLICE_FLOAT); });
+	if (n_records > 0xFFFFFFFFull) throw std::runtime_error("grid_backward: batch too large for the bucketed backward");
+	bk.overflow_counter = n_counters;
+	bk.overflow_capacity = (uint32_t)n_records;
+	bp.counters_bytes = next_multiple<size_t>(((size_t)n_counters + 1) * sizeof(uint32_t), 256);
+	bp.queues_offset = bp.counters_bytes;
+	bp.overflow_offset = bp.queues_offset + next_multiple<size_t>(n_queue_records * record_words * sizeof(uint32_t), 256);
+	bp.workspace_bytes = bk.n_levels ? bp.overflow_offset + next_multiple<size_t>(n_records * (record_words + 1) * sizeof(uint32_t), 256) : 0;
 
-	SlicePlan plan = {};
+	// long passes first (bucket owners, float slices), the short work (fixed-point chunks, atomic tiles) fills the tail
+	auto is_long = [](const Item& it) { return it.kind == SLICE_FLOAT || it.kind == SLICE_BUCKET; };
+	std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) { return is_long(a) > is_long(b); });
+
+	SlicePlan& plan = bp.slices;
 	plan.n_items = (uint32_t)items.size();
 	uint32_t blocks = 0;
 	for (uint32_t p = 0; p < plan.n_items; ++p) {
@@ -638,7 +958,54 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 		plan.n_slices[p] = it.n_slices;
 		plan.level[p] = (uint8_t)it.level;
 		plan.kind[p] = (uint8_t)it.kind;
+		plan.slot[p] = (uint8_t)it.slot;
+		bp.n_chunks.push_back(it.n_chunks);
 		blocks += it.n_slices * it.n_chunks;
+	}
+	plan.block_begin[plan.n_items] = blocks;
+	bp.blocks = blocks;
+	return bp;
+}
+
+size_t grid_backward_workspace_bytes(const GridMeta& meta, uint32_t n, GridBackwardMode mode, uint32_t lds_slice_bytes) {
+	if (mode != GridBackwardMode::Bucketed || n == 0) return 0;
+	return make_backward_plan(meta, n, true, true, lds_slice_bytes).workspace_bytes;
+}
+
+static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient,
+                                 bool accumulate, bool packed, bool bucketed, uint32_t lds_slice_bytes, void* workspace, size_t workspace_bytes) {
+	const uint32_t F = meta.n_feat;
+	packed = packed && (F % 2 == 0);
+	const BackwardPlan bp = make_backward_plan(meta, io.n, packed, bucketed, lds_slice_bytes);
+	lds_slice_bytes = bp.lds_slice_bytes;
+	const SlicePlan& plan = bp.slices;
+	const BucketPlan& bk = bp.buckets;
+	const uint32_t blocks = bp.blocks;
+	uint32_t* counters = nullptr;
+	uint32_t* queues = nullptr;
+	uint32_t* overflow = nullptr;
+	if (bk.n_levels) {
+		if (!workspace || workspace_bytes < bp.workspace_bytes) throw std::runtime_error("grid_backward: workspace too small for the bucketed backward");
+		counters = (uint32_t*)workspace;
+		queues = (uint32_t*)((unsigned char*)workspace + bp.queues_offset);
+		overflow = (uint32_t*)((unsigned char*)workspace + bp.overflow_offset);
+		if (hipMemsetAsync(counters, 0, bp.counters_bytes, stream) != hipSuccess) throw std::runtime_error("grid_backward: memset failed");
+		// pass A: derive every corner once, bin by owner
+		const uint32_t scatter_blocks = bk.n_levels * bk.tiles;
+		uint32_t max_buckets = 0;
+		for (uint32_t j = 0; j < bk.n_levels; ++j) max_buckets = std::max(max_buckets, bk.n_buckets[j]);
+#define BSCATTER(D_, F_)                                                                                                                      \
+	{                                                                                                                                         \
+		const uint32_t lds = bucket_spt(D_, F_) * BUCKET_THREADS * (1u << D_) * BucketRecord<F_>::WORDS * 4u + (3u * max_buckets + BUCKET_THREADS) * 4u; \
+		TCNN_SET_MAX_DYN_LDS((k_grid_bucket_scatter<D_, F_>), lds);                                                                           \
+		TCNN_LAUNCH((k_grid_bucket_scatter<D_, F_>), dim3(scatter_blocks), dim3(BUCKET_THREADS), lds, stream, meta, io, bk, dL_dy, counters,  \
+		            queues, overflow);                                                                                                        \
+	}
+		TCNN_GRID_DISPATCH(BSCATTER)
+#undef BSCATTER
+	}
+	for (uint32_t p = 0; p < plan.n_items; ++p) {
+		struct { uint32_t level, kind, n_chunks; } it = {plan.level[p], plan.kind[p], bp.n_chunks[p]};
 		if ((it.n_chunks > 1 || it.kind == SLICE_GLOBAL_ATOMIC) && !accumulate) {  // atomically updated levels start from zero
 			const uint32_t entries = meta.offset[it.level + 1] - meta.offset[it.level];
 			if (hipMemsetAsync(grid_gradient + (size_t)meta.offset[it.level] * F, 0, (size_t)entries * F * sizeof(half_t), stream) != hipSuccess) {
@@ -646,32 +1013,40 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 			}
 		}
 	}
-	plan.block_begin[plan.n_items] = blocks;
 	const int acc = accumulate ? 1 : 0;
 #define BWDS(D_, F_)                                                                                                                   \
 	if (packed) {                                                                                                                      \
 		if constexpr (F_ % 2 == 0) {                                                                                                   \
 			TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, true>), lds_slice_bytes);                                             \
 			TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, true>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io, \
-			            plan, dL_dy, grid_gradient, acc);                                                                              \
+			            plan, dL_dy, grid_gradient, acc, bk, (const uint32_t*)counters, (const uint32_t*)queues);                      \
 		}                                                                                                                              \
 	} else {                                                                                                                           \
 		TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, false>), lds_slice_bytes);                                                \
 		TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, false>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io,    \
-		            plan, dL_dy, grid_gradient, acc);                                                                                  \
+		            plan, dL_dy, grid_gradient, acc, bk, (const uint32_t*)counters, (const uint32_t*)queues);                          \
 	}
 	TCNN_GRID_DISPATCH(BWDS)
 #undef BWDS
+	if (bk.n_levels) {
+		// pass C: overflowed records (none for near-uniform inputs: the kernel reads one counter and exits)
+#define BOVF(D_, F_) TCNN_LAUNCH((k_grid_bucket_overflow<F_>), dim3(256), dim3(256), 0, stream, meta, bk, (const uint32_t*)counters, (const uint32_t*)overflow, grid_gradient);
+		TCNN_GRID_DISPATCH(BOVF)
+#undef BOVF
+	}
 }
 
 void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient, bool accumulate,
-                   GridBackwardMode mode, uint32_t lds_slice_bytes) {
+                   GridBackwardMode mode, uint32_t lds_slice_bytes, void* workspace, size_t workspace_bytes) {
 	if (io.n == 0) return;
 	if (!grid_gradient) throw std::runtime_error("grid_backward: missing gradient buffer");
 	switch (mode) {
-		case GridBackwardMode::SlicedF32: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, false, lds_slice_bytes); break;
-		case GridBackwardMode::SlicedF16: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, true, lds_slice_bytes); break;
+		case GridBackwardMode::SlicedF32: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, false, false, lds_slice_bytes, nullptr, 0); break;
+		case GridBackwardMode::SlicedF16: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, true, false, lds_slice_bytes, nullptr, 0); break;
 		case GridBackwardMode::Atomic: grid_backward_atomic(stream, meta, io, dL_dy, grid_gradient, accumulate); break;
+		case GridBackwardMode::Bucketed:
+			grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, true, true, lds_slice_bytes, workspace, workspace_bytes);
+			break;
 	}
 }
 

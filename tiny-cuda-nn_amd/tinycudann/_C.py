@@ -116,6 +116,7 @@ _sig("tcnn_trainer_stage_name", _cp, _i)
 _sig("tcnn_trainer_get_stage_times", _i, _vp, _vp, _vp)
 _sig("tcnn_trainer_set_lds_level_budget", _i, _vp, _u32)
 _sig("tcnn_set_grid_backward_mode", _i, _i)
+_sig("tcnn_get_grid_backward_mode", _i)
 
 EXPORTED_SYMBOLS = [n for n in dir(_lib) if n.startswith("tcnn_")]
 
@@ -152,6 +153,10 @@ def preferred_precision():
 
 def supports_jit_fusion(device=-1):
     return bool(_lib.tcnn_supports_jit_fusion(device))
+
+
+def get_grid_backward_mode():
+    return int(_lib.tcnn_get_grid_backward_mode())
 
 
 def set_grid_backward_mode(mode):

@@ -12,6 +12,9 @@ cases = {
     "hashed-only 13 levels (base 128)": {"otype": "HashGrid", "n_levels": 13, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 128, "per_level_scale": 2.0},
     "level 0 only (4096 entries)": {"otype": "HashGrid", "n_levels": 1, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 16, "per_level_scale": 2.0},
     "levels 0-2 (dense)": {"otype": "HashGrid", "n_levels": 3, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 16, "per_level_scale": 2.0},
+    "level 1 only (32768 entries)": {"otype": "HashGrid", "n_levels": 1, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 32, "per_level_scale": 2.0},
+    "level 2 only (262144 dense)": {"otype": "HashGrid", "n_levels": 1, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 64, "per_level_scale": 2.0},
+    "4 hashed levels (base 512)": {"otype": "HashGrid", "n_levels": 4, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 512, "per_level_scale": 2.0},
     "one hashed level (base 512)": {"otype": "HashGrid", "n_levels": 1, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 512, "per_level_scale": 2.0},
 }
 for name, enc in cases.items():
@@ -20,7 +23,7 @@ for name, enc in cases.items():
     xx = x.clone()
     ctx, y = m.fwd(xx, p)
     dy = (torch.randn_like(y.float()) * 0.01).half()
-    for mode, mname in ((0, "sliced_f32"), (1, "sliced_f16"), (2, "atomic")):
+    for mode, mname in ((1, "sliced_f16"), (3, "bucketed")):
         C.set_grid_backward_mode(mode)
         for _ in range(3):
             m.bwd(ctx, xx, p, y, dy)

@@ -52,10 +52,18 @@ int emu_grid_backward(const EmuGrid* e, const float* positions, uint32_t n, cons
 	try {
 		GridIO io = {positions, e->n_dims, 1, n, soa ? n : 1u, soa ? 1u : dy_stride};
 		const GridMeta meta = make_meta(e);
-		const size_t ws_bytes = grid_backward_workspace_bytes(meta, n, (GridBackwardMode)mode, lds_budget);
-		std::vector<unsigned char> ws(ws_bytes + 16, 0xCD);  // garbage-filled: the call must not rely on a clean workspace
-		grid_backward(nullptr, meta, io, (const half_t*)dL_dy, (half_t*)grad_half, accumulate != 0, (GridBackwardMode)mode, lds_budget,
-		              ws_bytes ? ws.data() : nullptr, ws_bytes);
+		GridBackwardWorkspace ws = grid_backward_workspace_size(meta, n, (GridBackwardMode)mode, lds_budget);
+		std::vector<unsigned char> scratch(ws.scratch_bytes + 16, 0xCD);  // garbage-filled: the call must not rely on clean scratch
+		static std::vector<uint32_t> counters;                            // zero on entry, zero on exit (checked below)
+		if (counters.size() < ws.n_counters) counters.assign(ws.n_counters, 0u);
+		if (ws.scratch_bytes) {
+			ws.scratch = scratch.data();
+			ws.counters = counters.data();
+		}
+		grid_backward(nullptr, meta, io, (const half_t*)dL_dy, (half_t*)grad_half, accumulate != 0, (GridBackwardMode)mode, lds_budget, ws);
+		for (uint32_t c : counters) {
+			if (c != 0u) throw std::runtime_error("bucketed backward left a non-zero counter behind");
+		}
 	} catch (const std::exception& ex) {
 		fprintf(stderr, "emu_grid_backward: %s\n", ex.what());
 		return 1;

@@ -94,6 +94,45 @@ private:
 	}
 };
 
+// Small per-stream device buffers that are zero whenever no kernel of that stream is using them (the bucketed grid
+// backward's queue counters: its kernels hand them back zeroed, so they are cleared exactly once, at allocation).
+class ZeroedCounters {
+public:
+	static uint32_t* get(hipStream_t stream, size_t n) {
+		std::lock_guard<std::mutex> lock(mutex());
+		auto& slot = slots()[stream];
+		if (slot.second < n) {
+			if (slot.first) {
+				HIP_CHECK(hipStreamSynchronize(stream));
+				(void)hipFree(slot.first);
+				slot = {nullptr, 0};
+			}
+			const size_t cap = std::max<size_t>(next_multiple<size_t>(n, 1024), 4096);
+			void* p = nullptr;
+			HIP_CHECK(hipMalloc(&p, cap * sizeof(uint32_t)));
+			HIP_CHECK(hipMemset(p, 0, cap * sizeof(uint32_t)));
+			slot = {(uint32_t*)p, cap};
+		}
+		return slot.first;
+	}
+	static void free_all() {
+		std::lock_guard<std::mutex> lock(mutex());
+		(void)hipDeviceSynchronize();
+		for (auto& kv : slots()) (void)hipFree(kv.second.first);
+		slots().clear();
+	}
+
+private:
+	static std::mutex& mutex() {
+		static std::mutex m;
+		return m;
+	}
+	static std::map<hipStream_t, std::pair<uint32_t*, size_t>>& slots() {
+		static std::map<hipStream_t, std::pair<uint32_t*, size_t>> s;
+		return s;
+	}
+};
+
 struct Scratch {
 	void* ptr = nullptr;
 	size_t bytes = 0;
@@ -579,10 +618,15 @@ static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx
 			// whole slices, so the reference's full-table memset is only issued for the atomic A/B mode.
 			ProfScope prof(stream, STAGE_GRID_BWD);
 			const GridBackwardMode mode = (GridBackwardMode)g_grid_backward_mode.load();
-			const size_t ws_bytes = grid_backward_workspace_bytes(e.grid, n, mode, lds_level_budget);
-			Scratch ws;
-			if (ws_bytes) ws = Scratch(stream, ws_bytes);
-			grid_backward(stream, e.grid, io, dL_denc, grid_grads, accumulate, mode, lds_level_budget, ws.ptr, ws.bytes);
+			GridBackwardWorkspace ws = grid_backward_workspace_size(e.grid, n, mode, lds_level_budget);
+			Scratch queues;
+			if (ws.scratch_bytes) {
+				queues = Scratch(stream, ws.scratch_bytes);
+				ws.scratch = queues.ptr;
+				ws.scratch_bytes = queues.bytes;
+				ws.counters = ZeroedCounters::get(stream, ws.n_counters);
+			}
+			grid_backward(stream, e.grid, io, dL_denc, grid_grads, accumulate, mode, lds_level_budget, ws);
 		}
 		if (dL_dinput) {
 			if (!ctx.dy_dx.ptr) throw std::runtime_error("backward: dL_dinput requested but forward was not run with prepare_input_gradients");
@@ -673,7 +717,10 @@ int tcnn_set_hip_device(int device) {
 	HIP_CHECK(hipSetDevice(device));
 	TCNN_API_END
 }
-void tcnn_free_temporary_memory(void) { ScratchCache::free_all(); }
+void tcnn_free_temporary_memory(void) {
+	ScratchCache::free_all();
+	ZeroedCounters::free_all();
+}
 int tcnn_has_networks(void) { return 1; }
 float tcnn_default_loss_scale(int precision) { return precision == TCNN_PRECISION_FP32 ? 1.0f : LOSS_SCALE_FP16; }
 int tcnn_preferred_precision(void) { return TCNN_PRECISION_FP16; }

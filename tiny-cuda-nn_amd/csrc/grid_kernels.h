@@ -54,13 +54,21 @@ void grid_forward(hipStream_t stream, const GridMeta& meta, const GridIO& io, co
 //                          kept for A/B measurements.
 //   Bucketed:              large levels derive every corner ONCE, bin the records by owning slice in HBM queues
 //                          and let the owner accumulate them in 64-bit fixed point in LDS; small levels as in
-//                          the sliced modes.  Needs `workspace` (grid_backward_workspace_bytes) -- device
-//                          memory the call may scribble on, no state is kept in it between calls.
+//                          the sliced modes.  Needs a GridBackwardWorkspace (sizes from grid_backward_workspace_size):
+//                          `scratch` is device memory the call may scribble on (nothing is kept in it between
+//                          calls); `counters` must be ZERO on entry and is left zeroed by the call, so a caller
+//                          keeps one such buffer per stream and never clears it again.
 // lds_slice_bytes: LDS bytes one workgroup devotes to its table slice (0 = default 128 KiB).
 enum class GridBackwardMode : int { SlicedF32 = 0, SlicedF16 = 1, Atomic = 2, Bucketed = 3 };
-size_t grid_backward_workspace_bytes(const GridMeta& meta, uint32_t n, GridBackwardMode mode, uint32_t lds_slice_bytes);
+struct GridBackwardWorkspace {
+	void* scratch = nullptr;
+	size_t scratch_bytes = 0;
+	uint32_t* counters = nullptr;
+	size_t n_counters = 0;
+};
+GridBackwardWorkspace grid_backward_workspace_size(const GridMeta& meta, uint32_t n, GridBackwardMode mode, uint32_t lds_slice_bytes);
 void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient, bool accumulate,
-                   GridBackwardMode mode, uint32_t lds_slice_bytes, void* workspace = nullptr, size_t workspace_bytes = 0);
+                   GridBackwardMode mode, uint32_t lds_slice_bytes, const GridBackwardWorkspace& workspace = GridBackwardWorkspace());
 
 // dL_dx[i][d] = sum_k dL_dy[k][i] * dy_dx[k][i][d]   (grid.h:323-349)
 void grid_backward_input(hipStream_t stream, uint32_t n_dims, uint32_t n_features, const GridIO& io,

@@ -470,14 +470,19 @@ struct BucketPlan {
 	uint32_t n_levels;  // bucketed levels
 	uint32_t shift;     // log2(entries per bucket)
 	uint32_t tiles;     // sample tiles per level in pass A
-	uint32_t overflow_counter;              // index of the overflow counter (== total number of buckets)
-	uint32_t overflow_capacity;             // records
-	uint8_t level[MAX_BUCKET_LEVELS];       // grid level of slot j
-	uint32_t n_buckets[MAX_BUCKET_LEVELS];
-	uint32_t capacity[MAX_BUCKET_LEVELS];      // records per bucket queue
-	uint32_t counter_base[MAX_BUCKET_LEVELS];  // first counter of slot j
-	uint64_t queue_base[MAX_BUCKET_LEVELS];    // first record of slot j's queues
+	uint32_t scatter_blocks;     // n_levels * tiles: pass-A blocks beyond these zero the gradients of chunked levels
+	uint32_t overflow_counter;   // index of the overflow counter (== total number of queues); the one after it counts finished pass-C blocks
+	uint32_t overflow_capacity;  // records
+	uint8_t level[MAX_BUCKET_LEVELS];             // grid level of slot j
+	uint32_t n_buckets[MAX_BUCKET_LEVELS];        // table slices
+	uint32_t n_chunks[MAX_BUCKET_LEVELS];         // sample chunks: a queue belongs to one (chunk, bucket); > 1 only for small tables
+	uint32_t tiles_per_chunk[MAX_BUCKET_LEVELS];
+	uint32_t capacity[MAX_BUCKET_LEVELS];         // records per queue
+	uint32_t counter_base[MAX_BUCKET_LEVELS];     // first counter of slot j; queue (chunk, bucket) uses counter chunk * n_buckets + bucket
+	uint32_t zero_block_begin[MAX_BUCKET_LEVELS + 1];  // pass-A zeroing blocks of slot j (4 KiB each; none unless chunked && !accumulate)
+	uint64_t queue_base[MAX_BUCKET_LEVELS];       // first record of slot j's queues
 };
+constexpr uint32_t ZERO_BLOCK_HALVES = 2048;  // 4 KiB per zeroing block
 
 // record = {entry index within the level, payload}: payload = F halves packed in pairs (F == 1: one fp32, the
 // reference's grad_t for a single feature is float, grid.h:665)
@@ -499,13 +504,26 @@ TCNN_DEVICE h2 bits_h2(uint32_t v) { return __builtin_bit_cast(h2, v); }
 template <uint32_t D, uint32_t F>
 __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const GridMeta meta, const GridIO io, const BucketPlan plan,
                                                                          const half_t* __restrict__ dL_dy, uint32_t* __restrict__ counters,
-                                                                         uint32_t* __restrict__ queues, uint32_t* __restrict__ overflow) {
+                                                                         uint32_t* __restrict__ queues, uint32_t* __restrict__ overflow,
+                                                                         half_t* __restrict__ grid_gradient) {
 	constexpr uint32_t N_CORNERS = 1u << D, PW = BucketRecord<F>::PAYLOAD_WORDS, W = BucketRecord<F>::WORDS;
 	constexpr uint32_t SPT = bucket_spt(D, F), TILE = SPT * BUCKET_THREADS, N_REC = TILE * N_CORNERS;
 	constexpr uint32_t INVALID = 0xFFFFFFFFu;
 	TCNN_DYN_LDS(lds_raw);
+	if (blockIdx.x >= plan.scatter_blocks) {
+		// gradients of chunked levels are accumulated with atomics by several owners in pass B: zero them here
+		const uint32_t z = blockIdx.x - plan.scatter_blocks;
+		uint32_t zj = 0;
+		while (zj + 1 < plan.n_levels && z >= plan.zero_block_begin[zj + 1]) ++zj;
+		const uint32_t zl = plan.level[zj];
+		const uint32_t n_halves = (meta.offset[zl + 1] - meta.offset[zl]) * F;  // a multiple of 8
+		const uint32_t h = (z - plan.zero_block_begin[zj]) * ZERO_BLOCK_HALVES + threadIdx.x * 8u;
+		if (h < n_halves) *(u4*)(grid_gradient + (size_t)meta.offset[zl] * F + h) = u4{0u, 0u, 0u, 0u};
+		return;
+	}
 	const uint32_t j = blockIdx.x / plan.tiles, tile = blockIdx.x % plan.tiles;
 	const uint32_t level = plan.level[j], nb = plan.n_buckets[j], shift = plan.shift;
+	const uint32_t chunk = tile / plan.tiles_per_chunk[j];
 	const uint32_t n_features = meta.n_levels * F;
 	const float max_level = (meta.max_level * (float)n_features) / (float)F;
 	if ((float)level > max_level + 1e-3f) return;  // grid.h:242: no records, the owners store zeros
@@ -575,7 +593,7 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 		const uint32_t c = cnt[b];
 		off[b] = running;
 		running += c;
-		gbase[b] = c ? atomic_add_u32(&counters[plan.counter_base[j] + b], c) : 0u;
+		gbase[b] = c ? atomic_add_u32(&counters[plan.counter_base[j] + chunk * nb + b], c) : 0u;
 	}
 	const uint32_t total = part[BUCKET_THREADS - 1];
 	__syncthreads();
@@ -600,7 +618,7 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 
 	// ---- append the runs to the bucket queues: consecutive threads -> consecutive records
 	const uint32_t cap = plan.capacity[j];
-	uint32_t* __restrict__ q = queues + plan.queue_base[j] * W;
+	uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)chunk * nb * cap) * W;
 	for (uint32_t t = threadIdx.x; t < total; t += BUCKET_THREADS) {
 		uint32_t rec[W];
 		if constexpr (W == 2) {
@@ -635,9 +653,9 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 
 // pass B: the owner of bucket `bucket` of slot `j` streams its queue into a 64-bit fixed-point LDS table
 template <uint32_t D, uint32_t F>
-TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t level, uint32_t j, uint32_t bucket, const BucketPlan& plan,
-                              const uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues, half_t* __restrict__ grid_gradient,
-                              bool accumulate, unsigned char* lds_raw) {
+TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t level, uint32_t j, uint32_t bucket, uint32_t chunk,
+                              const BucketPlan& plan, uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues,
+                              half_t* __restrict__ grid_gradient, bool accumulate, unsigned char* lds_raw) {
 	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, W = BucketRecord<F>::WORDS;
 	const uint32_t entries_per_bucket = 1u << plan.shift;
 	const uint32_t slice_begin = bucket * entries_per_bucket;
@@ -646,9 +664,10 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 	for (uint32_t e = threadIdx.x; e < slice_count * F * 2; e += SLICED_THREADS) ((uint32_t*)lds_raw)[e] = 0u;
 	__syncthreads();
 
-	const uint32_t cap = plan.capacity[j];
-	const uint32_t count = min(counters[plan.counter_base[j] + bucket], cap);
-	const uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)bucket * cap) * W;
+	const uint32_t cap = plan.capacity[j], n_chunks = plan.n_chunks[j];
+	const uint32_t queue = chunk * plan.n_buckets[j] + bucket;
+	const uint32_t count = min(counters[plan.counter_base[j] + queue], cap);
+	const uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)queue * cap) * W;
 	constexpr uint32_t U = 4;  // records in flight per lane
 	for (uint32_t base = threadIdx.x; base < count; base += SLICED_THREADS * U) {
 		uint32_t rec[U][W];
@@ -687,17 +706,28 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 	for (uint32_t e2 = threadIdx.x; e2 < n_halves / 2; e2 += SLICED_THREADS) {
 		const long long q0 = ((const long long*)lds_raw)[2 * e2], q1 = ((const long long*)lds_raw)[2 * e2 + 1];
 		h2 v = h2{(half_t)(float)((double)q0 * (1.0 / FIXED_SCALE)), (half_t)(float)((double)q1 * (1.0 / FIXED_SCALE))};
-		if (accumulate) v += *(const h2*)(grad + 2 * e2);
-		*(h2*)(grad + 2 * e2) = v;
+		if (n_chunks == 1) {  // sole owner of the slice: plain stores
+			if (accumulate) v += *(const h2*)(grad + 2 * e2);
+			*(h2*)(grad + 2 * e2) = v;
+		} else if (v[0] != (half_t)0.0f || v[1] != (half_t)0.0f) {
+			atomic_add_h2(grad + 2 * e2, v);  // small tables only: (table size) x (chunks) updates per level
+		}
 	}
+	if (threadIdx.x == 0) counters[plan.counter_base[j] + queue] = 0u;  // every thread read it before the barriers above: counters end the call zeroed
 }
 
 // pass C: queue overflow -> the reference's global atomics (runs after pass B stored the slices)
 template <uint32_t F>
-__global__ void __launch_bounds__(256) k_grid_bucket_overflow(const GridMeta meta, const BucketPlan plan, const uint32_t* __restrict__ counters,
+__global__ void __launch_bounds__(256) k_grid_bucket_overflow(const GridMeta meta, const BucketPlan plan, uint32_t* __restrict__ counters,
                                                                const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient) {
 	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, W = BucketRecord<F>::WORDS;
 	const uint32_t count = min(counters[plan.overflow_counter], plan.overflow_capacity);
+	__syncthreads();
+	// the last block to get here (every block has read `count` by then) leaves the two bookkeeping counters zeroed
+	if (threadIdx.x == 0 && atomic_add_u32(&counters[plan.overflow_counter + 1], 1u) == gridDim.x - 1u) {
+		counters[plan.overflow_counter] = 0u;
+		counters[plan.overflow_counter + 1] = 0u;
+	}
 	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < count; t += gridDim.x * 256u) {
 		const uint32_t* rec = overflow + (size_t)t * (W + 1);
 		half_t* __restrict__ grad = grid_gradient + (size_t)meta.offset[rec[0]] * F;
@@ -716,7 +746,7 @@ template <uint32_t D, uint32_t F, bool PACKED>
 __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const GridMeta meta, const GridIO io, const SlicePlan plan,
                                                                            const half_t* __restrict__ dL_dy, half_t* __restrict__ grid_gradient,
                                                                            const int accumulate, const BucketPlan bplan,
-                                                                           const uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues) {
+                                                                           uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues) {
 	TCNN_DYN_LDS(lds_raw);
 	uint32_t item = 0;
 	while (item + 1 < plan.n_items && blockIdx.x >= plan.block_begin[item + 1]) ++item;
@@ -732,7 +762,7 @@ __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const G
 	const Level<D> lv = make_level<D>(meta, level);
 
 	if (kind == SLICE_BUCKET) {
-		bucket_level<D, F>(meta, lv, level, plan.slot[item], slice, bplan, counters, queues, grid_gradient, accumulate != 0, lds_raw);
+		bucket_level<D, F>(meta, lv, level, plan.slot[item], slice, chunk, bplan, counters, queues, grid_gradient, accumulate != 0, lds_raw);
 		return;
 	}
 	if (kind == SLICE_GLOBAL_ATOMIC) {
@@ -868,10 +898,10 @@ struct BackwardPlan {
 	uint32_t lds_slice_bytes = 0, blocks = 0;
 	std::vector<uint32_t> n_chunks;  // per item
 	// workspace layout (bytes from its start)
-	size_t counters_bytes = 0, queues_offset = 0, overflow_offset = 0, workspace_bytes = 0;
+	size_t n_counters = 0, overflow_offset = 0, workspace_bytes = 0;  // queues at offset 0 of the workspace
 };
 
-static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool packed, bool bucketed, uint32_t lds_slice_bytes) {
+static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool packed, bool bucketed, bool accumulate, uint32_t lds_slice_bytes) {
 	const uint32_t F = meta.n_feat;
 	packed = packed && (F % 2 == 0);
 	if (lds_slice_bytes == 0 || lds_slice_bytes > SLICED_LDS_MAX_BYTES) lds_slice_bytes = SLICED_LDS_BYTES;
@@ -890,7 +920,7 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 	BucketPlan& bk = bp.buckets;
 	bk.shift = bucket_shift;
 	bk.tiles = div_round_up(n, bucket_spt(meta.n_dims, F) * BUCKET_THREADS);
-	uint32_t n_counters = 0;
+	uint32_t n_counters = 0, n_zero_blocks = 0;
 	uint64_t n_queue_records = 0, n_records = 0;
 
 	// Per level: accumulator kind by expected LDS-atomic density (see the comments above the kernels).
@@ -906,27 +936,39 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 		const uint32_t n_fixed = div_round_up(entries, cap_fixed);
 		const uint32_t n_buckets = div_round_up(entries, 1u << bucket_shift);
 		Item it = {l, SLICE_FIXED64, n_fixed, 1u, 0u};
-		if (n_fixed <= 8) {
-			// small table: every corner of every sample hits the slice(s) -> dense atomics -> fixed point;
-			// <= 4 slices also split the SAMPLES over up to 16 workgroups (few flush atomics)
-			if (n_fixed <= 4) it.n_chunks = std::max(1u, std::min(16u / n_fixed, div_round_up(n, 2048u)));
-		} else if (bucketed && bk.n_levels < MAX_BUCKET_LEVELS && n_buckets <= MAX_BUCKETS_PER_LEVEL) {
-			// large table: corners are derived once, binned by slice, accumulated by the slice's owner
+		if (bucketed && bk.n_levels < MAX_BUCKET_LEVELS && n_buckets <= MAX_BUCKETS_PER_LEVEL) {
+			// corners are derived once, binned by (table slice, sample chunk), accumulated by the queue's owner.
+			// Large tables: one owner per slice (plain stores).  Small tables have few slices: the samples are also
+			// split so that an owner sees ~32 Ki records; the owners of a slice then combine with packed-half atomics.
 			const uint32_t j = bk.n_levels++;
-			const uint64_t expected = (uint64_t)n * n_corners / n_buckets;
+			const uint64_t level_records = (uint64_t)n * n_corners;
+			const uint64_t per_bucket = level_records / n_buckets;
+			uint32_t n_chunks = per_bucket <= 65536 ? 1u : (uint32_t)std::min<uint64_t>(div_round_up<uint64_t>(per_bucket, 32768), bk.tiles);
+			const uint32_t tiles_per_chunk = div_round_up(bk.tiles, n_chunks);
+			n_chunks = div_round_up(bk.tiles, tiles_per_chunk);
+			const uint64_t expected = level_records / ((uint64_t)n_buckets * n_chunks);
 			const uint64_t capacity = next_multiple<uint64_t>(2 * expected + 1024, 64);
 			if (capacity > 0x7FFFFFFFull) throw std::runtime_error("grid_backward: batch too large for the bucketed backward");
 			bk.level[j] = (uint8_t)l;
 			bk.n_buckets[j] = n_buckets;
+			bk.n_chunks[j] = n_chunks;
+			bk.tiles_per_chunk[j] = tiles_per_chunk;
 			bk.capacity[j] = (uint32_t)capacity;
 			bk.counter_base[j] = n_counters;
 			bk.queue_base[j] = n_queue_records;
-			n_counters += n_buckets;
-			n_queue_records += capacity * n_buckets;
-			n_records += (uint64_t)n * n_corners;
+			bk.zero_block_begin[j] = n_zero_blocks;
+			if (n_chunks > 1 && !accumulate) n_zero_blocks += div_round_up(entries * F, ZERO_BLOCK_HALVES);
+			n_counters += n_buckets * n_chunks;
+			n_queue_records += capacity * n_buckets * n_chunks;
+			n_records += level_records;
 			it.kind = SLICE_BUCKET;
 			it.n_slices = n_buckets;
+			it.n_chunks = n_chunks;
 			it.slot = j;
+		} else if (n_fixed <= 8) {
+			// small table: every corner of every sample hits the slice(s) -> dense atomics -> fixed point;
+			// <= 4 slices also split the SAMPLES over up to 16 workgroups (few flush atomics)
+			if (n_fixed <= 4) it.n_chunks = std::max(1u, std::min(16u / n_fixed, div_round_up(n, 2048u)));
 		} else if (hashed) {
 			// hashed level: corners scatter over the table -> >= 16 float slices see <= 1/16 of them (sparse atomics)
 			it.kind = SLICE_FLOAT;
@@ -938,11 +980,12 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 		items.push_back(it);
 	}
 	if (n_records > 0xFFFFFFFFull) throw std::runtime_error("grid_backward: batch too large for the bucketed backward");
+	bk.scatter_blocks = bk.n_levels * bk.tiles;
+	bk.zero_block_begin[bk.n_levels] = n_zero_blocks;
 	bk.overflow_counter = n_counters;
 	bk.overflow_capacity = (uint32_t)n_records;
-	bp.counters_bytes = next_multiple<size_t>(((size_t)n_counters + 1) * sizeof(uint32_t), 256);
-	bp.queues_offset = bp.counters_bytes;
-	bp.overflow_offset = bp.queues_offset + next_multiple<size_t>(n_queue_records * record_words * sizeof(uint32_t), 256);
+	bp.n_counters = bk.n_levels ? n_counters + 2 : 0;
+	bp.overflow_offset = next_multiple<size_t>(n_queue_records * record_words * sizeof(uint32_t), 256);
 	bp.workspace_bytes = bk.n_levels ? bp.overflow_offset + next_multiple<size_t>(n_records * (record_words + 1) * sizeof(uint32_t), 256) : 0;
 
 	// long passes first (bucket owners, float slices), the short work (fixed-point chunks, atomic tiles) fills the tail
@@ -967,16 +1010,20 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 	return bp;
 }
 
-size_t grid_backward_workspace_bytes(const GridMeta& meta, uint32_t n, GridBackwardMode mode, uint32_t lds_slice_bytes) {
-	if (mode != GridBackwardMode::Bucketed || n == 0) return 0;
-	return make_backward_plan(meta, n, true, true, lds_slice_bytes).workspace_bytes;
+GridBackwardWorkspace grid_backward_workspace_size(const GridMeta& meta, uint32_t n, GridBackwardMode mode, uint32_t lds_slice_bytes) {
+	GridBackwardWorkspace ws;
+	if (mode != GridBackwardMode::Bucketed || n == 0) return ws;
+	const BackwardPlan bp = make_backward_plan(meta, n, true, true, false, lds_slice_bytes);
+	ws.scratch_bytes = bp.workspace_bytes;
+	ws.n_counters = bp.n_counters;
+	return ws;
 }
 
 static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient,
-                                 bool accumulate, bool packed, bool bucketed, uint32_t lds_slice_bytes, void* workspace, size_t workspace_bytes) {
+                                 bool accumulate, bool packed, bool bucketed, uint32_t lds_slice_bytes, const GridBackwardWorkspace& ws) {
 	const uint32_t F = meta.n_feat;
 	packed = packed && (F % 2 == 0);
-	const BackwardPlan bp = make_backward_plan(meta, io.n, packed, bucketed, lds_slice_bytes);
+	const BackwardPlan bp = make_backward_plan(meta, io.n, packed, bucketed, accumulate, lds_slice_bytes);
 	lds_slice_bytes = bp.lds_slice_bytes;
 	const SlicePlan& plan = bp.slices;
 	const BucketPlan& bk = bp.buckets;
@@ -985,13 +1032,14 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 	uint32_t* queues = nullptr;
 	uint32_t* overflow = nullptr;
 	if (bk.n_levels) {
-		if (!workspace || workspace_bytes < bp.workspace_bytes) throw std::runtime_error("grid_backward: workspace too small for the bucketed backward");
-		counters = (uint32_t*)workspace;
-		queues = (uint32_t*)((unsigned char*)workspace + bp.queues_offset);
-		overflow = (uint32_t*)((unsigned char*)workspace + bp.overflow_offset);
-		if (hipMemsetAsync(counters, 0, bp.counters_bytes, stream) != hipSuccess) throw std::runtime_error("grid_backward: memset failed");
-		// pass A: derive every corner once, bin by owner
-		const uint32_t scatter_blocks = bk.n_levels * bk.tiles;
+		if (!ws.scratch || ws.scratch_bytes < bp.workspace_bytes || !ws.counters || ws.n_counters < bp.n_counters) {
+			throw std::runtime_error("grid_backward: workspace too small for the bucketed backward");
+		}
+		counters = ws.counters;  // zero on entry (contract); the kernels below leave them zeroed again
+		queues = (uint32_t*)ws.scratch;
+		overflow = (uint32_t*)((unsigned char*)ws.scratch + bp.overflow_offset);
+		// pass A: derive every corner once, bin by owner (+ zero the gradients of chunked levels)
+		const uint32_t scatter_blocks = bk.scatter_blocks + bk.zero_block_begin[bk.n_levels];
 		uint32_t max_buckets = 0;
 		for (uint32_t j = 0; j < bk.n_levels; ++j) max_buckets = std::max(max_buckets, bk.n_buckets[j]);
 #define BSCATTER(D_, F_)                                                                                                                      \
@@ -999,14 +1047,14 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 		const uint32_t lds = bucket_spt(D_, F_) * BUCKET_THREADS * (1u << D_) * BucketRecord<F_>::WORDS * 4u + (3u * max_buckets + BUCKET_THREADS) * 4u; \
 		TCNN_SET_MAX_DYN_LDS((k_grid_bucket_scatter<D_, F_>), lds);                                                                           \
 		TCNN_LAUNCH((k_grid_bucket_scatter<D_, F_>), dim3(scatter_blocks), dim3(BUCKET_THREADS), lds, stream, meta, io, bk, dL_dy, counters,  \
-		            queues, overflow);                                                                                                        \
+		            queues, overflow, grid_gradient);                                                                                         \
 	}
 		TCNN_GRID_DISPATCH(BSCATTER)
 #undef BSCATTER
 	}
 	for (uint32_t p = 0; p < plan.n_items; ++p) {
 		struct { uint32_t level, kind, n_chunks; } it = {plan.level[p], plan.kind[p], bp.n_chunks[p]};
-		if ((it.n_chunks > 1 || it.kind == SLICE_GLOBAL_ATOMIC) && !accumulate) {  // atomically updated levels start from zero
+		if (it.kind != SLICE_BUCKET && (it.n_chunks > 1 || it.kind == SLICE_GLOBAL_ATOMIC) && !accumulate) {  // atomically updated levels start from zero
 			const uint32_t entries = meta.offset[it.level + 1] - meta.offset[it.level];
 			if (hipMemsetAsync(grid_gradient + (size_t)meta.offset[it.level] * F, 0, (size_t)entries * F * sizeof(half_t), stream) != hipSuccess) {
 				throw std::runtime_error("grid_backward: memset failed");
@@ -1019,33 +1067,33 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 		if constexpr (F_ % 2 == 0) {                                                                                                   \
 			TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, true>), lds_slice_bytes);                                             \
 			TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, true>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io, \
-			            plan, dL_dy, grid_gradient, acc, bk, (const uint32_t*)counters, (const uint32_t*)queues);                      \
+			            plan, dL_dy, grid_gradient, acc, bk, counters, (const uint32_t*)queues);                                       \
 		}                                                                                                                              \
 	} else {                                                                                                                           \
 		TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, false>), lds_slice_bytes);                                                \
 		TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, false>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io,    \
-		            plan, dL_dy, grid_gradient, acc, bk, (const uint32_t*)counters, (const uint32_t*)queues);                          \
+		            plan, dL_dy, grid_gradient, acc, bk, counters, (const uint32_t*)queues);                                           \
 	}
 	TCNN_GRID_DISPATCH(BWDS)
 #undef BWDS
 	if (bk.n_levels) {
 		// pass C: overflowed records (none for near-uniform inputs: the kernel reads one counter and exits)
-#define BOVF(D_, F_) TCNN_LAUNCH((k_grid_bucket_overflow<F_>), dim3(256), dim3(256), 0, stream, meta, bk, (const uint32_t*)counters, (const uint32_t*)overflow, grid_gradient);
+#define BOVF(D_, F_) TCNN_LAUNCH((k_grid_bucket_overflow<F_>), dim3(256), dim3(256), 0, stream, meta, bk, counters, (const uint32_t*)overflow, grid_gradient);
 		TCNN_GRID_DISPATCH(BOVF)
 #undef BOVF
 	}
 }
 
 void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient, bool accumulate,
-                   GridBackwardMode mode, uint32_t lds_slice_bytes, void* workspace, size_t workspace_bytes) {
+                   GridBackwardMode mode, uint32_t lds_slice_bytes, const GridBackwardWorkspace& ws) {
 	if (io.n == 0) return;
 	if (!grid_gradient) throw std::runtime_error("grid_backward: missing gradient buffer");
 	switch (mode) {
-		case GridBackwardMode::SlicedF32: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, false, false, lds_slice_bytes, nullptr, 0); break;
-		case GridBackwardMode::SlicedF16: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, true, false, lds_slice_bytes, nullptr, 0); break;
+		case GridBackwardMode::SlicedF32: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, false, false, lds_slice_bytes, ws); break;
+		case GridBackwardMode::SlicedF16: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, true, false, lds_slice_bytes, ws); break;
 		case GridBackwardMode::Atomic: grid_backward_atomic(stream, meta, io, dL_dy, grid_gradient, accumulate); break;
 		case GridBackwardMode::Bucketed:
-			grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, true, true, lds_slice_bytes, workspace, workspace_bytes);
+			grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, true, true, lds_slice_bytes, ws);
 			break;
 	}
 }

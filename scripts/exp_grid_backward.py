@@ -23,7 +23,7 @@ for name, enc in cases.items():
     xx = x.clone()
     ctx, y = m.fwd(xx, p)
     dy = (torch.randn_like(y.float()) * 0.01).half()
-    for mode, mname in ((1, "sliced_f16"), (3, "bucketed")):
+    for mode, mname in ((3, "bucketed"),):
         C.set_grid_backward_mode(mode)
         for _ in range(3):
             m.bwd(ctx, xx, p, y, dy)
@@ -34,4 +34,3 @@ for name, enc in cases.items():
             m.bwd(ctx, xx, p, y, dy)
         b.record(); torch.cuda.synchronize()
         print(f"{name:36s} {mname:10s} {a.elapsed_time(b)/10:8.4f} ms (incl. torch.empty of grads)")
-    C.set_grid_backward_mode(0)

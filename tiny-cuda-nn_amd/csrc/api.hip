@@ -217,10 +217,12 @@ static int initial_grid_backward_mode() {
 	const char* e = getenv("TCNN_GRID_BACKWARD");
 	if (e && std::string(e) == "atomic") return (int)GridBackwardMode::Atomic;
 	if (e && std::string(e) == "sliced_f32") return (int)GridBackwardMode::SlicedF32;
-	if (e && std::string(e) == "bucketed") return (int)GridBackwardMode::Bucketed;
-	return (int)GridBackwardMode::SlicedF16;  // default: fixed-point coarse levels + packed-fp16 slices (the reference's accumulation type)
+	if (e && std::string(e) == "sliced_f16") return (int)GridBackwardMode::SlicedF16;
+	return (int)GridBackwardMode::Bucketed;  // default: derive each corner once, bin by owner, exact fixed-point accumulation
 }
 static std::atomic<int> g_grid_backward_mode{initial_grid_backward_mode()};
+// TCNN_GRID_LDS_SLICE_BYTES: LDS bytes per table slice of the grid backward (tuning; 0 / unset = built-in default)
+static const uint32_t g_default_lds_slice_bytes = getenv("TCNN_GRID_LDS_SLICE_BYTES") ? (uint32_t)atoi(getenv("TCNN_GRID_LDS_SLICE_BYTES")) : 0u;
 
 struct ProfScope {
 	hipStream_t stream;
@@ -618,6 +620,7 @@ static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx
 			// whole slices, so the reference's full-table memset is only issued for the atomic A/B mode.
 			ProfScope prof(stream, STAGE_GRID_BWD);
 			const GridBackwardMode mode = (GridBackwardMode)g_grid_backward_mode.load();
+			if (lds_level_budget == 0) lds_level_budget = g_default_lds_slice_bytes;
 			GridBackwardWorkspace ws = grid_backward_workspace_size(e.grid, n, mode, lds_level_budget);
 			Scratch queues;
 			if (ws.scratch_bytes) {

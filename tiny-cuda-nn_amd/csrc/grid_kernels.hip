@@ -464,7 +464,10 @@ TCNN_DEVICE void sliced_level(const GridMeta& meta, const GridIO& io, const Leve
 constexpr uint32_t BUCKET_THREADS = 256;
 constexpr uint32_t MAX_BUCKET_LEVELS = 32;
 constexpr uint32_t MAX_BUCKETS_PER_LEVEL = 4096;
-constexpr uint32_t BUCKET_STAGE_BYTES = 64 * 1024;  // LDS staging area of pass A
+#ifndef TCNN_BUCKET_STAGE_BYTES
+#define TCNN_BUCKET_STAGE_BYTES (32 * 1024)  // measured: 32 KiB (4 workgroups per CU) beats 64 and 16 KiB
+#endif
+constexpr uint32_t BUCKET_STAGE_BYTES = TCNN_BUCKET_STAGE_BYTES;  // LDS staging area of pass A
 
 struct BucketPlan {
 	uint32_t n_levels;  // bucketed levels
@@ -581,6 +584,10 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 	uint32_t sum = 0;
 	for (uint32_t b = b_begin; b < b_end; ++b) sum += cnt[b];
 	part[threadIdx.x] = sum;
+	// the common case (<= 256 buckets): one bucket per thread -- reserve its run now, the scan below hides the
+	// round trip of the returning global atomic
+	uint32_t reserved = 0;
+	if (per_thread == 1u && sum) reserved = atomic_add_u32(&counters[plan.counter_base[j] + chunk * nb + b_begin], sum);
 	__syncthreads();
 	for (uint32_t d = 1; d < BUCKET_THREADS; d <<= 1) {
 		const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
@@ -593,7 +600,7 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 		const uint32_t c = cnt[b];
 		off[b] = running;
 		running += c;
-		gbase[b] = c ? atomic_add_u32(&counters[plan.counter_base[j] + chunk * nb + b], c) : 0u;
+		gbase[b] = per_thread == 1u ? reserved : (c ? atomic_add_u32(&counters[plan.counter_base[j] + chunk * nb + b], c) : 0u);
 	}
 	const uint32_t total = part[BUCKET_THREADS - 1];
 	__syncthreads();
@@ -661,41 +668,58 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 	const uint32_t slice_begin = bucket * entries_per_bucket;
 	const uint32_t slice_count = slice_begin < lv.hashmap_size ? min(entries_per_bucket, lv.hashmap_size - slice_begin) : 0u;
 	unsigned long long* tab = (unsigned long long*)lds_raw;  // [entries][F]
-	for (uint32_t e = threadIdx.x; e < slice_count * F * 2; e += SLICED_THREADS) ((uint32_t*)lds_raw)[e] = 0u;
-	__syncthreads();
-
 	const uint32_t cap = plan.capacity[j], n_chunks = plan.n_chunks[j];
 	const uint32_t queue = chunk * plan.n_buckets[j] + bucket;
-	const uint32_t count = min(counters[plan.counter_base[j] + queue], cap);
+	const uint32_t count = min(counters[plan.counter_base[j] + queue], cap);  // in flight while the table is cleared
 	const uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)queue * cap) * W;
-	constexpr uint32_t U = 4;  // records in flight per lane
-	for (uint32_t base = threadIdx.x; base < count; base += SLICED_THREADS * U) {
-		uint32_t rec[U][W];
+	for (uint32_t e = threadIdx.x; e < slice_count * F / 2; e += SLICED_THREADS) ((u4*)lds_raw)[e] = u4{0u, 0u, 0u, 0u};  // slice_count * F is even
+	__syncthreads();
+
+	auto add_record = [&](uint32_t index, const uint32_t* payload) {
+		const uint32_t rel = index & (entries_per_bucket - 1u);
+		if constexpr (F == 1) {
+			lds_atomic_add_u64(&tab[rel], (unsigned long long)to_fixed(__builtin_bit_cast(float, payload[0])));
+		} else {
 #pragma unroll
-		for (uint32_t u = 0; u < U; ++u) {
-			const uint32_t t = min(base + u * SLICED_THREADS, count - 1u);
-			if constexpr (W == 2) {
-				const u2 r = *(const u2*)&q[(size_t)t * 2];
-				rec[u][0] = r[0];
-				rec[u][1] = r[1];
-			} else {
+			for (uint32_t p = 0; p < PW; ++p) {
+				const h2 v = bits_h2(payload[p]);
+				lds_atomic_add_u64(&tab[rel * F + 2 * p], (unsigned long long)to_fixed((float)v[0]));
+				lds_atomic_add_u64(&tab[rel * F + 2 * p + 1], (unsigned long long)to_fixed((float)v[1]));
+			}
+		}
+	};
+	if constexpr (W == 2) {
+		// two records per 16-byte load, U loads in flight per lane: the queue is streamed at memory speed, not at
+		// one round trip per record
+		constexpr uint32_t U = 8;
+		const uint32_t n_pairs = (count + 1u) / 2u;
+		const u4* __restrict__ q4 = (const u4*)q;  // queues start on 256-byte boundaries
+		for (uint32_t base = threadIdx.x; base < n_pairs; base += SLICED_THREADS * U) {
+			u4 r[U];
+#pragma unroll
+			for (uint32_t u = 0; u < U; ++u) r[u] = q4[min(base + u * SLICED_THREADS, n_pairs - 1u)];
+#pragma unroll
+			for (uint32_t u = 0; u < U; ++u) {
+				const uint32_t pair = base + u * SLICED_THREADS;
+				if (pair >= n_pairs) continue;
+				const uint32_t p0[1] = {r[u][1]}, p1[1] = {r[u][3]};
+				add_record(r[u][0], p0);
+				if (2u * pair + 1u < count) add_record(r[u][2], p1);
+			}
+		}
+	} else {
+		constexpr uint32_t U = 4;  // records in flight per lane
+		for (uint32_t base = threadIdx.x; base < count; base += SLICED_THREADS * U) {
+			uint32_t rec[U][W];
+#pragma unroll
+			for (uint32_t u = 0; u < U; ++u) {
+				const uint32_t t = min(base + u * SLICED_THREADS, count - 1u);
 #pragma unroll
 				for (uint32_t w = 0; w < W; ++w) rec[u][w] = q[(size_t)t * W + w];
 			}
-		}
 #pragma unroll
-		for (uint32_t u = 0; u < U; ++u) {
-			if (base + u * SLICED_THREADS >= count) continue;
-			const uint32_t rel = rec[u][0] & (entries_per_bucket - 1u);
-			if constexpr (F == 1) {
-				lds_atomic_add_u64(&tab[rel], (unsigned long long)to_fixed(__builtin_bit_cast(float, rec[u][1])));
-			} else {
-#pragma unroll
-				for (uint32_t p = 0; p < PW; ++p) {
-					const h2 v = bits_h2(rec[u][1 + p]);
-					lds_atomic_add_u64(&tab[rel * F + 2 * p], (unsigned long long)to_fixed((float)v[0]));
-					lds_atomic_add_u64(&tab[rel * F + 2 * p + 1], (unsigned long long)to_fixed((float)v[1]));
-				}
+			for (uint32_t u = 0; u < U; ++u) {
+				if (base + u * SLICED_THREADS < count) add_record(rec[u][0], &rec[u][1]);
 			}
 		}
 	}

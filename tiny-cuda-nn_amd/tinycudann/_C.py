@@ -12,7 +12,8 @@ import os
 import torch  # must be imported first: libtcnn_hip.so binds to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libtcnn_hip.so")
+# TCNN_HIP_LIBRARY: load another build of the same library (kernel tuning experiments)
+_LIB_PATH = os.environ.get("TCNN_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libtcnn_hip.so")
 
 if not os.path.exists(_LIB_PATH):
     raise ImportError(

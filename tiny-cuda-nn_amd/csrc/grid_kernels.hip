@@ -480,10 +480,10 @@ struct BucketPlan {
 	uint32_t n_buckets[MAX_BUCKET_LEVELS];        // table slices
 	uint32_t n_chunks[MAX_BUCKET_LEVELS];         // sample chunks: a queue belongs to one (chunk, bucket); > 1 only for small tables
 	uint32_t tiles_per_chunk[MAX_BUCKET_LEVELS];
-	uint32_t capacity[MAX_BUCKET_LEVELS];         // records per queue
+	uint32_t capacity[MAX_BUCKET_LEVELS];         // PAIRS of records per queue
 	uint32_t counter_base[MAX_BUCKET_LEVELS];     // first counter of slot j; queue (chunk, bucket) uses counter chunk * n_buckets + bucket
 	uint32_t zero_block_begin[MAX_BUCKET_LEVELS + 1];  // pass-A zeroing blocks of slot j (4 KiB each; none unless chunked && !accumulate)
-	uint64_t queue_base[MAX_BUCKET_LEVELS];       // first record of slot j's queues
+	uint64_t queue_base[MAX_BUCKET_LEVELS];       // first pair of slot j's queues
 };
 constexpr uint32_t ZERO_BLOCK_HALVES = 2048;  // 4 KiB per zeroing block
 
@@ -501,6 +501,7 @@ TCNN_HOST_DEVICE constexpr uint32_t bucket_spt(uint32_t D, uint32_t F) {
 	return spt < 1u ? 1u : (spt > 8u ? 8u : spt);
 }
 
+constexpr uint32_t BUCKET_INVALID_INDEX = 0xFFFFFFFFu;  // second record of a pair that has none
 TCNN_DEVICE uint32_t h2_bits(h2 v) { return __builtin_bit_cast(uint32_t, v); }
 TCNN_DEVICE h2 bits_h2(uint32_t v) { return __builtin_bit_cast(h2, v); }
 
@@ -510,8 +511,9 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
                                                                          uint32_t* __restrict__ queues, uint32_t* __restrict__ overflow,
                                                                          half_t* __restrict__ grid_gradient) {
 	constexpr uint32_t N_CORNERS = 1u << D, PW = BucketRecord<F>::PAYLOAD_WORDS, W = BucketRecord<F>::WORDS;
-	constexpr uint32_t SPT = bucket_spt(D, F), TILE = SPT * BUCKET_THREADS, N_REC = TILE * N_CORNERS;
-	constexpr uint32_t INVALID = 0xFFFFFFFFu;
+	constexpr uint32_t N_PAIRS_PER_SAMPLE = N_CORNERS / 2;
+	constexpr uint32_t SPT = bucket_spt(D, F), TILE = SPT * BUCKET_THREADS, N_PAIR = TILE * N_PAIRS_PER_SAMPLE;
+	constexpr uint32_t INVALID = BUCKET_INVALID_INDEX;
 	TCNN_DYN_LDS(lds_raw);
 	if (blockIdx.x >= plan.scatter_blocks) {
 		// gradients of chunked levels are accumulated with atomics by several owners in pass B: zero them here
@@ -532,15 +534,29 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 	if ((float)level > max_level + 1e-3f) return;  // grid.h:242: no records, the owners store zeros
 	const Level<D> lv = make_level<D>(meta, level);
 
-	uint32_t* stage = (uint32_t*)lds_raw;  // [N_REC][W]
-	uint32_t* cnt = stage + N_REC * W;     // [nb] records of this workgroup per bucket
-	uint32_t* off = cnt + nb;              // [nb] exclusive prefix of cnt
-	uint32_t* gbase = off + nb;            // [nb] position of this workgroup's run in the bucket queue
-	uint32_t* part = gbase + nb;           // [BUCKET_THREADS] scan scratch
+	// Queue unit: a PAIR of records -- the two corners that differ in dimension 0 only.  Their table entries are
+	// neighbours (dense index +1; hashed: prime[0] == 1, so the indices differ in the low bits only) and therefore
+	// share a bucket except once in ~2^shift pairs: the second record of such a pair is routed through the overflow
+	// list instead.  Halves the ranking / reordering work per corner; a pair is 16 bytes for F == 2.
+	uint32_t* stage = (uint32_t*)lds_raw;   // [N_PAIR][2 * W]
+	uint32_t* cnt = stage + N_PAIR * 2 * W; // [nb] pairs of this workgroup per bucket
+	uint32_t* delta = cnt + nb;             // [nb] exclusive prefix of cnt, later (queue position - staging position)
+	uint32_t* part = delta + nb;            // [BUCKET_THREADS] scan scratch
 	for (uint32_t b = threadIdx.x; b < nb; b += BUCKET_THREADS) cnt[b] = 0u;
 	__syncthreads();
 
-	// ---- derive the records of my samples; rank each within its bucket
+	auto push_overflow = [&](uint32_t index, const uint32_t* payload) {
+		const uint32_t o = atomic_add_u32(&counters[plan.overflow_counter], 1u);
+		if (o < plan.overflow_capacity) {
+			uint32_t* dst = overflow + (size_t)o * (W + 1);
+			dst[0] = level;
+			dst[1] = index;
+#pragma unroll
+			for (uint32_t p = 0; p < PW; ++p) dst[2 + p] = payload[p];
+		}
+	};
+
+	// ---- derive the records of my samples; rank each pair within its bucket
 	float x[SPT][D];
 	half_t g[SPT][F];
 #pragma unroll
@@ -550,7 +566,7 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 #pragma unroll
 		for (uint32_t f = 0; f < F; ++f) g[s][f] = dL_dy[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i];
 	}
-	uint32_t ridx[SPT][N_CORNERS], rank[SPT][N_CORNERS], pay[SPT][N_CORNERS][PW];
+	uint32_t ridx[SPT][N_CORNERS], rank[SPT][N_PAIRS_PER_SAMPLE], pay[SPT][N_CORNERS][PW];
 	auto derive = [&](auto fast_tag) {
 		constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
@@ -559,8 +575,6 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 			const Cell<D> c = make_cell<D, FAST>(lv, x[s]);
 #pragma unroll
 			for (uint32_t idx = 0; idx < N_CORNERS; ++idx) {
-				const bool live = valid && (idx == 0u || !lv.nearest);
-				const uint32_t index = corner_index<D, FAST>(lv, c, idx);
 				const float weight = lv.nearest ? 1.0f : corner_weight<D>(c, idx);
 				if constexpr (F == 1) {
 					pay[s][idx][0] = __builtin_bit_cast(uint32_t, weight * (float)g[s][0]);
@@ -570,8 +584,22 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 #pragma unroll
 					for (uint32_t p = 0; p < PW; ++p) pay[s][idx][p] = h2_bits(w2 * h2{g[s][2 * p], g[s][2 * p + 1]});
 				}
-				ridx[s][idx] = live ? index : INVALID;
-				rank[s][idx] = live ? atomic_add_u32(&cnt[index >> shift], 1u) : 0u;
+				ridx[s][idx] = corner_index<D, FAST>(lv, c, idx);
+			}
+#pragma unroll
+			for (uint32_t pr = 0; pr < N_PAIRS_PER_SAMPLE; ++pr) {
+				const bool live = valid && (pr == 0u || !lv.nearest);
+				const uint32_t bucket = ridx[s][2 * pr] >> shift;
+				if (!live) {
+					ridx[s][2 * pr] = INVALID;
+					ridx[s][2 * pr + 1] = INVALID;
+				} else if (lv.nearest) {
+					ridx[s][2 * pr + 1] = INVALID;
+				} else if ((ridx[s][2 * pr + 1] >> shift) != bucket) {
+					push_overflow(ridx[s][2 * pr + 1], pay[s][2 * pr + 1]);
+					ridx[s][2 * pr + 1] = INVALID;
+				}
+				rank[s][pr] = live ? atomic_add_u32(&cnt[bucket], 1u) : 0u;
 			}
 		}
 	};
@@ -596,11 +624,10 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 		__syncthreads();
 	}
 	uint32_t running = part[threadIdx.x] - sum;
+	uint32_t my_offset = running, my_reserved = reserved;  // per_thread == 1: this thread's bucket
 	for (uint32_t b = b_begin; b < b_end; ++b) {
-		const uint32_t c = cnt[b];
-		off[b] = running;
-		running += c;
-		gbase[b] = per_thread == 1u ? reserved : (c ? atomic_add_u32(&counters[plan.counter_base[j] + chunk * nb + b], c) : 0u);
+		delta[b] = running;
+		running += cnt[b];
 	}
 	const uint32_t total = part[BUCKET_THREADS - 1];
 	__syncthreads();
@@ -609,51 +636,63 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 #pragma unroll
 	for (uint32_t s = 0; s < SPT; ++s) {
 #pragma unroll
-		for (uint32_t idx = 0; idx < N_CORNERS; ++idx) {
-			if (ridx[s][idx] == INVALID) continue;
-			const uint32_t pos = off[ridx[s][idx] >> shift] + rank[s][idx];
+		for (uint32_t pr = 0; pr < N_PAIRS_PER_SAMPLE; ++pr) {
+			const uint32_t i0 = ridx[s][2 * pr], i1 = ridx[s][2 * pr + 1];
+			if (i0 == INVALID) continue;
+			const uint32_t pos = delta[i0 >> shift] + rank[s][pr];
 			if constexpr (W == 2) {
-				*(u2*)&stage[pos * 2] = u2{ridx[s][idx], pay[s][idx][0]};
+				*(u4*)&stage[pos * 4] = u4{i0, pay[s][2 * pr][0], i1, pay[s][2 * pr + 1][0]};
 			} else {
-				stage[pos * W] = ridx[s][idx];
+				stage[pos * 2 * W] = i0;
+				stage[pos * 2 * W + W] = i1;
 #pragma unroll
-				for (uint32_t p = 0; p < PW; ++p) stage[pos * W + 1 + p] = pay[s][idx][p];
+				for (uint32_t p = 0; p < PW; ++p) {
+					stage[pos * 2 * W + 1 + p] = pay[s][2 * pr][p];
+					stage[pos * 2 * W + W + 1 + p] = pay[s][2 * pr + 1][p];
+				}
 			}
 		}
 	}
 	__syncthreads();
+	// delta[b] := (position of the run in bucket b's queue) - (position of the run in the staging area)
+	if (per_thread == 1u) {
+		if (b_begin < b_end) delta[b_begin] = my_reserved - my_offset;
+	} else {
+		for (uint32_t b = b_begin; b < b_end; ++b) {
+			const uint32_t c = cnt[b];
+			delta[b] = (c ? atomic_add_u32(&counters[plan.counter_base[j] + chunk * nb + b], c) : 0u) - delta[b];
+		}
+	}
+	__syncthreads();
 
-	// ---- append the runs to the bucket queues: consecutive threads -> consecutive records
+	// ---- append the runs to the bucket queues: consecutive threads -> consecutive pairs
 	const uint32_t cap = plan.capacity[j];
-	uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)chunk * nb * cap) * W;
+	uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)chunk * nb * cap) * 2 * W;
 	for (uint32_t t = threadIdx.x; t < total; t += BUCKET_THREADS) {
-		uint32_t rec[W];
+		uint32_t rec[2 * W];
 		if constexpr (W == 2) {
-			const u2 r = *(const u2*)&stage[t * 2];
+			const u4 r = *(const u4*)&stage[t * 4];
 			rec[0] = r[0];
 			rec[1] = r[1];
+			rec[2] = r[2];
+			rec[3] = r[3];
 		} else {
 #pragma unroll
-			for (uint32_t w = 0; w < W; ++w) rec[w] = stage[t * W + w];
+			for (uint32_t w = 0; w < 2 * W; ++w) rec[w] = stage[t * 2 * W + w];
 		}
 		const uint32_t b = rec[0] >> shift;
-		const uint32_t pos = gbase[b] + (t - off[b]);
+		const uint32_t pos = t + delta[b];  // wraps like the subtraction above
 		if (pos < cap) {
-			uint32_t* dst = q + ((size_t)b * cap + pos) * W;
+			uint32_t* dst = q + ((size_t)b * cap + pos) * 2 * W;
 			if constexpr (W == 2) {
-				*(u2*)dst = u2{rec[0], rec[1]};
+				*(u4*)dst = u4{rec[0], rec[1], rec[2], rec[3]};
 			} else {
 #pragma unroll
-				for (uint32_t w = 0; w < W; ++w) dst[w] = rec[w];
+				for (uint32_t w = 0; w < 2 * W; ++w) dst[w] = rec[w];
 			}
 		} else {
-			const uint32_t o = atomic_add_u32(&counters[plan.overflow_counter], 1u);
-			if (o < plan.overflow_capacity) {
-				uint32_t* dst = overflow + (size_t)o * (W + 1);
-				dst[0] = level;
-#pragma unroll
-				for (uint32_t w = 0; w < W; ++w) dst[1 + w] = rec[w];
-			}
+			push_overflow(rec[0], &rec[1]);
+			if (rec[W] != INVALID) push_overflow(rec[W], &rec[W + 1]);
 		}
 	}
 }
@@ -671,7 +710,7 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 	const uint32_t cap = plan.capacity[j], n_chunks = plan.n_chunks[j];
 	const uint32_t queue = chunk * plan.n_buckets[j] + bucket;
 	const uint32_t count = min(counters[plan.counter_base[j] + queue], cap);  // in flight while the table is cleared
-	const uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)queue * cap) * W;
+	const uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)queue * cap) * 2 * W;  // `count` PAIRS of records
 	for (uint32_t e = threadIdx.x; e < slice_count * F / 2; e += SLICED_THREADS) ((u4*)lds_raw)[e] = u4{0u, 0u, 0u, 0u};  // slice_count * F is even
 	__syncthreads();
 
@@ -689,37 +728,37 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 		}
 	};
 	if constexpr (W == 2) {
-		// two records per 16-byte load, U loads in flight per lane: the queue is streamed at memory speed, not at
-		// one round trip per record
+		// one pair per 16-byte load, U loads in flight per lane: the queue is streamed at memory speed, not at one
+		// round trip per record
 		constexpr uint32_t U = 8;
-		const uint32_t n_pairs = (count + 1u) / 2u;
 		const u4* __restrict__ q4 = (const u4*)q;  // queues start on 256-byte boundaries
-		for (uint32_t base = threadIdx.x; base < n_pairs; base += SLICED_THREADS * U) {
+		for (uint32_t base = threadIdx.x; base < count; base += SLICED_THREADS * U) {
 			u4 r[U];
 #pragma unroll
-			for (uint32_t u = 0; u < U; ++u) r[u] = q4[min(base + u * SLICED_THREADS, n_pairs - 1u)];
+			for (uint32_t u = 0; u < U; ++u) r[u] = q4[min(base + u * SLICED_THREADS, count - 1u)];
 #pragma unroll
 			for (uint32_t u = 0; u < U; ++u) {
-				const uint32_t pair = base + u * SLICED_THREADS;
-				if (pair >= n_pairs) continue;
+				if (base + u * SLICED_THREADS >= count) continue;
 				const uint32_t p0[1] = {r[u][1]}, p1[1] = {r[u][3]};
 				add_record(r[u][0], p0);
-				if (2u * pair + 1u < count) add_record(r[u][2], p1);
+				if (r[u][2] != BUCKET_INVALID_INDEX) add_record(r[u][2], p1);
 			}
 		}
 	} else {
-		constexpr uint32_t U = 4;  // records in flight per lane
+		constexpr uint32_t U = 2;  // pairs in flight per lane
 		for (uint32_t base = threadIdx.x; base < count; base += SLICED_THREADS * U) {
-			uint32_t rec[U][W];
+			uint32_t rec[U][2 * W];
 #pragma unroll
 			for (uint32_t u = 0; u < U; ++u) {
 				const uint32_t t = min(base + u * SLICED_THREADS, count - 1u);
 #pragma unroll
-				for (uint32_t w = 0; w < W; ++w) rec[u][w] = q[(size_t)t * W + w];
+				for (uint32_t w = 0; w < 2 * W; ++w) rec[u][w] = q[(size_t)t * 2 * W + w];
 			}
 #pragma unroll
 			for (uint32_t u = 0; u < U; ++u) {
-				if (base + u * SLICED_THREADS < count) add_record(rec[u][0], &rec[u][1]);
+				if (base + u * SLICED_THREADS >= count) continue;
+				add_record(rec[u][0], &rec[u][1]);
+				if (rec[u][W] != BUCKET_INVALID_INDEX) add_record(rec[u][W], &rec[u][W + 1]);
 			}
 		}
 	}
@@ -970,8 +1009,9 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 			uint32_t n_chunks = per_bucket <= 65536 ? 1u : (uint32_t)std::min<uint64_t>(div_round_up<uint64_t>(per_bucket, 32768), bk.tiles);
 			const uint32_t tiles_per_chunk = div_round_up(bk.tiles, n_chunks);
 			n_chunks = div_round_up(bk.tiles, tiles_per_chunk);
-			const uint64_t expected = level_records / ((uint64_t)n_buckets * n_chunks);
-			const uint64_t capacity = next_multiple<uint64_t>(2 * expected + 1024, 64);
+			const uint64_t level_pairs = (uint64_t)n * std::max(1u, n_corners / 2u);  // queue unit: a pair of records
+			const uint64_t expected = level_pairs / ((uint64_t)n_buckets * n_chunks);
+			const uint64_t capacity = next_multiple<uint64_t>(2 * expected + 512, 64);
 			if (capacity > 0x7FFFFFFFull) throw std::runtime_error("grid_backward: batch too large for the bucketed backward");
 			bk.level[j] = (uint8_t)l;
 			bk.n_buckets[j] = n_buckets;
@@ -1009,7 +1049,7 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 	bk.overflow_counter = n_counters;
 	bk.overflow_capacity = (uint32_t)n_records;
 	bp.n_counters = bk.n_levels ? n_counters + 2 : 0;
-	bp.overflow_offset = next_multiple<size_t>(n_queue_records * record_words * sizeof(uint32_t), 256);
+	bp.overflow_offset = next_multiple<size_t>(n_queue_records * 2 * record_words * sizeof(uint32_t), 256);  // n_queue_records counts pairs
 	bp.workspace_bytes = bk.n_levels ? bp.overflow_offset + next_multiple<size_t>(n_records * (record_words + 1) * sizeof(uint32_t), 256) : 0;
 
 	// long passes first (bucket owners, float slices), the short work (fixed-point chunks, atomic tiles) fills the tail
@@ -1068,7 +1108,7 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 		for (uint32_t j = 0; j < bk.n_levels; ++j) max_buckets = std::max(max_buckets, bk.n_buckets[j]);
 #define BSCATTER(D_, F_)                                                                                                                      \
 	{                                                                                                                                         \
-		const uint32_t lds = bucket_spt(D_, F_) * BUCKET_THREADS * (1u << D_) * BucketRecord<F_>::WORDS * 4u + (3u * max_buckets + BUCKET_THREADS) * 4u; \
+		const uint32_t lds = bucket_spt(D_, F_) * BUCKET_THREADS * (1u << D_) * BucketRecord<F_>::WORDS * 4u + (2u * max_buckets + BUCKET_THREADS) * 4u; \
 		TCNN_SET_MAX_DYN_LDS((k_grid_bucket_scatter<D_, F_>), lds);                                                                           \
 		TCNN_LAUNCH((k_grid_bucket_scatter<D_, F_>), dim3(scatter_blocks), dim3(BUCKET_THREADS), lds, stream, meta, io, bk, dL_dy, counters,  \
 		            queues, overflow, grid_gradient);                                                                                         \

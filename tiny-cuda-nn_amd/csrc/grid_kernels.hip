@@ -4,6 +4,7 @@
 #include "grid_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -159,10 +160,35 @@ TCNN_DEVICE void load_features(const half_t* p, h2 (&v)[(F + 1) / 2]) {
 	}
 }
 
+// The aligned PAIR of entries (i & ~1, i | 1) in one access (F <= 4: at most 16 bytes).  The two corners that differ in
+// dimension 0 are usually such a pair (dense: index + 1; hashed: prime[0] == 1 -> index ^ 1 when the coordinate is
+// even), so half of the x-neighbours cost one gather lane-operation instead of two -- the gather rate of this kernel is
+// bound by per-lane address processing, not by bytes.
+template <uint32_t F>
+TCNN_DEVICE void load_feature_pair(const half_t* grid, uint32_t i, h2 (&lo)[(F + 1) / 2], h2 (&hi)[(F + 1) / 2]) {
+	const half_t* p = grid + (size_t)(i & ~1u) * F;
+	if constexpr (F == 1) {
+		const h2 t = *(const h2*)p;
+		lo[0] = h2{t[0], (half_t)0.0f};
+		hi[0] = h2{t[1], (half_t)0.0f};
+	} else if constexpr (F == 2) {
+		const h4 t = *(const h4*)p;
+		lo[0] = h2{t[0], t[1]};
+		hi[0] = h2{t[2], t[3]};
+	} else {
+		static_assert(F == 4, "pair loads cover F <= 4");
+		const h8 t = *(const h8*)p;
+		lo[0] = h2{t[0], t[1]};
+		lo[1] = h2{t[2], t[3]};
+		hi[0] = h2{t[4], t[5]};
+		hi[1] = h2{t[6], t[7]};
+	}
+}
+
 // =============================================================================================
 // forward (grid.h:49-212)
 // =============================================================================================
-template <uint32_t D, uint32_t F, bool DYDX, bool FAST>
+template <uint32_t D, uint32_t F, bool DYDX, bool FAST, bool PAIR>
 TCNN_DEVICE void grid_forward_sample(const Level<D>& lv, const GridIO& io, const half_t* __restrict__ grid, uint32_t level, uint32_t i,
                                      bool level_off, half_t* __restrict__ out, float* __restrict__ dy_dx) {
 	constexpr uint32_t NP = (F + 1) / 2;
@@ -180,15 +206,33 @@ TCNN_DEVICE void grid_forward_sample(const Level<D>& lv, const GridIO& io, const
 		if (lv.nearest) {
 			load_features<F>(grid + (size_t)corner_index<D, FAST>(lv, c, 0) * F, result);
 		} else {
-			// N-linear interpolation, corner order and fp16 fma chain of grid.h:144-163
+			// gather all corners first (independent loads in flight) ...
+			h2 val[1u << D][NP];
+			if constexpr (PAIR && F <= 4) {
+#pragma unroll
+				for (uint32_t pr = 0; pr < (1u << (D - 1)); ++pr) {
+					const uint32_t i0 = corner_index<D, FAST>(lv, c, 2 * pr), i1 = corner_index<D, FAST>(lv, c, 2 * pr + 1);
+					h2 lo[NP], hi[NP];
+					load_feature_pair<F>(grid, i0, lo, hi);
+					const bool odd = (i0 & 1u) != 0u;
+#pragma unroll
+					for (uint32_t p = 0; p < NP; ++p) {
+						val[2 * pr][p] = odd ? hi[p] : lo[p];
+						val[2 * pr + 1][p] = odd ? lo[p] : hi[p];  // entry i0 ^ 1
+					}
+					if ((i0 ^ i1) != 1u) load_features<F>(grid + (size_t)i1 * F, val[2 * pr + 1]);
+				}
+			} else {
+#pragma unroll
+				for (uint32_t idx = 0; idx < (1u << D); ++idx) load_features<F>(grid + (size_t)corner_index<D, FAST>(lv, c, idx) * F, val[idx]);
+			}
+			// ... then the N-linear interpolation, corner order and fp16 fma chain of grid.h:144-163
 #pragma unroll
 			for (uint32_t idx = 0; idx < (1u << D); ++idx) {
-				h2 val[NP];
-				load_features<F>(grid + (size_t)corner_index<D, FAST>(lv, c, idx) * F, val);
 				const half_t wh = to_half_rn(corner_weight<D>(c, idx));
 				const h2 w2 = h2{wh, wh};
 #pragma unroll
-				for (uint32_t p = 0; p < NP; ++p) result[p] = fma_h2(w2, val[p], result[p]);
+				for (uint32_t p = 0; p < NP; ++p) result[p] = fma_h2(w2, val[idx][p], result[p]);
 			}
 			if constexpr (DYDX) {  // grid.h:172-211
 #pragma unroll
@@ -204,9 +248,8 @@ TCNN_DEVICE void grid_forward_sample(const Level<D>& lv, const GridIO& io, const
 							weight *= bit ? c.w[dim][1] : c.w[dim][0];
 							corner |= bit << dim;
 						}
-						h2 vl[NP], vr[NP];
-						load_features<F>(grid + (size_t)corner_index<D, FAST>(lv, c, corner) * F, vl);
-						load_features<F>(grid + (size_t)corner_index<D, FAST>(lv, c, corner | (1u << gd)) * F, vr);
+						const h2(&vl)[NP] = val[corner];
+						const h2(&vr)[NP] = val[corner | (1u << gd)];
 #pragma unroll
 						for (uint32_t f = 0; f < F; ++f) {
 							const float diff = (float)vr[f / 2][f % 2] - (float)vl[f / 2][f % 2];
@@ -230,7 +273,7 @@ TCNN_DEVICE void grid_forward_sample(const Level<D>& lv, const GridIO& io, const
 	}
 }
 
-template <uint32_t D, uint32_t F, bool DYDX>
+template <uint32_t D, uint32_t F, bool DYDX, bool PAIR>
 __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward(const GridMeta meta, const GridIO io, const half_t* __restrict__ params,
                                                                 half_t* __restrict__ out, float* __restrict__ dy_dx) {
 	uint32_t level, tile;
@@ -244,12 +287,12 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward(const GridMeta me
 #pragma unroll
 		for (uint32_t s = 0; s < GRID_SPT; ++s) {
 			const uint32_t i = tile * GRID_TILE + s * GRID_THREADS + threadIdx.x;
-			if (i < io.n) grid_forward_sample<D, F, DYDX, true>(lv, io, grid, level, i, level_off, out, dy_dx);
+			if (i < io.n) grid_forward_sample<D, F, DYDX, true, PAIR>(lv, io, grid, level, i, level_off, out, dy_dx);
 		}
 	} else {
 		for (uint32_t s = 0; s < GRID_SPT; ++s) {
 			const uint32_t i = tile * GRID_TILE + s * GRID_THREADS + threadIdx.x;
-			if (i < io.n) grid_forward_sample<D, F, DYDX, false>(lv, io, grid, level, i, level_off, out, dy_dx);
+			if (i < io.n) grid_forward_sample<D, F, DYDX, false, PAIR>(lv, io, grid, level, i, level_off, out, dy_dx);
 		}
 	}
 }
@@ -461,7 +504,10 @@ TCNN_DEVICE void sliced_level(const GridMeta& meta, const GridIO& io, const Leve
 //     only strongly non-uniform inputs get there) are applied with the reference's global atomics afterwards.
 // HBM traffic: 2 x 8 B per corner (F = 2) -- 0.44 GB per headline step, a fraction of the chip's bandwidth.
 // =============================================================================================
-constexpr uint32_t BUCKET_THREADS = 256;
+#ifndef TCNN_BUCKET_THREADS
+#define TCNN_BUCKET_THREADS 256
+#endif
+constexpr uint32_t BUCKET_THREADS = TCNN_BUCKET_THREADS;
 constexpr uint32_t MAX_BUCKET_LEVELS = 32;
 constexpr uint32_t MAX_BUCKETS_PER_LEVEL = 4096;
 #ifndef TCNN_BUCKET_STAGE_BYTES
@@ -615,7 +661,11 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 	// the common case (<= 256 buckets): one bucket per thread -- reserve its run now, the scan below hides the
 	// round trip of the returning global atomic
 	uint32_t reserved = 0;
+#if defined(TCNN_EXP_NO_RESERVE)
+	if (per_thread == 1u && sum) reserved = (tile % plan.tiles_per_chunk[j]) * 48u;  // timing experiment: no global atomics
+#else
 	if (per_thread == 1u && sum) reserved = atomic_add_u32(&counters[plan.counter_base[j] + chunk * nb + b_begin], sum);
+#endif
 	__syncthreads();
 	for (uint32_t d = 1; d < BUCKET_THREADS; d <<= 1) {
 		const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
@@ -684,12 +734,16 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 		const uint32_t pos = t + delta[b];  // wraps like the subtraction above
 		if (pos < cap) {
 			uint32_t* dst = q + ((size_t)b * cap + pos) * 2 * W;
+#if defined(TCNN_EXP_NO_STORE)
+			if (rec[0] == 0x12345u) dst[0] = 1;  // timing experiment: no queue traffic
+#else
 			if constexpr (W == 2) {
 				*(u4*)dst = u4{rec[0], rec[1], rec[2], rec[3]};
 			} else {
 #pragma unroll
 				for (uint32_t w = 0; w < 2 * W; ++w) dst[w] = rec[w];
 			}
+#endif
 		} else {
 			push_overflow(rec[0], &rec[1]);
 			if (rec[W] != INVALID) push_overflow(rec[W], &rec[W + 1]);
@@ -928,11 +982,19 @@ __global__ void k_grid_indices(const GridMeta meta, const GridIO io, uint32_t* _
 void grid_forward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* params, half_t* out, float* dy_dx) {
 	if (io.n == 0) return;
 	const uint32_t blocks = grid_n_blocks(meta.n_levels, io.n);
-#define FWD(D_, F_)                                                                                                                        \
-	if (dy_dx) {                                                                                                                           \
-		TCNN_LAUNCH((k_grid_forward<D_, F_, true>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, dy_dx);            \
-	} else {                                                                                                                               \
-		TCNN_LAUNCH((k_grid_forward<D_, F_, false>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, (float*)nullptr); \
+	// pair loads need the table 16-byte aligned (level offsets are multiples of 8 entries) and F <= 4
+	const bool pair = ((uintptr_t)params % 16u) == 0u && meta.n_feat <= 4u && !getenv("TCNN_GRID_FORWARD_NO_PAIR_LOADS");
+#define FWD(D_, F_)                                                                                                                              \
+	if (dy_dx) {                                                                                                                                 \
+		if (pair) {                                                                                                                              \
+			TCNN_LAUNCH((k_grid_forward<D_, F_, true, true>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, dy_dx);        \
+		} else {                                                                                                                                 \
+			TCNN_LAUNCH((k_grid_forward<D_, F_, true, false>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, dy_dx);       \
+		}                                                                                                                                        \
+	} else if (pair) {                                                                                                                           \
+		TCNN_LAUNCH((k_grid_forward<D_, F_, false, true>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, (float*)nullptr); \
+	} else {                                                                                                                                     \
+		TCNN_LAUNCH((k_grid_forward<D_, F_, false, false>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, (float*)nullptr); \
 	}
 	TCNN_GRID_DISPATCH(FWD)
 #undef FWD

@@ -379,22 +379,36 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 	}
 }
 
-__global__ void k_mlp_finalize_gradients(uint32_t n_params, uint32_t n_partials, const float* __restrict__ partials, half_t* __restrict__ grads,
-                                         int accumulate) {
-	// 256 threads = 32 parameters x 8 slab groups; fixed summation order -> deterministic gradients
-	__shared__ float red[8][32];
+constexpr uint32_t FINALIZE_GROUPS = 32;  // slab groups per block (x 32 parameters = 1024 threads)
+
+__global__ void __launch_bounds__(32 * FINALIZE_GROUPS) k_mlp_finalize_gradients(uint32_t n_params, uint32_t n_partials,
+                                                                                 const float* __restrict__ partials, half_t* __restrict__ grads,
+                                                                                 int accumulate) {
+	// 32 parameters x 32 slab groups; group g sums slabs g, g + 32, ... with 8 loads in flight (the sum over <= 512
+	// slabs is latency-bound otherwise); fixed summation order -> deterministic gradients
+	__shared__ float red[FINALIZE_GROUPS][32];
 	const uint32_t lane = threadIdx.x & 31u, group = threadIdx.x >> 5;
 	const uint32_t i = blockIdx.x * 32u + lane;
 	float s = 0.0f;
 	if (i < n_params) {
-		for (uint32_t b = group; b < n_partials; b += 8) s += partials[(size_t)b * n_params + i];
+		constexpr uint32_t U = 8;
+		for (uint32_t b = group; b < n_partials; b += FINALIZE_GROUPS * U) {
+			float v[U];
+#pragma unroll
+			for (uint32_t u = 0; u < U; ++u) {
+				const uint32_t bb = b + u * FINALIZE_GROUPS;
+				v[u] = bb < n_partials ? partials[(size_t)bb * n_params + i] : 0.0f;
+			}
+#pragma unroll
+			for (uint32_t u = 0; u < U; ++u) s += v[u];
+		}
 	}
 	red[group][lane] = s;
 	__syncthreads();
 	if (group == 0 && i < n_params) {
 		float t = red[0][lane];
 #pragma unroll
-		for (uint32_t k = 1; k < 8; ++k) t += red[k][lane];
+		for (uint32_t k = 1; k < FINALIZE_GROUPS; ++k) t += red[k][lane];
 		if (accumulate) t += (float)grads[i];
 		grads[i] = to_half_rn(t);
 	}
@@ -490,7 +504,7 @@ void mlp_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t
 }
 
 void mlp_finalize_gradients(hipStream_t stream, uint32_t n_params, uint32_t n_partials, const float* partials, half_t* grads, bool accumulate) {
-	TCNN_LAUNCH(k_mlp_finalize_gradients, dim3(div_round_up(n_params, 32u)), dim3(256), 0, stream, n_params, n_partials, partials, grads, accumulate ? 1 : 0);
+	TCNN_LAUNCH(k_mlp_finalize_gradients, dim3(div_round_up(n_params, 32u)), dim3(32 * FINALIZE_GROUPS), 0, stream, n_params, n_partials, partials, grads, accumulate ? 1 : 0);
 }
 
 }  // namespace tcnn_hip

@@ -41,6 +41,11 @@ CONFIG = {
                  "base_resolution": 16, "per_level_scale": 2.0},
     "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2},
 }
+# stage (HIP-event span inside the library) -> the kernel it brackets, as it appears in the rocprofv3 kernel stats
+STAGE_KERNEL = {"grid_forward": "tcnn_hip::k_grid_forward", "mlp_forward": "tcnn_hip::k_mlp_forward", "loss": "tcnn_hip::k_loss",
+                "mlp_backward": "tcnn_hip::k_mlp_transpose_weights + k_mlp_backward + k_mlp_finalize_gradients",
+                "grid_backward_scatter": "tcnn_hip::k_grid_bucket_scatter", "grid_backward": "tcnn_hip::k_grid_backward_sliced",
+                "grid_backward_overflow": "tcnn_hip::k_grid_bucket_overflow", "adam": "tcnn_hip::k_adam_step"}
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -55,8 +60,12 @@ def algorithmic_bytes(n, n_params, n_mlp_params):
         "mlp_forward": n * (enc_w * 2 + H * W * 2 + OUTP * 2) + n_mlp_params * 2,  # encoded read + saved hidden + output
         "loss": n * (OUTP * 2 + N_OUT * 4 + OUTP * 2),
         "mlp_backward": n * (enc_w * 2 + H * W * 2 + OUTP * 2 + enc_w * 2) + n_mlp_params * 4,
-        "grid_backward_zero": p_grid * 2,
-        "grid_backward": n * (4 * D + enc_w * 2 + 2 * L * C * F * 2),            # positions + dL/denc + RMW of 8 corners
+        # grid backward: positions + dL/denc + read-modify-write of the 8 corners = 12 + 64 + 2 * 512 B per sample.
+        # The bucketed implementation runs it as two kernels; the figure is apportioned, not re-derived from what they
+        # move: the record-scatter kernel carries the inputs and the read half of the RMW, the owner kernel the write half.
+        "grid_backward_scatter": n * (4 * D + enc_w * 2 + L * C * F * 2),
+        "grid_backward": n * L * C * F * 2,
+        "grid_backward_overflow": 0,
         "adam": n_params * 36,                                                   # 2 grad + (4+4)x(master, m, v, steps) + 2 fp16 param
         # fused-ideal step of SURVEY 8d: per sample 12 + 16 + 512 + 1024 B, per step P_grid*2 + P_total*36
         "step_ideal": n * (4 * D + 4 * N_OUT + L * C * F * 2 + 2 * L * C * F * 2) + p_grid * 2 + n_params * 36,
@@ -195,7 +204,7 @@ def main():
                                    "3D->4, RelativeL2, Adam(config_hash.json), training_step incl. optimizer",
                        "batch_per_gpu": BATCH, "global_batch": global_batch, "n_params": tm.n_params,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dominant, "kernel_symbol": STAGE_KERNEL.get(dominant), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": ab[dominant], "avg_launch_ms": dom_avg_s * 1e3, "launches_timed": int(dom_cnt)},
             "stages_ms": stages,

@@ -168,12 +168,13 @@ enum Stage : int {
 	STAGE_MLP_FWD,
 	STAGE_LOSS,
 	STAGE_MLP_BWD,       // weight transpose + fused backward + finalize
-	STAGE_GRID_BWD_ZERO, // gradient memset (grid.h:865-867)
-	STAGE_GRID_BWD,      // scatter kernels
+	STAGE_GRID_BWD_SCATTER,     // bucketed backward pass A: derive the corner records once, bin them by owning slice
+	STAGE_GRID_BWD,             // pass B (owners accumulate + store) -- or the whole backward in the sliced / atomic modes
+	STAGE_GRID_BWD_OVERFLOW,    // pass C: queue overflow through global atomics (normally empty)
 	STAGE_ADAM,
 	N_STAGES
 };
-static const char* const STAGE_NAMES[N_STAGES] = {"grid_forward", "mlp_forward", "loss", "mlp_backward", "grid_backward_zero", "grid_backward", "adam"};
+static const char* const STAGE_NAMES[N_STAGES] = {"grid_forward", "mlp_forward", "loss", "mlp_backward", "grid_backward_scatter", "grid_backward", "grid_backward_overflow", "adam"};
 
 struct Profiler {
 	int only_stage = -1;  // -1: all stages
@@ -242,6 +243,22 @@ struct ProfScope {
 		}
 	}
 };
+// grid_backward reports its kernels one by one (GridBackwardWorkspace::phase_hook); user = the stream
+static void grid_backward_phase_hook(void* user, int phase, int begin) {
+	static thread_local hipEvent_t a = nullptr;
+	const int stage = phase == 0 ? STAGE_GRID_BWD_SCATTER : (phase == 1 ? STAGE_GRID_BWD : STAGE_GRID_BWD_OVERFLOW);
+	if (!g_profiler || (g_profiler->only_stage >= 0 && g_profiler->only_stage != stage)) return;
+	if (begin) {
+		a = g_profiler->get();
+		HIP_CHECK(hipEventRecord(a, (hipStream_t)user));
+	} else if (a) {
+		hipEvent_t b = g_profiler->get();
+		HIP_CHECK(hipEventRecord(b, (hipStream_t)user));
+		g_profiler->spans.push_back({stage, a, b});
+		a = nullptr;
+	}
+}
+
 struct ProfilerGuard {
 	explicit ProfilerGuard(Profiler* p) { g_profiler = p; }
 	~ProfilerGuard() { g_profiler = nullptr; }
@@ -618,7 +635,6 @@ static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx
 			half_t* grid_grads = dL_dparams + md.n_mlp_params();
 			// Overwrite vs Accumulate (grid.h:865-867) is handled inside: the owner-computes kernel stores
 			// whole slices, so the reference's full-table memset is only issued for the atomic A/B mode.
-			ProfScope prof(stream, STAGE_GRID_BWD);
 			const GridBackwardMode mode = (GridBackwardMode)g_grid_backward_mode.load();
 			if (lds_level_budget == 0) lds_level_budget = g_default_lds_slice_bytes;
 			GridBackwardWorkspace ws = grid_backward_workspace_size(e.grid, n, mode, lds_level_budget);
@@ -629,6 +645,8 @@ static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx
 				ws.scratch_bytes = queues.bytes;
 				ws.counters = ZeroedCounters::get(stream, ws.n_counters);
 			}
+			ws.phase_hook = grid_backward_phase_hook;  // per-kernel timing when a profiler is attached
+			ws.hook_user = (void*)stream;
 			grid_backward(stream, e.grid, io, dL_denc, grid_grads, accumulate, mode, lds_level_budget, ws);
 		}
 		if (dL_dinput) {

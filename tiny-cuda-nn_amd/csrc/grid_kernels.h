@@ -65,6 +65,10 @@ struct GridBackwardWorkspace {
 	size_t scratch_bytes = 0;
 	uint32_t* counters = nullptr;
 	size_t n_counters = 0;
+	// optional: called right before (begin = 1) and after (begin = 0) each kernel sequence of the backward --
+	// phase 0: record scatter (bucketed mode only), 1: accumulation + stores (every mode), 2: overflow pass
+	void (*phase_hook)(void* user, int phase, int begin) = nullptr;
+	void* hook_user = nullptr;
 };
 GridBackwardWorkspace grid_backward_workspace_size(const GridMeta& meta, uint32_t n, GridBackwardMode mode, uint32_t lds_slice_bytes);
 void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient, bool accumulate,

@@ -160,35 +160,10 @@ TCNN_DEVICE void load_features(const half_t* p, h2 (&v)[(F + 1) / 2]) {
 	}
 }
 
-// The aligned PAIR of entries (i & ~1, i | 1) in one access (F <= 4: at most 16 bytes).  The two corners that differ in
-// dimension 0 are usually such a pair (dense: index + 1; hashed: prime[0] == 1 -> index ^ 1 when the coordinate is
-// even), so half of the x-neighbours cost one gather lane-operation instead of two -- the gather rate of this kernel is
-// bound by per-lane address processing, not by bytes.
-template <uint32_t F>
-TCNN_DEVICE void load_feature_pair(const half_t* grid, uint32_t i, h2 (&lo)[(F + 1) / 2], h2 (&hi)[(F + 1) / 2]) {
-	const half_t* p = grid + (size_t)(i & ~1u) * F;
-	if constexpr (F == 1) {
-		const h2 t = *(const h2*)p;
-		lo[0] = h2{t[0], (half_t)0.0f};
-		hi[0] = h2{t[1], (half_t)0.0f};
-	} else if constexpr (F == 2) {
-		const h4 t = *(const h4*)p;
-		lo[0] = h2{t[0], t[1]};
-		hi[0] = h2{t[2], t[3]};
-	} else {
-		static_assert(F == 4, "pair loads cover F <= 4");
-		const h8 t = *(const h8*)p;
-		lo[0] = h2{t[0], t[1]};
-		lo[1] = h2{t[2], t[3]};
-		hi[0] = h2{t[4], t[5]};
-		hi[1] = h2{t[6], t[7]};
-	}
-}
-
 // =============================================================================================
 // forward (grid.h:49-212)
 // =============================================================================================
-template <uint32_t D, uint32_t F, bool DYDX, bool FAST, bool PAIR>
+template <uint32_t D, uint32_t F, bool DYDX, bool FAST>
 TCNN_DEVICE void grid_forward_sample(const Level<D>& lv, const GridIO& io, const half_t* __restrict__ grid, uint32_t level, uint32_t i,
                                      bool level_off, half_t* __restrict__ out, float* __restrict__ dy_dx) {
 	constexpr uint32_t NP = (F + 1) / 2;
@@ -208,24 +183,8 @@ TCNN_DEVICE void grid_forward_sample(const Level<D>& lv, const GridIO& io, const
 		} else {
 			// gather all corners first (independent loads in flight) ...
 			h2 val[1u << D][NP];
-			if constexpr (PAIR && F <= 4) {
 #pragma unroll
-				for (uint32_t pr = 0; pr < (1u << (D - 1)); ++pr) {
-					const uint32_t i0 = corner_index<D, FAST>(lv, c, 2 * pr), i1 = corner_index<D, FAST>(lv, c, 2 * pr + 1);
-					h2 lo[NP], hi[NP];
-					load_feature_pair<F>(grid, i0, lo, hi);
-					const bool odd = (i0 & 1u) != 0u;
-#pragma unroll
-					for (uint32_t p = 0; p < NP; ++p) {
-						val[2 * pr][p] = odd ? hi[p] : lo[p];
-						val[2 * pr + 1][p] = odd ? lo[p] : hi[p];  // entry i0 ^ 1
-					}
-					if ((i0 ^ i1) != 1u) load_features<F>(grid + (size_t)i1 * F, val[2 * pr + 1]);
-				}
-			} else {
-#pragma unroll
-				for (uint32_t idx = 0; idx < (1u << D); ++idx) load_features<F>(grid + (size_t)corner_index<D, FAST>(lv, c, idx) * F, val[idx]);
-			}
+			for (uint32_t idx = 0; idx < (1u << D); ++idx) load_features<F>(grid + (size_t)corner_index<D, FAST>(lv, c, idx) * F, val[idx]);
 			// ... then the N-linear interpolation, corner order and fp16 fma chain of grid.h:144-163
 #pragma unroll
 			for (uint32_t idx = 0; idx < (1u << D); ++idx) {
@@ -273,7 +232,7 @@ TCNN_DEVICE void grid_forward_sample(const Level<D>& lv, const GridIO& io, const
 	}
 }
 
-template <uint32_t D, uint32_t F, bool DYDX, bool PAIR>
+template <uint32_t D, uint32_t F, bool DYDX>
 __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward(const GridMeta meta, const GridIO io, const half_t* __restrict__ params,
                                                                 half_t* __restrict__ out, float* __restrict__ dy_dx) {
 	uint32_t level, tile;
@@ -287,12 +246,12 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward(const GridMeta me
 #pragma unroll
 		for (uint32_t s = 0; s < GRID_SPT; ++s) {
 			const uint32_t i = tile * GRID_TILE + s * GRID_THREADS + threadIdx.x;
-			if (i < io.n) grid_forward_sample<D, F, DYDX, true, PAIR>(lv, io, grid, level, i, level_off, out, dy_dx);
+			if (i < io.n) grid_forward_sample<D, F, DYDX, true>(lv, io, grid, level, i, level_off, out, dy_dx);
 		}
 	} else {
 		for (uint32_t s = 0; s < GRID_SPT; ++s) {
 			const uint32_t i = tile * GRID_TILE + s * GRID_THREADS + threadIdx.x;
-			if (i < io.n) grid_forward_sample<D, F, DYDX, false, PAIR>(lv, io, grid, level, i, level_off, out, dy_dx);
+			if (i < io.n) grid_forward_sample<D, F, DYDX, false>(lv, io, grid, level, i, level_off, out, dy_dx);
 		}
 	}
 }
@@ -982,19 +941,11 @@ __global__ void k_grid_indices(const GridMeta meta, const GridIO io, uint32_t* _
 void grid_forward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* params, half_t* out, float* dy_dx) {
 	if (io.n == 0) return;
 	const uint32_t blocks = grid_n_blocks(meta.n_levels, io.n);
-	// pair loads need the table 16-byte aligned (level offsets are multiples of 8 entries) and F <= 4
-	const bool pair = ((uintptr_t)params % 16u) == 0u && meta.n_feat <= 4u && !getenv("TCNN_GRID_FORWARD_NO_PAIR_LOADS");
-#define FWD(D_, F_)                                                                                                                              \
-	if (dy_dx) {                                                                                                                                 \
-		if (pair) {                                                                                                                              \
-			TCNN_LAUNCH((k_grid_forward<D_, F_, true, true>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, dy_dx);        \
-		} else {                                                                                                                                 \
-			TCNN_LAUNCH((k_grid_forward<D_, F_, true, false>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, dy_dx);       \
-		}                                                                                                                                        \
-	} else if (pair) {                                                                                                                           \
-		TCNN_LAUNCH((k_grid_forward<D_, F_, false, true>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, (float*)nullptr); \
-	} else {                                                                                                                                     \
-		TCNN_LAUNCH((k_grid_forward<D_, F_, false, false>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, (float*)nullptr); \
+#define FWD(D_, F_)                                                                                                                        \
+	if (dy_dx) {                                                                                                                           \
+		TCNN_LAUNCH((k_grid_forward<D_, F_, true>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, dy_dx);            \
+	} else {                                                                                                                               \
+		TCNN_LAUNCH((k_grid_forward<D_, F_, false>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, (float*)nullptr); \
 	}
 	TCNN_GRID_DISPATCH(FWD)
 #undef FWD
@@ -1164,6 +1115,7 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 		counters = ws.counters;  // zero on entry (contract); the kernels below leave them zeroed again
 		queues = (uint32_t*)ws.scratch;
 		overflow = (uint32_t*)((unsigned char*)ws.scratch + bp.overflow_offset);
+		if (ws.phase_hook) ws.phase_hook(ws.hook_user, 0, 1);
 		// pass A: derive every corner once, bin by owner (+ zero the gradients of chunked levels)
 		const uint32_t scatter_blocks = bk.scatter_blocks + bk.zero_block_begin[bk.n_levels];
 		uint32_t max_buckets = 0;
@@ -1177,7 +1129,9 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 	}
 		TCNN_GRID_DISPATCH(BSCATTER)
 #undef BSCATTER
+		if (ws.phase_hook) ws.phase_hook(ws.hook_user, 0, 0);
 	}
+	if (ws.phase_hook) ws.phase_hook(ws.hook_user, 1, 1);
 	for (uint32_t p = 0; p < plan.n_items; ++p) {
 		struct { uint32_t level, kind, n_chunks; } it = {plan.level[p], plan.kind[p], bp.n_chunks[p]};
 		if (it.kind != SLICE_BUCKET && (it.n_chunks > 1 || it.kind == SLICE_GLOBAL_ATOMIC) && !accumulate) {  // atomically updated levels start from zero
@@ -1202,11 +1156,14 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 	}
 	TCNN_GRID_DISPATCH(BWDS)
 #undef BWDS
+	if (ws.phase_hook) ws.phase_hook(ws.hook_user, 1, 0);
 	if (bk.n_levels) {
+		if (ws.phase_hook) ws.phase_hook(ws.hook_user, 2, 1);
 		// pass C: overflowed records (none for near-uniform inputs: the kernel reads one counter and exits)
 #define BOVF(D_, F_) TCNN_LAUNCH((k_grid_bucket_overflow<F_>), dim3(256), dim3(256), 0, stream, meta, bk, counters, (const uint32_t*)overflow, grid_gradient);
 		TCNN_GRID_DISPATCH(BOVF)
 #undef BOVF
+		if (ws.phase_hook) ws.phase_hook(ws.hook_user, 2, 0);
 	}
 }
 
@@ -1217,7 +1174,11 @@ void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, c
 	switch (mode) {
 		case GridBackwardMode::SlicedF32: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, false, false, lds_slice_bytes, ws); break;
 		case GridBackwardMode::SlicedF16: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, true, false, lds_slice_bytes, ws); break;
-		case GridBackwardMode::Atomic: grid_backward_atomic(stream, meta, io, dL_dy, grid_gradient, accumulate); break;
+		case GridBackwardMode::Atomic:
+			if (ws.phase_hook) ws.phase_hook(ws.hook_user, 1, 1);
+			grid_backward_atomic(stream, meta, io, dL_dy, grid_gradient, accumulate);
+			if (ws.phase_hook) ws.phase_hook(ws.hook_user, 1, 0);
+			break;
 		case GridBackwardMode::Bucketed:
 			grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, true, true, lds_slice_bytes, ws);
 			break;

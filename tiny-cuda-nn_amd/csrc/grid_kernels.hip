@@ -468,6 +468,10 @@ TCNN_DEVICE void sliced_level(const GridMeta& meta, const GridIO& io, const Leve
 #endif
 constexpr uint32_t BUCKET_THREADS = TCNN_BUCKET_THREADS;
 constexpr uint32_t MAX_BUCKET_LEVELS = 32;
+#ifndef TCNN_BUCKET_RESIDENT_WGS
+#define TCNN_BUCKET_RESIDENT_WGS 1024
+#endif
+constexpr uint32_t BUCKET_RESIDENT_WGS = TCNN_BUCKET_RESIDENT_WGS;  // 256 CUs x 4
 constexpr uint32_t MAX_BUCKETS_PER_LEVEL = 4096;
 #ifndef TCNN_BUCKET_STAGE_BYTES
 #define TCNN_BUCKET_STAGE_BYTES (32 * 1024)  // measured: 32 KiB (4 workgroups per CU) beats 64 and 16 KiB
@@ -478,7 +482,8 @@ struct BucketPlan {
 	uint32_t n_levels;  // bucketed levels
 	uint32_t shift;     // log2(entries per bucket)
 	uint32_t tiles;     // sample tiles per level in pass A
-	uint32_t scatter_blocks;     // n_levels * tiles: pass-A blocks beyond these zero the gradients of chunked levels
+	uint32_t wgs_per_level;      // persistent pass-A workgroups per level (each walks tiles wg, wg + wgs_per_level, ...)
+	uint32_t scatter_blocks;     // n_levels * wgs_per_level: pass-A blocks beyond these zero the gradients of chunked levels
 	uint32_t overflow_counter;   // index of the overflow counter (== total number of queues); the one after it counts finished pass-C blocks
 	uint32_t overflow_capacity;  // records
 	uint8_t level[MAX_BUCKET_LEVELS];             // grid level of slot j
@@ -531,9 +536,9 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 		if (h < n_halves) *(u4*)(grid_gradient + (size_t)meta.offset[zl] * F + h) = u4{0u, 0u, 0u, 0u};
 		return;
 	}
-	const uint32_t j = blockIdx.x / plan.tiles, tile = blockIdx.x % plan.tiles;
+	// persistent workgroup: `wgs_per_level` of them share the sample tiles of one level
+	const uint32_t j = blockIdx.x / plan.wgs_per_level, first_tile = blockIdx.x % plan.wgs_per_level;
 	const uint32_t level = plan.level[j], nb = plan.n_buckets[j], shift = plan.shift;
-	const uint32_t chunk = tile / plan.tiles_per_chunk[j];
 	const uint32_t n_features = meta.n_levels * F;
 	const float max_level = (meta.max_level * (float)n_features) / (float)F;
 	if ((float)level > max_level + 1e-3f) return;  // grid.h:242: no records, the owners store zeros
@@ -544,11 +549,11 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 	// share a bucket except once in ~2^shift pairs: the second record of such a pair is routed through the overflow
 	// list instead.  Halves the ranking / reordering work per corner; a pair is 16 bytes for F == 2.
 	uint32_t* stage = (uint32_t*)lds_raw;   // [N_PAIR][2 * W]
-	uint32_t* cnt = stage + N_PAIR * 2 * W; // [nb] pairs of this workgroup per bucket
+	uint32_t* cnt = stage + N_PAIR * 2 * W; // [nb] pairs of this tile per bucket
 	uint32_t* delta = cnt + nb;             // [nb] exclusive prefix of cnt, later (queue position - staging position)
-	uint32_t* part = delta + nb;            // [BUCKET_THREADS] scan scratch
+	uint32_t* part = delta + nb;            // [64] scan scratch of wave 0
+	uint32_t* total_p = part + 64;          // [1]
 	for (uint32_t b = threadIdx.x; b < nb; b += BUCKET_THREADS) cnt[b] = 0u;
-	__syncthreads();
 
 	auto push_overflow = [&](uint32_t index, const uint32_t* payload) {
 		const uint32_t o = atomic_add_u32(&counters[plan.overflow_counter], 1u);
@@ -560,152 +565,175 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 			for (uint32_t p = 0; p < PW; ++p) dst[2 + p] = payload[p];
 		}
 	};
-
-	// ---- derive the records of my samples; rank each pair within its bucket
-	float x[SPT][D];
-	half_t g[SPT][F];
-#pragma unroll
-	for (uint32_t s = 0; s < SPT; ++s) {
-		const uint32_t i = min(tile * TILE + s * BUCKET_THREADS + threadIdx.x, io.n - 1u);
-		load_position<D>(io, i, x[s]);
-#pragma unroll
-		for (uint32_t f = 0; f < F; ++f) g[s][f] = dL_dy[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i];
-	}
-	uint32_t ridx[SPT][N_CORNERS], rank[SPT][N_PAIRS_PER_SAMPLE], pay[SPT][N_CORNERS][PW];
-	auto derive = [&](auto fast_tag) {
-		constexpr bool FAST = decltype(fast_tag)::value;
+	auto load_tile = [&](uint32_t tile, float (&x)[SPT][D], half_t (&g)[SPT][F]) {
 #pragma unroll
 		for (uint32_t s = 0; s < SPT; ++s) {
-			const bool valid = tile * TILE + s * BUCKET_THREADS + threadIdx.x < io.n;
-			const Cell<D> c = make_cell<D, FAST>(lv, x[s]);
+			const uint32_t i = min(tile * TILE + s * BUCKET_THREADS + threadIdx.x, io.n - 1u);
+			load_position<D>(io, i, x[s]);
 #pragma unroll
-			for (uint32_t idx = 0; idx < N_CORNERS; ++idx) {
-				const float weight = lv.nearest ? 1.0f : corner_weight<D>(c, idx);
-				if constexpr (F == 1) {
-					pay[s][idx][0] = __builtin_bit_cast(uint32_t, weight * (float)g[s][0]);
-				} else {
-					const half_t wh = to_half_rn(weight);  // (GRAD_T)weight, grid.h:254
-					const h2 w2 = h2{wh, wh};
-#pragma unroll
-					for (uint32_t p = 0; p < PW; ++p) pay[s][idx][p] = h2_bits(w2 * h2{g[s][2 * p], g[s][2 * p + 1]});
-				}
-				ridx[s][idx] = corner_index<D, FAST>(lv, c, idx);
-			}
-#pragma unroll
-			for (uint32_t pr = 0; pr < N_PAIRS_PER_SAMPLE; ++pr) {
-				const bool live = valid && (pr == 0u || !lv.nearest);
-				const uint32_t bucket = ridx[s][2 * pr] >> shift;
-				if (!live) {
-					ridx[s][2 * pr] = INVALID;
-					ridx[s][2 * pr + 1] = INVALID;
-				} else if (lv.nearest) {
-					ridx[s][2 * pr + 1] = INVALID;
-				} else if ((ridx[s][2 * pr + 1] >> shift) != bucket) {
-					push_overflow(ridx[s][2 * pr + 1], pay[s][2 * pr + 1]);
-					ridx[s][2 * pr + 1] = INVALID;
-				}
-				rank[s][pr] = live ? atomic_add_u32(&cnt[bucket], 1u) : 0u;
-			}
+			for (uint32_t f = 0; f < F; ++f) g[s][f] = dL_dy[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i];
 		}
 	};
-	if (lv.fast) derive(std::true_type{}); else derive(std::false_type{});
+
+	float x[SPT][D], x_next[SPT][D];
+	half_t g[SPT][F], g_next[SPT][F];
+	if (first_tile < plan.tiles) load_tile(first_tile, x, g);
 	__syncthreads();
 
-	// ---- exclusive scan of the bucket counts; reserve this workgroup's run in every bucket queue
-	const uint32_t per_thread = div_round_up(nb, BUCKET_THREADS);
-	const uint32_t b_begin = min(threadIdx.x * per_thread, nb), b_end = min(b_begin + per_thread, nb);
-	uint32_t sum = 0;
-	for (uint32_t b = b_begin; b < b_end; ++b) sum += cnt[b];
-	part[threadIdx.x] = sum;
-	// the common case (<= 256 buckets): one bucket per thread -- reserve its run now, the scan below hides the
-	// round trip of the returning global atomic
-	uint32_t reserved = 0;
-#if defined(TCNN_EXP_NO_RESERVE)
-	if (per_thread == 1u && sum) reserved = (tile % plan.tiles_per_chunk[j]) * 48u;  // timing experiment: no global atomics
-#else
-	if (per_thread == 1u && sum) reserved = atomic_add_u32(&counters[plan.counter_base[j] + chunk * nb + b_begin], sum);
-#endif
-	__syncthreads();
-	for (uint32_t d = 1; d < BUCKET_THREADS; d <<= 1) {
-		const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
-		__syncthreads();
-		part[threadIdx.x] += v;
-		__syncthreads();
-	}
-	uint32_t running = part[threadIdx.x] - sum;
-	uint32_t my_offset = running, my_reserved = reserved;  // per_thread == 1: this thread's bucket
-	for (uint32_t b = b_begin; b < b_end; ++b) {
-		delta[b] = running;
-		running += cnt[b];
-	}
-	const uint32_t total = part[BUCKET_THREADS - 1];
-	__syncthreads();
+	for (uint32_t tile = first_tile; tile < plan.tiles; tile += plan.wgs_per_level) {
+		const uint32_t chunk = tile / plan.tiles_per_chunk[j];
+		uint32_t* __restrict__ my_counters = counters + plan.counter_base[j] + chunk * nb;
 
-	// ---- reorder by bucket in LDS
+		// ---- derive the records of my samples; rank each pair within its bucket
+		uint32_t ridx[SPT][N_CORNERS], rank[SPT][N_PAIRS_PER_SAMPLE], pay[SPT][N_CORNERS][PW];
+		auto derive = [&](auto fast_tag) {
+			constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-	for (uint32_t s = 0; s < SPT; ++s) {
+			for (uint32_t s = 0; s < SPT; ++s) {
+				const bool valid = tile * TILE + s * BUCKET_THREADS + threadIdx.x < io.n;
+				const Cell<D> c = make_cell<D, FAST>(lv, x[s]);
 #pragma unroll
-		for (uint32_t pr = 0; pr < N_PAIRS_PER_SAMPLE; ++pr) {
-			const uint32_t i0 = ridx[s][2 * pr], i1 = ridx[s][2 * pr + 1];
-			if (i0 == INVALID) continue;
-			const uint32_t pos = delta[i0 >> shift] + rank[s][pr];
-			if constexpr (W == 2) {
-				*(u4*)&stage[pos * 4] = u4{i0, pay[s][2 * pr][0], i1, pay[s][2 * pr + 1][0]};
-			} else {
-				stage[pos * 2 * W] = i0;
-				stage[pos * 2 * W + W] = i1;
+				for (uint32_t idx = 0; idx < N_CORNERS; ++idx) {
+					const float weight = lv.nearest ? 1.0f : corner_weight<D>(c, idx);
+					if constexpr (F == 1) {
+						pay[s][idx][0] = __builtin_bit_cast(uint32_t, weight * (float)g[s][0]);
+					} else {
+						const half_t wh = to_half_rn(weight);  // (GRAD_T)weight, grid.h:254
+						const h2 w2 = h2{wh, wh};
 #pragma unroll
-				for (uint32_t p = 0; p < PW; ++p) {
-					stage[pos * 2 * W + 1 + p] = pay[s][2 * pr][p];
-					stage[pos * 2 * W + W + 1 + p] = pay[s][2 * pr + 1][p];
+						for (uint32_t p = 0; p < PW; ++p) pay[s][idx][p] = h2_bits(w2 * h2{g[s][2 * p], g[s][2 * p + 1]});
+					}
+					ridx[s][idx] = corner_index<D, FAST>(lv, c, idx);
+				}
+#pragma unroll
+				for (uint32_t pr = 0; pr < N_PAIRS_PER_SAMPLE; ++pr) {
+					const bool live = valid && (pr == 0u || !lv.nearest);
+					const uint32_t bucket = ridx[s][2 * pr] >> shift;
+					if (!live) {
+						ridx[s][2 * pr] = INVALID;
+						ridx[s][2 * pr + 1] = INVALID;
+					} else if (lv.nearest) {
+						ridx[s][2 * pr + 1] = INVALID;
+					} else if ((ridx[s][2 * pr + 1] >> shift) != bucket) {
+						push_overflow(ridx[s][2 * pr + 1], pay[s][2 * pr + 1]);
+						ridx[s][2 * pr + 1] = INVALID;
+					}
+					rank[s][pr] = live ? atomic_add_u32(&cnt[bucket], 1u) : 0u;
+				}
+			}
+		};
+		if (lv.fast) derive(std::true_type{}); else derive(std::false_type{});
+		// the next tile's inputs travel while this one is ranked, reordered and written
+		const uint32_t next_tile = tile + plan.wgs_per_level;
+		if (next_tile < plan.tiles) load_tile(next_tile, x_next, g_next);
+		__syncthreads();
+
+		// ---- reserve this tile's run in every bucket queue (one returning global atomic per non-empty bucket; the
+		// common case has one bucket per thread and hides the round trip behind the scan and the reordering) ...
+		uint32_t reserved = 0;
+		if (nb <= BUCKET_THREADS && threadIdx.x < nb) {
+			const uint32_t c = cnt[threadIdx.x];
+			if (c) reserved = atomic_add_u32(&my_counters[threadIdx.x], c);
+		}
+		// ... while wave 0 turns the counts into staging offsets (exclusive scan, wave-synchronous)
+		if (threadIdx.x < WAVE) {
+			const uint32_t per_lane = div_round_up(nb, WAVE);
+			const uint32_t b_begin = min(threadIdx.x * per_lane, nb), b_end = min(b_begin + per_lane, nb);
+			uint32_t sum = 0;
+			for (uint32_t b = b_begin; b < b_end; ++b) sum += cnt[b];
+			part[threadIdx.x] = sum;
+			wave_lds_sync();
+			for (uint32_t d = 1; d < WAVE; d <<= 1) {
+				const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+				wave_lds_sync();
+				part[threadIdx.x] += v;
+				wave_lds_sync();
+			}
+			uint32_t running = part[threadIdx.x] - sum;
+			for (uint32_t b = b_begin; b < b_end; ++b) {
+				delta[b] = running;
+				running += cnt[b];
+			}
+			if (threadIdx.x == WAVE - 1) total_p[0] = part[WAVE - 1];
+		}
+		__syncthreads();
+		const uint32_t total = total_p[0];
+
+		// ---- reorder by bucket in LDS
+#pragma unroll
+		for (uint32_t s = 0; s < SPT; ++s) {
+#pragma unroll
+			for (uint32_t pr = 0; pr < N_PAIRS_PER_SAMPLE; ++pr) {
+				const uint32_t i0 = ridx[s][2 * pr], i1 = ridx[s][2 * pr + 1];
+				if (i0 == INVALID) continue;
+				const uint32_t pos = delta[i0 >> shift] + rank[s][pr];
+				if constexpr (W == 2) {
+					*(u4*)&stage[pos * 4] = u4{i0, pay[s][2 * pr][0], i1, pay[s][2 * pr + 1][0]};
+				} else {
+					stage[pos * 2 * W] = i0;
+					stage[pos * 2 * W + W] = i1;
+#pragma unroll
+					for (uint32_t p = 0; p < PW; ++p) {
+						stage[pos * 2 * W + 1 + p] = pay[s][2 * pr][p];
+						stage[pos * 2 * W + W + 1 + p] = pay[s][2 * pr + 1][p];
+					}
 				}
 			}
 		}
-	}
-	__syncthreads();
-	// delta[b] := (position of the run in bucket b's queue) - (position of the run in the staging area)
-	if (per_thread == 1u) {
-		if (b_begin < b_end) delta[b_begin] = my_reserved - my_offset;
-	} else {
-		for (uint32_t b = b_begin; b < b_end; ++b) {
-			const uint32_t c = cnt[b];
-			delta[b] = (c ? atomic_add_u32(&counters[plan.counter_base[j] + chunk * nb + b], c) : 0u) - delta[b];
-		}
-	}
-	__syncthreads();
-
-	// ---- append the runs to the bucket queues: consecutive threads -> consecutive pairs
-	const uint32_t cap = plan.capacity[j];
-	uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)chunk * nb * cap) * 2 * W;
-	for (uint32_t t = threadIdx.x; t < total; t += BUCKET_THREADS) {
-		uint32_t rec[2 * W];
-		if constexpr (W == 2) {
-			const u4 r = *(const u4*)&stage[t * 4];
-			rec[0] = r[0];
-			rec[1] = r[1];
-			rec[2] = r[2];
-			rec[3] = r[3];
+		__syncthreads();
+		// delta[b] := (position of the run in bucket b's queue) - (position of the run in the staging area);
+		// the counts are dead from here on: clear them for the next tile
+		if (nb <= BUCKET_THREADS) {
+			if (threadIdx.x < nb) {
+				delta[threadIdx.x] = reserved - delta[threadIdx.x];
+				cnt[threadIdx.x] = 0u;
+			}
 		} else {
-#pragma unroll
-			for (uint32_t w = 0; w < 2 * W; ++w) rec[w] = stage[t * 2 * W + w];
+			for (uint32_t b = threadIdx.x; b < nb; b += BUCKET_THREADS) {
+				const uint32_t c = cnt[b];
+				delta[b] = (c ? atomic_add_u32(&my_counters[b], c) : 0u) - delta[b];
+				cnt[b] = 0u;
+			}
 		}
-		const uint32_t b = rec[0] >> shift;
-		const uint32_t pos = t + delta[b];  // wraps like the subtraction above
-		if (pos < cap) {
-			uint32_t* dst = q + ((size_t)b * cap + pos) * 2 * W;
-#if defined(TCNN_EXP_NO_STORE)
-			if (rec[0] == 0x12345u) dst[0] = 1;  // timing experiment: no queue traffic
-#else
+		__syncthreads();
+
+		// ---- append the runs to the bucket queues: consecutive threads -> consecutive pairs
+		const uint32_t cap = plan.capacity[j];
+		uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)chunk * nb * cap) * 2 * W;
+		for (uint32_t t = threadIdx.x; t < total; t += BUCKET_THREADS) {
+			uint32_t rec[2 * W];
 			if constexpr (W == 2) {
-				*(u4*)dst = u4{rec[0], rec[1], rec[2], rec[3]};
+				const u4 r = *(const u4*)&stage[t * 4];
+				rec[0] = r[0];
+				rec[1] = r[1];
+				rec[2] = r[2];
+				rec[3] = r[3];
 			} else {
 #pragma unroll
-				for (uint32_t w = 0; w < 2 * W; ++w) dst[w] = rec[w];
+				for (uint32_t w = 0; w < 2 * W; ++w) rec[w] = stage[t * 2 * W + w];
 			}
-#endif
-		} else {
-			push_overflow(rec[0], &rec[1]);
-			if (rec[W] != INVALID) push_overflow(rec[W], &rec[W + 1]);
+			const uint32_t b = rec[0] >> shift;
+			const uint32_t pos = t + delta[b];  // wraps like the subtraction above
+			if (pos < cap) {
+				uint32_t* dst = q + ((size_t)b * cap + pos) * 2 * W;
+				if constexpr (W == 2) {
+					*(u4*)dst = u4{rec[0], rec[1], rec[2], rec[3]};
+				} else {
+#pragma unroll
+					for (uint32_t w = 0; w < 2 * W; ++w) dst[w] = rec[w];
+				}
+			} else {
+				push_overflow(rec[0], &rec[1]);
+				if (rec[W] != INVALID) push_overflow(rec[W], &rec[W + 1]);
+			}
+		}
+		__syncthreads();  // the staging area and the offsets are reused by the next tile
+#pragma unroll
+		for (uint32_t s = 0; s < SPT; ++s) {
+#pragma unroll
+			for (uint32_t d = 0; d < D; ++d) x[s][d] = x_next[s][d];
+#pragma unroll
+			for (uint32_t f = 0; f < F; ++f) g[s][f] = g_next[s][f];
 		}
 	}
 }
@@ -1057,7 +1085,9 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 		items.push_back(it);
 	}
 	if (n_records > 0xFFFFFFFFull) throw std::runtime_error("grid_backward: batch too large for the bucketed backward");
-	bk.scatter_blocks = bk.n_levels * bk.tiles;
+	// persistent scatter workgroups: about four per CU over all levels (the LDS staging area allows four to be resident)
+	bk.wgs_per_level = bk.n_levels ? std::max(1u, std::min(bk.tiles, div_round_up(BUCKET_RESIDENT_WGS, bk.n_levels))) : 1u;
+	bk.scatter_blocks = bk.n_levels * bk.wgs_per_level;
 	bk.zero_block_begin[bk.n_levels] = n_zero_blocks;
 	bk.overflow_counter = n_counters;
 	bk.overflow_capacity = (uint32_t)n_records;
@@ -1122,7 +1152,7 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 		for (uint32_t j = 0; j < bk.n_levels; ++j) max_buckets = std::max(max_buckets, bk.n_buckets[j]);
 #define BSCATTER(D_, F_)                                                                                                                      \
 	{                                                                                                                                         \
-		const uint32_t lds = bucket_spt(D_, F_) * BUCKET_THREADS * (1u << D_) * BucketRecord<F_>::WORDS * 4u + (2u * max_buckets + BUCKET_THREADS) * 4u; \
+		const uint32_t lds = bucket_spt(D_, F_) * BUCKET_THREADS * (1u << D_) * BucketRecord<F_>::WORDS * 4u + (2u * max_buckets + WAVE + 4u) * 4u;       \
 		TCNN_SET_MAX_DYN_LDS((k_grid_bucket_scatter<D_, F_>), lds);                                                                           \
 		TCNN_LAUNCH((k_grid_bucket_scatter<D_, F_>), dim3(scatter_blocks), dim3(BUCKET_THREADS), lds, stream, meta, io, bk, dL_dy, counters,  \
 		            queues, overflow, grid_gradient);                                                                                         \

@@ -74,6 +74,19 @@ TCNN_DEVICE uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((20) | (0 << 6)
 
 TCNN_DEVICE uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// Orders the LDS accesses of ONE wavefront (all 64 lanes must call it): what a block barrier does for a workgroup,
+// for code that only one wave executes.  The hardware runs a wave in lock step; this pins the compiler and drains
+// the LDS queue.
+#if defined(TCNN_HOST_EMU)
+TCNN_DEVICE void wave_lds_sync() { ::emu::wave_barrier(); }
+#else
+TCNN_DEVICE void wave_lds_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#endif
+
 // fp32 -> fp16 with exactly ONE extra rounding (RNE) of an already rounded fp32 value.
 // Without the barrier hipcc folds `(half)(a * b)` / `(half)(a + b)` into v_fma_mixlo_f16, which rounds
 // the exact product/sum once -- a different (double- vs single-rounding) result in rare tie cases, and

@@ -469,9 +469,9 @@ TCNN_DEVICE void sliced_level(const GridMeta& meta, const GridIO& io, const Leve
 constexpr uint32_t BUCKET_THREADS = TCNN_BUCKET_THREADS;
 constexpr uint32_t MAX_BUCKET_LEVELS = 32;
 #ifndef TCNN_BUCKET_RESIDENT_WGS
-#define TCNN_BUCKET_RESIDENT_WGS 1024
+#define TCNN_BUCKET_RESIDENT_WGS 2048  // measured: 2 tiles in flight per resident slot beat 1, 1.5, 4 and 8 (profiles/r01_exp_scatter_wgs.txt)
 #endif
-constexpr uint32_t BUCKET_RESIDENT_WGS = TCNN_BUCKET_RESIDENT_WGS;  // 256 CUs x 4
+constexpr uint32_t BUCKET_RESIDENT_WGS = TCNN_BUCKET_RESIDENT_WGS;  // persistent scatter workgroups over all levels
 constexpr uint32_t MAX_BUCKETS_PER_LEVEL = 4096;
 #ifndef TCNN_BUCKET_STAGE_BYTES
 #define TCNN_BUCKET_STAGE_BYTES (32 * 1024)  // measured: 32 KiB (4 workgroups per CU) beats 64 and 16 KiB
@@ -1085,7 +1085,7 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 		items.push_back(it);
 	}
 	if (n_records > 0xFFFFFFFFull) throw std::runtime_error("grid_backward: batch too large for the bucketed backward");
-	// persistent scatter workgroups: about four per CU over all levels (the LDS staging area allows four to be resident)
+	// persistent scatter workgroups (four fit a CU's LDS at a time; twice that many are launched)
 	bk.wgs_per_level = bk.n_levels ? std::max(1u, std::min(bk.tiles, div_round_up(BUCKET_RESIDENT_WGS, bk.n_levels))) : 1u;
 	bk.scatter_blocks = bk.n_levels * bk.wgs_per_level;
 	bk.zero_block_begin[bk.n_levels] = n_zero_blocks;

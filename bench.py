@@ -44,6 +44,7 @@ CONFIG = {
 # stage (HIP-event span inside the library) -> the kernel it brackets, as it appears in the rocprofv3 kernel stats
 STAGE_KERNEL = {"grid_forward": "tcnn_hip::k_grid_forward", "mlp_forward": "tcnn_hip::k_mlp_forward", "loss": "tcnn_hip::k_loss",
                 "mlp_backward": "tcnn_hip::k_mlp_transpose_weights + k_mlp_backward + k_mlp_finalize_gradients",
+                "mlp_train_fused": "tcnn_hip::k_mlp_transpose_weights + k_mlp_train + k_mlp_finalize_gradients",
                 "grid_backward_scatter": "tcnn_hip::k_grid_bucket_scatter", "grid_backward": "tcnn_hip::k_grid_backward_sliced",
                 "grid_backward_overflow": "tcnn_hip::k_grid_bucket_overflow", "adam": "tcnn_hip::k_adam_step"}
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -60,6 +61,8 @@ def algorithmic_bytes(n, n_params, n_mlp_params):
         "mlp_forward": n * (enc_w * 2 + H * W * 2 + OUTP * 2) + n_mlp_params * 2,  # encoded read + saved hidden + output
         "loss": n * (OUTP * 2 + N_OUT * 4 + OUTP * 2),
         "mlp_backward": n * (enc_w * 2 + H * W * 2 + OUTP * 2 + enc_w * 2) + n_mlp_params * 4,
+        # fused forward + loss + backward: encoded in, prediction + dL/dy out (kept for the caller's context), targets in, dL/denc out
+        "mlp_train_fused": n * (enc_w * 2 + OUTP * 2 + OUTP * 2 + N_OUT * 4 + enc_w * 2) + n_mlp_params * 4,
         # grid backward: positions + dL/denc + read-modify-write of the 8 corners = 12 + 64 + 2 * 512 B per sample.
         # The bucketed implementation runs it as two kernels; the figure is apportioned, not re-derived from what they
         # move: the record-scatter kernel carries the inputs and the read half of the RMW, the owner kernel the write half.

@@ -11,6 +11,7 @@ STAGES = {  # stage -> [(kernel-name fragment, reads are wide streams?)]
     "mlp_forward": [("k_mlp_forward", True)],
     "loss": [("k_loss", True)],
     "mlp_backward": [("k_mlp_transpose_weights", True), ("k_mlp_backward", True), ("k_mlp_finalize_gradients", True)],
+    "mlp_train_fused": [("k_mlp_transpose_weights", True), ("k_mlp_train", True), ("k_mlp_finalize_gradients", True)],
     "grid_backward_scatter": [("k_grid_bucket_scatter", False)],
     "grid_backward": [("k_grid_backward_sliced", True)],
     "grid_backward_overflow": [("k_grid_bucket_overflow", False)],

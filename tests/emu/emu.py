@@ -162,6 +162,24 @@ def mlp_backward(om, params_h, input_soa_h, hidden, dL_doutput_h, want_dinput=Tr
     return grads, dinput
 
 
+def mlp_train(om, params_h, input_soa_h, loss_type, target, dims, loss_scale=128.0, data_pdf=None, n_total=None, want_dinput=True):
+    """Fused forward + loss + backward (k_mlp_train).  Returns (output, dL_doutput, dL_dinput, grads, loss_sum) or None if unsupported."""
+    n = input_soa_h.shape[1]
+    out = np.zeros((n, om.padded_out), dtype=np.uint16)
+    dy = np.zeros((n, om.padded_out), dtype=np.uint16)
+    dinput = np.zeros((om.in_width, n), dtype=np.uint16) if want_dinput else None
+    grads = np.full(om.n_params, 0x3C00, dtype=np.uint16)
+    s = np.zeros(1, dtype=np.float32)
+    m = mlp_meta(om)
+    r = lib().emu_mlp_train(C.byref(m), C.c_uint32(n), _p(params_h), _p(np.ascontiguousarray(input_soa_h)), C.c_int(loss_type),
+                            _p(np.ascontiguousarray(target, dtype=np.float32)), _p(data_pdf), C.c_uint32(dims), C.c_float(loss_scale),
+                            C.c_uint32(n_total if n_total is not None else n * dims), _p(out), _p(dy), _p(dinput), _p(grads), _p(s))
+    if r == 2:
+        return None
+    assert r == 0
+    return out, dy, dinput, grads, float(s[0])
+
+
 def loss(loss_type, prediction_h, target, dims, loss_scale=128.0, data_pdf=None, n_total=None):
     prediction_h = np.ascontiguousarray(prediction_h, dtype=np.uint16)
     n, stride = prediction_h.shape

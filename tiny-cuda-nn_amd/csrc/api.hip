@@ -168,13 +168,14 @@ enum Stage : int {
 	STAGE_MLP_FWD,
 	STAGE_LOSS,
 	STAGE_MLP_BWD,       // weight transpose + fused backward + finalize
+	STAGE_MLP_TRAIN,     // training_step fast path: weight transpose + forward/loss/backward in one kernel + finalize
 	STAGE_GRID_BWD_SCATTER,     // bucketed backward pass A: derive the corner records once, bin them by owning slice
 	STAGE_GRID_BWD,             // pass B (owners accumulate + store) -- or the whole backward in the sliced / atomic modes
 	STAGE_GRID_BWD_OVERFLOW,    // pass C: queue overflow through global atomics (normally empty)
 	STAGE_ADAM,
 	N_STAGES
 };
-static const char* const STAGE_NAMES[N_STAGES] = {"grid_forward", "mlp_forward", "loss", "mlp_backward", "grid_backward_scatter", "grid_backward", "grid_backward_overflow", "adam"};
+static const char* const STAGE_NAMES[N_STAGES] = {"grid_forward", "mlp_forward", "loss", "mlp_backward", "mlp_train_fused", "grid_backward_scatter", "grid_backward", "grid_backward_overflow", "adam"};
 
 struct Profiler {
 	int only_stage = -1;  // -1: all stages
@@ -597,12 +598,19 @@ static void model_forward(hipStream_t stream, const Model& md, uint32_t n, const
 	mlp_forward(stream, md.net.mlp, n, params, enc.as<half_t>(), hidden, output);
 }
 
+static void encoding_backward(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const half_t* dL_denc,
+                              uint32_t stride_k, uint32_t stride_i, half_t* dL_dparams, bool want_grads, bool accumulate, const float* input,
+                              uint32_t lds_level_budget);
+
 // NetworkWithInputEncoding::backward_impl (:83-113) / GridEncodingTemplated::backward_impl (grid.h:817-908)
 static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const half_t* dL_doutput,
                            half_t* dL_dparams, const float* input, const half_t* params, int gradient_mode, uint32_t lds_level_budget) {
 	check_batch(n);
 	if (n == 0) return;
 	if (ctx.n != n) throw std::runtime_error("backward: batch size does not match the forward context");
+	if (md.has_network && !ctx.hidden.ptr) {
+		throw std::runtime_error("backward: this context comes from the fused training_step and holds no saved activations; use forward() + backward()");
+	}
 	const bool want_grads = gradient_mode != TCNN_GRADIENT_IGNORE && dL_dparams != nullptr;
 	const bool accumulate = gradient_mode == TCNN_GRADIENT_ACCUMULATE;
 	const EncodingDesc& e = md.enc;
@@ -629,6 +637,14 @@ static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx
 		stride_i = 1u;
 	}
 
+	encoding_backward(stream, md, ctx, n, dL_dinput, dL_denc, stride_k, stride_i, dL_dparams, want_grads, accumulate, input, lds_level_budget);
+}
+
+// the encoding's share of the backward pass: dL_denc has element (feature k, sample i) at [k * stride_k + i * stride_i]
+static void encoding_backward(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const half_t* dL_denc,
+                              uint32_t stride_k, uint32_t stride_i, half_t* dL_dparams, bool want_grads, bool accumulate, const float* input,
+                              uint32_t lds_level_budget) {
+	const EncodingDesc& e = md.enc;
 	if (e.is_grid) {
 		GridIO io = {input, md.n_input_dims, 1u, n, stride_k, stride_i};
 		if (want_grads && e.n_params > 0) {
@@ -1013,11 +1029,84 @@ int tcnn_trainer_optimizer_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream
 	TCNN_API_END
 }
 
+// training_step fast path: encoding forward, ONE kernel for the network's forward + loss + backward, encoding backward.
+// Same results as forward() + backward() (bit-identical, tests/test_emu_kernels.py); the returned context carries the
+// prediction, dL_doutput and the loss, but no hidden activations.  TCNN_FUSED_MLP_TRAINING=0 disables it.
+static const bool g_fused_mlp_training = !(getenv("TCNN_FUSED_MLP_TRAINING") && std::string(getenv("TCNN_FUSED_MLP_TRAINING")) == "0");
+
+static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale, uint32_t n, const float* input, const float* target,
+                               const float* data_pdf, float* dL_dinput, int gradient_mode, tcnn_train_context_t** ctx_out) {
+	TCNN_API_BEGIN
+	ProfilerGuard pg(tm->profiler.get());
+	const Model& md = tm->md;
+	check_batch(n);
+	auto c = std::make_unique<tcnn_train_context>();
+	c->n = n;
+	c->stream = stream;
+	ForwardCtx& fc = c->model_ctx;
+	fc.stream = stream;
+	fc.n = n;
+	const uint32_t padded = md.padded_output_width();
+	const bool want_grads = gradient_mode != TCNN_GRADIENT_IGNORE;
+	const bool accumulate = gradient_mode == TCNN_GRADIENT_ACCUMULATE;
+	const EncodingDesc& e = md.enc;
+	c->output = Scratch(stream, (size_t)padded * n * sizeof(half_t));
+	c->dL_doutput = Scratch(stream, (size_t)padded * n * sizeof(half_t));
+	c->dL_doutput_ptr = c->dL_doutput.as<half_t>();
+	const uint64_t n_total = (tm->global_batch ? tm->global_batch : (uint64_t)n) * md.output_width();
+	if (n_total > 0xFFFFFFFFull) throw std::runtime_error("Trainer::forward: batch too large");
+	if (n == 0) {
+		*ctx_out = c.release();
+		return TCNN_OK;
+	}
+
+	float* dy_dx = nullptr;
+	if (dL_dinput && e.is_grid) {
+		fc.dy_dx = Scratch(stream, (size_t)e.n_output_dims * n * md.n_input_dims * sizeof(float));
+		dy_dx = fc.dy_dx.as<float>();
+	}
+	fc.enc = Scratch(stream, (size_t)e.padded_output_width * n * sizeof(half_t));
+	encoding_forward(stream, md, n, input, tm->params + md.n_mlp_params(), fc.enc.as<half_t>(), /*soa=*/true, dy_dx);
+
+	const bool need_denc = (want_grads && e.n_params > 0) || dL_dinput;
+	Scratch denc;
+	{
+		ProfScope prof(stream, STAGE_MLP_TRAIN);
+		Scratch params_t(stream, md.n_mlp_params() * sizeof(half_t));
+		mlp_transpose_weights(stream, md.net.mlp, tm->params, params_t.as<half_t>());
+		const uint32_t n_partials = mlp_backward_n_partials(md.net.mlp, n);
+		Scratch partials;
+		if (want_grads) partials = Scratch(stream, (size_t)n_partials * md.n_mlp_params() * sizeof(float));
+		if (need_denc) denc = Scratch(stream, (size_t)e.padded_output_width * n * sizeof(half_t));
+		c->n_block_sums = n_partials;
+		c->block_sums = Scratch(stream, (size_t)n_partials * sizeof(float));
+		const MlpLossArgs la = {tm->loss, target, data_pdf, md.output_width(), loss_scale, (uint32_t)n_total};
+		mlp_train(stream, md.net.mlp, n, tm->params, params_t.as<half_t>(), fc.enc.as<half_t>(), la, c->output.as<half_t>(), c->dL_doutput.as<half_t>(),
+		          need_denc ? denc.as<half_t>() : nullptr, want_grads ? partials.as<float>() : nullptr, c->block_sums.as<float>());
+		if (want_grads) mlp_finalize_gradients(stream, (uint32_t)md.n_mlp_params(), n_partials, partials.as<float>(), tm->grads, accumulate);
+	}
+	if (need_denc) {
+		encoding_backward(stream, md, fc, n, dL_dinput, denc.as<half_t>(), n, 1u, tm->grads, want_grads, accumulate, input, tm->lds_level_budget);
+	}
+	*ctx_out = c.release();
+	TCNN_API_END
+}
+
 int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream, uint32_t n, const float* input, const float* target,
                                const float* data_pdf, int run_optimizer, float* dL_dinput, int use_inference_params, int gradient_mode,
                                const void* external_dL_dy, tcnn_train_context_t** ctx_out) {
 	const float loss_scale = LOSS_SCALE_FP16;  // trainer.h:265
 	tcnn_train_context_t* ctx = nullptr;
+	if (g_fused_mlp_training && !external_dL_dy && target && tm->md.has_network && mlp_train_supported(tm->md.net.mlp)) {
+		int r = training_step_fused(tm, (hipStream_t)stream, loss_scale, n, input, target, data_pdf, dL_dinput, gradient_mode, &ctx);
+		if (r == TCNN_OK && run_optimizer) r = tcnn_trainer_optimizer_step(tm, stream, loss_scale);
+		if (ctx_out && r == TCNN_OK) {
+			*ctx_out = ctx;
+		} else {
+			delete ctx;
+		}
+		return r;
+	}
 	int r = tcnn_trainer_forward(tm, stream, loss_scale, n, input, target, data_pdf, use_inference_params, dL_dinput != nullptr, external_dL_dy, &ctx);
 	if (r == TCNN_OK) r = tcnn_trainer_backward(tm, stream, ctx, n, input, dL_dinput, use_inference_params, gradient_mode);
 	if (r == TCNN_OK && run_optimizer) r = tcnn_trainer_optimizer_step(tm, stream, loss_scale);

@@ -1,11 +1,12 @@
 // elementwise_kernels.h -- streaming (HBM-bound) kernels of the training step: loss, Adam, casts,
 // PCG32 fills, reductions, identity encoding.  Reference lines restated are cited per function.
 #pragma once
+#include "loss_device.h"
 #include "tcnn_device.h"
 
 namespace tcnn_hip {
 
-enum class LossType : int { L2 = 0, RelativeL2 = 1 };
+// LossType lives in loss_device.h (shared with the fused MLP training kernel)
 
 struct Pcg32 {  // reference dependencies/pcg32/pcg32.h:40-170
 	uint64_t state, inc;

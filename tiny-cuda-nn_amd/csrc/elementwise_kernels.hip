@@ -109,18 +109,9 @@ __global__ void __launch_bounds__(EW_THREADS) k_loss(uint32_t n_groups, uint32_t
 			const uint32_t target_idx = inter * dims + intra;
 			const float prediction = (float)p8[j];
 			const float pdf = data_pdf ? data_pdf[target_idx] : 1.0f;
-			const float difference = prediction - targets[target_idx];
-			float value, gradient;
-			if (LOSS == LossType::RelativeL2) {
-				const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
-				value = difference * difference / prediction_sq_plus_epsilon / pdf / n_total;
-				gradient = 2 * difference / prediction_sq_plus_epsilon / pdf;
-			} else {
-				value = difference * difference / pdf / n_total;
-				gradient = 2 * difference / pdf;
-			}
+			float value;
+			g8[j] = loss_element<LOSS>(prediction, targets[target_idx], pdf, n_total, loss_scale, value);
 			v8[j] = value;
-			g8[j] = to_half_rn(loss_scale * gradient / n_total);
 			local_sum += value;
 		}
 		*(h8*)(gradients + e0) = g8;

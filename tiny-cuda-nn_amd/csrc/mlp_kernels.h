@@ -20,6 +20,7 @@
 //   output / dL_doutput: half, sample-major  [n][16]         (the reference's CM padded output)
 //   hidden (saved)    : half, [n_hidden][n][WIDTH] post-activation (fully_fused_mlp.cu:841-854)
 #pragma once
+#include "loss_device.h"
 #include "tcnn_device.h"
 
 namespace tcnn_hip {
@@ -52,6 +53,22 @@ uint32_t mlp_backward_n_partials(const MlpMeta& m, uint32_t n);
 // [mlp_backward_n_partials][n_params] or null (GradientMode::Ignore).
 void mlp_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params_t, const half_t* input, const half_t* hidden,
                   const half_t* dL_doutput, half_t* dL_dinput, float* partials);
+
+// Fused training pass of Trainer::training_step (trainer.h:254-357): forward + loss + backward per sample tile in one
+// kernel -- the hidden activations stay in LDS, prediction / dL_doutput are written for the caller's ForwardContext
+// (either may be null), block_sums receives mlp_backward_n_partials() partial loss sums.  Bit-identical to
+// mlp_forward -> loss_evaluate -> mlp_backward.  Widths 16/32/64, up to 4 hidden layers (mlp_train_supported).
+struct MlpLossArgs {
+	LossType type;
+	const float* targets;   // fp32 [n][dims]
+	const float* data_pdf;  // nullable, like targets
+	uint32_t dims;          // unpadded output width
+	float loss_scale;
+	uint32_t n_total;       // elements the mean runs over (global batch x dims)
+};
+bool mlp_train_supported(const MlpMeta& m);
+void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
+               const MlpLossArgs& loss, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums);
 
 // grads[i] = (accumulate ? grads[i] : 0) + sum_b partials[b][i]   (fully_fused_mlp.cu:770 beta)
 void mlp_finalize_gradients(hipStream_t stream, uint32_t n_params, uint32_t n_partials, const float* partials, half_t* grads, bool accumulate);

@@ -7,6 +7,7 @@
 //             "feature-major" tile[k][SP]   (SP = S + 8)
 #include "mlp_kernels.h"
 
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 
@@ -379,6 +380,331 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 	}
 }
 
+// =============================================================================================
+// fused training pass: forward + loss + backward of one sample tile without leaving the CU.
+// What Trainer::training_step needs from the network (trainer.h:254-357) in ONE kernel: the hidden activations
+// never travel to HBM (2 x 64 MB at the headline config), the prediction / dL_doutput are written once for the
+// caller's ForwardContext, the encoded input is read once.  Same MFMA fragments and the same rounding points as
+// k_mlp_forward -> k_loss -> k_mlp_backward, so the results are bit-identical to the unfused path.
+// =============================================================================================
+template <uint32_t WIDTH, uint32_t HM, LossType LOSS>
+__global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
+                                                                const half_t* __restrict__ params_t, const half_t* __restrict__ input,
+                                                                const MlpLossArgs la, half_t* __restrict__ output, half_t* __restrict__ dL_doutput,
+                                                                half_t* __restrict__ dL_dinput, float* __restrict__ partials,
+                                                                float* __restrict__ block_sums) {
+	constexpr uint32_t NW = WIDTH / 16, THREADS = NW * 64, S = MLP_BWD_TILE, NT = S / 16, NTP = S / 32;
+	constexpr uint32_t SP = S + 8, LDW = WIDTH + 8, NB = WIDTH / 16, MAX_INB = MLP_MAX_IN_WIDTH / 16, LDY = 16 + 8;
+	TCNN_DYN_LDS(lds_raw);
+	__shared__ float red[THREADS];
+	const uint32_t IN = m.in_width, nb_in = IN / 16, ldi = IN + 8;
+	half_t* xT = (half_t*)lds_raw;                 // [IN][SP]           network input, feature-major (dW_in operand)
+	half_t* hT = xT + IN * SP;                     // [HM+1][WIDTH][SP]  forward activations, feature-major (dW operands, ReLU masks)
+	half_t* buf0 = hT + (HM + 1) * WIDTH * SP;     // [S][LDW]           sample-major ping-pong: forward activations, then dL/d(pre-activation)
+	half_t* buf1 = buf0 + S * LDW;
+	half_t* dyT = buf1 + S * LDW;                  // [16][SP]           dL/dy, feature-major (dW_out operand)
+	half_t* dys = dyT + 16 * SP;                   // [S][LDY]           dL/dy, sample-major (dA_last operand)
+	half_t* xs = dys + S * LDY;                    // [S][ldi]           network input, sample-major (first layer operand) ...
+	half_t* dxT = xs;                              // [IN][SP]           ... later dL/dinput, feature-major (the two never overlap in time)
+
+	const half_t* wt_in = params_t;                             // [IN][WIDTH]
+	const half_t* wt_hid = wt_in + (size_t)IN * WIDTH;          // HM x [WIDTH][WIDTH]
+	const half_t* wt_out = wt_hid + (size_t)HM * WIDTH * WIDTH; // [WIDTH][16]
+
+	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
+	const bool relu = m.activation == (uint32_t)Activation::ReLU;
+	const bool want_grads = partials != nullptr, want_dx = dL_dinput != nullptr;
+	const uint32_t n_tiles = n / S;
+	const float n_total = (float)la.n_total;
+	float loss_sum = 0.0f;
+
+	f4 accI[MAX_INB];
+	f4 accH[HM > 0 ? HM : 1][NB];
+	f4 accO = zero4();
+#pragma unroll
+	for (uint32_t b = 0; b < MAX_INB; ++b) accI[b] = zero4();
+#pragma unroll
+	for (uint32_t j = 0; j < (HM > 0 ? HM : 1); ++j)
+#pragma unroll
+		for (uint32_t b = 0; b < NB; ++b) accH[j][b] = zero4();
+
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		// ---- stage the input tile in both layouts (consecutive lanes = consecutive features: conflict-free transposition)
+		for (uint32_t c = tid; c < IN * (S / 8); c += THREADS) {
+			const uint32_t k = c % IN, cc = c / IN;
+			const h8 v = *(const h8*)(input + (size_t)k * n + (size_t)tile * S + 8 * cc);
+			*(h8*)(xT + k * SP + 8 * cc) = v;
+#pragma unroll
+			for (uint32_t j = 0; j < 8; ++j) xs[(8 * cc + j) * ldi + k] = v[j];
+		}
+		__syncthreads();
+
+		// ================= forward =================
+		{
+			const half_t* cur = xs;
+			uint32_t ldc = ldi;
+			half_t* nxt = buf0;
+			const half_t* Wl = params;
+			uint32_t K = IN;
+#pragma unroll
+			for (uint32_t layer = 0; layer <= HM; ++layer) {
+				f4 acc[NT];
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) acc[t] = zero4();
+				const half_t* wrow = Wl + (size_t)(16 * w + lr) * K;
+				for (uint32_t kb = 0; kb < K / 32; ++kb) {
+					const h8 a = *(const h8*)(wrow + 32 * kb + 8 * g);
+#pragma unroll
+					for (uint32_t t = 0; t < NT; ++t) {
+						const h8 b = *(const h8*)(cur + (16 * t + lr) * ldc + 32 * kb + 8 * g);
+						acc[t] = mfma_16x16x32(a, b, acc[t]);
+					}
+				}
+				if (K & 16u) {
+					const uint32_t k0 = K & ~31u;
+					const h4 a = *(const h4*)(wrow + k0 + 4 * g);
+#pragma unroll
+					for (uint32_t t = 0; t < NT; ++t) {
+						const h4 b = *(const h4*)(cur + (16 * t + lr) * ldc + k0 + 4 * g);
+						acc[t] = mfma_16x16x16(a, b, acc[t]);
+					}
+				}
+				// accumulator (neuron 16w+4g+r, sample 16t+lr) -> activation -> both layouts
+				half_t* hl = hT + layer * WIDTH * SP;
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) {
+					h4 o;
+#pragma unroll
+					for (uint32_t r = 0; r < 4; ++r) {
+						float v = acc[t][r];
+						if (relu) v = v > 0.0f ? v : 0.0f;
+						o[r] = (half_t)v;
+						hl[(16 * w + 4 * g + r) * SP + 16 * t + lr] = o[r];
+					}
+					*(h4*)(nxt + (16 * t + lr) * LDW + 16 * w + 4 * g) = o;
+				}
+				__syncthreads();
+				cur = nxt;
+				ldc = LDW;
+				nxt = nxt == buf0 ? buf1 : buf0;
+				Wl += (size_t)WIDTH * K;
+				K = WIDTH;
+			}
+			// ---- output layer + loss: (output 4g+r, sample 16t+lr)
+			for (uint32_t t = w; t < NT; t += NW) {
+				f4 acc = zero4();
+				const half_t* wrow = Wl + (size_t)lr * WIDTH;
+#pragma unroll
+				for (uint32_t kb = 0; kb < WIDTH / 32; ++kb) {
+					const h8 a = *(const h8*)(wrow + 32 * kb + 8 * g);
+					const h8 b = *(const h8*)(cur + (16 * t + lr) * LDW + 32 * kb + 8 * g);
+					acc = mfma_16x16x32(a, b, acc);
+				}
+				if constexpr (WIDTH % 32 != 0) {
+					constexpr uint32_t k0 = WIDTH & ~31u;
+					const h4 a = *(const h4*)(wrow + k0 + 4 * g);
+					const h4 b = *(const h4*)(cur + (16 * t + lr) * LDW + k0 + 4 * g);
+					acc = mfma_16x16x16(a, b, acc);
+				}
+				const h4 o = h4{(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};
+				const size_t i = (size_t)tile * S + 16 * t + lr;
+				h4 gy;
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) {
+					const uint32_t dim = 4 * g + r;
+					gy[r] = (half_t)0.0f;
+					if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
+						const size_t target_idx = i * la.dims + dim;
+						const float pdf = la.data_pdf ? la.data_pdf[target_idx] : 1.0f;
+						float value;
+						gy[r] = loss_element<LOSS>((float)o[r], la.targets[target_idx], pdf, n_total, la.loss_scale, value);
+						loss_sum += value;
+					}
+					dyT[dim * SP + 16 * t + lr] = gy[r];
+				}
+				*(h4*)(dys + (16 * t + lr) * LDY + 4 * g) = gy;
+				if (output) *(h4*)(output + i * 16 + 4 * g) = o;
+				if (dL_doutput) *(h4*)(dL_doutput + i * 16 + 4 * g) = gy;
+			}
+			__syncthreads();
+		}
+
+		// ================= backward (k_mlp_backward steps B-D on the LDS-resident tiles) =================
+		half_t* dact0 = buf0;
+		half_t* dact1 = buf1;
+		h4 da[NT];
+		{
+			const half_t* hlast = hT + HM * WIDTH * SP;
+			const h4 bw = *(const h4*)(wt_out + (size_t)(16 * w + lr) * 16 + 4 * g);
+#pragma unroll
+			for (uint32_t t = 0; t < NT; ++t) {
+				const h4 a = *(const h4*)(dys + (16 * t + lr) * LDY + 4 * g);
+				const f4 acc = mfma_16x16x16(a, bw, zero4());
+				const h4 hv = *(const h4*)(hlast + (16 * w + lr) * SP + 16 * t + 4 * g);
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) {
+					float v = acc[r];
+					if (relu && !(hv[r] > (half_t)0.0f)) v = 0.0f;
+					da[t][r] = (half_t)v;
+					dact0[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
+				}
+			}
+			if (want_grads) {
+#pragma unroll
+				for (uint32_t tp = 0; tp < NTP; ++tp) {
+					const h8 a = *(const h8*)(hlast + (16 * w + lr) * SP + 32 * tp + 8 * g);
+					const h8 b = *(const h8*)(dyT + lr * SP + 32 * tp + 8 * g);
+					accO = mfma_16x16x32(a, b, accO);
+				}
+			}
+		}
+		__syncthreads();
+
+		half_t* cur = dact0;
+		half_t* nxt = dact1;
+#pragma unroll
+		for (int j = (int)HM - 1; j >= 0; --j) {
+			const half_t* hj = hT + j * WIDTH * SP;
+			if (want_grads) {
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b) {
+#pragma unroll
+					for (uint32_t tp = 0; tp < NTP; ++tp) {
+						const h8 a = pack8(da[2 * tp], da[2 * tp + 1]);
+						const h4 b0 = *(const h4*)(hj + (16 * b + lr) * SP + 32 * tp + 4 * g);
+						const h4 b1 = *(const h4*)(hj + (16 * b + lr) * SP + 32 * tp + 16 + 4 * g);
+						accH[j][b] = mfma_16x16x32(a, pack8(b0, b1), accH[j][b]);
+					}
+				}
+			}
+			const half_t* wt = wt_hid + (size_t)j * WIDTH * WIDTH + (size_t)(16 * w + lr) * WIDTH;
+			f4 acc[NT];
+#pragma unroll
+			for (uint32_t t = 0; t < NT; ++t) acc[t] = zero4();
+#pragma unroll
+			for (uint32_t kb = 0; kb < WIDTH / 32; ++kb) {
+				const h8 bw = *(const h8*)(wt + 32 * kb + 8 * g);
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) {
+					const h8 a = *(const h8*)(cur + (16 * t + lr) * LDW + 32 * kb + 8 * g);
+					acc[t] = mfma_16x16x32(a, bw, acc[t]);
+				}
+			}
+			if constexpr (WIDTH % 32 != 0) {
+				constexpr uint32_t k0 = WIDTH & ~31u;
+				const h4 bw = *(const h4*)(wt + k0 + 4 * g);
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) {
+					const h4 a = *(const h4*)(cur + (16 * t + lr) * LDW + k0 + 4 * g);
+					acc[t] = mfma_16x16x16(a, bw, acc[t]);
+				}
+			}
+#pragma unroll
+			for (uint32_t t = 0; t < NT; ++t) {
+				const h4 hv = *(const h4*)(hj + (16 * w + lr) * SP + 16 * t + 4 * g);
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) {
+					float v = acc[t][r];
+					if (relu && !(hv[r] > (half_t)0.0f)) v = 0.0f;
+					da[t][r] = (half_t)v;
+					nxt[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
+				}
+			}
+			__syncthreads();
+			half_t* tmp = cur;
+			cur = nxt;
+			nxt = tmp;
+		}
+
+		if (want_grads) {
+#pragma unroll
+			for (uint32_t b = 0; b < MAX_INB; ++b) {
+				if (b < nb_in) {
+#pragma unroll
+					for (uint32_t tp = 0; tp < NTP; ++tp) {
+						const h8 a = pack8(da[2 * tp], da[2 * tp + 1]);
+						const h4 b0 = *(const h4*)(xT + (16 * b + lr) * SP + 32 * tp + 4 * g);
+						const h4 b1 = *(const h4*)(xT + (16 * b + lr) * SP + 32 * tp + 16 + 4 * g);
+						accI[b] = mfma_16x16x32(a, pack8(b0, b1), accI[b]);
+					}
+				}
+			}
+		}
+		if (want_dx) {
+			for (uint32_t sl = w; sl < nb_in; sl += NW) {
+				const half_t* wt = wt_in + (size_t)(16 * sl + lr) * WIDTH;
+				f4 acc[NT];
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) acc[t] = zero4();
+#pragma unroll
+				for (uint32_t kb = 0; kb < WIDTH / 32; ++kb) {
+					const h8 bw = *(const h8*)(wt + 32 * kb + 8 * g);
+#pragma unroll
+					for (uint32_t t = 0; t < NT; ++t) {
+						const h8 a = *(const h8*)(cur + (16 * t + lr) * LDW + 32 * kb + 8 * g);
+						acc[t] = mfma_16x16x32(a, bw, acc[t]);
+					}
+				}
+				if constexpr (WIDTH % 32 != 0) {
+					constexpr uint32_t k0 = WIDTH & ~31u;
+					const h4 bw = *(const h4*)(wt + k0 + 4 * g);
+#pragma unroll
+					for (uint32_t t = 0; t < NT; ++t) {
+						const h4 a = *(const h4*)(cur + (16 * t + lr) * LDW + k0 + 4 * g);
+						acc[t] = mfma_16x16x16(a, bw, acc[t]);
+					}
+				}
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) {
+					const h4 o = h4{(half_t)acc[t][0], (half_t)acc[t][1], (half_t)acc[t][2], (half_t)acc[t][3]};
+					*(h4*)(dxT + (16 * sl + lr) * SP + 16 * t + 4 * g) = o;
+				}
+			}
+		}
+		__syncthreads();
+		if (want_dx) {
+			for (uint32_t c = tid; c < IN * (S / 8); c += THREADS) {
+				const uint32_t k = c / (S / 8), cc = c % (S / 8);
+				*(h8*)(dL_dinput + (size_t)k * n + (size_t)tile * S + 8 * cc) = *(const h8*)(dxT + k * SP + 8 * cc);
+			}
+		}
+		__syncthreads();
+	}
+
+	// ---- this workgroup's share of the loss
+	if (block_sums) {
+		red[tid] = loss_sum;
+		__syncthreads();
+		for (uint32_t k = THREADS / 2; k > 0; k >>= 1) {
+			if (tid < k) red[tid] += red[tid + k];
+			__syncthreads();
+		}
+		if (tid == 0) block_sums[blockIdx.x] = red[0];
+	}
+
+	// ---- fp32 partial weight gradients of this workgroup, same layout as the parameters -------
+	if (want_grads) {
+		float* P = partials + (size_t)blockIdx.x * m.n_params();
+#pragma unroll
+		for (uint32_t b = 0; b < MAX_INB; ++b) {
+			if (b < nb_in) {
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) P[(size_t)(16 * w + 4 * g + r) * IN + 16 * b + lr] = accI[b][r];
+			}
+		}
+		const size_t off_hid = (size_t)WIDTH * IN;
+#pragma unroll
+		for (uint32_t j = 0; j < HM; ++j)
+#pragma unroll
+			for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) P[off_hid + (size_t)j * WIDTH * WIDTH + (size_t)(16 * w + 4 * g + r) * WIDTH + 16 * b + lr] = accH[j][b][r];
+		const size_t off_out = off_hid + (size_t)HM * WIDTH * WIDTH;
+#pragma unroll
+		for (uint32_t r = 0; r < 4; ++r) P[off_out + (size_t)lr * WIDTH + 16 * w + 4 * g + r] = accO[r];
+	}
+}
+
 constexpr uint32_t FINALIZE_GROUPS = 32;  // slab groups per block (x 32 parameters = 1024 threads)
 
 __global__ void __launch_bounds__(32 * FINALIZE_GROUPS) k_mlp_finalize_gradients(uint32_t n_params, uint32_t n_partials,
@@ -500,6 +826,52 @@ void mlp_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t
 		case 32: dispatch_backward<32>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
 		case 64: dispatch_backward<64>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
 		case 128: dispatch_backward<128>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
+	}
+}
+
+template <uint32_t WIDTH, uint32_t HM>
+static void launch_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
+                         const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
+	constexpr uint32_t S = MLP_BWD_TILE, SP = S + 8, LDW = WIDTH + 8, LDY = 16 + 8;
+	const uint32_t in_region = std::max(S * (m.in_width + 8), m.in_width * SP);  // xs, later dxT
+	const uint32_t halves = m.in_width * SP + (HM + 1) * WIDTH * SP + 2 * S * LDW + 16 * SP + S * LDY + in_region;
+	const uint32_t lds_bytes = halves * (uint32_t)sizeof(half_t);
+	const uint32_t blocks = mlp_backward_n_partials(m, n);
+#define TCNN_TRAIN_LAUNCH(LOSS_)                                                                                                                  \
+	TCNN_SET_MAX_DYN_LDS((k_mlp_train<WIDTH, HM, LOSS_>), lds_bytes);                                                                             \
+	TCNN_LAUNCH((k_mlp_train<WIDTH, HM, LOSS_>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params, params_t, input, la, output, \
+	            dL_doutput, dL_dinput, partials, block_sums);
+	if (la.type == LossType::RelativeL2) {
+		TCNN_TRAIN_LAUNCH(LossType::RelativeL2)
+	} else {
+		TCNN_TRAIN_LAUNCH(LossType::L2)
+	}
+#undef TCNN_TRAIN_LAUNCH
+}
+
+template <uint32_t WIDTH>
+static void dispatch_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
+                           const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
+	switch (m.n_hidden_matmuls) {
+		case 0: launch_train<WIDTH, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
+		case 1: launch_train<WIDTH, 1>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
+		case 2: launch_train<WIDTH, 2>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
+		case 3: launch_train<WIDTH, 3>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
+		default: throw std::runtime_error("mlp_train: unsupported depth (check mlp_train_supported first)");
+	}
+}
+
+bool mlp_train_supported(const MlpMeta& m) { return m.n_hidden_matmuls <= MLP_MAX_HIDDEN_MATMULS_TRAIN && m.width <= 64; }
+
+void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
+               const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
+	check_meta(m, n);
+	if (n == 0) return;
+	if (!mlp_train_supported(m)) throw std::runtime_error("mlp_train: unsupported network shape (check mlp_train_supported first)");
+	switch (m.width) {
+		case 16: dispatch_train<16>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
+		case 32: dispatch_train<32>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
+		case 64: dispatch_train<64>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 	}
 }
 

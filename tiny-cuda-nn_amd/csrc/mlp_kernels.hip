@@ -428,14 +428,51 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 #pragma unroll
 		for (uint32_t b = 0; b < NB; ++b) accH[j][b] = zero4();
 
+	// The first PF input chunks of a thread are fetched one tile ahead (registers), and the loss targets of a tile are
+	// requested before its forward pass: neither global round trip sits on the tile's critical path.
+	constexpr uint32_t PF = 2, NTW = (NT + NW - 1) / NW;
+	const uint32_t n_chunks = IN * (S / 8);
+	auto load_chunk = [&](uint32_t tile, uint32_t c) {
+		const uint32_t k = c % IN, cc = c / IN;
+		return *(const h8*)(input + (size_t)k * n + (size_t)tile * S + 8 * cc);
+	};
+	h8 pf[PF];
+#pragma unroll
+	for (uint32_t u = 0; u < PF; ++u) {
+		const uint32_t c = tid + u * THREADS;
+		if (blockIdx.x < n_tiles && c < n_chunks) pf[u] = load_chunk(blockIdx.x, c);
+	}
+
 	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		// ---- stage the input tile in both layouts (consecutive lanes = consecutive features: conflict-free transposition)
-		for (uint32_t c = tid; c < IN * (S / 8); c += THREADS) {
+		for (uint32_t c = tid, u = 0; c < n_chunks; c += THREADS, ++u) {
 			const uint32_t k = c % IN, cc = c / IN;
-			const h8 v = *(const h8*)(input + (size_t)k * n + (size_t)tile * S + 8 * cc);
+			const h8 v = u < PF ? pf[u < PF ? u : 0] : load_chunk(tile, c);
 			*(h8*)(xT + k * SP + 8 * cc) = v;
 #pragma unroll
 			for (uint32_t j = 0; j < 8; ++j) xs[(8 * cc + j) * ldi + k] = v[j];
+		}
+		{
+			const uint32_t next = tile + gridDim.x;
+#pragma unroll
+			for (uint32_t u = 0; u < PF; ++u) {
+				const uint32_t c = tid + u * THREADS;
+				if (next < n_tiles && c < n_chunks) pf[u] = load_chunk(next, c);
+			}
+		}
+		// this lane's targets (output 4g+r of sample 16t+lr for its output-layer tiles t = w, w + NW, ...)
+		float tgt[NTW][4], pdf[NTW][4];
+#pragma unroll
+		for (uint32_t q = 0; q < NTW; ++q) {
+			const uint32_t t = w + q * NW;
+#pragma unroll
+			for (uint32_t r = 0; r < 4; ++r) {
+				const uint32_t dim = 4 * g + r;
+				const bool live = t < NT && dim < la.dims;
+				const size_t target_idx = ((size_t)tile * S + 16 * t + lr) * la.dims + dim;
+				tgt[q][r] = live ? la.targets[target_idx] : 0.0f;
+				pdf[q][r] = live && la.data_pdf ? la.data_pdf[target_idx] : 1.0f;
+			}
 		}
 		__syncthreads();
 
@@ -491,7 +528,10 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 				K = WIDTH;
 			}
 			// ---- output layer + loss: (output 4g+r, sample 16t+lr)
-			for (uint32_t t = w; t < NT; t += NW) {
+#pragma unroll
+			for (uint32_t q = 0; q < NTW; ++q) {
+				const uint32_t t = w + q * NW;
+				if (t >= NT) break;
 				f4 acc = zero4();
 				const half_t* wrow = Wl + (size_t)lr * WIDTH;
 #pragma unroll
@@ -514,10 +554,8 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 					const uint32_t dim = 4 * g + r;
 					gy[r] = (half_t)0.0f;
 					if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
-						const size_t target_idx = i * la.dims + dim;
-						const float pdf = la.data_pdf ? la.data_pdf[target_idx] : 1.0f;
 						float value;
-						gy[r] = loss_element<LOSS>((float)o[r], la.targets[target_idx], pdf, n_total, la.loss_scale, value);
+						gy[r] = loss_element<LOSS>((float)o[r], tgt[q][r], pdf[q][r], n_total, la.loss_scale, value);
 						loss_sum += value;
 					}
 					dyT[dim * SP + 16 * t + lr] = gy[r];

@@ -17,7 +17,8 @@ MAX_LEVELS = 128
 
 GRID_HASH, GRID_DENSE, GRID_TILED = 0, 1, 2
 INTERP_NEAREST, INTERP_LINEAR, INTERP_SMOOTHSTEP = 0, 1, 2
-ACT_NONE, ACT_RELU = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_EXPONENTIAL, ACT_SIGMOID, ACT_SQUAREPLUS, ACT_SOFTPLUS, ACT_TANH = range(8)
+ACTIVATION_NAMES = ["None", "ReLU", "LeakyReLU", "Exponential", "Sigmoid", "Squareplus", "Softplus", "Tanh"]
 LOSS_L2, LOSS_RELATIVE_L2 = 0, 1
 
 

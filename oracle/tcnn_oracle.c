@@ -509,7 +509,35 @@ void orc_mlp_init_params(const orc_mlp* m, orc_pcg32* rng, float* p, float scale
 	xavier(rng, p, m->padded_out, m->width, scale);
 }
 
-static inline float act_fwd(int act, float x) { return act == ORC_ACT_RELU ? (x > 0.0f ? x : 0.0f) : x; }
+/* common_device.h:108-186 (K_ACT = 10) */
+static inline float act_fwd(int act, float x) {
+	switch (act) {
+		case ORC_ACT_RELU: return x > 0.0f ? x : 0.0f;
+		case ORC_ACT_LEAKY_RELU: return x * (x > 0.0f ? 1.0f : 0.01f);
+		case ORC_ACT_EXPONENTIAL: return expf(x);
+		case ORC_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+		case ORC_ACT_SQUAREPLUS: { float y = x * 10.0f; return 0.5f * (y + sqrtf(y * y + 4.0f)) / 10.0f; }
+		case ORC_ACT_SOFTPLUS: return logf(expf(x * 10.0f) + 1.0f) / 10.0f;
+		case ORC_ACT_TANH: return tanhf(x);
+		default: return x;
+	}
+}
+
+/* common_device.h:363-418: v * f'(x) through the POST-activation value y; the factor is a half in the reference */
+static inline float act_bwd(int act, float v, float y) {
+	float factor;
+	switch (act) {
+		case ORC_ACT_RELU: return y > 0.0f ? v : 0.0f;
+		case ORC_ACT_LEAKY_RELU: factor = y > 0.0f ? 1.0f : 0.01f; break;
+		case ORC_ACT_EXPONENTIAL: factor = y; break;
+		case ORC_ACT_SIGMOID: factor = orc_h2f(orc_f2h(y * orc_h2f(orc_f2h(1.0f - y)))); break;
+		case ORC_ACT_SQUAREPLUS: { float t = y * 10.0f; factor = t * t / (t * t + 1.0f); break; }
+		case ORC_ACT_SOFTPLUS: factor = 1.0f - expf(-y * 10.0f); break;
+		case ORC_ACT_TANH: factor = 1.0f - y * y; break;
+		default: return v;
+	}
+	return v * orc_h2f(orc_f2h(factor));
+}
 
 /* one dense layer for one sample: out[o] = act(sum_i W[o][i] * in[i]); W pre-converted to float */
 static void layer_fwd(const float* W, uint32_t n_out, uint32_t n_in, const float* in, int act, int accum_fp16,
@@ -565,7 +593,6 @@ void orc_mlp_forward(const orc_mlp* m, const uint16_t* params, const uint16_t* i
 void orc_mlp_backward(const orc_mlp* m, const uint16_t* params, const uint16_t* input, const uint16_t* hidden,
                       const uint16_t* output, const uint16_t* dL_doutput, uint32_t n, double* grad_params,
                       uint16_t* dL_dinput) {
-	(void)output; /* only needed for output activations other than None (cutlass_mlp.cu:231-235) */
 	const uint32_t W = m->width, IN = m->in_width, OUT = m->padded_out, H = m->n_hidden;
 	float* Wf = (float*)malloc(sizeof(float) * m->n_params);
 	orc_h2f_array(params, Wf, m->n_params);
@@ -590,7 +617,12 @@ void orc_mlp_backward(const orc_mlp* m, const uint16_t* params, const uint16_t* 
 		for (long long ii = 0; ii < (long long)n; ++ii) {
 			size_t i = (size_t)ii;
 			/* output layer: dY (half) */
-			for (uint32_t o = 0; o < OUT; ++o) d_cur[o] = orc_h2f(dL_doutput[i * OUT + o]);
+			for (uint32_t o = 0; o < OUT; ++o) {
+				float d = orc_h2f(dL_doutput[i * OUT + o]);
+				/* output activation: continue from dL/d(pre-activation), a half (fully_fused_mlp.cu:760-763) */
+				if (m->output_activation != ORC_ACT_NONE) d = orc_h2f(orc_f2h(act_bwd(m->output_activation, d, orc_h2f(output[i * OUT + o]))));
+				d_cur[o] = d;
+			}
 			uint32_t n_cur = OUT;            /* width of d_cur */
 			const float* Wl = Wf + off_out;  /* matrix producing d_cur's layer: [n_cur][W] */
 			size_t goff = off_out;
@@ -616,9 +648,7 @@ void orc_mlp_backward(const orc_mlp* m, const uint16_t* params, const uint16_t* 
 					}
 					if (l >= 0) {
 						for (uint32_t k = 0; k < n_prev; ++k) {
-							float v = d_nxt[k];
-							if (m->activation == ORC_ACT_RELU && !(act[k] > 0.0f)) v = 0.0f; /* common_device.h:363-368 */
-							d_nxt[k] = orc_h2f(orc_f2h(v));
+							d_nxt[k] = orc_h2f(orc_f2h(act_bwd(m->activation, d_nxt[k], act[k]))); /* common_device.h:363-418 */
 						}
 					} else {
 						for (uint32_t k = 0; k < n_prev; ++k) dL_dinput[i * IN + k] = orc_f2h(d_nxt[k]);

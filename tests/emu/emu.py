@@ -38,7 +38,7 @@ class EmuGrid(C.Structure):
 
 class EmuMlp(C.Structure):
     _fields_ = [("in_width", C.c_uint32), ("width", C.c_uint32), ("padded_out", C.c_uint32),
-                ("n_hidden_matmuls", C.c_uint32), ("activation", C.c_uint32)]
+                ("n_hidden_matmuls", C.c_uint32), ("activation", C.c_uint32), ("output_activation", C.c_uint32)]
 
 
 class EmuAdam(C.Structure):
@@ -136,7 +136,7 @@ def grid_indices(g, positions):
 
 def mlp_meta(om):
     """oracle.Mlp -> EmuMlp"""
-    return EmuMlp(om.in_width, om.width, om.padded_out, om.n_hidden - 1, om.activation)
+    return EmuMlp(om.in_width, om.width, om.padded_out, om.n_hidden - 1, om.activation, om.output_activation)
 
 
 def mlp_forward(om, params_h, input_soa_h, save_hidden=True):
@@ -149,7 +149,8 @@ def mlp_forward(om, params_h, input_soa_h, save_hidden=True):
     return hidden, out
 
 
-def mlp_backward(om, params_h, input_soa_h, hidden, dL_doutput_h, want_dinput=True, want_grads=True, grads_init=None):
+def mlp_backward(om, params_h, input_soa_h, hidden, dL_doutput_h, want_dinput=True, want_grads=True, grads_init=None, output=None):
+    """dL_doutput_h: gradient w.r.t. the network output; `output` is needed when the output activation is not None."""
     n = input_soa_h.shape[1]
     dinput = np.zeros((om.in_width, n), dtype=np.uint16) if want_dinput else None
     grads = None
@@ -157,7 +158,8 @@ def mlp_backward(om, params_h, input_soa_h, hidden, dL_doutput_h, want_dinput=Tr
         grads = np.zeros(om.n_params, dtype=np.uint16) if grads_init is None else grads_init.copy()
     m = mlp_meta(om)
     r = lib().emu_mlp_backward(C.byref(m), C.c_uint32(n), _p(params_h), _p(np.ascontiguousarray(input_soa_h)), _p(hidden),
-                               _p(np.ascontiguousarray(dL_doutput_h)), _p(dinput), _p(grads), C.c_int(int(grads_init is not None)))
+                               _p(np.ascontiguousarray(dL_doutput_h)), _p(dinput), _p(grads), C.c_int(int(grads_init is not None)),
+                               _p(None if output is None else np.ascontiguousarray(output)))
     assert r == 0
     return grads, dinput
 

@@ -85,9 +85,11 @@ int emu_grid_indices(const EmuGrid* e, const float* positions, uint32_t n, uint3
 }
 
 struct EmuMlp {
-	uint32_t in_width, width, padded_out, n_hidden_matmuls, activation;
+	uint32_t in_width, width, padded_out, n_hidden_matmuls, activation, output_activation;
 };
-static MlpMeta make_mlp(const EmuMlp* e) { return MlpMeta{e->in_width, e->width, e->padded_out, e->n_hidden_matmuls, e->activation}; }
+static MlpMeta make_mlp(const EmuMlp* e) {
+	return MlpMeta{e->in_width, e->width, e->padded_out, e->n_hidden_matmuls, e->activation, e->output_activation};
+}
 
 int emu_mlp_forward(const EmuMlp* e, uint32_t n, const uint16_t* params, const uint16_t* input_soa, uint16_t* hidden, uint16_t* output) {
 	try {
@@ -101,13 +103,20 @@ int emu_mlp_forward(const EmuMlp* e, uint32_t n, const uint16_t* params, const u
 
 // grads: half [n_params] (Overwrite unless accumulate); scratch sizes are handled here.
 int emu_mlp_backward(const EmuMlp* e, uint32_t n, const uint16_t* params, const uint16_t* input_soa, const uint16_t* hidden,
-                     const uint16_t* dL_doutput, uint16_t* dL_dinput_soa, uint16_t* grads, int accumulate) {
+                     const uint16_t* dL_doutput, uint16_t* dL_dinput_soa, uint16_t* grads, int accumulate, const uint16_t* output) {
 	try {
 		const MlpMeta m = make_mlp(e);
 		std::vector<uint16_t> params_t(m.n_params());
 		mlp_transpose_weights(nullptr, m, (const half_t*)params, (half_t*)params_t.data());
 		const uint32_t np = mlp_backward_n_partials(m, n);
 		std::vector<float> partials(grads ? (size_t)np * m.n_params() : 0, -12345.0f);
+		std::vector<uint16_t> dpre;
+		if (m.output_activation != (uint32_t)Activation::None) {
+			if (!output) throw std::runtime_error("output required");
+			dpre.resize((size_t)n * m.padded_out);
+			mlp_output_activation_backward(nullptr, m, n, (const half_t*)output, (const half_t*)dL_doutput, (half_t*)dpre.data());
+			dL_doutput = dpre.data();
+		}
 		mlp_backward(nullptr, m, n, (const half_t*)params_t.data(), (const half_t*)input_soa, (const half_t*)hidden,
 		             (const half_t*)dL_doutput, (half_t*)dL_dinput_soa, grads ? partials.data() : nullptr);
 		if (grads) mlp_finalize_gradients(nullptr, m.n_params(), np, partials.data(), (half_t*)grads, accumulate != 0);

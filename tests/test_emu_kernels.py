@@ -155,6 +155,40 @@ def test_mlp_forward_backward(case):
     assert g_none is None and np.array_equal(dx2, dx)
 
 
+ACTIVATION_CASES = [(O.ACT_LEAKY_RELU, O.ACT_NONE), (O.ACT_EXPONENTIAL, O.ACT_SIGMOID), (O.ACT_SIGMOID, O.ACT_EXPONENTIAL),
+                    (O.ACT_SQUAREPLUS, O.ACT_TANH), (O.ACT_SOFTPLUS, O.ACT_SOFTPLUS), (O.ACT_TANH, O.ACT_SQUAREPLUS),
+                    (O.ACT_NONE, O.ACT_RELU), (O.ACT_RELU, O.ACT_LEAKY_RELU)]
+
+
+@pytest.mark.parametrize("act,out_act", ACTIVATION_CASES)
+def test_mlp_activations(act, out_act):
+    """Hidden / output activations of FullyFusedMLP (common_device.h:108-186, 363-418) against the oracle; the fused
+    training kernel and the three-kernel path agree bit for bit."""
+    IN, W, OUT, H = 32, 64, 4, 2
+    rng = np.random.default_rng(11)
+    om = O.mlp_init(IN, W, OUT, H, activation=act, output_activation=out_act)
+    ph = O.f2h(O.mlp_init_params(om, O.pcg32(5)) * 0.5)
+    n = 256
+    x = O.f2h(rng.random((n, IN), dtype=np.float32) * 0.5)
+    xs = np.ascontiguousarray(x.T)
+    hid_ref, out_ref = O.mlp_forward(om, ph, x)
+    hid, out = emu.mlp_forward(om, ph, xs)
+    assert np.max(np.abs(O.h2f(out) - O.h2f(out_ref))) <= 2e-3 * max(1.0, np.abs(O.h2f(out_ref)).max())
+    assert np.max(np.abs(O.h2f(hid) - O.h2f(hid_ref))) <= 2e-3 * max(1.0, np.abs(O.h2f(hid_ref)).max())
+    dy = O.f2h((rng.standard_normal((n, om.padded_out)) * 0.01).astype(np.float32))
+    dy[:, OUT:] = 0
+    gref, dref = O.mlp_backward(om, ph, x, hid_ref, out_ref, dy)
+    gh, dx = emu.mlp_backward(om, ph, xs, hid_ref, dy, output=out_ref)
+    assert np.percentile(rae(O.h2f(gh), gref), 99) < 5e-3
+    assert np.max(np.abs(O.h2f(dx).T - O.h2f(dref))) <= 1e-4 + 5e-3 * np.abs(O.h2f(dref)).max()
+    # fused == unfused, including the output-activation transfer
+    target = rng.random((n, OUT), dtype=np.float32)
+    out_f, dy_f, dx_f, g_f, _ = emu.mlp_train(om, ph, xs, O.LOSS_L2, target, OUT)
+    _, dyl, _ = emu.loss(O.LOSS_L2, out, target, OUT)
+    g_u, dx_u = emu.mlp_backward(om, ph, xs, hid, dyl, output=out)
+    assert np.array_equal(out_f, out) and np.array_equal(dy_f, dyl) and np.array_equal(dx_f, dx_u) and np.array_equal(g_f, g_u)
+
+
 @pytest.mark.parametrize("case", MLP_CASES)
 @pytest.mark.parametrize("loss_type", [O.LOSS_L2, O.LOSS_RELATIVE_L2])
 def test_mlp_fused_training_pass_equals_the_unfused_kernels(case, loss_type):

@@ -530,3 +530,54 @@ def test_bucketed_grid_backward_full_size(clustered):
             if og.offsets[l + 1] - og.offsets[l] > 65536:
                 # (x-neighbour pairs straddling two slices -- about one in 2^13 -- take the overflow path: fp16 atomics)
                 assert np.mean(out[3][lo:hi].astype(np.float32) == O.h2f(O.f2h(ref[lo:hi].astype(np.float32)))) > 0.998, f"level {l}"
+
+
+@pytest.mark.parametrize("act,out_act", [("LeakyReLU", "None"), ("Exponential", "Sigmoid"), ("Sigmoid", "Exponential"), ("Squareplus", "Tanh"),
+                                         ("Softplus", "Softplus"), ("Tanh", "Squareplus"), ("None", "ReLU")])
+def test_network_activations(act, out_act):
+    """Hidden / output activations of FullyFusedMLP (common_device.h:108-186, 363-418; fully_fused_mlp.cu:690-697,
+    760-763) through tcnn.Network and through a trained model (fused training kernel) against the oracle."""
+    C = tcnn()._C
+    IN, W, OUT, H = 32, 64, 4, 2
+    m = C.create_network(IN, OUT, dict(MLP_64x2, activation=act, output_activation=out_act))
+    om = O.mlp_init(IN, W, OUT, H, activation=O.ACTIVATION_NAMES.index(act), output_activation=O.ACTIVATION_NAMES.index(out_act))
+    assert m.hyperparams()["output_activation"] == out_act and m.hyperparams()["activation"] == act
+    ph = O.f2h(O.mlp_init_params(om, O.pcg32(3)) * 0.5)
+    n = 1024
+    rng = np.random.default_rng(13)
+    xin = rng.random((n, IN), dtype=np.float32) * 0.5
+    x = torch.from_numpy(xin).cuda().requires_grad_(True)
+    p = h_t(ph).requires_grad_(True)
+    ctx, y = m.fwd(x, p)
+    torch.cuda.synchronize()
+    enc = O.identity_forward(xin, IN)
+    hid_ref, out_ref = O.mlp_forward(om, ph, enc)
+    scale = max(1.0, np.abs(O.h2f(out_ref)).max())
+    assert np.max(np.abs(O.h2f(h_np(y)) - O.h2f(out_ref))) < 4e-3 * scale
+    dy = np.zeros((n, 16), np.float32)
+    dy[:, :OUT] = rng.standard_normal((n, OUT)).astype(np.float32) * 0.05
+    dyh = O.f2h(dy)
+    dx, dp = m.bwd(ctx, x, p, y, h_t(dyh))
+    torch.cuda.synchronize()
+    gref, dref = O.mlp_backward(om, ph, enc, hid_ref, out_ref, dyh)
+    assert np.percentile(rae(dp.float().cpu().numpy(), gref), 99) < 6e-3
+    dx_ref = O.h2f(dref)[:, :IN]
+    assert np.allclose(dx.cpu().numpy(), dx_ref, rtol=3e-2, atol=4e-3 * np.abs(dx_ref).max())
+
+    # the fused training kernel and the forward()+backward() pair give the same parameter gradients
+    T = tcnn()
+    cfg = config_hash(log2_hashmap_size=14)
+    cfg["network"] = dict(cfg["network"], activation=act, output_activation=out_act)
+    tm = T.create_from_config(3, 4, cfg, seed=3)
+    w = tm.params_full_precision.clone()
+    w[tm.n_mlp_params:] *= 1.0e3
+    tm.set_params_full_precision(w)
+    pos = positions(2048, 3, seed=4)
+    xx, tt = torch.from_numpy(pos).cuda(), torch.from_numpy(targets_for(pos, 4)).cuda()
+    ctx_f = tm.training_step(xx, tt, run_optimizer=False)
+    g_fused, loss_fused = tm.param_gradients.clone(), tm.loss(ctx_f)
+    c2 = tm.forward(xx, tt)
+    tm.backward(c2, xx)
+    assert torch.equal(tm.param_gradients, g_fused)
+    assert abs(tm.loss(c2) - loss_fused) <= 1e-5 * abs(loss_fused) + 1e-9
+    assert torch.isfinite(g_fused.float()).all()

@@ -278,7 +278,8 @@ static const char* to_string(GridType t) { return t == GridType::Hash ? "Hash" :
 static const char* to_string(InterpolationType t) {
 	return t == InterpolationType::Nearest ? "Nearest" : t == InterpolationType::Linear ? "Linear" : "Smoothstep";
 }
-static const char* to_string(Activation a) { return a == Activation::ReLU ? "ReLU" : "None"; }
+static const char* const ACTIVATION_NAMES[] = {"None", "ReLU", "LeakyReLU", "Exponential", "Sigmoid", "Squareplus", "Softplus", "Tanh"};
+static const char* to_string(Activation a) { return ACTIVATION_NAMES[(int)a]; }
 
 static GridType string_to_grid_type(const std::string& s) {  // common_host.cu:112-122
 	if (equals_case_insensitive(s, "Hash")) return GridType::Hash;
@@ -293,9 +294,14 @@ static InterpolationType string_to_interpolation_type(const std::string& s) {  /
 	throw std::runtime_error("Invalid interpolation type: " + s);
 }
 static Activation string_to_activation(const std::string& s) {  // common_host.cu:70-96
-	if (equals_case_insensitive(s, "None")) return Activation::None;
-	if (equals_case_insensitive(s, "ReLU")) return Activation::ReLU;
-	throw std::runtime_error("Activation '" + s + "' is not available in this build (supported: None, ReLU).");
+	for (int i = 0; i < 8; ++i) {
+		if (equals_case_insensitive(s, ACTIVATION_NAMES[i])) return (Activation)i;
+	}
+	// SiLU and Sine need stored pre-activations, which FullyFusedMLP does not keep (common_device.h:377-386)
+	if (equals_case_insensitive(s, "SiLU") || equals_case_insensitive(s, "Sine")) {
+		throw std::runtime_error("Activation '" + s + "' is not supported by FullyFusedMLP (it needs stored pre-activations).");
+	}
+	throw std::runtime_error("Invalid activation name: " + s);  // common_host.cu:94
 }
 
 struct EncodingDesc {
@@ -442,7 +448,7 @@ struct NetworkDesc {
 		Json j = Json::object();
 		j["otype"] = "FullyFusedMLP";
 		j["activation"] = to_string((Activation)mlp.activation);
-		j["output_activation"] = "None";
+		j["output_activation"] = to_string((Activation)mlp.output_activation);
 		j["n_neurons"] = mlp.width;
 		j["n_hidden_layers"] = n_hidden_layers;
 		return j;
@@ -464,14 +470,14 @@ static NetworkDesc create_network_desc(uint32_t n_input_dims, uint32_t n_output_
 	d.n_hidden_layers = net.value("n_hidden_layers", 5u);
 	if (d.n_hidden_layers == 0) throw std::runtime_error("FullyFusedMLP requires at least 1 hidden layer (3 layers in total).");
 	const Activation act = string_to_activation(net.value("activation", "ReLU"));
-	const std::string out_act = net.value("output_activation", "None");
-	if (!equals_case_insensitive(out_act, "None")) throw std::runtime_error("output_activation '" + out_act + "' is not available in this build (supported: None).");
+	const Activation out_act = string_to_activation(net.value("output_activation", "None"));
 	d.n_output_dims = n_output_dims;
 	d.mlp.in_width = n_input_dims;
 	d.mlp.width = n_neurons;
 	d.mlp.padded_out = next_multiple(n_output_dims, 16u);  // fully_fused_mlp.cu:656
 	d.mlp.n_hidden_matmuls = d.n_hidden_layers - 1;
 	d.mlp.activation = (uint32_t)act;
+	d.mlp.output_activation = (uint32_t)out_act;
 	if (d.mlp.padded_out != 16) throw std::runtime_error("FullyFusedMLP: more than 16 output dimensions are not supported by the fused kernels of this build.");
 	if (n_input_dims % 16 != 0 || n_input_dims > MLP_MAX_IN_WIDTH) {
 		throw std::runtime_error("FullyFusedMLP: input width " + std::to_string(n_input_dims) + " must be a multiple of 16 and at most " + std::to_string(MLP_MAX_IN_WIDTH));
@@ -604,7 +610,8 @@ static void encoding_backward(hipStream_t stream, const Model& md, const Forward
 
 // NetworkWithInputEncoding::backward_impl (:83-113) / GridEncodingTemplated::backward_impl (grid.h:817-908)
 static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const half_t* dL_doutput,
-                           half_t* dL_dparams, const float* input, const half_t* params, int gradient_mode, uint32_t lds_level_budget) {
+                           half_t* dL_dparams, const float* input, const half_t* output, const half_t* params, int gradient_mode,
+                           uint32_t lds_level_budget) {
 	check_batch(n);
 	if (n == 0) return;
 	if (ctx.n != n) throw std::runtime_error("backward: batch size does not match the forward context");
@@ -628,6 +635,13 @@ static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx
 		Scratch partials;
 		if (want_grads) partials = Scratch(stream, (size_t)n_partials * md.n_mlp_params() * sizeof(float));
 		if (need_denc) denc = Scratch(stream, (size_t)e.padded_output_width * n * sizeof(half_t));
+		Scratch dpre;  // output activation: continue from dL/d(pre-activation) (fully_fused_mlp.cu:760-763)
+		if (md.net.mlp.output_activation != (uint32_t)Activation::None) {
+			if (!output) throw std::runtime_error("backward: the network output is required when an output activation is set");
+			dpre = Scratch(stream, (size_t)md.padded_output_width() * n * sizeof(half_t));
+			mlp_output_activation_backward(stream, md.net.mlp, n, output, dL_doutput, dpre.as<half_t>());
+			dL_doutput = dpre.as<half_t>();
+		}
 		mlp_backward(stream, md.net.mlp, n, params_t.as<half_t>(), ctx.enc.as<half_t>(), ctx.hidden.as<half_t>(), dL_doutput,
 		             need_denc ? denc.as<half_t>() : nullptr, want_grads ? partials.as<float>() : nullptr);
 		if (want_grads) mlp_finalize_gradients(stream, (uint32_t)md.n_mlp_params(), n_partials, partials.as<float>(), dL_dparams, accumulate);
@@ -816,7 +830,8 @@ int tcnn_module_backward(tcnn_module_t* m, tcnn_stream_t stream, const tcnn_cont
 	(void)output;
 	TCNN_API_BEGIN
 	if (!ctx) throw std::runtime_error("backward: missing forward context");
-	model_backward((hipStream_t)stream, m->md, ctx->ctx, n, dL_dinput, (const half_t*)dL_doutput, (half_t*)dL_dparams, input, (const half_t*)params,
+	model_backward((hipStream_t)stream, m->md, ctx->ctx, n, dL_dinput, (const half_t*)dL_doutput, (half_t*)dL_dparams, input, (const half_t*)output,
+	               (const half_t*)params,
 	               dL_dparams ? TCNN_GRADIENT_OVERWRITE : TCNN_GRADIENT_IGNORE, m->lds_level_budget);  // cpp_api.cu:115
 	TCNN_API_END
 }
@@ -1014,7 +1029,8 @@ int tcnn_trainer_backward(tcnn_trainable_model_t* tm, tcnn_stream_t stream, cons
 	TCNN_API_BEGIN
 	if (!ctx) throw std::runtime_error("Trainer::backward: missing forward context");
 	ProfilerGuard pg(tm->profiler.get());
-	model_backward((hipStream_t)stream, tm->md, ctx->model_ctx, n, dL_dinput, ctx->dL_doutput_ptr, tm->grads, input, tm->params, gradient_mode,
+	model_backward((hipStream_t)stream, tm->md, ctx->model_ctx, n, dL_dinput, ctx->dL_doutput_ptr, tm->grads, input, ctx->output.as<half_t>(),
+	               tm->params, gradient_mode,
 	               tm->lds_level_budget);
 	TCNN_API_END
 }

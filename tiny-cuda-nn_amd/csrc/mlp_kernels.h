@@ -20,19 +20,20 @@
 //   output / dL_doutput: half, sample-major  [n][16]         (the reference's CM padded output)
 //   hidden (saved)    : half, [n_hidden][n][WIDTH] post-activation (fully_fused_mlp.cu:841-854)
 #pragma once
+#include "activation_device.h"
 #include "loss_device.h"
 #include "tcnn_device.h"
 
 namespace tcnn_hip {
 
-enum class Activation : int { None = 0, ReLU = 1 };
 
 struct MlpMeta {
 	uint32_t in_width;          // multiple of 16
 	uint32_t width;             // 16 / 32 / 64 / 128
 	uint32_t padded_out;        // 16 (outputs wider than 16 are not fused yet)
 	uint32_t n_hidden_matmuls;  // n_hidden_layers - 1
-	uint32_t activation;        // Activation
+	uint32_t activation;        // Activation of the hidden layers
+	uint32_t output_activation; // Activation of the output layer (default None)
 	TCNN_HOST_DEVICE uint32_t n_params() const { return width * in_width + n_hidden_matmuls * width * width + padded_out * width; }
 };
 
@@ -49,7 +50,13 @@ void mlp_transpose_weights(hipStream_t stream, const MlpMeta& m, const half_t* p
 // Number of fp32 partial gradient slabs mlp_backward writes (== its grid size) for batch n.
 uint32_t mlp_backward_n_partials(const MlpMeta& m, uint32_t n);
 
-// Backward.  params_t from mlp_transpose_weights.  dL_dinput may be null.  partials: fp32
+// dL/d(pre-activation of the output layer) from dL/doutput and the (post-activation) output; only needed when the
+// output activation is not None (fully_fused_mlp.cu:760-763, common_device.h:923-932).  [n][16] each.
+void mlp_output_activation_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* output, const half_t* dL_doutput,
+                                    half_t* dL_dpreact);
+
+// Backward.  dL_doutput is the gradient w.r.t. the output layer's PRE-activation (== dL/doutput when the output
+// activation is None).  params_t from mlp_transpose_weights.  dL_dinput may be null.  partials: fp32
 // [mlp_backward_n_partials][n_params] or null (GradientMode::Ignore).
 void mlp_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params_t, const half_t* input, const half_t* hidden,
                   const half_t* dL_doutput, half_t* dL_dinput, float* partials);

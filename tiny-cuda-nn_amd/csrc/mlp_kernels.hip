@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_forward(const MlpMeta m
 	half_t* buf1 = buf0 + S * ld;
 
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
-	const bool relu = m.activation == (uint32_t)Activation::ReLU;
+	const uint32_t act = m.activation, out_act = m.output_activation;
 	const uint32_t n_tiles = n / S;
 
 	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -82,9 +82,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_forward(const MlpMeta m
 				h4 o;
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
-					float v = acc[t][r];
-					if (relu) v = v > 0.0f ? v : 0.0f;
-					o[r] = (half_t)v;
+					o[r] = (half_t)act_forward(act, acc[t][r]);
 				}
 				*(h4*)(nxt + (16 * t + lr) * ld + 16 * w + 4 * g) = o;
 			}
@@ -119,7 +117,8 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_forward(const MlpMeta m
 				const h4 b = *(const h4*)(cur + (16 * t + lr) * ld + k0 + 4 * g);
 				acc = mfma_16x16x16(a, b, acc);
 			}
-			const h4 o = h4{(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};
+			const h4 o = h4{(half_t)act_forward(out_act, acc[0]), (half_t)act_forward(out_act, acc[1]), (half_t)act_forward(out_act, acc[2]),
+			                (half_t)act_forward(out_act, acc[3])};
 			*(h4*)(output + ((size_t)tile * S + 16 * t + lr) * 16 + 4 * g) = o;  // (output 4g+r, sample 16t+lr)
 		}
 		__syncthreads();
@@ -174,7 +173,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 	const half_t* wt_out = wt_hid + (size_t)HM * WIDTH * WIDTH;  // [WIDTH][16]
 
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
-	const bool relu = m.activation == (uint32_t)Activation::ReLU;
+	const uint32_t act = m.activation;
 	const bool want_grads = partials != nullptr, want_dx = dL_dinput != nullptr;
 	const uint32_t n_tiles = n / S;
 
@@ -225,9 +224,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 				const h4 hv = *(const h4*)(hlast + (16 * w + lr) * SP + 16 * t + 4 * g);
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
-					float v = acc[r];
-					if (relu && !(hv[r] > (half_t)0.0f)) v = 0.0f;  // transfer on post-activation values (common_device.h:363-368)
-					da[t][r] = (half_t)v;
+					da[t][r] = (half_t)act_backward(act, acc[r], hv[r]);  // transfer on post-activation values (common_device.h:363-418)
 					dact0[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
 				}
 			}
@@ -289,9 +286,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 				const h4 hv = *(const h4*)(hj + (16 * w + lr) * SP + 16 * t + 4 * g);
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
-					float v = acc[t][r];
-					if (relu && !(hv[r] > (half_t)0.0f)) v = 0.0f;
-					da[t][r] = (half_t)v;
+					da[t][r] = (half_t)act_backward(act, acc[t][r], hv[r]);
 					nxt[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
 				}
 			}
@@ -412,7 +407,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 	const half_t* wt_out = wt_hid + (size_t)HM * WIDTH * WIDTH; // [WIDTH][16]
 
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
-	const bool relu = m.activation == (uint32_t)Activation::ReLU;
+	const uint32_t act = m.activation, out_act = m.output_activation;
 	const bool want_grads = partials != nullptr, want_dx = dL_dinput != nullptr;
 	const uint32_t n_tiles = n / S;
 	const float n_total = (float)la.n_total;
@@ -513,9 +508,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 					h4 o;
 #pragma unroll
 					for (uint32_t r = 0; r < 4; ++r) {
-						float v = acc[t][r];
-						if (relu) v = v > 0.0f ? v : 0.0f;
-						o[r] = (half_t)v;
+						o[r] = (half_t)act_forward(act, acc[t][r]);
 						hl[(16 * w + 4 * g + r) * SP + 16 * t + lr] = o[r];
 					}
 					*(h4*)(nxt + (16 * t + lr) * LDW + 16 * w + 4 * g) = o;
@@ -546,7 +539,8 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 					const h4 b = *(const h4*)(cur + (16 * t + lr) * LDW + k0 + 4 * g);
 					acc = mfma_16x16x16(a, b, acc);
 				}
-				const h4 o = h4{(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};
+				const h4 o = h4{(half_t)act_forward(out_act, acc[0]), (half_t)act_forward(out_act, acc[1]), (half_t)act_forward(out_act, acc[2]),
+				                (half_t)act_forward(out_act, acc[3])};
 				const size_t i = (size_t)tile * S + 16 * t + lr;
 				h4 gy;
 #pragma unroll
@@ -558,11 +552,15 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 						gy[r] = loss_element<LOSS>((float)o[r], tgt[q][r], pdf[q][r], n_total, la.loss_scale, value);
 						loss_sum += value;
 					}
-					dyT[dim * SP + 16 * t + lr] = gy[r];
+				}
+				if (output) *(h4*)(output + i * 16 + 4 * g) = o;
+				if (dL_doutput) *(h4*)(dL_doutput + i * 16 + 4 * g) = gy;  // the caller's context holds dL/doutput ...
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) {  // ... the backward pass continues from dL/d(pre-activation) (fully_fused_mlp.cu:760-763)
+					gy[r] = (half_t)act_backward(out_act, (float)gy[r], o[r]);
+					dyT[(4 * g + r) * SP + 16 * t + lr] = gy[r];
 				}
 				*(h4*)(dys + (16 * t + lr) * LDY + 4 * g) = gy;
-				if (output) *(h4*)(output + i * 16 + 4 * g) = o;
-				if (dL_doutput) *(h4*)(dL_doutput + i * 16 + 4 * g) = gy;
 			}
 			__syncthreads();
 		}
@@ -581,9 +579,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 				const h4 hv = *(const h4*)(hlast + (16 * w + lr) * SP + 16 * t + 4 * g);
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
-					float v = acc[r];
-					if (relu && !(hv[r] > (half_t)0.0f)) v = 0.0f;
-					da[t][r] = (half_t)v;
+					da[t][r] = (half_t)act_backward(act, acc[r], hv[r]);
 					dact0[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
 				}
 			}
@@ -642,9 +638,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 				const h4 hv = *(const h4*)(hj + (16 * w + lr) * SP + 16 * t + 4 * g);
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
-					float v = acc[t][r];
-					if (relu && !(hv[r] > (half_t)0.0f)) v = 0.0f;
-					da[t][r] = (half_t)v;
+					da[t][r] = (half_t)act_backward(act, acc[t][r], hv[r]);
 					nxt[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
 				}
 			}
@@ -741,6 +735,17 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 #pragma unroll
 		for (uint32_t r = 0; r < 4; ++r) P[off_out + (size_t)lr * WIDTH + 16 * w + 4 * g + r] = accO[r];
 	}
+}
+
+__global__ void __launch_bounds__(256) k_mlp_output_activation_backward(uint32_t n_groups, uint32_t act, const half_t* __restrict__ output,
+                                                                         const half_t* __restrict__ dL_doutput, half_t* __restrict__ dL_dpreact) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;  // 8 halves per thread
+	if (i >= n_groups) return;
+	const h8 o = *(const h8*)(output + (size_t)i * 8), d = *(const h8*)(dL_doutput + (size_t)i * 8);
+	h8 r;
+#pragma unroll
+	for (uint32_t j = 0; j < 8; ++j) r[j] = (half_t)act_backward(act, (float)d[j], o[j]);
+	*(h8*)(dL_dpreact + (size_t)i * 8) = r;
 }
 
 constexpr uint32_t FINALIZE_GROUPS = 32;  // slab groups per block (x 32 parameters = 1024 threads)
@@ -911,6 +916,14 @@ void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* p
 		case 32: dispatch_train<32>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		case 64: dispatch_train<64>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 	}
+}
+
+void mlp_output_activation_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* output, const half_t* dL_doutput,
+                                    half_t* dL_dpreact) {
+	if (n == 0) return;
+	const uint32_t n_groups = n * m.padded_out / 8u;
+	TCNN_LAUNCH(k_mlp_output_activation_backward, dim3(div_round_up(n_groups, 256u)), dim3(256), 0, stream, n_groups, m.output_activation, output,
+	            dL_doutput, dL_dpreact);
 }
 
 void mlp_finalize_gradients(hipStream_t stream, uint32_t n_params, uint32_t n_partials, const float* partials, half_t* grads, bool accumulate) {

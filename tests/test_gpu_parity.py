@@ -541,7 +541,8 @@ def test_network_activations(act, out_act):
     IN, W, OUT, H = 32, 64, 4, 2
     m = C.create_network(IN, OUT, dict(MLP_64x2, activation=act, output_activation=out_act))
     om = O.mlp_init(IN, W, OUT, H, activation=O.ACTIVATION_NAMES.index(act), output_activation=O.ACTIVATION_NAMES.index(out_act))
-    assert m.hyperparams()["output_activation"] == out_act and m.hyperparams()["activation"] == act
+    hp = m.hyperparams()["network"]
+    assert hp["output_activation"] == out_act and hp["activation"] == act
     ph = O.f2h(O.mlp_init_params(om, O.pcg32(3)) * 0.5)
     n = 1024
     rng = np.random.default_rng(13)

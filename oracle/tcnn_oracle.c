@@ -696,15 +696,56 @@ void orc_loss(int loss_type, uint32_t n, uint32_t stride, uint32_t dims, float l
 		const uint32_t target_idx = inter * dims + intra;
 		const float p = orc_h2f(prediction[i]);
 		const float pdf = data_pdf ? data_pdf[target_idx] : 1;
-		const float difference = p - target[target_idx];
-		float value, gradient;
-		if (loss_type == ORC_LOSS_RELATIVE_L2) {
-			const float psq = p * p + 0.01f;
-			value = difference * difference / psq / pdf / n_total;
-			gradient = 2 * difference / psq / pdf;
-		} else {
-			value = difference * difference / pdf / n_total;
-			gradient = 2 * difference / pdf;
+		const float tg = target[target_idx];
+		const float difference = p - tg;
+		float value, gradient; /* gradient: dL/dprediction * n_total */
+		switch (loss_type) {
+			case ORC_LOSS_RELATIVE_L2: { /* relative_l2.h:70-80 */
+				const float psq = p * p + 0.01f;
+				value = difference * difference / psq / pdf / n_total;
+				gradient = 2 * difference / psq / pdf;
+				break;
+			}
+			case ORC_LOSS_L1: /* l1.h:69-74 */
+				value = fabsf(difference) / pdf / n_total;
+				gradient = copysignf(1.0f / pdf, difference);
+				break;
+			case ORC_LOSS_RELATIVE_L1: { /* relative_l1.h:69-76 */
+				const float scale = 1.0f / (fabsf(p) + 1e-2f) / pdf;
+				value = fabsf(difference) * scale / n_total;
+				gradient = copysignf(scale, difference);
+				break;
+			}
+			case ORC_LOSS_MAPE: { /* mape.h:69-77 */
+				const float scale = 1.0f / (fabsf(tg) + 1e-2f) / pdf;
+				value = fabsf(difference) * scale / n_total;
+				gradient = copysignf(scale, difference);
+				break;
+			}
+			case ORC_LOSS_SMAPE: { /* smape.h:69-77 */
+				const float scale = 1.0f / (0.5f * (fabsf(tg) + fabsf(p)) + 1e-2f) / pdf;
+				value = fabsf(difference) * scale / n_total;
+				gradient = copysignf(scale, difference);
+				break;
+			}
+			case ORC_LOSS_CROSS_ENTROPY: { /* cross_entropy.h:66-76 */
+				const float factor = -tg / pdf / n_total;
+				value = factor * logf(p);
+				if (values) values[i] = value;
+				gradients[i] = orc_f2h(loss_scale * (factor / p));
+				continue;
+			}
+			case ORC_LOSS_VARIANCE: { /* variance_is.h:66-76 */
+				const float factor = tg * tg / pdf / n_total;
+				value = factor / p - factor / pdf;
+				if (values) values[i] = value;
+				gradients[i] = orc_f2h(loss_scale * (-factor / (p * p)));
+				continue;
+			}
+			default: /* L2, l2.h:69-74 */
+				value = difference * difference / pdf / n_total;
+				gradient = 2 * difference / pdf;
+				break;
 		}
 		if (values) values[i] = value;
 		gradients[i] = orc_f2h(loss_scale * gradient / n_total);

@@ -236,7 +236,7 @@ def _trainer_and_oracle(cfg, d, out, seed=1337):
     og = oracle_grid(cfg["encoding"], d)
     adam = O.adam_defaults(**{k: v for k, v in (("learning_rate", 1e-2), ("beta1", 0.9), ("beta2", 0.99), ("epsilon", 1e-15), ("l2_reg", 1e-6))})
     md = O.model_init(d, out, og, cfg["network"]["n_neurons"], cfg["network"]["n_hidden_layers"],
-                      O.LOSS_RELATIVE_L2 if cfg["loss"]["otype"] == "RelativeL2" else O.LOSS_L2, adam)
+                      O.LOSS_NAMES.index(cfg["loss"]["otype"]), adam)
     return tm, md
 
 
@@ -244,7 +244,7 @@ def targets_for(pos, out):
     return np.stack([0.5 + 0.5 * np.sin(2 * np.pi * (c + 1) * pos[:, 0]) * np.cos(2 * np.pi * pos[:, 1]) for c in range(out)], 1).astype(np.float32)
 
 
-@pytest.mark.parametrize("loss", ["RelativeL2", "L2"])
+@pytest.mark.parametrize("loss", ["RelativeL2", "L2", "L1", "RelativeL1", "Mape", "Smape"])
 def test_training_step_matches_oracle(loss):
     """create_from_config -> trainer.training_step -> trainer.loss -> network.inference against the oracle's
     whole-step restatement, starting from identical fp32 master parameters."""
@@ -582,3 +582,26 @@ def test_network_activations(act, out_act):
     assert torch.equal(tm.param_gradients, g_fused)
     assert abs(tm.loss(c2) - loss_fused) <= 1e-5 * abs(loss_fused) + 1e-9
     assert torch.isfinite(g_fused.float()).all()
+
+
+@pytest.mark.parametrize("loss", ["CrossEntropy", "Variance"])
+def test_losses_for_positive_predictions(loss):
+    """CrossEntropy / Variance (cross_entropy.h:66-76, variance_is.h:66-76) need positive predictions: an Exponential
+    output layer provides them.  Loss gradients are the oracle's bits on the GPU's own prediction."""
+    T = tcnn()
+    cfg = config_hash(log2_hashmap_size=14, loss=loss)
+    cfg["network"] = dict(cfg["network"], output_activation="Exponential")
+    tm = T.create_from_config(3, 4, cfg, seed=5)
+    assert tm.hyperparams()["loss"]["otype"] == loss
+    pos = positions(2048, 3, seed=8)
+    tgt = targets_for(pos, 4)
+    x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(tgt).cuda()
+    for fused in (True, False):
+        ctx = tm.training_step(x, t, run_optimizer=False) if fused else tm.forward(x, t)
+        pred = h_np(ctx.output)
+        assert (O.h2f(pred)[:, :4] > 0).all()
+        v_ref, g_ref = O.loss(O.LOSS_NAMES.index(loss), pred, tgt, 4)
+        got, ref = O.h2f(h_np(ctx.dL_doutput)), O.h2f(g_ref)
+        assert np.allclose(got, ref, rtol=2e-3, atol=1e-7)              # 1 / x and log on the device vs libm: an fp16 ulp at most
+        assert np.mean(h_np(ctx.dL_doutput) == g_ref) > 0.99
+        assert abs(tm.loss(ctx) - float(v_ref.sum(dtype=np.float64))) <= 1e-4 * abs(float(v_ref.sum(dtype=np.float64)))

@@ -888,6 +888,15 @@ int tcnn_module_grid_level_params_offset(const tcnn_module_t* m, uint32_t level,
 
 // ------------------------------------------------------------------------------------------------ trainer
 
+static const char* const LOSS_NAMES[N_LOSS_TYPES] = {"L2", "RelativeL2", "L1", "RelativeL1", "Mape", "Smape", "CrossEntropy", "Variance"};  // loss.cu:57-65
+static LossType string_to_loss(const std::string& s) {
+	for (int i = 0; i < N_LOSS_TYPES; ++i) {
+		if (equals_case_insensitive(s, LOSS_NAMES[i])) return (LossType)i;
+	}
+	if (equals_case_insensitive(s, "RelativeL2Luminance")) throw std::runtime_error("Loss 'RelativeL2Luminance' is not available in this build.");
+	throw std::runtime_error("Loss '" + s + "' not found");  // loss.cu:86
+}
+
 static void parse_adam(AdamHyper& h, const Json& p) {  // adam.h:221-281
 	h.beta1 = p.value("beta1", h.beta1);
 	h.beta2 = p.value("beta2", h.beta2);
@@ -925,7 +934,7 @@ static void refresh_hyper_json(tcnn_trainable_model* tm) {  // trainer.h:385-391
 	o["optimize_non_matrix_params"] = tm->adam.optimize_non_matrix_params;
 	o["skip_zero_grad_non_matrix_params"] = tm->adam.skip_zero_grad_non_matrix_params;
 	Json l = Json::object();
-	l["otype"] = tm->loss == LossType::RelativeL2 ? "RelativeL2" : "L2";
+	l["otype"] = LOSS_NAMES[(int)tm->loss];
 	Json j = Json::object();
 	j["otype"] = "Trainer";
 	j["optimizer"] = o;
@@ -947,9 +956,7 @@ int tcnn_create_from_config(uint32_t n_input_dims, uint32_t n_output_dims, const
 	const Json network_opts = config.value("network", Json::object());
 	const Json encoding_opts = config.value("encoding", Json::object());
 	const std::string loss_type = loss_opts.value("otype", "RelativeL2");  // loss.cu:81-83
-	if (equals_case_insensitive(loss_type, "RelativeL2")) tm->loss = LossType::RelativeL2;
-	else if (equals_case_insensitive(loss_type, "L2")) tm->loss = LossType::L2;
-	else throw std::runtime_error("Loss '" + loss_type + "' is not available in this build (supported: RelativeL2, L2).");
+	tm->loss = string_to_loss(loss_type);
 	const std::string opt_type = optimizer_opts.value("otype", "Adam");  // optimizer.cu:50
 	if (!equals_case_insensitive(opt_type, "Adam")) throw std::runtime_error("Optimizer '" + opt_type + "' is not available in this build (supported: Adam).");
 	parse_adam(tm->adam, optimizer_opts);

@@ -83,8 +83,7 @@ void trim_and_cast(hipStream_t stream, uint32_t n, uint32_t padded, uint32_t dim
 
 // ------------------------------------------------------------------------------------------ loss
 // One thread per 8 consecutive elements of the [n][stride] half prediction matrix (16-byte accesses).
-template <LossType LOSS>
-__global__ void __launch_bounds__(EW_THREADS) k_loss(uint32_t n_groups, uint32_t stride, uint32_t dims, float loss_scale,
+__global__ void __launch_bounds__(EW_THREADS) k_loss(const LossType type, uint32_t n_groups, uint32_t stride, uint32_t dims, float loss_scale,
                                                       const half_t* __restrict__ predictions, const float* __restrict__ targets,
                                                       const float* __restrict__ data_pdf, float* __restrict__ values,
                                                       half_t* __restrict__ gradients, float* __restrict__ block_sums, uint32_t n_total_u) {
@@ -110,7 +109,7 @@ __global__ void __launch_bounds__(EW_THREADS) k_loss(uint32_t n_groups, uint32_t
 			const float prediction = (float)p8[j];
 			const float pdf = data_pdf ? data_pdf[target_idx] : 1.0f;
 			float value;
-			g8[j] = loss_element<LOSS>(prediction, targets[target_idx], pdf, n_total, loss_scale, value);
+			g8[j] = loss_element(type, prediction, targets[target_idx], pdf, n_total, loss_scale, value);
 			v8[j] = value;
 			local_sum += value;
 		}
@@ -140,11 +139,8 @@ void loss_evaluate(hipStream_t stream, LossType type, uint32_t n, uint32_t strid
 	if (stride % 8 != 0) throw std::runtime_error("loss: padded output width must be a multiple of 8");
 	const uint32_t n_groups = n * stride / 8u;
 	const uint32_t blocks = div_round_up(n_groups, EW_THREADS);
-	if (type == LossType::RelativeL2) {
-		TCNN_LAUNCH((k_loss<LossType::RelativeL2>), dim3(blocks), dim3(EW_THREADS), 0, stream, n_groups, stride, dims, loss_scale, prediction, target, data_pdf, values, gradients, block_sums, n_total);
-	} else {
-		TCNN_LAUNCH((k_loss<LossType::L2>), dim3(blocks), dim3(EW_THREADS), 0, stream, n_groups, stride, dims, loss_scale, prediction, target, data_pdf, values, gradients, block_sums, n_total);
-	}
+	TCNN_LAUNCH(k_loss, dim3(blocks), dim3(EW_THREADS), 0, stream, type, n_groups, stride, dims, loss_scale, prediction, target, data_pdf, values, gradients,
+	            block_sums, n_total);
 }
 
 // ------------------------------------------------------------------------------------------ reduce

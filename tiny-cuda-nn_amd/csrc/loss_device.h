@@ -1,26 +1,66 @@
 // loss_device.h -- per-element loss value and scaled gradient, shared by the stand-alone loss kernel
 // (elementwise_kernels.hip) and the fused MLP training kernel (mlp_kernels.hip) so that both produce the same bits.
-// Reference: include/tiny-cuda-nn/losses/relative_l2.h:40-86, l2.h:40-83.
+// Reference: include/tiny-cuda-nn/losses/{l2,relative_l2,l1,relative_l1,mape,smape,cross_entropy,variance_is}.h
+// (the element kernels at :40-80 of each); names as registered in src/loss.cu:57-65.
 #pragma once
 #include "tcnn_device.h"
+#if defined(TCNN_HOST_EMU)
+#include <math.h>
+#endif
 
 namespace tcnn_hip {
 
-enum class LossType : int { L2 = 0, RelativeL2 = 1 };
+enum class LossType : int { L2 = 0, RelativeL2 = 1, L1 = 2, RelativeL1 = 3, Mape = 4, Smape = 5, CrossEntropy = 6, Variance = 7 };
+constexpr int N_LOSS_TYPES = 8;
 
-// prediction: the fp16 network output widened to fp32.  Returns the fp16 gradient loss_scale * dL/dprediction / n_total
-// (relative_l2.h:80), `value` receives this element's share of the mean loss (relative_l2.h:77).
-template <LossType LOSS>
-TCNN_DEVICE half_t loss_element(float prediction, float target, float pdf, float n_total, float loss_scale, float& value) {
+// prediction: the fp16 network output widened to fp32.  Returns the fp16 gradient loss_scale * dL/dprediction / n_total,
+// `value` receives this element's share of the mean loss.  `type` is uniform over the launch.
+TCNN_DEVICE half_t loss_element(LossType type, float prediction, float target, float pdf, float n_total, float loss_scale, float& value) {
 	const float difference = prediction - target;
-	float gradient;
-	if (LOSS == LossType::RelativeL2) {
-		const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
-		value = difference * difference / prediction_sq_plus_epsilon / pdf / n_total;
-		gradient = 2 * difference / prediction_sq_plus_epsilon / pdf;
-	} else {
-		value = difference * difference / pdf / n_total;
-		gradient = 2 * difference / pdf;
+	float gradient;  // dL/dprediction before the 1 / n_total of the mean
+	switch (type) {
+		case LossType::RelativeL2: {  // relative_l2.h:70-80
+			const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
+			value = difference * difference / prediction_sq_plus_epsilon / pdf / n_total;
+			gradient = 2 * difference / prediction_sq_plus_epsilon / pdf;
+			break;
+		}
+		case LossType::L1:  // l1.h:69-74
+			value = fabsf(difference) / pdf / n_total;
+			gradient = copysignf(1.0f / pdf, difference);
+			break;
+		case LossType::RelativeL1: {  // relative_l1.h:69-76
+			const float scale = 1.0f / (fabsf(prediction) + 1e-2f) / pdf;
+			value = fabsf(difference) * scale / n_total;
+			gradient = copysignf(scale, difference);
+			break;
+		}
+		case LossType::Mape: {  // mape.h:69-77
+			const float scale = 1.0f / (fabsf(target) + 1e-2f) / pdf;
+			value = fabsf(difference) * scale / n_total;
+			gradient = copysignf(scale, difference);
+			break;
+		}
+		case LossType::Smape: {  // smape.h:69-77
+			const float scale = 1.0f / (0.5f * (fabsf(target) + fabsf(prediction)) + 1e-2f) / pdf;
+			value = fabsf(difference) * scale / n_total;
+			gradient = copysignf(scale, difference);
+			break;
+		}
+		case LossType::CrossEntropy: {  // cross_entropy.h:66-76: the factor already holds 1 / n_total
+			const float factor = -target / pdf / n_total;
+			value = factor * logf(prediction);
+			return to_half_rn(loss_scale * (factor / prediction));
+		}
+		case LossType::Variance: {  // variance_is.h:66-76
+			const float factor = target * target / pdf / n_total;
+			value = factor / prediction - factor / pdf;
+			return to_half_rn(loss_scale * (-factor / (prediction * prediction)));
+		}
+		default:  // L2, l2.h:69-74
+			value = difference * difference / pdf / n_total;
+			gradient = 2 * difference / pdf;
+			break;
 	}
 	return to_half_rn(loss_scale * gradient / n_total);
 }

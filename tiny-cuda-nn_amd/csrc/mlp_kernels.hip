@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 // caller's ForwardContext, the encoded input is read once.  Same MFMA fragments and the same rounding points as
 // k_mlp_forward -> k_loss -> k_mlp_backward, so the results are bit-identical to the unfused path.
 // =============================================================================================
-template <uint32_t WIDTH, uint32_t HM, LossType LOSS>
+template <uint32_t WIDTH, uint32_t HM>
 __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
                                                                 const half_t* __restrict__ params_t, const half_t* __restrict__ input,
                                                                 const MlpLossArgs la, half_t* __restrict__ output, half_t* __restrict__ dL_doutput,
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 					gy[r] = (half_t)0.0f;
 					if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
 						float value;
-						gy[r] = loss_element<LOSS>((float)o[r], tgt[q][r], pdf[q][r], n_total, la.loss_scale, value);
+						gy[r] = loss_element(la.type, (float)o[r], tgt[q][r], pdf[q][r], n_total, la.loss_scale, value);
 						loss_sum += value;
 					}
 				}
@@ -880,16 +880,9 @@ static void launch_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const
 	const uint32_t halves = m.in_width * SP + (HM + 1) * WIDTH * SP + 2 * S * LDW + 16 * SP + S * LDY + in_region;
 	const uint32_t lds_bytes = halves * (uint32_t)sizeof(half_t);
 	const uint32_t blocks = mlp_backward_n_partials(m, n);
-#define TCNN_TRAIN_LAUNCH(LOSS_)                                                                                                                  \
-	TCNN_SET_MAX_DYN_LDS((k_mlp_train<WIDTH, HM, LOSS_>), lds_bytes);                                                                             \
-	TCNN_LAUNCH((k_mlp_train<WIDTH, HM, LOSS_>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params, params_t, input, la, output, \
-	            dL_doutput, dL_dinput, partials, block_sums);
-	if (la.type == LossType::RelativeL2) {
-		TCNN_TRAIN_LAUNCH(LossType::RelativeL2)
-	} else {
-		TCNN_TRAIN_LAUNCH(LossType::L2)
-	}
-#undef TCNN_TRAIN_LAUNCH
+	TCNN_SET_MAX_DYN_LDS((k_mlp_train<WIDTH, HM>), lds_bytes);
+	TCNN_LAUNCH((k_mlp_train<WIDTH, HM>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params, params_t, input, la, output, dL_doutput,
+	            dL_dinput, partials, block_sums);
 }
 
 template <uint32_t WIDTH>

@@ -605,3 +605,60 @@ def test_losses_for_positive_predictions(loss):
         assert np.allclose(got, ref, rtol=2e-3, atol=1e-7)              # 1 / x and log on the device vs libm: an fp16 ulp at most
         assert np.mean(h_np(ctx.dL_doutput) == g_ref) > 0.99
         assert abs(tm.loss(ctx) - float(v_ref.sum(dtype=np.float64))) <= 1e-4 * abs(float(v_ref.sum(dtype=np.float64)))
+
+
+def test_wrapper_optimizers_ema_and_exponential_decay():
+    """instant-ngp style optimizer: Ema(ExponentialDecay(Adam)) -- optimizers/ema.h:45-141, exponential_decay.h:59-70.
+    The learning-rate schedule is checked through the oracle's Adam, the EMA bit-exactly on the GPU's own weights."""
+    import msgpack
+    T = tcnn()
+    cfg = config_hash(log2_hashmap_size=14)
+    adam = dict(cfg["optimizer"])
+    cfg["optimizer"] = {"otype": "Ema", "decay": 0.9, "nested": {"otype": "ExponentialDecay", "decay_start": 2, "decay_interval": 2, "decay_base": 0.5,
+                                                                 "nested": adam}}
+    tm, md = _trainer_and_oracle(dict(cfg, optimizer=adam), 3, 4)
+    del tm
+    tm = T.create_from_config(3, 4, cfg)
+    hp = tm.hyperparams()["optimizer"]
+    assert hp["otype"] == "EMA" and hp["nested"]["otype"] == "ExponentialDecay" and hp["nested"]["nested"]["otype"] == "Adam"
+    init = tm.params_full_precision.cpu().numpy().copy()
+    init[md.mlp.n_params:] *= 1.0e3
+    tm.set_params_full_precision(torch.from_numpy(init))
+    st = O.TrainState(md, init)
+    n = 2048
+    pos = positions(n, 3, seed=2)
+    tgt = targets_for(pos, 4)
+    x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(tgt).cuda()
+    ema = np.zeros(tm.n_params, np.float32)   # fp16 average, held as the fp32 value of the half
+    lr0, factor = adam["learning_rate"], 1.0
+    for step in range(6):
+        if step >= 2 and (step - 2) % 2 == 0:
+            factor *= 0.5
+        st.md.adam.learning_rate = np.float32(lr0) * np.float32(factor)
+        tm.training_step(x, t, want_context=False)
+        O.training_step(st, pos, tgt)
+        w16 = O.h2f(h_np(tm.params))
+        k = step + 1
+        old = np.float32(1 - np.float32(0.9 ** (k - 1)))
+        new = np.float32(1.0) / np.float32(1 - np.float32(0.9 ** k))
+        ema = O.h2f(O.f2h((ema * np.float32(0.9) * old + w16 * np.float32(1 - np.float32(0.9))) * new))
+        assert np.array_equal(O.h2f(h_np(tm.params_inference)), ema), f"EMA after step {k}"
+    assert abs(tm.hyperparams()["optimizer"]["nested"]["nested"]["learning_rate"] - lr0 * 0.25) < 1e-9
+    m, ref = tm.params_full_precision.cpu().numpy(), st.w32
+    assert np.percentile(np.abs(m - ref)[:md.mlp.n_params], 99) < 2e-3
+    # inference uses the EMA weights by default (object.h:214-271 use_inference_params = true), training the raw ones
+    y_ema = tm.inference(x)
+    raw = tm.params.clone()
+    assert not torch.equal(tm.params_inference, raw)
+    # snapshot: params_binary holds the INFERENCE parameters (trainer.h:448), the optimizer state nests like the reference's
+    doc = msgpack.unpackb(tm.serialize(serialize_optimizer=True), raw=False)
+    assert doc["params_binary"] == tm.params_inference.cpu().numpy().tobytes()
+    opt = doc["optimizer"]
+    assert set(opt) == {"nested", "weights_ema_binary"} and set(opt["nested"]) == {"learning_rate", "learning_rate_factor", "nested"}
+    assert opt["nested"]["learning_rate_factor"] == 0.25 and opt["nested"]["nested"]["current_step"] == 6
+    other = T.create_from_config(3, 4, cfg, seed=5)
+    other.deserialize(tm.serialize(serialize_optimizer=True))
+    assert torch.equal(other.params_inference, tm.params_inference) and other.optimizer_step_count == 6
+    assert torch.equal(other.inference(x), y_ema)
+    tm.update_hyperparams({"optimizer": {"decay": 0.5, "nested": {"decay_base": 0.1}}})
+    assert tm.hyperparams()["optimizer"]["decay"] == 0.5 and abs(tm.hyperparams()["optimizer"]["nested"]["decay_base"] - 0.1) < 1e-7

@@ -729,6 +729,16 @@ struct tcnn_trainable_model {
 	Model md;
 	LossType loss = LossType::RelativeL2;
 	AdamHyper adam;
+	// wrapper optimizers around Adam (optimizers/ema.h, exponential_decay.h), outermost first
+	std::vector<std::string> optimizer_order;  // e.g. {"Ema", "ExponentialDecay"}
+	bool ema = false, ema_full_precision = false;
+	float ema_decay = 0.99f;
+	half_t* params_ema = nullptr;  // custom_weights(): the inference parameters while EMA is on (trainer.h:497-500)
+	float* ema_tmp = nullptr;      // fp32 shadow of the average (full_precision)
+	bool lr_decay = false;
+	float decay_base = 0.1f, lr_factor = 1.0f, base_lr = 0.0f;
+	uint32_t decay_interval = 10000, decay_start = 10000, decay_end = 10000000;
+	half_t* inference_params() const { return ema ? params_ema : params; }
 	uint32_t optimizer_step = 0;
 	Pcg32 rng;
 	void* buffer = nullptr;  // [fp32 master | half params | half grads], trainer.h:76, 489-495
@@ -915,6 +925,57 @@ static void parse_adam(AdamHyper& h, const Json& p) {  // adam.h:221-281
 	h.skip_zero_grad_non_matrix_params = p.value("skip_zero_grad_non_matrix_params", h.skip_zero_grad_non_matrix_params);
 }
 
+// optimizer.cu:50-86 for the optimizers of this build: Adam, optionally inside Ema / ExponentialDecay wrappers.
+// `creating`: build the chain from the config; otherwise walk the existing chain (update_hyperparams, trainer.h:380-383).
+static void apply_optimizer_json(tcnn_trainable_model* tm, const Json& opts, bool creating) {
+	Json cur = opts;
+	size_t depth = 0;
+	for (;;) {
+		std::string otype = cur.value("otype", creating ? "Adam" : (depth < tm->optimizer_order.size() ? tm->optimizer_order[depth] : "Adam"));
+		if (equals_case_insensitive(otype, "Ema")) {
+			if (creating) {
+				if (tm->ema) throw std::runtime_error("Optimizer: nested Ema inside Ema is not supported");
+				tm->ema = true;
+				tm->optimizer_order.push_back("Ema");
+			} else if (depth >= tm->optimizer_order.size() || tm->optimizer_order[depth] != "Ema") {
+				throw std::runtime_error("update_hyperparams: optimizer structure does not match the trainer's");
+			}
+			tm->ema_decay = cur.value("decay", tm->ema_decay);
+			if (creating) tm->ema_full_precision = cur.value("full_precision", tm->ema_full_precision);
+		} else if (equals_case_insensitive(otype, "ExponentialDecay")) {
+			if (creating) {
+				if (tm->lr_decay) throw std::runtime_error("Optimizer: nested ExponentialDecay inside ExponentialDecay is not supported");
+				tm->lr_decay = true;
+				tm->optimizer_order.push_back("ExponentialDecay");
+			} else if (depth >= tm->optimizer_order.size() || tm->optimizer_order[depth] != "ExponentialDecay") {
+				throw std::runtime_error("update_hyperparams: optimizer structure does not match the trainer's");
+			}
+			tm->decay_base = cur.value("decay_base", tm->decay_base);
+			tm->decay_interval = cur.value("decay_interval", tm->decay_interval);
+			tm->decay_start = cur.value("decay_start", tm->decay_start);
+			tm->decay_end = cur.value("decay_end", tm->decay_end);
+			if (tm->decay_interval == 0) throw std::runtime_error("ExponentialDecay: decay_interval must be positive");
+		} else if (equals_case_insensitive(otype, "Adam")) {
+			const float lr_before = tm->adam.learning_rate;
+			parse_adam(tm->adam, cur);
+			if (tm->lr_decay) {
+				if (creating) {
+					tm->base_lr = tm->adam.learning_rate;  // exponential_decay.h:52
+				} else if (tm->adam.learning_rate != lr_before) {
+					tm->base_lr = tm->adam.learning_rate;  // the nested optimizer's learning rate was set directly
+					tm->adam.learning_rate = tm->base_lr * tm->lr_factor;
+				}
+			}
+			return;
+		} else {
+			throw std::runtime_error("Optimizer '" + otype + "' is not available in this build (supported: Adam, Ema, ExponentialDecay).");
+		}
+		if (!creating && !cur.contains("nested")) return;
+		cur = cur.value("nested", Json::object());
+		++depth;
+	}
+}
+
 static void refresh_hyper_json(tcnn_trainable_model* tm) {  // trainer.h:385-391, adam.h:283-302
 	Json o = Json::object();
 	o["otype"] = "Adam";
@@ -933,6 +994,24 @@ static void refresh_hyper_json(tcnn_trainable_model* tm) {  // trainer.h:385-391
 	o["optimize_matrix_params"] = tm->adam.optimize_matrix_params;
 	o["optimize_non_matrix_params"] = tm->adam.optimize_non_matrix_params;
 	o["skip_zero_grad_non_matrix_params"] = tm->adam.skip_zero_grad_non_matrix_params;
+	if (tm->lr_decay) o["learning_rate"] = tm->base_lr * tm->lr_factor;
+	for (size_t k = tm->optimizer_order.size(); k-- > 0;) {  // wrap inside-out (ema.h:181-188, exponential_decay.h:116-125)
+		Json wrapper = Json::object();
+		if (tm->optimizer_order[k] == "Ema") {
+			wrapper["otype"] = "EMA";
+			wrapper["nested"] = o;
+			wrapper["decay"] = tm->ema_decay;
+			wrapper["full_precision"] = tm->ema_full_precision;
+		} else {
+			wrapper["otype"] = "ExponentialDecay";
+			wrapper["nested"] = o;
+			wrapper["decay_base"] = tm->decay_base;
+			wrapper["decay_interval"] = tm->decay_interval;
+			wrapper["decay_start"] = tm->decay_start;
+			wrapper["decay_end"] = tm->decay_end;
+		}
+		o = wrapper;
+	}
 	Json l = Json::object();
 	l["otype"] = LOSS_NAMES[(int)tm->loss];
 	Json j = Json::object();
@@ -957,9 +1036,7 @@ int tcnn_create_from_config(uint32_t n_input_dims, uint32_t n_output_dims, const
 	const Json encoding_opts = config.value("encoding", Json::object());
 	const std::string loss_type = loss_opts.value("otype", "RelativeL2");  // loss.cu:81-83
 	tm->loss = string_to_loss(loss_type);
-	const std::string opt_type = optimizer_opts.value("otype", "Adam");  // optimizer.cu:50
-	if (!equals_case_insensitive(opt_type, "Adam")) throw std::runtime_error("Optimizer '" + opt_type + "' is not available in this build (supported: Adam).");
-	parse_adam(tm->adam, optimizer_opts);
+	apply_optimizer_json(tm.get(), optimizer_opts, /*creating=*/true);
 	tm->md = make_nwie(n_input_dims, n_output_dims, encoding_opts, network_opts);
 	refresh_hyper_json(tm.get());
 
@@ -976,6 +1053,14 @@ int tcnn_create_from_config(uint32_t n_input_dims, uint32_t n_output_dims, const
 	HIP_CHECK(hipMemset(tm->m1, 0, n * sizeof(float)));
 	HIP_CHECK(hipMemset(tm->m2, 0, n * sizeof(float)));
 	HIP_CHECK(hipMemset(tm->steps, 0, n * sizeof(uint32_t)));
+	if (tm->ema) {  // ema.h:90-102
+		HIP_CHECK(hipMalloc((void**)&tm->params_ema, n * sizeof(half_t)));
+		HIP_CHECK(hipMemset(tm->params_ema, 0, n * sizeof(half_t)));
+		if (tm->ema_full_precision) {
+			HIP_CHECK(hipMalloc((void**)&tm->ema_tmp, n * sizeof(float)));
+			HIP_CHECK(hipMemset(tm->ema_tmp, 0, n * sizeof(float)));
+		}
+	}
 	HIP_CHECK(hipMalloc((void**)&tm->loss_scratch, 1032 * sizeof(float)));
 	std::seed_seq seq{seed};
 	std::vector<uint32_t> seeds(2);
@@ -995,6 +1080,8 @@ void tcnn_trainable_model_destroy(tcnn_trainable_model_t* tm) {
 	(void)hipFree(tm->m1);
 	(void)hipFree(tm->m2);
 	(void)hipFree(tm->steps);
+	(void)hipFree(tm->params_ema);
+	(void)hipFree(tm->ema_tmp);
 	(void)hipFree(tm->loss_scratch);
 	delete tm;
 }
@@ -1002,16 +1089,16 @@ void tcnn_trainable_model_destroy(tcnn_trainable_model_t* tm) {
 int tcnn_trainer_forward(tcnn_trainable_model_t* tm, tcnn_stream_t stream_, float loss_scale, uint32_t n, const float* input, const float* target,
                          const float* data_pdf, int use_inference_params, int prepare_input_gradients, const void* external_dL_dy,
                          tcnn_train_context_t** ctx_out) {
-	(void)use_inference_params;  // Adam has no custom inference weights: params_inference == params (trainer.h:497-500)
 	TCNN_API_BEGIN
 	ProfilerGuard pg(tm->profiler.get());
 	hipStream_t stream = (hipStream_t)stream_;
+	const half_t* params = use_inference_params ? tm->inference_params() : tm->params;  // trainer.h:497-500 (EMA weights when Ema is on)
 	auto c = std::make_unique<tcnn_train_context>();
 	c->n = n;
 	c->stream = stream;
 	const uint32_t padded = tm->md.padded_output_width();
 	c->output = Scratch(stream, (size_t)padded * n * sizeof(half_t));
-	model_forward(stream, tm->md, n, input, c->output.as<half_t>(), tm->params, &c->model_ctx, prepare_input_gradients != 0);
+	model_forward(stream, tm->md, n, input, c->output.as<half_t>(), params, &c->model_ctx, prepare_input_gradients != 0);
 	if (external_dL_dy) {  // trainer.h:124-128
 		c->dL_doutput_ptr = (const half_t*)external_dL_dy;
 	} else {
@@ -1032,23 +1119,29 @@ int tcnn_trainer_forward(tcnn_trainable_model_t* tm, tcnn_stream_t stream_, floa
 
 int tcnn_trainer_backward(tcnn_trainable_model_t* tm, tcnn_stream_t stream, const tcnn_train_context_t* ctx, uint32_t n, const float* input,
                           float* dL_dinput, int use_inference_params, int gradient_mode) {
-	(void)use_inference_params;
 	TCNN_API_BEGIN
 	if (!ctx) throw std::runtime_error("Trainer::backward: missing forward context");
 	ProfilerGuard pg(tm->profiler.get());
 	model_backward((hipStream_t)stream, tm->md, ctx->model_ctx, n, dL_dinput, ctx->dL_doutput_ptr, tm->grads, input, ctx->output.as<half_t>(),
-	               tm->params, gradient_mode,
+	               use_inference_params ? tm->inference_params() : tm->params, gradient_mode,
 	               tm->lds_level_budget);
 	TCNN_API_END
 }
 
 int tcnn_trainer_optimizer_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale) {
 	TCNN_API_BEGIN
+	if (tm->lr_decay) {  // exponential_decay.h:59-70, with step() == the nested optimizer's step count before this step
+		const uint32_t step = tm->optimizer_step;
+		if (step == 0) tm->lr_factor = 1.0f;
+		if (step >= tm->decay_start && (step - tm->decay_start) % tm->decay_interval == 0 && step <= tm->decay_end) tm->lr_factor *= tm->decay_base;
+		tm->adam.learning_rate = tm->base_lr * tm->lr_factor;
+	}
 	++tm->optimizer_step;  // adam.h:159
 	ProfilerGuard pg(tm->profiler.get());
 	ProfScope prof((hipStream_t)stream, STAGE_ADAM);
 	adam_step((hipStream_t)stream, tm->adam, (uint32_t)tm->md.n_params(), (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master,
 	          tm->params, tm->grads, tm->m1, tm->m2, tm->steps);
+	if (tm->ema) ema_step((hipStream_t)stream, (uint32_t)tm->md.n_params(), tm->ema_decay, tm->optimizer_step, tm->params, tm->params_ema, tm->ema_tmp);
 	TCNN_API_END
 }
 
@@ -1058,8 +1151,9 @@ int tcnn_trainer_optimizer_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream
 static const bool g_fused_mlp_training = !(getenv("TCNN_FUSED_MLP_TRAINING") && std::string(getenv("TCNN_FUSED_MLP_TRAINING")) == "0");
 
 static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale, uint32_t n, const float* input, const float* target,
-                               const float* data_pdf, float* dL_dinput, int gradient_mode, tcnn_train_context_t** ctx_out) {
+                               const float* data_pdf, float* dL_dinput, int use_inference_params, int gradient_mode, tcnn_train_context_t** ctx_out) {
 	TCNN_API_BEGIN
+	const half_t* params = use_inference_params ? tm->inference_params() : tm->params;
 	ProfilerGuard pg(tm->profiler.get());
 	const Model& md = tm->md;
 	check_batch(n);
@@ -1089,14 +1183,14 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 		dy_dx = fc.dy_dx.as<float>();
 	}
 	fc.enc = Scratch(stream, (size_t)e.padded_output_width * n * sizeof(half_t));
-	encoding_forward(stream, md, n, input, tm->params + md.n_mlp_params(), fc.enc.as<half_t>(), /*soa=*/true, dy_dx);
+	encoding_forward(stream, md, n, input, params + md.n_mlp_params(), fc.enc.as<half_t>(), /*soa=*/true, dy_dx);
 
 	const bool need_denc = (want_grads && e.n_params > 0) || dL_dinput;
 	Scratch denc;
 	{
 		ProfScope prof(stream, STAGE_MLP_TRAIN);
 		Scratch params_t(stream, md.n_mlp_params() * sizeof(half_t));
-		mlp_transpose_weights(stream, md.net.mlp, tm->params, params_t.as<half_t>());
+		mlp_transpose_weights(stream, md.net.mlp, params, params_t.as<half_t>());
 		const uint32_t n_partials = mlp_backward_n_partials(md.net.mlp, n);
 		Scratch partials;
 		if (want_grads) partials = Scratch(stream, (size_t)n_partials * md.n_mlp_params() * sizeof(float));
@@ -1104,7 +1198,7 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 		c->n_block_sums = n_partials;
 		c->block_sums = Scratch(stream, (size_t)n_partials * sizeof(float));
 		const MlpLossArgs la = {tm->loss, target, data_pdf, md.output_width(), loss_scale, (uint32_t)n_total};
-		mlp_train(stream, md.net.mlp, n, tm->params, params_t.as<half_t>(), fc.enc.as<half_t>(), la, c->output.as<half_t>(), c->dL_doutput.as<half_t>(),
+		mlp_train(stream, md.net.mlp, n, params, params_t.as<half_t>(), fc.enc.as<half_t>(), la, c->output.as<half_t>(), c->dL_doutput.as<half_t>(),
 		          need_denc ? denc.as<half_t>() : nullptr, want_grads ? partials.as<float>() : nullptr, c->block_sums.as<float>());
 		if (want_grads) mlp_finalize_gradients(stream, (uint32_t)md.n_mlp_params(), n_partials, partials.as<float>(), tm->grads, accumulate);
 	}
@@ -1121,7 +1215,7 @@ int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
 	const float loss_scale = LOSS_SCALE_FP16;  // trainer.h:265
 	tcnn_train_context_t* ctx = nullptr;
 	if (g_fused_mlp_training && !external_dL_dy && target && tm->md.has_network && mlp_train_supported(tm->md.net.mlp)) {
-		int r = training_step_fused(tm, (hipStream_t)stream, loss_scale, n, input, target, data_pdf, dL_dinput, gradient_mode, &ctx);
+		int r = training_step_fused(tm, (hipStream_t)stream, loss_scale, n, input, target, data_pdf, dL_dinput, use_inference_params, gradient_mode, &ctx);
 		if (r == TCNN_OK && run_optimizer) r = tcnn_trainer_optimizer_step(tm, stream, loss_scale);
 		if (ctx_out && r == TCNN_OK) {
 			*ctx_out = ctx;
@@ -1156,12 +1250,11 @@ const void* tcnn_train_context_output(const tcnn_train_context_t* ctx) { return 
 const void* tcnn_train_context_dL_doutput(const tcnn_train_context_t* ctx) { return ctx->dL_doutput_ptr; }
 
 int tcnn_network_inference(tcnn_trainable_model_t* tm, tcnn_stream_t stream_, uint32_t n, const float* input, float* output, int use_inference_params) {
-	(void)use_inference_params;
 	TCNN_API_BEGIN
 	hipStream_t stream = (hipStream_t)stream_;
 	const uint32_t padded = tm->md.padded_output_width();
 	Scratch tmp(stream, (size_t)padded * n * sizeof(half_t));  // object.h:260
-	model_forward(stream, tm->md, n, input, tmp.as<half_t>(), tm->params, nullptr, false);
+	model_forward(stream, tm->md, n, input, tmp.as<half_t>(), use_inference_params ? tm->inference_params() : tm->params, nullptr, false);
 	trim_and_cast(stream, n, padded, tm->md.output_width(), tmp.as<half_t>(), output, tm->md.output_width(), 1u);  // object.h:269-270
 	TCNN_API_END
 }
@@ -1169,7 +1262,7 @@ int tcnn_network_inference(tcnn_trainable_model_t* tm, tcnn_stream_t stream_, ui
 size_t tcnn_trainer_n_params(const tcnn_trainable_model_t* tm) { return tm->md.n_params(); }
 float* tcnn_trainer_params_full_precision(tcnn_trainable_model_t* tm) { return tm->master; }
 void* tcnn_trainer_params(tcnn_trainable_model_t* tm) { return tm->params; }
-void* tcnn_trainer_params_inference(tcnn_trainable_model_t* tm) { return tm->params; }
+void* tcnn_trainer_params_inference(tcnn_trainable_model_t* tm) { return tm->inference_params(); }
 void* tcnn_trainer_param_gradients(tcnn_trainable_model_t* tm) { return tm->grads; }
 
 int tcnn_trainer_set_params_full_precision(tcnn_trainable_model_t* tm, const float* params, size_t n_params, int device_ptr) {
@@ -1202,6 +1295,13 @@ static Snapshot snapshot_shape(const tcnn_trainable_model* tm, bool with_optimiz
 	s.base_learning_rate = tm->adam.learning_rate;
 	s.first_moments.size = s.second_moments.size = n * sizeof(float);
 	s.param_steps.size = n * sizeof(uint32_t);
+	s.wrappers = tm->optimizer_order;
+	if (tm->ema) s.weights_ema.size = n * sizeof(half_t);
+	if (tm->lr_decay) {
+		s.base_learning_rate = tm->adam.learning_rate;  // Adam's own (already scaled) rate, adam.h:307
+		s.decay_learning_rate = tm->base_lr;
+		s.decay_learning_rate_factor = tm->lr_factor;
+	}
 	return s;
 }
 
@@ -1213,8 +1313,8 @@ int tcnn_trainer_serialize(tcnn_trainable_model_t* tm, int serialize_optimizer, 
 	if (buffer) {
 		if (capacity < needed) throw std::runtime_error("tcnn_trainer_serialize: buffer too small (" + std::to_string(capacity) + " < " + std::to_string(needed) + " bytes)");
 		HIP_CHECK(hipDeviceSynchronize());
-		std::vector<uint8_t> host_params(s.params.size), host_m1, host_m2, host_steps;
-		HIP_CHECK(hipMemcpy(host_params.data(), tm->params, s.params.size, hipMemcpyDeviceToHost));
+		std::vector<uint8_t> host_params(s.params.size), host_m1, host_m2, host_steps, host_ema;
+		HIP_CHECK(hipMemcpy(host_params.data(), tm->inference_params(), s.params.size, hipMemcpyDeviceToHost));  // trainer.h:448: params_inference
 		s.params.data = host_params.data();
 		if (s.has_optimizer) {
 			host_m1.resize(s.first_moments.size);
@@ -1226,6 +1326,11 @@ int tcnn_trainer_serialize(tcnn_trainable_model_t* tm, int serialize_optimizer, 
 			s.first_moments.data = host_m1.data();
 			s.second_moments.data = host_m2.data();
 			s.param_steps.data = host_steps.data();
+			if (tm->ema) {
+				host_ema.resize(s.weights_ema.size);
+				HIP_CHECK(hipMemcpy(host_ema.data(), tm->params_ema, host_ema.size(), hipMemcpyDeviceToHost));
+				s.weights_ema.data = host_ema.data();
+			}
 		}
 		const std::vector<uint8_t> bytes = snapshot_encode(s);
 		std::memcpy(buffer, bytes.data(), bytes.size());
@@ -1261,6 +1366,15 @@ int tcnn_trainer_deserialize(tcnn_trainable_model_t* tm, const void* data, size_
 		}
 		tm->optimizer_step = s.current_step;
 		tm->adam.learning_rate = s.base_learning_rate;
+		if (tm->ema) {  // ema.h:195-204
+			if (!s.weights_ema.present() || s.weights_ema.size != n * sizeof(half_t)) throw std::runtime_error("Trainer: EMA snapshot does not match the number of parameters");
+			HIP_CHECK(hipMemcpy(tm->params_ema, s.weights_ema.data, s.weights_ema.size, hipMemcpyHostToDevice));
+			if (tm->ema_tmp) cast_f16_to_f32(nullptr, n, tm->params_ema, tm->ema_tmp);
+		}
+		if (tm->lr_decay && s.has_decay) {  // exponential_decay.h:144-148
+			tm->base_lr = s.decay_learning_rate;
+			tm->lr_factor = s.decay_learning_rate_factor;
+		}
 		refresh_hyper_json(tm);
 	}
 	HIP_CHECK(hipDeviceSynchronize());
@@ -1270,7 +1384,7 @@ int tcnn_trainer_deserialize(tcnn_trainable_model_t* tm, const void* data, size_
 int tcnn_trainer_update_hyperparams(tcnn_trainable_model_t* tm, const char* json) {
 	TCNN_API_BEGIN
 	const Json j = Json::parse(json);
-	parse_adam(tm->adam, j.value("optimizer", Json::object()));
+	if (j.contains("optimizer")) apply_optimizer_json(tm, j.value("optimizer", Json::object()), /*creating=*/false);
 	refresh_hyper_json(tm);
 	TCNN_API_END
 }

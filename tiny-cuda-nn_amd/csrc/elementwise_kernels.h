@@ -79,6 +79,10 @@ struct AdamHyper {  // optimizers/adam.h:330-351 defaults
 	bool optimize_matrix_params = true, optimize_non_matrix_params = true, skip_zero_grad_non_matrix_params = true;
 };
 // optimizers/adam.h:48-127, 158-199.  current_step = optimizer step AFTER the increment.
+// optimizers/ema.h:45-141: weights_ema <- debiased EMA of weights after optimizer step `current_step` (>= 1);
+// tmp: fp32 shadow of the average (full_precision) or nullptr.
+void ema_step(hipStream_t stream, uint32_t n, float ema_decay, uint32_t current_step, const half_t* weights, half_t* weights_ema, float* tmp);
+
 void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale,
                uint32_t current_step, float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2,
                uint32_t* param_steps);

@@ -3,6 +3,8 @@
 // Build with -ffp-contract=off (loss / Adam arithmetic is checked against the CPU oracle).
 #include "elementwise_kernels.h"
 
+#include <cmath>
+
 #include <stdexcept>
 
 namespace tcnn_hip {
@@ -161,6 +163,43 @@ void reduce_sum(hipStream_t stream, const float* in, size_t n, float* workspace,
 	const uint32_t blocks = (uint32_t)(n == 0 ? 1 : (div_round_up(n, (size_t)EW_THREADS) < 1024 ? div_round_up(n, (size_t)EW_THREADS) : 1024));
 	TCNN_LAUNCH(k_reduce_partial, dim3(blocks), dim3(EW_THREADS), 0, stream, in, n, workspace);
 	TCNN_LAUNCH(k_reduce_partial, dim3(1), dim3(EW_THREADS), 0, stream, (const float*)workspace, (size_t)blocks, out);
+}
+
+// ------------------------------------------------------------------------------------------ EMA of the weights
+// optimizers/ema.h:45-81: debiased exponential moving average of the fp16 weights, kept in fp16 (tmp == nullptr) or
+// in an fp32 shadow (full_precision).  8 weights per lane.
+__global__ void __launch_bounds__(EW_THREADS) k_ema_step(uint32_t n, float ema_decay, float ema_debias_old, float ema_debias_new,
+                                                          const half_t* __restrict__ weights, half_t* __restrict__ weights_ema, float* __restrict__ tmp) {
+	const uint32_t i0 = (blockIdx.x * EW_THREADS + threadIdx.x) * 8u;
+	if (i0 >= n) return;
+	if (i0 + 8u <= n) {
+		const h8 w = *(const h8*)(weights + i0);
+		h8 e = *(const h8*)(weights_ema + i0);
+#pragma unroll
+		for (uint32_t j = 0; j < 8; ++j) {
+			const float old = tmp ? tmp[i0 + j] : (float)e[j];
+			const float filtered = (old * ema_decay * ema_debias_old + (float)w[j] * (1 - ema_decay)) * ema_debias_new;
+			if (tmp) tmp[i0 + j] = filtered;
+			e[j] = (half_t)filtered;
+		}
+		*(h8*)(weights_ema + i0) = e;
+	} else {
+		for (uint32_t i = i0; i < n; ++i) {
+			const float old = tmp ? tmp[i] : (float)weights_ema[i];
+			const float filtered = (old * ema_decay * ema_debias_old + (float)weights[i] * (1 - ema_decay)) * ema_debias_new;
+			if (tmp) tmp[i] = filtered;
+			weights_ema[i] = (half_t)filtered;
+		}
+	}
+}
+
+void ema_step(hipStream_t stream, uint32_t n, float ema_decay, uint32_t current_step, const half_t* weights, half_t* weights_ema, float* tmp) {
+	if (n == 0) return;
+	// ema.h:113-114 (float pow through double, as std::pow(float, unsigned) does)
+	const float ema_debias_old = 1 - (float)std::pow((double)ema_decay, (double)(current_step - 1));
+	const float ema_debias_new = 1.0f / (1 - (float)std::pow((double)ema_decay, (double)current_step));
+	TCNN_LAUNCH(k_ema_step, dim3(div_round_up(div_round_up(n, 8u), EW_THREADS)), dim3(EW_THREADS), 0, stream, n, ema_decay, ema_debias_old,
+	            ema_debias_new, weights, weights_ema, tmp);
 }
 
 // ------------------------------------------------------------------------------------------ Adam

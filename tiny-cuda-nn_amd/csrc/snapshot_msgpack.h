@@ -35,6 +35,12 @@ struct Snapshot {
 	uint32_t current_step = 0;
 	float base_learning_rate = 0.f;
 	SnapshotBlob first_moments, second_moments, param_steps;
+	// wrapper optimizers, outermost first ("Ema" / "ExponentialDecay"): each nests the next one's state under "nested"
+	// (ema.h:190-205: {"nested", "weights_ema_binary"}; exponential_decay.h:135-148: {"nested", "learning_rate", "learning_rate_factor"})
+	std::vector<std::string> wrappers;
+	SnapshotBlob weights_ema;
+	bool has_decay = false;
+	float decay_learning_rate = 0.f, decay_learning_rate_factor = 1.f;
 };
 
 namespace msgpack_detail {
@@ -220,6 +226,8 @@ struct Reader {
 
 namespace msgpack_detail {
 inline void write_snapshot(Writer& w, const Snapshot& s);
+inline void write_optimizer(Writer& w, const Snapshot& s, size_t depth);
+inline void read_optimizer(Reader& r, Snapshot& s);
 }
 
 // Bytes snapshot_encode() will produce; only the blob SIZES of `s` are read.
@@ -238,20 +246,56 @@ inline std::vector<uint8_t> snapshot_encode(const Snapshot& s) {
 	return out;
 }
 
+// keys of every map in lexicographic order, as nlohmann's std::map emits them
+inline void msgpack_detail::write_optimizer(Writer& w, const Snapshot& s, size_t depth) {
+	if (depth < s.wrappers.size()) {
+		if (s.wrappers[depth] == "Ema") {
+			w.map(2);
+			w.str("nested"); write_optimizer(w, s, depth + 1);
+			w.str("weights_ema_binary"); w.bin(s.weights_ema.data, s.weights_ema.size);
+		} else {  // ExponentialDecay
+			w.map(3);
+			w.str("learning_rate"); w.real(double(s.decay_learning_rate));
+			w.str("learning_rate_factor"); w.real(double(s.decay_learning_rate_factor));
+			w.str("nested"); write_optimizer(w, s, depth + 1);
+		}
+		return;
+	}
+	w.map(5);  // Adam, adam.h:304-312
+	w.str("base_learning_rate"); w.real(double(s.base_learning_rate));
+	w.str("current_step"); w.uint(s.current_step);
+	w.str("first_moments_binary"); w.bin(s.first_moments.data, s.first_moments.size);
+	w.str("param_steps_binary"); w.bin(s.param_steps.data, s.param_steps.size);
+	w.str("second_moments_binary"); w.bin(s.second_moments.data, s.second_moments.size);
+}
+
 inline void msgpack_detail::write_snapshot(Writer& w, const Snapshot& s) {
 	w.map(s.has_optimizer ? 4 : 3);
 	w.str("n_params"); w.uint(s.n_params);
 	if (s.has_optimizer) {
 		w.str("optimizer");
-		w.map(5);
-		w.str("base_learning_rate"); w.real(double(s.base_learning_rate));
-		w.str("current_step"); w.uint(s.current_step);
-		w.str("first_moments_binary"); w.bin(s.first_moments.data, s.first_moments.size);
-		w.str("param_steps_binary"); w.bin(s.param_steps.data, s.param_steps.size);
-		w.str("second_moments_binary"); w.bin(s.second_moments.data, s.second_moments.size);
+		write_optimizer(w, s, 0);
 	}
 	w.str("params_binary"); w.bin(s.params.data, s.params.size);
 	w.str("params_type"); w.str(s.params_type);
+}
+
+// one optimizer state map; wrapper optimizers hold the next one under "nested" -- their own keys are distinct, so the
+// fields are collected by name whatever the nesting order
+inline void msgpack_detail::read_optimizer(Reader& r, Snapshot& s) {
+	for (uint32_t k = 0, m = r.map_header(); k < m; ++k) {
+		const std::string okey = r.str();
+		if (okey == "current_step") s.current_step = uint32_t(r.unsigned_integer());
+		else if (okey == "base_learning_rate") s.base_learning_rate = float(r.number());
+		else if (okey == "first_moments_binary") r.blob(s.first_moments);
+		else if (okey == "second_moments_binary") r.blob(s.second_moments);
+		else if (okey == "param_steps_binary") r.blob(s.param_steps);
+		else if (okey == "weights_ema_binary") r.blob(s.weights_ema);
+		else if (okey == "learning_rate") { s.decay_learning_rate = float(r.number()); s.has_decay = true; }
+		else if (okey == "learning_rate_factor") s.decay_learning_rate_factor = float(r.number());
+		else if (okey == "nested" && r.is_map()) read_optimizer(r, s);
+		else r.skip();
+	}
 }
 
 // Blobs point into [data, data + size) unless they came from a {"bytes":[...]} array.
@@ -266,15 +310,7 @@ inline Snapshot snapshot_decode(const uint8_t* data, size_t size) {
 		else if (key == "params_binary") r.blob(s.params);
 		else if (key == "optimizer") {
 			s.has_optimizer = true;
-			for (uint32_t k = 0, m = r.map_header(); k < m; ++k) {
-				const std::string okey = r.str();
-				if (okey == "current_step") s.current_step = uint32_t(r.unsigned_integer());
-				else if (okey == "base_learning_rate") s.base_learning_rate = float(r.number());
-				else if (okey == "first_moments_binary") r.blob(s.first_moments);
-				else if (okey == "second_moments_binary") r.blob(s.second_moments);
-				else if (okey == "param_steps_binary") r.blob(s.param_steps);
-				else r.skip();
-			}
+			msgpack_detail::read_optimizer(r, s);
 		} else r.skip();
 	}
 	(void)have_type;  // absent -> the trainer's own parameter type, trainer.h:458

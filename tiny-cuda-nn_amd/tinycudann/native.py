@@ -129,6 +129,11 @@ class TrainableModel:
         return self._tensor(_lib.tcnn_trainer_params(self._h), "<f2")
 
     @property
+    def params_inference(self):
+        """Trainer::params_inference (trainer.h:497-500): the EMA weights when the optimizer is wrapped in Ema, else `params`."""
+        return self._tensor(_lib.tcnn_trainer_params_inference(self._h), "<f2")
+
+    @property
     def param_gradients(self):
         return self._tensor(_lib.tcnn_trainer_param_gradients(self._h), "<f2")
 

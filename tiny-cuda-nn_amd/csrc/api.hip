@@ -1388,7 +1388,10 @@ int tcnn_trainer_update_hyperparams(tcnn_trainable_model_t* tm, const char* json
 	refresh_hyper_json(tm);
 	TCNN_API_END
 }
-const char* tcnn_trainer_hyperparams_json(tcnn_trainable_model_t* tm) { return tm->hyper_json.c_str(); }
+const char* tcnn_trainer_hyperparams_json(tcnn_trainable_model_t* tm) {
+	refresh_hyper_json(tm);  // the learning rate moves with the ExponentialDecay schedule
+	return tm->hyper_json.c_str();
+}
 uint32_t tcnn_trainer_optimizer_step_count(const tcnn_trainable_model_t* tm) { return tm->optimizer_step; }
 uint32_t tcnn_trainer_padded_output_width(const tcnn_trainable_model_t* tm) { return tm->md.padded_output_width(); }
 uint32_t tcnn_trainer_n_mlp_params(const tcnn_trainable_model_t* tm) { return (uint32_t)tm->md.n_mlp_params(); }

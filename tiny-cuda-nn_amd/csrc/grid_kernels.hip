@@ -499,14 +499,29 @@ constexpr uint32_t ZERO_BLOCK_HALVES = 2048;  // 4 KiB per zeroing block
 
 // record = {entry index within the level, payload}: payload = F halves packed in pairs (F == 1: one fp32, the
 // reference's grad_t for a single feature is float, grid.h:665)
+//
+// Queue unit: a PAIR of records -- the two corners that differ in dimension 0 only -- in 1 + 2 * PAYLOAD_WORDS words:
+//   word 0 = index of the first entry (25 bits) | t << 25 | has_second << 30, then the two payloads.
+// The second entry is DERIVED: dense-indexed levels: index + 1 (wrapping at the table size); hashed levels (prime[0] == 1,
+// power-of-two table): index ^ (2^(t+1) - 1), t = number of trailing one bits of the cell's x coordinate.  12 bytes per
+// pair for F == 2 instead of 16: the queues are the backward pass's HBM traffic.
 template <uint32_t F>
 struct BucketRecord {
 	static constexpr uint32_t PAYLOAD_WORDS = (F + 1) / 2;
-	static constexpr uint32_t WORDS = 1 + PAYLOAD_WORDS;
+	static constexpr uint32_t WORDS = 1 + PAYLOAD_WORDS;           // overflow-list record: one entry
+	static constexpr uint32_t PAIR_WORDS = 1 + 2 * PAYLOAD_WORDS;  // queue record: two entries
 };
+constexpr uint32_t PAIR_INDEX_BITS = 25, PAIR_INDEX_MASK = (1u << PAIR_INDEX_BITS) - 1u, PAIR_HAS_SECOND = 1u << 30;
+template <uint32_t D>
+TCNN_DEVICE uint32_t pair_second_index(const Level<D>& lv, uint32_t word0) {
+	const uint32_t i0 = word0 & PAIR_INDEX_MASK;
+	if (lv.fast) return (i0 ^ ((2u << ((word0 >> PAIR_INDEX_BITS) & 31u)) - 1u)) & lv.mask;
+	const uint32_t i1 = i0 + 1u;
+	return i1 == lv.hashmap_size ? 0u : i1;
+}
 // samples per thread of pass A: as many as fit the staging area, at least one
 TCNN_HOST_DEVICE constexpr uint32_t bucket_spt(uint32_t D, uint32_t F) {
-	const uint32_t per_sample_bytes = (1u << D) * (1u + (F + 1) / 2) * 4u;
+	const uint32_t per_sample_bytes = ((1u << D) / 2u) * (1u + 2u * ((F + 1) / 2)) * 4u;
 	const uint32_t spt = BUCKET_STAGE_BYTES / (per_sample_bytes * BUCKET_THREADS);
 	return spt < 1u ? 1u : (spt > 8u ? 8u : spt);
 }
@@ -520,7 +535,7 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
                                                                          const half_t* __restrict__ dL_dy, uint32_t* __restrict__ counters,
                                                                          uint32_t* __restrict__ queues, uint32_t* __restrict__ overflow,
                                                                          half_t* __restrict__ grid_gradient) {
-	constexpr uint32_t N_CORNERS = 1u << D, PW = BucketRecord<F>::PAYLOAD_WORDS, W = BucketRecord<F>::WORDS;
+	constexpr uint32_t N_CORNERS = 1u << D, PW = BucketRecord<F>::PAYLOAD_WORDS, W = BucketRecord<F>::WORDS, PWP = BucketRecord<F>::PAIR_WORDS;
 	constexpr uint32_t N_PAIRS_PER_SAMPLE = N_CORNERS / 2;
 	constexpr uint32_t SPT = bucket_spt(D, F), TILE = SPT * BUCKET_THREADS, N_PAIR = TILE * N_PAIRS_PER_SAMPLE;
 	constexpr uint32_t INVALID = BUCKET_INVALID_INDEX;
@@ -548,8 +563,8 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 	// neighbours (dense index +1; hashed: prime[0] == 1, so the indices differ in the low bits only) and therefore
 	// share a bucket except once in ~2^shift pairs: the second record of such a pair is routed through the overflow
 	// list instead.  Halves the ranking / reordering work per corner; a pair is 16 bytes for F == 2.
-	uint32_t* stage = (uint32_t*)lds_raw;   // [N_PAIR][2 * W]
-	uint32_t* cnt = stage + N_PAIR * 2 * W; // [nb] pairs of this tile per bucket
+	uint32_t* stage = (uint32_t*)lds_raw;   // [N_PAIR][PWP]
+	uint32_t* cnt = stage + N_PAIR * PWP;   // [nb] pairs of this tile per bucket
 	uint32_t* delta = cnt + nb;             // [nb] exclusive prefix of cnt, later (queue position - staging position)
 	uint32_t* part = delta + nb;            // [64] scan scratch of wave 0
 	uint32_t* total_p = part + 64;          // [1]
@@ -614,9 +629,19 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 						ridx[s][2 * pr + 1] = INVALID;
 					} else if (lv.nearest) {
 						ridx[s][2 * pr + 1] = INVALID;
-					} else if ((ridx[s][2 * pr + 1] >> shift) != bucket) {
-						push_overflow(ridx[s][2 * pr + 1], pay[s][2 * pr + 1]);
-						ridx[s][2 * pr + 1] = INVALID;
+					} else {
+						// word 0 of the pair; the second entry must be derivable from it AND live in the same bucket,
+						// otherwise (about one pair in 2^shift) it travels through the overflow list
+						uint32_t t = 0;
+						if constexpr (FAST) t = (uint32_t)__builtin_popcount(c.hlo[0] ^ c.hhi[0]) - 1u;
+						const uint32_t word0 = ridx[s][2 * pr] | (t << PAIR_INDEX_BITS) | PAIR_HAS_SECOND;
+						const uint32_t i1 = ridx[s][2 * pr + 1];
+						if ((i1 >> shift) != bucket || pair_second_index<D>(lv, word0) != i1) {
+							push_overflow(i1, pay[s][2 * pr + 1]);
+							ridx[s][2 * pr + 1] = INVALID;
+						} else {
+							ridx[s][2 * pr] = word0;
+						}
 					}
 					rank[s][pr] = live ? atomic_add_u32(&cnt[bucket], 1u) : 0u;
 				}
@@ -664,19 +689,14 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 		for (uint32_t s = 0; s < SPT; ++s) {
 #pragma unroll
 			for (uint32_t pr = 0; pr < N_PAIRS_PER_SAMPLE; ++pr) {
-				const uint32_t i0 = ridx[s][2 * pr], i1 = ridx[s][2 * pr + 1];
-				if (i0 == INVALID) continue;
-				const uint32_t pos = delta[i0 >> shift] + rank[s][pr];
-				if constexpr (W == 2) {
-					*(u4*)&stage[pos * 4] = u4{i0, pay[s][2 * pr][0], i1, pay[s][2 * pr + 1][0]};
-				} else {
-					stage[pos * 2 * W] = i0;
-					stage[pos * 2 * W + W] = i1;
+				const uint32_t word0 = ridx[s][2 * pr];  // index | t | has_second (INVALID: no pair)
+				if (word0 == INVALID) continue;
+				const uint32_t pos = delta[(word0 & PAIR_INDEX_MASK) >> shift] + rank[s][pr];
+				stage[pos * PWP] = word0;
 #pragma unroll
-					for (uint32_t p = 0; p < PW; ++p) {
-						stage[pos * 2 * W + 1 + p] = pay[s][2 * pr][p];
-						stage[pos * 2 * W + W + 1 + p] = pay[s][2 * pr + 1][p];
-					}
+				for (uint32_t p = 0; p < PW; ++p) {
+					stage[pos * PWP + 1 + p] = pay[s][2 * pr][p];
+					stage[pos * PWP + 1 + PW + p] = pay[s][2 * pr + 1][p];
 				}
 			}
 		}
@@ -699,32 +719,20 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 
 		// ---- append the runs to the bucket queues: consecutive threads -> consecutive pairs
 		const uint32_t cap = plan.capacity[j];
-		uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)chunk * nb * cap) * 2 * W;
+		uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)chunk * nb * cap) * PWP;
 		for (uint32_t t = threadIdx.x; t < total; t += BUCKET_THREADS) {
-			uint32_t rec[2 * W];
-			if constexpr (W == 2) {
-				const u4 r = *(const u4*)&stage[t * 4];
-				rec[0] = r[0];
-				rec[1] = r[1];
-				rec[2] = r[2];
-				rec[3] = r[3];
-			} else {
+			uint32_t rec[PWP];
 #pragma unroll
-				for (uint32_t w = 0; w < 2 * W; ++w) rec[w] = stage[t * 2 * W + w];
-			}
-			const uint32_t b = rec[0] >> shift;
+			for (uint32_t w = 0; w < PWP; ++w) rec[w] = stage[t * PWP + w];
+			const uint32_t b = (rec[0] & PAIR_INDEX_MASK) >> shift;
 			const uint32_t pos = t + delta[b];  // wraps like the subtraction above
 			if (pos < cap) {
-				uint32_t* dst = q + ((size_t)b * cap + pos) * 2 * W;
-				if constexpr (W == 2) {
-					*(u4*)dst = u4{rec[0], rec[1], rec[2], rec[3]};
-				} else {
+				uint32_t* dst = q + ((size_t)b * cap + pos) * PWP;
 #pragma unroll
-					for (uint32_t w = 0; w < 2 * W; ++w) dst[w] = rec[w];
-				}
+				for (uint32_t w = 0; w < PWP; ++w) dst[w] = rec[w];
 			} else {
-				push_overflow(rec[0], &rec[1]);
-				if (rec[W] != INVALID) push_overflow(rec[W], &rec[W + 1]);
+				push_overflow(rec[0] & PAIR_INDEX_MASK, &rec[1]);
+				if (rec[0] & PAIR_HAS_SECOND) push_overflow(pair_second_index<D>(lv, rec[0]), &rec[1 + PW]);
 			}
 		}
 		__syncthreads();  // the staging area and the offsets are reused by the next tile
@@ -743,7 +751,7 @@ template <uint32_t D, uint32_t F>
 TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t level, uint32_t j, uint32_t bucket, uint32_t chunk,
                               const BucketPlan& plan, uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues,
                               half_t* __restrict__ grid_gradient, bool accumulate, unsigned char* lds_raw) {
-	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, W = BucketRecord<F>::WORDS;
+	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, PWP = BucketRecord<F>::PAIR_WORDS;
 	const uint32_t entries_per_bucket = 1u << plan.shift;
 	const uint32_t slice_begin = bucket * entries_per_bucket;
 	const uint32_t slice_count = slice_begin < lv.hashmap_size ? min(entries_per_bucket, lv.hashmap_size - slice_begin) : 0u;
@@ -751,7 +759,7 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 	const uint32_t cap = plan.capacity[j], n_chunks = plan.n_chunks[j];
 	const uint32_t queue = chunk * plan.n_buckets[j] + bucket;
 	const uint32_t count = min(counters[plan.counter_base[j] + queue], cap);  // in flight while the table is cleared
-	const uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)queue * cap) * 2 * W;  // `count` PAIRS of records
+	const uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)queue * cap) * PWP;  // `count` PAIRS of records
 	for (uint32_t e = threadIdx.x; e < slice_count * F / 2; e += SLICED_THREADS) ((u4*)lds_raw)[e] = u4{0u, 0u, 0u, 0u};  // slice_count * F is even
 	__syncthreads();
 
@@ -768,38 +776,23 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 			}
 		}
 	};
-	if constexpr (W == 2) {
-		// one pair per 16-byte load, U loads in flight per lane: the queue is streamed at memory speed, not at one
+	{
+		// U pair records (12 bytes each for F == 2) in flight per lane: the queue is streamed at memory speed, not at one
 		// round trip per record
-		constexpr uint32_t U = 8;
-		const u4* __restrict__ q4 = (const u4*)q;  // queues start on 256-byte boundaries
+		constexpr uint32_t U = PWP <= 3 ? 8 : (PWP <= 5 ? 4 : 2);
 		for (uint32_t base = threadIdx.x; base < count; base += SLICED_THREADS * U) {
-			u4 r[U];
-#pragma unroll
-			for (uint32_t u = 0; u < U; ++u) r[u] = q4[min(base + u * SLICED_THREADS, count - 1u)];
-#pragma unroll
-			for (uint32_t u = 0; u < U; ++u) {
-				if (base + u * SLICED_THREADS >= count) continue;
-				const uint32_t p0[1] = {r[u][1]}, p1[1] = {r[u][3]};
-				add_record(r[u][0], p0);
-				if (r[u][2] != BUCKET_INVALID_INDEX) add_record(r[u][2], p1);
-			}
-		}
-	} else {
-		constexpr uint32_t U = 2;  // pairs in flight per lane
-		for (uint32_t base = threadIdx.x; base < count; base += SLICED_THREADS * U) {
-			uint32_t rec[U][2 * W];
+			uint32_t rec[U][PWP];
 #pragma unroll
 			for (uint32_t u = 0; u < U; ++u) {
 				const uint32_t t = min(base + u * SLICED_THREADS, count - 1u);
 #pragma unroll
-				for (uint32_t w = 0; w < 2 * W; ++w) rec[u][w] = q[(size_t)t * 2 * W + w];
+				for (uint32_t w = 0; w < PWP; ++w) rec[u][w] = q[(size_t)t * PWP + w];
 			}
 #pragma unroll
 			for (uint32_t u = 0; u < U; ++u) {
 				if (base + u * SLICED_THREADS >= count) continue;
-				add_record(rec[u][0], &rec[u][1]);
-				if (rec[u][W] != BUCKET_INVALID_INDEX) add_record(rec[u][W], &rec[u][W + 1]);
+				add_record(rec[u][0] & PAIR_INDEX_MASK, &rec[u][1]);
+				if (rec[u][0] & PAIR_HAS_SECOND) add_record(pair_second_index<D>(lv, rec[u][0]), &rec[u][1 + PW]);
 			}
 		}
 	}
@@ -1040,7 +1033,7 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 		const uint32_t n_fixed = div_round_up(entries, cap_fixed);
 		const uint32_t n_buckets = div_round_up(entries, 1u << bucket_shift);
 		Item it = {l, SLICE_FIXED64, n_fixed, 1u, 0u};
-		if (bucketed && bk.n_levels < MAX_BUCKET_LEVELS && n_buckets <= MAX_BUCKETS_PER_LEVEL) {
+		if (bucketed && bk.n_levels < MAX_BUCKET_LEVELS && n_buckets <= MAX_BUCKETS_PER_LEVEL && entries <= (1u << PAIR_INDEX_BITS)) {
 			// corners are derived once, binned by (table slice, sample chunk), accumulated by the queue's owner.
 			// Large tables: one owner per slice (plain stores).  Small tables have few slices: the samples are also
 			// split so that an owner sees ~32 Ki records; the owners of a slice then combine with packed-half atomics.
@@ -1092,7 +1085,7 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 	bk.overflow_counter = n_counters;
 	bk.overflow_capacity = (uint32_t)n_records;
 	bp.n_counters = bk.n_levels ? n_counters + 2 : 0;
-	bp.overflow_offset = next_multiple<size_t>(n_queue_records * 2 * record_words * sizeof(uint32_t), 256);  // n_queue_records counts pairs
+	bp.overflow_offset = next_multiple<size_t>(n_queue_records * (2 * record_words - 1) * sizeof(uint32_t), 256);  // n_queue_records counts pairs
 	bp.workspace_bytes = bk.n_levels ? bp.overflow_offset + next_multiple<size_t>(n_records * (record_words + 1) * sizeof(uint32_t), 256) : 0;
 
 	// long passes first (bucket owners, float slices), the short work (fixed-point chunks, atomic tiles) fills the tail
@@ -1152,7 +1145,8 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 		for (uint32_t j = 0; j < bk.n_levels; ++j) max_buckets = std::max(max_buckets, bk.n_buckets[j]);
 #define BSCATTER(D_, F_)                                                                                                                      \
 	{                                                                                                                                         \
-		const uint32_t lds = bucket_spt(D_, F_) * BUCKET_THREADS * (1u << D_) * BucketRecord<F_>::WORDS * 4u + (2u * max_buckets + WAVE + 4u) * 4u;       \
+		const uint32_t lds = bucket_spt(D_, F_) * BUCKET_THREADS * ((1u << D_) / 2u) * BucketRecord<F_>::PAIR_WORDS * 4u +                          \
+		                     (2u * max_buckets + WAVE + 4u) * 4u;                                                                             \
 		TCNN_SET_MAX_DYN_LDS((k_grid_bucket_scatter<D_, F_>), lds);                                                                           \
 		TCNN_LAUNCH((k_grid_bucket_scatter<D_, F_>), dim3(scatter_blocks), dim3(BUCKET_THREADS), lds, stream, meta, io, bk, dL_dy, counters,  \
 		            queues, overflow, grid_gradient);                                                                                         \

@@ -12,8 +12,17 @@ namespace tcnn_hip {
 enum class Activation : int { None = 0, ReLU = 1, LeakyReLU = 2, Exponential = 3, Sigmoid = 4, Squareplus = 5, Softplus = 6, Tanh = 7 };
 constexpr float K_ACT = 10.0f;  // common_device.h:108
 
+// The fused kernels evaluate activations at dozens of unrolled sites: ReLU / None stay inline, everything else is ONE
+// out-of-line copy (inlining the transcendental bodies everywhere doubled the training kernel's run time through
+// instruction-cache misses).
+#if defined(TCNN_HOST_EMU)
+#define TCNN_DEVICE_NOINLINE inline
+#else
+#define TCNN_DEVICE_NOINLINE __device__ __attribute__((noinline))
+#endif
+
 // activation of a pre-activation accumulator (fp32); the caller rounds the result to fp16 once
-TCNN_DEVICE float act_forward(uint32_t act, float x) {
+TCNN_DEVICE_NOINLINE float act_forward_general(uint32_t act, float x) {
 	switch ((Activation)act) {
 		case Activation::ReLU: return x > 0.0f ? x : 0.0f;
 		case Activation::LeakyReLU: return x * (x > 0.0f ? 1.0f : 0.01f);
@@ -29,9 +38,15 @@ TCNN_DEVICE float act_forward(uint32_t act, float x) {
 	}
 }
 
+TCNN_DEVICE float act_forward(uint32_t act, float x) {
+	if (act == (uint32_t)Activation::ReLU) return x > 0.0f ? x : 0.0f;
+	if (act == (uint32_t)Activation::None) return x;
+	return act_forward_general(act, x);
+}
+
 // dL/d(pre-activation) = v * f'(x) with f' written in terms of the stored fp16 post-activation value; the factor is
 // rounded to fp16 like the reference's (T)(...) before the multiply.  ReLU keeps the select form (exact, no -0).
-TCNN_DEVICE float act_backward(uint32_t act, float v, half_t forward_value) {
+TCNN_DEVICE_NOINLINE float act_backward_general(uint32_t act, float v, half_t forward_value) {
 	const float y = (float)forward_value;
 	float factor;
 	switch ((Activation)act) {
@@ -49,6 +64,12 @@ TCNN_DEVICE float act_backward(uint32_t act, float v, half_t forward_value) {
 		default: return v;
 	}
 	return v * (float)(half_t)factor;
+}
+
+TCNN_DEVICE float act_backward(uint32_t act, float v, half_t forward_value) {
+	if (act == (uint32_t)Activation::ReLU) return forward_value > (half_t)0.0f ? v : 0.0f;
+	if (act == (uint32_t)Activation::None) return v;
+	return act_backward_general(act, v, forward_value);
 }
 
 }  // namespace tcnn_hip

@@ -15,7 +15,12 @@ constexpr int N_LOSS_TYPES = 8;
 
 // prediction: the fp16 network output widened to fp32.  Returns the fp16 gradient loss_scale * dL/dprediction / n_total,
 // `value` receives this element's share of the mean loss.  `type` is uniform over the launch.
-TCNN_DEVICE half_t loss_element(LossType type, float prediction, float target, float pdf, float n_total, float loss_scale, float& value) {
+#if defined(TCNN_HOST_EMU)
+#define TCNN_LOSS_NOINLINE inline
+#else
+#define TCNN_LOSS_NOINLINE __device__ __attribute__((noinline))
+#endif
+TCNN_LOSS_NOINLINE half_t loss_element_general(LossType type, float prediction, float target, float pdf, float n_total, float loss_scale, float& value) {
 	const float difference = prediction - target;
 	float gradient;  // dL/dprediction before the 1 / n_total of the mean
 	switch (type) {
@@ -63,6 +68,18 @@ TCNN_DEVICE half_t loss_element(LossType type, float prediction, float target, f
 			break;
 	}
 	return to_half_rn(loss_scale * gradient / n_total);
+}
+
+// RelativeL2 / L2 (the defaults) inline, the rest through one out-of-line copy (see activation_device.h)
+TCNN_DEVICE half_t loss_element(LossType type, float prediction, float target, float pdf, float n_total, float loss_scale, float& value) {
+	if (type == LossType::RelativeL2 || type == LossType::L2) {
+		const float difference = prediction - target;
+		const float denom = type == LossType::RelativeL2 ? prediction * prediction + 0.01f : 1.0f;
+		value = type == LossType::RelativeL2 ? difference * difference / denom / pdf / n_total : difference * difference / pdf / n_total;
+		const float gradient = type == LossType::RelativeL2 ? 2 * difference / denom / pdf : 2 * difference / pdf;
+		return to_half_rn(loss_scale * gradient / n_total);
+	}
+	return loss_element_general(type, prediction, target, pdf, n_total, loss_scale, value);
 }
 
 }  // namespace tcnn_hip

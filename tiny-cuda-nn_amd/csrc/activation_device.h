@@ -38,11 +38,16 @@ TCNN_DEVICE_NOINLINE float act_forward_general(uint32_t act, float x) {
 	}
 }
 
+// GENERAL == false: the kernel instance only ever sees ReLU / None (no call sites at all in its body)
+template <bool GENERAL>
 TCNN_DEVICE float act_forward(uint32_t act, float x) {
 	if (act == (uint32_t)Activation::ReLU) return x > 0.0f ? x : 0.0f;
-	if (act == (uint32_t)Activation::None) return x;
-	return act_forward_general(act, x);
+	if constexpr (GENERAL) {
+		if (act != (uint32_t)Activation::None) return act_forward_general(act, x);
+	}
+	return x;
 }
+TCNN_HOST_DEVICE bool act_is_simple(uint32_t act) { return act == (uint32_t)Activation::ReLU || act == (uint32_t)Activation::None; }
 
 // dL/d(pre-activation) = v * f'(x) with f' written in terms of the stored fp16 post-activation value; the factor is
 // rounded to fp16 like the reference's (T)(...) before the multiply.  ReLU keeps the select form (exact, no -0).
@@ -66,10 +71,13 @@ TCNN_DEVICE_NOINLINE float act_backward_general(uint32_t act, float v, half_t fo
 	return v * (float)(half_t)factor;
 }
 
+template <bool GENERAL>
 TCNN_DEVICE float act_backward(uint32_t act, float v, half_t forward_value) {
 	if (act == (uint32_t)Activation::ReLU) return forward_value > (half_t)0.0f ? v : 0.0f;
-	if (act == (uint32_t)Activation::None) return v;
-	return act_backward_general(act, v, forward_value);
+	if constexpr (GENERAL) {
+		if (act != (uint32_t)Activation::None) return act_backward_general(act, v, forward_value);
+	}
+	return v;
 }
 
 }  // namespace tcnn_hip

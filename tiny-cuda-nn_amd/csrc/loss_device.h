@@ -71,15 +71,17 @@ TCNN_LOSS_NOINLINE half_t loss_element_general(LossType type, float prediction, 
 }
 
 // RelativeL2 / L2 (the defaults) inline, the rest through one out-of-line copy (see activation_device.h)
+TCNN_HOST_DEVICE bool loss_is_simple(LossType type) { return type == LossType::RelativeL2 || type == LossType::L2; }
+template <bool GENERAL = true>
 TCNN_DEVICE half_t loss_element(LossType type, float prediction, float target, float pdf, float n_total, float loss_scale, float& value) {
-	if (type == LossType::RelativeL2 || type == LossType::L2) {
+	if (!GENERAL || type == LossType::RelativeL2 || type == LossType::L2) {
 		const float difference = prediction - target;
 		const float denom = type == LossType::RelativeL2 ? prediction * prediction + 0.01f : 1.0f;
 		value = type == LossType::RelativeL2 ? difference * difference / denom / pdf / n_total : difference * difference / pdf / n_total;
 		const float gradient = type == LossType::RelativeL2 ? 2 * difference / denom / pdf : 2 * difference / pdf;
 		return to_half_rn(loss_scale * gradient / n_total);
 	}
-	return loss_element_general(type, prediction, target, pdf, n_total, loss_scale, value);
+	if constexpr (GENERAL) return loss_element_general(type, prediction, target, pdf, n_total, loss_scale, value);
 }
 
 }  // namespace tcnn_hip

@@ -23,7 +23,7 @@ constexpr uint32_t MLP_BWD_TILE = 64;
 // =============================================================================================
 // forward / inference
 // =============================================================================================
-template <uint32_t WIDTH, bool SAVE>
+template <uint32_t WIDTH, bool SAVE, bool GENERAL>
 __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_forward(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
                                                                   const half_t* __restrict__ input, half_t* __restrict__ hidden,
                                                                   half_t* __restrict__ output) {
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_forward(const MlpMeta m
 				h4 o;
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
-					o[r] = (half_t)act_forward(act, acc[t][r]);
+					o[r] = (half_t)act_forward<GENERAL>(act, acc[t][r]);
 				}
 				*(h4*)(nxt + (16 * t + lr) * ld + 16 * w + 4 * g) = o;
 			}
@@ -117,8 +117,8 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_forward(const MlpMeta m
 				const h4 b = *(const h4*)(cur + (16 * t + lr) * ld + k0 + 4 * g);
 				acc = mfma_16x16x16(a, b, acc);
 			}
-			const h4 o = h4{(half_t)act_forward(out_act, acc[0]), (half_t)act_forward(out_act, acc[1]), (half_t)act_forward(out_act, acc[2]),
-			                (half_t)act_forward(out_act, acc[3])};
+			const h4 o = h4{(half_t)act_forward<GENERAL>(out_act, acc[0]), (half_t)act_forward<GENERAL>(out_act, acc[1]), (half_t)act_forward<GENERAL>(out_act, acc[2]),
+			                (half_t)act_forward<GENERAL>(out_act, acc[3])};
 			*(h4*)(output + ((size_t)tile * S + 16 * t + lr) * 16 + 4 * g) = o;  // (output 4g+r, sample 16t+lr)
 		}
 		__syncthreads();
@@ -152,7 +152,7 @@ __global__ void k_mlp_transpose_weights(const MlpMeta m, const half_t* __restric
 // =============================================================================================
 // backward (activation gradients + weight gradients)
 // =============================================================================================
-template <uint32_t WIDTH, uint32_t HM>
+template <uint32_t WIDTH, uint32_t HM, bool GENERAL>
 __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params_t,
                                                                    const half_t* __restrict__ input, const half_t* __restrict__ hidden,
                                                                    const half_t* __restrict__ dL_doutput, half_t* __restrict__ dL_dinput,
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 				const h4 hv = *(const h4*)(hlast + (16 * w + lr) * SP + 16 * t + 4 * g);
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
-					da[t][r] = (half_t)act_backward(act, acc[r], hv[r]);  // transfer on post-activation values (common_device.h:363-418)
+					da[t][r] = (half_t)act_backward<GENERAL>(act, acc[r], hv[r]);  // transfer on post-activation values (common_device.h:363-418)
 					dact0[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
 				}
 			}
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 				const h4 hv = *(const h4*)(hj + (16 * w + lr) * SP + 16 * t + 4 * g);
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
-					da[t][r] = (half_t)act_backward(act, acc[t][r], hv[r]);
+					da[t][r] = (half_t)act_backward<GENERAL>(act, acc[t][r], hv[r]);
 					nxt[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
 				}
 			}
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 // caller's ForwardContext, the encoded input is read once.  Same MFMA fragments and the same rounding points as
 // k_mlp_forward -> k_loss -> k_mlp_backward, so the results are bit-identical to the unfused path.
 // =============================================================================================
-template <uint32_t WIDTH, uint32_t HM>
+template <uint32_t WIDTH, uint32_t HM, bool GENERAL>
 __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
                                                                 const half_t* __restrict__ params_t, const half_t* __restrict__ input,
                                                                 const MlpLossArgs la, half_t* __restrict__ output, half_t* __restrict__ dL_doutput,
@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 					h4 o;
 #pragma unroll
 					for (uint32_t r = 0; r < 4; ++r) {
-						o[r] = (half_t)act_forward(act, acc[t][r]);
+						o[r] = (half_t)act_forward<GENERAL>(act, acc[t][r]);
 						hl[(16 * w + 4 * g + r) * SP + 16 * t + lr] = o[r];
 					}
 					*(h4*)(nxt + (16 * t + lr) * LDW + 16 * w + 4 * g) = o;
@@ -539,8 +539,8 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 					const h4 b = *(const h4*)(cur + (16 * t + lr) * LDW + k0 + 4 * g);
 					acc = mfma_16x16x16(a, b, acc);
 				}
-				const h4 o = h4{(half_t)act_forward(out_act, acc[0]), (half_t)act_forward(out_act, acc[1]), (half_t)act_forward(out_act, acc[2]),
-				                (half_t)act_forward(out_act, acc[3])};
+				const h4 o = h4{(half_t)act_forward<GENERAL>(out_act, acc[0]), (half_t)act_forward<GENERAL>(out_act, acc[1]), (half_t)act_forward<GENERAL>(out_act, acc[2]),
+				                (half_t)act_forward<GENERAL>(out_act, acc[3])};
 				const size_t i = (size_t)tile * S + 16 * t + lr;
 				h4 gy;
 #pragma unroll
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 					gy[r] = (half_t)0.0f;
 					if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
 						float value;
-						gy[r] = loss_element(la.type, (float)o[r], tgt[q][r], pdf[q][r], n_total, la.loss_scale, value);
+						gy[r] = loss_element<GENERAL>(la.type, (float)o[r], tgt[q][r], pdf[q][r], n_total, la.loss_scale, value);
 						loss_sum += value;
 					}
 				}
@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 				if (dL_doutput) *(h4*)(dL_doutput + i * 16 + 4 * g) = gy;  // the caller's context holds dL/doutput ...
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {  // ... the backward pass continues from dL/d(pre-activation) (fully_fused_mlp.cu:760-763)
-					gy[r] = (half_t)act_backward(out_act, (float)gy[r], o[r]);
+					gy[r] = (half_t)act_backward<GENERAL>(out_act, (float)gy[r], o[r]);
 					dyT[(4 * g + r) * SP + 16 * t + lr] = gy[r];
 				}
 				*(h4*)(dys + (16 * t + lr) * LDY + 4 * g) = gy;
@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 				const h4 hv = *(const h4*)(hlast + (16 * w + lr) * SP + 16 * t + 4 * g);
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
-					da[t][r] = (half_t)act_backward(act, acc[r], hv[r]);
+					da[t][r] = (half_t)act_backward<GENERAL>(act, acc[r], hv[r]);
 					dact0[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
 				}
 			}
@@ -638,7 +638,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 				const h4 hv = *(const h4*)(hj + (16 * w + lr) * SP + 16 * t + 4 * g);
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
-					da[t][r] = (half_t)act_backward(act, acc[t][r], hv[r]);
+					da[t][r] = (half_t)act_backward<GENERAL>(act, acc[t][r], hv[r]);
 					nxt[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
 				}
 			}
@@ -744,7 +744,7 @@ __global__ void __launch_bounds__(256) k_mlp_output_activation_backward(uint32_t
 	const h8 o = *(const h8*)(output + (size_t)i * 8), d = *(const h8*)(dL_doutput + (size_t)i * 8);
 	h8 r;
 #pragma unroll
-	for (uint32_t j = 0; j < 8; ++j) r[j] = (half_t)act_backward(act, (float)d[j], o[j]);
+	for (uint32_t j = 0; j < 8; ++j) r[j] = (half_t)act_backward<true>(act, (float)d[j], o[j]);
 	*(h8*)(dL_dpreact + (size_t)i * 8) = r;
 }
 
@@ -805,13 +805,16 @@ static void launch_forward(hipStream_t stream, const MlpMeta& m, uint32_t n, con
 	const uint32_t lds_bytes = 2 * S * ld * (uint32_t)sizeof(half_t);
 	const uint32_t n_tiles = n / S;
 	const uint32_t blocks = n_tiles < 2048 ? n_tiles : 2048;
+	const bool general = !act_is_simple(m.activation) || !act_is_simple(m.output_activation);
+#define TCNN_FWD_LAUNCH(SAVE_, GENERAL_)                                                                                                      \
+	TCNN_SET_MAX_DYN_LDS((k_mlp_forward<WIDTH, SAVE_, GENERAL_>), lds_bytes);                                                                 \
+	TCNN_LAUNCH((k_mlp_forward<WIDTH, SAVE_, GENERAL_>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params, input, hidden, output);
 	if (hidden) {
-		TCNN_SET_MAX_DYN_LDS((k_mlp_forward<WIDTH, true>), lds_bytes);
-		TCNN_LAUNCH((k_mlp_forward<WIDTH, true>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params, input, hidden, output);
+		if (general) { TCNN_FWD_LAUNCH(true, true) } else { TCNN_FWD_LAUNCH(true, false) }
 	} else {
-		TCNN_SET_MAX_DYN_LDS((k_mlp_forward<WIDTH, false>), lds_bytes);
-		TCNN_LAUNCH((k_mlp_forward<WIDTH, false>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params, input, hidden, output);
+		if (general) { TCNN_FWD_LAUNCH(false, true) } else { TCNN_FWD_LAUNCH(false, false) }
 	}
+#undef TCNN_FWD_LAUNCH
 }
 
 void mlp_forward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* hidden, half_t* output) {
@@ -842,8 +845,13 @@ static void launch_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, co
 	const uint32_t halves = 2 * m.in_width * SP + (HM + 1) * WIDTH * SP + 2 * S * LDW + 16 * SP;
 	const uint32_t lds_bytes = halves * (uint32_t)sizeof(half_t);
 	const uint32_t blocks = mlp_backward_n_partials(m, n);
-	TCNN_SET_MAX_DYN_LDS((k_mlp_backward<WIDTH, HM>), lds_bytes);
-	TCNN_LAUNCH((k_mlp_backward<WIDTH, HM>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials);
+	if (!act_is_simple(m.activation)) {
+		TCNN_SET_MAX_DYN_LDS((k_mlp_backward<WIDTH, HM, true>), lds_bytes);
+		TCNN_LAUNCH((k_mlp_backward<WIDTH, HM, true>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials);
+	} else {
+		TCNN_SET_MAX_DYN_LDS((k_mlp_backward<WIDTH, HM, false>), lds_bytes);
+		TCNN_LAUNCH((k_mlp_backward<WIDTH, HM, false>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials);
+	}
 }
 
 template <uint32_t WIDTH>
@@ -880,9 +888,15 @@ static void launch_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const
 	const uint32_t halves = m.in_width * SP + (HM + 1) * WIDTH * SP + 2 * S * LDW + 16 * SP + S * LDY + in_region;
 	const uint32_t lds_bytes = halves * (uint32_t)sizeof(half_t);
 	const uint32_t blocks = mlp_backward_n_partials(m, n);
-	TCNN_SET_MAX_DYN_LDS((k_mlp_train<WIDTH, HM>), lds_bytes);
-	TCNN_LAUNCH((k_mlp_train<WIDTH, HM>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params, params_t, input, la, output, dL_doutput,
-	            dL_dinput, partials, block_sums);
+	if (!act_is_simple(m.activation) || !act_is_simple(m.output_activation) || !loss_is_simple(la.type)) {
+		TCNN_SET_MAX_DYN_LDS((k_mlp_train<WIDTH, HM, true>), lds_bytes);
+		TCNN_LAUNCH((k_mlp_train<WIDTH, HM, true>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params, params_t, input, la, output,
+		            dL_doutput, dL_dinput, partials, block_sums);
+	} else {  // ReLU / None activations and (Relative)L2: an instance without any out-of-line call in its body
+		TCNN_SET_MAX_DYN_LDS((k_mlp_train<WIDTH, HM, false>), lds_bytes);
+		TCNN_LAUNCH((k_mlp_train<WIDTH, HM, false>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params, params_t, input, la, output,
+		            dL_doutput, dL_dinput, partials, block_sums);
+	}
 }
 
 template <uint32_t WIDTH>

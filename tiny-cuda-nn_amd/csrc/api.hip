@@ -739,6 +739,10 @@ struct tcnn_trainable_model {
 	float decay_base = 0.1f, lr_factor = 1.0f, base_lr = 0.0f;
 	uint32_t decay_interval = 10000, decay_start = 10000, decay_end = 10000000;
 	half_t* inference_params() const { return ema ? params_ema : params; }
+	// transposed copy of the network weights for the backward kernels; Adam keeps it current, anything else that writes
+	// `params` invalidates it
+	half_t* params_t = nullptr;
+	bool params_t_valid = false;
 	uint32_t optimizer_step = 0;
 	Pcg32 rng;
 	void* buffer = nullptr;  // [fp32 master | half params | half grads], trainer.h:76, 489-495
@@ -1023,6 +1027,22 @@ static void refresh_hyper_json(tcnn_trainable_model* tm) {  // trainer.h:385-391
 
 static void cast_master_to_params(tcnn_trainable_model* tm, hipStream_t stream) {  // trainer.h:409-421
 	cast_f32_to_f16(stream, tm->md.n_params(), tm->master, tm->params);
+	tm->params_t_valid = false;
+}
+
+// transposed network weights matching `params` (the pointer the pass is about to use)
+static const half_t* trainer_params_t(tcnn_trainable_model* tm, hipStream_t stream, const half_t* params, Scratch& local) {
+	if (!tm->md.has_network) return nullptr;
+	if (params != tm->params || !tm->params_t) {  // EMA / foreign parameters: one-off transposition
+		local = Scratch(stream, tm->md.n_mlp_params() * sizeof(half_t));
+		mlp_transpose_weights(stream, tm->md.net.mlp, params, local.as<half_t>());
+		return local.as<half_t>();
+	}
+	if (!tm->params_t_valid) {
+		mlp_transpose_weights(stream, tm->md.net.mlp, tm->params, tm->params_t);
+		tm->params_t_valid = true;
+	}
+	return tm->params_t;
 }
 
 int tcnn_create_from_config(uint32_t n_input_dims, uint32_t n_output_dims, const char* config_json, uint32_t seed, tcnn_trainable_model_t** out) {
@@ -1061,6 +1081,7 @@ int tcnn_create_from_config(uint32_t n_input_dims, uint32_t n_output_dims, const
 			HIP_CHECK(hipMemset(tm->ema_tmp, 0, n * sizeof(float)));
 		}
 	}
+	if (tm->md.has_network) HIP_CHECK(hipMalloc((void**)&tm->params_t, tm->md.n_mlp_params() * sizeof(half_t)));
 	HIP_CHECK(hipMalloc((void**)&tm->loss_scratch, 1032 * sizeof(float)));
 	std::seed_seq seq{seed};
 	std::vector<uint32_t> seeds(2);
@@ -1080,6 +1101,7 @@ void tcnn_trainable_model_destroy(tcnn_trainable_model_t* tm) {
 	(void)hipFree(tm->m1);
 	(void)hipFree(tm->m2);
 	(void)hipFree(tm->steps);
+	(void)hipFree(tm->params_t);
 	(void)hipFree(tm->params_ema);
 	(void)hipFree(tm->ema_tmp);
 	(void)hipFree(tm->loss_scratch);
@@ -1140,7 +1162,8 @@ int tcnn_trainer_optimizer_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream
 	ProfilerGuard pg(tm->profiler.get());
 	ProfScope prof((hipStream_t)stream, STAGE_ADAM);
 	adam_step((hipStream_t)stream, tm->adam, (uint32_t)tm->md.n_params(), (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master,
-	          tm->params, tm->grads, tm->m1, tm->m2, tm->steps);
+	          tm->params, tm->grads, tm->m1, tm->m2, tm->steps, tm->params_t_valid ? tm->params_t : nullptr,
+	          tm->md.has_network ? &tm->md.net.mlp : nullptr);
 	if (tm->ema) ema_step((hipStream_t)stream, (uint32_t)tm->md.n_params(), tm->ema_decay, tm->optimizer_step, tm->params, tm->params_ema, tm->ema_tmp);
 	TCNN_API_END
 }
@@ -1189,8 +1212,8 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 	Scratch denc;
 	{
 		ProfScope prof(stream, STAGE_MLP_TRAIN);
-		Scratch params_t(stream, md.n_mlp_params() * sizeof(half_t));
-		mlp_transpose_weights(stream, md.net.mlp, params, params_t.as<half_t>());
+		Scratch params_t_local;
+		const half_t* params_t = trainer_params_t(tm, stream, params, params_t_local);
 		const uint32_t n_partials = mlp_backward_n_partials(md.net.mlp, n);
 		Scratch partials;
 		if (want_grads) partials = Scratch(stream, (size_t)n_partials * md.n_mlp_params() * sizeof(float));
@@ -1198,7 +1221,7 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 		c->n_block_sums = n_partials;
 		c->block_sums = Scratch(stream, (size_t)n_partials * sizeof(float));
 		const MlpLossArgs la = {tm->loss, target, data_pdf, md.output_width(), loss_scale, (uint32_t)n_total};
-		mlp_train(stream, md.net.mlp, n, params, params_t.as<half_t>(), fc.enc.as<half_t>(), la, c->output.as<half_t>(), c->dL_doutput.as<half_t>(),
+		mlp_train(stream, md.net.mlp, n, params, params_t, fc.enc.as<half_t>(), la, c->output.as<half_t>(), c->dL_doutput.as<half_t>(),
 		          need_denc ? denc.as<half_t>() : nullptr, want_grads ? partials.as<float>() : nullptr, c->block_sums.as<float>());
 		if (want_grads) mlp_finalize_gradients(stream, (uint32_t)md.n_mlp_params(), n_partials, partials.as<float>(), tm->grads, accumulate);
 	}
@@ -1261,7 +1284,10 @@ int tcnn_network_inference(tcnn_trainable_model_t* tm, tcnn_stream_t stream_, ui
 
 size_t tcnn_trainer_n_params(const tcnn_trainable_model_t* tm) { return tm->md.n_params(); }
 float* tcnn_trainer_params_full_precision(tcnn_trainable_model_t* tm) { return tm->master; }
-void* tcnn_trainer_params(tcnn_trainable_model_t* tm) { return tm->params; }
+void* tcnn_trainer_params(tcnn_trainable_model_t* tm) {
+	tm->params_t_valid = false;  // a mutable pointer leaves the library: assume the caller writes through it
+	return tm->params;
+}
 void* tcnn_trainer_params_inference(tcnn_trainable_model_t* tm) { return tm->inference_params(); }
 void* tcnn_trainer_param_gradients(tcnn_trainable_model_t* tm) { return tm->grads; }
 
@@ -1278,6 +1304,7 @@ int tcnn_trainer_set_params(tcnn_trainable_model_t* tm, const void* params_fp16,
 	TCNN_API_BEGIN
 	if (n_params != tm->md.n_params()) throw std::runtime_error("Can't set params because buffer has the wrong size.");  // trainer.h:424-426
 	HIP_CHECK(hipMemcpy(tm->params, params_fp16, sizeof(half_t) * n_params, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+	tm->params_t_valid = false;
 	cast_f16_to_f32(nullptr, n_params, tm->params, tm->master);
 	HIP_CHECK(hipDeviceSynchronize());
 	TCNN_API_END
@@ -1349,6 +1376,7 @@ int tcnn_trainer_deserialize(tcnn_trainable_model_t* tm, const void* data, size_
 	} else if (s.params_type == "__half") {
 		if (s.params.size != n * sizeof(half_t)) throw std::runtime_error("Can't set params because buffer has the wrong size.");  // trainer.h:424-426
 		HIP_CHECK(hipMemcpy(tm->params, s.params.data, s.params.size, hipMemcpyHostToDevice));
+		tm->params_t_valid = false;
 		cast_f16_to_f32(nullptr, n, tm->params, tm->master);
 	} else {
 		throw std::runtime_error("Trainer: snapshot parameters must be of type float of __half");  // trainer.h:473

@@ -2,6 +2,7 @@
 // PCG32 fills, reductions, identity encoding.  Reference lines restated are cited per function.
 #pragma once
 #include "loss_device.h"
+#include "mlp_kernels.h"
 #include "tcnn_device.h"
 
 namespace tcnn_hip {
@@ -83,9 +84,11 @@ struct AdamHyper {  // optimizers/adam.h:330-351 defaults
 // tmp: fp32 shadow of the average (full_precision) or nullptr.
 void ema_step(hipStream_t stream, uint32_t n, float ema_decay, uint32_t current_step, const half_t* weights, half_t* weights_ema, float* tmp);
 
+// weights_t (nullable) + mlp: also keep the transposed copy of the network weights (mlp_transposed_index) current, so
+// that the next training step does not need a transposition pass.
 void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale,
                uint32_t current_step, float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2,
-               uint32_t* param_steps);
+               uint32_t* param_steps, half_t* weights_t = nullptr, const MlpMeta* mlp = nullptr);
 
 // encodings/identity.h:46-84.  in: fp32 element (dim j, sample i) at in[i*in_stride_i + j*in_stride_j];
 // out: half element (k, i) at out[k*stride_k + i*stride_i], k < padded, padding value 1.

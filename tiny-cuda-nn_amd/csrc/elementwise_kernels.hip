@@ -209,6 +209,7 @@ struct AdamArgs {
 	float loss_scale, learning_rate, non_matrix_learning_rate_factor;
 	int optimize_matrix_params, optimize_non_matrix_params, skip_zero_grad_non_matrix_params;
 	float beta1, beta2, epsilon, lower_lr_bound, upper_lr_bound, l2_reg, non_matrix_l2_reg;
+	MlpMeta mlp;  // layout of the matrix weights (for weights_t)
 };
 
 // One parameter, exactly the arithmetic of adam.h:66-126.  Returns false if the parameter is skipped.
@@ -251,7 +252,8 @@ TCNN_DEVICE bool adam_one(const AdamArgs& a, uint32_t i, float gradient_raw, flo
 // untouched hash-table entries cost 2 B/param as in the reference (adam.h:79-82).
 __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, float* __restrict__ weights_fp32, half_t* __restrict__ weights,
                                                            const half_t* __restrict__ gradients, float* __restrict__ first_moments,
-                                                           float* __restrict__ second_moments, uint32_t* __restrict__ param_steps) {
+                                                           float* __restrict__ second_moments, uint32_t* __restrict__ param_steps,
+                                                           half_t* __restrict__ weights_t) {
 	const uint32_t i0 = (blockIdx.x * EW_THREADS + threadIdx.x) * 4;
 	if (i0 >= a.n_elements) return;
 	if (i0 + 3 < a.n_elements) {
@@ -277,6 +279,7 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 				m2[j] = m2j;
 				st[j] = sj;
 				wh[j] = to_half_rn(wj);
+				if (weights_t && i0 + j < a.n_matrix_weights) weights_t[mlp_transposed_index(a.mlp, i0 + j)] = wh[j];
 				any = true;
 			}
 		}
@@ -297,14 +300,17 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 				second_moments[i] = m2j;
 				param_steps[i] = sj;
 				weights[i] = to_half_rn(wj);
+				if (weights_t && i < a.n_matrix_weights) weights_t[mlp_transposed_index(a.mlp, i)] = weights[i];
 			}
 		}
 	}
 }
 
 void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale, uint32_t current_step,
-               float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2, uint32_t* param_steps) {
+               float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2, uint32_t* param_steps, half_t* weights_t,
+               const MlpMeta* mlp) {
 	if (n == 0) return;
+	if (weights_t && !mlp) throw std::runtime_error("adam_step: weights_t needs the network layout");
 	AdamArgs a;
 	a.n_elements = n;
 	a.n_matrix_weights = n_matrix_weights;
@@ -329,7 +335,9 @@ void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_ma
 	}
 	a.l2_reg = h.l2_reg;
 	a.non_matrix_l2_reg = h.non_matrix_l2_reg;
-	TCNN_LAUNCH(k_adam_step, dim3(div_round_up(div_round_up(n, 4u), EW_THREADS)), dim3(EW_THREADS), 0, stream, a, weights_fp32, weights, gradients, m1, m2, param_steps);
+	a.mlp = mlp ? *mlp : MlpMeta{};
+	TCNN_LAUNCH(k_adam_step, dim3(div_round_up(div_round_up(n, 4u), EW_THREADS)), dim3(EW_THREADS), 0, stream, a, weights_fp32, weights, gradients, m1, m2,
+	            param_steps, weights_t);
 }
 
 // ------------------------------------------------------------------------------------------ identity

@@ -37,6 +37,25 @@ struct MlpMeta {
 	TCNN_HOST_DEVICE uint32_t n_params() const { return width * in_width + n_hidden_matmuls * width * width + padded_out * width; }
 };
 
+// position of parameter i (natural layout: [W][IN] | HM x [W][W] | [OUTP][W], row-major) in the transposed scratch the
+// backward kernels read ([IN][W] | HM x [W][W]^T | [W][OUTP])
+TCNN_HOST_DEVICE uint32_t mlp_transposed_index(const MlpMeta& m, uint32_t i) {
+	const uint32_t W = m.width, IN = m.in_width;
+	const uint32_t n_in = W * IN, n_hid = m.n_hidden_matmuls * W * W;
+	if (i < n_in) {
+		const uint32_t o = i / IN, k = i % IN;
+		return k * W + o;
+	}
+	if (i < n_in + n_hid) {
+		const uint32_t local = i - n_in, j = local / (W * W), e = local % (W * W);
+		const uint32_t o = e / W, k = e % W;
+		return n_in + j * W * W + k * W + o;
+	}
+	const uint32_t local = i - n_in - n_hid;
+	const uint32_t o = local / W, k = local % W;
+	return n_in + n_hid + k * m.padded_out + o;
+}
+
 constexpr uint32_t MLP_MAX_HIDDEN_MATMULS_TRAIN = 3;  // backward kernels are instantiated for 0..3
 constexpr uint32_t MLP_MAX_IN_WIDTH = 128;
 

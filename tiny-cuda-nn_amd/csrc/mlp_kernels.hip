@@ -130,22 +130,8 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_forward(const MlpMeta m
 // =============================================================================================
 __global__ void k_mlp_transpose_weights(const MlpMeta m, const half_t* __restrict__ params, half_t* __restrict__ params_t) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t W = m.width, IN = m.in_width;
-	const uint32_t n_in = W * IN, n_hid = m.n_hidden_matmuls * W * W, n_out = m.padded_out * W;
-	if (i >= n_in + n_hid + n_out) return;
-	uint32_t dst;
-	if (i < n_in) {
-		const uint32_t o = i / IN, k = i % IN;
-		dst = k * W + o;
-	} else if (i < n_in + n_hid) {
-		const uint32_t local = i - n_in, j = local / (W * W), e = local % (W * W);
-		const uint32_t o = e / W, k = e % W;
-		dst = n_in + j * W * W + k * W + o;
-	} else {
-		const uint32_t local = i - n_in - n_hid;
-		const uint32_t o = local / W, k = local % W;
-		dst = n_in + n_hid + k * m.padded_out + o;
-	}
+	if (i >= m.n_params()) return;
+	const uint32_t dst = mlp_transposed_index(m, i);
 	params_t[dst] = params[i];
 }
 

@@ -526,6 +526,15 @@ TCNN_HOST_DEVICE constexpr uint32_t bucket_spt(uint32_t D, uint32_t F) {
 	return spt < 1u ? 1u : (spt > 8u ? 8u : spt);
 }
 
+// The queues are written once and read once: stream them past the caches (non-temporal) so that they do not evict the
+// optimizer state the step's last kernel re-reads.  TCNN_QUEUE_TEMPORAL=1 builds the plain variant for A/B runs.
+#if defined(TCNN_HOST_EMU) || defined(TCNN_QUEUE_TEMPORAL)
+TCNN_DEVICE void queue_store(uint32_t* p, uint32_t v) { *p = v; }
+TCNN_DEVICE uint32_t queue_load(const uint32_t* p) { return *p; }
+#else
+TCNN_DEVICE void queue_store(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+TCNN_DEVICE uint32_t queue_load(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+#endif
 constexpr uint32_t BUCKET_INVALID_INDEX = 0xFFFFFFFFu;  // second record of a pair that has none
 TCNN_DEVICE uint32_t h2_bits(h2 v) { return __builtin_bit_cast(uint32_t, v); }
 TCNN_DEVICE h2 bits_h2(uint32_t v) { return __builtin_bit_cast(h2, v); }
@@ -729,7 +738,7 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 			if (pos < cap) {
 				uint32_t* dst = q + ((size_t)b * cap + pos) * PWP;
 #pragma unroll
-				for (uint32_t w = 0; w < PWP; ++w) dst[w] = rec[w];
+				for (uint32_t w = 0; w < PWP; ++w) queue_store(dst + w, rec[w]);
 			} else {
 				push_overflow(rec[0] & PAIR_INDEX_MASK, &rec[1]);
 				if (rec[0] & PAIR_HAS_SECOND) push_overflow(pair_second_index<D>(lv, rec[0]), &rec[1 + PW]);
@@ -786,7 +795,7 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 			for (uint32_t u = 0; u < U; ++u) {
 				const uint32_t t = min(base + u * SLICED_THREADS, count - 1u);
 #pragma unroll
-				for (uint32_t w = 0; w < PWP; ++w) rec[u][w] = q[(size_t)t * PWP + w];
+				for (uint32_t w = 0; w < PWP; ++w) rec[u][w] = queue_load(q + (size_t)t * PWP + w);
 			}
 #pragma unroll
 			for (uint32_t u = 0; u < U; ++u) {

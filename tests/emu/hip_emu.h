@@ -61,7 +61,6 @@ struct Fiber {
 struct Wave {
 	unsigned gen = 0, arrived = 0, size = 64;
 	eh8 a[64], b[64];
-	uint32_t x[64];  // lane exchange buffer
 };
 
 struct State {
@@ -241,16 +240,6 @@ inline void atomic_add_f32(float* addr, float v) { *addr = *addr + v; }
 inline void lds_atomic_add_f32(float* addr, float v) { *addr = *addr + v; }
 inline void lds_atomic_add_u64(unsigned long long* addr, unsigned long long v) { *addr = *addr + v; }
 inline void lds_atomic_add_h2(h2* addr, h2 v) { atomic_add_h2((half_t*)addr, v); }
-// value held by lane (lane ^ 1); every lane of the wave must call it (v_mov_b32_dpp quad_perm:[1,0,3,2] on the device)
-inline uint32_t lane_xor1(uint32_t v) {
-	const unsigned lane = ::emu::g.cur->tidx.x & 63u;
-	::emu::Wave& w = ::emu::g.waves[::emu::g.cur->tidx.x / 64];
-	w.x[lane] = v;
-	::emu::wave_barrier();
-	const uint32_t r = w.x[lane ^ 1u];
-	::emu::wave_barrier();
-	return r;
-}
 inline uint32_t atomic_add_u32(uint32_t* addr, uint32_t v) { const uint32_t old = *addr; *addr = old + v; return old; }
 inline h2 fma_h2(h2 a, h2 b, h2 c) {
 	return h2{emu_round_h((double)a[0] * (double)b[0] + (double)c[0]), emu_round_h((double)a[1] * (double)b[1] + (double)c[1])};

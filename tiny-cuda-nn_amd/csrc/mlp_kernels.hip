@@ -17,21 +17,6 @@ namespace tcnn_hip {
 TCNN_DEVICE h8 pack8(h4 a, h4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 TCNN_DEVICE f4 zero4() { return f4{0.0f, 0.0f, 0.0f, 0.0f}; }
 
-// Transposing LDS store without 2-byte writes.  This lane holds v[r] = element (row r, column col) for r < 4, its
-// lane ^ 1 neighbour the same rows of column col ^ 1 (col's parity == the lane's).  The two lanes trade halves of
-// their data with one DPP move, then each writes two packed pairs: rows {0, 2} by the even lane, {1, 3} by the odd one.
-// Every lane of the wave must call it.  base points at (row 0, column 0); row_stride in halves, even.
-TCNN_DEVICE void store_rows_paired(half_t* base, uint32_t row_stride, uint32_t col, h4 v) {
-	const bool odd = (col & 1u) != 0u;
-	const h2 send = odd ? h2{v[0], v[2]} : h2{v[1], v[3]};
-	const h2 recv = __builtin_bit_cast(h2, lane_xor1(__builtin_bit_cast(uint32_t, send)));
-	const h2 lo = odd ? h2{recv[0], v[1]} : h2{v[0], recv[0]};
-	const h2 hi = odd ? h2{recv[1], v[3]} : h2{v[2], recv[1]};
-	half_t* p = base + (odd ? row_stride : 0u) + (col & ~1u);
-	*(h2*)p = lo;
-	*(h2*)(p + 2 * row_stride) = hi;
-}
-
 constexpr uint32_t mlp_fwd_tile(uint32_t width) { return width == 128 ? 128u : 64u; }
 constexpr uint32_t MLP_BWD_TILE = 64;
 
@@ -445,8 +430,8 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 			const uint32_t k = c % IN, cc = c / IN;
 			const h8 v = u < PF ? pf[u < PF ? u : 0] : load_chunk(tile, c);
 			*(h8*)(xT + k * SP + 8 * cc) = v;
-			store_rows_paired(xs + (8 * cc) * ldi, ldi, k, h4{v[0], v[1], v[2], v[3]});      // xs[(8cc + j)][k] = v[j]
-			store_rows_paired(xs + (8 * cc + 4) * ldi, ldi, k, h4{v[4], v[5], v[6], v[7]});
+#pragma unroll
+			for (uint32_t j = 0; j < 8; ++j) xs[(8 * cc + j) * ldi + k] = v[j];
 		}
 		{
 			const uint32_t next = tile + gridDim.x;
@@ -510,8 +495,8 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 #pragma unroll
 					for (uint32_t r = 0; r < 4; ++r) {
 						o[r] = (half_t)act_forward<GENERAL>(act, acc[t][r]);
+						hl[(16 * w + 4 * g + r) * SP + 16 * t + lr] = o[r];
 					}
-					store_rows_paired(hl + (16 * w + 4 * g) * SP, SP, 16 * t + lr, o);  // hl[neuron 16w+4g+r][sample 16t+lr] = o[r]
 					*(h4*)(nxt + (16 * t + lr) * LDW + 16 * w + 4 * g) = o;
 				}
 				__syncthreads();
@@ -559,8 +544,8 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {  // ... the backward pass continues from dL/d(pre-activation) (fully_fused_mlp.cu:760-763)
 					gy[r] = (half_t)act_backward<GENERAL>(out_act, (float)gy[r], o[r]);
+					dyT[(4 * g + r) * SP + 16 * t + lr] = gy[r];
 				}
-				store_rows_paired(dyT + (4 * g) * SP, SP, 16 * t + lr, gy);  // dyT[output 4g+r][sample 16t+lr] = gy[r]
 				*(h4*)(dys + (16 * t + lr) * LDY + 4 * g) = gy;
 			}
 			__syncthreads();
@@ -581,8 +566,8 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
 					da[t][r] = (half_t)act_backward<GENERAL>(act, acc[r], hv[r]);
+					dact0[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
 				}
-				store_rows_paired(dact0 + (16 * t + 4 * g) * LDW, LDW, 16 * w + lr, da[t]);  // dact0[sample 16t+4g+r][neuron 16w+lr] = da[t][r]
 			}
 			if (want_grads) {
 #pragma unroll
@@ -640,8 +625,8 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta 
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
 					da[t][r] = (half_t)act_backward<GENERAL>(act, acc[t][r], hv[r]);
+					nxt[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
 				}
-				store_rows_paired(nxt + (16 * t + 4 * g) * LDW, LDW, 16 * w + lr, da[t]);
 			}
 			__syncthreads();
 			half_t* tmp = cur;

@@ -69,8 +69,6 @@ TCNN_DEVICE void lds_atomic_add_h2(h2* addr, h2 v) {  // ds_pk_add_f16
 TCNN_DEVICE uint32_t atomic_add_u32(uint32_t* addr, uint32_t v) { return atomicAdd(addr, v); }  // returns the old value (LDS or global)
 TCNN_DEVICE h2 fma_h2(h2 a, h2 b, h2 c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f16
 TCNN_DEVICE half_t fma_h(half_t a, half_t b, half_t c) { return __builtin_fmaf16(a, b, c); }
-// value held by lane (lane ^ 1): v_mov_b32_dpp quad_perm:[1,0,3,2]; all lanes of the wave must be active
-TCNN_DEVICE uint32_t lane_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
 TCNN_DEVICE uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)); }  // HW_REG_XCC_ID
 #endif
 

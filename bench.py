@@ -142,8 +142,7 @@ def main():
         x, t = batches[i % len(batches)]
         if world > 1:
             tm.training_step(x, t, run_optimizer=False, want_context=False)
-            par.all_reduce_gradients(grads)
-            tm.optimizer_step()
+            par.reduce_and_step(tm, grads)  # bucketed all-reduce overlapped with the optimizer
         else:
             tm.training_step(x, t, want_context=False)
 

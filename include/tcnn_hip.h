@@ -150,6 +150,11 @@ uint32_t tcnn_trainer_n_mlp_params(const tcnn_trainable_model_t* tm); /* "matrix
  * SUM over ranks of the local gradient buffers equals the single-GPU gradient of the global batch.  The
  * host all-reduces tcnn_trainer_param_gradients() (RCCL) between backward and optimizer_step. */
 int tcnn_trainer_set_global_batch_size(tcnn_trainable_model_t* tm, uint64_t global_batch_size);
+/* Optimizer step over the parameter range [begin, end) only (begin a multiple of 8).  Lets a data-parallel host step
+ * each gradient bucket as soon as its all-reduce has finished, overlapping the optimizer with the remaining
+ * communication.  One optimizer step == ranges that tile [0, n_params) exactly once, the range with begin == 0 first
+ * (it advances the step counter and the learning-rate schedule). */
+int tcnn_trainer_optimizer_step_range(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale, size_t begin, size_t end);
 
 /* Measurement hooks (no reference counterpart): HIP events recorded around each stage of the training step
  * on the stream the kernels are launched on.  only_stage < 0 times every stage, otherwise just that one.

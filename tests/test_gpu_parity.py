@@ -663,3 +663,24 @@ def test_wrapper_optimizers_ema_and_exponential_decay():
     assert torch.equal(other.inference(x), y_ema)
     tm.update_hyperparams({"optimizer": {"decay": 0.5, "nested": {"decay_base": 0.1}}})
     assert tm.hyperparams()["optimizer"]["decay"] == 0.5 and abs(tm.hyperparams()["optimizer"]["nested"]["decay_base"] - 0.1) < 1e-7
+
+
+def test_bucketed_optimizer_step_equals_the_whole_step():
+    """Data-parallel hosts step each gradient bucket as soon as its all-reduce finished (tinycudann.parallel.
+    reduce_and_step): stepping [0, n) in ranges gives exactly the parameters of one whole optimizer step."""
+    T = tcnn()
+    from tinycudann import parallel as par
+    cfg = config_hash(log2_hashmap_size=14)
+    cfg["optimizer"] = {"otype": "Ema", "decay": 0.9, "nested": cfg["optimizer"]}
+    a, b = T.create_from_config(3, 4, cfg, seed=3), T.create_from_config(3, 4, cfg, seed=3)
+    pos = positions(2048, 3, seed=6)
+    x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(targets_for(pos, 4)).cuda()
+    assert par.bucket_ranges(1000, 3) == [(0, 336), (336, 672), (672, 1000)]
+    for _ in range(3):
+        a.training_step(x, t, want_context=False)
+        b.training_step(x, t, run_optimizer=False, want_context=False)
+        par.reduce_and_step(b, b.param_gradients, n_buckets=5)
+    assert a.optimizer_step_count == b.optimizer_step_count == 3
+    assert torch.equal(a.params_full_precision, b.params_full_precision) and torch.equal(a.params, b.params)
+    assert torch.equal(a.params_inference, b.params_inference)
+    assert torch.equal(a.inference(x), b.inference(x))

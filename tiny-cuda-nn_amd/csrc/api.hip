@@ -1150,22 +1150,35 @@ int tcnn_trainer_backward(tcnn_trainable_model_t* tm, tcnn_stream_t stream, cons
 	TCNN_API_END
 }
 
-int tcnn_trainer_optimizer_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale) {
+// Optimizer::step over the parameter range [begin, end) (multiples of 8).  The call with begin == 0 advances the step
+// counter and the learning-rate schedule; a data-parallel host steps a range as soon as its gradients are reduced.
+int tcnn_trainer_optimizer_step_range(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale, size_t begin, size_t end) {
 	TCNN_API_BEGIN
-	if (tm->lr_decay) {  // exponential_decay.h:59-70, with step() == the nested optimizer's step count before this step
-		const uint32_t step = tm->optimizer_step;
-		if (step == 0) tm->lr_factor = 1.0f;
-		if (step >= tm->decay_start && (step - tm->decay_start) % tm->decay_interval == 0 && step <= tm->decay_end) tm->lr_factor *= tm->decay_base;
-		tm->adam.learning_rate = tm->base_lr * tm->lr_factor;
+	const size_t n = tm->md.n_params();
+	if (end > n) end = n;
+	if (begin % 8 != 0 || begin > end) throw std::runtime_error("optimizer_step_range: range must start at a multiple of 8");
+	if (begin == 0) {
+		if (tm->lr_decay) {  // exponential_decay.h:59-70, with step() == the nested optimizer's step count before this step
+			const uint32_t step = tm->optimizer_step;
+			if (step == 0) tm->lr_factor = 1.0f;
+			if (step >= tm->decay_start && (step - tm->decay_start) % tm->decay_interval == 0 && step <= tm->decay_end) tm->lr_factor *= tm->decay_base;
+			tm->adam.learning_rate = tm->base_lr * tm->lr_factor;
+		}
+		++tm->optimizer_step;  // adam.h:159
 	}
-	++tm->optimizer_step;  // adam.h:159
 	ProfilerGuard pg(tm->profiler.get());
 	ProfScope prof((hipStream_t)stream, STAGE_ADAM);
-	adam_step((hipStream_t)stream, tm->adam, (uint32_t)tm->md.n_params(), (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master,
-	          tm->params, tm->grads, tm->m1, tm->m2, tm->steps, tm->params_t_valid ? tm->params_t : nullptr,
-	          tm->md.has_network ? &tm->md.net.mlp : nullptr);
-	if (tm->ema) ema_step((hipStream_t)stream, (uint32_t)tm->md.n_params(), tm->ema_decay, tm->optimizer_step, tm->params, tm->params_ema, tm->ema_tmp);
+	adam_step((hipStream_t)stream, tm->adam, (uint32_t)n, (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master, tm->params, tm->grads,
+	          tm->m1, tm->m2, tm->steps, tm->params_t_valid ? tm->params_t : nullptr, tm->md.has_network ? &tm->md.net.mlp : nullptr, (uint32_t)begin,
+	          (uint32_t)end);
+	if (tm->ema) {
+		ema_step((hipStream_t)stream, (uint32_t)n, tm->ema_decay, tm->optimizer_step, tm->params, tm->params_ema, tm->ema_tmp, (uint32_t)begin, (uint32_t)end);
+	}
 	TCNN_API_END
+}
+
+int tcnn_trainer_optimizer_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale) {
+	return tcnn_trainer_optimizer_step_range(tm, stream, loss_scale, 0, tm->md.n_params());
 }
 
 // training_step fast path: encoding forward, ONE kernel for the network's forward + loss + backward, encoding backward.

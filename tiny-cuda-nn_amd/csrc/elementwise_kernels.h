@@ -82,13 +82,14 @@ struct AdamHyper {  // optimizers/adam.h:330-351 defaults
 // optimizers/adam.h:48-127, 158-199.  current_step = optimizer step AFTER the increment.
 // optimizers/ema.h:45-141: weights_ema <- debiased EMA of weights after optimizer step `current_step` (>= 1);
 // tmp: fp32 shadow of the average (full_precision) or nullptr.
-void ema_step(hipStream_t stream, uint32_t n, float ema_decay, uint32_t current_step, const half_t* weights, half_t* weights_ema, float* tmp);
+void ema_step(hipStream_t stream, uint32_t n, float ema_decay, uint32_t current_step, const half_t* weights, half_t* weights_ema, float* tmp,
+              uint32_t begin = 0, uint32_t end = 0xFFFFFFFFu);
 
 // weights_t (nullable) + mlp: also keep the transposed copy of the network weights (mlp_transposed_index) current, so
 // that the next training step does not need a transposition pass.
 void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale,
                uint32_t current_step, float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2,
-               uint32_t* param_steps, half_t* weights_t = nullptr, const MlpMeta* mlp = nullptr);
+               uint32_t* param_steps, half_t* weights_t = nullptr, const MlpMeta* mlp = nullptr, uint32_t begin = 0, uint32_t end = 0xFFFFFFFFu);
 
 // encodings/identity.h:46-84.  in: fp32 element (dim j, sample i) at in[i*in_stride_i + j*in_stride_j];
 // out: half element (k, i) at out[k*stride_k + i*stride_i], k < padded, padding value 1.

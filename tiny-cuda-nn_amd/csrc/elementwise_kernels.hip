@@ -193,8 +193,15 @@ __global__ void __launch_bounds__(EW_THREADS) k_ema_step(uint32_t n, float ema_d
 	}
 }
 
-void ema_step(hipStream_t stream, uint32_t n, float ema_decay, uint32_t current_step, const half_t* weights, half_t* weights_ema, float* tmp) {
-	if (n == 0) return;
+void ema_step(hipStream_t stream, uint32_t n, float ema_decay, uint32_t current_step, const half_t* weights, half_t* weights_ema, float* tmp,
+              uint32_t begin, uint32_t end) {
+	if (end > n) end = n;
+	if (begin >= end) return;
+	if (begin % 8u != 0u) throw std::runtime_error("ema_step: a parameter range must start at a multiple of 8");
+	weights += begin;
+	weights_ema += begin;
+	if (tmp) tmp += begin;
+	n = end - begin;
 	// ema.h:113-114 (float pow through double, as std::pow(float, unsigned) does)
 	const float ema_debias_old = 1 - (float)std::pow((double)ema_decay, (double)(current_step - 1));
 	const float ema_debias_new = 1.0f / (1 - (float)std::pow((double)ema_decay, (double)current_step));
@@ -204,7 +211,7 @@ void ema_step(hipStream_t stream, uint32_t n, float ema_decay, uint32_t current_
 
 // ------------------------------------------------------------------------------------------ Adam
 struct AdamArgs {
-	uint32_t n_elements, n_matrix_weights;
+	uint32_t begin, n_elements, n_matrix_weights;  // parameters [begin, n_elements) are stepped (begin % 4 == 0)
 	float relative_weight_decay, absolute_weight_decay, weight_clipping_magnitude, gradient_clipping_magnitude;
 	float loss_scale, learning_rate, non_matrix_learning_rate_factor;
 	int optimize_matrix_params, optimize_non_matrix_params, skip_zero_grad_non_matrix_params;
@@ -277,7 +284,7 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
                                                            const half_t* __restrict__ gradients, float* __restrict__ first_moments,
                                                            float* __restrict__ second_moments, uint32_t* __restrict__ param_steps,
                                                            half_t* __restrict__ weights_t) {
-	const uint32_t i0 = (blockIdx.x * EW_THREADS + threadIdx.x) * 4;
+	const uint32_t i0 = a.begin + (blockIdx.x * EW_THREADS + threadIdx.x) * 4;
 	if (i0 >= a.n_elements) return;
 	if (i0 + 3 < a.n_elements) {
 		const h4 g = *(const h4*)(gradients + i0);
@@ -342,11 +349,14 @@ constexpr size_t ADAM_STREAM_THRESHOLD_BYTES = 192u << 20;  // optimizer state b
 
 void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale, uint32_t current_step,
                float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2, uint32_t* param_steps, half_t* weights_t,
-               const MlpMeta* mlp) {
-	if (n == 0) return;
+               const MlpMeta* mlp, uint32_t begin, uint32_t end) {
+	if (end > n) end = n;
+	if (begin >= end) return;
+	if (begin % 4u != 0u) throw std::runtime_error("adam_step: a parameter range must start at a multiple of 4");
 	if (weights_t && !mlp) throw std::runtime_error("adam_step: weights_t needs the network layout");
 	AdamArgs a;
-	a.n_elements = n;
+	a.begin = begin;
+	a.n_elements = end;
 	a.n_matrix_weights = n_matrix_weights;
 	a.relative_weight_decay = h.relative_weight_decay;
 	a.absolute_weight_decay = h.absolute_weight_decay;
@@ -370,7 +380,7 @@ void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_ma
 	a.l2_reg = h.l2_reg;
 	a.non_matrix_l2_reg = h.non_matrix_l2_reg;
 	a.mlp = mlp ? *mlp : MlpMeta{};
-	const dim3 grid(div_round_up(div_round_up(n, 4u), EW_THREADS));
+	const dim3 grid(div_round_up(div_round_up(end - begin, 4u), EW_THREADS));
 	if ((size_t)n * 32u > ADAM_STREAM_THRESHOLD_BYTES) {
 		TCNN_LAUNCH(k_adam_step<true>, grid, dim3(EW_THREADS), 0, stream, a, weights_fp32, weights, gradients, m1, m2, param_steps, weights_t);
 	} else {

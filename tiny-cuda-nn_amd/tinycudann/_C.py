@@ -111,6 +111,7 @@ _sig("tcnn_trainer_optimizer_step_count", _u32, _vp)
 _sig("tcnn_trainer_padded_output_width", _u32, _vp)
 _sig("tcnn_trainer_n_mlp_params", _u32, _vp)
 _sig("tcnn_trainer_set_global_batch_size", _i, _vp, _u64)
+_sig("tcnn_trainer_optimizer_step_range", _i, _vp, _vp, _f, _sz, _sz)
 _sig("tcnn_trainer_set_profiling", _i, _vp, _i, _i)
 _sig("tcnn_trainer_n_stages", _i)
 _sig("tcnn_trainer_stage_name", _cp, _i)

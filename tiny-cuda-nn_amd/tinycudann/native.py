@@ -95,6 +95,10 @@ class TrainableModel:
     def optimizer_step(self, loss_scale=128.0):
         _check(_lib.tcnn_trainer_optimizer_step(self._h, _stream(), loss_scale))
 
+    def optimizer_step_range(self, begin, end, loss_scale=128.0):
+        """Optimizer step over parameters [begin, end) (begin a multiple of 8); the range starting at 0 must come first."""
+        _check(_lib.tcnn_trainer_optimizer_step_range(self._h, _stream(), float(loss_scale), int(begin), int(end)))
+
     def loss(self, ctx):
         v = C.c_float()
         _check(_lib.tcnn_trainer_loss(self._h, _stream(), ctx._h, C.byref(v)))

@@ -44,6 +44,28 @@ def all_reduce_gradients(grads, world=None):
     return grads
 
 
+def bucket_ranges(n_params, n_buckets):
+    """[begin, end) ranges tiling [0, n_params), each starting at a multiple of 8."""
+    per = -(-n_params // n_buckets)
+    per = -(-per // 8) * 8
+    return [(b, min(b + per, n_params)) for b in range(0, n_params, per)]
+
+
+def reduce_and_step(tm, grads, n_buckets=4, loss_scale=128.0):
+    """Bucketed gradient all-reduce overlapped with the optimizer: the buckets are reduced in order on the
+    communication stream; as soon as bucket k is summed its parameters are stepped while buckets k+1.. are still on the
+    wire (xGMI ring all-reduce of the 28 MB fp16 buffer takes longer than the whole optimizer step)."""
+    ranges = bucket_ranges(grads.numel(), n_buckets)
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        for b, e in ranges:
+            tm.optimizer_step_range(b, e, loss_scale)
+        return
+    works = [dist.all_reduce(grads[b:e], op=dist.ReduceOp.SUM, async_op=True) for b, e in ranges]
+    for (b, e), w in zip(ranges, works):
+        w.wait()  # the current stream waits for this bucket only
+        tm.optimizer_step_range(b, e, loss_scale)
+
+
 def all_reduce_max(value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:
@@ -70,6 +92,5 @@ def training_step(tm, input, target, global_batch):
     from ._C import GradientMode
     tm.set_global_batch_size(global_batch)
     ctx = tm.training_step(input, target, run_optimizer=False, gradient_mode=GradientMode.Overwrite)
-    all_reduce_gradients(tm.param_gradients)
-    tm.optimizer_step()
+    reduce_and_step(tm, tm.param_gradients)
     return ctx

@@ -17,8 +17,11 @@ STAGES = {  # stage -> [(kernel-name fragment, reads are wide streams?)]
     "grid_backward_overflow": [("k_grid_bucket_overflow", False)],
     "adam": [("k_adam_step", True)],
 }
+fused = any("k_mlp_train" in name for name in summary)  # training_step ran the fused network kernel: the three-kernel stages did not run
 out = {}
 for stage, kernels in STAGES.items():
+    if fused and stage in ("mlp_forward", "loss", "mlp_backward"):
+        continue
     total = 0.0
     for frag, wide in kernels:
         for name, cs in summary.items():

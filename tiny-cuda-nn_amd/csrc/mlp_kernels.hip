@@ -368,8 +368,11 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 // caller's ForwardContext, the encoded input is read once.  Same MFMA fragments and the same rounding points as
 // k_mlp_forward -> k_loss -> k_mlp_backward, so the results are bit-identical to the unfused path.
 // =============================================================================================
+#ifndef TCNN_MLP_TRAIN_MIN_BLOCKS
+#define TCNN_MLP_TRAIN_MIN_BLOCKS 2
+#endif
 template <uint32_t WIDTH, uint32_t HM, bool GENERAL>
-__global__ void __launch_bounds__(WIDTH / 16 * 64, 2) k_mlp_train(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
+__global__ void __launch_bounds__(WIDTH / 16 * 64, TCNN_MLP_TRAIN_MIN_BLOCKS) k_mlp_train(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
                                                                 const half_t* __restrict__ params_t, const half_t* __restrict__ input,
                                                                 const MlpLossArgs la, half_t* __restrict__ output, half_t* __restrict__ dL_doutput,
                                                                 half_t* __restrict__ dL_dinput, float* __restrict__ partials,
@@ -821,7 +824,10 @@ void mlp_transpose_weights(hipStream_t stream, const MlpMeta& m, const half_t* p
 uint32_t mlp_backward_n_partials(const MlpMeta& m, uint32_t n) {
 	(void)m;
 	const uint32_t n_tiles = n / MLP_BWD_TILE;
-	return n_tiles < 512 ? n_tiles : 512;  // two persistent workgroups per CU (latency hiding); measured better than 256
+#ifndef TCNN_MLP_PARTIALS
+#define TCNN_MLP_PARTIALS 512
+#endif
+	return n_tiles < TCNN_MLP_PARTIALS ? n_tiles : TCNN_MLP_PARTIALS;  // two persistent workgroups per CU (latency hiding); measured better than 256
 }
 
 template <uint32_t WIDTH, uint32_t HM>

@@ -311,7 +311,10 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_backward_atomic(const Gri
 //   * large tables (fine / hashed levels, a slice sees ~1/16 of the corners -> sparse atomics):
 //     packed fp16 (the reference's own accumulation type, vec.h:328-351) or fp32 slices.
 // =============================================================================================
-constexpr uint32_t SLICED_THREADS = 1024;
+#ifndef TCNN_SLICED_THREADS
+#define TCNN_SLICED_THREADS 1024
+#endif
+constexpr uint32_t SLICED_THREADS = TCNN_SLICED_THREADS;
 constexpr uint32_t SLICED_LDS_BYTES = 128 * 1024;      // default slice size
 constexpr uint32_t SLICED_LDS_MAX_BYTES = 160 * 1024;  // one CU's LDS
 constexpr double FIXED_SCALE = 16777216.0;             // 2^24: below the smallest fp16 subnormal

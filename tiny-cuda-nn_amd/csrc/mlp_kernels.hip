@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 #define TCNN_MLP_TRAIN_MIN_BLOCKS 2
 #endif
 template <uint32_t WIDTH, uint32_t HM, bool GENERAL>
-__global__ void __launch_bounds__(WIDTH / 16 * 64, TCNN_MLP_TRAIN_MIN_BLOCKS) k_mlp_train(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
+__global__ void __launch_bounds__(WIDTH / 16 * 64, WIDTH == 128 ? 1 : TCNN_MLP_TRAIN_MIN_BLOCKS) k_mlp_train(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
                                                                 const half_t* __restrict__ params_t, const half_t* __restrict__ input,
                                                                 const MlpLossArgs la, half_t* __restrict__ output, half_t* __restrict__ dL_doutput,
                                                                 half_t* __restrict__ dL_dinput, float* __restrict__ partials,
@@ -872,13 +872,16 @@ void mlp_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t
 	}
 }
 
+static uint32_t mlp_train_lds_bytes(const MlpMeta& m) {
+	const uint32_t S = MLP_BWD_TILE, SP = S + 8, LDW = m.width + 8, LDY = 16 + 8;
+	const uint32_t in_region = std::max(S * (m.in_width + 8), m.in_width * SP);  // xs, later dxT
+	return (m.in_width * SP + (m.n_hidden_matmuls + 1) * m.width * SP + 2 * S * LDW + 16 * SP + S * LDY + in_region) * (uint32_t)sizeof(half_t);
+}
+
 template <uint32_t WIDTH, uint32_t HM>
 static void launch_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
                          const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
-	constexpr uint32_t S = MLP_BWD_TILE, SP = S + 8, LDW = WIDTH + 8, LDY = 16 + 8;
-	const uint32_t in_region = std::max(S * (m.in_width + 8), m.in_width * SP);  // xs, later dxT
-	const uint32_t halves = m.in_width * SP + (HM + 1) * WIDTH * SP + 2 * S * LDW + 16 * SP + S * LDY + in_region;
-	const uint32_t lds_bytes = halves * (uint32_t)sizeof(half_t);
+	const uint32_t lds_bytes = mlp_train_lds_bytes(m);
 	const uint32_t blocks = mlp_backward_n_partials(m, n);
 	if (!act_is_simple(m.activation) || !act_is_simple(m.output_activation) || !loss_is_simple(la.type)) {
 		TCNN_SET_MAX_DYN_LDS((k_mlp_train<WIDTH, HM, true>), lds_bytes);
@@ -903,7 +906,9 @@ static void dispatch_train(hipStream_t stream, const MlpMeta& m, uint32_t n, con
 	}
 }
 
-bool mlp_train_supported(const MlpMeta& m) { return m.n_hidden_matmuls <= MLP_MAX_HIDDEN_MATMULS_TRAIN && m.width <= 64; }
+bool mlp_train_supported(const MlpMeta& m) {
+	return m.n_hidden_matmuls <= MLP_MAX_HIDDEN_MATMULS_TRAIN && mlp_train_lds_bytes(m) + 4096u <= 160u * 1024u;  // + the static loss scratch
+}
 
 void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
                const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
@@ -914,6 +919,7 @@ void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* p
 		case 16: dispatch_train<16>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		case 32: dispatch_train<32>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		case 64: dispatch_train<64>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
+		case 128: dispatch_train<128>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 	}
 }
 

@@ -203,6 +203,9 @@ def test_mlp_fused_training_pass_equals_the_unfused_kernels(case, loss_type):
     target = rng.random((n, OUT), dtype=np.float32)
     pdf = (0.5 + rng.random((n, OUT), dtype=np.float32)) if loss_type == O.LOSS_L2 else None
     fused = emu.mlp_train(om, ph, xs, loss_type, target, OUT, data_pdf=pdf, n_total=2 * n * OUT)
+    if W > 64:
+        assert fused is None  # 128-wide networks keep the three-kernel path (measured: no gain from fusing)
+        return
     out_f, dy_f, dx_f, g_f, loss_f = fused
     hid, out = emu.mlp_forward(om, ph, xs)
     _, dy, loss_u = emu.loss(loss_type, out, target, OUT, data_pdf=pdf, n_total=2 * n * OUT)

@@ -907,7 +907,9 @@ static void dispatch_train(hipStream_t stream, const MlpMeta& m, uint32_t n, con
 }
 
 bool mlp_train_supported(const MlpMeta& m) {
-	return m.n_hidden_matmuls <= MLP_MAX_HIDDEN_MATMULS_TRAIN && mlp_train_lds_bytes(m) + 4096u <= 160u * 1024u;  // + the static loss scratch
+	// 128-wide networks: measured no faster than the three-kernel path (the weight-gradient accumulators of four
+	// 128 x 128 matrices spill), so they keep it
+	return m.width <= 64 && m.n_hidden_matmuls <= MLP_MAX_HIDDEN_MATMULS_TRAIN && mlp_train_lds_bytes(m) + 4096u <= 160u * 1024u;
 }
 
 void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
@@ -919,7 +921,6 @@ void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* p
 		case 16: dispatch_train<16>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		case 32: dispatch_train<32>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		case 64: dispatch_train<64>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
-		case 128: dispatch_train<128>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 	}
 }
 

@@ -117,8 +117,9 @@ int emu_mlp_backward(const EmuMlp* e, uint32_t n, const uint16_t* params, const 
 			mlp_output_activation_backward(nullptr, m, n, (const half_t*)output, (const half_t*)dL_doutput, (half_t*)dpre.data());
 			dL_doutput = dpre.data();
 		}
+		std::vector<unsigned char> deep(mlp_backward_workspace_bytes(m, n) + 16, 0xCD);
 		mlp_backward(nullptr, m, n, (const half_t*)params_t.data(), (const half_t*)input_soa, (const half_t*)hidden,
-		             (const half_t*)dL_doutput, (half_t*)dL_dinput_soa, grads ? partials.data() : nullptr);
+		             (const half_t*)dL_doutput, (half_t*)dL_dinput_soa, grads ? partials.data() : nullptr, deep.data());
 		if (grads) mlp_finalize_gradients(nullptr, m.n_params(), np, partials.data(), (half_t*)grads, accumulate != 0);
 	} catch (const std::exception& ex) {
 		fprintf(stderr, "emu_mlp_backward: %s\n", ex.what());

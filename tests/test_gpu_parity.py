@@ -149,7 +149,8 @@ def test_grid_forward_full_size_bit_exact_and_checksum():
     assert np.all(np.abs(sums - ref) <= scale * 2.0 ** -8 + 1e-2)
 
 
-MLP_CASES = [(32, 64, 4, 2), (16, 16, 3, 1), (48, 32, 16, 3), (32, 128, 16, 4), (128, 64, 5, 2), (64, 64, 16, 2), (16, 32, 2, 4)]
+MLP_CASES = [(32, 64, 4, 2), (16, 16, 3, 1), (48, 32, 16, 3), (32, 128, 16, 4), (128, 64, 5, 2), (64, 64, 16, 2), (16, 32, 2, 4),
+             (32, 64, 4, 6), (32, 128, 8, 8)]  # the last two: deeper than the register-resident kernels (layer-by-layer backward)
 
 
 @pytest.mark.parametrize("IN,W,OUT,H", MLP_CASES)

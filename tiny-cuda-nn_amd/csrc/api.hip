@@ -642,8 +642,10 @@ static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx
 			mlp_output_activation_backward(stream, md.net.mlp, n, output, dL_doutput, dpre.as<half_t>());
 			dL_doutput = dpre.as<half_t>();
 		}
+		Scratch deep;
+		if (const size_t deep_bytes = mlp_backward_workspace_bytes(md.net.mlp, n)) deep = Scratch(stream, deep_bytes);
 		mlp_backward(stream, md.net.mlp, n, params_t.as<half_t>(), ctx.enc.as<half_t>(), ctx.hidden.as<half_t>(), dL_doutput,
-		             need_denc ? denc.as<half_t>() : nullptr, want_grads ? partials.as<float>() : nullptr);
+		             need_denc ? denc.as<half_t>() : nullptr, want_grads ? partials.as<float>() : nullptr, deep.ptr);
 		if (want_grads) mlp_finalize_gradients(stream, (uint32_t)md.n_mlp_params(), n_partials, partials.as<float>(), dL_dparams, accumulate);
 		if (!need_denc) return;
 		dL_denc = denc.as<half_t>();

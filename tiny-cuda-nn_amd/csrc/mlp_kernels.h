@@ -56,7 +56,7 @@ TCNN_HOST_DEVICE uint32_t mlp_transposed_index(const MlpMeta& m, uint32_t i) {
 	return n_in + n_hid + k * m.padded_out + o;
 }
 
-constexpr uint32_t MLP_MAX_HIDDEN_MATMULS_TRAIN = 3;  // backward kernels are instantiated for 0..3
+constexpr uint32_t MLP_MAX_HIDDEN_MATMULS_TRAIN = 3;  // the register-resident backward / training kernels are instantiated for 0..3
 constexpr uint32_t MLP_MAX_IN_WIDTH = 128;
 
 // Forward.  hidden == nullptr -> inference (nothing saved).
@@ -77,8 +77,11 @@ void mlp_output_activation_backward(hipStream_t stream, const MlpMeta& m, uint32
 // Backward.  dL_doutput is the gradient w.r.t. the output layer's PRE-activation (== dL/doutput when the output
 // activation is None).  params_t from mlp_transpose_weights.  dL_dinput may be null.  partials: fp32
 // [mlp_backward_n_partials][n_params] or null (GradientMode::Ignore).
+// Networks with more than MLP_MAX_HIDDEN_MATMULS_TRAIN + 1 hidden layers run a layer-by-layer formulation that
+// needs `workspace` (mlp_backward_workspace_bytes, 0 for the shallower ones).
+size_t mlp_backward_workspace_bytes(const MlpMeta& m, uint32_t n);
 void mlp_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params_t, const half_t* input, const half_t* hidden,
-                  const half_t* dL_doutput, half_t* dL_dinput, float* partials);
+                  const half_t* dL_doutput, half_t* dL_dinput, float* partials, void* workspace = nullptr);
 
 // Fused training pass of Trainer::training_step (trainer.h:254-357): forward + loss + backward per sample tile in one
 // kernel -- the hidden activations stay in LDS, prediction / dL_doutput are written for the caller's ForwardContext

@@ -362,6 +362,208 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 }
 
 // =============================================================================================
+// backward for networks deeper than the register-resident kernels cover (more than 4 hidden layers): the structure
+// of the reference (fully_fused_mlp.cu:740-837) -- one pass propagates dL/d(pre-activation) through all layers and
+// stores it per layer, then one weight-gradient product per matrix.  Depth is a run-time value here.
+// =============================================================================================
+template <uint32_t WIDTH, bool GENERAL>
+__global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward_chain(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params_t,
+                                                                         const half_t* __restrict__ hidden, const half_t* __restrict__ dL_doutput,
+                                                                         half_t* __restrict__ dact_all, half_t* __restrict__ dL_dinput) {
+	constexpr uint32_t NW = WIDTH / 16, THREADS = NW * 64, S = MLP_BWD_TILE, NT = S / 16;
+	constexpr uint32_t SP = S + 8, LDW = WIDTH + 8;
+	TCNN_DYN_LDS(lds_raw);
+	const uint32_t IN = m.in_width, nb_in = IN / 16, HM = m.n_hidden_matmuls;
+	half_t* hT = (half_t*)lds_raw;        // [WIDTH][SP]  forward activation of the current layer, feature-major (masks)
+	half_t* dact0 = hT + WIDTH * SP;      // [S][LDW]     dL/d(pre-activation), sample-major ping-pong
+	half_t* dact1 = dact0 + S * LDW;
+	half_t* dxT = dact1 + S * LDW;        // [IN][SP]
+
+	const half_t* wt_in = params_t;
+	const half_t* wt_hid = wt_in + (size_t)IN * WIDTH;
+	const half_t* wt_out = wt_hid + (size_t)HM * WIDTH * WIDTH;
+	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
+	const uint32_t act = m.activation;
+	const uint32_t n_tiles = n / S;
+
+	auto stage_hidden = [&](uint32_t layer, uint32_t tile) {  // hidden[layer] tile, transposed (consecutive lanes = consecutive neurons)
+		const half_t* src = hidden + ((size_t)layer * n + (size_t)tile * S) * WIDTH;
+		for (uint32_t c = tid; c < S * (WIDTH / 8); c += THREADS) {
+			const uint32_t i = c % S, cc = c / S;
+			const h8 v = *(const h8*)(src + (size_t)i * WIDTH + 8 * cc);
+#pragma unroll
+			for (uint32_t j = 0; j < 8; ++j) hT[(8 * cc + j) * SP + i] = v[j];
+		}
+	};
+	auto store_dact = [&](uint32_t layer, uint32_t tile, const half_t* tile_lds) {  // sample-major LDS tile -> dact_all[layer]
+		half_t* dst = dact_all + ((size_t)layer * n + (size_t)tile * S) * WIDTH;
+		for (uint32_t c = tid; c < S * (WIDTH / 8); c += THREADS) {
+			const uint32_t i = c / (WIDTH / 8), cc = c % (WIDTH / 8);
+			*(h8*)(dst + (size_t)i * WIDTH + 8 * cc) = *(const h8*)(tile_lds + i * LDW + 8 * cc);
+		}
+	};
+
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		stage_hidden(HM, tile);
+		__syncthreads();
+		{  // output matrix: dA_last[s][k] = sum_o dY[s][o] W_out[o][k], transferred through the last hidden activation
+			const h4 bw = *(const h4*)(wt_out + (size_t)(16 * w + lr) * 16 + 4 * g);
+#pragma unroll
+			for (uint32_t t = 0; t < NT; ++t) {
+				const h4 a = *(const h4*)(dL_doutput + ((size_t)tile * S + 16 * t + lr) * 16 + 4 * g);
+				const f4 acc = mfma_16x16x16(a, bw, zero4());
+				const h4 hv = *(const h4*)(hT + (16 * w + lr) * SP + 16 * t + 4 * g);
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) dact0[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = (half_t)act_backward<GENERAL>(act, acc[r], hv[r]);
+			}
+		}
+		__syncthreads();
+		store_dact(HM, tile, dact0);
+		half_t* cur = dact0;
+		half_t* nxt = dact1;
+		for (int j = (int)HM - 1; j >= 0; --j) {
+			stage_hidden((uint32_t)j, tile);  // hT is free: the previous layer's masks were consumed before the barrier above
+			__syncthreads();
+			const half_t* wt = wt_hid + (size_t)j * WIDTH * WIDTH + (size_t)(16 * w + lr) * WIDTH;
+			f4 acc[NT];
+#pragma unroll
+			for (uint32_t t = 0; t < NT; ++t) acc[t] = zero4();
+#pragma unroll
+			for (uint32_t kb = 0; kb < WIDTH / 32; ++kb) {
+				const h8 bw = *(const h8*)(wt + 32 * kb + 8 * g);
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) {
+					const h8 a = *(const h8*)(cur + (16 * t + lr) * LDW + 32 * kb + 8 * g);
+					acc[t] = mfma_16x16x32(a, bw, acc[t]);
+				}
+			}
+			if constexpr (WIDTH % 32 != 0) {
+				constexpr uint32_t k0 = WIDTH & ~31u;
+				const h4 bw = *(const h4*)(wt + k0 + 4 * g);
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) {
+					const h4 a = *(const h4*)(cur + (16 * t + lr) * LDW + k0 + 4 * g);
+					acc[t] = mfma_16x16x16(a, bw, acc[t]);
+				}
+			}
+#pragma unroll
+			for (uint32_t t = 0; t < NT; ++t) {
+				const h4 hv = *(const h4*)(hT + (16 * w + lr) * SP + 16 * t + 4 * g);
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) nxt[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = (half_t)act_backward<GENERAL>(act, acc[t][r], hv[r]);
+			}
+			__syncthreads();
+			store_dact((uint32_t)j, tile, nxt);
+			half_t* tmp = cur;
+			cur = nxt;
+			nxt = tmp;
+		}
+		if (dL_dinput) {  // dX[s][k] = sum_jj dA_0[s][jj] M_in[jj][k]
+			for (uint32_t sl = w; sl < nb_in; sl += NW) {
+				const half_t* wt = wt_in + (size_t)(16 * sl + lr) * WIDTH;
+				f4 acc[NT];
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) acc[t] = zero4();
+#pragma unroll
+				for (uint32_t kb = 0; kb < WIDTH / 32; ++kb) {
+					const h8 bw = *(const h8*)(wt + 32 * kb + 8 * g);
+#pragma unroll
+					for (uint32_t t = 0; t < NT; ++t) {
+						const h8 a = *(const h8*)(cur + (16 * t + lr) * LDW + 32 * kb + 8 * g);
+						acc[t] = mfma_16x16x32(a, bw, acc[t]);
+					}
+				}
+				if constexpr (WIDTH % 32 != 0) {
+					constexpr uint32_t k0 = WIDTH & ~31u;
+					const h4 bw = *(const h4*)(wt + k0 + 4 * g);
+#pragma unroll
+					for (uint32_t t = 0; t < NT; ++t) {
+						const h4 a = *(const h4*)(cur + (16 * t + lr) * LDW + k0 + 4 * g);
+						acc[t] = mfma_16x16x16(a, bw, acc[t]);
+					}
+				}
+#pragma unroll
+				for (uint32_t t = 0; t < NT; ++t) {
+					const h4 o = h4{(half_t)acc[t][0], (half_t)acc[t][1], (half_t)acc[t][2], (half_t)acc[t][3]};
+					*(h4*)(dxT + (16 * sl + lr) * SP + 16 * t + 4 * g) = o;
+				}
+			}
+			__syncthreads();
+			for (uint32_t c = tid; c < IN * (S / 8); c += THREADS) {
+				const uint32_t k = c / (S / 8), cc = c % (S / 8);
+				*(h8*)(dL_dinput + (size_t)k * n + (size_t)tile * S + 8 * cc) = *(const h8*)(dxT + k * SP + 8 * cc);
+			}
+		}
+		__syncthreads();
+	}
+}
+
+// dW[out][in] += sum_s d[s][out] * a[s][in] for ONE matrix.  d: sample-major [n][d_stride] (WO columns used), a: sample-major
+// [n][WI] (a_feature_major == 0) or feature-major [WI][n].  Accumulators stay in registers over all tiles of a persistent
+// workgroup; P = this workgroup's fp32 slab at the matrix' offset, natural [out][in] layout.  THREADS = WIDTH / 16 * 64.
+template <uint32_t WIDTH>
+__global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_weight_gradient(const uint32_t n, const uint32_t WO, const uint32_t WI, const half_t* __restrict__ d,
+                                                                          const uint32_t d_stride, const half_t* __restrict__ a, const int a_feature_major,
+                                                                          float* __restrict__ partials, const size_t slab_stride, const size_t matrix_offset) {
+	constexpr uint32_t NW = WIDTH / 16, THREADS = NW * 64, S = MLP_BWD_TILE, NTP = S / 32, SP = S + 8, MAXP = 8;
+	TCNN_DYN_LDS(lds_raw);
+	half_t* dT = (half_t*)lds_raw;  // [WO][SP]
+	half_t* aT = dT + WO * SP;      // [WI][SP]
+	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
+	const uint32_t n_ob = WO / 16, n_ib = WI / 16, n_pairs = n_ob * n_ib;  // (out block, in block) products, dealt round-robin to the waves
+	f4 acc[MAXP];
+#pragma unroll
+	for (uint32_t q = 0; q < MAXP; ++q) acc[q] = zero4();
+	const uint32_t n_tiles = n / S;
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		for (uint32_t c = tid; c < S * (WO / 8); c += THREADS) {  // transpose d (consecutive lanes = consecutive samples' rows, 16 bytes each)
+			const uint32_t i = c % S, cc = c / S;
+			const h8 v = *(const h8*)(d + ((size_t)tile * S + i) * d_stride + 8 * cc);
+#pragma unroll
+			for (uint32_t j = 0; j < 8; ++j) dT[(8 * cc + j) * SP + i] = v[j];
+		}
+		if (a_feature_major) {
+			for (uint32_t c = tid; c < WI * (S / 8); c += THREADS) {
+				const uint32_t k = c / (S / 8), cc = c % (S / 8);
+				*(h8*)(aT + k * SP + 8 * cc) = *(const h8*)(a + (size_t)k * n + (size_t)tile * S + 8 * cc);
+			}
+		} else {
+			for (uint32_t c = tid; c < S * (WI / 8); c += THREADS) {
+				const uint32_t i = c % S, cc = c / S;
+				const h8 v = *(const h8*)(a + ((size_t)tile * S + i) * WI + 8 * cc);
+#pragma unroll
+				for (uint32_t j = 0; j < 8; ++j) aT[(8 * cc + j) * SP + i] = v[j];
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (uint32_t q = 0; q < MAXP; ++q) {
+			const uint32_t p = w + q * NW;
+			if (p < n_pairs) {
+				const uint32_t ob = p / n_ib, ib = p % n_ib;
+#pragma unroll
+				for (uint32_t tp = 0; tp < NTP; ++tp) {
+					const h8 av = *(const h8*)(dT + (16 * ob + lr) * SP + 32 * tp + 8 * g);
+					const h8 bv = *(const h8*)(aT + (16 * ib + lr) * SP + 32 * tp + 8 * g);
+					acc[q] = mfma_16x16x32(av, bv, acc[q]);
+				}
+			}
+		}
+		__syncthreads();
+	}
+	float* P = partials + (size_t)blockIdx.x * slab_stride + matrix_offset;
+#pragma unroll
+	for (uint32_t q = 0; q < MAXP; ++q) {
+		const uint32_t p = w + q * NW;
+		if (p < n_pairs) {
+			const uint32_t ob = p / n_ib, ib = p % n_ib;
+#pragma unroll
+			for (uint32_t r = 0; r < 4; ++r) P[(size_t)(16 * ob + 4 * g + r) * WI + 16 * ib + lr] = acc[q][r];
+		}
+	}
+}
+
+// =============================================================================================
 // fused training pass: forward + loss + backward of one sample tile without leaving the CU.
 // What Trainer::training_step needs from the network (trainer.h:254-357) in ONE kernel: the hidden activations
 // never travel to HBM (2 x 64 MB at the headline config), the prediction / dL_doutput are written once for the
@@ -846,29 +1048,63 @@ static void launch_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, co
 	}
 }
 
+// networks with more than MLP_MAX_HIDDEN_MATMULS_TRAIN + 1 hidden layers: chain kernel + one weight-gradient product per matrix
+template <uint32_t WIDTH>
+static void launch_backward_deep(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params_t, const half_t* input, const half_t* hidden,
+                                 const half_t* dL_doutput, half_t* dL_dinput, float* partials, void* workspace) {
+	constexpr uint32_t S = MLP_BWD_TILE, SP = S + 8, LDW = WIDTH + 8, THREADS = WIDTH / 16 * 64;
+	if (!workspace) throw std::runtime_error("mlp_backward: networks with more than 4 hidden layers need a workspace (mlp_backward_workspace_bytes)");
+	half_t* dact_all = (half_t*)workspace;  // [n_hidden][n][WIDTH]
+	const uint32_t blocks = mlp_backward_n_partials(m, n);
+	const uint32_t chain_lds = (WIDTH * SP + 2 * S * LDW + m.in_width * SP) * (uint32_t)sizeof(half_t);
+	if (!act_is_simple(m.activation)) {
+		TCNN_SET_MAX_DYN_LDS((k_mlp_backward_chain<WIDTH, true>), chain_lds);
+		TCNN_LAUNCH((k_mlp_backward_chain<WIDTH, true>), dim3(blocks), dim3(THREADS), chain_lds, stream, m, n, params_t, hidden, dL_doutput, dact_all, dL_dinput);
+	} else {
+		TCNN_SET_MAX_DYN_LDS((k_mlp_backward_chain<WIDTH, false>), chain_lds);
+		TCNN_LAUNCH((k_mlp_backward_chain<WIDTH, false>), dim3(blocks), dim3(THREADS), chain_lds, stream, m, n, params_t, hidden, dL_doutput, dact_all, dL_dinput);
+	}
+	if (!partials) return;
+	const uint32_t HM = m.n_hidden_matmuls, IN = m.in_width;
+	const size_t slab = m.n_params(), off_hid = (size_t)WIDTH * IN, off_out = off_hid + (size_t)HM * WIDTH * WIDTH;
+	auto product = [&](uint32_t WO, uint32_t WI, const half_t* d, uint32_t d_stride, const half_t* a, int a_fm, size_t offset) {
+		const uint32_t lds = (WO + WI) * SP * (uint32_t)sizeof(half_t);
+		TCNN_SET_MAX_DYN_LDS((k_mlp_weight_gradient<WIDTH>), lds);
+		TCNN_LAUNCH((k_mlp_weight_gradient<WIDTH>), dim3(blocks), dim3(THREADS), lds, stream, n, WO, WI, d, d_stride, a, a_fm, partials, slab, offset);
+	};
+	// output matrix [16][W]: d = dL/doutput, a = last hidden activation
+	product(m.padded_out, WIDTH, dL_doutput, m.padded_out, hidden + (size_t)HM * n * WIDTH, 0, off_out);
+	for (uint32_t j = 0; j < HM; ++j) {  // hidden matrix j: d = dL/d(pre-activation of hidden layer j + 1), a = hidden layer j
+		product(WIDTH, WIDTH, dact_all + (size_t)(j + 1) * n * WIDTH, WIDTH, hidden + (size_t)j * n * WIDTH, 0, off_hid + (size_t)j * WIDTH * WIDTH);
+	}
+	product(WIDTH, IN, dact_all, WIDTH, input, 1, 0);  // input matrix: a = the feature-major network input
+}
+
 template <uint32_t WIDTH>
 static void dispatch_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params_t, const half_t* input, const half_t* hidden,
-                              const half_t* dL_doutput, half_t* dL_dinput, float* partials) {
+                              const half_t* dL_doutput, half_t* dL_dinput, float* partials, void* workspace) {
 	switch (m.n_hidden_matmuls) {
 		case 0: launch_backward<WIDTH, 0>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
 		case 1: launch_backward<WIDTH, 1>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
 		case 2: launch_backward<WIDTH, 2>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
 		case 3: launch_backward<WIDTH, 3>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
-		default:
-			throw std::runtime_error("FullyFusedMLP backward: at most " + std::to_string(MLP_MAX_HIDDEN_MATMULS_TRAIN + 1) +
-			                         " hidden layers are supported by the fused training kernels.");
+		default: launch_backward_deep<WIDTH>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials, workspace); break;
 	}
 }
 
+size_t mlp_backward_workspace_bytes(const MlpMeta& m, uint32_t n) {
+	return m.n_hidden_matmuls > MLP_MAX_HIDDEN_MATMULS_TRAIN ? (size_t)(m.n_hidden_matmuls + 1) * n * m.width * sizeof(half_t) : 0;
+}
+
 void mlp_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params_t, const half_t* input, const half_t* hidden,
-                  const half_t* dL_doutput, half_t* dL_dinput, float* partials) {
+                  const half_t* dL_doutput, half_t* dL_dinput, float* partials, void* workspace) {
 	check_meta(m, n);
 	if (n == 0) return;
 	switch (m.width) {
-		case 16: dispatch_backward<16>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
-		case 32: dispatch_backward<32>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
-		case 64: dispatch_backward<64>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
-		case 128: dispatch_backward<128>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
+		case 16: dispatch_backward<16>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials, workspace); break;
+		case 32: dispatch_backward<32>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials, workspace); break;
+		case 64: dispatch_backward<64>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials, workspace); break;
+		case 128: dispatch_backward<128>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials, workspace); break;
 	}
 }
 

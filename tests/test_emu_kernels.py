@@ -123,7 +123,8 @@ def test_grid_backward_bucket_chunks():
 
 
 MLP_CASES = [(32, 64, 4, 2), (16, 16, 3, 1), (48, 32, 16, 3), (32, 128, 16, 4), (128, 64, 5, 2), (64, 64, 1, 1),
-             (32, 64, 4, 6), (48, 16, 2, 5)]  # the last two: deeper than the register-resident kernels (layer-by-layer backward)
+             (32, 64, 4, 6), (48, 16, 2, 5),  # deeper than the register-resident kernels (layer-by-layer backward)
+             (32, 64, 40, 2), (16, 32, 100, 3)]  # more than 16 outputs (several output blocks, layer-by-layer backward)
 
 
 @pytest.mark.parametrize("case", MLP_CASES)
@@ -204,8 +205,8 @@ def test_mlp_fused_training_pass_equals_the_unfused_kernels(case, loss_type):
     target = rng.random((n, OUT), dtype=np.float32)
     pdf = (0.5 + rng.random((n, OUT), dtype=np.float32)) if loss_type == O.LOSS_L2 else None
     fused = emu.mlp_train(om, ph, xs, loss_type, target, OUT, data_pdf=pdf, n_total=2 * n * OUT)
-    if W > 64 or H > 4:
-        assert fused is None  # 128-wide (measured: no gain from fusing) and deep networks keep the multi-kernel path
+    if W > 64 or H > 4 or OUT > 16:
+        assert fused is None  # 128-wide (measured: no gain from fusing), deep and wide-output networks keep the multi-kernel path
         return
     out_f, dy_f, dx_f, g_f, loss_f = fused
     hid, out = emu.mlp_forward(om, ph, xs)

@@ -150,7 +150,8 @@ def test_grid_forward_full_size_bit_exact_and_checksum():
 
 
 MLP_CASES = [(32, 64, 4, 2), (16, 16, 3, 1), (48, 32, 16, 3), (32, 128, 16, 4), (128, 64, 5, 2), (64, 64, 16, 2), (16, 32, 2, 4),
-             (32, 64, 4, 6), (32, 128, 8, 8)]  # the last two: deeper than the register-resident kernels (layer-by-layer backward)
+             (32, 64, 4, 6), (32, 128, 8, 8),  # deeper than the register-resident kernels (layer-by-layer backward)
+             (32, 64, 40, 2), (16, 32, 100, 3)]  # more than 16 outputs
 
 
 @pytest.mark.parametrize("IN,W,OUT,H", MLP_CASES)
@@ -165,7 +166,7 @@ def test_network_forward_backward(IN, W, OUT, H):
     act = "ReLU" if H <= 4 else "None"
     m = C.create_network(n_in, OUT, dict(MLP_64x2, n_neurons=W, n_hidden_layers=H, activation=act))
     om = O.mlp_init(IN, W, OUT, H, activation=O.ACTIVATION_NAMES.index(act))
-    assert m.n_params() == om.n_params and m.n_output_dims() == 16
+    assert m.n_params() == om.n_params and m.n_output_dims() == om.padded_out == (OUT + 15) // 16 * 16
     p32 = m.initial_params(1337).cpu().numpy()
     assert np.array_equal(p32, O.mlp_init_params(om, O.pcg32(1337)))  # Xavier draw order, gpu_matrix.h:292-307
     ph = O.f2h(p32)
@@ -184,7 +185,7 @@ def test_network_forward_backward(IN, W, OUT, H):
     assert np.percentile(rae(O.h2f(h_np(y)), O.h2f(out_ref)), 99) < bar
     assert np.max(np.abs(O.h2f(h_np(y)) - O.h2f(out_ref))) < 2e-2 * max(1.0, np.abs(O.h2f(out_ref)).max())
 
-    dy = np.zeros((n, 16), np.float32)
+    dy = np.zeros((n, om.padded_out), np.float32)
     dy[:, :OUT] = rng.standard_normal((n, OUT)).astype(np.float32) * 0.05
     dyh = O.f2h(dy)
     dx, dp = m.bwd(ctx, x, p, y, h_t(dyh))

@@ -478,7 +478,9 @@ static NetworkDesc create_network_desc(uint32_t n_input_dims, uint32_t n_output_
 	d.mlp.n_hidden_matmuls = d.n_hidden_layers - 1;
 	d.mlp.activation = (uint32_t)act;
 	d.mlp.output_activation = (uint32_t)out_act;
-	if (d.mlp.padded_out != 16) throw std::runtime_error("FullyFusedMLP: more than 16 output dimensions are not supported by the fused kernels of this build.");
+	if (d.mlp.padded_out > MLP_MAX_OUT_WIDTH) {
+		throw std::runtime_error("FullyFusedMLP: more than " + std::to_string(MLP_MAX_OUT_WIDTH) + " output dimensions are not supported by this build.");
+	}
 	if (n_input_dims % 16 != 0 || n_input_dims > MLP_MAX_IN_WIDTH) {
 		throw std::runtime_error("FullyFusedMLP: input width " + std::to_string(n_input_dims) + " must be a multiple of 16 and at most " + std::to_string(MLP_MAX_IN_WIDTH));
 	}

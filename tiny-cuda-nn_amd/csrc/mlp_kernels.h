@@ -30,7 +30,7 @@ namespace tcnn_hip {
 struct MlpMeta {
 	uint32_t in_width;          // multiple of 16
 	uint32_t width;             // 16 / 32 / 64 / 128
-	uint32_t padded_out;        // 16 (outputs wider than 16 are not fused yet)
+	uint32_t padded_out;        // multiple of 16, <= MLP_MAX_OUT_WIDTH
 	uint32_t n_hidden_matmuls;  // n_hidden_layers - 1
 	uint32_t activation;        // Activation of the hidden layers
 	uint32_t output_activation; // Activation of the output layer (default None)
@@ -58,6 +58,7 @@ TCNN_HOST_DEVICE uint32_t mlp_transposed_index(const MlpMeta& m, uint32_t i) {
 
 constexpr uint32_t MLP_MAX_HIDDEN_MATMULS_TRAIN = 3;  // the register-resident backward / training kernels are instantiated for 0..3
 constexpr uint32_t MLP_MAX_IN_WIDTH = 128;
+constexpr uint32_t MLP_MAX_OUT_WIDTH = 128;  // padded; more than 16 outputs train through the layer-by-layer backward
 
 // Forward.  hidden == nullptr -> inference (nothing saved).
 void mlp_forward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* hidden,

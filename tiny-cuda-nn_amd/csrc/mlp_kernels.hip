@@ -101,10 +101,12 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_forward(const MlpMeta m
 			K = WIDTH;
 		}
 
-		// ---- output layer: 16 (padded) outputs; sample tiles are spread over the waves
-		for (uint32_t t = w; t < NT; t += NW) {
+		// ---- output layer: padded_out / 16 blocks of 16 outputs; (sample tile, output block) items are spread over the waves
+		const uint32_t OUTP = m.padded_out;
+		for (uint32_t item = w; item < NT * (OUTP / 16); item += NW) {
+			const uint32_t t = item % NT, ob = item / NT;
 			f4 acc = zero4();
-			const half_t* wrow = Wl + (size_t)lr * WIDTH;
+			const half_t* wrow = Wl + (size_t)(16 * ob + lr) * WIDTH;
 #pragma unroll
 			for (uint32_t kb = 0; kb < WIDTH / 32; ++kb) {
 				const h8 a = *(const h8*)(wrow + 32 * kb + 8 * g);
@@ -119,7 +121,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_forward(const MlpMeta m
 			}
 			const h4 o = h4{(half_t)act_forward<GENERAL>(out_act, acc[0]), (half_t)act_forward<GENERAL>(out_act, acc[1]), (half_t)act_forward<GENERAL>(out_act, acc[2]),
 			                (half_t)act_forward<GENERAL>(out_act, acc[3])};
-			*(h4*)(output + ((size_t)tile * S + 16 * t + lr) * 16 + 4 * g) = o;  // (output 4g+r, sample 16t+lr)
+			*(h4*)(output + ((size_t)tile * S + 16 * t + lr) * OUTP + 16 * ob + 4 * g) = o;  // (output 16ob+4g+r, sample 16t+lr)
 		}
 		__syncthreads();
 	}
@@ -407,11 +409,15 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward_chain(const Ml
 		stage_hidden(HM, tile);
 		__syncthreads();
 		{  // output matrix: dA_last[s][k] = sum_o dY[s][o] W_out[o][k], transferred through the last hidden activation
-			const h4 bw = *(const h4*)(wt_out + (size_t)(16 * w + lr) * 16 + 4 * g);
+			const uint32_t OUTP = m.padded_out;
 #pragma unroll
 			for (uint32_t t = 0; t < NT; ++t) {
-				const h4 a = *(const h4*)(dL_doutput + ((size_t)tile * S + 16 * t + lr) * 16 + 4 * g);
-				const f4 acc = mfma_16x16x16(a, bw, zero4());
+				f4 acc = zero4();
+				for (uint32_t ob = 0; ob < OUTP / 16; ++ob) {
+					const h4 bw = *(const h4*)(wt_out + (size_t)(16 * w + lr) * OUTP + 16 * ob + 4 * g);
+					const h4 a = *(const h4*)(dL_doutput + ((size_t)tile * S + 16 * t + lr) * OUTP + 16 * ob + 4 * g);
+					acc = mfma_16x16x16(a, bw, acc);
+				}
 				const h4 hv = *(const h4*)(hT + (16 * w + lr) * SP + 16 * t + 4 * g);
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) dact0[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = (half_t)act_backward<GENERAL>(act, acc[r], hv[r]);
@@ -984,7 +990,9 @@ static void check_meta(const MlpMeta& m, uint32_t n) {
 	if (m.in_width % 16 != 0 || m.in_width == 0 || m.in_width > MLP_MAX_IN_WIDTH) {
 		throw std::runtime_error("FullyFusedMLP: input width must be a multiple of 16 and at most " + std::to_string(MLP_MAX_IN_WIDTH) + ".");
 	}
-	if (m.padded_out != 16) throw std::runtime_error("FullyFusedMLP: only up to 16 output dimensions are supported by the fused kernels.");
+	if (m.padded_out % 16 != 0 || m.padded_out == 0 || m.padded_out > MLP_MAX_OUT_WIDTH) {
+		throw std::runtime_error("FullyFusedMLP: at most " + std::to_string(MLP_MAX_OUT_WIDTH) + " output dimensions are supported.");
+	}
 	if (n % BATCH_SIZE_GRANULARITY != 0) throw std::runtime_error("Batch size must be a multiple of 256.");
 }
 
@@ -1053,7 +1061,7 @@ template <uint32_t WIDTH>
 static void launch_backward_deep(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params_t, const half_t* input, const half_t* hidden,
                                  const half_t* dL_doutput, half_t* dL_dinput, float* partials, void* workspace) {
 	constexpr uint32_t S = MLP_BWD_TILE, SP = S + 8, LDW = WIDTH + 8, THREADS = WIDTH / 16 * 64;
-	if (!workspace) throw std::runtime_error("mlp_backward: networks with more than 4 hidden layers need a workspace (mlp_backward_workspace_bytes)");
+	if (!workspace) throw std::runtime_error("mlp_backward: networks with more than 4 hidden layers or 16 outputs need a workspace (mlp_backward_workspace_bytes)");
 	half_t* dact_all = (half_t*)workspace;  // [n_hidden][n][WIDTH]
 	const uint32_t blocks = mlp_backward_n_partials(m, n);
 	const uint32_t chain_lds = (WIDTH * SP + 2 * S * LDW + m.in_width * SP) * (uint32_t)sizeof(half_t);
@@ -1083,6 +1091,10 @@ static void launch_backward_deep(hipStream_t stream, const MlpMeta& m, uint32_t 
 template <uint32_t WIDTH>
 static void dispatch_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params_t, const half_t* input, const half_t* hidden,
                               const half_t* dL_doutput, half_t* dL_dinput, float* partials, void* workspace) {
+	if (m.padded_out != 16) {  // the register-resident kernels are built for one block of 16 outputs
+		launch_backward_deep<WIDTH>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials, workspace);
+		return;
+	}
 	switch (m.n_hidden_matmuls) {
 		case 0: launch_backward<WIDTH, 0>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
 		case 1: launch_backward<WIDTH, 1>(stream, m, n, params_t, input, hidden, dL_doutput, dL_dinput, partials); break;
@@ -1093,7 +1105,8 @@ static void dispatch_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, 
 }
 
 size_t mlp_backward_workspace_bytes(const MlpMeta& m, uint32_t n) {
-	return m.n_hidden_matmuls > MLP_MAX_HIDDEN_MATMULS_TRAIN ? (size_t)(m.n_hidden_matmuls + 1) * n * m.width * sizeof(half_t) : 0;
+	const bool layer_by_layer = m.n_hidden_matmuls > MLP_MAX_HIDDEN_MATMULS_TRAIN || m.padded_out != 16;
+	return layer_by_layer ? (size_t)(m.n_hidden_matmuls + 1) * n * m.width * sizeof(half_t) : 0;
 }
 
 void mlp_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params_t, const half_t* input, const half_t* hidden,
@@ -1145,7 +1158,7 @@ static void dispatch_train(hipStream_t stream, const MlpMeta& m, uint32_t n, con
 bool mlp_train_supported(const MlpMeta& m) {
 	// 128-wide networks: measured no faster than the three-kernel path (the weight-gradient accumulators of four
 	// 128 x 128 matrices spill), so they keep it
-	return m.width <= 64 && m.n_hidden_matmuls <= MLP_MAX_HIDDEN_MATMULS_TRAIN && mlp_train_lds_bytes(m) + 4096u <= 160u * 1024u;
+	return m.width <= 64 && m.padded_out == 16 && m.n_hidden_matmuls <= MLP_MAX_HIDDEN_MATMULS_TRAIN && mlp_train_lds_bytes(m) + 4096u <= 160u * 1024u;
 }
 
 void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,

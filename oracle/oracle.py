@@ -19,8 +19,8 @@ GRID_HASH, GRID_DENSE, GRID_TILED = 0, 1, 2
 INTERP_NEAREST, INTERP_LINEAR, INTERP_SMOOTHSTEP = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_EXPONENTIAL, ACT_SIGMOID, ACT_SQUAREPLUS, ACT_SOFTPLUS, ACT_TANH = range(8)
 ACTIVATION_NAMES = ["None", "ReLU", "LeakyReLU", "Exponential", "Sigmoid", "Squareplus", "Softplus", "Tanh"]
-LOSS_L2, LOSS_RELATIVE_L2, LOSS_L1, LOSS_RELATIVE_L1, LOSS_MAPE, LOSS_SMAPE, LOSS_CROSS_ENTROPY, LOSS_VARIANCE = range(8)
-LOSS_NAMES = ["L2", "RelativeL2", "L1", "RelativeL1", "Mape", "Smape", "CrossEntropy", "Variance"]
+LOSS_L2, LOSS_RELATIVE_L2, LOSS_L1, LOSS_RELATIVE_L1, LOSS_MAPE, LOSS_SMAPE, LOSS_CROSS_ENTROPY, LOSS_VARIANCE, LOSS_RELATIVE_L2_LUMINANCE = range(9)
+LOSS_NAMES = ["L2", "RelativeL2", "L1", "RelativeL1", "Mape", "Smape", "CrossEntropy", "Variance", "RelativeL2Luminance"]
 
 
 def build(force=False):

@@ -700,6 +700,16 @@ void orc_loss(int loss_type, uint32_t n, uint32_t stride, uint32_t dims, float l
 		const float difference = p - tg;
 		float value, gradient; /* gradient: dL/dprediction * n_total */
 		switch (loss_type) {
+			case ORC_LOSS_RELATIVE_L2_LUMINANCE: { /* relative_l2_luminance.h:66-86 */
+				const uint16_t* row = prediction + (size_t)inter * stride;
+				float r = orc_h2f(row[0]), g = orc_h2f(row[1]), b = orc_h2f(row[2]);
+				if (dims >= 6) { r += orc_h2f(row[3]); g += orc_h2f(row[4]); b += orc_h2f(row[5]); }
+				const float lum = 0.299f * r + 0.587f * g + 0.114f * b;
+				const float psq = lum * lum + 0.01f;
+				value = difference * difference / psq / pdf / n_total;
+				gradient = 2 * difference / psq / pdf;
+				break;
+			}
 			case ORC_LOSS_RELATIVE_L2: { /* relative_l2.h:70-80 */
 				const float psq = p * p + 0.01f;
 				value = difference * difference / psq / pdf / n_total;

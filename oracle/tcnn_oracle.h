@@ -37,7 +37,7 @@ enum { ORC_INTERP_NEAREST = 0, ORC_INTERP_LINEAR = 1, ORC_INTERP_SMOOTHSTEP = 2 
 enum { ORC_ACT_NONE = 0, ORC_ACT_RELU = 1, ORC_ACT_LEAKY_RELU = 2, ORC_ACT_EXPONENTIAL = 3, ORC_ACT_SIGMOID = 4, ORC_ACT_SQUAREPLUS = 5,
        ORC_ACT_SOFTPLUS = 6, ORC_ACT_TANH = 7 }; /* common_device.h:108-186, 363-418 */
 enum { ORC_LOSS_L2 = 0, ORC_LOSS_RELATIVE_L2 = 1, ORC_LOSS_L1 = 2, ORC_LOSS_RELATIVE_L1 = 3, ORC_LOSS_MAPE = 4, ORC_LOSS_SMAPE = 5,
-       ORC_LOSS_CROSS_ENTROPY = 6, ORC_LOSS_VARIANCE = 7 }; /* names: src/loss.cu:57-65 */
+       ORC_LOSS_CROSS_ENTROPY = 6, ORC_LOSS_VARIANCE = 7, ORC_LOSS_RELATIVE_L2_LUMINANCE = 8 }; /* names: src/loss.cu:57-65 */
 
 /* ---- fp16 ---- */
 uint16_t orc_f2h(float f);

@@ -253,7 +253,7 @@ def targets_for(pos, out):
     return np.stack([0.5 + 0.5 * np.sin(2 * np.pi * (c + 1) * pos[:, 0]) * np.cos(2 * np.pi * pos[:, 1]) for c in range(out)], 1).astype(np.float32)
 
 
-@pytest.mark.parametrize("loss", ["RelativeL2", "L2", "L1", "RelativeL1", "Mape", "Smape"])
+@pytest.mark.parametrize("loss", ["RelativeL2", "L2", "L1", "RelativeL1", "Mape", "Smape", "RelativeL2Luminance"])
 def test_training_step_matches_oracle(loss):
     """create_from_config -> trainer.training_step -> trainer.loss -> network.inference against the oracle's
     whole-step restatement, starting from identical fp32 master parameters."""

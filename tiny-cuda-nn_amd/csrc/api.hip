@@ -906,12 +906,12 @@ int tcnn_module_grid_level_params_offset(const tcnn_module_t* m, uint32_t level,
 
 // ------------------------------------------------------------------------------------------------ trainer
 
-static const char* const LOSS_NAMES[N_LOSS_TYPES] = {"L2", "RelativeL2", "L1", "RelativeL1", "Mape", "Smape", "CrossEntropy", "Variance"};  // loss.cu:57-65
+static const char* const LOSS_NAMES[N_LOSS_TYPES] = {"L2",   "RelativeL2",   "L1",       "RelativeL1",         "Mape",
+                                                    "Smape", "CrossEntropy", "Variance", "RelativeL2Luminance"};  // loss.cu:57-65
 static LossType string_to_loss(const std::string& s) {
 	for (int i = 0; i < N_LOSS_TYPES; ++i) {
 		if (equals_case_insensitive(s, LOSS_NAMES[i])) return (LossType)i;
 	}
-	if (equals_case_insensitive(s, "RelativeL2Luminance")) throw std::runtime_error("Loss 'RelativeL2Luminance' is not available in this build.");
 	throw std::runtime_error("Loss '" + s + "' not found");  // loss.cu:86
 }
 
@@ -1254,7 +1254,7 @@ int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
                                const void* external_dL_dy, tcnn_train_context_t** ctx_out) {
 	const float loss_scale = LOSS_SCALE_FP16;  // trainer.h:265
 	tcnn_train_context_t* ctx = nullptr;
-	if (g_fused_mlp_training && !external_dL_dy && target && tm->md.has_network && mlp_train_supported(tm->md.net.mlp)) {
+	if (g_fused_mlp_training && !external_dL_dy && target && tm->md.has_network && mlp_train_supported(tm->md.net.mlp) && loss_is_elementwise(tm->loss)) {
 		int r = training_step_fused(tm, (hipStream_t)stream, loss_scale, n, input, target, data_pdf, dL_dinput, use_inference_params, gradient_mode, &ctx);
 		if (r == TCNN_OK && run_optimizer) r = tcnn_trainer_optimizer_step(tm, stream, loss_scale);
 		if (ctx_out && r == TCNN_OK) {

@@ -99,6 +99,17 @@ __global__ void __launch_bounds__(EW_THREADS) k_loss(const LossType type, uint32
 		h8 g8;
 		float v8[8];
 		const float n_total = (float)n_total_u;
+		float luminance = 0.0f;
+		if (type == LossType::RelativeL2Luminance) {  // relative_l2_luminance.h:68-76: from the first 3 (dims >= 6: 3 + 3) outputs of the row
+			const h8 row = *(const h8*)(predictions + (size_t)inter * stride);
+			float r = (float)row[0], g = (float)row[1], b = (float)row[2];
+			if (dims >= 6) {
+				r += (float)row[3];
+				g += (float)row[4];
+				b += (float)row[5];
+			}
+			luminance = loss_row_luminance(r, g, b);
+		}
 #pragma unroll
 		for (uint32_t j = 0; j < 8; ++j) {
 			const uint32_t intra = intra0 + j;
@@ -111,7 +122,8 @@ __global__ void __launch_bounds__(EW_THREADS) k_loss(const LossType type, uint32
 			const float prediction = (float)p8[j];
 			const float pdf = data_pdf ? data_pdf[target_idx] : 1.0f;
 			float value;
-			g8[j] = loss_element(type, prediction, targets[target_idx], pdf, n_total, loss_scale, value);
+			g8[j] = type == LossType::RelativeL2Luminance ? loss_element_luminance(prediction, luminance, targets[target_idx], pdf, n_total, loss_scale, value)
+			                                              : loss_element(type, prediction, targets[target_idx], pdf, n_total, loss_scale, value);
 			v8[j] = value;
 			local_sum += value;
 		}
@@ -139,6 +151,7 @@ void loss_evaluate(hipStream_t stream, LossType type, uint32_t n, uint32_t strid
                    float* block_sums, uint32_t n_total) {
 	if (n == 0) return;
 	if (stride % 8 != 0) throw std::runtime_error("loss: padded output width must be a multiple of 8");
+	if (type == LossType::RelativeL2Luminance && dims < 3) throw std::runtime_error("RelativeL2Luminance needs at least 3 output dimensions");
 	const uint32_t n_groups = n * stride / 8u;
 	const uint32_t blocks = div_round_up(n_groups, EW_THREADS);
 	TCNN_LAUNCH(k_loss, dim3(blocks), dim3(EW_THREADS), 0, stream, type, n_groups, stride, dims, loss_scale, prediction, target, data_pdf, values, gradients,

@@ -10,8 +10,10 @@
 
 namespace tcnn_hip {
 
-enum class LossType : int { L2 = 0, RelativeL2 = 1, L1 = 2, RelativeL1 = 3, Mape = 4, Smape = 5, CrossEntropy = 6, Variance = 7 };
-constexpr int N_LOSS_TYPES = 8;
+enum class LossType : int { L2 = 0, RelativeL2 = 1, L1 = 2, RelativeL1 = 3, Mape = 4, Smape = 5, CrossEntropy = 6, Variance = 7, RelativeL2Luminance = 8 };
+constexpr int N_LOSS_TYPES = 9;
+// RelativeL2Luminance (relative_l2_luminance.h:66-86) normalises by the luminance of the sample's first three (six) outputs:
+// it needs the whole row, so only the stand-alone loss kernel evaluates it (loss_row_luminance + loss_element_luminance).
 
 // prediction: the fp16 network output widened to fp32.  Returns the fp16 gradient loss_scale * dL/dprediction / n_total,
 // `value` receives this element's share of the mean loss.  `type` is uniform over the launch.
@@ -70,8 +72,18 @@ TCNN_LOSS_NOINLINE half_t loss_element_general(LossType type, float prediction, 
 	return to_half_rn(loss_scale * gradient / n_total);
 }
 
+TCNN_DEVICE float loss_row_luminance(float r, float g, float b) { return 0.299f * r + 0.587f * g + 0.114f * b; }
+TCNN_DEVICE half_t loss_element_luminance(float prediction, float luminance, float target, float pdf, float n_total, float loss_scale, float& value) {
+	const float prediction_sq_plus_epsilon = luminance * luminance + 0.01f;
+	const float difference = prediction - target;
+	value = difference * difference / prediction_sq_plus_epsilon / pdf / n_total;
+	const float gradient = 2 * difference / prediction_sq_plus_epsilon / pdf;
+	return to_half_rn(loss_scale * gradient / n_total);
+}
+
 // RelativeL2 / L2 (the defaults) inline, the rest through one out-of-line copy (see activation_device.h)
 TCNN_HOST_DEVICE bool loss_is_simple(LossType type) { return type == LossType::RelativeL2 || type == LossType::L2; }
+TCNN_HOST_DEVICE bool loss_is_elementwise(LossType type) { return type != LossType::RelativeL2Luminance; }
 template <bool GENERAL = true>
 TCNN_DEVICE half_t loss_element(LossType type, float prediction, float target, float pdf, float n_total, float loss_scale, float& value) {
 	if (!GENERAL || type == LossType::RelativeL2 || type == LossType::L2) {

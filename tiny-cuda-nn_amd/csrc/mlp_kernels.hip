@@ -1166,6 +1166,7 @@ void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* p
 	check_meta(m, n);
 	if (n == 0) return;
 	if (!mlp_train_supported(m)) throw std::runtime_error("mlp_train: unsupported network shape (check mlp_train_supported first)");
+	if (!loss_is_elementwise(la.type)) throw std::runtime_error("mlp_train: this loss needs whole output rows; use the stand-alone loss kernel");
 	switch (m.width) {
 		case 16: dispatch_train<16>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		case 32: dispatch_train<32>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;

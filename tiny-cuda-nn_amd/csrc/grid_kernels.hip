@@ -324,7 +324,7 @@ enum SliceKind : uint32_t { SLICE_FIXED64 = 0, SLICE_FLOAT = 1, SLICE_GLOBAL_ATO
 // Work list of one launch, in dispatch order (long slice passes first, short work fills the tail).
 struct SlicePlan {
 	uint32_t n_items;
-	uint32_t blocks_per_item;                // launch stride: max workgroups of any item
+	uint32_t blocks_per_item;                // launch stride (max workgroups of any item) of a near-uniform plan, else 0
 	uint32_t block_begin[MAX_N_LEVELS + 1];  // first workgroup of item p
 	uint32_t n_slices[MAX_N_LEVELS];         // slices (FIXED64 / FLOAT) or sample tiles (GLOBAL_ATOMIC) of item p
 	uint8_t level[MAX_N_LEVELS];             // grid level of item p
@@ -858,9 +858,18 @@ __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const G
                                                                            const int accumulate, const BucketPlan bplan,
                                                                            uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues) {
 	TCNN_DYN_LDS(lds_raw);
-	// work item = blockIdx / stride (no search through the plan); items with fewer workgroups than the stride leave the rest idle
-	const uint32_t item = blockIdx.x / plan.blocks_per_item, local_block = blockIdx.x % plan.blocks_per_item;
-	if (local_block >= plan.block_begin[item + 1] - plan.block_begin[item]) return;
+	uint32_t item = 0, local_block;
+	if (plan.blocks_per_item) {
+		// near-uniform plan (the bucketed backward): work item = blockIdx / stride, no search; an item with fewer workgroups
+		// than the stride leaves the rest idle (each idle workgroup still claims a CU's LDS for an instant, so the host only
+		// picks this when almost nothing is padded)
+		item = blockIdx.x / plan.blocks_per_item;
+		local_block = blockIdx.x % plan.blocks_per_item;
+		if (local_block >= plan.block_begin[item + 1] - plan.block_begin[item]) return;
+	} else {
+		while (item + 1 < plan.n_items && blockIdx.x >= plan.block_begin[item + 1]) ++item;
+		local_block = blockIdx.x - plan.block_begin[item];
+	}
 	const uint32_t level = plan.level[item], kind = plan.kind[item];
 	const uint32_t n_slices = plan.n_slices[item];
 	const uint32_t n_chunks = (plan.block_begin[item + 1] - plan.block_begin[item]) / n_slices;
@@ -1119,9 +1128,15 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 		blocks += it.n_slices * it.n_chunks;
 	}
 	plan.block_begin[plan.n_items] = blocks;
-	plan.blocks_per_item = 1;
-	for (uint32_t p = 0; p < plan.n_items; ++p) plan.blocks_per_item = std::max(plan.blocks_per_item, plan.block_begin[p + 1] - plan.block_begin[p]);
-	bp.blocks = plan.n_items * plan.blocks_per_item;
+	uint32_t widest = 1;
+	for (uint32_t p = 0; p < plan.n_items; ++p) widest = std::max(widest, plan.block_begin[p + 1] - plan.block_begin[p]);
+	if ((uint64_t)plan.n_items * widest * 10 <= (uint64_t)blocks * 11) {  // <= 10 % padding: index by arithmetic
+		plan.blocks_per_item = widest;
+		bp.blocks = plan.n_items * widest;
+	} else {
+		plan.blocks_per_item = 0;
+		bp.blocks = blocks;
+	}
 	return bp;
 }
 

@@ -178,6 +178,21 @@ def grid_backward_input(g, dL_dy_h, dy_dx):
     return out
 
 
+def grid_backward_backward_input(g, params_h, positions, ddx, dL_dy_h, dy_dx=None):
+    """Second order (grid.h:352-655).  Returns (grad_params float64, dL_ddLdy half [n, stride] or None, dL_dx float32 [n, D])."""
+    positions = np.ascontiguousarray(positions, dtype=np.float32)
+    ddx = np.ascontiguousarray(ddx, dtype=np.float32)
+    dL_dy_h = np.ascontiguousarray(dL_dy_h, dtype=np.uint16)
+    n = positions.shape[0]
+    grad = np.zeros(g.n_params, dtype=np.float64)
+    dLddy = np.zeros_like(dL_dy_h) if dy_dx is not None else None
+    dx = np.zeros((n, g.n_dims), dtype=np.float32)
+    lib().orc_grid_backward_backward_input(C.byref(g), _p(np.ascontiguousarray(params_h, dtype=np.uint16)), _p(positions), _p(ddx), C.c_uint32(n),
+                                           _p(dL_dy_h), C.c_uint32(dL_dy_h.shape[1]), _p(None if dy_dx is None else np.ascontiguousarray(dy_dx, dtype=np.float32)),
+                                           _p(grad), _p(dLddy), _p(dx))
+    return grad, dLddy, dx
+
+
 # ---------------------------------------------------------------- mlp
 def mlp_init(in_width, width, out_width, n_hidden, activation=ACT_RELU, output_activation=ACT_NONE):
     m = Mlp()

@@ -455,6 +455,106 @@ void orc_grid_backward(const orc_grid* g, const float* positions, uint32_t n, co
 	}
 }
 
+/* Second order: gradients of dL_dx = sum_k dL_dy[k] dy_dx[k] w.r.t. the grid parameters, dL_dy and the positions, given
+ * ddx = dL/d(dL_dx).  Restates grid.h:352-455 (backward_input_backward_grid), :457-620 (backward_input_backward_input) and
+ * :623-653 (backward_dLdoutput), following the reference's loop structure (gradient dimension outer, the 2^(D-1) corners
+ * of the remaining dimensions inner, left / right along the gradient dimension).  grad_params (double, accumulated into),
+ * dL_ddLdy (half [n][dy_stride], first L*F columns written) and dL_dx (fp32 [n][D], overwritten) may each be NULL.
+ * dy_dx: orc_grid_forward's [i][k][d] layout, needed for dL_ddLdy only. */
+void orc_grid_backward_backward_input(const orc_grid* g, const uint16_t* params, const float* positions, const float* ddx, uint32_t n,
+                                      const uint16_t* dL_dy, uint32_t dy_stride, const float* dy_dx, double* grad_params,
+                                      uint16_t* dL_ddLdy, float* dL_dx) {
+	const uint32_t D = g->n_dims, L = g->n_levels, F = g->n_features_per_level, C2 = 1u << (D - 1);
+#pragma omp parallel for schedule(static)
+	for (long long ii = 0; ii < (long long)n; ++ii) {
+		uint32_t i = (uint32_t)ii;
+		if (dL_ddLdy) { /* grid.h:637-648 */
+			for (uint32_t k = 0; k < L * F; ++k) {
+				float result = 0;
+				for (uint32_t d = 0; d < D; ++d) result += dy_dx[((size_t)i * L * F + k) * D + d] * ddx[(size_t)i * D + d];
+				dL_ddLdy[(size_t)i * dy_stride + k] = orc_f2h(result);
+			}
+		}
+		float out[ORC_MAX_DIMS] = {0};
+		for (uint32_t level = 0; level < L && g->interpolation != ORC_INTERP_NEAREST; ++level) {
+			const float scale = g->scale[level];
+			float pos[ORC_MAX_DIMS], pd[ORC_MAX_DIMS], pd2[ORC_MAX_DIMS];
+			uint32_t pg[ORC_MAX_DIMS];
+			for (uint32_t d = 0; d < D; ++d) {
+				pos_fract(g, positions[(size_t)i * D + d], scale, &pos[d], &pd[d], &pg[d]);
+				float p = fmaf(scale, positions[(size_t)i * D + d], 0.5f);
+				p -= floorf(p);
+				pd2[d] = g->interpolation == ORC_INTERP_SMOOTHSTEP ? 6.0f - 12.0f * p : 0.0f; /* common_device.h:984-986 */
+			}
+			const uint16_t* dy = dL_dy + (size_t)i * dy_stride + level * F;
+			const uint16_t* table = params ? params + (size_t)g->offsets[level] * F : NULL;
+			double* gg = grad_params ? grad_params + (size_t)g->offsets[level] * F : NULL;
+			for (uint32_t gd = 0; gd < D; ++gd) {
+				const float grad_in = scale * ddx[(size_t)i * D + gd] * pd[gd];                       /* grid.h:429 */
+				const float grad_in_diag = scale * scale * ddx[(size_t)i * D + gd] * pd2[gd];           /* grid.h:546 */
+				float grad_out = 0;
+				for (uint32_t idx = 0; idx < C2; ++idx) {
+					/* corners of the dimensions other than gd */
+					float weight = 1;
+					uint32_t local[ORC_MAX_DIMS];
+					for (uint32_t nd = 0; nd + 1 < D; ++nd) {
+						const uint32_t dim = nd >= gd ? nd + 1 : nd;
+						if ((idx & (1u << nd)) == 0) { weight *= 1 - pos[dim]; local[dim] = pg[dim]; }
+						else { weight *= pos[dim]; local[dim] = pg[dim] + 1; }
+					}
+					for (int side = 0; side < 2; ++side) { /* left, right along gd */
+						local[gd] = pg[gd] + (uint32_t)side;
+						const float sgn = side ? 1.0f : -1.0f;
+						const uint32_t index = orc_grid_index(g, level, local) * F;
+						if (gg) { /* grid.h:448-453: (GRAD_T)weight * grad */
+							for (uint32_t f = 0; f < F; ++f) {
+								const float w = sgn * grad_in * weight;
+								double c = F == 1 ? (double)(w * orc_h2f(dy[f])) : (double)orc_h2f(hmul(orc_f2h(w), dy[f]));
+#pragma omp atomic
+								gg[index + f] += c;
+							}
+						}
+						if (dL_dx && table && g->interpolation == ORC_INTERP_SMOOTHSTEP) { /* diagonal of the Hessian, grid.h:561-582 */
+							float v = 0;
+							for (uint32_t f = 0; f < F; ++f) v += orc_h2f(table[index + f]) * orc_h2f(dy[f]) * (sgn * grad_in_diag * weight);
+							grad_out += v;
+						}
+					}
+				}
+				if (dL_dx && table) { /* mixed terms, grid.h:585-616: d(dy/dx[other]) / dx[gd] */
+					for (uint32_t od = 0; od < D; ++od) {
+						if (od == gd) continue;
+						const float base = scale * scale * ddx[(size_t)i * D + od] * pd[od] * pd[gd];
+						for (uint32_t idx = 0; idx < C2; ++idx) {
+							float weight = base;
+							uint32_t local[ORC_MAX_DIMS];
+							for (uint32_t nd = 0; nd + 1 < D; ++nd) {
+								const uint32_t dim = nd >= od ? nd + 1 : nd; /* dimensions other than od */
+								if ((idx & (1u << nd)) == 0) {
+									if (dim != gd) weight *= 1 - pos[dim]; else weight *= -1;
+									local[dim] = pg[dim];
+								} else {
+									if (dim != gd) weight *= pos[dim];
+									local[dim] = pg[dim] + 1;
+								}
+							}
+							for (int side = 0; side < 2; ++side) {
+								local[od] = pg[od] + (uint32_t)side;
+								const uint32_t index = orc_grid_index(g, level, local) * F;
+								float v = 0;
+								for (uint32_t f = 0; f < F; ++f) v += orc_h2f(table[index + f]) * orc_h2f(dy[f]) * ((side ? 1.0f : -1.0f) * weight);
+								grad_out += v;
+							}
+						}
+					}
+				}
+				out[gd] += grad_out;
+			}
+		}
+		if (dL_dx) for (uint32_t d = 0; d < D; ++d) dL_dx[(size_t)i * D + d] = out[d];
+	}
+}
+
 void orc_grid_backward_input(const orc_grid* g, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride,
                              const float* dy_dx, float* dL_dx) {
 	const uint32_t D = g->n_dims, K = g->n_levels * g->n_features_per_level;

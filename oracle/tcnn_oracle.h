@@ -100,6 +100,10 @@ void orc_grid_backward(const orc_grid* g, const float* positions, uint32_t n, co
                        uint32_t dy_stride, double* grad);
 
 /* grid.h:323-349 input gradient: dL_dx [N][D] fp32 */
+/* second order (grid.h:352-655): see the definition; every output may be NULL */
+void orc_grid_backward_backward_input(const orc_grid* g, const uint16_t* params, const float* positions, const float* ddx, uint32_t n,
+                                      const uint16_t* dL_dy, uint32_t dy_stride, const float* dy_dx, double* grad_params,
+                                      uint16_t* dL_ddLdy, float* dL_dx);
 void orc_grid_backward_input(const orc_grid* g, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride,
                              const float* dy_dx, float* dL_dx);
 

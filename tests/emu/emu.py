@@ -116,6 +116,23 @@ def grid_backward(g, positions, dL_dy_h, soa=True, mode=SLICED_F32, lds_budget=0
     return grad_h
 
 
+def grid_backward_backward(g, positions, ddx, dL_dy_soa_h, params_h, dy_dx_kn):
+    """Second-order pass.  dL_dy / dL_ddLdy feature-major [K][n]; dy_dx in the kernels' [K][n][D] layout.
+    Returns (grad_half, dL_ddLdy, dL_dx)."""
+    og = g.og
+    positions = np.ascontiguousarray(positions, dtype=np.float32)
+    ddx = np.ascontiguousarray(ddx, dtype=np.float32)
+    n = positions.shape[0]
+    dy = np.ascontiguousarray(dL_dy_soa_h, dtype=np.uint16)
+    grad = np.full(og.n_params, 0x3C00, dtype=np.uint16)
+    dLddy = np.zeros_like(dy)
+    dx = np.full((n, og.n_dims), 7.0, dtype=np.float32)
+    r = lib().emu_grid_backward_backward(C.byref(g.c), _p(positions), _p(ddx), C.c_uint32(n), _p(dy), _p(np.ascontiguousarray(params_h, dtype=np.uint16)),
+                                         _p(np.ascontiguousarray(dy_dx_kn, dtype=np.float32)), _p(grad), _p(dLddy), _p(dx))
+    assert r == 0
+    return grad, dLddy, dx
+
+
 def grid_backward_input(g, dL_dy_soa_h, dy_dx):
     og = g.og
     n = dL_dy_soa_h.shape[1]

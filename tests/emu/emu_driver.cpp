@@ -71,6 +71,32 @@ int emu_grid_backward(const EmuGrid* e, const float* positions, uint32_t n, cons
 	return 0;
 }
 
+// second order (grid.h:352-655): any of grad_half / dL_ddLdy / dL_dx may be null.  dL_dy and dL_ddLdy feature-major [K][n].
+int emu_grid_backward_backward(const EmuGrid* e, const float* positions, const float* ddx, uint32_t n, const uint16_t* dL_dy, const uint16_t* params,
+                               const float* dy_dx, uint16_t* grad_half, uint16_t* dL_ddLdy, float* dL_dx) {
+	try {
+		const GridMeta meta = make_meta(e);
+		GridIO io = {positions, e->n_dims, 1, n, n, 1u};
+		io.ddx = ddx;
+		io.ddx_stride_i = e->n_dims;
+		io.ddx_stride_d = 1;
+		if (grad_half) {
+			GridBackwardWorkspace ws = grid_backward_workspace_size(meta, n, GridBackwardMode::Bucketed, 0);
+			std::vector<unsigned char> scratch(ws.scratch_bytes + 16, 0xCD);
+			std::vector<uint32_t> counters(ws.n_counters + 1, 0u);
+			ws.scratch = scratch.data();
+			ws.counters = counters.data();
+			grid_backward(nullptr, meta, io, (const half_t*)dL_dy, (half_t*)grad_half, false, GridBackwardMode::Bucketed, 0, ws);
+		}
+		if (dL_ddLdy) grid_backward_backward_dLdoutput(nullptr, e->n_dims, e->n_levels * e->n_feat, 0, io, dy_dx, (half_t*)dL_ddLdy);
+		if (dL_dx) grid_backward_backward_input(nullptr, meta, io, (const half_t*)dL_dy, (const half_t*)params, dL_dx, e->n_dims, 1);
+	} catch (const std::exception& ex) {
+		fprintf(stderr, "emu_grid_backward_backward: %s\n", ex.what());
+		return 1;
+	}
+	return 0;
+}
+
 int emu_grid_backward_input(const EmuGrid* e, uint32_t n, const uint16_t* dL_dy, int soa, uint32_t dy_stride, const float* dy_dx,
                             float* dL_dx) {
 	GridIO io = {nullptr, e->n_dims, 1, n, soa ? n : 1u, soa ? 1u : dy_stride};

@@ -84,6 +84,30 @@ def test_grid_backward(case, mode, lds_budget):
     assert dl.shape == (n, D)
 
 
+@pytest.mark.parametrize("case", [GRID_CASES[0], GRID_CASES[1], GRID_CASES[2], GRID_CASES[4], GRID_CASES[5], GRID_CASES[6]])
+def test_grid_second_order(case):
+    """d(dL_dx)/d(grid), d(dL_dx)/d(dL_dy), d(dL_dx)/dx (grid.h:352-655) against the oracle (which is checked against
+    finite differences of its own first-order gradient in tests/test_oracle.py)."""
+    D, L, F, T, base, scale, gtype, interp = case
+    rng = np.random.default_rng(8)
+    og = O.grid_init(D, L, F, T, base, scale, gtype, interp)
+    g = emu.Grid(og)
+    n = 700
+    pos = rng.random((n, D), dtype=np.float32)
+    params = O.f2h(((rng.random(og.n_params, dtype=np.float32) * 2 - 1) * 0.5))
+    dy = O.f2h(rng.standard_normal((n, L * F)).astype(np.float32))
+    ddx = rng.standard_normal((n, D)).astype(np.float32)
+    _, dydx = O.grid_forward(og, params, pos, want_dy_dx=True)
+    gp_ref, dLddy_ref, dx_ref = O.grid_backward_backward_input(og, params, pos, ddx, dy, dy_dx=dydx)
+    grad, dLddy, dx = emu.grid_backward_backward(g, pos, ddx, np.ascontiguousarray(dy.T), params, np.ascontiguousarray(np.transpose(dydx, (1, 0, 2))))
+    assert np.array_equal(dLddy.T, dLddy_ref)
+    assert np.allclose(dx, dx_ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(dx_ref).max()))
+    # the oracle rounds every (weight, gradient) contribution to half like the reference; the kernel sums a corner's D
+    # weights in fp32 first: compare against the magnitude that was accumulated
+    mag = np.abs(O.grid_backward_backward_input(og, params, pos, np.abs(ddx), O.f2h(np.abs(O.h2f(dy))))[0]) + np.abs(gp_ref)
+    assert np.all(np.abs(O.h2f(grad).astype(np.float64) - gp_ref) <= 2.0 ** -8 * mag + 2e-3 * max(1.0, np.abs(gp_ref).max()) * 2.0 ** -4)
+
+
 def test_grid_backward_bucket_overflow():
     """Strongly clustered samples overflow their bucket queues; the overflow list + atomic pass keeps the sum right."""
     D, L, F, T = 3, 3, 2, 14

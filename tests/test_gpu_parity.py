@@ -715,3 +715,64 @@ def test_deep_network_trains():
     assert np.percentile(rae(g, gref), 90) < 1e-2
     losses = [tm.loss(tm.training_step(x, t)) for _ in range(30)]
     assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0]
+
+
+@pytest.mark.parametrize("interp", ["Linear", "Smoothstep"])
+def test_grid_second_order_through_c_abi_and_double_backward(interp):
+    """backward_backward_input of the grid encoding (grid.h:352-655, 910-1042): the three native outputs against the
+    oracle, and torch double backward (an eikonal-style loss on d(encoding)/dx) against torch.autograd.gradcheck-free
+    finite differences."""
+    C = tcnn()._C
+    enc = dict(HASH_ENCODING_SMALL, interpolation=interp)
+    d = 3
+    m = C.create_encoding(d, enc)
+    og = oracle_grid(enc, d)
+    n = 2048
+    pos = positions(n, d, seed=31)
+    rng = np.random.default_rng(5)
+    params = O.f2h((rng.random(og.n_params, dtype=np.float32) * 2 - 1) * 0.5)
+    K = m.n_output_dims()
+    dy = O.f2h(rng.standard_normal((n, K)).astype(np.float32))
+    ddx = rng.standard_normal((n, d)).astype(np.float32)
+    x = torch.from_numpy(pos).cuda().requires_grad_(True)
+    p = h_t(params).requires_grad_(True)
+    ctx, y = m.fwd(x, p)
+    dyt = h_t(dy).requires_grad_(True)
+    d_dy, d_p, d_x = m.bwd_bwd_input(ctx, x, p, torch.from_numpy(ddx).cuda(), dyt)
+    torch.cuda.synchronize()
+    _, dydx = O.grid_forward(og, params, pos, want_dy_dx=True)
+    gp_ref, dLddy_ref, dx_ref = O.grid_backward_backward_input(og, params, pos, ddx, dy, dy_dx=dydx)
+    assert np.array_equal(h_np(d_dy)[:, :og.n_levels * og.n_features_per_level], dLddy_ref[:, :og.n_levels * og.n_features_per_level])
+    assert np.allclose(d_x.cpu().numpy(), dx_ref, rtol=1e-3, atol=1e-4 * max(1.0, np.abs(dx_ref).max()))
+    mag = np.abs(O.grid_backward_backward_input(og, params, pos, np.abs(ddx), O.f2h(np.abs(O.h2f(dy))))[0]) + np.abs(gp_ref)
+    assert np.all(np.abs(d_p.float().cpu().numpy().astype(np.float64) - gp_ref) <= 2.0 ** -8 * mag + 1e-3 * max(1.0, np.abs(gp_ref).max()))
+
+    # torch: loss = sum(|d(sum of features)/dx|^2) -- needs the double backward through the encoding
+    tcnn_mod = tcnn().Encoding(d, enc, dtype=torch.half)
+    with torch.no_grad():
+        tcnn_mod.params.copy_(torch.from_numpy(O.h2f(params)).cuda() * 10.0)
+    xt = torch.from_numpy(pos[:512]).cuda().requires_grad_(True)
+    feat = tcnn_mod(xt).float().sum()
+    (gx,) = torch.autograd.grad(feat, xt, create_graph=True)
+    loss = (gx ** 2).sum()
+    loss.backward()
+    assert torch.isfinite(tcnn_mod.params.grad).all() and float(tcnn_mod.params.grad.abs().max()) > 0
+    # finite difference of the loss with respect to a few touched parameters (the loss is quadratic in them)
+    g = tcnn_mod.params.grad.float().clone()
+    idx = torch.topk(g.abs(), 4).indices.tolist()
+
+    def loss_at(pvec):
+        with torch.no_grad():
+            tcnn_mod.params.copy_(pvec)
+        xq = xt.detach().clone().requires_grad_(True)
+        (gq,) = torch.autograd.grad(tcnn_mod(xq).float().sum(), xq, create_graph=False)
+        return float((gq.double() ** 2).sum())
+
+    base = tcnn_mod.params.detach().clone()
+    for j in idx:
+        step = max(abs(float(base[j])) * 2.0 ** -4, 2.0 ** -6)
+        hi, lo = base.clone(), base.clone()
+        hi[j] += step
+        lo[j] -= step
+        fd = (loss_at(hi) - loss_at(lo)) / (float(hi[j]) - float(lo[j]))
+        assert abs(fd - float(g[j])) <= 0.1 * abs(float(g[j])) + 1e-3 * float(g.abs().max()), (j, fd, float(g[j]))

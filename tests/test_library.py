@@ -97,8 +97,15 @@ def test_log_callback_receives_errors():
     assert seen and seen[-1][0] == C.LogSeverity.Error and "number of input dims" in seen[-1][1]
 
 
-def test_second_order_is_reported_unsupported():
+def test_second_order_exists_for_the_grid_encoding_only():
+    """backward_backward_input: implemented by GridEncoding alone in the reference (grid.h:910-1042; object.h:468 throws
+    for every other object).  No GPU here: only the host-side dispatch is checked."""
+    import ctypes as C_
     C = _lib()
-    e = C.create_encoding(3, {"otype": "HashGrid"})
-    with pytest.raises(RuntimeError, match="not part of"):
-        e.bwd_bwd_input(None, None, None, None, None)
+    lib = C._lib
+    net = C.create_network(16, 4, {"otype": "FullyFusedMLP", "n_neurons": 16, "n_hidden_layers": 1})
+    rc = lib.tcnn_module_backward_backward_input(net._h, None, None, 256, None, None, None, None, None, None, None)
+    assert rc == 2 and b"not implemented" in lib.tcnn_last_error()  # TCNN_ERROR_UNSUPPORTED
+    enc = C.create_encoding(3, {"otype": "HashGrid"})
+    rc = lib.tcnn_module_backward_backward_input(enc._h, None, None, 256, None, None, None, None, None, None, None)
+    assert rc == 1 and b"missing forward context" in lib.tcnn_last_error()

@@ -249,3 +249,56 @@ def test_training_reduces_loss():
     tgt = np.stack([np.sin(6.28 * (c + 1) * pos[:, 0]) * np.cos(6.28 * pos[:, 1]) * 0.5 + 0.5 for c in range(4)], 1).astype(np.float32)
     losses = [O.training_step(st, pos, tgt) for _ in range(30)]
     assert losses[-1] < 0.5 * losses[0]
+
+
+@pytest.mark.parametrize("interp", [O.INTERP_LINEAR, O.INTERP_SMOOTHSTEP])
+@pytest.mark.parametrize("gtype,d", [(O.GRID_HASH, 3), (O.GRID_DENSE, 2)])
+def test_grid_second_order_is_the_derivative_of_the_first_backward(interp, gtype, d):
+    """orc_grid_backward_backward_input (grid.h:352-655) against finite differences of the oracle's OWN first-order
+    input gradient: f(params, x, dL_dy) = sum ddx * dL_dx(params, x, dL_dy) is linear in params and dL_dy (exact
+    checks) and smooth in x inside a cell (central differences)."""
+    rng = np.random.default_rng(4)
+    g = O.grid_init(d, 3, 2, 12, 4, 1.7, gtype, interp)
+    n = 64
+    pos = (0.05 + 0.9 * rng.random((n, d))).astype(np.float32)
+    params = O.f2h((rng.standard_normal(g.n_params) * 0.5).astype(np.float32))
+    dy = O.f2h(rng.standard_normal((n, 3 * 2)).astype(np.float32))
+    ddx = rng.standard_normal((n, d)).astype(np.float32)
+
+    def dl_dx(p_h, x, dy_h):
+        _, dydx = O.grid_forward(g, p_h, x, want_dy_dx=True)
+        return O.grid_backward_input(g, dy_h, dydx), dydx
+
+    def f(p_h, x, dy_h):
+        return float(np.sum(ddx.astype(np.float64) * dl_dx(p_h, x, dy_h)[0].astype(np.float64)))
+
+    _, dydx = dl_dx(params, pos, dy)
+    gp, dLddy, dx2 = O.grid_backward_backward_input(g, params, pos, ddx, dy, dy_dx=dydx)
+    # w.r.t. dL_dy: f is linear in it, the coefficient of dL_dy[i, k] is sum_d dy_dx[i, k, d] * ddx[i, d]
+    coeff = np.einsum("ikd,id->ik", dydx.astype(np.float64), ddx.astype(np.float64))
+    assert np.allclose(O.h2f(dLddy), coeff, rtol=2e-3, atol=2e-3 * np.abs(coeff).max())
+    # w.r.t. the parameters: linear again -- move a few table entries by an exactly representable step
+    pf = O.h2f(params)
+    touched = np.flatnonzero(gp)
+    assert touched.size > 0
+    for j in rng.choice(touched, 12, replace=False):
+        step = 0.25
+        hi, lo = pf.copy(), pf.copy()
+        hi[j] += step
+        lo[j] -= step
+        fd = (f(O.f2h(hi), pos, dy) - f(O.f2h(lo), pos, dy)) / (2 * step)
+        assert abs(fd - gp[j]) <= 2e-2 * max(1.0, abs(gp[j])), (j, fd, gp[j])
+    # w.r.t. the positions: central differences, samples whose cell does not change at any level
+    eps = 1.0 / 1024
+    checked = 0
+    for i in range(n):
+        for a in range(d):
+            xp, xm = pos.copy(), pos.copy()
+            xp[i, a] += eps
+            xm[i, a] -= eps
+            if not np.array_equal(O.grid_indices(g, xp)[i], O.grid_indices(g, xm)[i]):
+                continue
+            fd = (f(params, xp, dy) - f(params, xm, dy)) / (2 * eps)
+            assert abs(fd - dx2[i, a]) <= 3e-2 * max(1.0, np.abs(dx2).max()), (i, a, fd, dx2[i, a])
+            checked += 1
+    assert checked > n

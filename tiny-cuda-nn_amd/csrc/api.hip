@@ -854,12 +854,53 @@ int tcnn_module_backward(tcnn_module_t* m, tcnn_stream_t stream, const tcnn_cont
 	TCNN_API_END
 }
 
-int tcnn_module_backward_backward_input(tcnn_module_t*, tcnn_stream_t, const tcnn_context_t*, uint32_t, const float*, const float*, const void*,
-                                        void*, void*, float*, const void*) {
-	g_last_error = "backward_backward_input (second-order grid gradients, grid.h:352-655) is not part of this build";
-	return TCNN_ERROR_UNSUPPORTED;
+// cpp_api.cu:117-135 -> DifferentiableObject::backward_backward_input, implemented by the grid encoding only in the
+// reference (grid.h:910-1042; object.h:468 throws for everything else).
+int tcnn_module_backward_backward_input(tcnn_module_t* m, tcnn_stream_t stream_, const tcnn_context_t* ctx, uint32_t n, const float* dL_ddLdinput,
+                                        const float* input, const void* dL_doutput, void* dL_dparams, void* dL_ddLdoutput, float* dL_dinput,
+                                        const void* params) {
+	if (m->md.has_network || !m->md.enc.is_grid) {
+		g_last_error = "DifferentiableObject::backward_backward_input_impl: not implemented error";  // object.h:478
+		return TCNN_ERROR_UNSUPPORTED;
+	}
+	TCNN_API_BEGIN
+	if (!ctx) throw std::runtime_error("backward_backward_input: missing forward context");
+	check_batch(n);
+	if (n == 0) return TCNN_OK;
+	if (ctx->ctx.n != n) throw std::runtime_error("backward_backward_input: batch size does not match the forward context");
+	if (!dL_ddLdinput) throw std::runtime_error("backward_backward_input: dL_ddLdinput is required");
+	hipStream_t stream = (hipStream_t)stream_;
+	const Model& md = m->md;
+	const EncodingDesc& e = md.enc;
+	GridIO io = {input, md.n_input_dims, 1u, n, 1u, e.padded_output_width};  // the bare encoding's output is sample-major (cpp_api.cu:94-95)
+	io.ddx = dL_ddLdinput;
+	io.ddx_stride_i = md.n_input_dims;
+	io.ddx_stride_d = 1u;
+	if (dL_ddLdoutput) {  // grid.h:1012-1035
+		if (!ctx->ctx.dy_dx.ptr) throw std::runtime_error("backward_backward_input: the forward pass did not prepare input gradients");
+		grid_backward_backward_dLdoutput(stream, md.n_input_dims, e.n_output_dims, e.padded_output_width - e.n_output_dims, io, ctx->ctx.dy_dx.as<float>(),
+		                                 (half_t*)dL_ddLdoutput);
+	}
+	if (dL_dparams || dL_dinput) {
+		if (!dL_doutput) throw std::runtime_error("backward_backward_input: dL_doutput is required for parameter / input gradients");
+	}
+	if (dL_dparams && e.n_params > 0) {  // grid.h:942-975, GradientMode::Overwrite
+		uint32_t budget = m->lds_level_budget ? m->lds_level_budget : g_default_lds_slice_bytes;
+		GridBackwardWorkspace ws = grid_backward_workspace_size(e.grid, n, GridBackwardMode::Bucketed, budget);
+		Scratch queues;
+		if (ws.scratch_bytes) {
+			queues = Scratch(stream, ws.scratch_bytes);
+			ws.scratch = queues.ptr;
+			ws.scratch_bytes = queues.bytes;
+			ws.counters = ZeroedCounters::get(stream, ws.n_counters);
+		}
+		grid_backward(stream, e.grid, io, (const half_t*)dL_doutput, (half_t*)dL_dparams, false, GridBackwardMode::Bucketed, budget, ws);
+	}
+	if (dL_dinput) {  // grid.h:977-1010
+		grid_backward_backward_input(stream, e.grid, io, (const half_t*)dL_doutput, (const half_t*)params, dL_dinput, md.n_input_dims, 1u);
+	}
+	TCNN_API_END
 }
-
 void tcnn_context_destroy(tcnn_context_t* ctx) { delete ctx; }
 
 uint32_t tcnn_module_n_input_dims(const tcnn_module_t* m) { return m->md.n_input_dims; }

@@ -39,6 +39,9 @@ struct GridIO {
 	//   SoA (feature-major, the reference's preferred layout grid.h:1070-1072): stride_k = n, stride_i = 1
 	//   AoS (cpp_api.cu:94-95 forces it):                                       stride_k = 1, stride_i = padded width
 	uint32_t stride_k, stride_i;
+	// second-order pass only: dL/d(dL_dx), element (dim d, sample i) at ddx[i * ddx_stride_i + d * ddx_stride_d]
+	const float* ddx = nullptr;
+	uint32_t ddx_stride_i = 0, ddx_stride_d = 0;
 };
 
 // Forward: writes n_levels*F features (padding columns are the caller's job). dy_dx may be null;
@@ -78,6 +81,19 @@ void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, c
 void grid_backward_input(hipStream_t stream, uint32_t n_dims, uint32_t n_features, const GridIO& io,
                          const half_t* dL_dy, const float* dy_dx, float* dL_dx, uint32_t dx_stride_i,
                          uint32_t dx_stride_d);
+
+// ---- second order: gradients of dL_dx = sum_k dL_dy[k] * dy_dx[k] (the first backward's input gradient) --------------
+// (grid.h:352-655, 910-1042: what SDF / eikonal losses differentiate through)
+//  * w.r.t. the grid parameters: grid_backward() with io.ddx set -- the same scatter with the corner weight
+//    scale * sum_d ddx[d] * pos'(d) * (+-1 along d) * prod_{e != d} w_e  (kernel_grid_backward_input_backward_grid);
+//  * w.r.t. dL_dy:  dL_ddLdy[k][i] = sum_d dy_dx[k][i][d] * ddx[i][d]   (kernel_grid_backward_input_backward_dLdoutput);
+//    padding features k in [n_features, n_features + n_to_pad) are written as zero;
+//  * w.r.t. the positions (kernel_grid_backward_input_backward_input): mixed second derivatives of the interpolation
+//    (and the diagonal ones for Smoothstep); dL_dx[i][d] is OVERWRITTEN.  io.ddx must be set for all three.
+void grid_backward_backward_dLdoutput(hipStream_t stream, uint32_t n_dims, uint32_t n_features, uint32_t n_to_pad, const GridIO& io,
+                                      const float* dy_dx, half_t* dL_ddLdy);
+void grid_backward_backward_input(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, const half_t* params,
+                                  float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_d);
 
 // Debug/parity helper: entry index per (sample, level, corner) -> indices[(i*L + l)*2^D + c]
 void grid_indices(hipStream_t stream, const GridMeta& meta, const GridIO& io, uint32_t* indices);

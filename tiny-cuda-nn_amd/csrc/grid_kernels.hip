@@ -139,6 +139,28 @@ TCNN_DEVICE float corner_weight(const Cell<D>& c, uint32_t idx) {
 	return weight;
 }
 
+// Corner weight of the SECOND-ORDER scatter (kernel_grid_backward_input_backward_grid, grid.h:427-455, summed over the
+// gradient dimensions): scale * sum_d ddx[d] * pos'(d) * (+1 right / -1 left along d) * prod_{e != d} w_e(corner).
+template <uint32_t D>
+TCNN_DEVICE float corner_weight_second_order(const Level<D>& lv, const Cell<D>& c, uint32_t idx, const float (&ddx)[D]) {
+	float total = 0.0f;
+#pragma unroll
+	for (uint32_t d = 0; d < D; ++d) {
+		float weight = lv.scale * ddx[d] * c.derivative[d];
+#pragma unroll
+		for (uint32_t e = 0; e < D; ++e) {
+			if (e != d) weight *= ((idx >> e) & 1u) ? c.w[e][1] : c.w[e][0];
+		}
+		total += ((idx >> d) & 1u) ? weight : -weight;
+	}
+	return total;
+}
+template <uint32_t D>
+TCNN_DEVICE void load_ddx(const GridIO& io, uint32_t i, float (&v)[D]) {
+#pragma unroll
+	for (uint32_t d = 0; d < D; ++d) v[d] = io.ddx[(size_t)i * io.ddx_stride_i + (size_t)d * io.ddx_stride_d];
+}
+
 // F halves at `p` -> NP packed pairs (F == 1: {x, 0})
 template <uint32_t F>
 TCNN_DEVICE void load_features(const half_t* p, h2 (&v)[(F + 1) / 2]) {
@@ -605,6 +627,7 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 
 	float x[SPT][D], x_next[SPT][D];
 	half_t g[SPT][F], g_next[SPT][F];
+	const bool second_order = io.ddx != nullptr;  // scatter d(dL_dx)/d(grid) instead of dy/d(grid)
 	if (first_tile < plan.tiles) load_tile(first_tile, x, g);
 	__syncthreads();
 
@@ -620,9 +643,13 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 			for (uint32_t s = 0; s < SPT; ++s) {
 				const bool valid = tile * TILE + s * BUCKET_THREADS + threadIdx.x < io.n;
 				const Cell<D> c = make_cell<D, FAST>(lv, x[s]);
+				float dd[D];
+#pragma unroll
+				for (uint32_t d = 0; d < D; ++d) dd[d] = 0.0f;
+				if (second_order) load_ddx<D>(io, min(tile * TILE + s * BUCKET_THREADS + threadIdx.x, io.n - 1u), dd);
 #pragma unroll
 				for (uint32_t idx = 0; idx < N_CORNERS; ++idx) {
-					const float weight = lv.nearest ? 1.0f : corner_weight<D>(c, idx);
+					const float weight = second_order ? corner_weight_second_order<D>(lv, c, idx, dd) : (lv.nearest ? 1.0f : corner_weight<D>(c, idx));
 					if constexpr (F == 1) {
 						pay[s][idx][0] = __builtin_bit_cast(uint32_t, weight * (float)g[s][0]);
 					} else {
@@ -942,6 +969,99 @@ __global__ void k_grid_backward_input(uint32_t n_dims, uint32_t n_features, Grid
 	for (uint32_t d = 0; d < n_dims; ++d) dL_dx[(size_t)i * dx_stride_i + (size_t)d * dx_stride_d] = result[d];
 }
 
+// second order w.r.t. dL_dy: dL_ddLdy[k][i] = sum_d dy_dx[k][i][d] * ddx[i][d]  (grid.h:623-653)
+__global__ void k_grid_backward_backward_dLdoutput(uint32_t n_dims, uint32_t n_features, uint32_t n_to_pad, GridIO io, const float* __restrict__ dy_dx,
+                                                   half_t* __restrict__ dL_ddLdy) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= io.n) return;
+	float dd[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+	for (uint32_t d = 0; d < n_dims; ++d) dd[d] = io.ddx[(size_t)i * io.ddx_stride_i + (size_t)d * io.ddx_stride_d];
+	for (uint32_t k = 0; k < n_features; ++k) {
+		float result = 0.0f;
+		for (uint32_t d = 0; d < n_dims; ++d) result += dy_dx[((size_t)k * io.n + i) * n_dims + d] * dd[d];
+		dL_ddLdy[(size_t)k * io.stride_k + (size_t)i * io.stride_i] = to_half_rn(result);
+	}
+	for (uint32_t k = n_features; k < n_features + n_to_pad; ++k) dL_ddLdy[(size_t)k * io.stride_k + (size_t)i * io.stride_i] = (half_t)0.0f;
+}
+
+// second order w.r.t. the positions (grid.h:457-620).  With v(corner) = sum_f grid[corner][f] * dL_dy[f] and s_d = +-1
+// (right / left corner along d):
+//   dL_dx[a] = scale^2 * ( ddx[a] * pos''(a) * sum_c s_a prod_{e != a} w_e v(c)                           (Smoothstep only)
+//                        + sum_{b != a} ddx[b] * pos'(b) * pos'(a) * sum_c s_a s_b prod_{e != a, b} w_e v(c) )
+// summed over the levels; one thread per sample walks the levels (no atomics, fixed order).
+template <uint32_t D, uint32_t F>
+__global__ void __launch_bounds__(128) k_grid_backward_backward_input(const GridMeta meta, const GridIO io, const half_t* __restrict__ dL_dy,
+                                                                       const half_t* __restrict__ params, float* __restrict__ dL_dx,
+                                                                       uint32_t dx_stride_i, uint32_t dx_stride_d) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= io.n) return;
+	constexpr uint32_t N_CORNERS = 1u << D, NP = (F + 1) / 2;
+	float x[D], dd[D], out[D];
+	load_position<D>(io, i, x);
+	load_ddx<D>(io, i, dd);
+#pragma unroll
+	for (uint32_t d = 0; d < D; ++d) out[d] = 0.0f;
+	const uint32_t n_features = meta.n_levels * F;
+	const float max_level = (meta.max_level * (float)n_features) / (float)F;
+	const bool nearest = meta.interp == (uint32_t)InterpolationType::Nearest;
+	for (uint32_t level = 0; level < meta.n_levels && !nearest; ++level) {
+		if ((float)level > max_level + 1e-3f) break;  // grid.h:483
+		const Level<D> lv = make_level<D>(meta, level);
+		const half_t* __restrict__ grid = params + (size_t)meta.offset[level] * F;
+		const Cell<D> c = make_cell<D, false>(lv, x);
+		float d2[D];  // pos''(d): 0 for Linear, smoothstep'' = 6 - 12 t otherwise (common_device.h:1012-1014)
+#pragma unroll
+		for (uint32_t d = 0; d < D; ++d) {
+			float p = __builtin_fmaf(lv.scale, x[d], 0.5f);
+			p -= __builtin_floorf(p);
+			d2[d] = lv.smooth ? 6.0f - 12.0f * p : 0.0f;
+		}
+		float gy[F];
+#pragma unroll
+		for (uint32_t f = 0; f < F; ++f) gy[f] = (float)dL_dy[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i];
+		float v[N_CORNERS];
+#pragma unroll
+		for (uint32_t idx = 0; idx < N_CORNERS; ++idx) {
+			h2 val[NP];
+			load_features<F>(grid + (size_t)corner_index<D, false>(lv, c, idx) * F, val);
+			float acc = 0.0f;
+#pragma unroll
+			for (uint32_t f = 0; f < F; ++f) acc += (float)val[f / 2][f % 2] * gy[f];
+			v[idx] = acc;
+		}
+		const float s2 = lv.scale * lv.scale;
+#pragma unroll
+		for (uint32_t a = 0; a < D; ++a) {
+			float grad_out = 0.0f;
+#pragma unroll
+			for (uint32_t idx = 0; idx < N_CORNERS; ++idx) {
+				const float sa = ((idx >> a) & 1u) ? 1.0f : -1.0f;
+				if (lv.smooth) {  // diagonal of the Hessian
+					float wgt = s2 * dd[a] * d2[a] * sa;
+#pragma unroll
+					for (uint32_t e = 0; e < D; ++e) {
+						if (e != a) wgt *= ((idx >> e) & 1u) ? c.w[e][1] : c.w[e][0];
+					}
+					grad_out += wgt * v[idx];
+				}
+#pragma unroll
+				for (uint32_t b = 0; b < D; ++b) {  // mixed terms
+					if (b == a) continue;
+					float wgt = s2 * dd[b] * c.derivative[b] * c.derivative[a] * sa * (((idx >> b) & 1u) ? 1.0f : -1.0f);
+#pragma unroll
+					for (uint32_t e = 0; e < D; ++e) {
+						if (e != a && e != b) wgt *= ((idx >> e) & 1u) ? c.w[e][1] : c.w[e][0];
+					}
+					grad_out += wgt * v[idx];
+				}
+			}
+			out[a] += grad_out;
+		}
+	}
+#pragma unroll
+	for (uint32_t d = 0; d < D; ++d) dL_dx[(size_t)i * dx_stride_i + (size_t)d * dx_stride_d] = out[d];
+}
+
 template <uint32_t D>
 __global__ void k_grid_indices(const GridMeta meta, const GridIO io, uint32_t* __restrict__ indices) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
@@ -1158,6 +1278,11 @@ static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const
 	const SlicePlan& plan = bp.slices;
 	const BucketPlan& bk = bp.buckets;
 	const uint32_t blocks = bp.blocks;
+	if (io.ddx) {
+		for (uint32_t p = 0; p < plan.n_items; ++p) {
+			if (plan.kind[p] != SLICE_BUCKET) throw std::runtime_error("grid_backward: second-order scatter needs every level in the bucketed path (table too large)");
+		}
+	}
 	uint32_t* counters = nullptr;
 	uint32_t* queues = nullptr;
 	uint32_t* overflow = nullptr;
@@ -1225,6 +1350,14 @@ void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, c
                    GridBackwardMode mode, uint32_t lds_slice_bytes, const GridBackwardWorkspace& ws) {
 	if (io.n == 0) return;
 	if (!grid_gradient) throw std::runtime_error("grid_backward: missing gradient buffer");
+	if (io.ddx) {  // second-order scatter
+		if (meta.interp == (uint32_t)InterpolationType::Nearest) {  // d(dy_dx)/d(grid) == 0 without interpolation (grid.h:422-425)
+			const size_t bytes = (size_t)meta.offset[meta.n_levels] * meta.n_feat * sizeof(half_t);
+			if (!accumulate && hipMemsetAsync(grid_gradient, 0, bytes, stream) != hipSuccess) throw std::runtime_error("grid_backward: memset failed");
+			return;
+		}
+		if (mode != GridBackwardMode::Bucketed) throw std::runtime_error("grid_backward: the second-order scatter runs in the bucketed mode only");
+	}
 	switch (mode) {
 		case GridBackwardMode::SlicedF32: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, false, false, lds_slice_bytes, ws); break;
 		case GridBackwardMode::SlicedF16: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, true, false, lds_slice_bytes, ws); break;
@@ -1244,6 +1377,23 @@ void grid_backward_input(hipStream_t stream, uint32_t n_dims, uint32_t n_feature
 	if (io.n == 0) return;
 	TCNN_LAUNCH(k_grid_backward_input, dim3(div_round_up(io.n, 128u)), dim3(128), 0, stream, n_dims, n_features, io, dL_dy, dy_dx,
 	            dL_dx, dx_stride_i, dx_stride_d);
+}
+
+void grid_backward_backward_dLdoutput(hipStream_t stream, uint32_t n_dims, uint32_t n_features, uint32_t n_to_pad, const GridIO& io,
+                                      const float* dy_dx, half_t* dL_ddLdy) {
+	if (io.n == 0) return;
+	if (!io.ddx || !dy_dx) throw std::runtime_error("grid second-order pass: dL_ddLdinput and the forward's dy_dx are required");
+	TCNN_LAUNCH(k_grid_backward_backward_dLdoutput, dim3(div_round_up(io.n, 128u)), dim3(128), 0, stream, n_dims, n_features, n_to_pad, io, dy_dx, dL_ddLdy);
+}
+
+void grid_backward_backward_input(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, const half_t* params,
+                                  float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_d) {
+	if (io.n == 0) return;
+	if (!io.ddx) throw std::runtime_error("grid second-order pass: dL_ddLdinput is required");
+	const uint32_t blocks = div_round_up(io.n, 128u);
+#define BBI(D_, F_) TCNN_LAUNCH((k_grid_backward_backward_input<D_, F_>), dim3(blocks), dim3(128), 0, stream, meta, io, dL_dy, params, dL_dx, dx_stride_i, dx_stride_d);
+	TCNN_GRID_DISPATCH(BBI)
+#undef BBI
 }
 
 void grid_indices(hipStream_t stream, const GridMeta& meta, const GridIO& io, uint32_t* indices) {

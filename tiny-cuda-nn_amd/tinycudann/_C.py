@@ -278,8 +278,26 @@ class Module:
                                                  _ptr(dL_dparams), _ptr(input), _ptr(output), _ptr(params)))
             return dL_dinput, dL_dparams
 
-    def bwd_bwd_input(self, ctx, input, params, dL_ddLdinput, dL_doutput):
-        raise RuntimeError("bwd_bwd_input (second-order gradients) is not part of the MI355X build yet")
+    def bwd_bwd_input(self, ctx, input, params, dL_ddLdinput, dL_doutput):  # bindings.cpp:193-241
+        """Second-order pass of the grid encoding -> (dL_ddLdoutput, dL_dparams, dL_dinput); entries are None when the
+        corresponding tensor does not require a gradient."""
+        for t in (input, params, dL_ddLdinput, dL_doutput):
+            if not t.is_cuda or not t.is_contiguous():
+                raise RuntimeError("bwd_bwd_input: tensors must be contiguous and on the GPU")
+        if input.dtype != torch.float32 or dL_ddLdinput.dtype != torch.float32 or dL_doutput.dtype != self._torch_output_dtype():
+            raise RuntimeError("bwd_bwd_input: wrong tensor dtype")
+        if input.shape[1] != self.n_input_dims() or dL_doutput.shape[1] != self.n_output_dims() or dL_ddLdinput.shape != input.shape or \
+                params.shape[0] != self.n_params() or dL_doutput.shape[0] != input.shape[0]:
+            raise RuntimeError("bwd_bwd_input: wrong tensor size")
+        with torch.cuda.device(input.device):
+            batch_size = input.shape[0]
+            dL_ddLdoutput = torch.zeros((batch_size, self.n_output_dims()), dtype=self._torch_output_dtype(), device=input.device) if dL_doutput.requires_grad else None
+            dL_dparams = torch.zeros((self.n_params(),), dtype=self._torch_param_dtype(), device=input.device) if params.requires_grad else None
+            dL_dinput = torch.zeros((batch_size, input.shape[1]), dtype=torch.float32, device=input.device) if input.requires_grad else None
+            if dL_doutput.requires_grad or params.requires_grad or input.requires_grad:
+                _check(_lib.tcnn_module_backward_backward_input(self._h, _stream(), ctx._h, batch_size, _ptr(dL_ddLdinput), _ptr(input), _ptr(dL_doutput),
+                                                                _ptr(dL_dparams), _ptr(dL_ddLdoutput), _ptr(dL_dinput), _ptr(params)))
+            return dL_ddLdoutput, dL_dparams, dL_dinput
 
     def initial_params(self, seed):  # bindings.cpp:284-289
         out = torch.zeros((self.n_params(),), dtype=torch.float32, device="cuda")

@@ -10,7 +10,7 @@ Behavioural contract kept from the reference:
   * output gradients are multiplied by the loss scale (128 for fp16) before the native backward and
     the returned gradients divided by it (modules.py:161-171);
   * native objects are not pickled; they are rebuilt from the stored configs on unpickling.
-Second-order gradients (`bwd_bwd_input`) are not part of this build yet and raise.
+Second-order gradients of the grid encoding (`bwd_bwd_input`) are available through double backward, as in the reference.
 """
 import gc
 import warnings
@@ -62,12 +62,52 @@ class _NativeFunction(torch.autograd.Function):
             warnings.warn("doutput must be a GPU tensor, but isn't. This indicates suboptimal performance.")
             dy = dy.cuda()
         x, params, y = ctx.saved_tensors
+        # a Function of its own, so that the input gradient can be differentiated again (eikonal / SDF losses)
+        dx, dparams = _NativeBackwardFunction.apply(ctx, dy, x, params, y)
+        return None, _none_if_scalar(dx), _none_if_scalar(dparams), None
+
+
+def _scalar_like(t):
+    return torch.empty([], dtype=t.dtype, device=t.device)  # placeholder for "no gradient": autograd outputs must be tensors
+
+
+def _none_if_scalar(t):
+    return None if t.dim() == 0 else t
+
+
+class _NativeBackwardFunction(torch.autograd.Function):
+    """First-order backward as a differentiable op.  Its own backward is the native second-order pass
+    (`bwd_bwd_input`, reference modules.py:163-203 / grid.h:910-1042): gradients of dL_dinput with respect to
+    dL_doutput, the parameters and the input.  Gradients OF the parameter gradient are not available."""
+
+    @staticmethod
+    def forward(ctx, fwd_ctx, dy, x, params, y):
+        ctx.fwd_ctx = fwd_ctx
+        ctx.save_for_backward(x, params, dy)
+        scale = fwd_ctx.loss_scale
         with torch.no_grad():
-            scaled = (dy * ctx.loss_scale).to(y.dtype).contiguous()
-            dx, dparams = ctx.native_module.bwd(ctx.native_ctx, x, params, y, scaled)
-            dx = None if dx is None else dx / ctx.loss_scale
-            dparams = None if dparams is None else dparams / ctx.loss_scale
-        return None, dx, dparams, None
+            dx, dparams = fwd_ctx.native_module.bwd(fwd_ctx.native_ctx, x, params, y, (dy * scale).to(y.dtype).contiguous())
+        return (_scalar_like(x) if dx is None else dx / scale), (_scalar_like(params) if dparams is None else dparams / scale)
+
+    @staticmethod
+    def backward(ctx, ddx, ddparams):
+        x, params, dy = ctx.saved_tensors
+        fwd_ctx = ctx.fwd_ctx
+        scale = fwd_ctx.loss_scale
+        if ddx is None or ddx.dim() == 0:
+            return None, None, None, None, None
+        with torch.enable_grad():  # keeps dy's requires_grad flag (this method runs under no_grad by default)
+            scaled_dy = (dy * scale).to(_precision_dtype(fwd_ctx.native_module)).contiguous()
+        with torch.no_grad():
+            d_dy, d_params, d_x = fwd_ctx.native_module.bwd_bwd_input(fwd_ctx.native_ctx, x, params, ddx.to(torch.float).contiguous(), scaled_dy)
+            # d_dy depends on ddx only; the other two carry one factor of the loss scale through scaled_dy
+            d_params = None if d_params is None else d_params / scale
+            d_x = None if d_x is None else d_x / scale
+        return None, d_dy, d_x, d_params, None
+
+
+def _precision_dtype(native_module):
+    return _torch_precision(native_module.output_precision())
 
 
 class Module(torch.nn.Module):

@@ -755,7 +755,7 @@ def test_grid_second_order_through_c_abi_and_double_backward(interp):
     xt = torch.from_numpy(pos[:512]).cuda().requires_grad_(True)
     feat = tcnn_mod(xt).float().sum()
     (gx,) = torch.autograd.grad(feat, xt, create_graph=True)
-    loss = (gx ** 2).sum()
+    loss = (gx ** 2).sum() * 1e-3  # small enough for the fp16 parameter gradient (x loss scale 128) of the coarsest table
     loss.backward()
     assert torch.isfinite(tcnn_mod.params.grad).all() and float(tcnn_mod.params.grad.abs().max()) > 0
     # finite difference of the loss with respect to a few touched parameters (the loss is quadratic in them)
@@ -767,7 +767,7 @@ def test_grid_second_order_through_c_abi_and_double_backward(interp):
             tcnn_mod.params.copy_(pvec)
         xq = xt.detach().clone().requires_grad_(True)
         (gq,) = torch.autograd.grad(tcnn_mod(xq).float().sum(), xq, create_graph=False)
-        return float((gq.double() ** 2).sum())
+        return float((gq.double() ** 2).sum()) * 1e-3
 
     base = tcnn_mod.params.detach().clone()
     for j in idx:

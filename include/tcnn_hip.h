@@ -70,6 +70,11 @@ int tcnn_module_forward(tcnn_module_t* m, tcnn_stream_t stream, uint32_t n_eleme
 int tcnn_module_backward(tcnn_module_t* m, tcnn_stream_t stream, const tcnn_context_t* ctx, uint32_t n_elements,
                          float* dL_dinput, const void* dL_doutput, void* dL_dparams, const float* input,
                          const void* output, const void* params);
+/* cpp_api.h:106-108 -> DifferentiableObject::backward_backward_input: second-order pass through dL_dinput.  Like the
+ * reference, implemented by the grid encoding only (grid.h:910-1042); TCNN_ERROR_UNSUPPORTED for every other module.
+ * dL_ddLdinput: fp32 [n][n_input_dims] (required); the three outputs dL_dparams (fp16, overwritten), dL_ddLdoutput (fp16
+ * [n][padded width]) and dL_dinput (fp32, overwritten) are each optional; the context must come from a forward pass with
+ * prepare_input_gradients. */
 int tcnn_module_backward_backward_input(tcnn_module_t* m, tcnn_stream_t stream, const tcnn_context_t* ctx, uint32_t n_elements,
                                         const float* dL_ddLdinput, const float* input, const void* dL_doutput,
                                         void* dL_dparams, void* dL_ddLdoutput, float* dL_dinput, const void* params);

@@ -677,17 +677,9 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, WIDTH == 128 ? 1 : TCNN_MLP_T
 			uint32_t K = IN;
 #pragma unroll
 			for (uint32_t layer = 0; layer <= HM; ++layer) {
-				// Every product is issued twice with the operands swapped: mfma(a, b) leaves (neuron 16w+4g+r, sample 16t+lr) in
-				// a lane -- four neurons of one sample, the sample-major store the next layer reads -- and mfma(b, a), the same
-				// sums with rows and columns exchanged, leaves (sample 16t+4g+r, neuron 16w+lr): four samples of one neuron, the
-				// feature-major store the backward pass reads.  Both operand fragments index their outer dimension by lane & 15
-				// and k by lane >> 4, so the swap needs no extra loads; the MFMA pipe is ~10 % busy, 2-byte LDS stores are not free.
-				f4 acc[NT], accT[NT];
+				f4 acc[NT];
 #pragma unroll
-				for (uint32_t t = 0; t < NT; ++t) {
-					acc[t] = zero4();
-					accT[t] = zero4();
-				}
+				for (uint32_t t = 0; t < NT; ++t) acc[t] = zero4();
 				const half_t* wrow = Wl + (size_t)(16 * w + lr) * K;
 				for (uint32_t kb = 0; kb < K / 32; ++kb) {
 					const h8 a = *(const h8*)(wrow + 32 * kb + 8 * g);
@@ -695,7 +687,6 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, WIDTH == 128 ? 1 : TCNN_MLP_T
 					for (uint32_t t = 0; t < NT; ++t) {
 						const h8 b = *(const h8*)(cur + (16 * t + lr) * ldc + 32 * kb + 8 * g);
 						acc[t] = mfma_16x16x32(a, b, acc[t]);
-						accT[t] = mfma_16x16x32(b, a, accT[t]);
 					}
 				}
 				if (K & 16u) {
@@ -705,20 +696,19 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, WIDTH == 128 ? 1 : TCNN_MLP_T
 					for (uint32_t t = 0; t < NT; ++t) {
 						const h4 b = *(const h4*)(cur + (16 * t + lr) * ldc + k0 + 4 * g);
 						acc[t] = mfma_16x16x16(a, b, acc[t]);
-						accT[t] = mfma_16x16x16(b, a, accT[t]);
 					}
 				}
+				// accumulator (neuron 16w+4g+r, sample 16t+lr) -> activation -> both layouts
 				half_t* hl = hT + layer * WIDTH * SP;
 #pragma unroll
 				for (uint32_t t = 0; t < NT; ++t) {
-					h4 o, oT;
+					h4 o;
 #pragma unroll
 					for (uint32_t r = 0; r < 4; ++r) {
 						o[r] = (half_t)act_forward<GENERAL>(act, acc[t][r]);
-						oT[r] = (half_t)act_forward<GENERAL>(act, accT[t][r]);
+						hl[(16 * w + 4 * g + r) * SP + 16 * t + lr] = o[r];
 					}
-					*(h4*)(nxt + (16 * t + lr) * LDW + 16 * w + 4 * g) = o;   // [sample 16t+lr][neurons 16w+4g ..]
-					*(h4*)(hl + (16 * w + lr) * SP + 16 * t + 4 * g) = oT;    // [neuron 16w+lr][samples 16t+4g ..]
+					*(h4*)(nxt + (16 * t + lr) * LDW + 16 * w + 4 * g) = o;
 				}
 				__syncthreads();
 				cur = nxt;

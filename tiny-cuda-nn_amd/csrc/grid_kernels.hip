@@ -1269,8 +1269,23 @@ GridBackwardWorkspace grid_backward_workspace_size(const GridMeta& meta, uint32_
 	return ws;
 }
 
+static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient,
+                                          bool accumulate, bool packed, bool bucketed, uint32_t lds_slice_bytes, const GridBackwardWorkspace& ws);
+
+// The queue counters are handed back zeroed by the kernels themselves; if the launch sequence is cut short by an error
+// they are cleared here, so that the contract ("zero on entry") survives for the next call.
 static void grid_backward_sliced(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient,
                                  bool accumulate, bool packed, bool bucketed, uint32_t lds_slice_bytes, const GridBackwardWorkspace& ws) {
+	try {
+		grid_backward_sliced_launches(stream, meta, io, dL_dy, grid_gradient, accumulate, packed, bucketed, lds_slice_bytes, ws);
+	} catch (...) {
+		if (bucketed && ws.counters) (void)hipMemsetAsync(ws.counters, 0, ws.n_counters * sizeof(uint32_t), stream);
+		throw;
+	}
+}
+
+static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient,
+                                          bool accumulate, bool packed, bool bucketed, uint32_t lds_slice_bytes, const GridBackwardWorkspace& ws) {
 	const uint32_t F = meta.n_feat;
 	packed = packed && (F % 2 == 0);
 	const BackwardPlan bp = make_backward_plan(meta, io.n, packed, bucketed, accumulate, lds_slice_bytes);

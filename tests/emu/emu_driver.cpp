@@ -5,6 +5,7 @@
 #include "../../tiny-cuda-nn_amd/csrc/grid_kernels.hip"
 #include "../../tiny-cuda-nn_amd/csrc/elementwise_kernels.hip"
 #include "../../tiny-cuda-nn_amd/csrc/mlp_kernels.hip"
+#include "../../tiny-cuda-nn_amd/csrc/mlp_train_wave.hip"
 
 using namespace tcnn_hip;
 
@@ -163,7 +164,7 @@ int emu_mlp_train(const EmuMlp* e, uint32_t n, const uint16_t* params, const uin
 		if (!mlp_train_supported(m)) return 2;
 		std::vector<uint16_t> params_t(m.n_params());
 		mlp_transpose_weights(nullptr, m, (const half_t*)params, (half_t*)params_t.data());
-		const uint32_t np = mlp_backward_n_partials(m, n);
+		const uint32_t np = mlp_train_n_partials(m, n, (LossType)loss_type);
 		std::vector<float> partials(grads ? (size_t)np * m.n_params() : 0, -12345.0f), block_sums(np, -777.0f), ws(1024);
 		const MlpLossArgs la = {(LossType)loss_type, target, data_pdf, dims, loss_scale, n_total};
 		mlp_train(nullptr, m, n, (const half_t*)params, (const half_t*)params_t.data(), (const half_t*)input_soa, la, (half_t*)output,

@@ -151,6 +151,13 @@ MLP_CASES = [(32, 64, 4, 2), (16, 16, 3, 1), (48, 32, 16, 3), (32, 128, 16, 4), 
              (32, 64, 40, 2), (16, 32, 100, 3)]  # more than 16 outputs (several output blocks, layer-by-layer backward)
 
 
+def same_weight_gradients(a, b):
+    """The register-resident training kernel sums the same fp32 products per weight as the stand-alone backward kernel,
+    grouped by wavefront instead of by workgroup: equal up to the last fp16 bit of a few entries."""
+    fa, fb = O.h2f(a), O.h2f(b)
+    return np.mean(a != b) < 0.05 and np.allclose(fa, fb, rtol=2e-3, atol=1e-7 + 1e-3 * np.abs(fb).max() * 2.0 ** -10)
+
+
 @pytest.mark.parametrize("case", MLP_CASES)
 def test_mlp_forward_backward(case):
     IN, W, OUT, H = case
@@ -212,14 +219,19 @@ def test_mlp_activations(act, out_act):
     out_f, dy_f, dx_f, g_f, _ = emu.mlp_train(om, ph, xs, O.LOSS_L2, target, OUT)
     _, dyl, _ = emu.loss(O.LOSS_L2, out, target, OUT)
     g_u, dx_u = emu.mlp_backward(om, ph, xs, hid, dyl, output=out)
-    assert np.array_equal(out_f, out) and np.array_equal(dy_f, dyl) and np.array_equal(dx_f, dx_u) and np.array_equal(g_f, g_u)
+    assert np.array_equal(out_f, out) and np.array_equal(dy_f, dyl) and np.array_equal(dx_f, dx_u) and same_weight_gradients(g_f, g_u)
 
 
-@pytest.mark.parametrize("case", MLP_CASES)
+# the shapes with a register-resident (wave per strip) instance: 32 inputs, 64 neurons x 1-2 layers or 32 neurons x 1-3 layers
+WAVE_CASES = [(32, 64, 3, 1), (32, 32, 2, 1), (32, 32, 4, 2), (32, 32, 16, 3)]
+
+
+@pytest.mark.parametrize("case", MLP_CASES + WAVE_CASES)
 @pytest.mark.parametrize("loss_type", [O.LOSS_L2, O.LOSS_RELATIVE_L2])
 def test_mlp_fused_training_pass_equals_the_unfused_kernels(case, loss_type):
     """k_mlp_train (forward + loss + backward in one kernel) must give the same BITS as k_mlp_forward -> k_loss ->
-    k_mlp_backward: same MFMA fragments, same rounding points; only the loss partial sums are grouped differently."""
+    k_mlp_backward: same MFMA fragments, same rounding points; only the loss partial sums (and, in the register-resident
+    variant, the fp32 weight-gradient partial sums) are grouped differently."""
     IN, W, OUT, H = case
     rng = np.random.default_rng(7)
     om = O.mlp_init(IN, W, OUT, H)
@@ -237,11 +249,11 @@ def test_mlp_fused_training_pass_equals_the_unfused_kernels(case, loss_type):
     _, dy, loss_u = emu.loss(loss_type, out, target, OUT, data_pdf=pdf, n_total=2 * n * OUT)
     g, dx = emu.mlp_backward(om, ph, xs, hid, dy)
     assert np.array_equal(out_f, out) and np.array_equal(dy_f, dy)
-    assert np.array_equal(dx_f, dx) and np.array_equal(g_f, g)
+    assert np.array_equal(dx_f, dx) and same_weight_gradients(g_f, g)
     assert abs(loss_f - loss_u) <= 1e-5 * abs(loss_u) + 1e-12
     # without input gradients / without a context to fill
     out2 = emu.mlp_train(om, ph, xs, loss_type, target, OUT, data_pdf=pdf, n_total=2 * n * OUT, want_dinput=False)
-    assert out2[2] is None and np.array_equal(out2[3], g)
+    assert out2[2] is None and np.array_equal(out2[3], g_f)
 
 
 @pytest.mark.parametrize("loss_type", range(len(O.LOSS_NAMES)))

@@ -588,7 +588,12 @@ def test_network_activations(act, out_act):
     g_fused, loss_fused = tm.param_gradients.clone(), tm.loss(ctx_f)
     c2 = tm.forward(xx, tt)
     tm.backward(c2, xx)
-    assert torch.equal(tm.param_gradients, g_fused)
+    # ... bit for bit in the encoding (dL/dinput is identical); the network's fp32 weight-gradient partial sums are grouped
+    # per wavefront in the register-resident kernel and per workgroup in the stand-alone one: last-bit differences
+    g_pair, nm = tm.param_gradients, tm.n_mlp_params
+    assert torch.equal(g_pair[nm:], g_fused[nm:])
+    assert (g_pair[:nm] != g_fused[:nm]).float().mean() < 0.05
+    assert torch.allclose(g_pair[:nm].float(), g_fused[:nm].float(), rtol=2e-3, atol=1e-3 * float(g_fused[:nm].float().abs().max()) * 2.0 ** -10 + 1e-7)
     assert abs(tm.loss(c2) - loss_fused) <= 1e-5 * abs(loss_fused) + 1e-9
     assert torch.isfinite(g_fused.float()).all()
 

@@ -1272,7 +1272,7 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 		ProfScope prof(stream, STAGE_MLP_TRAIN);
 		Scratch params_t_local;
 		const half_t* params_t = trainer_params_t(tm, stream, params, params_t_local);
-		const uint32_t n_partials = mlp_backward_n_partials(md.net.mlp, n);
+		const uint32_t n_partials = mlp_train_n_partials(md.net.mlp, n, tm->loss);
 		Scratch partials;
 		if (want_grads) partials = Scratch(stream, (size_t)n_partials * md.n_mlp_params() * sizeof(float));
 		if (need_denc) denc = Scratch(stream, (size_t)e.padded_output_width * n * sizeof(half_t));

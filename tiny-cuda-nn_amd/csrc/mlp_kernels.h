@@ -97,6 +97,17 @@ struct MlpLossArgs {
 	uint32_t n_total;       // elements the mean runs over (global batch x dims)
 };
 bool mlp_train_supported(const MlpMeta& m);
+// The register-resident instances of the training pass (mlp_train_wave.hip): one wavefront per strip of 32 samples, for
+// 32 inputs x {64 neurons, 1-2 hidden layers | 32 neurons, 1-3 hidden layers} x 16 padded outputs, ReLU / None activations,
+// (Relative)L2 loss.  mlp_train() picks them
+// when available (TCNN_MLP_TRAIN_WAVE=0 in the environment disables them); same contract as mlp_train().
+bool mlp_train_wave_supported(const MlpMeta& m, uint32_t n, LossType loss);
+uint32_t mlp_train_wave_n_partials(uint32_t n);
+void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
+                    const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums);
+
+// number of fp32 slabs / loss partial sums mlp_train() writes for this shape and batch (<= mlp_backward_n_partials)
+uint32_t mlp_train_n_partials(const MlpMeta& m, uint32_t n, LossType loss);
 void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
                const MlpLossArgs& loss, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums);
 

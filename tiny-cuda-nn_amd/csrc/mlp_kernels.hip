@@ -7,6 +7,8 @@
 //             "feature-major" tile[k][SP]   (SP = S + 8)
 #include "mlp_kernels.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <stdexcept>
 #include <string>
@@ -14,8 +16,6 @@
 namespace tcnn_hip {
 
 
-TCNN_DEVICE h8 pack8(h4 a, h4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
-TCNN_DEVICE f4 zero4() { return f4{0.0f, 0.0f, 0.0f, 0.0f}; }
 
 constexpr uint32_t mlp_fwd_tile(uint32_t width) { return width == 128 ? 128u : 64u; }
 constexpr uint32_t MLP_BWD_TILE = 64;
@@ -1155,6 +1155,10 @@ static void dispatch_train(hipStream_t stream, const MlpMeta& m, uint32_t n, con
 	}
 }
 
+uint32_t mlp_train_n_partials(const MlpMeta& m, uint32_t n, LossType loss) {
+	return mlp_train_wave_supported(m, n, loss) ? mlp_train_wave_n_partials(n) : mlp_backward_n_partials(m, n);
+}
+
 bool mlp_train_supported(const MlpMeta& m) {
 	// 128-wide networks: measured no faster than the three-kernel path (the weight-gradient accumulators of four
 	// 128 x 128 matrices spill), so they keep it
@@ -1167,6 +1171,10 @@ void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* p
 	if (n == 0) return;
 	if (!mlp_train_supported(m)) throw std::runtime_error("mlp_train: unsupported network shape (check mlp_train_supported first)");
 	if (!loss_is_elementwise(la.type)) throw std::runtime_error("mlp_train: this loss needs whole output rows; use the stand-alone loss kernel");
+	if (mlp_train_wave_supported(m, n, la.type)) {
+		mlp_train_wave(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums);
+		return;
+	}
 	switch (m.width) {
 		case 16: dispatch_train<16>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		case 32: dispatch_train<32>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;

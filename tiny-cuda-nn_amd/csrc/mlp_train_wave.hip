@@ -1,0 +1,431 @@
+// mlp_train_wave.hip -- the register-resident training kernel of the fully fused MLP (one wavefront per strip of samples).
+// Register budget: 256 per wave (two waves per SIMD).  At that budget the compiler keeps every MFMA result in VGPRs; with
+// one wave per SIMD (512 registers) it routes them through AGPRs and v_accvgpr_read unless built with
+// -mllvm -amdgpu-mfma-vgpr-form -- measured slower either way (profiles/r01_exp_notes.txt).
+#include "mlp_kernels.h"
+
+#include <stdlib.h>
+
+#include <stdexcept>
+
+namespace tcnn_hip {
+
+// =============================================================================================
+// fused training pass, one wavefront per strip of 32 samples, everything in registers.
+//
+// k_mlp_train above shares a 64-sample tile between the waves of a workgroup: every layer costs each wave a read of
+// the whole activation tile from LDS, two LDS copies of what it produced (both layouts) and a workgroup barrier, and
+// the PMC counters show the LDS pipe, not MFMA or HBM, bounding it.  Here a wave owns its samples through all layers:
+//   * an MFMA accumulator tile (row 4g+r, col lr) IS a 16x16x16 B operand (k = 4g+j, n = lr), and two of them whose
+//     rows interleave (rows of block 2p: neurons 32p + 8g + {0..3}, of block 2p+1: 32p + 8g + {4..7}) are a 16x16x32
+//     B operand in natural k order.  So layer l+1 consumes layer l's accumulators directly; the permutation lives in
+//     which weight ROW each lane of the A operand holds (perm32) and costs nothing.
+//   * the weight gradients contract over samples and need both factors with the samples in the operand's k slots,
+//     i.e. the transposed tiles.  A 16x16 tile is transposed exactly by one MFMA against the identity
+//     (D = A * I with the tile as A operand), no LDS round trip.
+//   * the network input arrives feature-major: a 16-byte load per lane is already the "samples in k" operand of
+//     dL/dW_in; one MFMA against a selection matrix turns it into the first layer's B operand.  dL/dinput is
+//     produced sample-transposed (D = dA^T * W) so that it leaves as 16-byte feature-major stores.
+// The weights (both orientations, pre-arranged as operands) are read-only in LDS; nothing a wave computes for its
+// samples goes through LDS, which otherwise only serves the final reduction of the four waves' weight-gradient accumulators.  Same products, same k order and same rounding points
+// as k_mlp_forward / k_loss / k_mlp_backward: activations, outputs and dL/dinput are bit-identical; the fp32 weight
+// gradient partial sums are grouped differently.
+// =============================================================================================
+TCNN_DEVICE uint32_t perm32(uint32_t b, uint32_t row) { return 32u * (b >> 1) + 8u * (row >> 2) + 4u * (b & 1u) + (row & 3u); }
+TCNN_DEVICE h4 to_h4(f4 v) { return h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}; }
+
+// ReLU / None on packed halves (the GENERAL == false instances).  Same values as activation_device.h's scalar forms:
+//   forward  (half)(x > 0 ? x : 0) == max((half)x, 0)   rounding is monotonic; "None" takes the maximum with -inf
+//   backward (half)(h > 0 ? v : 0): the fp16 bits of (half)v ANDed with 0xFFFF where h != +-0 and with 0 elsewhere
+//            (h >= 0 after ReLU; +0 for masked entries); "None" forces the mask to ones
+typedef int16_t ss2 __attribute__((ext_vector_type(2)));
+struct PackedAct {
+	h2 floor2;            // forward: {0, 0} for ReLU, {-inf, -inf} for None
+	uint32_t keep_bits;   // backward: 0 for ReLU, 0x00010001 for None
+};
+TCNN_DEVICE PackedAct packed_act(uint32_t act) {
+	const half_t lo = act == (uint32_t)Activation::ReLU ? (half_t)0.0f : (half_t)-__builtin_inff();
+	return {h2{lo, lo}, act == (uint32_t)Activation::ReLU ? 0u : 0x00010001u};
+}
+template <bool GENERAL>
+TCNN_DEVICE h4 act_forward4(uint32_t act, const PackedAct& pa, f4 x) {
+	if constexpr (GENERAL) {
+		return h4{(half_t)act_forward<true>(act, x[0]), (half_t)act_forward<true>(act, x[1]), (half_t)act_forward<true>(act, x[2]), (half_t)act_forward<true>(act, x[3])};
+	} else {
+		const h2 a = __builtin_elementwise_max(h2{(half_t)x[0], (half_t)x[1]}, pa.floor2);
+		const h2 b = __builtin_elementwise_max(h2{(half_t)x[2], (half_t)x[3]}, pa.floor2);
+		return pack4(a, b);
+	}
+}
+TCNN_DEVICE h2 relu_mask(h2 d, h2 forward_value, uint32_t keep_bits) {
+	const uint32_t t = (__builtin_bit_cast(uint32_t, forward_value) & 0x7FFF7FFFu) | keep_bits;
+	const ss2 keep = (ss2)(-__builtin_bit_cast(ss2, t)) >> 15;  // 0xFFFF where the (sign-stripped) forward value is not zero
+	return __builtin_bit_cast(h2, __builtin_bit_cast(uint32_t, d) & __builtin_bit_cast(uint32_t, keep));
+}
+template <bool GENERAL>
+TCNN_DEVICE h4 act_backward4(uint32_t act, const PackedAct& pa, f4 v, h4 forward_value) {
+	if constexpr (GENERAL) {
+		return h4{(half_t)act_backward<true>(act, v[0], forward_value[0]), (half_t)act_backward<true>(act, v[1], forward_value[1]),
+		          (half_t)act_backward<true>(act, v[2], forward_value[2]), (half_t)act_backward<true>(act, v[3], forward_value[3])};
+	} else {
+		const h4 d = to_h4(v);
+		return pack4(relu_mask(__builtin_shufflevector(d, d, 0, 1), __builtin_shufflevector(forward_value, forward_value, 0, 1), pa.keep_bits),
+		             relu_mask(__builtin_shufflevector(d, d, 2, 3), __builtin_shufflevector(forward_value, forward_value, 2, 3), pa.keep_bits));
+	}
+}
+
+// (Relative)L2 gradient with the divisions that cannot change a bit left out: x / pdf when there is no pdf (x / 1), and the
+// per-element loss VALUE, of which only the sum is ever used: the caller sums difference * gradient (= 2 n_total value up to
+// one rounding) and scales once.  The gradient itself is evaluated exactly as loss_element() does.
+TCNN_DEVICE half_t loss_gradient_simple(bool relative, bool has_pdf, float prediction, float target, float pdf, float n_total, float loss_scale,
+                                        float& difference_times_gradient) {
+	const float difference = prediction - target;
+	float gradient = 2 * difference;
+	if (relative) gradient = gradient / (prediction * prediction + 0.01f);
+	if (has_pdf) gradient = gradient / pdf;
+	difference_times_gradient = difference * gradient;
+	return to_half_rn(loss_scale * gradient / n_total);
+}
+
+#ifndef TCNN_MLP_WAVE_BLOCKS
+#define TCNN_MLP_WAVE_BLOCKS 512  // two workgroups of four waves per CU (256 registers per wave): the second wave of a SIMD fills the first one's stalls
+#endif
+#ifndef TCNN_MLP_WAVE_MIN_BLOCKS
+#define TCNN_MLP_WAVE_MIN_BLOCKS 2
+#endif
+constexpr uint32_t MLP_WAVE_STRIP = 32, MLP_WAVE_THREADS = 256;
+
+template <uint32_t WIDTH, uint32_t IN, uint32_t HM, bool GENERAL>
+__global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_mlp_train_wave(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
+                                                                        const half_t* __restrict__ params_t, const half_t* __restrict__ input,
+                                                                        const MlpLossArgs la, half_t* __restrict__ output, half_t* __restrict__ dL_doutput,
+                                                                        half_t* __restrict__ dL_dinput, float* __restrict__ partials,
+                                                                        float* __restrict__ block_sums) {
+	constexpr uint32_t NB = WIDTH / 16, NP = WIDTH / 32, FB = IN / 16, FP = IN / 32, NWAVES = MLP_WAVE_THREADS / 64, HMX = HM > 0 ? HM : 1;
+	constexpr uint32_t N_PARAMS = WIDTH * IN + HM * WIDTH * WIDTH + 16 * WIDTH;
+	__shared__ float slab[N_PARAMS];
+	__shared__ float red[MLP_WAVE_THREADS];
+	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
+	const uint32_t act = m.activation, out_act = m.output_activation;
+	const bool want_grads = partials != nullptr, want_dx = dL_dinput != nullptr;
+	const float n_total = (float)la.n_total;
+	const PackedAct pa = packed_act(act);
+	const bool relative = la.type == LossType::RelativeL2, has_pdf = la.data_pdf != nullptr;
+
+	// ---- weights, both orientations, as MFMA operands (lane lr <-> the row/column perm32 assigns to it), staged once per
+	// workgroup in LDS in lane order: a fragment is one conflict-free 16-byte read per lane wherever it is used
+	const half_t* W_in = params;                                // [WIDTH][IN]
+	const half_t* W_hid = W_in + (size_t)WIDTH * IN;            // HM x [WIDTH][WIDTH]
+	const half_t* W_out = W_hid + (size_t)HM * WIDTH * WIDTH;   // [16][WIDTH]
+	const half_t* wt_in = params_t;                             // [IN][WIDTH]
+	const half_t* wt_hid = wt_in + (size_t)IN * WIDTH;          // HM x [WIDTH][WIDTH]
+	const half_t* wt_out = wt_hid + (size_t)HM * WIDTH * WIDTH; // [WIDTH][16]
+	constexpr uint32_t F_WINA = 0, F_WHIDA = F_WINA + NB * FP, F_WHIDT = F_WHIDA + HM * NB * NP, F_WOUTA = F_WHIDT + HM * NB * NP,
+	                   F_WINB = F_WOUTA + NP, N_FRAG = F_WINB + FB * NP;
+	__shared__ h8 wfrag[N_FRAG][64];
+	__shared__ h4 wfrag_out_t[NB][64];
+	for (uint32_t f = w; f < N_FRAG; f += NWAVES) {
+		const half_t* src;
+		if (f < F_WHIDA) {
+			const uint32_t b = (f - F_WINA) / FP, p = (f - F_WINA) % FP;
+			src = W_in + (size_t)perm32(b, lr) * IN + 32 * p + 8 * g;
+		} else if (f < F_WOUTA) {
+			const bool transposed = f >= F_WHIDT;
+			const uint32_t e = f - (transposed ? F_WHIDT : F_WHIDA), j = e / (NB * NP), b = e / NP % NB, p = e % NP;
+			src = (transposed ? wt_hid : W_hid) + (size_t)j * WIDTH * WIDTH + (size_t)perm32(b, lr) * WIDTH + 32 * p + 8 * g;
+		} else if (f < F_WINB) {
+			src = W_out + (size_t)lr * WIDTH + 32 * (f - F_WOUTA) + 8 * g;
+		} else {
+			const uint32_t b = (f - F_WINB) / NP, p = (f - F_WINB) % NP;
+			src = wt_in + (size_t)(16 * b + lr) * WIDTH + 32 * p + 8 * g;
+		}
+		wfrag[f][lane] = *(const h8*)src;
+	}
+	for (uint32_t b = w; b < NB; b += NWAVES) wfrag_out_t[b][lane] = *(const h4*)(wt_out + (size_t)perm32(b, lr) * 16 + 4 * g);
+	// the two sample selections (16x16x32 B operand: column lr picks sample perm32(s, lr)), kept with the weights
+	__shared__ h8 sel_frag[2][64];
+	if (w < 2) {
+		h8 v;
+#pragma unroll
+		for (uint32_t j = 0; j < 8; ++j) v[j] = (half_t)(8 * g + j == perm32(w, lr) ? 1.0f : 0.0f);
+		sel_frag[w][lane] = v;
+	}
+	__syncthreads();
+	auto winA = [&](uint32_t b, uint32_t p) { return wfrag[F_WINA + b * FP + p][lane]; };
+	auto whidA = [&](uint32_t j, uint32_t b, uint32_t p) { return wfrag[F_WHIDA + (j * NB + b) * NP + p][lane]; };
+	auto whidT = [&](uint32_t j, uint32_t b, uint32_t p) { return wfrag[F_WHIDT + (j * NB + b) * NP + p][lane]; };
+	auto woutA = [&](uint32_t p) { return wfrag[F_WOUTA + p][lane]; };
+	auto winB = [&](uint32_t b, uint32_t p) { return wfrag[F_WINB + b * NP + p][lane]; };
+	auto woutT = [&](uint32_t b) { return wfrag_out_t[b][lane]; };
+	h4 eye;  // identity (16x16x16 B operand)
+#pragma unroll
+	for (uint32_t j = 0; j < 4; ++j) eye[j] = (half_t)(4 * g + j == lr ? 1.0f : 0.0f);
+
+	f4 accI[NB][FB], accH[HMX][NB][NB], accO[NB];
+#pragma unroll
+	for (uint32_t b = 0; b < NB; ++b) {
+		accO[b] = zero4();
+#pragma unroll
+		for (uint32_t f = 0; f < FB; ++f) accI[b][f] = zero4();
+#pragma unroll
+		for (uint32_t j = 0; j < HMX; ++j)
+#pragma unroll
+			for (uint32_t i = 0; i < NB; ++i) accH[j][b][i] = zero4();
+	}
+	float loss_sum = 0.0f;
+
+	// transposes NB tiles (rows 4g+r of block b, sample perm32(s, lr)) of both sample blocks into "samples in k" operands
+	auto transpose = [&](const h4 (&p)[2][NB], h8 (&q)[NB]) {
+#pragma unroll
+		for (uint32_t b = 0; b < NB; ++b) q[b] = pack8(to_h4(mfma_16x16x16(p[0][b], eye, zero4())), to_h4(mfma_16x16x16(p[1][b], eye, zero4())));
+	};
+
+	const uint32_t n_strips = n / MLP_WAVE_STRIP, stride = gridDim.x * NWAVES;
+	uint32_t strip = blockIdx.x * NWAVES + w;
+	h8 xq_next[FB];
+#pragma unroll
+	for (uint32_t f = 0; f < FB; ++f)
+		if (strip < n_strips) xq_next[f] = *(const h8*)(input + (perm32(f, lr) * n + strip * MLP_WAVE_STRIP + 8 * g));
+
+	for (; strip < n_strips; strip += stride) {
+		asm volatile("" ::: "memory");  // the weight fragments are re-read from LDS where they are used, not hoisted into registers for the whole loop
+		const uint32_t base = strip * MLP_WAVE_STRIP;  // element offsets fit 32 bits (the host checks n): scalar base + 32-bit lane offset addressing
+		h8 xq[FB];  // lane lr <-> feature perm32(f, lr), k = sample 8g+j
+#pragma unroll
+		for (uint32_t f = 0; f < FB; ++f) xq[f] = xq_next[f];
+		if (strip + stride < n_strips) {
+#pragma unroll
+			for (uint32_t f = 0; f < FB; ++f) xq_next[f] = *(const h8*)(input + (perm32(f, lr) * n + (strip + stride) * MLP_WAVE_STRIP + 8 * g));
+		}
+		// this lane's targets: output 4g+r of sample perm32(s, lr)
+		float tgt[2][4];
+#pragma unroll
+		for (uint32_t s = 0; s < 2; ++s) {
+#pragma unroll
+			for (uint32_t r = 0; r < 4; ++r) {
+				const uint32_t dim = 4 * g + r;
+				const bool live = dim < la.dims;
+				const uint32_t target_idx = (base + perm32(s, lr)) * la.dims + dim;
+				tgt[s][r] = live ? la.targets[target_idx] : 0.0f;
+			}
+		}
+
+		// ================= forward =================
+		h4 hp[HM + 1][2][NB];  // layer, sample block, neuron block: (neuron perm32(b, 4g+r), sample perm32(s, lr))
+		{
+			h8 xb[2][FP];  // first layer's B operand: k = feature 32p + 8g + j, n = sample perm32(s, lr)
+#pragma unroll
+			for (uint32_t s = 0; s < 2; ++s) {
+				const h8 sel = sel_frag[s][lane];
+#pragma unroll
+				for (uint32_t p = 0; p < FP; ++p)
+					xb[s][p] = pack8(to_h4(mfma_16x16x32(xq[2 * p], sel, zero4())), to_h4(mfma_16x16x32(xq[2 * p + 1], sel, zero4())));
+			}
+			sched_fence();
+#pragma unroll
+			for (uint32_t s = 0; s < 2; ++s)
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b) {
+					f4 acc = zero4();
+#pragma unroll
+					for (uint32_t p = 0; p < FP; ++p) acc = mfma_16x16x32(winA(b, p), xb[s][p], acc);
+					hp[0][s][b] = act_forward4<GENERAL>(act, pa, acc);
+				}
+			sched_fence();
+		}
+#pragma unroll
+		for (uint32_t j = 0; j < HM; ++j) {
+#pragma unroll
+			for (uint32_t s = 0; s < 2; ++s)
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b) {
+					f4 acc = zero4();
+#pragma unroll
+					for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(whidA(j, b, p), pack8(hp[j][s][2 * p], hp[j][s][2 * p + 1]), acc);
+					hp[j + 1][s][b] = act_forward4<GENERAL>(act, pa, acc);
+				}
+			sched_fence();
+		}
+		// ---- output layer + loss: (output 4g+r, sample perm32(s, lr))
+		h4 dyp[2];
+#pragma unroll
+		for (uint32_t s = 0; s < 2; ++s) {
+			f4 acc = zero4();
+#pragma unroll
+			for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(woutA(p), pack8(hp[HM][s][2 * p], hp[HM][s][2 * p + 1]), acc);
+			const h4 o = h4{(half_t)act_forward<GENERAL>(out_act, acc[0]), (half_t)act_forward<GENERAL>(out_act, acc[1]), (half_t)act_forward<GENERAL>(out_act, acc[2]),
+			                (half_t)act_forward<GENERAL>(out_act, acc[3])};
+			const uint32_t i = base + perm32(s, lr);
+			h4 gy;
+#pragma unroll
+			for (uint32_t r = 0; r < 4; ++r) {
+				const uint32_t dim = 4 * g + r;
+				gy[r] = (half_t)0.0f;
+				if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
+					const float pdf = has_pdf ? la.data_pdf[i * la.dims + dim] : 1.0f;  // rare: fetched where it is used
+					float value;
+					if constexpr (GENERAL) gy[r] = loss_element<true>(la.type, (float)o[r], tgt[s][r], pdf, n_total, la.loss_scale, value);
+					else gy[r] = loss_gradient_simple(relative, has_pdf, (float)o[r], tgt[s][r], pdf, n_total, la.loss_scale, value);
+					loss_sum += value;
+				}
+			}
+			if (output) *(h4*)(output + i * 16 + 4 * g) = o;
+			if (dL_doutput) *(h4*)(dL_doutput + i * 16 + 4 * g) = gy;
+#pragma unroll
+			for (uint32_t r = 0; r < 4; ++r) dyp[s][r] = (half_t)act_backward<GENERAL>(out_act, (float)gy[r], o[r]);  // fully_fused_mlp.cu:760-763
+			sched_fence();
+		}
+
+		sched_fence();
+		// ================= backward =================
+		{  // dW_out[output][neuron] += dY * H_last^T  (accumulated unconditionally: a branch around the MFMAs costs the in-place accumulators)
+			const h8 dyq = pack8(to_h4(mfma_16x16x16(dyp[0], eye, zero4())), to_h4(mfma_16x16x16(dyp[1], eye, zero4())));
+			h8 hq[NB];  // the layer's activations with the samples in k: lane lr <-> neuron perm32(b, lr), k = sample 8g+j
+			transpose(hp[HM], hq);
+#pragma unroll
+			for (uint32_t b = 0; b < NB; ++b) accO[b] = mfma_16x16x32(dyq, hq[b], accO[b]);
+		}
+		h4 dap[2][NB];  // dL/d(pre-activation) of the current layer, same tile layout as hp
+#pragma unroll
+		for (uint32_t s = 0; s < 2; ++s)
+#pragma unroll
+			for (uint32_t b = 0; b < NB; ++b) {
+				dap[s][b] = act_backward4<GENERAL>(act, pa, mfma_16x16x16(woutT(b), dyp[s], zero4()), hp[HM][s][b]);
+			}
+		sched_fence();
+#pragma unroll
+		for (int j = (int)HM - 1; j >= 0; --j) {
+			{  // dW_hid_j[out][in] += dA_{j+1} * H_j^T
+				h8 daq[NB], hq[NB];
+				transpose(dap, daq);
+				transpose(hp[j], hq);
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+					for (uint32_t i = 0; i < NB; ++i) accH[j][b][i] = mfma_16x16x32(daq[b], hq[i], accH[j][b][i]);
+			}
+			sched_fence();
+			h4 prev[2][NB];
+#pragma unroll
+			for (uint32_t s = 0; s < 2; ++s)
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b) {
+					f4 acc = zero4();
+#pragma unroll
+					for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(whidT(j, b, p), pack8(dap[s][2 * p], dap[s][2 * p + 1]), acc);
+					prev[s][b] = act_backward4<GENERAL>(act, pa, acc, hp[j][s][b]);
+				}
+#pragma unroll
+			for (uint32_t s = 0; s < 2; ++s)
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b) dap[s][b] = prev[s][b];
+			sched_fence();
+		}
+		{  // dW_in[out][feature] += dA_0 * X^T
+			h8 daq[NB];
+			transpose(dap, daq);
+#pragma unroll
+			for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+				for (uint32_t f = 0; f < FB; ++f) accI[b][f] = mfma_16x16x32(daq[b], xq[f], accI[b][f]);
+		}
+		sched_fence();
+		if (want_dx) {  // dX^T = dA_0^T * W_in: (sample perm32(s, 4g+r) = 8g + 4s + r, feature 16f + lr) -> eight consecutive samples per lane
+#pragma unroll
+			for (uint32_t f = 0; f < FB; ++f) {
+				h4 d[2];
+#pragma unroll
+				for (uint32_t s = 0; s < 2; ++s) {
+					f4 acc = zero4();
+#pragma unroll
+					for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(pack8(dap[s][2 * p], dap[s][2 * p + 1]), winB(f, p), acc);
+					d[s] = to_h4(acc);
+				}
+				*(h8*)(dL_dinput + ((16 * f + lr) * n + base + 8 * g)) = pack8(d[0], d[1]);
+			}
+		}
+	}
+
+	// ---- this workgroup's share of the loss
+	if (block_sums) {
+		if constexpr (!GENERAL) loss_sum = loss_sum * 0.5f / n_total;  // see loss_gradient_simple
+		red[tid] = loss_sum;
+		__syncthreads();
+		for (uint32_t k = MLP_WAVE_THREADS / 2; k > 0; k >>= 1) {
+			if (tid < k) red[tid] += red[tid + k];
+			__syncthreads();
+		}
+		if (tid == 0) block_sums[blockIdx.x] = red[0];
+	}
+
+	// ---- fp32 partial weight gradients: the four waves' accumulators meet in LDS, one slab per workgroup in parameter layout
+	if (want_grads) {
+		constexpr uint32_t off_hid = WIDTH * IN, off_out = off_hid + HM * WIDTH * WIDTH;
+		for (uint32_t turn = 0; turn < NWAVES; ++turn) {
+			if (w == turn) {
+				auto put = [&](uint32_t idx, float v) { slab[idx] = turn == 0 ? v : slab[idx] + v; };
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+					for (uint32_t r = 0; r < 4; ++r) {
+#pragma unroll
+						for (uint32_t f = 0; f < FB; ++f) put(perm32(b, 4 * g + r) * IN + perm32(f, lr), accI[b][f][r]);
+#pragma unroll
+						for (uint32_t j = 0; j < HM; ++j)
+#pragma unroll
+							for (uint32_t i = 0; i < NB; ++i) put(off_hid + j * WIDTH * WIDTH + perm32(b, 4 * g + r) * WIDTH + perm32(i, lr), accH[j][b][i][r]);
+						put(off_out + (4 * g + r) * WIDTH + perm32(b, lr), accO[b][r]);
+					}
+			}
+			__syncthreads();
+		}
+		float* P = partials + (size_t)blockIdx.x * N_PARAMS;
+		for (uint32_t i = tid; i < N_PARAMS; i += MLP_WAVE_THREADS) P[i] = slab[i];
+	}
+}
+
+// ---- the register-resident wave-per-strip variant: instantiated for the shapes whose operands fit one wave's registers
+static bool mlp_train_wave_enabled() {
+	static const bool enabled = [] {
+		const char* e = getenv("TCNN_MLP_TRAIN_WAVE");
+		return !(e && e[0] == '0');
+	}();
+	return enabled;
+}
+
+bool mlp_train_wave_supported(const MlpMeta& m, uint32_t n, LossType loss) {
+	if (!mlp_train_wave_enabled() || m.padded_out != 16 || m.in_width != 32) return false;
+	// ReLU / None and (Relative)L2 only: the instances with out-of-line activation / loss calls gain nothing here
+	if (!act_is_simple(m.activation) || !act_is_simple(m.output_activation) || !loss_is_simple(loss)) return false;
+	if (n > (1u << 26)) return false;  // 32-bit element offsets inside the kernel
+	return (m.width == 64 && m.n_hidden_matmuls <= 1) || (m.width == 32 && m.n_hidden_matmuls <= 2);
+}
+
+uint32_t mlp_train_wave_n_partials(uint32_t n) {
+	const uint32_t wanted = div_round_up(n / MLP_WAVE_STRIP, MLP_WAVE_THREADS / 64u);
+	return wanted < TCNN_MLP_WAVE_BLOCKS ? wanted : TCNN_MLP_WAVE_BLOCKS;
+}
+
+template <uint32_t WIDTH, uint32_t IN, uint32_t HM>
+static void launch_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
+                              const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
+	const uint32_t blocks = mlp_train_wave_n_partials(n);
+	TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la, output,
+	            dL_doutput, dL_dinput, partials, block_sums);
+}
+
+void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
+                    const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
+	if (!mlp_train_wave_supported(m, n, la.type)) throw std::runtime_error("mlp_train_wave: unsupported shape, activation or loss (check mlp_train_wave_supported first)");
+	const uint32_t key = m.width * 10u + m.n_hidden_matmuls;
+	switch (key) {
+		case 640: launch_train_wave<64, 32, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
+		case 641: launch_train_wave<64, 32, 1>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
+		case 320: launch_train_wave<32, 32, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
+		case 321: launch_train_wave<32, 32, 1>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
+		case 322: launch_train_wave<32, 32, 2>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
+		default: throw std::runtime_error("mlp_train: no register-resident instance for this shape");
+	}
+}
+
+}  // namespace tcnn_hip

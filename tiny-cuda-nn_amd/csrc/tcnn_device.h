@@ -72,6 +72,10 @@ TCNN_DEVICE half_t fma_h(half_t a, half_t b, half_t c) { return __builtin_fmaf16
 TCNN_DEVICE uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)); }  // HW_REG_XCC_ID
 #endif
 
+TCNN_DEVICE h8 pack8(h4 a, h4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+TCNN_DEVICE h4 pack4(h2 a, h2 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3); }
+TCNN_DEVICE f4 zero4() { return f4{0.0f, 0.0f, 0.0f, 0.0f}; }
+
 TCNN_DEVICE uint32_t lane_id() { return threadIdx.x & 63u; }
 
 // Orders the LDS accesses of ONE wavefront (all 64 lanes must call it): what a block barrier does for a workgroup,
@@ -85,6 +89,14 @@ TCNN_DEVICE void wave_lds_sync() {
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+#endif
+
+// Scheduling fence: the compiler may not move instructions across it.  Bounds the live ranges of a long unrolled body
+// (the scheduler otherwise hoists every LDS/global read to the top of the block and runs out of registers).
+#if defined(TCNN_HOST_EMU)
+TCNN_DEVICE void sched_fence() {}
+#else
+TCNN_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 #endif
 
 // fp32 -> fp16 with exactly ONE extra rounding (RNE) of an already rounded fp32 value.

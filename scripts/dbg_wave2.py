@@ -23,4 +23,4 @@ for first in sys.argv[1:]:
         gp = b.param_gradients.clone(); lp = b.loss(c2)
         nm = b.n_mlp_params
         print(first, rep, "mlp mismatch", float((gf[:nm] != gp[:nm]).float().mean()), "max diff", float((gf[:nm].float() - gp[:nm].float()).abs().max()),
-              "grid equal", bool(torch.equal(gf[nm:], gp[nm:])), "loss", lf, lp)
+              "grid mismatch", float((gf[nm:] != gp[nm:]).float().mean()), "max", float((gf[nm:].float() - gp[nm:].float()).abs().max()), "of", float(gp[nm:].float().abs().max()), "loss", lf, lp)

@@ -588,10 +588,12 @@ def test_network_activations(act, out_act):
     g_fused, loss_fused = tm.param_gradients.clone(), tm.loss(ctx_f)
     c2 = tm.forward(xx, tt)
     tm.backward(c2, xx)
-    # ... bit for bit in the encoding (dL/dinput is identical); the network's fp32 weight-gradient partial sums are grouped
-    # per wavefront in the register-resident kernel and per workgroup in the stand-alone one: last-bit differences
+    # ... up to the association order of fp32 sums: the register-resident kernel holds output 4r+g (not 4g+r) in k slot
+    # (g, r) of the output layer's backward MFMA and groups the weight-gradient partial sums per wavefront, not per workgroup
     g_pair, nm = tm.param_gradients, tm.n_mlp_params
-    assert torch.equal(g_pair[nm:], g_fused[nm:])
+    grid_pair, grid_fused = g_pair[nm:].float(), g_fused[nm:].float()
+    assert (grid_pair != grid_fused).float().mean() < 0.02
+    assert torch.allclose(grid_pair, grid_fused, rtol=4e-3, atol=2e-3 * float(grid_fused.abs().max()))
     assert (g_pair[:nm] != g_fused[:nm]).float().mean() < 0.05
     assert torch.allclose(g_pair[:nm].float(), g_fused[:nm].float(), rtol=2e-3, atol=1e-3 * float(g_fused[:nm].float().abs().max()) * 2.0 ** -10 + 1e-7)
     assert abs(tm.loss(c2) - loss_fused) <= 1e-5 * abs(loss_fused) + 1e-9

@@ -32,6 +32,11 @@ namespace tcnn_hip {
 // gradient partial sums are grouped differently.
 // =============================================================================================
 TCNN_DEVICE uint32_t perm32(uint32_t b, uint32_t row) { return 32u * (b >> 1) + 8u * (row >> 2) + 4u * (b & 1u) + (row & 3u); }
+// Output rows: accumulator row 4g+r of the output layer holds output 4r+g (a 4x4 transpose of the 16 padded outputs, done
+// by the weight row each lane of the A operand holds).  The live outputs (< dims, usually 3 or 4) then sit in element
+// r = 0 of ALL four lane groups instead of in four elements of one group: the loss is evaluated once per lane, not
+// four times on a quarter of the lanes.
+TCNN_DEVICE uint32_t out_perm(uint32_t row) { return 4u * (row & 3u) + (row >> 2); }
 TCNN_DEVICE h4 to_h4(f4 v) { return h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}; }
 
 // ReLU / None on packed halves (the GENERAL == false instances).  Same values as activation_device.h's scalar forms:
@@ -77,13 +82,15 @@ TCNN_DEVICE h4 act_backward4(uint32_t act, const PackedAct& pa, f4 v, h4 forward
 // (Relative)L2 gradient with the divisions that cannot change a bit left out: x / pdf when there is no pdf (x / 1), and the
 // per-element loss VALUE, of which only the sum is ever used: the caller sums difference * gradient (= 2 n_total value up to
 // one rounding) and scales once.  The gradient itself is evaluated exactly as loss_element() does.
-TCNN_DEVICE half_t loss_gradient_simple(bool relative, bool has_pdf, float prediction, float target, float pdf, float n_total, float loss_scale,
-                                        float& difference_times_gradient) {
+// x / n_total is x * (1 / n_total) bit for bit when n_total is a power of two (the usual batch x outputs): no division then.
+TCNN_DEVICE half_t loss_gradient_simple(bool relative, bool has_pdf, float prediction, float target, float pdf, float n_total, float inv_n_total_if_exact,
+                                        float loss_scale, float& difference_times_gradient) {
 	const float difference = prediction - target;
 	float gradient = 2 * difference;
 	if (relative) gradient = gradient / (prediction * prediction + 0.01f);
 	if (has_pdf) gradient = gradient / pdf;
 	difference_times_gradient = difference * gradient;
+	if (inv_n_total_if_exact != 0.0f) return to_half_rn(loss_scale * gradient * inv_n_total_if_exact);
 	return to_half_rn(loss_scale * gradient / n_total);
 }
 
@@ -103,7 +110,8 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
                                                                         float* __restrict__ block_sums) {
 	constexpr uint32_t NB = WIDTH / 16, NP = WIDTH / 32, FB = IN / 16, FP = IN / 32, NWAVES = MLP_WAVE_THREADS / 64, HMX = HM > 0 ? HM : 1;
 	constexpr uint32_t N_PARAMS = WIDTH * IN + HM * WIDTH * WIDTH + 16 * WIDTH;
-	__shared__ float slab[N_PARAMS];
+	constexpr uint32_t N_TILES = NB * FB + HM * NB * NB + NB;  // accumulator tiles per wave
+	__shared__ f4 exchange[N_TILES * 64];
 	__shared__ float red[MLP_WAVE_THREADS];
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
 	const uint32_t act = m.activation, out_act = m.output_activation;
@@ -111,6 +119,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
 	const float n_total = (float)la.n_total;
 	const PackedAct pa = packed_act(act);
 	const bool relative = la.type == LossType::RelativeL2, has_pdf = la.data_pdf != nullptr;
+	const float inv_n_total = (la.n_total & (la.n_total - 1u)) == 0u && la.n_total != 0u ? 1.0f / n_total : 0.0f;  // exact reciprocal or "divide"
 
 	// ---- weights, both orientations, as MFMA operands (lane lr <-> the row/column perm32 assigns to it), staged once per
 	// workgroup in LDS in lane order: a fragment is one conflict-free 16-byte read per lane wherever it is used
@@ -122,7 +131,8 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
 	const half_t* wt_out = wt_hid + (size_t)HM * WIDTH * WIDTH; // [WIDTH][16]
 	constexpr uint32_t F_WINA = 0, F_WHIDA = F_WINA + NB * FP, F_WHIDT = F_WHIDA + HM * NB * NP, F_WOUTA = F_WHIDT + HM * NB * NP,
 	                   F_WINB = F_WOUTA + NP, N_FRAG = F_WINB + FB * NP;
-	__shared__ h8 wfrag[N_FRAG][64];
+	constexpr uint32_t N_FRAG_LDS = N_FRAG > N_TILES ? N_FRAG : N_TILES;  // the region doubles as the second exchange buffer at the end
+	__shared__ h8 wfrag[N_FRAG_LDS][64];
 	__shared__ h4 wfrag_out_t[NB][64];
 	for (uint32_t f = w; f < N_FRAG; f += NWAVES) {
 		const half_t* src;
@@ -134,14 +144,17 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
 			const uint32_t e = f - (transposed ? F_WHIDT : F_WHIDA), j = e / (NB * NP), b = e / NP % NB, p = e % NP;
 			src = (transposed ? wt_hid : W_hid) + (size_t)j * WIDTH * WIDTH + (size_t)perm32(b, lr) * WIDTH + 32 * p + 8 * g;
 		} else if (f < F_WINB) {
-			src = W_out + (size_t)lr * WIDTH + 32 * (f - F_WOUTA) + 8 * g;
+			src = W_out + (size_t)out_perm(lr) * WIDTH + 32 * (f - F_WOUTA) + 8 * g;
 		} else {
 			const uint32_t b = (f - F_WINB) / NP, p = (f - F_WINB) % NP;
 			src = wt_in + (size_t)(16 * b + lr) * WIDTH + 32 * p + 8 * g;
 		}
 		wfrag[f][lane] = *(const h8*)src;
 	}
-	for (uint32_t b = w; b < NB; b += NWAVES) wfrag_out_t[b][lane] = *(const h4*)(wt_out + (size_t)perm32(b, lr) * 16 + 4 * g);
+	for (uint32_t b = w; b < NB; b += NWAVES) {  // k slot 4g+i of the output-layer backward <-> output 4i+g
+		const half_t* row = wt_out + (size_t)perm32(b, lr) * 16;
+		wfrag_out_t[b][lane] = h4{row[g], row[4 + g], row[8 + g], row[12 + g]};
+	}
 	// the two sample selections (16x16x32 B operand: column lr picks sample perm32(s, lr)), kept with the weights
 	__shared__ h8 sel_frag[2][64];
 	if (w < 2) {
@@ -197,13 +210,13 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
 #pragma unroll
 			for (uint32_t f = 0; f < FB; ++f) xq_next[f] = *(const h8*)(input + (perm32(f, lr) * n + (strip + stride) * MLP_WAVE_STRIP + 8 * g));
 		}
-		// this lane's targets: output 4g+r of sample perm32(s, lr)
+		// this lane's targets: output 4r+g of sample perm32(s, lr)
 		float tgt[2][4];
 #pragma unroll
 		for (uint32_t s = 0; s < 2; ++s) {
 #pragma unroll
 			for (uint32_t r = 0; r < 4; ++r) {
-				const uint32_t dim = 4 * g + r;
+				const uint32_t dim = 4 * r + g;
 				const bool live = dim < la.dims;
 				const uint32_t target_idx = (base + perm32(s, lr)) * la.dims + dim;
 				tgt[s][r] = live ? la.targets[target_idx] : 0.0f;
@@ -246,7 +259,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
 				}
 			sched_fence();
 		}
-		// ---- output layer + loss: (output 4g+r, sample perm32(s, lr))
+		// ---- output layer + loss: (output 4r+g, sample perm32(s, lr))
 		h4 dyp[2];
 #pragma unroll
 		for (uint32_t s = 0; s < 2; ++s) {
@@ -259,18 +272,21 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
 			h4 gy;
 #pragma unroll
 			for (uint32_t r = 0; r < 4; ++r) {
-				const uint32_t dim = 4 * g + r;
+				const uint32_t dim = 4 * r + g;
 				gy[r] = (half_t)0.0f;
 				if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
 					const float pdf = has_pdf ? la.data_pdf[i * la.dims + dim] : 1.0f;  // rare: fetched where it is used
 					float value;
 					if constexpr (GENERAL) gy[r] = loss_element<true>(la.type, (float)o[r], tgt[s][r], pdf, n_total, la.loss_scale, value);
-					else gy[r] = loss_gradient_simple(relative, has_pdf, (float)o[r], tgt[s][r], pdf, n_total, la.loss_scale, value);
+					else gy[r] = loss_gradient_simple(relative, has_pdf, (float)o[r], tgt[s][r], pdf, n_total, inv_n_total, la.loss_scale, value);
 					loss_sum += value;
 				}
 			}
-			if (output) *(h4*)(output + i * 16 + 4 * g) = o;
-			if (dL_doutput) *(h4*)(dL_doutput + i * 16 + 4 * g) = gy;
+#pragma unroll
+			for (uint32_t r = 0; r < 4; ++r) {  // the four lane groups together write 8 contiguous bytes per sample and r
+				if (output) output[i * 16 + 4 * r + g] = o[r];
+				if (dL_doutput) dL_doutput[i * 16 + 4 * r + g] = gy[r];
+			}
 #pragma unroll
 			for (uint32_t r = 0; r < 4; ++r) dyp[s][r] = (half_t)act_backward<GENERAL>(out_act, (float)gy[r], o[r]);  // fully_fused_mlp.cu:760-763
 			sched_fence();
@@ -358,29 +374,55 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
 		if (tid == 0) block_sums[blockIdx.x] = red[0];
 	}
 
-	// ---- fp32 partial weight gradients: the four waves' accumulators meet in LDS, one slab per workgroup in parameter layout
+	// ---- fp32 partial weight gradients: (wave 0 + wave 2) + (wave 1 + wave 3), exchanged through LDS in register order
+	// (tile t of lane l at [t][l]: conflict-free 16-byte accesses; all waves share the lane <-> element map), then written
+	// by wave 0 as this workgroup's slab in parameter layout
 	if (want_grads) {
-		constexpr uint32_t off_hid = WIDTH * IN, off_out = off_hid + HM * WIDTH * WIDTH;
-		for (uint32_t turn = 0; turn < NWAVES; ++turn) {
-			if (w == turn) {
-				auto put = [&](uint32_t idx, float v) { slab[idx] = turn == 0 ? v : slab[idx] + v; };
+		auto for_each_tile = [&](auto&& fn) {
+			uint32_t t = 0;
 #pragma unroll
-				for (uint32_t b = 0; b < NB; ++b)
+			for (uint32_t b = 0; b < NB; ++b) {
 #pragma unroll
-					for (uint32_t r = 0; r < 4; ++r) {
+				for (uint32_t f = 0; f < FB; ++f) fn(t++, accI[b][f]);
 #pragma unroll
-						for (uint32_t f = 0; f < FB; ++f) put(perm32(b, 4 * g + r) * IN + perm32(f, lr), accI[b][f][r]);
+				for (uint32_t j = 0; j < HM; ++j)
 #pragma unroll
-						for (uint32_t j = 0; j < HM; ++j)
-#pragma unroll
-							for (uint32_t i = 0; i < NB; ++i) put(off_hid + j * WIDTH * WIDTH + perm32(b, 4 * g + r) * WIDTH + perm32(i, lr), accH[j][b][i][r]);
-						put(off_out + (4 * g + r) * WIDTH + perm32(b, lr), accO[b][r]);
-					}
+					for (uint32_t i = 0; i < NB; ++i) fn(t++, accH[j][b][i]);
+				fn(t++, accO[b]);
 			}
-			__syncthreads();
+		};
+		f4* ex0 = (f4*)exchange;
+		f4* ex1 = (f4*)wfrag;  // the weights are not needed any more
+		__syncthreads();
+		if (w >= 2) {
+			f4* ex = w == 2 ? ex0 : ex1;
+			for_each_tile([&](uint32_t t, f4& a) { ex[t * 64 + lane] = a; });
 		}
-		float* P = partials + (size_t)blockIdx.x * N_PARAMS;
-		for (uint32_t i = tid; i < N_PARAMS; i += MLP_WAVE_THREADS) P[i] = slab[i];
+		__syncthreads();
+		if (w < 2) {
+			const f4* ex = w == 0 ? ex0 : ex1;
+			for_each_tile([&](uint32_t t, f4& a) { a += ex[t * 64 + lane]; });
+		}
+		__syncthreads();
+		if (w == 1) for_each_tile([&](uint32_t t, f4& a) { ex0[t * 64 + lane] = a; });
+		__syncthreads();
+		if (w == 0) {
+			for_each_tile([&](uint32_t t, f4& a) { a += ex0[t * 64 + lane]; });
+			constexpr uint32_t off_hid = WIDTH * IN, off_out = off_hid + HM * WIDTH * WIDTH;
+			float* P = partials + (size_t)blockIdx.x * N_PARAMS;
+#pragma unroll
+			for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) {
+#pragma unroll
+					for (uint32_t f = 0; f < FB; ++f) P[perm32(b, 4 * g + r) * IN + perm32(f, lr)] = accI[b][f][r];
+#pragma unroll
+					for (uint32_t j = 0; j < HM; ++j)
+#pragma unroll
+						for (uint32_t i = 0; i < NB; ++i) P[off_hid + j * WIDTH * WIDTH + perm32(b, 4 * g + r) * WIDTH + perm32(i, lr)] = accH[j][b][i][r];
+					P[off_out + (4 * r + g) * WIDTH + perm32(b, lr)] = accO[b][r];  // accumulator row 4g+r <-> output 4r+g
+				}
+		}
 	}
 }
 

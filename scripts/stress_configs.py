@@ -10,6 +10,7 @@ def hash_enc(T=19, L=16): return {"otype": "HashGrid", "n_levels": L, "n_feature
 def mlp(w=64, h=2): return {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": w, "n_hidden_layers": h}
 CASES = [
     ("cfg[1] MLP 64x2 only (Identity encoding), N=2^18", 16, 4, {"otype": "Identity"}, mlp(), 1 << 18),
+    ("cfg[1] MLP 64x2 only, 64 inputs (benchmarks/mlp shape), N=2^18", 64, 16, {"otype": "Identity"}, mlp(), 1 << 18),
     ("cfg[2] headline, N=2^18", 3, 4, hash_enc(), mlp(), 1 << 18),
     ("cfg[2] headline, N=2^21", 3, 4, hash_enc(), mlp(), 1 << 21),
     ("cfg[2] headline, N=256", 3, 4, hash_enc(), mlp(), 256),
@@ -29,7 +30,11 @@ for name, d_in, d_out, enc, net, n in CASES:
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 30 * 1e3
     l1 = tm.loss(tm.training_step(x, t))
     y = tm.inference(x)
+    for _ in range(10): tm.inference(x)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(30): tm.inference(x)
+    torch.cuda.synchronize(); ms_inf = (time.perf_counter() - t0) / 30 * 1e3
     ok = np.isfinite(l1) and l1 < l0 and bool(torch.isfinite(y).all())
-    print(f"{name:70s} params {tm.n_params:>10d}  {ms:8.4f} ms/step  {n / ms / 1e3:9.1f} M samples/s  loss {l0:.4g} -> {l1:.4g}  {'OK' if ok else 'FAILED'}", flush=True)
+    print(f"{name:70s} params {tm.n_params:>10d}  {ms:8.4f} ms/step  {n / ms / 1e3:9.1f} M samples/s  inference {ms_inf:7.4f} ms {n / ms_inf / 1e3:9.1f} M/s  loss {l0:.4g} -> {l1:.4g}  {'OK' if ok else 'FAILED'}", flush=True)
     del tm
     tcnn.free_temporary_memory()

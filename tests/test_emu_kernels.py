@@ -226,6 +226,22 @@ def test_mlp_activations(act, out_act):
 WAVE_CASES = [(32, 64, 3, 1), (32, 32, 2, 1), (32, 32, 4, 2), (32, 32, 16, 3)]
 
 
+@pytest.mark.parametrize("case", WAVE_CASES + [(32, 64, 4, 2), (32, 64, 5, 3), (32, 32, 7, 4), (64, 64, 16, 2), (64, 64, 1, 3)])
+@pytest.mark.parametrize("act", [O.ACT_RELU, O.ACT_NONE])
+def test_mlp_register_resident_inference_equals_forward(case, act):
+    """k_mlp_infer_wave (inference: no saved activations) gives the bits of k_mlp_forward: the reference's
+    inference == forward invariant (tests/test_networks.cu:38-79) holds exactly."""
+    IN, W, OUT, H = case
+    rng = np.random.default_rng(11)
+    om = O.mlp_init(IN, W, OUT, H, activation=act, output_activation=O.ACT_RELU if act == O.ACT_NONE else O.ACT_NONE)
+    ph = O.f2h(O.mlp_init_params(om, O.pcg32(17)))
+    n = 768
+    xs = np.ascontiguousarray(O.f2h(rng.random((n, IN), dtype=np.float32) - 0.25).T)
+    _, out = emu.mlp_forward(om, ph, xs)
+    _, out_inf = emu.mlp_forward(om, ph, xs, save_hidden=False)
+    assert np.array_equal(out, out_inf)
+
+
 @pytest.mark.parametrize("case", MLP_CASES + WAVE_CASES)
 @pytest.mark.parametrize("loss_type", [O.LOSS_L2, O.LOSS_RELATIVE_L2])
 def test_mlp_fused_training_pass_equals_the_unfused_kernels(case, loss_type):

@@ -106,6 +106,11 @@ uint32_t mlp_train_wave_n_partials(uint32_t n);
 void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
                     const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums);
 
+// Inference (no saved activations) of the same shapes, also with 64 inputs, with up to 3 (64 neurons) / 4 (32 neurons) hidden layers: the forward
+// half of the register-resident kernel.  mlp_forward() picks it when `hidden` is null.
+bool mlp_infer_wave_supported(const MlpMeta& m, uint32_t n);
+void mlp_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output);
+
 // number of fp32 slabs / loss partial sums mlp_train() writes for this shape and batch (<= mlp_backward_n_partials)
 uint32_t mlp_train_n_partials(const MlpMeta& m, uint32_t n, LossType loss);
 void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,

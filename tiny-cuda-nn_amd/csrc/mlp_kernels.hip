@@ -1019,6 +1019,10 @@ static void launch_forward(hipStream_t stream, const MlpMeta& m, uint32_t n, con
 void mlp_forward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* hidden, half_t* output) {
 	check_meta(m, n);
 	if (n == 0) return;
+	if (!hidden && mlp_infer_wave_supported(m, n)) {
+		mlp_infer_wave(stream, m, n, params, input, output);
+		return;
+	}
 	switch (m.width) {
 		case 16: launch_forward<16>(stream, m, n, params, input, hidden, output); break;
 		case 32: launch_forward<32>(stream, m, n, params, input, hidden, output); break;

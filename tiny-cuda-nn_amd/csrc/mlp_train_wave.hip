@@ -426,6 +426,99 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
 	}
 }
 
+// =============================================================================================
+// inference (Network::inference_mixed_precision_impl, fully_fused_mlp.cu:680-708): the forward half of the kernel above.
+// A wave chains the layers of its 32 samples in registers; the only memory traffic is the encoded input in and the
+// padded output out.  Natural output rows (accumulator row 4g+r = output 4g+r): 8-byte stores.
+// =============================================================================================
+#ifndef TCNN_MLP_INFER_BLOCKS
+#define TCNN_MLP_INFER_BLOCKS 1024  // four workgroups per CU; the instance needs < 128 registers and 8-12 KiB of LDS
+#endif
+template <uint32_t WIDTH, uint32_t IN, uint32_t HM>
+__global__ void __launch_bounds__(MLP_WAVE_THREADS) k_mlp_infer_wave(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
+                                                                     const half_t* __restrict__ input, half_t* __restrict__ output) {
+	constexpr uint32_t NB = WIDTH / 16, NP = WIDTH / 32, FB = IN / 16, FP = IN / 32, NWAVES = MLP_WAVE_THREADS / 64;
+	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
+	const uint32_t out_act = m.output_activation;
+	const PackedAct pa = packed_act(m.activation);
+	const half_t* W_in = params;
+	const half_t* W_hid = W_in + (size_t)WIDTH * IN;
+	const half_t* W_out = W_hid + (size_t)HM * WIDTH * WIDTH;
+	constexpr uint32_t F_WINA = 0, F_WHIDA = F_WINA + NB * FP, F_WOUTA = F_WHIDA + HM * NB * NP, F_SEL = F_WOUTA + NP, N_FRAG = F_SEL + 2;
+	__shared__ h8 wfrag[N_FRAG][64];
+	for (uint32_t f = w; f < N_FRAG; f += NWAVES) {
+		h8 v;
+		if (f < F_WHIDA) {
+			const uint32_t b = f / FP, p = f % FP;
+			v = *(const h8*)(W_in + (size_t)perm32(b, lr) * IN + 32 * p + 8 * g);
+		} else if (f < F_WOUTA) {
+			const uint32_t e = f - F_WHIDA, j = e / (NB * NP), b = e / NP % NB, p = e % NP;
+			v = *(const h8*)(W_hid + (size_t)j * WIDTH * WIDTH + (size_t)perm32(b, lr) * WIDTH + 32 * p + 8 * g);
+		} else if (f < F_SEL) {
+			v = *(const h8*)(W_out + (size_t)lr * WIDTH + 32 * (f - F_WOUTA) + 8 * g);
+		} else {
+#pragma unroll
+			for (uint32_t j = 0; j < 8; ++j) v[j] = (half_t)(8 * g + j == perm32(f - F_SEL, lr) ? 1.0f : 0.0f);
+		}
+		wfrag[f][lane] = v;
+	}
+	__syncthreads();
+
+	const uint32_t n_strips = n / MLP_WAVE_STRIP, stride = gridDim.x * NWAVES;
+	for (uint32_t strip = blockIdx.x * NWAVES + w; strip < n_strips; strip += stride) {
+		const uint32_t base = strip * MLP_WAVE_STRIP;
+		h8 xq[FB];
+#pragma unroll
+		for (uint32_t f = 0; f < FB; ++f) xq[f] = *(const h8*)(input + (perm32(f, lr) * n + base + 8 * g));
+		h4 hp[2][NB];
+		{
+			h8 xb[2][FP];
+#pragma unroll
+			for (uint32_t s = 0; s < 2; ++s) {
+				const h8 sel = wfrag[F_SEL + s][lane];
+#pragma unroll
+				for (uint32_t p = 0; p < FP; ++p)
+					xb[s][p] = pack8(to_h4(mfma_16x16x32(xq[2 * p], sel, zero4())), to_h4(mfma_16x16x32(xq[2 * p + 1], sel, zero4())));
+			}
+#pragma unroll
+			for (uint32_t s = 0; s < 2; ++s)
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b) {
+					f4 acc = zero4();
+#pragma unroll
+					for (uint32_t p = 0; p < FP; ++p) acc = mfma_16x16x32(wfrag[F_WINA + b * FP + p][lane], xb[s][p], acc);
+					hp[s][b] = act_forward4<false>(m.activation, pa, acc);
+				}
+		}
+#pragma unroll
+		for (uint32_t j = 0; j < HM; ++j) {
+			h4 nx[2][NB];
+#pragma unroll
+			for (uint32_t s = 0; s < 2; ++s)
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b) {
+					f4 acc = zero4();
+#pragma unroll
+					for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(wfrag[F_WHIDA + (j * NB + b) * NP + p][lane], pack8(hp[s][2 * p], hp[s][2 * p + 1]), acc);
+					nx[s][b] = act_forward4<false>(m.activation, pa, acc);
+				}
+#pragma unroll
+			for (uint32_t s = 0; s < 2; ++s)
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b) hp[s][b] = nx[s][b];
+		}
+#pragma unroll
+		for (uint32_t s = 0; s < 2; ++s) {
+			f4 acc = zero4();
+#pragma unroll
+			for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(wfrag[F_WOUTA + p][lane], pack8(hp[s][2 * p], hp[s][2 * p + 1]), acc);
+			const h4 o = h4{(half_t)act_forward<false>(out_act, acc[0]), (half_t)act_forward<false>(out_act, acc[1]), (half_t)act_forward<false>(out_act, acc[2]),
+			                (half_t)act_forward<false>(out_act, acc[3])};
+			*(h4*)(output + ((base + perm32(s, lr)) * 16 + 4 * g)) = o;
+		}
+	}
+}
+
 // ---- the register-resident wave-per-strip variant: instantiated for the shapes whose operands fit one wave's registers
 static bool mlp_train_wave_enabled() {
 	static const bool enabled = [] {
@@ -467,6 +560,37 @@ void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half
 		case 321: launch_train_wave<32, 32, 1>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		case 322: launch_train_wave<32, 32, 2>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		default: throw std::runtime_error("mlp_train: no register-resident instance for this shape");
+	}
+}
+
+// ---- inference instances
+bool mlp_infer_wave_supported(const MlpMeta& m, uint32_t n) {
+	if (!mlp_train_wave_enabled() || m.padded_out != 16 || (m.in_width != 32 && m.in_width != 64) || n > (1u << 25)) return false;
+	if (!act_is_simple(m.activation) || !act_is_simple(m.output_activation)) return false;
+	return (m.width == 64 && m.n_hidden_matmuls <= 2) || (m.width == 32 && m.n_hidden_matmuls <= 3 && m.in_width == 32);
+}
+
+template <uint32_t WIDTH, uint32_t IN, uint32_t HM>
+static void launch_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output) {
+	const uint32_t wanted = div_round_up(n / MLP_WAVE_STRIP, MLP_WAVE_THREADS / 64u);
+	const uint32_t blocks = wanted < TCNN_MLP_INFER_BLOCKS ? wanted : TCNN_MLP_INFER_BLOCKS;
+	TCNN_LAUNCH((k_mlp_infer_wave<WIDTH, IN, HM>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, input, output);
+}
+
+void mlp_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output) {
+	if (!mlp_infer_wave_supported(m, n)) throw std::runtime_error("mlp_infer_wave: unsupported shape or activation (check mlp_infer_wave_supported first)");
+	switch (m.width * 1000u + m.in_width * 10u + m.n_hidden_matmuls) {
+		case 64320: launch_infer_wave<64, 32, 0>(stream, m, n, params, input, output); break;
+		case 64321: launch_infer_wave<64, 32, 1>(stream, m, n, params, input, output); break;
+		case 64322: launch_infer_wave<64, 32, 2>(stream, m, n, params, input, output); break;
+		case 64640: launch_infer_wave<64, 64, 0>(stream, m, n, params, input, output); break;
+		case 64641: launch_infer_wave<64, 64, 1>(stream, m, n, params, input, output); break;
+		case 64642: launch_infer_wave<64, 64, 2>(stream, m, n, params, input, output); break;
+		case 32320: launch_infer_wave<32, 32, 0>(stream, m, n, params, input, output); break;
+		case 32321: launch_infer_wave<32, 32, 1>(stream, m, n, params, input, output); break;
+		case 32322: launch_infer_wave<32, 32, 2>(stream, m, n, params, input, output); break;
+		case 32323: launch_infer_wave<32, 32, 3>(stream, m, n, params, input, output); break;
+		default: throw std::runtime_error("mlp_infer_wave: no instance for this shape");
 	}
 }
 

@@ -96,7 +96,11 @@ TCNN_DEVICE void wave_lds_sync() {
 #if defined(TCNN_HOST_EMU)
 TCNN_DEVICE void sched_fence() {}
 #else
+#if defined(TCNN_NO_SCHED_FENCE)
+TCNN_DEVICE void sched_fence() {}
+#else
 TCNN_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+#endif
 #endif
 
 // fp32 -> fp16 with exactly ONE extra rounding (RNE) of an already rounded fp32 value.

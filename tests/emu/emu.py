@@ -213,10 +213,15 @@ def loss(loss_type, prediction_h, target, dims, loss_scale=128.0, data_pdf=None,
     return values, grads, float(s[0])
 
 
-def adam_step(oh, n_matrix, loss_scale, current_step, w32, w16, grads_h, m1, m2, steps):
+def adam_step(oh, n_matrix, loss_scale, current_step, w32, w16, grads_h, m1, m2, steps, steps_are_deficits=False):
     e = EmuAdam(*[getattr(oh, f[0]) for f in EmuAdam._fields_])
     lib().emu_adam_step(C.byref(e), C.c_uint32(w32.size), C.c_uint32(n_matrix), C.c_float(loss_scale), C.c_uint32(current_step),
-                        _p(w32), _p(w16), _p(grads_h), _p(m1), _p(m2), _p(steps))
+                        _p(w32), _p(w16), _p(grads_h), _p(m1), _p(m2), _p(steps), C.c_int(int(steps_are_deficits)))
+
+
+def adam_flip_steps(steps_done, steps):
+    """counters <-> deficits, in place"""
+    lib().emu_adam_flip_steps(C.c_uint32(steps.size), C.c_uint32(steps_done), _p(steps))
 
 
 def generate_random_uniform(rng, n, lower, upper):

@@ -313,6 +313,33 @@ def test_adam_matches_oracle():
     assert np.mean(a[1] != b[1]) < 1e-3
 
 
+def test_adam_step_counters_kept_as_deficits():
+    """The per-parameter step counters (adam.h:84) kept as `steps done - counter`: every step gives the same state as the
+    counter form, whichever form each step uses and wherever the representation is flipped."""
+    rng = np.random.default_rng(5)
+    h = O.adam_defaults(learning_rate=1e-2, beta2=0.99, epsilon=1e-15, l2_reg=1e-6)
+    n, nm = 4096 + 3, 1024
+    w = rng.standard_normal(n).astype(np.float32)
+    a = [w.copy(), O.f2h(w), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint32)]
+    b = [x.copy() for x in a]
+    deficits = False
+    for step, use_deficits in enumerate([True, True, False, True, True, True], start=1):
+        g = (rng.standard_normal(n) * 20).astype(np.float32)
+        g[rng.random(n) < 0.3] = 0  # untouched hash entries are skipped (adam.h:79-82) ...
+        g[2000:2400] = 0            # ... whole groups of four as well
+        gh = O.f2h(g)
+        if use_deficits != deficits:
+            emu.adam_flip_steps(step - 1, b[4])
+            deficits = use_deficits
+        emu.adam_step(h, nm, 128.0, step, a[0], a[1], gh, a[2], a[3], a[4])
+        emu.adam_step(h, nm, 128.0, step, b[0], b[1], gh, b[2], b[3], b[4], steps_are_deficits=deficits)
+        counters = (step - b[4]).astype(np.uint32) if deficits else b[4]
+        assert np.array_equal(counters, a[4])
+        for x, y in zip(a[:4], b[:4]):
+            assert np.array_equal(x, y)
+    assert a[4].min() < a[4].max()
+
+
 def test_rng_casts_identity():
     r1, r2 = O.pcg32(1337), O.pcg32(1337)
     a = O.generate_random_uniform(r1, 5001, -1e-4, 1e-4)

@@ -755,6 +755,10 @@ struct tcnn_trainable_model {
 	half_t* grads = nullptr;
 	float *m1 = nullptr, *m2 = nullptr;
 	uint32_t* steps = nullptr;
+	// `steps` holds the counters' deficits instead (elementwise_kernels.h: adam_flip_step_representation) while most
+	// table entries are stepped every time; chosen per optimizer step from the last batch size, see choose_step_representation
+	bool steps_are_deficits = false;
+	uint32_t last_batch = 0;
 	uint64_t global_batch = 0;
 	uint32_t lds_level_budget = 0;  // 0: default LDS slice size of the sliced grid backward
 	std::string hyper_json;
@@ -1187,12 +1191,31 @@ int tcnn_trainer_forward(tcnn_trainable_model_t* tm, tcnn_stream_t stream_, floa
 int tcnn_trainer_backward(tcnn_trainable_model_t* tm, tcnn_stream_t stream, const tcnn_train_context_t* ctx, uint32_t n, const float* input,
                           float* dL_dinput, int use_inference_params, int gradient_mode) {
 	TCNN_API_BEGIN
+	tm->last_batch = n;
 	if (!ctx) throw std::runtime_error("Trainer::backward: missing forward context");
 	ProfilerGuard pg(tm->profiler.get());
 	model_backward((hipStream_t)stream, tm->md, ctx->model_ctx, n, dL_dinput, ctx->dL_doutput_ptr, tm->grads, input, ctx->output.as<half_t>(),
 	               use_inference_params ? tm->inference_params() : tm->params, gradient_mode,
 	               tm->lds_level_budget);
 	TCNN_API_END
+}
+
+// Per-parameter step counters (adam.h:84) as counters or as deficits?  A stepped parameter costs 8 B of counter traffic in
+// the first form and 4 B in the second, a skipped (zero-gradient) hash-table entry 0 B and 8 B.  With N samples touching
+// 2^D corners per level, an entry of a level with T entries is skipped with probability exp(-N 2^D / T): deficits pay off
+// below ~1/3, i.e. for N 2^D >= T at the largest level (the headline: 4 T).  TCNN_ADAM_STEP_DEFICITS=0/1 forces a form.
+static bool choose_step_representation(const tcnn_trainable_model* tm) {
+	static const int forced = [] {
+		const char* e = getenv("TCNN_ADAM_STEP_DEFICITS");
+		return e ? (e[0] == '0' ? 0 : 1) : -1;
+	}();
+	if (forced >= 0) return forced != 0;
+	if (!tm->md.enc.is_grid) return true;  // network weights are stepped every time
+	const auto& g = tm->md.enc.grid;
+	uint32_t largest = 0;
+	for (uint32_t l = 0; l < g.n_levels; ++l) largest = std::max(largest, g.offset[l + 1] - g.offset[l]);
+	const uint64_t batch = tm->global_batch ? tm->global_batch : tm->last_batch;  // the reduced gradient covers the global batch
+	return (batch << g.n_dims) >= (uint64_t)largest;
 }
 
 // Optimizer::step over the parameter range [begin, end) (multiples of 8).  The call with begin == 0 advances the step
@@ -1210,12 +1233,17 @@ int tcnn_trainer_optimizer_step_range(tcnn_trainable_model_t* tm, tcnn_stream_t 
 			tm->adam.learning_rate = tm->base_lr * tm->lr_factor;
 		}
 		++tm->optimizer_step;  // adam.h:159
+		const bool want_deficits = choose_step_representation(tm);
+		if (want_deficits != tm->steps_are_deficits) {
+			adam_flip_step_representation((hipStream_t)stream, (uint32_t)n, tm->optimizer_step - 1u, tm->steps);
+			tm->steps_are_deficits = want_deficits;
+		}
 	}
 	ProfilerGuard pg(tm->profiler.get());
 	ProfScope prof((hipStream_t)stream, STAGE_ADAM);
 	adam_step((hipStream_t)stream, tm->adam, (uint32_t)n, (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master, tm->params, tm->grads,
 	          tm->m1, tm->m2, tm->steps, tm->params_t_valid ? tm->params_t : nullptr, tm->md.has_network ? &tm->md.net.mlp : nullptr, (uint32_t)begin,
-	          (uint32_t)end);
+	          (uint32_t)end, tm->steps_are_deficits);
 	if (tm->ema) {
 		ema_step((hipStream_t)stream, (uint32_t)n, tm->ema_decay, tm->optimizer_step, tm->params, tm->params_ema, tm->ema_tmp, (uint32_t)begin, (uint32_t)end);
 	}
@@ -1294,6 +1322,7 @@ int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
                                const float* data_pdf, int run_optimizer, float* dL_dinput, int use_inference_params, int gradient_mode,
                                const void* external_dL_dy, tcnn_train_context_t** ctx_out) {
 	const float loss_scale = LOSS_SCALE_FP16;  // trainer.h:265
+	tm->last_batch = n;
 	tcnn_train_context_t* ctx = nullptr;
 	if (g_fused_mlp_training && !external_dL_dy && target && tm->md.has_network && mlp_train_supported(tm->md.net.mlp) && loss_is_elementwise(tm->loss)) {
 		int r = training_step_fused(tm, (hipStream_t)stream, loss_scale, n, input, target, data_pdf, dL_dinput, use_inference_params, gradient_mode, &ctx);
@@ -1369,6 +1398,8 @@ int tcnn_trainer_set_params(tcnn_trainable_model_t* tm, const void* params_fp16,
 }
 
 // Trainer::serialize / deserialize, trainer.h:442-481 + adam.h:304-325; document layout in snapshot_msgpack.h.
+static size_t n_params_of(const tcnn_trainable_model* tm) { return tm->md.n_params(); }
+
 static Snapshot snapshot_shape(const tcnn_trainable_model* tm, bool with_optimizer) {
 	const size_t n = tm->md.n_params();
 	Snapshot s;
@@ -1408,6 +1439,10 @@ int tcnn_trainer_serialize(tcnn_trainable_model_t* tm, int serialize_optimizer, 
 			HIP_CHECK(hipMemcpy(host_m1.data(), tm->m1, host_m1.size(), hipMemcpyDeviceToHost));
 			HIP_CHECK(hipMemcpy(host_m2.data(), tm->m2, host_m2.size(), hipMemcpyDeviceToHost));
 			HIP_CHECK(hipMemcpy(host_steps.data(), tm->steps, host_steps.size(), hipMemcpyDeviceToHost));
+			if (tm->steps_are_deficits) {  // snapshots hold the counters themselves (adam.h:311)
+				uint32_t* counters = (uint32_t*)host_steps.data();
+				for (size_t i = 0; i < n_params_of(tm); ++i) counters[i] = tm->optimizer_step - counters[i];
+			}
 			s.first_moments.data = host_m1.data();
 			s.second_moments.data = host_m2.data();
 			s.param_steps.data = host_steps.data();
@@ -1450,6 +1485,7 @@ int tcnn_trainer_deserialize(tcnn_trainable_model_t* tm, const void* data, size_
 		} else {
 			HIP_CHECK(hipMemset(tm->steps, 0, n * sizeof(uint32_t)));
 		}
+		tm->steps_are_deficits = false;  // the next optimizer step picks the representation again
 		tm->optimizer_step = s.current_step;
 		tm->adam.learning_rate = s.base_learning_rate;
 		if (tm->ema) {  // ema.h:195-204

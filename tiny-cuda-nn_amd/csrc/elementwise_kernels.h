@@ -89,7 +89,13 @@ void ema_step(hipStream_t stream, uint32_t n, float ema_decay, uint32_t current_
 // that the next training step does not need a transposition pass.
 void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale,
                uint32_t current_step, float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2,
-               uint32_t* param_steps, half_t* weights_t = nullptr, const MlpMeta* mlp = nullptr, uint32_t begin = 0, uint32_t end = 0xFFFFFFFFu);
+               uint32_t* param_steps, half_t* weights_t = nullptr, const MlpMeta* mlp = nullptr, uint32_t begin = 0, uint32_t end = 0xFFFFFFFFu,
+               bool steps_are_deficits = false);
+// param_steps holds either the per-parameter step counters (adam.h:84) or, with steps_are_deficits, their deficit
+// steps_done - counter (steps_done = current_step - 1): a stepped parameter then reads its 4 bytes and writes nothing, a
+// skipped one is incremented -- cheaper when most parameters are stepped every time (the headline table: 98 %), dearer
+// when most are skipped.  This converts one representation into the other, in place (its own inverse).
+void adam_flip_step_representation(hipStream_t stream, uint32_t n, uint32_t steps_done, uint32_t* param_steps);
 
 // encodings/identity.h:46-84.  in: fp32 element (dim j, sample i) at in[i*in_stride_i + j*in_stride_j];
 // out: half element (k, i) at out[k*stride_k + i*stride_i], k < padded, padding value 1.

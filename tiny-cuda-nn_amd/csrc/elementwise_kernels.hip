@@ -230,6 +230,12 @@ struct AdamArgs {
 	int optimize_matrix_params, optimize_non_matrix_params, skip_zero_grad_non_matrix_params;
 	float beta1, beta2, epsilon, lower_lr_bound, upper_lr_bound, l2_reg, non_matrix_l2_reg;
 	MlpMeta mlp;  // layout of the matrix weights (for weights_t)
+	// Representation of the per-parameter step counters (adam.h:84 m_param_steps).  deficit == 0: the counters themselves.
+	// deficit != 0: the array holds steps_done - counter, the number of optimizer steps that SKIPPED the parameter; a
+	// parameter that is stepped then costs a 4-byte read and no write (its deficit does not change), only skipped ones
+	// are written.  steps_done = optimizer steps before this one.
+	uint32_t steps_done;
+	int deficit;
 };
 
 // One parameter, exactly the arithmetic of adam.h:66-126.  Returns false if the parameter is skipped.
@@ -304,6 +310,11 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 		const bool all_non_matrix = i0 >= a.n_matrix_weights;
 		if (all_non_matrix && a.skip_zero_grad_non_matrix_params && g[0] == (half_t)0.0f && g[1] == (half_t)0.0f && g[2] == (half_t)0.0f &&
 		    g[3] == (half_t)0.0f) {
+			if (a.deficit) {  // all four skipped: one more missed step each
+				u4 st = adam_load<STREAM>((const u4*)(param_steps + i0));
+				st += 1u;
+				adam_store<STREAM>((u4*)(param_steps + i0), st);
+			}
 			return;
 		}
 		f4 w = adam_load<STREAM>((const f4*)(weights_fp32 + i0));
@@ -316,18 +327,21 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 #pragma unroll
 		for (uint32_t j = 0; j < 4; ++j) {
 			float wj = w[j], m1j = m1[j], m2j = m2[j];
-			uint32_t sj = st[j];
+			uint32_t sj = a.deficit ? a.steps_done - st[j] : st[j];
 			if (adam_one(a, i0 + j, (float)g[j], wj, m1j, m2j, sj)) {
 				w[j] = wj;
 				m1[j] = m1j;
 				m2[j] = m2j;
-				st[j] = sj;
+				if (!a.deficit) st[j] = sj;
 				wh[j] = to_half_rn(wj);
 				if (weights_t && i0 + j < a.n_matrix_weights) weights_t[mlp_transposed_index(a.mlp, i0 + j)] = wh[j];
 				any = true;
 				updated |= 1u << j;
+			} else if (a.deficit) {
+				st[j] += 1u;
 			}
 		}
+		if (a.deficit && updated != 0xFu) adam_store<STREAM>((u4*)(param_steps + i0), st);
 		if (any) {
 			if (updated != 0xFu) {  // rare: keep the fp16 weights of the parameters that were skipped (only then are they read)
 				const h4 old = *(const h4*)(weights + i0);
@@ -339,20 +353,22 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 			adam_store<STREAM>((f4*)(weights_fp32 + i0), w);
 			adam_store<STREAM>((f4*)(first_moments + i0), m1);
 			adam_store<STREAM>((f4*)(second_moments + i0), m2);
-			adam_store<STREAM>((u4*)(param_steps + i0), st);
+			if (!a.deficit) adam_store<STREAM>((u4*)(param_steps + i0), st);
 			*(h4*)(weights + i0) = wh;
 		}
 	} else {
 		for (uint32_t i = i0; i < a.n_elements; ++i) {
 			float wj = weights_fp32[i], m1j = first_moments[i], m2j = second_moments[i];
-			uint32_t sj = param_steps[i];
+			uint32_t sj = a.deficit ? a.steps_done - param_steps[i] : param_steps[i];
 			if (adam_one(a, i, (float)gradients[i], wj, m1j, m2j, sj)) {
 				weights_fp32[i] = wj;
 				first_moments[i] = m1j;
 				second_moments[i] = m2j;
-				param_steps[i] = sj;
+				if (!a.deficit) param_steps[i] = sj;
 				weights[i] = to_half_rn(wj);
 				if (weights_t && i < a.n_matrix_weights) weights_t[mlp_transposed_index(a.mlp, i)] = weights[i];
+			} else if (a.deficit) {
+				param_steps[i] += 1u;
 			}
 		}
 	}
@@ -362,7 +378,7 @@ constexpr size_t ADAM_STREAM_THRESHOLD_BYTES = 192u << 20;  // optimizer state b
 
 void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale, uint32_t current_step,
                float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2, uint32_t* param_steps, half_t* weights_t,
-               const MlpMeta* mlp, uint32_t begin, uint32_t end) {
+               const MlpMeta* mlp, uint32_t begin, uint32_t end, bool steps_are_deficits) {
 	if (end > n) end = n;
 	if (begin >= end) return;
 	if (begin % 4u != 0u) throw std::runtime_error("adam_step: a parameter range must start at a multiple of 4");
@@ -393,12 +409,24 @@ void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_ma
 	a.l2_reg = h.l2_reg;
 	a.non_matrix_l2_reg = h.non_matrix_l2_reg;
 	a.mlp = mlp ? *mlp : MlpMeta{};
+	a.steps_done = current_step - 1u;
+	a.deficit = steps_are_deficits ? 1 : 0;
 	const dim3 grid(div_round_up(div_round_up(end - begin, 4u), EW_THREADS));
 	if ((size_t)n * 32u > ADAM_STREAM_THRESHOLD_BYTES) {
 		TCNN_LAUNCH(k_adam_step<true>, grid, dim3(EW_THREADS), 0, stream, a, weights_fp32, weights, gradients, m1, m2, param_steps, weights_t);
 	} else {
 		TCNN_LAUNCH(k_adam_step<false>, grid, dim3(EW_THREADS), 0, stream, a, weights_fp32, weights, gradients, m1, m2, param_steps, weights_t);
 	}
+}
+
+// counters <-> deficits: x -> steps_done - x is its own inverse (mod 2^32)
+__global__ void __launch_bounds__(EW_THREADS) k_adam_flip_steps(uint32_t n, uint32_t steps_done, uint32_t* __restrict__ param_steps) {
+	const uint32_t i = blockIdx.x * EW_THREADS + threadIdx.x;
+	if (i < n) param_steps[i] = steps_done - param_steps[i];
+}
+void adam_flip_step_representation(hipStream_t stream, uint32_t n, uint32_t steps_done, uint32_t* param_steps) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_adam_flip_steps, dim3(div_round_up(n, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, steps_done, param_steps);
 }
 
 // ------------------------------------------------------------------------------------------ identity

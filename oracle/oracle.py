@@ -159,13 +159,13 @@ def grid_forward(g, params_h, positions, out_stride=None, want_dy_dx=False):
     return (out, dy_dx) if want_dy_dx else out
 
 
-def grid_backward(g, positions, dL_dy_h):
+def grid_backward(g, positions, dL_dy_h, stochastic_interpolation=False):
     positions = np.ascontiguousarray(positions, dtype=np.float32)
     dL_dy_h = np.ascontiguousarray(dL_dy_h, dtype=np.uint16)
     n = positions.shape[0]
     grad = np.zeros(g.n_params, dtype=np.float64)
-    lib().orc_grid_backward(C.byref(g), _p(positions), C.c_uint32(n), _p(dL_dy_h), C.c_uint32(dL_dy_h.shape[1]),
-                            _p(grad))
+    fn = lib().orc_grid_backward_stochastic if stochastic_interpolation else lib().orc_grid_backward
+    fn(C.byref(g), _p(positions), C.c_uint32(n), _p(dL_dy_h), C.c_uint32(dL_dy_h.shape[1]), _p(grad))
     return grad
 
 

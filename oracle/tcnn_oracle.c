@@ -406,6 +406,40 @@ void orc_grid_forward(const orc_grid* g, const uint16_t* params, const float* po
 	}
 }
 
+/* grid.h:284-299: stochastic interpolation -- the whole gradient of (sample, level) goes, unweighted, to ONE corner chosen
+ * by a single uniform variate: per dimension the upper neighbour iff sample < pos[d].
+ * random_val(1337, i + level * n): common_device.h:469-473 (pcg32{seed}, advance(idx), next_float). */
+void orc_grid_backward_stochastic(const orc_grid* g, const float* positions, uint32_t n, const uint16_t* dL_dy,
+                                  uint32_t dy_stride, double* grad) {
+	const uint32_t D = g->n_dims, L = g->n_levels, F = g->n_features_per_level;
+#pragma omp parallel for schedule(static)
+	for (long long ii = 0; ii < (long long)n; ++ii) {
+		uint32_t i = (uint32_t)ii;
+		for (uint32_t level = 0; level < L; ++level) {
+			double* gg = grad + (size_t)g->offsets[level] * F;
+			float pos[ORC_MAX_DIMS], pd[ORC_MAX_DIMS];
+			uint32_t pg[ORC_MAX_DIMS];
+			for (uint32_t d = 0; d < D; ++d) pos_fract(g, positions[(size_t)i * D + d], g->scale[level], &pos[d], &pd[d], &pg[d]);
+			const uint16_t* dy = dL_dy + (size_t)i * dy_stride + level * F;
+			if (g->interpolation != ORC_INTERP_NEAREST) { /* Nearest returns before the stochastic branch (grid.h:279-282) */
+				orc_pcg32 rng;
+				orc_pcg32_seed(&rng, 1337u, 1u);
+				orc_pcg32_advance(&rng, (int64_t)(uint32_t)(i + level * n));
+				const float sample = orc_pcg32_next_float(&rng);
+				for (uint32_t d = 0; d < D; ++d) {
+					if (!(sample >= pos[d])) pg[d] += 1;
+				}
+			}
+			uint32_t index = orc_grid_index(g, level, pg) * F;
+			for (uint32_t f = 0; f < F; ++f) {
+				double c = (double)orc_h2f(dy[f]);
+#pragma omp atomic
+				gg[index + f] += c;
+			}
+		}
+	}
+}
+
 void orc_grid_backward(const orc_grid* g, const float* positions, uint32_t n, const uint16_t* dL_dy,
                        uint32_t dy_stride, double* grad) {
 	const uint32_t D = g->n_dims, L = g->n_levels, F = g->n_features_per_level, C = 1u << D;

@@ -96,6 +96,8 @@ void orc_grid_forward(const orc_grid* g, const uint16_t* params, const float* po
 /* grid.h:215-320 backward.  dL_dy: half bits AoS [N][dy_stride].  grad: double [n_params],
  * accumulated (+=) with each contribution rounded to half as the reference does
  * ((GRAD_T)weight * grad, grid.h:254) but summed exactly -- the "ideal" atomics result. */
+void orc_grid_backward_stochastic(const orc_grid* g, const float* positions, uint32_t n, const uint16_t* dL_dy,
+                                  uint32_t dy_stride, double* grad);
 void orc_grid_backward(const orc_grid* g, const float* positions, uint32_t n, const uint16_t* dL_dy,
                        uint32_t dy_stride, double* grad);
 

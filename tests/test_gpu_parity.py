@@ -125,6 +125,38 @@ def test_grid_backward_and_input_gradient(d, enc):
         assert np.allclose(dx.cpu().numpy(), dref, rtol=1e-4, atol=1e-3 * np.abs(dref).max())
 
 
+@pytest.mark.parametrize("d,enc", [(3, dict(HASH_ENCODING, log2_hashmap_size=15, n_levels=8)),
+                                   (2, {"otype": "DenseGrid", "n_levels": 4, "base_resolution": 8, "per_level_scale": 2.0, "interpolation": "Smoothstep"})])
+def test_grid_stochastic_interpolation(d, enc):
+    """stochastic_interpolation (grid.h:284-299): the backward pass sends the whole gradient of (sample, level) to one corner
+    picked by random_val(1337, i + level * n); the forward pass is the ordinary interpolation.  Same corner as the oracle
+    for every sample (sums of up to a few hundred fp16 terms per entry), and the scatter conserves the gradient mass."""
+    C = tcnn()._C
+    enc = dict(enc, stochastic_interpolation=True)
+    m = C.create_encoding(d, enc)
+    og = oracle_grid(enc, d)
+    n = 8192
+    pos = positions(n, d, seed=9)
+    rng = np.random.default_rng(2)
+    params = O.f2h((rng.random(og.n_params, dtype=np.float32) * 2 - 1) * 0.5)
+    dy = O.f2h(rng.standard_normal((n, m.n_output_dims())).astype(np.float32))
+    x = torch.from_numpy(pos).cuda()
+    p = h_t(params).requires_grad_(True)
+    ctx, y = m.fwd(x, p)
+    assert np.array_equal(h_np(y), O.grid_forward(og, params, pos))
+    _, dp = m.bwd(ctx, x, p, y, h_t(dy))
+    got = dp.float().cpu().numpy().astype(np.float64)
+    ref = O.grid_backward(og, pos, dy, stochastic_interpolation=True)
+    absacc = O.grid_backward(og, pos, O.f2h(np.abs(O.h2f(dy))), stochastic_interpolation=True)
+    assert np.all(np.abs(got - ref) <= absacc * 2.0 ** -8 + 2e-3)
+    assert not np.allclose(ref, O.grid_backward(og, pos, dy), atol=1e-2)  # not the interpolating scatter
+    F = enc.get("n_features_per_level", 2)
+    for level in range(og.n_levels):
+        lo, hi = og.offsets[level] * F, og.offsets[level + 1] * F
+        want = O.h2f(dy)[:, level * F:(level + 1) * F].astype(np.float64).sum()
+        assert abs(got[lo:hi].sum() - want) <= 1e-2 * np.abs(O.h2f(dy)[:, level * F:(level + 1) * F]).sum() * 2.0 ** -6 + 0.5
+
+
 def test_grid_forward_full_size_bit_exact_and_checksum():
     """BASELINE size: N = 2^18, T = 2^19.  Bit-exact against the oracle, plus the size-independent scatter
     property sum_entries grad[level, f] == sum_i dL_dy[i, level, f] (interpolation weights sum to one)."""

@@ -302,3 +302,22 @@ def test_grid_second_order_is_the_derivative_of_the_first_backward(interp, gtype
             assert abs(fd - dx2[i, a]) <= 3e-2 * max(1.0, np.abs(dx2).max()), (i, a, fd, dx2[i, a])
             checked += 1
     assert checked > n
+
+
+def test_grid_stochastic_backward_moves_the_whole_gradient_to_one_corner():
+    """grid.h:284-299 restated: per (sample, level) exactly one entry receives the unweighted gradient, the choice follows
+    random_val(1337, i + level * n) and is one of the cell's 2^D corners; P(upper neighbour along d) = pos[d]."""
+    g = O.grid_init(2, 3, 2, 12, 4, 2.0, O.GRID_HASH, O.INTERP_LINEAR)
+    n = 4000
+    pos = O.generate_random_uniform(O.pcg32(3), n * 2, 0.0, 1.0).reshape(n, 2)
+    dy = O.f2h(np.ones((n, 6), dtype=np.float32))
+    grad = O.grid_backward(g, pos, dy, stochastic_interpolation=True)
+    full = O.grid_backward(g, pos, dy)
+    for level in range(3):
+        lo, hi = g.offsets[level] * 2, g.offsets[level + 1] * 2
+        assert grad[lo:hi].sum() == 2 * n          # every sample lands exactly once per feature
+        assert np.all(grad[lo:hi] == np.round(grad[lo:hi]))  # unweighted
+        assert np.all((grad[lo:hi] > 0) <= (full[lo:hi] > 0))  # only corners of the sample's own cell
+    # a single sample: the chosen corner follows the variate
+    one = O.grid_backward(g, pos[:1], dy[:1], stochastic_interpolation=True)
+    assert np.count_nonzero(one) == 3 * 2

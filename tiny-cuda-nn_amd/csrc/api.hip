@@ -374,7 +374,7 @@ static EncodingDesc create_grid_encoding(uint32_t n_dims, const Json& enc) {  //
 	const uint32_t base_resolution = enc.value("base_resolution", 16u);
 	const float default_scale = grid_type == GridType::Dense ? std::exp(std::log(256.0f / (float)base_resolution) / (float)(n_levels - 1)) : 2.0f;
 	const float per_level_scale = enc.value("per_level_scale", default_scale);
-	if (enc.value("stochastic_interpolation", false)) throw std::runtime_error("GridEncoding: stochastic_interpolation is not available in this build.");
+
 	const InterpolationType interp = string_to_interpolation_type(enc.value("interpolation", "Linear"));
 	if (n_dims < 2 || n_dims > 4) throw std::runtime_error("GridEncoding: number of input dims must be 2, 3 or 4.");
 	if (n_levels > MAX_N_LEVELS) throw std::runtime_error("GridEncoding: m_n_levels=" + std::to_string(n_levels) + " must be at most MAX_N_LEVELS=" + std::to_string(MAX_N_LEVELS));
@@ -387,6 +387,7 @@ static EncodingDesc create_grid_encoding(uint32_t n_dims, const Json& enc) {  //
 	g.grid_type = (uint32_t)grid_type;
 	g.interp = (uint32_t)interp;
 	g.max_level = 1.0f;
+	g.stochastic = enc.value("stochastic_interpolation", false) ? 1u : 0u;  // grid.h:1752
 	// grid.h:699-727; the scale / resolution table is computed here once (fp32, same expressions as
 	// common_device.h:886-895) and handed to the kernels, see GridMeta.
 	const float log2_per_level_scale = std::log2(per_level_scale);

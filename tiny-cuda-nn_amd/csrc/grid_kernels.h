@@ -25,6 +25,7 @@ struct GridMeta {
 	uint32_t grid_type;   // GridType
 	uint32_t interp;      // InterpolationType
 	float max_level;      // reference MultiLevelEncoding::m_max_level (1.0 = all levels)
+	uint32_t stochastic;  // grid.h:284-299: backward sends (sample, level)'s gradient to ONE randomly chosen corner (forward is unaffected)
 	uint32_t offset[MAX_N_LEVELS + 1];
 	float scale[MAX_N_LEVELS];
 	uint32_t resolution[MAX_N_LEVELS];

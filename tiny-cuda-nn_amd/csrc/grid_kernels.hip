@@ -2,6 +2,7 @@
 // Build with -ffp-contract=off: the fp32 position/weight arithmetic must round exactly as written so
 // that indices AND interpolated features are bit-identical to the CPU oracle.
 #include "grid_kernels.h"
+#include "elementwise_kernels.h"  // Pcg32 (stochastic interpolation)
 
 #include <algorithm>
 #include <cstdlib>
@@ -297,16 +298,26 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_backward_atomic(const Gri
 	for (uint32_t s = 0; s < GRID_SPT; ++s) {
 		const uint32_t i = tile * GRID_TILE + s * GRID_THREADS + threadIdx.x;
 		if (i >= io.n) continue;
-		const Cell<D> c = make_cell<D, false>(lv, io, i);
+		Cell<D> c = make_cell<D, false>(lv, io, i);
 		h2 g[F / 2];
 #pragma unroll
 		for (uint32_t p = 0; p < F / 2; ++p) {
 			g[p] = h2{dL_dy[(size_t)(level * F + 2 * p) * io.stride_k + (size_t)i * io.stride_i],
 			          dL_dy[(size_t)(level * F + 2 * p + 1) * io.stride_k + (size_t)i * io.stride_i]};
 		}
-		const uint32_t n_corners = lv.nearest ? 1u : (1u << D);
+		const bool one_corner = lv.nearest || meta.stochastic != 0u;
+		if (meta.stochastic != 0u && !lv.nearest) {  // grid.h:284-299, random_val(1337, i + level * n): common_device.h:469-473
+			Pcg32 rng(1337u);
+			rng.advance((int64_t)(uint32_t)(i + level * io.n));
+			const float sample = rng.next_float();
+#pragma unroll
+			for (uint32_t d = 0; d < D; ++d) {
+				if (!(sample >= c.w[d][1])) c.grid[d] += 1u;
+			}
+		}
+		const uint32_t n_corners = one_corner ? 1u : (1u << D);
 		for (uint32_t idx = 0; idx < n_corners; ++idx) {
-			const half_t wh = lv.nearest ? (half_t)1.0f : to_half_rn(corner_weight<D>(c, idx));
+			const half_t wh = one_corner ? (half_t)1.0f : to_half_rn(corner_weight<D>(c, idx));
 			const h2 w2 = h2{wh, wh};
 			const uint32_t index = corner_index<D, false>(lv, c, idx);
 #pragma unroll
@@ -1373,6 +1384,9 @@ void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, c
 		}
 		if (mode != GridBackwardMode::Bucketed) throw std::runtime_error("grid_backward: the second-order scatter runs in the bucketed mode only");
 	}
+	// stochastic interpolation (one unweighted update per sample and level): the reference's atomic form; the owner-computes
+	// passes are built around all 2^D weighted corners
+	if (meta.stochastic != 0u && !io.ddx) mode = GridBackwardMode::Atomic;
 	switch (mode) {
 		case GridBackwardMode::SlicedF32: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, false, false, lds_slice_bytes, ws); break;
 		case GridBackwardMode::SlicedF16: grid_backward_sliced(stream, meta, io, dL_dy, grid_gradient, accumulate, true, false, lds_slice_bytes, ws); break;

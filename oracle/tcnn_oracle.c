@@ -964,6 +964,59 @@ void orc_adam_step(const orc_adam_hparams* h, uint32_t n, uint32_t n_matrix_weig
 
 /* ------------------------------------------------------------------ identity */
 
+/* ---- one-blob encoding: encodings/oneblob.h:84-164 (kernel_one_blob_soa / kernel_one_blob_backward) with the quartic
+ * kernel of common_device.h:1076-1095.  Outputs fp16, padding value 1 (oneblob.h:214-216). ---- */
+static float orc_quartic(float x, float inv_radius) {
+	const float u = x * inv_radius;
+	const float tmp = fmaxf(1 - u * u, 0.0f);
+	return ((float)15 / 16) * tmp * tmp;
+}
+static float orc_quartic_cdf_deriv(float x, float inv_radius) { return orc_quartic(x, inv_radius) * inv_radius; }
+static float orc_quartic_cdf(float x, float inv_radius) {
+	const float u = x * inv_radius;
+	const float u2 = u * u;
+	const float u4 = u2 * u2;
+	return fmaxf(0.0f, fminf(1.0f, ((float)15 / 16) * u * (1 - ((float)2 / 3) * u2 + ((float)1 / 5) * u4) + 0.5f));
+}
+void orc_oneblob_forward(uint32_t n, uint32_t n_dims, uint32_t n_bins, uint32_t padded, const float* in, uint16_t* out) {
+	uint32_t log2_bins = 0;
+	while ((1u << log2_bins) < n_bins) ++log2_bins;
+	for (uint32_t i = 0; i < n; ++i) {
+		for (uint32_t j = 0; j < n_dims; ++j) {
+			const float x = in[(size_t)i * n_dims + j];
+			float left_cdf = orc_quartic_cdf(-x, (float)n_bins) + orc_quartic_cdf(-x - 1.0f, (float)n_bins) + orc_quartic_cdf(-x + 1.0f, (float)n_bins);
+			for (uint32_t k = 0; k < n_bins; ++k) {
+				const float right_boundary = scalbnf((float)(k + 1), -(int)log2_bins);
+				const float right_cdf = orc_quartic_cdf(right_boundary - x, (float)n_bins) + orc_quartic_cdf(right_boundary - x - 1.0f, (float)n_bins) +
+				                        orc_quartic_cdf(right_boundary - x + 1.0f, (float)n_bins);
+				out[(size_t)i * padded + j * n_bins + k] = orc_f2h(right_cdf - left_cdf);
+				left_cdf = right_cdf;
+			}
+		}
+		for (uint32_t k = n_dims * n_bins; k < padded; ++k) out[(size_t)i * padded + k] = orc_f2h(1.0f);
+	}
+}
+void orc_oneblob_backward(uint32_t n, uint32_t n_dims, uint32_t n_bins, uint32_t padded, const float* in, const uint16_t* dL_dy, float* dL_dx) {
+	uint32_t log2_bins = 0;
+	while ((1u << log2_bins) < n_bins) ++log2_bins;
+	for (uint32_t i = 0; i < n; ++i) {
+		for (uint32_t j = 0; j < n_dims; ++j) {
+			const float x = in[(size_t)i * n_dims + j];
+			float result = 0;
+			float left_cdf = orc_quartic_cdf_deriv(-x, (float)n_bins) + orc_quartic_cdf_deriv(-x - 1.0f, (float)n_bins) + orc_quartic_cdf_deriv(-x + 1.0f, (float)n_bins);
+			for (uint32_t k = 0; k < n_bins; ++k) {
+				const float right_boundary = scalbnf((float)(k + 1), -(int)log2_bins);
+				const float right_cdf = orc_quartic_cdf_deriv(right_boundary - x, (float)n_bins) + orc_quartic_cdf_deriv(right_boundary - x - 1.0f, (float)n_bins) +
+				                        orc_quartic_cdf_deriv(right_boundary - x + 1.0f, (float)n_bins);
+				const float deriv = left_cdf - right_cdf;
+				left_cdf = right_cdf;
+				result += orc_h2f(dL_dy[(size_t)i * padded + j * n_bins + k]) * deriv;
+			}
+			dL_dx[(size_t)i * n_dims + j] = result;
+		}
+	}
+}
+
 void orc_identity_forward(uint32_t n, uint32_t n_dims, uint32_t padded, const float* in, uint16_t* out) {
 	for (size_t i = 0; i < n; ++i)
 		for (uint32_t j = 0; j < padded; ++j)

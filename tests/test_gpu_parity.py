@@ -232,6 +232,54 @@ def test_network_forward_backward(IN, W, OUT, H):
     assert np.allclose(dx.cpu().numpy(), dx_ref, rtol=2e-2, atol=(2e-3 if H <= 4 else 6e-3) * np.abs(dx_ref).max())
 
 
+@pytest.mark.parametrize("d,n_bins", [(2, 64), (3, 16), (1, 4)])
+def test_oneblob_encoding(d, n_bins):
+    """OneBlob (encodings/oneblob.h:84-164, BASELINE configs[0]'s encoding) through the module API: the bin integrals are the
+    oracle's bits, dL/dinput matches its restatement of kernel_one_blob_backward."""
+    C = tcnn()._C
+    m = C.create_encoding(d, {"otype": "OneBlob", "n_bins": n_bins})
+    assert m.n_output_dims() == d * n_bins and m.n_params() == 0 and m.hyperparams() == {"otype": "OneBlob", "n_bins": n_bins}
+    n = 1024
+    rng = np.random.default_rng(21)
+    xin = rng.random((n, d), dtype=np.float32)
+    x = torch.from_numpy(xin).cuda().requires_grad_(True)
+    p = torch.zeros(0, dtype=torch.float16, device="cuda")
+    ctx, y = m.fwd(x, p)
+    assert np.array_equal(h_np(y), O.oneblob_forward(xin, n_bins))
+    dy = O.f2h(rng.standard_normal((n, d * n_bins)).astype(np.float32))
+    dx, _ = m.bwd(ctx, x, p, y, h_t(dy))
+    ref = O.oneblob_backward(xin, n_bins, dy)
+    assert np.allclose(dx.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    with pytest.raises(RuntimeError, match="power of 2"):
+        C.create_encoding(2, {"otype": "OneBlob", "n_bins": 48})
+
+
+def test_config_oneblob_trains_and_matches_the_composed_oracle():
+    """BASELINE configs[0]: data/config_oneblob.json as shipped (OneBlob 64 bins + FullyFusedMLP 128 x 5, RelativeL2, Adam) on
+    2-D -> 3 data.  Inference equals oracle(one-blob) -> oracle(MLP) on the trained fp16 parameters; the loss drops."""
+    T = tcnn()
+    cfg = {"loss": {"otype": "RelativeL2"},
+           "optimizer": {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-8, "l2_reg": 1e-8},
+           "encoding": {"otype": "OneBlob", "n_bins": 64},
+           "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128, "n_hidden_layers": 5}}
+    tm = T.create_from_config(2, 3, cfg, seed=1337)
+    assert tm.n_params == 128 * 128 + 4 * 128 * 128 + 16 * 128
+    n = 1 << 14
+    pos = positions(n, 2, seed=5)
+    x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(targets_for(pos, 3)).cuda()
+    first = tm.loss(tm.training_step(x, t))
+    for _ in range(60):
+        tm.training_step(x, t, want_context=False)
+    last = tm.loss(tm.training_step(x, t))
+    assert np.isfinite(last) and last < 0.25 * first
+    y = tm.inference(x).cpu().numpy()
+    om = O.mlp_init(128, 128, 3, 5)
+    ph = h_np(tm.params)
+    _, out_ref = O.mlp_forward(om, ph, O.oneblob_forward(pos, 64))
+    ref = O.h2f(out_ref)[:, :3]
+    assert np.percentile(rae(y, ref), 99) < 1e-2 and np.max(np.abs(y - ref)) < 3e-2 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("d,enc,net,out", [
     (3, HASH_ENCODING_SMALL, MLP_64x2, 4),
     (2, HASH_ENCODING_SMALL, MLP_64x2, 3),

@@ -321,3 +321,28 @@ def test_grid_stochastic_backward_moves_the_whole_gradient_to_one_corner():
     # a single sample: the chosen corner follows the variate
     one = O.grid_backward(g, pos[:1], dy[:1], stochastic_interpolation=True)
     assert np.count_nonzero(one) == 3 * 2
+
+
+def test_oneblob_properties():
+    """encodings/oneblob.h restated: the bins integrate a wrapped unit-mass blob (they sum to one), the blob sits in the bin
+    that holds x, and the backward pass is the derivative of the forward pass (central differences)."""
+    rng = np.random.default_rng(8)
+    x = rng.random((200, 2), dtype=np.float32)
+    for n_bins in (4, 16, 64):
+        y = O.h2f(O.oneblob_forward(x, n_bins))
+        assert y.shape == (200, 2 * n_bins)
+        assert np.allclose(y.reshape(200, 2, n_bins).sum(-1), 1.0, atol=4e-3)
+        assert np.array_equal(y.reshape(200, 2, n_bins).argmax(-1), np.minimum((x * n_bins).astype(np.int64), n_bins - 1))
+        dy = rng.standard_normal((200, 2 * n_bins)).astype(np.float32)
+        dx = O.oneblob_backward(x, n_bins, O.f2h(dy))
+        h = 1e-3 / n_bins
+        num = np.zeros_like(x)
+        for d in range(2):
+            e = np.zeros_like(x); e[:, d] = h
+            # fp32 forward differences of the UNROUNDED encoding are not available: use the half outputs with a wide step
+            yp, ym = O.h2f(O.oneblob_forward(x + 50 * e, n_bins)), O.h2f(O.oneblob_forward(x - 50 * e, n_bins))
+            num[:, d] = ((yp - ym) * O.h2f(O.f2h(dy))).sum(1) / (100 * h)
+        inside = (x > 0.1).all(1) & (x < 0.9).all(1)
+        assert np.allclose(dx[inside], num[inside], rtol=0.15, atol=0.15 * np.abs(num).max())
+    padded = O.h2f(O.oneblob_forward(x, 4, padded=16))
+    assert np.all(padded[:, 8:] == 1.0)

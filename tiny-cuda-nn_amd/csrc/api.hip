@@ -312,6 +312,9 @@ struct EncodingDesc {
 	float per_level_scale = 2.0f;
 	// identity (identity.h:88-93)
 	float id_scale = 1.0f, id_offset = 0.0f;
+	// one-blob (oneblob.h:168-178): n_bins outputs per input dimension
+	bool is_oneblob = false;
+	uint32_t n_bins = 0;
 	uint32_t n_dims = 0;
 	uint32_t n_output_dims = 0;  // before padding
 	uint32_t n_params = 0;
@@ -342,6 +345,9 @@ struct EncodingDesc {
 			j["interpolation"] = to_string((InterpolationType)grid.interp);
 			j["hash"] = "CoherentPrime";
 			if ((GridType)grid.grid_type == GridType::Hash) j["log2_hashmap_size"] = log2_hashmap_size;
+		} else if (is_oneblob) {  // oneblob.h:296-301
+			j["otype"] = "OneBlob";
+			j["n_bins"] = n_bins;
 		} else {
 			j["otype"] = "Identity";
 			j["scale"] = id_scale;
@@ -433,8 +439,15 @@ static EncodingDesc create_encoding_desc(uint32_t n_dims, const Json& enc, uint3
 		e.id_offset = enc.value("offset", 0.0f);
 		e.n_output_dims = n_dims;
 		e.padded_output_width = n_dims;
+	} else if (equals_case_insensitive(name, "OneBlob")) {  // encoding.cu:118-120
+		e.is_oneblob = true;
+		e.n_dims = n_dims;
+		e.n_bins = enc.value("n_bins", 16u);
+		if (e.n_bins == 0 || (e.n_bins & (e.n_bins - 1)) != 0) throw std::runtime_error("Number of bins must be a power of 2");  // oneblob.h:174-176
+		e.n_output_dims = n_dims * e.n_bins;
+		e.padded_output_width = e.n_output_dims;
 	} else {
-		throw std::runtime_error("Encoding '" + name + "' not found (this build provides Grid/HashGrid/DenseGrid/TiledGrid and Identity)");
+		throw std::runtime_error("Encoding '" + name + "' not found (this build provides Grid/HashGrid/DenseGrid/TiledGrid, OneBlob and Identity)");
 	}
 	if (alignment > 0) e.set_alignment(alignment);
 	return e;
@@ -500,7 +513,7 @@ struct Model {
 	size_t n_params() const { return n_mlp_params() + enc.n_params; }  // network first, then encoding (:115-122)
 	uint32_t padded_output_width() const { return has_network ? net.mlp.padded_out : enc.padded_output_width; }
 	uint32_t output_width() const { return has_network ? net.n_output_dims : enc.padded_output_width; }
-	std::string name() const { return has_network ? "NetworkWithInputEncoding" : (enc.is_grid ? "GridEncoding" : "IdentityEncoding"); }
+	std::string name() const { return has_network ? "NetworkWithInputEncoding" : (enc.is_grid ? "GridEncoding" : (enc.is_oneblob ? "OneBlobEncoding" : "IdentityEncoding")); }
 
 	void finish() {
 		Json j = Json::object();
@@ -571,6 +584,8 @@ static void encoding_forward(hipStream_t stream, const Model& md, uint32_t n, co
 				HIP_CHECK(hipMemset2DAsync(out + e.n_output_dims, (size_t)e.padded_output_width * sizeof(half_t), 0, (size_t)n_to_pad * sizeof(half_t), n, stream));
 			}
 		}
+	} else if (e.is_oneblob) {
+		oneblob_forward(stream, n, e.n_dims, e.n_bins, e.padded_output_width, input, md.n_input_dims, 1u, out, stride_k, stride_i);
 	} else {
 		identity_forward(stream, n, e.n_dims, e.padded_output_width, e.id_scale, e.id_offset, input, md.n_input_dims, 1u, out, stride_k, stride_i);
 	}
@@ -688,6 +703,8 @@ static void encoding_backward(hipStream_t stream, const Model& md, const Forward
 			if (!ctx.dy_dx.ptr) throw std::runtime_error("backward: dL_dinput requested but forward was not run with prepare_input_gradients");
 			grid_backward_input(stream, md.n_input_dims, e.n_output_dims, io, dL_denc, ctx.dy_dx.as<float>(), dL_dinput, md.n_input_dims, 1u);
 		}
+	} else if (dL_dinput && e.is_oneblob) {
+		oneblob_backward(stream, n, e.n_dims, e.n_bins, dL_denc, stride_k, stride_i, input, md.n_input_dims, 1u, dL_dinput, md.n_input_dims, 1u);
 	} else if (dL_dinput) {
 		identity_backward(stream, n, e.n_dims, e.id_scale, dL_denc, stride_k, stride_i, dL_dinput, md.n_input_dims, 1u);
 	}

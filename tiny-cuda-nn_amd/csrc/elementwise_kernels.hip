@@ -466,4 +466,78 @@ void identity_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, float sc
 	TCNN_LAUNCH(k_identity_backward, dim3(div_round_up(n * n_dims, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, scale, dL_dy, stride_k, stride_i, dL_dx, dx_stride_i, dx_stride_j);
 }
 
+// ------------------------------------------------------------------------------------------ one-blob
+// encodings/oneblob.h:84-164 (the SoA kernels' arithmetic) with common_device.h:1076-1095 (quartic kernel).  One thread per
+// (dimension j, sample i), i fastest: the n_bins bin integrals of a quartic blob centred at x, wrapped around [0, 1).
+TCNN_DEVICE float quartic(float x, float inv_radius) {
+	const float u = x * inv_radius;
+	const float tmp = __builtin_fmaxf(1 - u * u, 0.0f);
+	return ((float)15 / 16) * tmp * tmp;
+}
+TCNN_DEVICE float quartic_cdf_deriv(float x, float inv_radius) { return quartic(x, inv_radius) * inv_radius; }
+TCNN_DEVICE float quartic_cdf(float x, float inv_radius) {
+	const float u = x * inv_radius;
+	const float u2 = u * u;
+	const float u4 = u2 * u2;
+	return __builtin_fmaxf(0.0f, __builtin_fminf(1.0f, ((float)15 / 16) * u * (1 - ((float)2 / 3) * u2 + ((float)1 / 5) * u4) + 0.5f));
+}
+__global__ void __launch_bounds__(EW_THREADS) k_oneblob_forward(uint32_t n, uint32_t n_dims, uint32_t log2_bins, uint32_t padded, const float* __restrict__ in,
+                                                                uint32_t in_stride_i, uint32_t in_stride_j, half_t* __restrict__ out, uint32_t stride_k,
+                                                                uint32_t stride_i) {
+	const uint32_t e = blockIdx.x * EW_THREADS + threadIdx.x;
+	const uint32_t n_bins = 1u << log2_bins, n_out = n_dims * n_bins;
+	if (e < n * n_dims) {
+		const uint32_t j = e / n, i = e - j * n;
+		const float x = in[(size_t)i * in_stride_i + (size_t)j * in_stride_j];
+		const float nb = (float)n_bins, inv_bins = 1.0f / nb;  // scalbnf(k, -log2_bins) == k * inv_bins exactly
+		float left_cdf = quartic_cdf(-x, nb) + quartic_cdf(-x - 1.0f, nb) + quartic_cdf(-x + 1.0f, nb);
+		for (uint32_t k = 0; k < n_bins; ++k) {
+			const float right_boundary = (float)(k + 1) * inv_bins;
+			const float right_cdf = quartic_cdf(right_boundary - x, nb) + quartic_cdf(right_boundary - x - 1.0f, nb) + quartic_cdf(right_boundary - x + 1.0f, nb);
+			out[(size_t)(j * n_bins + k) * stride_k + (size_t)i * stride_i] = to_half_rn(right_cdf - left_cdf);
+			left_cdf = right_cdf;
+		}
+	} else if (e < n * n_dims + n * (padded - n_out)) {  // oneblob.h:214-216, 232-234: padding is 1
+		const uint32_t q = e - n * n_dims, k = n_out + q / n, i = q % n;
+		out[(size_t)k * stride_k + (size_t)i * stride_i] = (half_t)1.0f;
+	}
+}
+__global__ void __launch_bounds__(EW_THREADS) k_oneblob_backward(uint32_t n, uint32_t n_dims, uint32_t log2_bins, const half_t* __restrict__ dL_dy, uint32_t stride_k,
+                                                                 uint32_t stride_i, const float* __restrict__ in, uint32_t in_stride_i, uint32_t in_stride_j,
+                                                                 float* __restrict__ dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
+	const uint32_t e = blockIdx.x * EW_THREADS + threadIdx.x;
+	if (e >= n * n_dims) return;
+	const uint32_t j = e / n, i = e - j * n, n_bins = 1u << log2_bins;
+	const float x = in[(size_t)i * in_stride_i + (size_t)j * in_stride_j];
+	const float nb = (float)n_bins, inv_bins = 1.0f / nb;
+	float result = 0;
+	float left_cdf = quartic_cdf_deriv(-x, nb) + quartic_cdf_deriv(-x - 1.0f, nb) + quartic_cdf_deriv(-x + 1.0f, nb);
+	for (uint32_t k = 0; k < n_bins; ++k) {
+		const float right_boundary = (float)(k + 1) * inv_bins;
+		const float right_cdf = quartic_cdf_deriv(right_boundary - x, nb) + quartic_cdf_deriv(right_boundary - x - 1.0f, nb) + quartic_cdf_deriv(right_boundary - x + 1.0f, nb);
+		const float deriv = left_cdf - right_cdf;
+		left_cdf = right_cdf;
+		result += (float)dL_dy[(size_t)(j * n_bins + k) * stride_k + (size_t)i * stride_i] * deriv;
+	}
+	dL_dx[(size_t)i * dx_stride_i + (size_t)j * dx_stride_j] = result;
+}
+
+void oneblob_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_bins, uint32_t padded, const float* in, uint32_t in_stride_i,
+                     uint32_t in_stride_j, half_t* out, uint32_t stride_k, uint32_t stride_i) {
+	if (n == 0) return;
+	uint32_t log2_bins = 0;
+	while ((1u << log2_bins) < n_bins) ++log2_bins;
+	const uint32_t work = n * n_dims + n * (padded - n_dims * n_bins);
+	TCNN_LAUNCH(k_oneblob_forward, dim3(div_round_up(work, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, log2_bins, padded, in, in_stride_i, in_stride_j, out,
+	            stride_k, stride_i);
+}
+void oneblob_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_bins, const half_t* dL_dy, uint32_t stride_k, uint32_t stride_i, const float* in,
+                      uint32_t in_stride_i, uint32_t in_stride_j, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
+	if (n == 0) return;
+	uint32_t log2_bins = 0;
+	while ((1u << log2_bins) < n_bins) ++log2_bins;
+	TCNN_LAUNCH(k_oneblob_backward, dim3(div_round_up(n * n_dims, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, log2_bins, dL_dy, stride_k, stride_i, in,
+	            in_stride_i, in_stride_j, dL_dx, dx_stride_i, dx_stride_j);
+}
+
 }  // namespace tcnn_hip

@@ -51,10 +51,20 @@ def bucket_ranges(n_params, n_buckets):
     return [(b, min(b + per, n_params)) for b in range(0, n_params, per)]
 
 
-def reduce_and_step(tm, grads, n_buckets=4, loss_scale=128.0):
+BUCKET_BYTES = 16 << 20  # xGMI collectives are per-link bound and their bus bandwidth still grows steeply between 4 and 32 MB:
+#                          few large buckets (two for the 28 MB headline gradient) rather than many latency-priced small ones
+
+
+def default_n_buckets(n_bytes):
+    return max(1, round(n_bytes / BUCKET_BYTES))
+
+
+def reduce_and_step(tm, grads, n_buckets=None, loss_scale=128.0):
     """Bucketed gradient all-reduce overlapped with the optimizer: the buckets are reduced in order on the
     communication stream; as soon as bucket k is summed its parameters are stepped while buckets k+1.. are still on the
     wire (xGMI ring all-reduce of the 28 MB fp16 buffer takes longer than the whole optimizer step)."""
+    if n_buckets is None:
+        n_buckets = default_n_buckets(grads.numel() * grads.element_size())
     ranges = bucket_ranges(grads.numel(), n_buckets)
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         for b, e in ranges:

@@ -184,6 +184,7 @@ struct Profiler {
 	struct Span {
 		int stage;
 		hipEvent_t a, b;
+		bool counts;
 	};
 	std::vector<Span> spans;
 	double total_ms[N_STAGES] = {};
@@ -203,7 +204,7 @@ struct Profiler {
 			float ms = 0.0f;
 			HIP_CHECK(hipEventElapsedTime(&ms, s.a, s.b));
 			total_ms[s.stage] += ms;
-			count[s.stage]++;
+			if (s.counts) count[s.stage]++;
 		}
 		spans.clear();
 		next = 0;
@@ -229,8 +230,9 @@ static const uint32_t g_default_lds_slice_bytes = getenv("TCNN_GRID_LDS_SLICE_BY
 struct ProfScope {
 	hipStream_t stream;
 	int stage;
+	bool counts;  // false: a further piece of a stage that is launched in several parts per step (time adds up, the launch count does not)
 	hipEvent_t a = nullptr;
-	ProfScope(hipStream_t s, int st) : stream(s), stage(st) {
+	ProfScope(hipStream_t s, int st, bool counts_ = true) : stream(s), stage(st), counts(counts_) {
 		if (g_profiler && (g_profiler->only_stage < 0 || g_profiler->only_stage == st)) {
 			a = g_profiler->get();
 			HIP_CHECK(hipEventRecord(a, stream));
@@ -240,7 +242,7 @@ struct ProfScope {
 		if (a) {
 			hipEvent_t b = g_profiler->get();
 			(void)hipEventRecord(b, stream);
-			g_profiler->spans.push_back({stage, a, b});
+			g_profiler->spans.push_back({stage, a, b, counts});
 		}
 	}
 };
@@ -255,7 +257,7 @@ static void grid_backward_phase_hook(void* user, int phase, int begin) {
 	} else if (a) {
 		hipEvent_t b = g_profiler->get();
 		HIP_CHECK(hipEventRecord(b, (hipStream_t)user));
-		g_profiler->spans.push_back({stage, a, b});
+		g_profiler->spans.push_back({stage, a, b, true});
 		a = nullptr;
 	}
 }
@@ -1258,7 +1260,7 @@ int tcnn_trainer_optimizer_step_range(tcnn_trainable_model_t* tm, tcnn_stream_t 
 		}
 	}
 	ProfilerGuard pg(tm->profiler.get());
-	ProfScope prof((hipStream_t)stream, STAGE_ADAM);
+	ProfScope prof((hipStream_t)stream, STAGE_ADAM, /*counts=*/begin == 0);  // a ranged (bucketed) step is ONE optimizer step
 	adam_step((hipStream_t)stream, tm->adam, (uint32_t)n, (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master, tm->params, tm->grads,
 	          tm->m1, tm->m2, tm->steps, tm->params_t_valid ? tm->params_t : nullptr, tm->md.has_network ? &tm->md.net.mlp : nullptr, (uint32_t)begin,
 	          (uint32_t)end, tm->steps_are_deficits);

@@ -121,7 +121,14 @@ def main():
     import tinycudann as tcnn  # fails loudly if libtcnn_hip.so is missing
     from tinycudann import parallel as par
 
-    rank, local_rank, world = par.init_from_env()
+    # TCNN_BENCH_BACKEND / TCNN_BENCH_DEVICE: dry runs of the multi-rank branch on a one-GPU box (gloo, every rank on one
+    # device); never set by the driver
+    backend = os.environ.get("TCNN_BENCH_BACKEND")
+    if os.environ.get("TCNN_BENCH_DEVICE") is not None and torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ["TCNN_BENCH_DEVICE"]))
+    rank, local_rank, world = par.init_from_env(backend=backend)
+    if os.environ.get("TCNN_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["TCNN_BENCH_DEVICE"])
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():

@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
                                                                         float* __restrict__ block_sums) {
 	constexpr uint32_t NB = WIDTH / 16, NP = WIDTH / 32, FB = IN / 16, FP = IN / 32, NWAVES = MLP_WAVE_THREADS / 64, HMX = HM > 0 ? HM : 1;
 	constexpr uint32_t N_PARAMS = WIDTH * IN + HM * WIDTH * WIDTH + 16 * WIDTH;
+	static_assert(NWAVES == 4 && WIDTH % 32 == 0 && IN % 32 == 0, "the final reduction pairs waves (0,2) and (1,3); operands are built from pairs of 16-row tiles");
 	constexpr uint32_t N_TILES = NB * FB + HM * NB * NB + NB;  // accumulator tiles per wave
 	__shared__ f4 exchange[N_TILES * 64];
 	__shared__ float red[MLP_WAVE_THREADS];

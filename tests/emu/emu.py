@@ -240,6 +240,22 @@ def cast_f32_to_f16(x):
     return out
 
 
+def oneblob_forward(x, n_bins, padded=None):
+    """feature-major half [padded, n]"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    padded = padded or x.shape[1] * n_bins
+    out = np.zeros((padded, x.shape[0]), dtype=np.uint16)
+    lib().emu_oneblob_forward(C.c_uint32(x.shape[0]), C.c_uint32(x.shape[1]), C.c_uint32(n_bins), C.c_uint32(padded), _p(x), _p(out))
+    return out
+
+
+def oneblob_backward(x, n_bins, dL_dy_soa_h):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros_like(x)
+    lib().emu_oneblob_backward(C.c_uint32(x.shape[0]), C.c_uint32(x.shape[1]), C.c_uint32(n_bins), _p(np.ascontiguousarray(dL_dy_soa_h, dtype=np.uint16)), _p(x), _p(out))
+    return out
+
+
 def identity_forward(x, padded):
     x = np.ascontiguousarray(x, dtype=np.float32)
     out = np.zeros((padded, x.shape[0]), dtype=np.uint16)

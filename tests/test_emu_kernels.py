@@ -340,6 +340,19 @@ def test_adam_step_counters_kept_as_deficits():
     assert a[4].min() < a[4].max()
 
 
+@pytest.mark.parametrize("d,n_bins,padded", [(2, 64, 128), (3, 16, 48), (1, 4, 16)])
+def test_oneblob_encoding(d, n_bins, padded):
+    """k_oneblob_forward / k_oneblob_backward (encodings/oneblob.h:84-164) against the oracle: the bin integrals and the
+    padding bit for bit, dL/dinput to fp32 rounding."""
+    rng = np.random.default_rng(31)
+    x = rng.random((513, d), dtype=np.float32)
+    ref = O.oneblob_forward(x, n_bins, padded=padded)
+    assert np.array_equal(emu.oneblob_forward(x, n_bins, padded=padded).T, ref)
+    dy = O.f2h(rng.standard_normal((513, padded)).astype(np.float32))
+    got, want = emu.oneblob_backward(x, n_bins, np.ascontiguousarray(dy.T)), O.oneblob_backward(x, n_bins, dy)
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-6 * np.abs(want).max())
+
+
 def test_rng_casts_identity():
     r1, r2 = O.pcg32(1337), O.pcg32(1337)
     a = O.generate_random_uniform(r1, 5001, -1e-4, 1e-4)

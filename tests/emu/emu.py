@@ -72,13 +72,14 @@ def _p(a):
 class Grid:
     """Wraps an oracle grid description (oracle.Grid) for the emulated kernels."""
 
-    def __init__(self, og, max_level=1.0):
+    def __init__(self, og, max_level=1.0, stochastic_interpolation=False):
         self.og = og
         L = og.n_levels
         self._off = np.array(og.offsets[: L + 1], dtype=np.uint32)
         self._scale = np.array(og.scale[:L], dtype=np.float32)
         self._res = np.array(og.resolution[:L], dtype=np.uint32)
-        self.c = EmuGrid(og.n_dims, L, og.n_features_per_level, og.grid_type, og.interpolation, max_level,
+        # bit 8 of the interpolation word carries stochastic_interpolation to the driver (GridMeta::stochastic)
+        self.c = EmuGrid(og.n_dims, L, og.n_features_per_level, og.grid_type, og.interpolation | (0x100 if stochastic_interpolation else 0), max_level,
                          self._off.ctypes.data, self._scale.ctypes.data, self._res.ctypes.data)
 
 

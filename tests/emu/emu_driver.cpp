@@ -25,7 +25,8 @@ static GridMeta make_meta(const EmuGrid* e) {
 	m.n_levels = e->n_levels;
 	m.n_feat = e->n_feat;
 	m.grid_type = e->grid_type;
-	m.interp = e->interp;
+	m.interp = e->interp & 0xFFu;
+	m.stochastic = (e->interp >> 8) & 1u;  // emu.py packs the flag into the interpolation word
 	m.max_level = e->max_level;
 	for (uint32_t l = 0; l <= e->n_levels; ++l) m.offset[l] = e->offset[l];
 	for (uint32_t l = 0; l < e->n_levels; ++l) {

@@ -340,6 +340,21 @@ def test_adam_step_counters_kept_as_deficits():
     assert a[4].min() < a[4].max()
 
 
+def test_grid_stochastic_interpolation_backward():
+    """stochastic_interpolation (grid.h:284-299): every backward mode routes to the single-corner atomic scatter; the corner
+    is the oracle's for every (sample, level) -- the sums are exact in fp16 here (unit gradients, few samples per entry)."""
+    og = O.grid_init(3, 6, 2, 12, 8, 1.6, O.GRID_HASH, O.INTERP_LINEAR)
+    g = emu.Grid(og, stochastic_interpolation=True)
+    n = 512
+    pos = O.generate_random_uniform(O.pcg32(12), n * 3, 0.0, 1.0).reshape(n, 3)
+    dy = O.f2h(np.ones((n, 12), dtype=np.float32))
+    ref = O.grid_backward(og, pos, dy, stochastic_interpolation=True)
+    for mode in (emu.SLICED_F32, emu.BUCKETED):
+        got = O.h2f(emu.grid_backward(g, pos, np.ascontiguousarray(dy.T), mode=mode)).astype(np.float64)
+        assert np.array_equal(got, ref)
+    assert not np.array_equal(ref, O.grid_backward(og, pos, dy))
+
+
 @pytest.mark.parametrize("d,n_bins,padded", [(2, 64, 128), (3, 16, 48), (1, 4, 16)])
 def test_oneblob_encoding(d, n_bins, padded):
     """k_oneblob_forward / k_oneblob_backward (encodings/oneblob.h:84-164) against the oracle: the bin integrals and the

@@ -252,6 +252,24 @@ def adam_step(h, n_matrix_weights, loss_scale, current_step, w32, w16, grads_h, 
                         C.c_uint32(current_step), _p(w32), _p(w16), _p(grads_h), _p(m1), _p(m2), _p(steps))
 
 
+def frequency_forward(x, n_frequencies, padded=None):
+    """encodings/frequency.h:46-79; x: [n, d] fp32 -> half [n, padded]"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    padded = padded or x.shape[1] * n_frequencies * 2
+    out = np.empty((x.shape[0], padded), dtype=np.uint16)
+    lib().orc_frequency_forward(C.c_uint32(x.shape[0]), C.c_uint32(x.shape[1]), C.c_uint32(n_frequencies), C.c_uint32(padded), _p(x), _p(out))
+    return out
+
+
+def frequency_backward(x, n_frequencies, dL_dy_h):
+    """encodings/frequency.h:82-104; dL_dy_h: half [n, padded] -> fp32 [n, d]"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    dL_dy_h = np.ascontiguousarray(dL_dy_h, dtype=np.uint16)
+    out = np.empty_like(x)
+    lib().orc_frequency_backward(C.c_uint32(x.shape[0]), C.c_uint32(x.shape[1]), C.c_uint32(n_frequencies), C.c_uint32(dL_dy_h.shape[1]), _p(x), _p(dL_dy_h), _p(out))
+    return out
+
+
 def oneblob_forward(x, n_bins, padded=None):
     """encodings/oneblob.h:84-110; x: [n, d] fp32 -> half [n, padded]"""
     x = np.ascontiguousarray(x, dtype=np.float32)

@@ -964,6 +964,42 @@ void orc_adam_step(const orc_adam_hparams* h, uint32_t n, uint32_t n_matrix_weig
 
 /* ------------------------------------------------------------------ identity */
 
+/* ---- frequency encoding: encodings/frequency.h:46-104.  sinf / cosf of the reference's fp32 argument (the reference uses the
+ * __sinf / __cosf approximations, see the kernel's header: parity with the reference itself is to that intrinsic's accuracy). ---- */
+#define ORC_PI_F 3.14159265358979323846f
+void orc_frequency_forward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, uint32_t padded, const float* in, uint16_t* out) {
+	const uint32_t fan_out_encoded = n_dims * n_frequencies * 2;
+	for (uint32_t i = 0; i < n; ++i) {
+		for (uint32_t j = 0; j < padded; ++j) {
+			if (j >= fan_out_encoded) {
+				out[(size_t)i * padded + j] = orc_f2h(1.0f);
+				continue;
+			}
+			const uint32_t d = j / (n_frequencies * 2), log2_frequency = (j / 2) % n_frequencies;
+			const float phase_shift = (float)(j % 2) * (ORC_PI_F / 2);
+			const float x = scalbnf(in[(size_t)i * n_dims + d], (int)log2_frequency);
+			const float input = x * ORC_PI_F + phase_shift;
+			out[(size_t)i * padded + j] = orc_f2h(sinf(input));
+		}
+	}
+}
+void orc_frequency_backward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, uint32_t padded, const float* in, const uint16_t* dL_dy, float* dL_dx) {
+	const uint32_t outputs_per_input = n_frequencies * 2;
+	for (uint32_t i = 0; i < n; ++i) {
+		for (uint32_t d = 0; d < n_dims; ++d) {
+			float result = 0;
+			for (uint32_t k = 0; k < outputs_per_input; ++k) {
+				const uint32_t j = d * outputs_per_input + k, log2_frequency = k / 2;
+				const float phase_shift = (float)(k % 2) * (ORC_PI_F / 2);
+				const float input = scalbnf(in[(size_t)i * n_dims + d], (int)log2_frequency) * ORC_PI_F + phase_shift;
+				const float dy_dx = scalbnf(1.0f, (int)log2_frequency) * ORC_PI_F * cosf(input);
+				result += orc_h2f(dL_dy[(size_t)i * padded + j]) * dy_dx;
+			}
+			dL_dx[(size_t)i * n_dims + d] = result;
+		}
+	}
+}
+
 /* ---- one-blob encoding: encodings/oneblob.h:84-164 (kernel_one_blob_soa / kernel_one_blob_backward) with the quartic
  * kernel of common_device.h:1076-1095.  Outputs fp16, padding value 1 (oneblob.h:214-216). ---- */
 static float orc_quartic(float x, float inv_radius) {

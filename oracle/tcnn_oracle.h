@@ -161,6 +161,10 @@ void orc_adam_step(const orc_adam_hparams* h, uint32_t n, uint32_t n_matrix_weig
                    uint32_t current_step, float* weights_fp32, uint16_t* weights_half,
                    const uint16_t* gradients, float* m1, float* m2, uint32_t* param_steps);
 
+/* ---- frequency encoding (encodings/frequency.h:46-104): in [N][n_dims] fp32, out / dL_dy [N][padded] half, pads with 1.0 ---- */
+void orc_frequency_forward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, uint32_t padded, const float* in, uint16_t* out);
+void orc_frequency_backward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, uint32_t padded, const float* in, const uint16_t* dL_dy, float* dL_dx);
+
 /* ---- one-blob encoding (encodings/oneblob.h:84-164): in [N][n_dims] fp32, out / dL_dy [N][padded] half, pads with 1.0 ---- */
 void orc_oneblob_forward(uint32_t n, uint32_t n_dims, uint32_t n_bins, uint32_t padded, const float* in, uint16_t* out);
 void orc_oneblob_backward(uint32_t n, uint32_t n_dims, uint32_t n_bins, uint32_t padded, const float* in, const uint16_t* dL_dy, float* dL_dx);

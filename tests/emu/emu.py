@@ -241,6 +241,22 @@ def cast_f32_to_f16(x):
     return out
 
 
+def frequency_forward(x, n_frequencies, padded=None):
+    """feature-major half [padded, n]"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    padded = padded or x.shape[1] * n_frequencies * 2
+    out = np.zeros((padded, x.shape[0]), dtype=np.uint16)
+    lib().emu_frequency_forward(C.c_uint32(x.shape[0]), C.c_uint32(x.shape[1]), C.c_uint32(n_frequencies), C.c_uint32(padded), _p(x), _p(out))
+    return out
+
+
+def frequency_backward(x, n_frequencies, dL_dy_soa_h):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros_like(x)
+    lib().emu_frequency_backward(C.c_uint32(x.shape[0]), C.c_uint32(x.shape[1]), C.c_uint32(n_frequencies), _p(np.ascontiguousarray(dL_dy_soa_h, dtype=np.uint16)), _p(x), _p(out))
+    return out
+
+
 def oneblob_forward(x, n_bins, padded=None):
     """feature-major half [padded, n]"""
     x = np.ascontiguousarray(x, dtype=np.float32)

@@ -244,6 +244,14 @@ int emu_identity_forward(uint32_t n, uint32_t n_dims, uint32_t padded, const flo
 	return 0;
 }
 
+int emu_frequency_forward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, uint32_t padded, const float* in, uint16_t* out_soa) {
+	frequency_forward(nullptr, n, n_dims, n_frequencies, padded, in, n_dims, 1, (half_t*)out_soa, n, 1);
+	return 0;
+}
+int emu_frequency_backward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const uint16_t* dL_dy_soa, const float* in, float* dL_dx) {
+	frequency_backward(nullptr, n, n_dims, n_frequencies, (const half_t*)dL_dy_soa, n, 1, in, n_dims, 1, dL_dx, n_dims, 1);
+	return 0;
+}
 // one-blob encoding: feature-major output (as the network consumes it) and dL/dinput
 int emu_oneblob_forward(uint32_t n, uint32_t n_dims, uint32_t n_bins, uint32_t padded, const float* in, uint16_t* out_soa) {
 	oneblob_forward(nullptr, n, n_dims, n_bins, padded, in, n_dims, 1, (half_t*)out_soa, n, 1);

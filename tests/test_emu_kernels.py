@@ -355,6 +355,18 @@ def test_grid_stochastic_interpolation_backward():
     assert not np.array_equal(ref, O.grid_backward(og, pos, dy))
 
 
+@pytest.mark.parametrize("d,n_frequencies,padded", [(3, 12, 80), (2, 4, 16), (5, 10, 112)])
+def test_frequency_encoding(d, n_frequencies, padded):
+    """k_frequency_forward / k_frequency_backward (encodings/frequency.h:46-104) against the oracle (same libm on the host)."""
+    rng = np.random.default_rng(32)
+    x = (rng.random((257, d), dtype=np.float32) * 2 - 0.5).astype(np.float32)
+    ref = O.frequency_forward(x, n_frequencies, padded=padded)
+    assert np.array_equal(emu.frequency_forward(x, n_frequencies, padded=padded).T, ref)
+    dy = O.f2h(rng.standard_normal((257, padded)).astype(np.float32))
+    got, want = emu.frequency_backward(x, n_frequencies, np.ascontiguousarray(dy.T)), O.frequency_backward(x, n_frequencies, dy)
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-6 * np.abs(want).max())
+
+
 @pytest.mark.parametrize("d,n_bins,padded", [(2, 64, 128), (3, 16, 48), (1, 4, 16)])
 def test_oneblob_encoding(d, n_bins, padded):
     """k_oneblob_forward / k_oneblob_backward (encodings/oneblob.h:84-164) against the oracle: the bin integrals and the

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import HASH_ENCODING, HASH_ENCODING_SMALL, MLP_64x2, ROOT, config_hash
+from conftest import ADAM_HASH, HASH_ENCODING, HASH_ENCODING_SMALL, MLP_64x2, ROOT, config_hash
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -252,6 +252,39 @@ def test_oneblob_encoding(d, n_bins):
     assert np.allclose(dx.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
     with pytest.raises(RuntimeError, match="power of 2"):
         C.create_encoding(2, {"otype": "OneBlob", "n_bins": 48})
+
+
+@pytest.mark.parametrize("d,n_frequencies", [(3, 12), (2, 6)])
+def test_frequency_encoding(d, n_frequencies):
+    """Frequency encoding (encodings/frequency.h:46-104) through the module API against the oracle: device sinf / cosf vs the
+    host's differ in the last fp32 bit at most, i.e. in the fp16 output bit of a few entries; and as a network's input."""
+    C = tcnn()._C
+    m = C.create_encoding(d, {"otype": "Frequency", "n_frequencies": n_frequencies})
+    assert m.n_output_dims() == 2 * d * n_frequencies and m.n_params() == 0
+    assert m.hyperparams() == {"otype": "Frequency", "n_frequencies": n_frequencies}
+    n = 2048
+    rng = np.random.default_rng(22)
+    xin = rng.random((n, d), dtype=np.float32)
+    x = torch.from_numpy(xin).cuda().requires_grad_(True)
+    p = torch.zeros(0, dtype=torch.float16, device="cuda")
+    ctx, y = m.fwd(x, p)
+    got, ref = h_np(y), O.frequency_forward(xin, n_frequencies)
+    assert np.mean(got != ref) < 2e-3 and np.max(np.abs(O.h2f(got) - O.h2f(ref))) <= 2.0 ** -10
+    dy = O.f2h(rng.standard_normal((n, 2 * d * n_frequencies)).astype(np.float32))
+    dx, _ = m.bwd(ctx, x, p, y, h_t(dy))
+    dref = O.frequency_backward(xin, n_frequencies, dy)
+    assert np.allclose(dx.cpu().numpy(), dref, rtol=1e-4, atol=1e-4 * np.abs(dref).max())
+    # NeRF-style: positional encoding + MLP trains (72 -> 80 padded inputs for d = 3: the tiled network kernels)
+    T = tcnn()
+    cfg = {"loss": {"otype": "RelativeL2"}, "optimizer": dict(ADAM_HASH), "encoding": {"otype": "Frequency", "n_frequencies": n_frequencies},
+           "network": dict(MLP_64x2)}
+    tm = T.create_from_config(d, 3, cfg, seed=5)
+    pos = positions(1 << 13, d, seed=6)
+    xx, tt = torch.from_numpy(pos).cuda(), torch.from_numpy(targets_for(pos, 3)).cuda()
+    first = tm.loss(tm.training_step(xx, tt))
+    for _ in range(40):
+        tm.training_step(xx, tt, want_context=False)
+    assert tm.loss(tm.training_step(xx, tt)) < 0.5 * first
 
 
 def test_config_oneblob_trains_and_matches_the_composed_oracle():

@@ -346,3 +346,25 @@ def test_oneblob_properties():
         assert np.allclose(dx[inside], num[inside], rtol=0.15, atol=0.15 * np.abs(num).max())
     padded = O.h2f(O.oneblob_forward(x, 4, padded=16))
     assert np.all(padded[:, 8:] == 1.0)
+
+
+def test_frequency_properties():
+    """encodings/frequency.h restated: pairs (sin, cos) of 2^f pi x; sin^2 + cos^2 = 1 up to fp16 rounding; the backward pass
+    is the derivative (central differences on the low octaves, where fp16 outputs resolve them)."""
+    rng = np.random.default_rng(9)
+    x = rng.random((300, 3), dtype=np.float32)
+    y = O.h2f(O.frequency_forward(x, 6, padded=48))
+    assert y.shape == (300, 48) and np.all(y[:, 36:] == 1.0)
+    enc = y[:, :36].reshape(300, 3, 6, 2)
+    assert np.allclose(enc[..., 0] ** 2 + enc[..., 1] ** 2, 1.0, atol=3e-3)
+    assert np.allclose(enc[:, :, 0, 0], np.sin(np.pi * x), atol=1e-3) and np.allclose(enc[:, :, 3, 1], np.cos(8 * np.pi * x), atol=2e-3)
+    dy = np.zeros((300, 36), dtype=np.float32)
+    dy.reshape(300, 3, 6, 2)[:, :, :2, :] = rng.standard_normal((300, 3, 2, 2))
+    dx = O.frequency_backward(x, 6, O.f2h(dy))
+    h = 2e-3
+    num = np.zeros_like(x)
+    for d in range(3):
+        e = np.zeros_like(x); e[:, d] = h
+        yp, ym = O.h2f(O.frequency_forward(x + e, 6)), O.h2f(O.frequency_forward(x - e, 6))
+        num[:, d] = ((yp - ym) * O.h2f(O.f2h(dy))).sum(1) / (2 * h)
+    assert np.allclose(dx, num, rtol=0.1, atol=0.1 * np.abs(num).max())

@@ -317,6 +317,9 @@ struct EncodingDesc {
 	// one-blob (oneblob.h:168-178): n_bins outputs per input dimension
 	bool is_oneblob = false;
 	uint32_t n_bins = 0;
+	// frequency (frequency.h:106-111): sin and cos of n_frequencies octaves per input dimension
+	bool is_frequency = false;
+	uint32_t n_frequencies = 0;
 	uint32_t n_dims = 0;
 	uint32_t n_output_dims = 0;  // before padding
 	uint32_t n_params = 0;
@@ -347,6 +350,9 @@ struct EncodingDesc {
 			j["interpolation"] = to_string((InterpolationType)grid.interp);
 			j["hash"] = "CoherentPrime";
 			if ((GridType)grid.grid_type == GridType::Hash) j["log2_hashmap_size"] = log2_hashmap_size;
+		} else if (is_frequency) {  // frequency.h:200-205
+			j["otype"] = "Frequency";
+			j["n_frequencies"] = n_frequencies;
 		} else if (is_oneblob) {  // oneblob.h:296-301
 			j["otype"] = "OneBlob";
 			j["n_bins"] = n_bins;
@@ -441,6 +447,13 @@ static EncodingDesc create_encoding_desc(uint32_t n_dims, const Json& enc, uint3
 		e.id_offset = enc.value("offset", 0.0f);
 		e.n_output_dims = n_dims;
 		e.padded_output_width = n_dims;
+	} else if (equals_case_insensitive(name, "Frequency")) {  // encoding.cu:65-67
+		e.is_frequency = true;
+		e.n_dims = n_dims;
+		e.n_frequencies = enc.value("n_frequencies", 12u);
+		if (e.n_frequencies == 0 || e.n_frequencies > 32) throw std::runtime_error("FrequencyEncoding: n_frequencies must be in [1, 32]");
+		e.n_output_dims = n_dims * e.n_frequencies * 2u;
+		e.padded_output_width = e.n_output_dims;
 	} else if (equals_case_insensitive(name, "OneBlob")) {  // encoding.cu:118-120
 		e.is_oneblob = true;
 		e.n_dims = n_dims;
@@ -449,7 +462,7 @@ static EncodingDesc create_encoding_desc(uint32_t n_dims, const Json& enc, uint3
 		e.n_output_dims = n_dims * e.n_bins;
 		e.padded_output_width = e.n_output_dims;
 	} else {
-		throw std::runtime_error("Encoding '" + name + "' not found (this build provides Grid/HashGrid/DenseGrid/TiledGrid, OneBlob and Identity)");
+		throw std::runtime_error("Encoding '" + name + "' not found (this build provides Grid/HashGrid/DenseGrid/TiledGrid, Frequency, OneBlob and Identity)");
 	}
 	if (alignment > 0) e.set_alignment(alignment);
 	return e;
@@ -515,7 +528,7 @@ struct Model {
 	size_t n_params() const { return n_mlp_params() + enc.n_params; }  // network first, then encoding (:115-122)
 	uint32_t padded_output_width() const { return has_network ? net.mlp.padded_out : enc.padded_output_width; }
 	uint32_t output_width() const { return has_network ? net.n_output_dims : enc.padded_output_width; }
-	std::string name() const { return has_network ? "NetworkWithInputEncoding" : (enc.is_grid ? "GridEncoding" : (enc.is_oneblob ? "OneBlobEncoding" : "IdentityEncoding")); }
+	std::string name() const { return has_network ? "NetworkWithInputEncoding" : (enc.is_grid ? "GridEncoding" : (enc.is_oneblob ? "OneBlobEncoding" : (enc.is_frequency ? "FrequencyEncoding" : "IdentityEncoding"))); }
 
 	void finish() {
 		Json j = Json::object();
@@ -586,6 +599,8 @@ static void encoding_forward(hipStream_t stream, const Model& md, uint32_t n, co
 				HIP_CHECK(hipMemset2DAsync(out + e.n_output_dims, (size_t)e.padded_output_width * sizeof(half_t), 0, (size_t)n_to_pad * sizeof(half_t), n, stream));
 			}
 		}
+	} else if (e.is_frequency) {
+		frequency_forward(stream, n, e.n_dims, e.n_frequencies, e.padded_output_width, input, md.n_input_dims, 1u, out, stride_k, stride_i);
 	} else if (e.is_oneblob) {
 		oneblob_forward(stream, n, e.n_dims, e.n_bins, e.padded_output_width, input, md.n_input_dims, 1u, out, stride_k, stride_i);
 	} else {
@@ -705,6 +720,8 @@ static void encoding_backward(hipStream_t stream, const Model& md, const Forward
 			if (!ctx.dy_dx.ptr) throw std::runtime_error("backward: dL_dinput requested but forward was not run with prepare_input_gradients");
 			grid_backward_input(stream, md.n_input_dims, e.n_output_dims, io, dL_denc, ctx.dy_dx.as<float>(), dL_dinput, md.n_input_dims, 1u);
 		}
+	} else if (dL_dinput && e.is_frequency) {
+		frequency_backward(stream, n, e.n_dims, e.n_frequencies, dL_denc, stride_k, stride_i, input, md.n_input_dims, 1u, dL_dinput, md.n_input_dims, 1u);
 	} else if (dL_dinput && e.is_oneblob) {
 		oneblob_backward(stream, n, e.n_dims, e.n_bins, dL_denc, stride_k, stride_i, input, md.n_input_dims, 1u, dL_dinput, md.n_input_dims, 1u);
 	} else if (dL_dinput) {

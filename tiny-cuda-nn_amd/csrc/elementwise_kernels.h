@@ -105,6 +105,12 @@ void identity_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t 
 void identity_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, float scale, const half_t* dL_dy, uint32_t stride_k,
                        uint32_t stride_i, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j);
 
+// encodings/frequency.h:46-104: sin / cos of 2^f pi x, padding value 1; dL/dinput recomputes the derivative the reference stores.
+void frequency_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_frequencies, uint32_t padded, const float* in, uint32_t in_stride_i,
+                       uint32_t in_stride_j, half_t* out, uint32_t stride_k, uint32_t stride_i);
+void frequency_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const half_t* dL_dy, uint32_t stride_k, uint32_t stride_i,
+                        const float* in, uint32_t in_stride_i, uint32_t in_stride_j, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j);
+
 // encodings/oneblob.h:84-164 (n_bins a power of two; padding value 1).  Same addressing conventions as the identity encoding.
 void oneblob_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_bins, uint32_t padded, const float* in, uint32_t in_stride_i,
                      uint32_t in_stride_j, half_t* out, uint32_t stride_k, uint32_t stride_i);

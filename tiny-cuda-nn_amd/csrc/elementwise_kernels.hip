@@ -466,6 +466,59 @@ void identity_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, float sc
 	TCNN_LAUNCH(k_identity_backward, dim3(div_round_up(n * n_dims, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, scale, dL_dy, stride_k, stride_i, dL_dx, dx_stride_i, dx_stride_j);
 }
 
+// ------------------------------------------------------------------------------------------ frequency
+// encodings/frequency.h:46-79, 82-104: output j of sample i = sin(2^f pi x_d + (j & 1) pi / 2), d = j / (2 n_frequencies),
+// f = (j / 2) % n_frequencies; padding 1.  The reference evaluates __sinf / __cosf (hardware approximations whose error grows
+// with the argument, up to 2^11 pi here); this kernel and the oracle evaluate sinf / cosf of the SAME fp32 argument
+// x 2^f * pi + phase, so parity with the reference is to its intrinsic's accuracy (a fp16 ulp at these magnitudes), parity
+// between kernel and oracle to libm rounding.  One thread per output element (k-major, i fastest).
+#define TCNN_PI_F 3.14159265358979323846f
+__global__ void __launch_bounds__(EW_THREADS) k_frequency_forward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, uint32_t padded, const float* __restrict__ in,
+                                                                  uint32_t in_stride_i, uint32_t in_stride_j, half_t* __restrict__ out, uint32_t stride_k,
+                                                                  uint32_t stride_i) {
+	const uint32_t e = blockIdx.x * EW_THREADS + threadIdx.x;
+	if (e >= n * padded) return;
+	const uint32_t j = e / n, i = e - j * n;
+	half_t v = (half_t)1.0f;
+	if (j < n_dims * n_frequencies * 2u) {
+		const uint32_t d = j / (n_frequencies * 2u), log2_frequency = (j / 2u) % n_frequencies;
+		const float phase_shift = (float)(j % 2u) * (TCNN_PI_F / 2);
+		const float x = __builtin_scalbnf(in[(size_t)i * in_stride_i + (size_t)d * in_stride_j], (int)log2_frequency);
+		const float input = x * TCNN_PI_F + phase_shift;
+		v = to_half_rn(sinf(input));
+	}
+	out[(size_t)j * stride_k + (size_t)i * stride_i] = v;
+}
+__global__ void __launch_bounds__(EW_THREADS) k_frequency_backward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const half_t* __restrict__ dL_dy,
+                                                                   uint32_t stride_k, uint32_t stride_i, const float* __restrict__ in, uint32_t in_stride_i,
+                                                                   uint32_t in_stride_j, float* __restrict__ dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
+	const uint32_t e = blockIdx.x * EW_THREADS + threadIdx.x;
+	if (e >= n * n_dims) return;
+	const uint32_t d = e / n, i = e - d * n, outputs_per_input = n_frequencies * 2u;
+	const float x0 = in[(size_t)i * in_stride_i + (size_t)d * in_stride_j];
+	float result = 0;
+	for (uint32_t k = 0; k < outputs_per_input; ++k) {
+		const uint32_t j = d * outputs_per_input + k, log2_frequency = k / 2u;
+		const float phase_shift = (float)(k % 2u) * (TCNN_PI_F / 2);
+		const float input = __builtin_scalbnf(x0, (int)log2_frequency) * TCNN_PI_F + phase_shift;
+		const float dy_dx = __builtin_scalbnf(1.0f, (int)log2_frequency) * TCNN_PI_F * cosf(input);  // what the reference's forward pass stores
+		result += (float)dL_dy[(size_t)j * stride_k + (size_t)i * stride_i] * dy_dx;
+	}
+	dL_dx[(size_t)i * dx_stride_i + (size_t)d * dx_stride_j] = result;
+}
+void frequency_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_frequencies, uint32_t padded, const float* in, uint32_t in_stride_i,
+                       uint32_t in_stride_j, half_t* out, uint32_t stride_k, uint32_t stride_i) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_frequency_forward, dim3(div_round_up(n * padded, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, n_frequencies, padded, in, in_stride_i,
+	            in_stride_j, out, stride_k, stride_i);
+}
+void frequency_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const half_t* dL_dy, uint32_t stride_k, uint32_t stride_i,
+                        const float* in, uint32_t in_stride_i, uint32_t in_stride_j, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_frequency_backward, dim3(div_round_up(n * n_dims, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, n_frequencies, dL_dy, stride_k, stride_i, in,
+	            in_stride_i, in_stride_j, dL_dx, dx_stride_i, dx_stride_j);
+}
+
 // ------------------------------------------------------------------------------------------ one-blob
 // encodings/oneblob.h:84-164 (the SoA kernels' arithmetic) with common_device.h:1076-1095 (quartic kernel).  One thread per
 // (dimension j, sample i), i fastest: the n_bins bin integrals of a quartic blob centred at x, wrapped around [0, 1).

@@ -71,7 +71,7 @@ def test_network_with_input_encoding_layout():
     ({"otype": "HashGrid"}, {"otype": "FullyFusedMLP", "n_neurons": 64, "n_hidden_layers": 0}, "at least 1 hidden layer"),
     ({"otype": "HashGrid", "n_features_per_level": 3}, {"n_neurons": 64}, "n_features_per_level must be 1, 2, 4, or 8"),
     ({"otype": "HashGrid", "n_features": 32, "n_levels": 16}, {"n_neurons": 64}, "may not specify n_features and n_levels"),
-    ({"otype": "Frequency"}, {"n_neurons": 64}, "not found"),
+    ({"otype": "SphericalHarmonics"}, {"n_neurons": 64}, "not found"),
     ({"otype": "HashGrid"}, {"otype": "Transformer"}, "Invalid network type"),
 ])
 def test_config_errors_raise_runtime_error(enc, net, msg):

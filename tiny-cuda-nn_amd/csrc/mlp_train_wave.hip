@@ -13,7 +13,7 @@ namespace tcnn_hip {
 // =============================================================================================
 // fused training pass, one wavefront per strip of 32 samples, everything in registers.
 //
-// k_mlp_train above shares a 64-sample tile between the waves of a workgroup: every layer costs each wave a read of
+// k_mlp_train (mlp_kernels.hip) shares a 64-sample tile between the waves of a workgroup: every layer costs each wave a read of
 // the whole activation tile from LDS, two LDS copies of what it produced (both layouts) and a workgroup barrier, and
 // the PMC counters show the LDS pipe, not MFMA or HBM, bounding it.  Here a wave owns its samples through all layers:
 //   * an MFMA accumulator tile (row 4g+r, col lr) IS a 16x16x16 B operand (k = 4g+j, n = lr), and two of them whose
@@ -27,9 +27,11 @@ namespace tcnn_hip {
 //     dL/dW_in; one MFMA against a selection matrix turns it into the first layer's B operand.  dL/dinput is
 //     produced sample-transposed (D = dA^T * W) so that it leaves as 16-byte feature-major stores.
 // The weights (both orientations, pre-arranged as operands) are read-only in LDS; nothing a wave computes for its
-// samples goes through LDS, which otherwise only serves the final reduction of the four waves' weight-gradient accumulators.  Same products, same k order and same rounding points
-// as k_mlp_forward / k_loss / k_mlp_backward: activations, outputs and dL/dinput are bit-identical; the fp32 weight
-// gradient partial sums are grouped differently.
+// samples goes through LDS, which otherwise only serves the final reduction of the four waves' weight-gradient
+// accumulators.  Same products and the same rounding points as k_mlp_forward / k_loss / k_mlp_backward: activations,
+// outputs and dL/doutput are bit-identical; the output layer's backward MFMA holds the outputs in permuted k slots
+// (out_perm) and the fp32 weight-gradient partial sums are grouped per wavefront, so dL/dinput and the weight
+// gradients agree to the association order of fp32 sums (a last fp16 bit in ~1e-5 / ~1e-3 of the entries).
 // =============================================================================================
 TCNN_DEVICE uint32_t perm32(uint32_t b, uint32_t row) { return 32u * (b >> 1) + 8u * (row >> 2) + 4u * (b & 1u) + (row & 3u); }
 // Output rows: accumulator row 4g+r of the output layer holds output 4r+g (a 4x4 transpose of the 16 padded outputs, done

@@ -9,6 +9,7 @@ ADAM = {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "ep
 def hash_enc(T=19, L=16): return {"otype": "HashGrid", "n_levels": L, "n_features_per_level": 2, "log2_hashmap_size": T, "base_resolution": 16, "per_level_scale": 2.0 if T <= 19 else 1.5}
 def mlp(w=64, h=2): return {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": w, "n_hidden_layers": h}
 CASES = [
+    ("cfg[0] data/config_oneblob.json: OneBlob(64) + MLP 128x5, 2D->3, N=2^14", 2, 3, {"otype": "OneBlob", "n_bins": 64}, mlp(128, 5), 1 << 14),
     ("cfg[1] MLP 64x2 only (Identity encoding), N=2^18", 16, 4, {"otype": "Identity"}, mlp(), 1 << 18),
     ("cfg[1] MLP 64x2 only, 64 inputs (benchmarks/mlp shape), N=2^18", 64, 16, {"otype": "Identity"}, mlp(), 1 << 18),
     ("cfg[2] headline, N=2^18", 3, 4, hash_enc(), mlp(), 1 << 18),

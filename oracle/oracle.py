@@ -63,6 +63,11 @@ class AdamHParams(C.Structure):
     ]
 
 
+class StepOptions(C.Structure):
+    _fields_ = [("data_pdf", C.c_void_p), ("external_dL_dy", C.c_void_p), ("dL_dinput", C.c_void_p), ("accum_fp16", C.c_int),
+                ("n_total_override", C.c_uint64)]
+
+
 class Model(C.Structure):
     _fields_ = [("grid", Grid), ("mlp", Mlp), ("loss_type", C.c_int), ("adam", AdamHParams),
                 ("n_params", C.c_uint32), ("n_out", C.c_uint32)]
@@ -84,6 +89,7 @@ def lib():
         _lib.orc_seed_seq_first.restype = C.c_uint32
         _lib.orc_grid_index.restype = C.c_uint32
         _lib.orc_training_step.restype = C.c_double
+        _lib.orc_training_step_ex.restype = C.c_double
     return _lib
 
 
@@ -218,12 +224,13 @@ def mlp_forward(m, params_h, input_h, accum_fp16=False):
     return hidden, out
 
 
-def mlp_backward(m, params_h, input_h, hidden, output, dL_doutput_h, want_dinput=True):
+def mlp_backward(m, params_h, input_h, hidden, output, dL_doutput_h, want_dinput=True, accum_fp16=False):
     n = input_h.shape[0]
     grad = np.zeros(m.n_params, dtype=np.float64)
     dinput = np.empty((n, m.in_width), dtype=np.uint16) if want_dinput else None
-    lib().orc_mlp_backward(C.byref(m), _p(params_h), _p(np.ascontiguousarray(input_h)), _p(hidden), _p(output),
-                           _p(np.ascontiguousarray(dL_doutput_h, dtype=np.uint16)), C.c_uint32(n), _p(grad), _p(dinput))
+    lib().orc_mlp_backward_ex(C.byref(m), _p(params_h), _p(np.ascontiguousarray(input_h)), _p(hidden), _p(output),
+                              _p(np.ascontiguousarray(dL_doutput_h, dtype=np.uint16)), C.c_uint32(n), _p(grad), _p(dinput),
+                              C.c_int(int(accum_fp16)))
     return grad, dinput
 
 
@@ -325,17 +332,24 @@ class TrainState:
         self.step = 0
 
 
-def training_step(st, positions, targets, loss_scale=128.0, run_optimizer=True, want_prediction=False):
+def training_step(st, positions, targets, loss_scale=128.0, run_optimizer=True, want_prediction=False, data_pdf=None,
+                  external_dL_dy=None, dL_dinput=None, accum_fp16=False, n_total=0):
+    """Trainer::training_step (trainer.h:254-357).  dL_dinput: float32 [n, n_dims] array that receives the input gradient."""
     md = st.md
     positions = np.ascontiguousarray(positions, dtype=np.float32)
-    targets = np.ascontiguousarray(targets, dtype=np.float32)
+    targets = None if targets is None else np.ascontiguousarray(targets, dtype=np.float32)
     n = positions.shape[0]
     pred = np.empty((n, md.mlp.padded_out), dtype=np.uint16) if want_prediction else None
     if run_optimizer:
         st.step += 1
-    l = lib().orc_training_step(C.byref(md), C.c_uint32(n), _p(positions), _p(targets), _p(st.w32), _p(st.w16),
-                                _p(st.grads), _p(st.m1), _p(st.m2), _p(st.steps), C.c_uint32(st.step),
-                                C.c_float(loss_scale), C.c_int(int(run_optimizer)), _p(pred))
+    keep = [None if a is None else np.ascontiguousarray(a, dtype=t) for a, t in ((data_pdf, np.float32), (external_dL_dy, np.uint16))]
+    if dL_dinput is not None:
+        assert dL_dinput.dtype == np.float32 and dL_dinput.flags["C_CONTIGUOUS"] and dL_dinput.shape == (n, md.grid.n_dims)
+    opt = StepOptions(keep[0].ctypes.data if keep[0] is not None else None, keep[1].ctypes.data if keep[1] is not None else None,
+                      dL_dinput.ctypes.data if dL_dinput is not None else None, int(accum_fp16), int(n_total))
+    l = lib().orc_training_step_ex(C.byref(md), C.c_uint32(n), _p(positions), _p(targets), _p(st.w32), _p(st.w16),
+                                   _p(st.grads), _p(st.m1), _p(st.m2), _p(st.steps), C.c_uint32(st.step),
+                                   C.c_float(loss_scale), C.c_int(int(run_optimizer)), _p(pred), C.byref(opt))
     return (float(l), pred) if want_prediction else float(l)
 
 

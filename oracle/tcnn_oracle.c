@@ -727,6 +727,16 @@ void orc_mlp_forward(const orc_mlp* m, const uint16_t* params, const uint16_t* i
 void orc_mlp_backward(const orc_mlp* m, const uint16_t* params, const uint16_t* input, const uint16_t* hidden,
                       const uint16_t* output, const uint16_t* dL_doutput, uint32_t n, double* grad_params,
                       uint16_t* dL_dinput) {
+	orc_mlp_backward_ex(m, params, input, hidden, output, dL_doutput, n, grad_params, dL_dinput, 0);
+}
+
+/* accum_fp16 != 0: the reference's accumulator type (wmma half fragments fully_fused_mlp.cu:68,198; CUTLASS
+ * ElementAccumulator = half, cutlass_matmul.h:67): the running sum is rounded to half after every 16 k-steps (one
+ * 16x16x16 MMA).  For the weight gradients k runs over the SAMPLES: each thread rounds its running sums every 16
+ * samples; the per-thread sums are combined in double (the reference's split-K reduction is not modelled). */
+void orc_mlp_backward_ex(const orc_mlp* m, const uint16_t* params, const uint16_t* input, const uint16_t* hidden,
+                         const uint16_t* output, const uint16_t* dL_doutput, uint32_t n, double* grad_params,
+                         uint16_t* dL_dinput, int accum_fp16) {
 	const uint32_t W = m->width, IN = m->in_width, OUT = m->padded_out, H = m->n_hidden;
 	float* Wf = (float*)malloc(sizeof(float) * m->n_params);
 	orc_h2f_array(params, Wf, m->n_params);
@@ -747,9 +757,14 @@ void orc_mlp_backward(const orc_mlp* m, const uint16_t* params, const uint16_t* 
 		float* d_cur = (float*)malloc(sizeof(float) * mx);
 		float* d_nxt = (float*)malloc(sizeof(float) * mx);
 		float* act = (float*)malloc(sizeof(float) * mx);
+		uint32_t since_round = 0;
 #pragma omp for schedule(static)
 		for (long long ii = 0; ii < (long long)n; ++ii) {
 			size_t i = (size_t)ii;
+			if (accum_fp16 && gp && ++since_round == 16) { /* one MMA k-step of samples done: half accumulators */
+				since_round = 0;
+				for (size_t k = 0; k < m->n_params; ++k) gp[k] = (double)orc_h2f(d2h(gp[k]));
+			}
 			/* output layer: dY (half) */
 			for (uint32_t o = 0; o < OUT; ++o) {
 				float d = orc_h2f(dL_doutput[i * OUT + o]);
@@ -779,6 +794,9 @@ void orc_mlp_backward(const orc_mlp* m, const uint16_t* params, const uint16_t* 
 						float d = d_cur[o];
 						const float* w = Wl + (size_t)o * n_prev;
 						for (uint32_t k = 0; k < n_prev; ++k) d_nxt[k] += w[k] * d;
+						if (accum_fp16 && (o % 16 == 15 || o + 1 == n_cur)) {
+							for (uint32_t k = 0; k < n_prev; ++k) d_nxt[k] = orc_h2f(orc_f2h(d_nxt[k]));
+						}
 					}
 					if (l >= 0) {
 						for (uint32_t k = 0; k < n_prev; ++k) {
@@ -1080,25 +1098,48 @@ double orc_training_step(const orc_model* md, uint32_t n, const float* positions
                          float* params_fp32, uint16_t* params_half, uint16_t* grads_half, float* m1,
                          float* m2, uint32_t* steps, uint32_t current_step, float loss_scale,
                          int run_optimizer, uint16_t* out_prediction) {
+	return orc_training_step_ex(md, n, positions, targets, params_fp32, params_half, grads_half, m1, m2, steps, current_step,
+	                            loss_scale, run_optimizer, out_prediction, NULL);
+}
+
+/* Trainer::training_step with its optional arguments (trainer.h:254-357): data_pdf (losses divide by it),
+ * external_dL_dy (replaces the loss gradient, trainer.h:124-128; the returned loss is then 0), dL_dinput
+ * (network_with_input_encoding.h:83-113 -> grid.h:897-907), the data-parallel n_total, and the fp16-accumulate
+ * bracket of the network numerics. */
+double orc_training_step_ex(const orc_model* md, uint32_t n, const float* positions, const float* targets,
+                            float* params_fp32, uint16_t* params_half, uint16_t* grads_half, float* m1,
+                            float* m2, uint32_t* steps, uint32_t current_step, float loss_scale,
+                            int run_optimizer, uint16_t* out_prediction, const orc_step_options* opt) {
 	const orc_mlp* m = &md->mlp;
 	const uint32_t IN = m->in_width, W = m->width, OUT = m->padded_out, H = m->n_hidden;
 	const uint16_t* mlp_params = params_half;                 /* network first ... */
 	const uint16_t* grid_params = params_half + m->n_params;  /* ... then encoding (nwie.h:115-122) */
+	const int accum_fp16 = opt ? opt->accum_fp16 : 0;
+	const uint32_t K = md->grid.n_levels * md->grid.n_features_per_level;
 
 	uint16_t* enc = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)n * IN);
 	uint16_t* hidden = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)n * W * H);
 	uint16_t* out = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)n * OUT);
 	uint16_t* dout = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)n * OUT);
-	float* L = (float*)malloc(sizeof(float) * (size_t)n * OUT);
+	float* L = (float*)calloc((size_t)n * OUT, sizeof(float));
 	uint16_t* denc = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)n * IN);
 	double* gmlp = (double*)calloc(m->n_params, sizeof(double));
 	double* ggrid = (double*)calloc(md->grid.n_params, sizeof(double));
+	float* dy_dx = (opt && opt->dL_dinput) ? (float*)malloc(sizeof(float) * (size_t)n * K * md->grid.n_dims) : NULL;
 
-	orc_grid_forward(&md->grid, grid_params, positions, n, enc, IN, NULL);
-	orc_mlp_forward(m, mlp_params, enc, n, hidden, out, 0);
-	orc_loss(md->loss_type, n, OUT, md->n_out, loss_scale, out, targets, NULL, L, dout, 0);
-	orc_mlp_backward(m, mlp_params, enc, hidden, out, dout, n, gmlp, denc);
+	memset(enc, 0, sizeof(uint16_t) * (size_t)n * IN); /* padded encoding columns are zero (grid.h:757-766) */
+	orc_grid_forward(&md->grid, grid_params, positions, n, enc, IN, dy_dx);
+	orc_mlp_forward(m, mlp_params, enc, n, hidden, out, accum_fp16);
+	const uint16_t* dL_dy = dout;
+	if (opt && opt->external_dL_dy) {
+		dL_dy = opt->external_dL_dy;
+	} else {
+		orc_loss(md->loss_type, n, OUT, md->n_out, loss_scale, out, targets, opt ? opt->data_pdf : NULL, L, dout,
+		         opt ? opt->n_total_override : 0);
+	}
+	orc_mlp_backward_ex(m, mlp_params, enc, hidden, out, dL_dy, n, gmlp, denc, accum_fp16);
 	orc_grid_backward(&md->grid, positions, n, denc, IN, ggrid);
+	if (dy_dx) orc_grid_backward_input(&md->grid, n, denc, IN, dy_dx, opt->dL_dinput);
 
 	double loss = 0.0;
 	for (size_t i = 0; i < (size_t)n * OUT; ++i) loss += (double)L[i];
@@ -1110,7 +1151,7 @@ double orc_training_step(const orc_model* md, uint32_t n, const float* positions
 		orc_adam_step(&md->adam, md->n_params, m->n_params, loss_scale, current_step, params_fp32, params_half,
 		              grads_half, m1, m2, steps);
 	}
-	free(enc); free(hidden); free(out); free(dout); free(L); free(denc); free(gmlp); free(ggrid);
+	free(enc); free(hidden); free(out); free(dout); free(L); free(denc); free(gmlp); free(ggrid); free(dy_dx);
 	return loss;
 }
 

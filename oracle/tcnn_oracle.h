@@ -139,6 +139,11 @@ void orc_mlp_backward(const orc_mlp* m, const uint16_t* params, const uint16_t* 
                       const uint16_t* output, const uint16_t* dL_doutput, uint32_t n, double* grad_params,
                       uint16_t* dL_dinput);
 
+/* the same with the reference's half accumulators emulated (see the definition) */
+void orc_mlp_backward_ex(const orc_mlp* m, const uint16_t* params, const uint16_t* input, const uint16_t* hidden,
+                         const uint16_t* output, const uint16_t* dL_doutput, uint32_t n, double* grad_params,
+                         uint16_t* dL_dinput, int accum_fp16);
+
 /* ---- losses (losses/relative_l2.h:40-76, losses/l2.h:40-76) ----
  * prediction half [N][stride]; target fp32 [N][dims]; values fp32 [N][stride]; gradients half [N][stride].
  * n_total_override: 0 -> N*dims (reference); else used as n_total (data-parallel global batch). */
@@ -190,6 +195,18 @@ double orc_training_step(const orc_model* md, uint32_t n, const float* positions
                          float* params_fp32, uint16_t* params_half, uint16_t* grads_half, float* m1,
                          float* m2, uint32_t* steps, uint32_t current_step, float loss_scale,
                          int run_optimizer, uint16_t* out_prediction /*[N][padded_out] or NULL*/);
+/* optional arguments of Trainer::training_step (trainer.h:254-264); any pointer may be NULL */
+typedef struct {
+	const float* data_pdf;          /* [N][n_out] */
+	const uint16_t* external_dL_dy; /* half [N][padded_out], replaces the loss gradient (trainer.h:124-128) */
+	float* dL_dinput;               /* out: [N][n_dims] */
+	int accum_fp16;                 /* network GEMMs with the reference's half accumulators */
+	uint64_t n_total_override;      /* loss normalisation count of the GLOBAL batch under data parallelism, 0 = N*dims */
+} orc_step_options;
+double orc_training_step_ex(const orc_model* md, uint32_t n, const float* positions, const float* targets,
+                            float* params_fp32, uint16_t* params_half, uint16_t* grads_half, float* m1,
+                            float* m2, uint32_t* steps, uint32_t current_step, float loss_scale,
+                            int run_optimizer, uint16_t* out_prediction, const orc_step_options* opt);
 void orc_inference(const orc_model* md, uint32_t n, const float* positions, const uint16_t* params_half,
                    float* out /*[N][n_out]*/);
 

@@ -368,3 +368,66 @@ def test_frequency_properties():
         yp, ym = O.h2f(O.frequency_forward(x + e, 6)), O.h2f(O.frequency_forward(x - e, 6))
         num[:, d] = ((yp - ym) * O.h2f(O.f2h(dy))).sum(1) / (2 * h)
     assert np.allclose(dx, num, rtol=0.1, atol=0.1 * np.abs(num).max())
+
+
+def _small_model(loss=O.LOSS_RELATIVE_L2):
+    g = O.grid_init(3, 8, 2, 12, 8, 1.5)
+    md = O.model_init(3, 4, g, 64, 2, loss, O.adam_defaults(learning_rate=1e-2, beta2=0.99, epsilon=1e-15, l2_reg=1e-6))
+    w = O.model_init_params(md, 7)
+    w[md.mlp.n_params:] *= 1.0e3
+    return md, w
+
+
+def _targets(pos):
+    return np.stack([0.5 + 0.5 * np.sin(6.2831853 * (c + 1) * pos[:, 0]) * np.cos(6.2831853 * pos[:, 1]) for c in range(4)], 1).astype(np.float32)
+
+
+def test_training_step_options_data_pdf_external_gradient_and_input_gradient():
+    """Optional arguments of Trainer::training_step (trainer.h:254-264) in the oracle's whole-step restatement."""
+    md, w = _small_model()
+    n = 512
+    pos = O.generate_random_uniform(O.pcg32(5), n * 3).reshape(n, 3)
+    tgt = _targets(pos)
+    base = O.TrainState(md, w)
+    l0, pred = O.training_step(base, pos, tgt, run_optimizer=False, want_prediction=True)
+    g0 = O.h2f(base.grads)
+    # data_pdf == 2 everywhere: every loss value and gradient is divided by two, exactly (relative_l2.h:64-76)
+    st = O.TrainState(md, w)
+    l1 = O.training_step(st, pos, tgt, run_optimizer=False, data_pdf=np.full((n, 4), 2.0, np.float32))
+    assert abs(l1 - l0 / 2) <= 1e-6 * abs(l0)
+    v, dl = O.loss(md.loss_type, pred, tgt, 4)
+    v2, dl2 = O.loss(md.loss_type, pred, tgt, 4, data_pdf=np.full((n, 4), 2.0, np.float32))
+    assert np.array_equal(v2, v / 2) and np.allclose(O.h2f(dl2), O.h2f(dl) / 2, rtol=0, atol=6e-8)
+    # external_dL_dy equal to the loss gradient reproduces the step's gradients; the loss is then not evaluated
+    st = O.TrainState(md, w)
+    dx = np.zeros((n, 3), np.float32)
+    l2 = O.training_step(st, pos, None, run_optimizer=False, external_dL_dy=dl, dL_dinput=dx)
+    assert l2 == 0.0 and np.array_equal(st.grads, base.grads)
+    assert np.isfinite(dx).all() and np.abs(dx).max() > 0
+    # ... and the input gradient is linear in it (power-of-two scaling is exact in fp16 away from the subnormals)
+    st = O.TrainState(md, w)
+    dx2 = np.zeros((n, 3), np.float32)
+    O.training_step(st, pos, None, run_optimizer=False, external_dL_dy=O.f2h(O.h2f(dl) * 2), dL_dinput=dx2)
+    assert np.allclose(dx2, 2 * dx, rtol=2e-3, atol=1e-3 * np.abs(dx).max())
+    # global-batch normalisation (data parallel): n_total = 2 n halves the gradients
+    st = O.TrainState(md, w)
+    O.training_step(st, pos, tgt, run_optimizer=False, n_total=2 * n * 4)
+    assert np.allclose(O.h2f(st.grads), g0 / 2, rtol=2e-3, atol=1e-4 * np.abs(g0).max())
+
+
+def test_fp16_accumulate_mode_brackets_the_fp32_accumulate_results():
+    """The reference accumulates the network GEMMs in half (fully_fused_mlp.cu:68,198; cutlass_matmul.h:67); the oracle's
+    default is fp32.  The two modes must agree to fp16 accuracy, and differ (otherwise the switch does nothing)."""
+    md, w = _small_model()
+    n = 1024
+    pos = O.generate_random_uniform(O.pcg32(9), n * 3).reshape(n, 3)
+    tgt = _targets(pos)
+    a, b = O.TrainState(md, w), O.TrainState(md, w)
+    la, pa = O.training_step(a, pos, tgt, run_optimizer=False, want_prediction=True)
+    lb, pb = O.training_step(b, pos, tgt, run_optimizer=False, want_prediction=True, accum_fp16=True)
+    pa, pb = O.h2f(pa)[:, :4], O.h2f(pb)[:, :4]
+    assert not np.array_equal(pa, pb)
+    assert np.abs(pa - pb).max() < 2e-2 and abs(la - lb) < 2e-2 * abs(la)
+    ga, gb = O.h2f(a.grads)[:md.mlp.n_params], O.h2f(b.grads)[:md.mlp.n_params]
+    assert not np.array_equal(ga, gb)
+    assert np.linalg.norm(ga - gb) < 3e-2 * np.linalg.norm(ga)

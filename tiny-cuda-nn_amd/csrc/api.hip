@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <functional>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -47,17 +48,38 @@ static void log_message(int severity, const std::string& msg) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// stream-keyed scratch cache (stands where the reference's per-stream GPUMemoryArena stands,
-// gpu_memory.h:405-700): blocks are recycled per stream, so steady-state steps allocate nothing
-// (a precondition for hipGraph capture) and a recycled block is only ever reused in stream order.
+// (device, stream)-keyed scratch cache (stands where the reference's per-stream GPUMemoryArena stands,
+// gpu_memory.h:405-700; its null-stream arenas are per device, global_gpu_memory_arenas()[cuda_device()]): blocks are
+// recycled per stream of one device, so steady-state steps allocate nothing (a precondition for hipGraph capture), a
+// recycled block is only ever reused in stream order, and a block never crosses to another GPU (the default stream's
+// handle is 0 on every device).
 // ------------------------------------------------------------------------------------------------
+typedef std::pair<int, hipStream_t> StreamKey;
+static StreamKey stream_key(hipStream_t stream) {
+	int device = 0;
+	(void)hipGetDevice(&device);
+	return {device, stream};
+}
+// synchronises and frees `blocks` with their own device current
+template <typename F>
+static void for_each_device_of(const std::map<StreamKey, F>& m, const std::function<void(const StreamKey&, const F&)>& fn) {
+	int before = 0;
+	(void)hipGetDevice(&before);
+	for (auto& kv : m) {
+		(void)hipSetDevice(kv.first.first);
+		(void)hipDeviceSynchronize();
+		fn(kv.first, kv.second);
+	}
+	(void)hipSetDevice(before);
+}
+
 class ScratchCache {
 public:
 	static void* acquire(hipStream_t stream, size_t bytes, size_t* granted) {
 		bytes = next_multiple(bytes ? bytes : (size_t)1, (size_t)256);
 		{
 			std::lock_guard<std::mutex> lock(mutex());
-			auto& fl = lists()[stream];
+			auto& fl = lists()[stream_key(stream)];
 			auto it = fl.lower_bound(bytes);
 			if (it != fl.end() && it->first <= 2 * bytes) {
 				void* p = it->second;
@@ -71,15 +93,15 @@ public:
 		*granted = bytes;
 		return p;
 	}
-	static void release(hipStream_t stream, void* p, size_t bytes) {
+	static void release(const StreamKey& key, void* p, size_t bytes) {
 		std::lock_guard<std::mutex> lock(mutex());
-		lists()[stream].emplace(bytes, p);
+		lists()[key].emplace(bytes, p);
 	}
 	static void free_all() {
 		std::lock_guard<std::mutex> lock(mutex());
-		(void)hipDeviceSynchronize();
-		for (auto& kv : lists())
-			for (auto& b : kv.second) (void)hipFree(b.second);
+		for_each_device_of<std::multimap<size_t, void*>>(lists(), [](const StreamKey&, const std::multimap<size_t, void*>& blocks) {
+			for (auto& b : blocks) (void)hipFree(b.second);
+		});
 		lists().clear();
 	}
 
@@ -88,8 +110,8 @@ private:
 		static std::mutex m;
 		return m;
 	}
-	static std::map<hipStream_t, std::multimap<size_t, void*>>& lists() {
-		static std::map<hipStream_t, std::multimap<size_t, void*>> l;
+	static std::map<StreamKey, std::multimap<size_t, void*>>& lists() {
+		static std::map<StreamKey, std::multimap<size_t, void*>> l;
 		return l;
 	}
 };
@@ -100,7 +122,7 @@ class ZeroedCounters {
 public:
 	static uint32_t* get(hipStream_t stream, size_t n) {
 		std::lock_guard<std::mutex> lock(mutex());
-		auto& slot = slots()[stream];
+		auto& slot = slots()[stream_key(stream)];
 		if (slot.second < n) {
 			if (slot.first) {
 				HIP_CHECK(hipStreamSynchronize(stream));
@@ -117,8 +139,7 @@ public:
 	}
 	static void free_all() {
 		std::lock_guard<std::mutex> lock(mutex());
-		(void)hipDeviceSynchronize();
-		for (auto& kv : slots()) (void)hipFree(kv.second.first);
+		for_each_device_of<std::pair<uint32_t*, size_t>>(slots(), [](const StreamKey&, const std::pair<uint32_t*, size_t>& slot) { (void)hipFree(slot.first); });
 		slots().clear();
 	}
 
@@ -127,8 +148,8 @@ private:
 		static std::mutex m;
 		return m;
 	}
-	static std::map<hipStream_t, std::pair<uint32_t*, size_t>>& slots() {
-		static std::map<hipStream_t, std::pair<uint32_t*, size_t>> s;
+	static std::map<StreamKey, std::pair<uint32_t*, size_t>>& slots() {
+		static std::map<StreamKey, std::pair<uint32_t*, size_t>> s;
 		return s;
 	}
 };
@@ -136,9 +157,9 @@ private:
 struct Scratch {
 	void* ptr = nullptr;
 	size_t bytes = 0;
-	hipStream_t stream = nullptr;
+	StreamKey stream = {0, nullptr};  // (device, stream) the block belongs to
 	Scratch() = default;
-	Scratch(hipStream_t s, size_t n_bytes) : stream(s) { ptr = ScratchCache::acquire(s, n_bytes, &bytes); }
+	Scratch(hipStream_t s, size_t n_bytes) : stream(stream_key(s)) { ptr = ScratchCache::acquire(s, n_bytes, &bytes); }
 	Scratch(const Scratch&) = delete;
 	Scratch& operator=(const Scratch&) = delete;
 	Scratch(Scratch&& o) noexcept { *this = std::move(o); }
@@ -568,11 +589,16 @@ struct Model {
 	}
 };
 
-static void check_batch(uint32_t n) {
+static void check_batch(uint32_t n, uint32_t widest = 128) {
 	if (n % BATCH_SIZE_GRANULARITY != 0) {  // object.h:170, 217, 298
 		throw std::runtime_error("Batch size " + std::to_string(n) + " must be a multiple of " + std::to_string(BATCH_SIZE_GRANULARITY) + ".");
 	}
+	// the element-wise kernels index (sample, feature) pairs with 32 bits
+	if ((uint64_t)n * widest > 0xFFFFFFFFull) {
+		throw std::runtime_error("Batch size " + std::to_string(n) + " x " + std::to_string(widest) + " features exceeds 2^32 elements; split the batch.");
+	}
 }
+static uint32_t widest_matrix(const struct Model& md);
 
 struct ForwardCtx {
 	hipStream_t stream = nullptr;
@@ -611,7 +637,7 @@ static void encoding_forward(hipStream_t stream, const Model& md, uint32_t n, co
 // NetworkWithInputEncoding::forward_impl / inference_mixed_precision_impl (:60-81).  ctx == nullptr: inference.
 static void model_forward(hipStream_t stream, const Model& md, uint32_t n, const float* input, half_t* output, const half_t* params,
                           ForwardCtx* ctx, bool prepare_input_gradients) {
-	check_batch(n);
+	check_batch(n, widest_matrix(md));
 	if (n == 0) return;
 	if (ctx) {
 		ctx->stream = stream;
@@ -642,12 +668,18 @@ static void model_forward(hipStream_t stream, const Model& md, uint32_t n, const
 static void encoding_backward(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const half_t* dL_denc,
                               uint32_t stride_k, uint32_t stride_i, half_t* dL_dparams, bool want_grads, bool accumulate, const float* input,
                               uint32_t lds_level_budget);
+static uint32_t widest_matrix(const Model& md) {
+	uint32_t w = std::max(md.enc.padded_output_width, md.n_input_dims);
+	if (md.has_network) w = std::max(w, std::max(md.net.mlp.width * md.net.n_hidden_layers, md.net.mlp.padded_out));
+	if (md.enc.is_grid) w = std::max(w, md.enc.n_output_dims * md.n_input_dims);  // dy_dx
+	return w;
+}
 
 // NetworkWithInputEncoding::backward_impl (:83-113) / GridEncodingTemplated::backward_impl (grid.h:817-908)
 static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const half_t* dL_doutput,
                            half_t* dL_dparams, const float* input, const half_t* output, const half_t* params, int gradient_mode,
                            uint32_t lds_level_budget) {
-	check_batch(n);
+	check_batch(n, widest_matrix(md));
 	if (n == 0) return;
 	if (ctx.n != n) throw std::runtime_error("backward: batch size does not match the forward context");
 	if (md.has_network && !ctx.hidden.ptr) {
@@ -784,6 +816,9 @@ struct tcnn_trainable_model {
 	// `params` invalidates it
 	half_t* params_t = nullptr;
 	bool params_t_valid = false;
+	// a mutable pointer to `params` has left the library (tcnn_trainer_params / _params_inference): the caller may write
+	// through it at any time, so from then on the transposed copy is rebuilt before every pass that needs it
+	bool params_exposed = false;
 	uint32_t optimizer_step = 0;
 	Pcg32 rng;
 	void* buffer = nullptr;  // [fp32 master | half params | half grads], trainer.h:76, 489-495
@@ -906,7 +941,7 @@ int tcnn_module_backward_backward_input(tcnn_module_t* m, tcnn_stream_t stream_,
 	}
 	TCNN_API_BEGIN
 	if (!ctx) throw std::runtime_error("backward_backward_input: missing forward context");
-	check_batch(n);
+	check_batch(n, widest_matrix(m->md));
 	if (n == 0) return TCNN_OK;
 	if (ctx->ctx.n != n) throw std::runtime_error("backward_backward_input: batch size does not match the forward context");
 	if (!dL_ddLdinput) throw std::runtime_error("backward_backward_input: dL_ddLdinput is required");
@@ -1114,6 +1149,7 @@ static void refresh_hyper_json(tcnn_trainable_model* tm) {  // trainer.h:385-391
 static void cast_master_to_params(tcnn_trainable_model* tm, hipStream_t stream) {  // trainer.h:409-421
 	cast_f32_to_f16(stream, tm->md.n_params(), tm->master, tm->params);
 	tm->params_t_valid = false;
+	HIP_CHECK(hipMemsetAsync(tm->grads, 0, tm->md.n_params() * sizeof(half_t), stream));  // reset_param_gradients, trainer.h:419
 }
 
 // transposed network weights matching `params` (the pointer the pass is about to use)
@@ -1124,7 +1160,7 @@ static const half_t* trainer_params_t(tcnn_trainable_model* tm, hipStream_t stre
 		mlp_transpose_weights(stream, tm->md.net.mlp, params, local.as<half_t>());
 		return local.as<half_t>();
 	}
-	if (!tm->params_t_valid) {
+	if (!tm->params_t_valid || tm->params_exposed) {
 		mlp_transpose_weights(stream, tm->md.net.mlp, tm->params, tm->params_t);
 		tm->params_t_valid = true;
 	}
@@ -1302,7 +1338,7 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 	const half_t* params = use_inference_params ? tm->inference_params() : tm->params;
 	ProfilerGuard pg(tm->profiler.get());
 	const Model& md = tm->md;
-	check_batch(n);
+	check_batch(n, widest_matrix(md));
 	auto c = std::make_unique<tcnn_train_context>();
 	c->n = n;
 	c->stream = stream;
@@ -1409,10 +1445,13 @@ int tcnn_network_inference(tcnn_trainable_model_t* tm, tcnn_stream_t stream_, ui
 size_t tcnn_trainer_n_params(const tcnn_trainable_model_t* tm) { return tm->md.n_params(); }
 float* tcnn_trainer_params_full_precision(tcnn_trainable_model_t* tm) { return tm->master; }
 void* tcnn_trainer_params(tcnn_trainable_model_t* tm) {
-	tm->params_t_valid = false;  // a mutable pointer leaves the library: assume the caller writes through it
+	tm->params_exposed = true;  // a mutable pointer leaves the library: assume the caller writes through it, now or later
 	return tm->params;
 }
-void* tcnn_trainer_params_inference(tcnn_trainable_model_t* tm) { return tm->inference_params(); }
+void* tcnn_trainer_params_inference(tcnn_trainable_model_t* tm) {
+	if (!tm->ema) tm->params_exposed = true;  // the same buffer as `params` (trainer.h:497-500)
+	return tm->inference_params();
+}
 void* tcnn_trainer_param_gradients(tcnn_trainable_model_t* tm) { return tm->grads; }
 
 int tcnn_trainer_set_params_full_precision(tcnn_trainable_model_t* tm, const float* params, size_t n_params, int device_ptr) {
@@ -1430,6 +1469,7 @@ int tcnn_trainer_set_params(tcnn_trainable_model_t* tm, const void* params_fp16,
 	HIP_CHECK(hipMemcpy(tm->params, params_fp16, sizeof(half_t) * n_params, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
 	tm->params_t_valid = false;
 	cast_f16_to_f32(nullptr, n_params, tm->params, tm->master);
+	HIP_CHECK(hipMemsetAsync(tm->grads, 0, n_params * sizeof(half_t), nullptr));  // reset_param_gradients, trainer.h:437
 	HIP_CHECK(hipDeviceSynchronize());
 	TCNN_API_END
 }
@@ -1508,6 +1548,7 @@ int tcnn_trainer_deserialize(tcnn_trainable_model_t* tm, const void* data, size_
 		HIP_CHECK(hipMemcpy(tm->params, s.params.data, s.params.size, hipMemcpyHostToDevice));
 		tm->params_t_valid = false;
 		cast_f16_to_f32(nullptr, n, tm->params, tm->master);
+		HIP_CHECK(hipMemsetAsync(tm->grads, 0, n * sizeof(half_t), nullptr));
 	} else {
 		throw std::runtime_error("Trainer: snapshot parameters must be of type float of __half");  // trainer.h:473
 	}

@@ -279,6 +279,103 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward(const GridMeta me
 	}
 }
 
+// ---------------------------------------------------------------------------------------------
+// forward, the form training and inference run (no dy_dx).
+//
+// What bounds it (scripts/microbench_l1.hip, profiles/r02_microbench_l1.txt): a gather instruction whose 64 lanes miss
+// the CU's L1 costs ~150 clk per CU however wide the access is and whatever cache-policy bits it carries -- the XCD's
+// L2 hands out one 128-byte line per channel and clock (~263 G lines/s chip-wide), and each x-neighbour corner pair of
+// a sample is one line with 8 useful bytes in it.  The same instruction costs ~37 clk when it hits L1, ~20 clk for the
+// 12-byte-strided position loads, ~16 clk from LDS.  So the levers are (1) as few instructions per (sample, level) as
+// possible besides the 2^(D-1) line fetches, (2) an even load per XCD:
+//   * a thread owns SPT samples of ONE level and issues all their 2^D * SPT gathers before the first use (walking
+//     several levels per block with the positions loaded once measured slower: two tables then compete for the L2);
+//   * the (level, tile) items are laid end to end, each with a cost weight (tables that fit the CU's L1 are cheap),
+//     and cut into 8 runs of equal cost, one per XCD (block b runs on XCD b % 8 -- observed, only speed depends on
+//     it): every XCD sees its 1-3 tables, 2 MiB each at the headline size, hot in its private 4 MiB L2.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t FWD_MAX_SEGMENTS = 20;  // per XCD: ceil(MAX_N_LEVELS / 8) + the two cut levels at the ends of a run
+struct ForwardPlan {
+	uint32_t tiles;  // sample tiles per level
+	uint32_t n_segments[8];
+	struct Segment {
+		uint32_t level, tile_begin, tile_end;
+	} segments[8][FWD_MAX_SEGMENTS];
+};
+
+template <uint32_t D, uint32_t F, uint32_t SPT, bool FAST>
+TCNN_DEVICE void grid_forward_tile(const Level<D>& lv, const GridIO& io, const half_t* __restrict__ grid, uint32_t level, uint32_t first,
+                                   const float (&x)[SPT][D], half_t* __restrict__ out) {
+	constexpr uint32_t NP = (F + 1) / 2, NC = 1u << D;
+	Cell<D> c[SPT];
+	h2 val[SPT][NC][NP];
+#pragma unroll
+	for (uint32_t s = 0; s < SPT; ++s) {
+		c[s] = make_cell<D, FAST>(lv, x[s]);
+#pragma unroll
+		for (uint32_t idx = 0; idx < NC; ++idx) load_features<F>(grid + (size_t)corner_index<D, FAST>(lv, c[s], idx) * F, val[s][idx]);
+	}
+#pragma unroll
+	for (uint32_t s = 0; s < SPT; ++s) {
+		h2 result[NP];
+#pragma unroll
+		for (uint32_t p = 0; p < NP; ++p) result[p] = h2{(half_t)0.0f, (half_t)0.0f};
+#pragma unroll
+		for (uint32_t idx = 0; idx < NC; ++idx) {  // corner order and fp16 fma chain of grid.h:144-163
+			const half_t wh = to_half_rn(corner_weight<D>(c[s], idx));
+			const h2 w2 = h2{wh, wh};
+#pragma unroll
+			for (uint32_t p = 0; p < NP; ++p) result[p] = fma_h2(w2, val[s][idx][p], result[p]);
+		}
+		const uint32_t i = first + s * GRID_THREADS + threadIdx.x;
+		if (i < io.n) {
+#pragma unroll
+			for (uint32_t f = 0; f < F; ++f) out[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i] = result[f / 2][f % 2];
+		}
+	}
+}
+
+template <uint32_t D, uint32_t F, uint32_t SPT>
+__global__ void __launch_bounds__(GRID_THREADS) k_grid_forward_tiles(const GridMeta meta, const GridIO io, const ForwardPlan plan,
+                                                                      const half_t* __restrict__ params, half_t* __restrict__ out) {
+	constexpr uint32_t TILE = GRID_THREADS * SPT;
+	// block -> (segment of its XCD's run, tile): level-major, so an XCD walks one table at a time
+	const uint32_t xcd = blockIdx.x & 7u;
+	uint32_t slot = blockIdx.x >> 3, level = 0, tile = 0;
+	bool found = false;
+	for (uint32_t k = 0; k < plan.n_segments[xcd]; ++k) {
+		const ForwardPlan::Segment seg = plan.segments[xcd][k];
+		const uint32_t n = seg.tile_end - seg.tile_begin;
+		if (slot < n) {
+			level = seg.level;
+			tile = seg.tile_begin + slot;
+			found = true;
+			break;
+		}
+		slot -= n;
+	}
+	if (!found) return;
+	const uint32_t first = tile * TILE;
+	float x[SPT][D];
+#pragma unroll
+	for (uint32_t s = 0; s < SPT; ++s) load_position<D>(io, min(first + s * GRID_THREADS + threadIdx.x, io.n - 1u), x[s]);
+	const Level<D> lv = make_level<D>(meta, level);
+	const half_t* __restrict__ grid = params + (size_t)meta.offset[level] * F;
+	const uint32_t n_features = meta.n_levels * F;
+	const float max_level = (meta.max_level * (float)n_features) / (float)F;  // grid.h:72
+	const bool level_off = (float)level >= max_level + 1e-3f;               // grid.h:75
+	if (level_off || lv.nearest) {  // rare forms: one sample at a time
+		for (uint32_t s = 0; s < SPT; ++s) {
+			const uint32_t i = first + s * GRID_THREADS + threadIdx.x;
+			if (i < io.n) grid_forward_sample<D, F, false, false>(lv, io, grid, level, i, level_off, out, nullptr);
+		}
+	} else if (lv.fast) {  // wave-uniform: one lean code path per level kind
+		grid_forward_tile<D, F, SPT, true>(lv, io, grid, level, first, x, out);
+	} else {
+		grid_forward_tile<D, F, SPT, false>(lv, io, grid, level, first, x, out);
+	}
+}
+
 // =============================================================================================
 // backward, the reference's formulation (grid.h:215-320): one packed-half global atomic per corner.
 // Kept for A/B measurements only (F >= 2): scattered global atomics top out at ~21 G updates/s on
@@ -1112,8 +1209,72 @@ __global__ void k_grid_indices(const GridMeta meta, const GridIO io, uint32_t* _
 		default: throw std::runtime_error("GridEncoding: number of input dims must be 2, 3 or 4."); \
 	}
 
+// Cuts the (level, tile) items, level-major, into 8 runs of equal cost.  Cost of an item (measured per kind of level,
+// profiles/r02_exp_forward.txt): 4 for a level whose table fits a CU's 32 KiB L1 next to the streaming traffic
+// (<= 24 KiB), 8 for a hashed level (one L2 line per corner pair), 11 for a larger densely indexed level.  Falls back
+// to uniform costs if a run would need more than FWD_MAX_SEGMENTS segments.
+static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t tile_samples) {
+	for (int uniform = 0; uniform < 2; ++uniform) {
+		ForwardPlan plan = {};
+		plan.tiles = div_round_up(n, tile_samples);
+		uint64_t total = 0;
+		uint32_t cost[MAX_N_LEVELS];
+		for (uint32_t l = 0; l < meta.n_levels; ++l) {
+			const size_t table_bytes = (size_t)(meta.offset[l + 1] - meta.offset[l]) * meta.n_feat * sizeof(half_t);
+			const uint32_t entries = meta.offset[l + 1] - meta.offset[l];
+			const bool pow2 = (entries & (entries - 1u)) == 0u;  // hashed levels; densely indexed ones measure dearer per sample
+			cost[l] = uniform ? 8u : (table_bytes <= 24u * 1024u ? 4u : (pow2 ? 8u : 11u));
+			total += (uint64_t)cost[l] * plan.tiles;
+		}
+		bool ok = true;
+		uint64_t done = 0;  // cost of the items already assigned
+		uint32_t xcd = 0;
+		for (uint32_t l = 0; l < meta.n_levels && ok; ++l) {
+			uint32_t t = 0;
+			while (t < plan.tiles) {
+				// XCD `xcd` takes items while the cost assigned so far stays below its cumulative share
+				const uint64_t limit = (total * (xcd + 1) + 7) / 8;
+				uint32_t take = (uint32_t)std::min<uint64_t>(plan.tiles - t, (limit - done + cost[l] - 1) / cost[l]);
+				if (xcd == 7) take = plan.tiles - t;
+				if (take > 0) {
+					uint32_t& ns = plan.n_segments[xcd];
+					if (ns == FWD_MAX_SEGMENTS) {
+						ok = false;
+						break;
+					}
+					plan.segments[xcd][ns++] = {l, t, t + take};
+					t += take;
+					done += (uint64_t)take * cost[l];
+				}
+				if (done >= limit && xcd < 7) ++xcd;
+			}
+		}
+		if (ok) return plan;
+	}
+	throw std::runtime_error("grid_forward: could not build the work plan");
+}
+
+template <uint32_t D, uint32_t F, uint32_t SPT>
+static void launch_forward_tiles(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* params, half_t* out) {
+	const ForwardPlan plan = make_forward_plan(meta, io.n, GRID_THREADS * SPT);
+	uint32_t slots = 0;
+	for (uint32_t x = 0; x < 8; ++x) {
+		uint32_t n = 0;
+		for (uint32_t k = 0; k < plan.n_segments[x]; ++k) n += plan.segments[x][k].tile_end - plan.segments[x][k].tile_begin;
+		slots = std::max(slots, n);
+	}
+	TCNN_LAUNCH((k_grid_forward_tiles<D, F, SPT>), dim3(8u * slots), dim3(GRID_THREADS), 0, stream, meta, io, plan, params, out);
+}
+
 void grid_forward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* params, half_t* out, float* dy_dx) {
 	if (io.n == 0) return;
+	static const bool per_sample_form = getenv("TCNN_GRID_FWD") && atoi(getenv("TCNN_GRID_FWD")) == 0;  // A/B switch: the first implementation
+	if (!dy_dx && out && !per_sample_form) {
+#define FWD_TILES(D_, F_) launch_forward_tiles<D_, F_, 2>(stream, meta, io, params, out);
+		TCNN_GRID_DISPATCH(FWD_TILES)
+#undef FWD_TILES
+		return;
+	}
 	const uint32_t blocks = grid_n_blocks(meta.n_levels, io.n);
 #define FWD(D_, F_)                                                                                                                        \
 	if (dy_dx) {                                                                                                                           \

@@ -2,22 +2,29 @@
 """Headline benchmark: training samples/s of HashGrid + FullyFusedMLP(64, 2 hidden) at batch 2^18 per GPU
 (BASELINE.json `metric`; workload = BASELINE.json configs[2] / SURVEY.md 8d "cfg3").
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 1000 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
 One step = trainer.training_step (grid forward -> fused MLP forward -> RelativeL2 loss -> fused MLP backward
 incl. weight gradients -> grid backward scatter -> Adam) on one batch of synthetic 3-D -> 4 samples that is
-already resident in HBM.  For N > 1 every rank trains on its own 2^18-sample shard of a global batch of
-N * 2^18 (weak scaling), loss gradients are normalised by the global batch, and the fp16 gradient buffer
-[MLP | grid] is all-reduced (RCCL over xGMI) between backward and the optimizer step.
+already resident in HBM (positions drawn by the library's pcg32 kernel, seed 1337 + rank).
+For N > 1 every rank trains on its own shard -- 2^18 samples each (weak scaling, the default) or 2^18 / N
+(strong scaling) -- loss gradients are normalised by the global batch, and the fp16 gradient buffer [MLP | grid]
+is exchanged over RCCL/xGMI between backward and the optimizer step (tinycudann/parallel.py: reduce-scatter ->
+Adam on the rank's own 1/N of the parameters -> all-gather of the fp16 parameters).
+
+Other workloads of BASELINE.json (`--workload`), same protocol, each with its own roofline (they are parity-test cases
+and measurements for profiles/, not the driver's bench line):
+    mlp     configs[1]: FullyFusedMLP 64 -> 64x2 -> 16, ReLU, no encoding, L2 loss against zero, batch 2^18
+    stress  configs[4]: HashGrid T=2^22 + FullyFusedMLP 128x4, 3-D -> 16, batch 2^18
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
   roofline     -- the dominant kernel of the step, timed with HIP events on the stream it runs on inside the
                   timed region (tcnn_trainer_set_profiling), against the 8 TB/s HBM peak;
   cpu_baseline -- the CPU oracle ("port": the reference has no CPU path and cannot be built here) timed on
-                  this box's host cores on the same workload (rank 0, --gpus 1 only);
-  stages       -- per-stage mean times of a second, fully instrumented pass (not part of `value`).
+                  this box's host cores on the same workload and the same first batch (rank 0, --gpus 1 only);
+  stages_ms    -- per-stage mean times of a second, fully instrumented pass (not part of `value`).
 """
 import argparse
 import json
@@ -33,90 +40,171 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 BATCH = 1 << 18
-N_IN, N_OUT = 3, 4
-CONFIG = {
-    "loss": {"otype": "RelativeL2"},
-    "optimizer": {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6},
-    "encoding": {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19,
-                 "base_resolution": 16, "per_level_scale": 2.0},
-    "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2},
+ADAM = {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6}  # data/config_hash.json:5-12
+
+
+def _hash(log2_t, scale):
+    return {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": log2_t, "base_resolution": 16, "per_level_scale": scale}
+
+
+def _mlp(width, hidden):
+    return {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": width, "n_hidden_layers": hidden}
+
+
+WORKLOADS = {
+    "hash": {
+        "n_in": 3, "n_out": 4, "metric": "training samples/s, HashGrid+FullyFusedMLP(64,2) @ batch 2^18",
+        "config": {"loss": {"otype": "RelativeL2"}, "optimizer": ADAM, "encoding": _hash(19, 2.0), "network": _mlp(64, 2)},
+        "describe": "BASELINE configs[2]: HashGrid(L=16,F=2,T=2^19,base 16,per_level_scale 2.0) + FullyFusedMLP 64x2 ReLU, 3D->4, "
+                    "RelativeL2, Adam(config_hash.json), training_step incl. optimizer",
+    },
+    "mlp": {
+        "n_in": 64, "n_out": 16, "metric": "training samples/s, FullyFusedMLP(64,2) without encoding @ batch 2^18",
+        "config": {"loss": {"otype": "L2"}, "optimizer": ADAM, "encoding": {"otype": "Identity"}, "network": _mlp(64, 2)},
+        "describe": "BASELINE configs[1]: FullyFusedMLP 64 -> 64x2 -> 16 ReLU, Identity encoding, L2 against a zero target, "
+                    "Adam, training_step incl. optimizer (benchmarks/mlp shape)",
+    },
+    "stress": {
+        "n_in": 3, "n_out": 16, "metric": "training samples/s, HashGrid(T=2^22)+FullyFusedMLP(128,4) @ batch 2^18",
+        "config": {"loss": {"otype": "RelativeL2"}, "optimizer": ADAM, "encoding": _hash(22, 1.5), "network": _mlp(128, 4)},
+        "describe": "BASELINE configs[4]: HashGrid(L=16,F=2,T=2^22,base 16,per_level_scale 1.5) + FullyFusedMLP 128x4 ReLU, 3D->16, "
+                    "RelativeL2, Adam, training_step incl. optimizer",
+    },
 }
 # stage (HIP-event span inside the library) -> the kernel it brackets, as it appears in the rocprofv3 kernel stats
-STAGE_KERNEL = {"grid_forward": "tcnn_hip::k_grid_forward", "mlp_forward": "tcnn_hip::k_mlp_forward", "loss": "tcnn_hip::k_loss",
+STAGE_KERNEL = {"grid_forward": "tcnn_hip::k_grid_forward_tiles", "mlp_forward": "tcnn_hip::k_mlp_forward", "loss": "tcnn_hip::k_loss",
                 "mlp_backward": "tcnn_hip::k_mlp_transpose_weights + k_mlp_backward + k_mlp_finalize_gradients",
-                "mlp_train_fused": "tcnn_hip::k_mlp_train_wave + k_mlp_finalize_gradients",
+                "mlp_train_fused": "tcnn_hip::k_mlp_train_wave (or k_mlp_train) + k_mlp_finalize_gradients",
                 "grid_backward_scatter": "tcnn_hip::k_grid_bucket_scatter", "grid_backward": "tcnn_hip::k_grid_backward_sliced",
                 "grid_backward_overflow": "tcnn_hip::k_grid_bucket_overflow", "adam": "tcnn_hip::k_adam_step"}
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense fp16/bf16 MFMA
 
 
-def algorithmic_bytes(n, n_params, n_mlp_params):
+def algorithmic_bytes(w, n, n_params, n_mlp_params):
     """ALGORITHMIC bytes per launch of each stage (DESIGN.md "Roofline accounting"; SURVEY.md 8d per-unit figures):
     what the stage must move at minimum with fp16 params/grads, NOT what the implementation happens to move."""
-    L, F, D, C = 16, 2, 3, 8
-    enc_w, W, H, OUTP = L * F, 64, 2, 16
+    cfg = w["config"]
+    net = cfg["network"]
+    W, H, n_out = net["n_neurons"], net["n_hidden_layers"], w["n_out"]
+    OUTP = -(-n_out // 16) * 16
+    D = w["n_in"]
+    is_grid = cfg["encoding"]["otype"] == "HashGrid"
+    L, F, C = (16, 2, 1 << D) if is_grid else (0, 0, 0)
+    enc_w = L * F if is_grid else -(-D // 16) * 16
     p_grid = n_params - n_mlp_params
+    gather = L * C * F * 2
     return {
-        "grid_forward": n * (4 * D + L * C * F * 2 + enc_w * 2),                 # positions + 8-corner gather + encoded write
+        # grid: positions + 2^D-corner gather + encoded write; identity: fp32 input read + padded fp16 write
+        "grid_forward": n * (4 * D + gather + enc_w * 2),
         "mlp_forward": n * (enc_w * 2 + H * W * 2 + OUTP * 2) + n_mlp_params * 2,  # encoded read + saved hidden + output
-        "loss": n * (OUTP * 2 + N_OUT * 4 + OUTP * 2),
+        "loss": n * (OUTP * 2 + n_out * 4 + OUTP * 2),
         "mlp_backward": n * (enc_w * 2 + H * W * 2 + OUTP * 2 + enc_w * 2) + n_mlp_params * 4,
         # fused forward + loss + backward: encoded in, prediction + dL/dy out (kept for the caller's context), targets in, dL/denc out
-        "mlp_train_fused": n * (enc_w * 2 + OUTP * 2 + OUTP * 2 + N_OUT * 4 + enc_w * 2) + n_mlp_params * 4,
-        # grid backward (SURVEY 8d): positions + dL/denc + read-modify-write of the 8 corners = 12 + 64 + 2 * 512 B per sample.
-        # The bucketed implementation runs it as two kernels; the figure is apportioned, not re-derived from what they
-        # move: the record-scatter kernel carries the inputs and the read half of the RMW, the owner kernel the write half.
-        "grid_backward_scatter": n * (4 * D + enc_w * 2 + L * C * F * 2),
-        "grid_backward": n * L * C * F * 2,
+        "mlp_train_fused": n * (enc_w * 2 + OUTP * 2 + OUTP * 2 + n_out * 4 + (enc_w * 2 if is_grid else 0)) + n_mlp_params * 4,
+        # grid backward (SURVEY 8d): positions + dL/denc + read-modify-write of the corners = 12 + 64 + 2 * 512 B per sample at the
+        # headline shape.  The bucketed implementation runs it as two kernels; the figure is apportioned, not re-derived from what
+        # they move: the record-scatter kernel carries the inputs and the read half of the RMW, the owner kernel the write half.
+        "grid_backward_scatter": n * (4 * D + enc_w * 2 + gather),
+        "grid_backward": n * gather,
         "grid_backward_overflow": 0,
         "adam": n_params * 36,                                                   # 2 grad + (4+4)x(master, m, v, steps) + 2 fp16 param
-        # fused-ideal step of SURVEY 8d: per sample 12 + 16 + 512 + 1024 B, per step P_grid*2 + P_total*36
-        "step_ideal": n * (4 * D + 4 * N_OUT + L * C * F * 2 + 2 * L * C * F * 2) + p_grid * 2 + n_params * 36,
+        # fused-ideal step of SURVEY 8d: per sample inputs + targets + gather + scatter RMW, per step P_grid*2 + P_total*36
+        "step_ideal": n * (4 * D + 4 * n_out + gather + 2 * gather) + p_grid * 2 + n_params * 36,
     }
 
 
-def make_batches(n, n_batches, seed, device):
-    """Synthetic 3-D -> 4 regression data, U[0,1)^3 positions, smooth analytic targets."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
+def network_flops_per_sample(w):
+    """Padded-shape 2*MAC count of forward + backward (dL/dactivations and dL/dweights): 3x the forward."""
+    net = w["config"]["network"]
+    W, H = net["n_neurons"], net["n_hidden_layers"]
+    enc_w = 32 if w["config"]["encoding"]["otype"] == "HashGrid" else -(-w["n_in"] // 16) * 16
+    OUTP = -(-w["n_out"] // 16) * 16
+    return 3 * 2 * (enc_w * W + (H - 1) * W * W + W * OUTP)
+
+
+def make_targets(x, n_out):
+    """Smooth analytic n_in-D -> n_out function (sinusoid products of frequencies 1..)."""
+    d = x.shape[1]
+    return torch.stack([0.5 + 0.5 * torch.sin(2 * np.pi * (c % 4 + 1) * x[:, 0]) * torch.cos(2 * np.pi * (c % 4 + 1) * x[:, 1 % d]) * torch.sin(2 * np.pi * x[:, 2 % d] + c)
+                        for c in range(n_out)], dim=1).contiguous()
+
+
+def make_batches(w, n, n_batches, seed, device, tcnn):
+    """Synthetic regression data: U[0,1)^n_in positions from the library's pcg32 kernel (random.h:39-75, seed 1337 + rank), smooth
+    analytic targets; the `mlp` workload regresses against zero (benchmarks/mlp: L2 vs zero target)."""
+    rng = tcnn._C.Pcg32(seed)
     out = []
     for _ in range(n_batches):
-        x = torch.rand((n, N_IN), generator=g, device=device, dtype=torch.float32)
-        t = torch.stack([0.5 + 0.5 * torch.sin(2 * np.pi * (c + 1) * x[:, 0]) * torch.cos(2 * np.pi * (c + 1) * x[:, 1]) * torch.sin(2 * np.pi * x[:, 2] + c)
-                         for c in range(N_OUT)], dim=1).contiguous()
-        out.append((x.contiguous(), t))
+        x = rng.uniform_(torch.empty((n, w["n_in"]), device=device, dtype=torch.float32))
+        t = torch.zeros((n, w["n_out"]), device=device) if w is WORKLOADS["mlp"] else make_targets(x, w["n_out"])
+        out.append((x, t))
     return out
 
 
-def cpu_baseline(n_steps=9):  # about 11 s on the GPU box's 128 host threads (the brief asks for a 10-30 s sample)
-    """The reference's path has no CPU implementation and cannot be compiled here; the baseline is
-    the CPU oracle restating it (oracle/tcnn_oracle.c, OpenMP), same config, same batch size, fresh random batch."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(w, x, t, budget_s=12.0):
+    """The reference's path has no CPU implementation and cannot be compiled here; the baseline is the CPU oracle
+    restating it (oracle/tcnn_oracle.c, OpenMP), same config, the GPU leg's first batch, as many whole steps as fit `budget_s`."""
     from oracle import oracle as O
-    g = O.grid_init(3, 16, 2, 19, 16, 2.0)
+    cfg = w["config"]
+    net, enc = cfg["network"], cfg["encoding"]
+    pos, tgt = x.cpu().numpy(), t.cpu().numpy()
     adam = O.adam_defaults(learning_rate=1e-2, beta1=0.9, beta2=0.99, epsilon=1e-15, l2_reg=1e-6)
-    md = O.model_init(N_IN, N_OUT, g, 64, 2, O.LOSS_RELATIVE_L2, adam)
-    st = O.TrainState(md, O.model_init_params(md, 1337))
-    rng = np.random.default_rng(0)
-    pos = rng.random((BATCH, N_IN), dtype=np.float32)
-    tgt = rng.random((BATCH, N_OUT), dtype=np.float32)
-    O.training_step(st, pos, tgt)  # warm-up (page faults, thread pool)
-    t0 = time.perf_counter()
-    for _ in range(n_steps):
-        O.training_step(st, pos, tgt)
-    dt = time.perf_counter() - t0
-    return {"value": n_steps * BATCH / dt, "unit": "samples/s", "cores": O.num_threads(), "kind": "port",
-            "sample": f"{n_steps} full training steps of the same config at batch 2^18 ({dt:.1f} s), after 1 warm-up step"}
+    if enc["otype"] == "HashGrid":
+        g = O.grid_init(w["n_in"], 16, 2, enc["log2_hashmap_size"], 16, enc["per_level_scale"])
+        md = O.model_init(w["n_in"], w["n_out"], g, net["n_neurons"], net["n_hidden_layers"], O.LOSS_NAMES.index(cfg["loss"]["otype"]), adam)
+        st = O.TrainState(md, O.model_init_params(md, 1337))
+
+        def step():
+            O.training_step(st, pos, tgt)
+    else:  # network only: identity encoding -> MLP -> L2 -> backward -> Adam, composed from the oracle's pieces
+        m = O.mlp_init(w["n_in"], net["n_neurons"], w["n_out"], net["n_hidden_layers"])
+        w32 = O.mlp_init_params(m, O.pcg32(1337))
+        state = {"w32": w32, "w16": O.f2h(w32), "m1": np.zeros_like(w32), "m2": np.zeros_like(w32), "steps": np.zeros(w32.size, np.uint32), "k": 0}
+
+        def step():
+            enc_h = O.identity_forward(pos, w["n_in"])
+            hidden, out = O.mlp_forward(m, state["w16"], enc_h)
+            _, dl = O.loss(O.LOSS_L2, out, tgt, w["n_out"])
+            grad, _ = O.mlp_backward(m, state["w16"], enc_h, hidden, out, dl, want_dinput=False)
+            state["k"] += 1
+            O.adam_step(adam, m.n_params, 128.0, state["k"], state["w32"], state["w16"], O.f2h(grad.astype(np.float32)), state["m1"], state["m2"], state["steps"])
+    step()  # warm-up (page faults, thread pool)
+    n_steps, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n_steps += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n_steps >= 200:
+            break
+    n = pos.shape[0]
+    return {"value": n_steps * n / dt, "unit": "samples/s", "cores": O.num_threads(), "kind": "port", "cpu_model": cpu_model_name(),
+            "sample": f"{n_steps} full training steps of the same config on the GPU leg's first batch of {n} samples ({dt:.1f} s), after 1 warm-up step"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="hash")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: 2^18 samples per GPU (weak) or 2^18 in total (strong)")
+    ap.add_argument("--dp", choices=["sharded", "allreduce"], default="sharded", help="N > 1: gradient exchange (tinycudann/parallel.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dominant", default="auto", help="stage timed with HIP events inside the timed region (auto: the slowest stage of a short probe pass)")
     ap.add_argument("--lds-budget", type=int, default=None, help="grid backward: LDS bytes per level table (tuning knob)")
     args = ap.parse_args()
+    w = WORKLOADS[args.workload]
 
     import tinycudann as tcnn  # fails loudly if libtcnn_hip.so is missing
     from tinycudann import parallel as par
@@ -136,20 +224,22 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    tm = tcnn.create_from_config(N_IN, N_OUT, CONFIG, seed=1337)
+    tm = tcnn.create_from_config(w["n_in"], w["n_out"], w["config"], seed=1337)
     if args.lds_budget is not None:
         tm.set_lds_level_budget(args.lds_budget)
-    global_batch = BATCH * world
+    local_batch = BATCH if args.scaling == "weak" else par.shard_rows(BATCH, rank, world)[1] - par.shard_rows(BATCH, rank, world)[0]
+    global_batch = local_batch * world
+    dp = None
     if world > 1:
         tm.set_global_batch_size(global_batch)
-    batches = make_batches(BATCH, 4, seed=1337 + rank, device=device)
-    grads = tm.param_gradients
+        dp = par.DataParallel(tm, mode=args.dp)
+    batches = make_batches(w, local_batch, 4, seed=1337 + rank, device=device, tcnn=tcnn)
 
     def step(i):
         x, t = batches[i % len(batches)]
-        if world > 1:
+        if dp is not None:
             tm.training_step(x, t, run_optimizer=False, want_context=False)
-            par.reduce_and_step(tm, grads)  # bucketed all-reduce overlapped with the optimizer
+            dp.exchange_and_step()
         else:
             tm.training_step(x, t, want_context=False)
 
@@ -165,11 +255,13 @@ def main():
             step(i)
         torch.cuda.synchronize()
         probe = tm.stage_times()
-        dominant = max(probe, key=lambda k: probe[k][0])
+        dominant = max(probe, key=lambda k: probe[k][0] / max(probe[k][1], 1))
         dominant = par.broadcast_object(dominant)
 
     # ---- timed region: EXACTLY --steps steps, barrier + synchronize on both sides -----------------------
     tm.set_profiling(True, only_stage=dominant)  # 2 HIP events per step around the dominant kernel only
+    if dp is not None:
+        dp.reset_timers()
     par.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -180,6 +272,7 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = par.all_reduce_max(elapsed, device=device)
     dom_ms, dom_cnt = tm.stage_times()[dominant]
+    comm = dp.comm_seconds() if dp is not None else None
 
     # ---- second, fully instrumented pass (breakdown only; not part of `value`) ----------------------------
     tm.set_profiling(True)
@@ -197,31 +290,39 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = global_batch * args.steps / elapsed
-        ab = algorithmic_bytes(BATCH, tm.n_params, tm.n_mlp_params)
+        ab = algorithmic_bytes(w, local_batch, tm.n_params, tm.n_mlp_params)
         dom_avg_s = dom_ms / max(dom_cnt, 1) * 1e-3
         achieved = ab[dominant] / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch, if a pass was recorded
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dominant)
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch from a SEPARATE rocprofv3 --pmc pass
+        if args.workload == "hash" and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic = tj.get(dominant)
+            traffic_source = tj.get("_source", "profiles/traffic.json: separate rocprofv3 --pmc passes of the same command (scripts/gpu_pmc.sh); not measured in this run")
+        roofline = {"bound": "hbm", "kernel": dominant, "kernel_symbol": STAGE_KERNEL.get(dominant), "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                    "algorithmic_bytes_per_launch": ab[dominant], "avg_launch_ms": dom_avg_s * 1e3, "launches_timed": int(dom_cnt)}
+        if dominant in ("mlp_train_fused", "mlp_backward", "mlp_forward"):  # also against the matrix-core roof (north_star asks for it)
+            share = {"mlp_train_fused": 1.0, "mlp_backward": 2.0 / 3.0, "mlp_forward": 1.0 / 3.0}[dominant]
+            tflops = network_flops_per_sample(w) * share * local_batch / dom_avg_s / 1e12 if dom_avg_s > 0 else 0.0
+            roofline["mfma"] = {"achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS}
         line = {
-            "metric": "training samples/s, HashGrid+FullyFusedMLP(64,2) @ batch 2^18",
+            "metric": w["metric"] + (", 1/2/4/8 GPU" if args.workload == "hash" else ""),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f16 (fp16 params/activations/gradients, fp32 MFMA accumulate, fp32 Adam state)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: HashGrid(L=16,F=2,T=2^19,base 16,per_level_scale 2.0) + FullyFusedMLP 64x2 ReLU, "
-                                   "3D->4, RelativeL2, Adam(config_hash.json), training_step incl. optimizer",
-                       "batch_per_gpu": BATCH, "global_batch": global_batch, "n_params": tm.n_params,
-                       "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": {"bound": "hbm", "kernel": dominant, "kernel_symbol": STAGE_KERNEL.get(dominant), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ab[dominant], "avg_launch_ms": dom_avg_s * 1e3, "launches_timed": int(dom_cnt)},
+            "config": {"workload": w["describe"], "batch_per_gpu": local_batch, "global_batch": global_batch, "n_params": tm.n_params,
+                       "parallelism": f"dp{world} ({args.dp})" if world > 1 else "single"},
+            "roofline": roofline,
             "stages_ms": stages,
             "step_ideal_GBps": ab["step_ideal"] / (elapsed / args.steps) / 1e9,
             "final_loss": final_loss,
         }
+        if comm is not None:
+            line["comm"] = {"seconds_per_step": comm / args.steps, "share_of_step": comm / elapsed,
+                            "note": "host-side wall time inside the collective calls + waits of rank 0 (overlapped GPU work not subtracted)"}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(w, *batches[0])
         print(json.dumps(line))
     par.barrier()
     if world > 1:

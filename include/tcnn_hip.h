@@ -150,6 +150,12 @@ uint32_t tcnn_trainer_optimizer_step_count(const tcnn_trainable_model_t* tm);   
 uint32_t tcnn_trainer_padded_output_width(const tcnn_trainable_model_t* tm);
 uint32_t tcnn_trainer_n_mlp_params(const tcnn_trainable_model_t* tm); /* "matrix" params: leading part of the buffer */
 
+/* generate_random_uniform<float>(stream, rng, n, out, lower, upper) with `default_rng_t rng{seed}` (random.h:39-75,
+ * pcg32.h:40-170): out[0..n) = U[lower, upper) from the pcg32 stream of `seed`, starting `*position` draws into it;
+ * `*position` is advanced by n (what the reference's `rng.advance(n)` does), so successive calls continue one stream.
+ * The synthetic inputs of samples/ and bench.py come from here (pcg32 seed 1337). */
+int tcnn_generate_random_uniform(tcnn_stream_t stream, uint64_t seed, uint64_t* position, size_t n, float* out, float lower, float upper);
+
 /* Data parallelism (no reference counterpart; the reference is single-GPU).
  * Loss gradients are normalised by global_batch_size * n_output_dims instead of the local batch, so the
  * SUM over ranks of the local gradient buffers equals the single-GPU gradient of the global batch.  The
@@ -160,6 +166,20 @@ int tcnn_trainer_set_global_batch_size(tcnn_trainable_model_t* tm, uint64_t glob
  * communication.  One optimizer step == ranges that tile [0, n_params) exactly once, the range with begin == 0 first
  * (it advances the step counter and the learning-rate schedule). */
 int tcnn_trainer_optimizer_step_range(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale, size_t begin, size_t end);
+/* ONE optimizer step over the union of n_ranges parameter ranges only (begins multiples of 8): a rank that owns a shard of
+ * the parameters (reduce-scatter of the gradients -> this -> all-gather of tcnn_trainer_params) steps just its shard; the
+ * optimizer state of the other parameters is not touched on this rank. */
+int tcnn_trainer_optimizer_step_ranges(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale, size_t n_ranges, const size_t* begins,
+                                       const size_t* ends);
+/* Gradient exchange hook for a data-parallel C/C++ host: training_step(run_optimizer = 1) calls `exchange` between backward
+ * and the optimizer with the fp16 gradient buffer [network | encoding] on the step's stream; the host issues its
+ * collective there, e.g. ncclAllReduce(g, g, n, ncclHalf, ncclSum, comm, (hipStream_t)stream).  The
+ * library links no collective library itself.  exchange == NULL removes the hook. */
+int tcnn_trainer_set_gradient_exchange(tcnn_trainable_model_t* tm, void (*exchange)(void* user, void* gradients_fp16, size_t n_params, tcnn_stream_t stream),
+                                       void* user);
+/* Adam's state (device pointers, n_params elements each): which = 0 first moments (fp32), 1 second moments (fp32),
+ * 2 per-parameter step counters (u32; *steps_are_deficits = 1: the array holds `optimizer steps done - counter`). */
+void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* steps_are_deficits);
 
 /* Measurement hooks (no reference counterpart): HIP events recorded around each stage of the training step
  * on the stream the kernels are launched on.  only_stage < 0 times every stage, otherwise just that one.

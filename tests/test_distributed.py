@@ -86,3 +86,120 @@ def test_two_rank_gradient_allreduce_equals_single_process(tmp_path):
     assert np.allclose(red["grads"], ref, rtol=1e-9, atol=1e-12)
     assert abs(red["loss"][0] - ref_loss) < 1e-6 * abs(ref_loss)
     assert red["slowest"] == 2.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DataParallel (sharded: reduce-scatter -> Adam on the own shard -> all-gather; allreduce: bucketed) with a CPU stand-in
+# for the trainer: same attribute surface as tinycudann.native.TrainableModel, Adam from the oracle.
+# ---------------------------------------------------------------------------------------------------------------------
+class _CpuTrainer:
+    def __init__(self, n, seed=3):
+        sys.path.insert(0, ROOT)
+        from oracle import oracle as O
+        self.O = O
+        rng = np.random.default_rng(seed)
+        self.n_params = n
+        self.w32 = rng.standard_normal(n).astype(np.float32)
+        self.params = torch.from_numpy(O.f2h(self.w32).view(np.int16)).view(torch.half)
+        self.params_inference = self.params
+        self.param_gradients = torch.zeros(n, dtype=torch.half)
+        self.m1, self.m2, self.steps = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint32)
+        self.step = 0
+        self.adam = O.adam_defaults(learning_rate=1e-2, beta2=0.99, epsilon=1e-15, l2_reg=0.0)
+
+    @property
+    def params_full_precision(self):
+        return torch.from_numpy(self.w32)
+
+    def optimizer_state(self):
+        return torch.from_numpy(self.m1), torch.from_numpy(self.m2), torch.from_numpy(self.steps.view(np.int32)), False
+
+    def _adam(self, b, e):
+        w16 = self.params.numpy().view(np.uint16)
+        g = self.param_gradients.numpy().view(np.uint16)
+        self.O.adam_step(self.adam, 0, 128.0, self.step, self.w32[b:e], w16[b:e], np.ascontiguousarray(g[b:e]), self.m1[b:e], self.m2[b:e], self.steps[b:e])
+
+    def optimizer_step(self, loss_scale=128.0):
+        self.optimizer_step_ranges([(0, self.n_params)], loss_scale)
+
+    def optimizer_step_range(self, b, e, loss_scale=128.0):
+        if b == 0:
+            self.step += 1
+        self._adam(b, min(e, self.n_params))
+
+    def optimizer_step_ranges(self, ranges, loss_scale=128.0):
+        self.step += 1
+        for b, e in ranges:
+            assert b % 8 == 0
+            self._adam(b, e)
+
+
+def _rank_gradients(n, rank, step):
+    rng = np.random.default_rng(100 * step + rank)
+    g = (rng.standard_normal(n) * 4).astype(np.float16)
+    g[rng.random(n) < 0.2] = 0
+    return g
+
+
+def _dp_worker(rank, world, port, n, mode, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ["OMP_NUM_THREADS"] = "1"
+    par = _load_parallel()
+    par.init_from_env(backend="gloo")
+    tm = _CpuTrainer(n)
+    dp = par.DataParallel(tm, mode=mode, n_buckets=3)
+    assert dp.shard % 8 == 0 and dp.main <= n and n - dp.main < 8 * world
+    for step in range(3):
+        tm.param_gradients.copy_(torch.from_numpy(_rank_gradients(n, rank, step).view(np.int16)).view(torch.half))
+        dp.exchange_and_step()
+    assert dp.comm_seconds() > 0
+    own = dp.shard_range()
+    before = tm.m1.copy()
+    dp.gather_optimizer_state()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), params=tm.params.numpy().view(np.uint16), w32=tm.w32, m1=tm.m1, m2=tm.m2, steps=tm.steps,
+             own=np.array(own), m1_before_gather=before)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
+def test_data_parallel_exchange_matches_single_process(tmp_path, mode):
+    n, world = 8 * 2 * 37 + 11, 2  # a tail of 11 parameters that no shard covers
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_worker, args=(world, port, n, mode, str(tmp_path)), nprocs=world, join=True)
+    ref = _CpuTrainer(n)
+    for step in range(3):
+        total = sum(_rank_gradients(n, r, step).astype(np.float32) for r in range(world))  # fp16 sum of two addends is exact up to one rounding
+        ref.param_gradients.copy_(torch.from_numpy(total.astype(np.float16).view(np.int16)).view(torch.half))
+        ref.optimizer_step()
+    ranks = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    for r, d in enumerate(ranks):
+        assert np.array_equal(d["params"], ref.params.numpy().view(np.uint16)), (mode, r)  # replicas identical to the single-process run
+        assert np.array_equal(d["w32"], ref.w32) and np.array_equal(d["m1"], ref.m1) and np.array_equal(d["m2"], ref.m2) and np.array_equal(d["steps"], ref.steps)
+        if mode == "sharded":  # before the gather a rank held the optimizer state of its own shard (and the tail) only
+            b, e = d["own"]
+            other = np.ones(n, bool)
+            other[b:e] = False
+            other[(n // 16) * 16:] = False
+            assert np.array_equal(d["m1_before_gather"][b:e], ref.m1[b:e]) and not d["m1_before_gather"][other].any()
+
+
+def test_fp16_gradient_sum_over_eight_ranks_does_not_overflow():
+    """Every rank normalises its loss gradient by the GLOBAL batch, so the partial sums of a ring all-reduce stay within
+    the single-GPU gradient's magnitude: fp16 SUM over P = 8 at loss scale 128 is finite and within fp16 rounding of the
+    exact sum (the order of a ring reduction is emulated: rank 0 + rank 1 + ... in fp16)."""
+    n, world = 2048, 8
+    pos, tgt = _data(n)
+    full, _ = _local_gradients(pos, tgt, n)
+    partial = []
+    for r in range(world):
+        b, e = r * n // world, (r + 1) * n // world
+        g, _ = _local_gradients(pos[b:e], tgt[b:e], n)
+        partial.append(g.astype(np.float16))
+    acc = partial[0].copy()
+    for g in partial[1:]:
+        acc = (acc.astype(np.float32) + g.astype(np.float32)).astype(np.float16)
+    assert np.isfinite(acc).all() and np.abs(full).max() < 6.0e4
+    scale = np.abs(full).max()
+    assert np.abs(acc.astype(np.float64) - full).max() < 4e-3 * scale

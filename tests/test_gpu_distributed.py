@@ -1,5 +1,6 @@
 """Two data-parallel ranks on ONE MI355X (gloo transport, both processes on cuda:0): the full multi-process path of
-tinycudann.parallel -- global-batch loss normalisation, bucketed asynchronous all-reduce of the library-owned fp16
+tinycudann.parallel -- global-batch loss normalisation, the sharded (reduce-scatter, Adam on the own shard, all-gather) and
+bucketed all-reduce exchanges of the library-owned fp16
 gradient buffer, per-bucket optimizer steps -- against a single process training on the whole batch.  RCCL itself
 refuses two ranks on one device, so the collective runs over gloo here; everything above the backend is identical to
 what `bench.py --gpus N` runs."""
@@ -41,7 +42,7 @@ def _model():
     return tm
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, mode):
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, os.path.join(ROOT, "tiny-cuda-nn_amd"))
     import torch.distributed as dist
@@ -53,19 +54,24 @@ def _worker(rank, world, port, out_path):
     b, e = par.shard_rows(N, r, w)
     xs, ts = x[b:e].cuda(), t[b:e].cuda()
     losses = []
+    dp = par.DataParallel(tm, mode=mode) if mode else None  # None: the module-level bucketed all-reduce helper
     for _ in range(STEPS):
-        ctx = par.training_step(tm, xs, ts, N)
+        ctx = par.training_step(tm, xs, ts, N, dp=dp)
         part = torch.tensor([tm.loss(ctx)], dtype=torch.float64)  # each rank's share of the global mean
         dist.all_reduce(part)
         losses.append(float(part.item()))
     torch.cuda.synchronize()
+    if dp is not None:
+        dp.gather_optimizer_state()  # sharded mode: fp32 master weights live on their owners
+        assert dp.comm_seconds() > 0
     if r == 0:
         torch.save({"params": tm.params_full_precision.cpu(), "losses": losses, "steps": tm.optimizer_step_count}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
+@pytest.mark.parametrize("mode", [None, "sharded", "allreduce"])
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path, mode):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -73,7 +79,7 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     s.close()
     out = str(tmp_path / "dp.pt")
     try:
-        mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, out, mode), nprocs=2, join=True)
     except Exception as ex:  # gloo without device-tensor support on this build
         if "gloo" in str(ex).lower() and "cuda" in str(ex).lower():
             pytest.skip(f"gloo cannot move GPU tensors here: {ex}")

@@ -836,6 +836,9 @@ struct tcnn_trainable_model {
 	std::string hyper_json;
 	float* loss_scratch = nullptr;  // 1024 + 1 floats
 	std::unique_ptr<Profiler> profiler;  // null unless tcnn_trainer_set_profiling enabled it
+	// data-parallel hosts: called between backward and the optimizer (tcnn_trainer_set_gradient_exchange)
+	void (*exchange)(void* user, void* gradients_fp16, size_t n_params, tcnn_stream_t stream) = nullptr;
+	void* exchange_user = nullptr;
 };
 
 #define TCNN_API_BEGIN try {
@@ -871,6 +874,15 @@ float tcnn_default_loss_scale(int precision) { return precision == TCNN_PRECISIO
 int tcnn_preferred_precision(void) { return TCNN_PRECISION_FP16; }
 int tcnn_supports_jit_fusion(int) { return 0; }
 void tcnn_set_log_callback(void (*callback)(int, const char*)) { g_log_callback = callback; }
+
+int tcnn_generate_random_uniform(tcnn_stream_t stream, uint64_t seed, uint64_t* position, size_t n, float* out, float lower, float upper) {
+	TCNN_API_BEGIN
+	Pcg32 rng{seed};
+	if (position && *position) rng.advance((int64_t)*position);
+	generate_random_uniform((hipStream_t)stream, rng, n, out, lower, upper);
+	if (position) *position += n;
+	TCNN_API_END
+}
 
 int tcnn_create_network_with_input_encoding(uint32_t n_input_dims, uint32_t n_output_dims, const char* encoding_json, const char* network_json,
                                             tcnn_module_t** out) {
@@ -1291,14 +1303,16 @@ static bool choose_step_representation(const tcnn_trainable_model* tm) {
 	return (batch << g.n_dims) >= (uint64_t)largest;
 }
 
-// Optimizer::step over the parameter range [begin, end) (multiples of 8).  The call with begin == 0 advances the step
-// counter and the learning-rate schedule; a data-parallel host steps a range as soon as its gradients are reduced.
-int tcnn_trainer_optimizer_step_range(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale, size_t begin, size_t end) {
-	TCNN_API_BEGIN
+// Optimizer::step over a set of parameter ranges [begin, end) (begins multiples of 8).  `advance`: this call opens a new
+// optimizer step (step counter, learning-rate schedule, step-counter representation); the other calls of the same step
+// (a data-parallel host steps each gradient bucket as soon as it is reduced) continue it.
+static void optimizer_step_ranges(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale, size_t n_ranges, const size_t* begins, const size_t* ends,
+                                  bool advance) {
 	const size_t n = tm->md.n_params();
-	if (end > n) end = n;
-	if (begin % 8 != 0 || begin > end) throw std::runtime_error("optimizer_step_range: range must start at a multiple of 8");
-	if (begin == 0) {
+	for (size_t r = 0; r < n_ranges; ++r) {
+		if (begins[r] % 8 != 0 || begins[r] > std::min(ends[r], n)) throw std::runtime_error("optimizer_step_range: a range must start at a multiple of 8 and not end before it");
+	}
+	if (advance) {
 		if (tm->lr_decay) {  // exponential_decay.h:59-70, with step() == the nested optimizer's step count before this step
 			const uint32_t step = tm->optimizer_step;
 			if (step == 0) tm->lr_factor = 1.0f;
@@ -1308,23 +1322,57 @@ int tcnn_trainer_optimizer_step_range(tcnn_trainable_model_t* tm, tcnn_stream_t 
 		++tm->optimizer_step;  // adam.h:159
 		const bool want_deficits = choose_step_representation(tm);
 		if (want_deficits != tm->steps_are_deficits) {
-			adam_flip_step_representation((hipStream_t)stream, (uint32_t)n, tm->optimizer_step - 1u, tm->steps);
+			adam_flip_step_representation(stream, (uint32_t)n, tm->optimizer_step - 1u, tm->steps);
 			tm->steps_are_deficits = want_deficits;
 		}
 	}
 	ProfilerGuard pg(tm->profiler.get());
-	ProfScope prof((hipStream_t)stream, STAGE_ADAM, /*counts=*/begin == 0);  // a ranged (bucketed) step is ONE optimizer step
-	adam_step((hipStream_t)stream, tm->adam, (uint32_t)n, (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master, tm->params, tm->grads,
-	          tm->m1, tm->m2, tm->steps, tm->params_t_valid ? tm->params_t : nullptr, tm->md.has_network ? &tm->md.net.mlp : nullptr, (uint32_t)begin,
-	          (uint32_t)end, tm->steps_are_deficits);
-	if (tm->ema) {
-		ema_step((hipStream_t)stream, (uint32_t)n, tm->ema_decay, tm->optimizer_step, tm->params, tm->params_ema, tm->ema_tmp, (uint32_t)begin, (uint32_t)end);
+	for (size_t r = 0; r < n_ranges; ++r) {
+		const size_t begin = begins[r], end = std::min(ends[r], n);
+		if (begin == end) continue;
+		ProfScope prof(stream, STAGE_ADAM, /*counts=*/advance && r == 0);  // a ranged (bucketed) step is ONE optimizer step
+		adam_step(stream, tm->adam, (uint32_t)n, (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master, tm->params, tm->grads,
+		          tm->m1, tm->m2, tm->steps, tm->params_t_valid ? tm->params_t : nullptr, tm->md.has_network ? &tm->md.net.mlp : nullptr, (uint32_t)begin,
+		          (uint32_t)end, tm->steps_are_deficits);
+		if (tm->ema) ema_step(stream, (uint32_t)n, tm->ema_decay, tm->optimizer_step, tm->params, tm->params_ema, tm->ema_tmp, (uint32_t)begin, (uint32_t)end);
 	}
+}
+
+// One optimizer step == calls whose ranges tile [0, n_params) exactly once, the range with begin == 0 first.
+int tcnn_trainer_optimizer_step_range(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale, size_t begin, size_t end) {
+	TCNN_API_BEGIN
+	optimizer_step_ranges(tm, (hipStream_t)stream, loss_scale, 1, &begin, &end, /*advance=*/begin == 0);
+	TCNN_API_END
+}
+
+// One optimizer step over the union of the given ranges only (a rank that owns a shard of the parameters, ZeRO-1 style:
+// the other parameters' optimizer state is left untouched on this rank).
+int tcnn_trainer_optimizer_step_ranges(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale, size_t n_ranges, const size_t* begins,
+                                       const size_t* ends) {
+	TCNN_API_BEGIN
+	optimizer_step_ranges(tm, (hipStream_t)stream, loss_scale, n_ranges, begins, ends, /*advance=*/true);
 	TCNN_API_END
 }
 
 int tcnn_trainer_optimizer_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale) {
 	return tcnn_trainer_optimizer_step_range(tm, stream, loss_scale, 0, tm->md.n_params());
+}
+
+// Gradient exchange hook of a data-parallel C/C++ host: called by training_step(run_optimizer = true) between backward and
+// the optimizer with the fp16 gradient buffer [network | encoding] and the stream the step runs on; the callback issues
+// e.g. ncclAllReduce(grads, grads, n, ncclHalf, ncclSum, comm, stream).  The library itself links no collective library.
+int tcnn_trainer_set_gradient_exchange(tcnn_trainable_model_t* tm, void (*exchange)(void* user, void* gradients_fp16, size_t n_params, tcnn_stream_t stream),
+                                       void* user) {
+	tm->exchange = exchange;
+	tm->exchange_user = user;
+	return TCNN_OK;
+}
+
+// Adam's state for snapshots / sharded data parallelism: which = 0 first moments (fp32), 1 second moments (fp32),
+// 2 per-parameter step counters (u32; *steps_are_deficits tells their representation, see tcnn_trainer_optimizer_step_range).
+void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* steps_are_deficits) {
+	if (steps_are_deficits) *steps_are_deficits = tm->steps_are_deficits ? 1 : 0;
+	return which == 0 ? (void*)tm->m1 : which == 1 ? (void*)tm->m2 : which == 2 ? (void*)tm->steps : nullptr;
 }
 
 // training_step fast path: encoding forward, ONE kernel for the network's forward + loss + backward, encoding backward.
@@ -1399,6 +1447,7 @@ int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
 	tcnn_train_context_t* ctx = nullptr;
 	if (g_fused_mlp_training && !external_dL_dy && target && tm->md.has_network && mlp_train_supported(tm->md.net.mlp) && loss_is_elementwise(tm->loss)) {
 		int r = training_step_fused(tm, (hipStream_t)stream, loss_scale, n, input, target, data_pdf, dL_dinput, use_inference_params, gradient_mode, &ctx);
+		if (r == TCNN_OK && run_optimizer && tm->exchange) tm->exchange(tm->exchange_user, tm->grads, tm->md.n_params(), stream);
 		if (r == TCNN_OK && run_optimizer) r = tcnn_trainer_optimizer_step(tm, stream, loss_scale);
 		if (ctx_out && r == TCNN_OK) {
 			*ctx_out = ctx;
@@ -1409,6 +1458,7 @@ int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
 	}
 	int r = tcnn_trainer_forward(tm, stream, loss_scale, n, input, target, data_pdf, use_inference_params, dL_dinput != nullptr, external_dL_dy, &ctx);
 	if (r == TCNN_OK) r = tcnn_trainer_backward(tm, stream, ctx, n, input, dL_dinput, use_inference_params, gradient_mode);
+	if (r == TCNN_OK && run_optimizer && tm->exchange) tm->exchange(tm->exchange_user, tm->grads, tm->md.n_params(), stream);
 	if (r == TCNN_OK && run_optimizer) r = tcnn_trainer_optimizer_step(tm, stream, loss_scale);
 	if (ctx_out && r == TCNN_OK) {
 		*ctx_out = ctx;

@@ -63,6 +63,7 @@ _sig("tcnn_default_loss_scale", _f, _i)
 _sig("tcnn_preferred_precision", _i)
 _sig("tcnn_supports_jit_fusion", _i, _i)
 _sig("tcnn_set_log_callback", None, _vp)
+_sig("tcnn_generate_random_uniform", _i, _vp, _u64, C.POINTER(_u64), _sz, _vp, _f, _f)
 _sig("tcnn_create_network_with_input_encoding", _i, _u32, _u32, _cp, _cp, C.POINTER(_vp))
 _sig("tcnn_create_network", _i, _u32, _u32, _cp, C.POINTER(_vp))
 _sig("tcnn_create_encoding", _i, _u32, _cp, _i, C.POINTER(_vp))
@@ -112,6 +113,9 @@ _sig("tcnn_trainer_padded_output_width", _u32, _vp)
 _sig("tcnn_trainer_n_mlp_params", _u32, _vp)
 _sig("tcnn_trainer_set_global_batch_size", _i, _vp, _u64)
 _sig("tcnn_trainer_optimizer_step_range", _i, _vp, _vp, _f, _sz, _sz)
+_sig("tcnn_trainer_optimizer_step_ranges", _i, _vp, _vp, _f, _sz, C.POINTER(_sz), C.POINTER(_sz))
+_sig("tcnn_trainer_set_gradient_exchange", _i, _vp, _vp, _vp)
+_sig("tcnn_trainer_optimizer_state", _vp, _vp, _i, C.POINTER(_i))
 _sig("tcnn_trainer_set_profiling", _i, _vp, _i, _i)
 _sig("tcnn_trainer_n_stages", _i)
 _sig("tcnn_trainer_stage_name", _cp, _i)
@@ -352,6 +356,20 @@ class Module:
         v = C.c_size_t()
         _check(_lib.tcnn_module_grid_level_params_offset(self._h, level, C.byref(v)))
         return v.value
+
+
+class Pcg32:
+    """`default_rng_t rng{seed}` + generate_random_uniform (random.h:39-75): a position in the pcg32 stream of `seed`."""
+
+    def __init__(self, seed=1337):
+        self.seed = int(seed)
+        self.position = C.c_uint64(0)
+
+    def uniform_(self, out, lower=0.0, upper=1.0):
+        """Fills the float32 GPU tensor `out` with the next out.numel() draws and returns it."""
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+        _check(_lib.tcnn_generate_random_uniform(_stream(), self.seed, C.byref(self.position), out.numel(), _ptr(out), lower, upper))
+        return out
 
 
 def _dumps(cfg):

@@ -99,6 +99,21 @@ class TrainableModel:
         """Optimizer step over parameters [begin, end) (begin a multiple of 8); the range starting at 0 must come first."""
         _check(_lib.tcnn_trainer_optimizer_step_range(self._h, _stream(), float(loss_scale), int(begin), int(end)))
 
+    def optimizer_step_ranges(self, ranges, loss_scale=128.0):
+        """ONE optimizer step over the union of the [begin, end) ranges only (begins multiples of 8): sharded data parallelism."""
+        n = len(ranges)
+        b = (C.c_size_t * n)(*[int(r[0]) for r in ranges])
+        e = (C.c_size_t * n)(*[int(r[1]) for r in ranges])
+        _check(_lib.tcnn_trainer_optimizer_step_ranges(self._h, _stream(), float(loss_scale), n, b, e))
+
+    def optimizer_state(self):
+        """(first_moments fp32, second_moments fp32, param_steps int32-viewed u32, steps_are_deficits) as zero-copy views of Adam's state."""
+        flag = C.c_int(0)
+        m1 = self._tensor(_lib.tcnn_trainer_optimizer_state(self._h, 0, C.byref(flag)), "<f4")
+        m2 = self._tensor(_lib.tcnn_trainer_optimizer_state(self._h, 1, None), "<f4")
+        steps = self._tensor(_lib.tcnn_trainer_optimizer_state(self._h, 2, None), "<i4")
+        return m1, m2, steps, bool(flag.value)
+
     def loss(self, ctx):
         v = C.c_float()
         _check(_lib.tcnn_trainer_loss(self._h, _stream(), ctx._h, C.byref(v)))

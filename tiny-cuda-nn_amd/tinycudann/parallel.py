@@ -4,8 +4,20 @@ its loss gradient by the GLOBAL batch (tcnn_trainer_set_global_batch_size) so th
 gradient buffers equals the single-GPU gradient; one all-reduce(sum) of the contiguous fp16 gradient buffer
 [MLP | grid] per step (RCCL over xGMI: backend "nccl"); then the identical Adam step on every rank keeps the
 replicas in lock-step without a parameter broadcast.  Nothing here touches the compute path itself, so the
-same functions are exercised on CPU with the gloo backend in tests/test_distributed.py."""
+same functions are exercised on CPU with the gloo backend in tests/test_distributed.py.
+
+Two exchange schemes (class DataParallel):
+  * "sharded" (default): reduce-scatter of the gradient buffer -> every rank runs Adam on its own 1/P of the parameters
+    (tcnn_trainer_optimizer_step_ranges) -> all-gather of the fp16 parameters.  Same bytes on the wire as an all-reduce
+    (xGMI collectives are per-link bound, so that is what a step costs), but the optimizer -- the largest HBM consumer of
+    a step, 36 B per parameter -- shrinks by P, and the replicas cannot drift apart: every rank receives the same fp16
+    parameters.  fp32 master weights and Adam moments exist only on the owning rank (gather_optimizer_state() collects
+    them for a snapshot).
+  * "allreduce": bucketed all-reduce, identical Adam on every rank, each bucket stepped as soon as it is summed.
+Gradients are summed in fp16: every rank's buffer is already normalised by the GLOBAL batch, so the partial sums of a
+ring are bounded by the single-GPU gradient's own magnitude (tests/test_distributed.py checks P = 8 at loss scale 128)."""
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -76,6 +88,113 @@ def reduce_and_step(tm, grads, n_buckets=None, loss_scale=128.0):
         tm.optimizer_step_range(b, e, loss_scale)
 
 
+class DataParallel:
+    """Gradient exchange + optimizer of one data-parallel rank.  `tm`: a tinycudann.native.TrainableModel (or anything with
+    param_gradients / params / params_inference / n_params / optimizer_step / optimizer_step_range(s) / optimizer_state)."""
+
+    def __init__(self, tm, mode="sharded", loss_scale=128.0, n_buckets=None):
+        if mode not in ("sharded", "allreduce"):
+            raise ValueError(f"unknown data-parallel mode {mode!r}")
+        self.tm, self.mode, self.loss_scale, self.n_buckets = tm, mode, loss_scale, n_buckets
+        self.active = dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.active else 1
+        self.rank = dist.get_rank() if self.active else 0
+        self.grads = tm.param_gradients
+        self.params = tm.params
+        inf = tm.params_inference
+        self.params_inference = inf if inf.data_ptr() != self.params.data_ptr() else None  # EMA weights (trainer.h:497-500)
+        n = self.grads.numel()
+        # parameters [0, main) are sharded evenly (shard boundaries are multiples of 8, what the optimizer ranges need); the
+        # < 8 P parameters of the tail [main, n) are all-reduced and stepped by every rank (replicated state)
+        self.shard = (n // (8 * self.world)) * 8
+        self.main = self.shard * self.world
+        self.n = n
+        self._comm_s = 0.0
+        self._events = []
+
+    def shard_range(self, rank=None):
+        r = self.rank if rank is None else rank
+        return r * self.shard, (r + 1) * self.shard
+
+    # ---- timing of the communication share (bench.py) ----------------------------------------------------------------
+    def reset_timers(self):
+        self._comm_s, self._events = 0.0, []
+
+    def comm_seconds(self):
+        """Time between issuing a step's collectives and their completion, summed: GPU time between events recorded on the
+        step's stream for device tensors (includes the sharded optimizer that sits between the two collectives), host wall
+        time for CPU tensors."""
+        if self._events:
+            torch.cuda.synchronize()
+            self._comm_s += sum(a.elapsed_time(b) for a, b in self._events) * 1e-3
+            self._events = []
+        return self._comm_s
+
+    def _tic(self):
+        if self.grads.is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        return time.perf_counter()
+
+    def _toc(self, start):
+        if self.grads.is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._events.append((start, e))
+        else:
+            self._comm_s += time.perf_counter() - start
+
+    # ---- collectives with fall-backs for backends that lack the fused forms (gloo) ------------------------------------
+    def _reduce_scatter(self, buf):
+        """Sum over ranks; afterwards this rank's shard of buf[:main] holds the reduced values (in place)."""
+        b, e = self.shard_range()
+        try:
+            dist.reduce_scatter_tensor(buf[b:e], buf[: self.main], op=dist.ReduceOp.SUM)
+        except (RuntimeError, NotImplementedError):
+            dist.all_reduce(buf[: self.main], op=dist.ReduceOp.SUM)  # twice the bytes, same result in the own shard
+
+    def _all_gather(self, buf):
+        """Every rank's shard of buf[:main] -> all ranks (in place)."""
+        b, e = self.shard_range()
+        try:
+            dist.all_gather_into_tensor(buf[: self.main], buf[b:e])
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather([buf[r * self.shard:(r + 1) * self.shard] for r in range(self.world)], buf[b:e].clone())
+
+    # ---- one step ------------------------------------------------------------------------------------------------------
+    def exchange_and_step(self):
+        """Call after training_step(run_optimizer=False): exchanges the gradients and runs the optimizer."""
+        if not self.active:
+            self.tm.optimizer_step(self.loss_scale)
+            return
+        start = self._tic()
+        if self.mode == "allreduce":
+            reduce_and_step(self.tm, self.grads, self.n_buckets, self.loss_scale)
+        else:
+            if self.main:
+                self._reduce_scatter(self.grads)
+            ranges = [self.shard_range()] if self.main else []
+            if self.main < self.n:
+                dist.all_reduce(self.grads[self.main:], op=dist.ReduceOp.SUM)
+                ranges.append((self.main, self.n))
+            self.tm.optimizer_step_ranges(ranges, self.loss_scale)
+            if self.main:
+                self._all_gather(self.params)
+                if self.params_inference is not None:
+                    self._all_gather(self.params_inference)
+        self._toc(start)
+
+    def gather_optimizer_state(self):
+        """Sharded mode: collects the fp32 master weights and Adam's state from their owners so that this rank can write a
+        complete snapshot (Trainer::serialize with the optimizer, trainer.h:442-455)."""
+        if not self.active or self.mode != "sharded" or not self.main:
+            return
+        m1, m2, steps, _ = self.tm.optimizer_state()
+        for buf in (self.tm.params_full_precision, m1, m2, steps):
+            self._all_gather(buf)
+
+
 def all_reduce_max(value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:
@@ -97,10 +216,14 @@ def barrier():
         dist.barrier()
 
 
-def training_step(tm, input, target, global_batch):
-    """One data-parallel training step on this rank's shard (`input`/`target` already sharded)."""
+def training_step(tm, input, target, global_batch, dp=None):
+    """One data-parallel training step on this rank's shard (`input`/`target` already sharded).  `dp`: a DataParallel to
+    reuse across steps (default: the bucketed all-reduce scheme)."""
     from ._C import GradientMode
     tm.set_global_batch_size(global_batch)
     ctx = tm.training_step(input, target, run_optimizer=False, gradient_mode=GradientMode.Overwrite)
-    reduce_and_step(tm, tm.param_gradients)
+    if dp is not None:
+        dp.exchange_and_step()
+    else:
+        reduce_and_step(tm, tm.param_gradients)
     return ctx

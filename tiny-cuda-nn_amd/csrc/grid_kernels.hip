@@ -1211,8 +1211,9 @@ __global__ void k_grid_indices(const GridMeta meta, const GridIO io, uint32_t* _
 
 // Cuts the (level, tile) items, level-major, into 8 runs of equal cost.  Cost of an item (measured per kind of level,
 // profiles/r02_exp_forward.txt): 4 for a level whose table fits a CU's 32 KiB L1 next to the streaming traffic
-// (<= 24 KiB), 8 for a hashed level (one L2 line per corner pair), 11 for a larger densely indexed level.  Falls back
-// to uniform costs if a run would need more than FWD_MAX_SEGMENTS segments.
+// (<= 24 KiB), 8 for a hashed level (one L2 line per corner pair), 11 for a larger densely indexed level, each times
+// (1 + 1.5 x the share of fetches that miss the L2) for tables beyond the L2 (T = 2^22: 16 MiB per level, 2.4x the
+// time of a 2 MiB level).  Falls back to uniform costs if a run would need more than FWD_MAX_SEGMENTS segments.
 static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t tile_samples) {
 	for (int uniform = 0; uniform < 2; ++uniform) {
 		ForwardPlan plan = {};
@@ -1223,7 +1224,10 @@ static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t 
 			const size_t table_bytes = (size_t)(meta.offset[l + 1] - meta.offset[l]) * meta.n_feat * sizeof(half_t);
 			const uint32_t entries = meta.offset[l + 1] - meta.offset[l];
 			const bool pow2 = (entries & (entries - 1u)) == 0u;  // hashed levels; densely indexed ones measure dearer per sample
-			cost[l] = uniform ? 8u : (table_bytes <= 24u * 1024u ? 4u : (pow2 ? 8u : 11u));
+			// share of the line fetches that miss the XCD's 4 MiB L2 (about 3 MiB of it hold the table while outputs stream through)
+			const double miss = std::max(0.0, 1.0 - 3.0 * 1048576.0 / (double)table_bytes);
+			const double base = table_bytes <= 24u * 1024u ? 4.0 : (pow2 ? 8.0 : 11.0);
+			cost[l] = uniform ? 16u : (uint32_t)(2.0 * base * (1.0 + 1.5 * miss) + 0.5);
 			total += (uint64_t)cost[l] * plan.tiles;
 		}
 		bool ok = true;

@@ -532,10 +532,14 @@ static bool mlp_train_wave_enabled() {
 }
 
 bool mlp_train_wave_supported(const MlpMeta& m, uint32_t n, LossType loss) {
-	if (!mlp_train_wave_enabled() || m.padded_out != 16 || m.in_width != 32) return false;
+	if (!mlp_train_wave_enabled() || m.padded_out != 16 || (m.in_width != 32 && m.in_width != 64)) return false;
 	// ReLU / None and (Relative)L2 only: the instances with out-of-line activation / loss calls gain nothing here
 	if (!act_is_simple(m.activation) || !act_is_simple(m.output_activation) || !loss_is_simple(loss)) return false;
 	if (n > (1u << 26)) return false;  // 32-bit element offsets inside the kernel
+	// 64 inputs: one hidden layer only -- with two (the benchmarks/mlp shape) the 144 fp32 weight-gradient accumulators per lane
+	// spill at two waves per SIMD (101 registers) and the instance measured slower than the workgroup-tiled kernel
+	// (0.077 vs 0.068 ms at N = 2^18, profiles/r02_exp_notes.txt)
+	if (m.in_width == 64) return m.width == 64 && m.n_hidden_matmuls == 0;
 	return (m.width == 64 && m.n_hidden_matmuls <= 1) || (m.width == 32 && m.n_hidden_matmuls <= 2);
 }
 
@@ -555,8 +559,9 @@ static void launch_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, 
 void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
                     const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
 	if (!mlp_train_wave_supported(m, n, la.type)) throw std::runtime_error("mlp_train_wave: unsupported shape, activation or loss (check mlp_train_wave_supported first)");
-	const uint32_t key = m.width * 10u + m.n_hidden_matmuls;
+	const uint32_t key = (m.in_width == 64 ? 10000u : 0u) + m.width * 10u + m.n_hidden_matmuls;
 	switch (key) {
+		case 10640: launch_train_wave<64, 64, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		case 640: launch_train_wave<64, 32, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		case 641: launch_train_wave<64, 32, 1>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		case 320: launch_train_wave<32, 32, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;

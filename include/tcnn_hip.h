@@ -150,6 +150,25 @@ uint32_t tcnn_trainer_optimizer_step_count(const tcnn_trainable_model_t* tm);   
 uint32_t tcnn_trainer_padded_output_width(const tcnn_trainable_model_t* tm);
 uint32_t tcnn_trainer_n_mlp_params(const tcnn_trainable_model_t* tm); /* "matrix" params: leading part of the buffer */
 
+/* GPUMatrixDynamic<T> as it crosses the boundary (gpu_matrix.h:106-250): m rows (features) x n columns (samples);
+ * column-major (CM == AoS, one sample's values contiguous, common.h:166-176): element (r, c) at data[c * stride + r];
+ * row-major (RM == SoA): data[r * stride + c].  stride >= the leading dimension, in elements. */
+#define TCNN_LAYOUT_ROW_MAJOR 0
+#define TCNN_LAYOUT_COLUMN_MAJOR 1
+typedef struct tcnn_matrix {
+	void* data;
+	uint32_t m, n, stride;
+	int layout;
+} tcnn_matrix_t;
+/* Trainer::training_step / Network::inference with the reference's matrix-typed signatures (trainer.h:254-264,
+ * object.h:214): `input`, `dL_dinput` and the inference `output` are GPUMatrixDynamic (any layout / stride); target,
+ * data_pdf and external_dL_dy are GPUMatrix (dense column-major), as in the reference.  Optional arguments may be NULL. */
+int tcnn_trainer_training_step_matrices(tcnn_trainable_model_t* tm, tcnn_stream_t stream, const tcnn_matrix_t* input, const tcnn_matrix_t* target,
+                                        const tcnn_matrix_t* data_pdf, int run_optimizer, const tcnn_matrix_t* dL_dinput, int use_inference_params,
+                                        int gradient_mode, const tcnn_matrix_t* external_dL_dy, tcnn_train_context_t** ctx_out);
+int tcnn_network_inference_matrices(tcnn_trainable_model_t* tm, tcnn_stream_t stream, const tcnn_matrix_t* input, const tcnn_matrix_t* output,
+                                    int use_inference_params);
+
 /* generate_random_uniform<float>(stream, rng, n, out, lower, upper) with `default_rng_t rng{seed}` (random.h:39-75,
  * pcg32.h:40-170): out[0..n) = U[lower, upper) from the pcg32 stream of `seed`, starting `*position` draws into it;
  * `*position` is advanced by n (what the reference's `rng.advance(n)` does), so successive calls continue one stream.

@@ -1,4 +1,4 @@
-// learn_function.cpp -- the hot path through the C++ facade (include/tiny-cuda-nn/config.h), spelled the way a
+// learn_function.cpp -- the hot path through the C++ facade (include/tiny-cuda-nn/*.h), host code only, spelled the way a
 // reference application spells it (README.md:40-67 / samples/mlp_learning_an_image.cu:214-311 of the reference):
 //   create_from_config -> trainer->training_step -> trainer->loss -> network->inference.
 // Learns a smooth 3-D -> 4-D function from synthetic samples, prints the loss curve, checks a snapshot round trip.
@@ -61,7 +61,7 @@ int main(int argc, char** argv) {
 		std::printf("inference mse=%g\n", mse);
 
 		// snapshot -> fresh model -> identical inference
-		const std::string snapshot = model.trainer->serialize(true);
+		const std::vector<uint8_t> snapshot = model.trainer->serialize(true);
 		auto restored = tcnn::create_from_config(n_input_dims, n_output_dims, CONFIG, /*seed=*/7);
 		restored.trainer->deserialize(snapshot);
 		tcnn::GPUMatrix<float> prediction2(n_output_dims, batch_size);
@@ -69,6 +69,36 @@ int main(int argc, char** argv) {
 		tcnn::hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 		const bool same = prediction2.to_cpu_vector() == pred;
 		std::printf("snapshot bytes=%zu restored_inference_identical=%d\n", snapshot.size(), int(same));
+
+		// GPUMatrixDynamic layouts (gpu_matrix.h:106-250): the same batch row-major (SoA), and column-major with a padded stride,
+		// must give the same inference bits; the output is written row-major with a stride as well
+		bool layouts_ok = true;
+		{
+			std::vector<float> soa(xs.size()), padded(size_t(n_input_dims + 1) * batch_size, -1.0f);
+			for (uint32_t i = 0; i < batch_size; ++i)
+				for (uint32_t d = 0; d < n_input_dims; ++d) {
+					soa[size_t(d) * batch_size + i] = xs[size_t(i) * n_input_dims + d];
+					padded[size_t(i) * (n_input_dims + 1) + d] = xs[size_t(i) * n_input_dims + d];
+				}
+			tcnn::GPUMatrixDynamic<float> in_rm(n_input_dims, batch_size, tcnn::RM);
+			in_rm.copy_from_host(soa);
+			tcnn::GPUMemory<float> padded_mem(padded.size());
+			padded_mem.copy_from_host(padded);
+			tcnn::GPUMatrixDynamic<float> in_strided(padded_mem.data(), n_input_dims, batch_size, tcnn::CM, n_input_dims + 1);
+			tcnn::GPUMatrixDynamic<float> out_a(n_output_dims, batch_size), out_rm(n_output_dims, batch_size, tcnn::RM);
+			model.network->inference(stream, in_rm, out_a);
+			model.network->inference(stream, in_strided, out_rm);
+			tcnn::hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+			const std::vector<float> a = out_a.to_cpu_vector(), b = out_rm.to_cpu_vector();
+			for (uint32_t i = 0; i < batch_size && layouts_ok; ++i)
+				for (uint32_t j = 0; j < n_output_dims; ++j)
+					layouts_ok = layouts_ok && a[size_t(i) * n_output_dims + j] == pred[size_t(i) * n_output_dims + j] && b[size_t(j) * batch_size + i] == pred[size_t(i) * n_output_dims + j];
+			// a training step from the row-major batch gives the same loss as from the column-major one (no optimizer step)
+			auto c1 = model.trainer->training_step(stream, training_batch, training_target, nullptr, /*run_optimizer=*/false);
+			auto c2 = model.trainer->training_step(stream, in_rm, training_target, nullptr, /*run_optimizer=*/false);
+			layouts_ok = layouts_ok && model.trainer->loss(stream, *c1) == model.trainer->loss(stream, *c2);
+			std::printf("layouts_identical=%d\n", int(layouts_ok));
+		}
 
 		// error behaviour: the reference throws std::runtime_error for a batch that is not a multiple of 256
 		bool threw = false;
@@ -78,7 +108,7 @@ int main(int argc, char** argv) {
 		} catch (const std::runtime_error& e) { threw = true; std::printf("expected error: %s\n", e.what()); }
 
 		(void)hipStreamDestroy(stream);
-		const bool ok = std::isfinite(last_loss) && last_loss < 0.5f * first_loss && same && threw;
+		const bool ok = std::isfinite(last_loss) && last_loss < 0.5f * first_loss && same && threw && layouts_ok;
 		std::printf(ok ? "OK\n" : "FAILED\n");
 		return ok ? 0 : 1;
 	} catch (const std::exception& e) {

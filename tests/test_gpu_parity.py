@@ -601,16 +601,18 @@ def test_snapshot_round_trip_resumes_training_bit_exactly():
         b.deserialize(msgpack.packb({"n_params": 4, "params_type": "__half", "params_binary": b"12345678"}, use_bin_type=True))
 
 
-def test_cpp_facade_sample():
-    """The header-only C++ facade (include/tiny-cuda-nn/config.h) over the C ABI: the sample application trains,
-    infers, round-trips a snapshot and sees the reference's error for a bad batch size."""
+@pytest.mark.parametrize("exe_name", ["learn_function", "learn_function_minijson"])
+def test_cpp_facade_sample(exe_name):
+    """The header-only C++ facade (include/tiny-cuda-nn/*.h) over the C ABI, with nlohmann::json and with the built-in
+    JSON value: the sample application trains, infers, round-trips a snapshot, feeds row-major / strided GPUMatrixDynamic
+    views (same bits as the dense column-major batch) and sees the reference's error for a bad batch size."""
     import subprocess
-    exe = os.path.join(ROOT, "samples", "learn_function")
+    exe = os.path.join(ROOT, "samples", exe_name)
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "samples"), "-s"])
     r = subprocess.run([exe, "150", "16384"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
-    assert "restored_inference_identical=1" in r.stdout
+    assert "restored_inference_identical=1" in r.stdout and "layouts_identical=1" in r.stdout
 
 
 @pytest.mark.parametrize("clustered", [False, True])
@@ -900,13 +902,14 @@ def test_grid_second_order_through_c_abi_and_double_backward(interp):
 
 
 def test_cpp_sample_learns_an_image(tmp_path):
-    """The reference's demo (samples/mlp_learning_an_image.cu) through the C++ facade: 2-D hash grid + MLP learn a test
-    card from random pixel lookups; the rendered image reaches a PSNR that only a working training path gives."""
+    """The reference's demo (samples/mlp_learning_an_image.cu; its training loop kept line for line in
+    samples/mlp_learning_an_image.hip) against the C++ facade: 2-D hash grid + MLP learn a test card from random pixel
+    lookups drawn by the library's pcg32 kernel; the rendered image reaches a PSNR that only a working training path gives."""
     import subprocess
     exe = os.path.join(ROOT, "samples", "mlp_learning_an_image")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "samples"), "-s"])
-    r = subprocess.run([exe, "-", "300", "65536"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    r = subprocess.run([exe, "-", "-", "300"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout + r.stderr
     psnr = float(r.stdout.split("psnr=")[1].split()[0])
     assert psnr > 25.0, r.stdout

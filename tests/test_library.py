@@ -109,3 +109,36 @@ def test_second_order_exists_for_the_grid_encoding_only():
     enc = C.create_encoding(3, {"otype": "HashGrid"})
     rc = lib.tcnn_module_backward_backward_input(enc._h, None, None, 256, None, None, None, None, None, None, None)
     assert rc == 1 and b"missing forward context" in lib.tcnn_last_error()
+
+
+@pytest.mark.parametrize("json_flag", [[], ["-DTCNN_JSON_HEADER=\"/opt/conda/include/json.hpp\""]])
+def test_cpp_facade_headers_compile_for_the_host(tmp_path, json_flag):
+    """include/tiny-cuda-nn/*.h are header-only host code over the C ABI: a caller spelled like the reference's
+    (create_from_config / Trainer<float, precision_t, precision_t> / GPUMatrixDynamic / GPUMemory / default_rng_t) compiles with g++,
+    with nlohmann::json where a copy exists and with the built-in JSON value otherwise."""
+    import subprocess
+    if json_flag and not os.path.exists("/opt/conda/include/json.hpp"):
+        pytest.skip("no nlohmann/json.hpp in this image")
+    src = tmp_path / "caller.cpp"
+    src.write_text(r'''
+#include <tiny-cuda-nn/config.h>
+using namespace tcnn;
+int caller(hipStream_t stream, json config, GPUMatrixDynamic<float>& in, GPUMatrix<float>& tgt, GPUMatrixDynamic<float>& out) {
+	TrainableModel m = create_from_config(3, 4, config);
+	auto ctx = m.trainer->training_step(stream, in, tgt, nullptr, true, nullptr, false, GradientMode::Overwrite, nullptr);
+	float l = m.trainer->loss(stream, *ctx);
+	m.network->inference(stream, in, out);
+	std::shared_ptr<Loss<precision_t>> loss{create_loss<precision_t>(config.value("loss", json::object()))};
+	std::shared_ptr<Optimizer<precision_t>> opt{create_optimizer<precision_t>(config.value("optimizer", json::object()))};
+	auto net = std::make_shared<NetworkWithInputEncoding<precision_t>>(3u, 4u, config.value("encoding", json::object()), config.value("network", json::object()));
+	Trainer<float, precision_t, precision_t> trainer(net, opt, loss);
+	default_rng_t rng{1337};
+	GPUMemory<float> mem(1024);
+	generate_random_uniform<float>(stream, rng, mem.size(), mem.data());
+	GPUMatrix<float> view = GPUMatrix<float>(mem.data(), 4, 256).slice_cols(0, 128);
+	return (int)l + (int)view.n() + (int)trainer.n_params() + (int)float(half(1.5f));
+}
+''')
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-D__HIP_PLATFORM_AMD__", *json_flag, "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", str(src)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]

@@ -21,7 +21,7 @@
 #include "../../include/tcnn_hip.h"
 #include "elementwise_kernels.h"
 #include "grid_kernels.h"
-#include "json_mini.h"
+#include "../../include/tiny-cuda-nn/json_mini.h"
 #include "mlp_kernels.h"
 #include "snapshot_msgpack.h"
 
@@ -589,6 +589,25 @@ struct Model {
 	}
 };
 
+// Layout of the caller's fp32 input / dL_dinput matrices (GPUMatrixDynamic: row- or column-major with a stride,
+// gpu_matrix.h:106-250).  The plain entry points pass dense column-major matrices (one sample's values contiguous); the
+// *_matrices entry points set this for the duration of their call (thread-local: one call per thread at a time).
+struct IoLayout {
+	bool set = false;
+	uint32_t in_stride_i = 0, in_stride_d = 0;  // input element (sample i, dim d) at [i * in_stride_i + d * in_stride_d]
+	uint32_t dx_stride_i = 0, dx_stride_d = 0;  // the same for dL_dinput
+};
+static thread_local IoLayout g_io_layout;
+static uint32_t in_stride_d() { return g_io_layout.set ? g_io_layout.in_stride_d : 1u; }
+static uint32_t dx_stride_d() { return g_io_layout.set ? g_io_layout.dx_stride_d : 1u; }
+struct IoLayoutGuard {
+	explicit IoLayoutGuard(const IoLayout& l) { g_io_layout = l; }
+	~IoLayoutGuard() { g_io_layout = IoLayout(); }
+};
+
+static uint32_t in_stride_i(const Model& md) { return g_io_layout.set ? g_io_layout.in_stride_i : md.n_input_dims; }
+static uint32_t dx_stride_i(const Model& md) { return g_io_layout.set ? g_io_layout.dx_stride_i : md.n_input_dims; }
+
 static void check_batch(uint32_t n, uint32_t widest = 128) {
 	if (n % BATCH_SIZE_GRANULARITY != 0) {  // object.h:170, 217, 298
 		throw std::runtime_error("Batch size " + std::to_string(n) + " must be a multiple of " + std::to_string(BATCH_SIZE_GRANULARITY) + ".");
@@ -615,7 +634,7 @@ static void encoding_forward(hipStream_t stream, const Model& md, uint32_t n, co
 	const uint32_t stride_k = soa ? n : 1u, stride_i = soa ? 1u : e.padded_output_width;
 	ProfScope prof(stream, STAGE_GRID_FWD);
 	if (e.is_grid) {
-		GridIO io = {input, md.n_input_dims, 1u, n, stride_k, stride_i};
+		GridIO io = {input, in_stride_i(md), in_stride_d(), n, stride_k, stride_i};
 		grid_forward(stream, e.grid, io, enc_params, out, dy_dx);
 		const uint32_t n_to_pad = e.padded_output_width - e.n_output_dims;
 		if (n_to_pad > 0) {  // grid.h:757-766: padded dims are zero
@@ -626,11 +645,11 @@ static void encoding_forward(hipStream_t stream, const Model& md, uint32_t n, co
 			}
 		}
 	} else if (e.is_frequency) {
-		frequency_forward(stream, n, e.n_dims, e.n_frequencies, e.padded_output_width, input, md.n_input_dims, 1u, out, stride_k, stride_i);
+		frequency_forward(stream, n, e.n_dims, e.n_frequencies, e.padded_output_width, input, in_stride_i(md), in_stride_d(), out, stride_k, stride_i);
 	} else if (e.is_oneblob) {
-		oneblob_forward(stream, n, e.n_dims, e.n_bins, e.padded_output_width, input, md.n_input_dims, 1u, out, stride_k, stride_i);
+		oneblob_forward(stream, n, e.n_dims, e.n_bins, e.padded_output_width, input, in_stride_i(md), in_stride_d(), out, stride_k, stride_i);
 	} else {
-		identity_forward(stream, n, e.n_dims, e.padded_output_width, e.id_scale, e.id_offset, input, md.n_input_dims, 1u, out, stride_k, stride_i);
+		identity_forward(stream, n, e.n_dims, e.padded_output_width, e.id_scale, e.id_offset, input, in_stride_i(md), in_stride_d(), out, stride_k, stride_i);
 	}
 }
 
@@ -729,7 +748,7 @@ static void encoding_backward(hipStream_t stream, const Model& md, const Forward
                               uint32_t lds_level_budget) {
 	const EncodingDesc& e = md.enc;
 	if (e.is_grid) {
-		GridIO io = {input, md.n_input_dims, 1u, n, stride_k, stride_i};
+		GridIO io = {input, in_stride_i(md), in_stride_d(), n, stride_k, stride_i};
 		if (want_grads && e.n_params > 0) {
 			half_t* grid_grads = dL_dparams + md.n_mlp_params();
 			// Overwrite vs Accumulate (grid.h:865-867) is handled inside: the owner-computes kernel stores
@@ -750,14 +769,14 @@ static void encoding_backward(hipStream_t stream, const Model& md, const Forward
 		}
 		if (dL_dinput) {
 			if (!ctx.dy_dx.ptr) throw std::runtime_error("backward: dL_dinput requested but forward was not run with prepare_input_gradients");
-			grid_backward_input(stream, md.n_input_dims, e.n_output_dims, io, dL_denc, ctx.dy_dx.as<float>(), dL_dinput, md.n_input_dims, 1u);
+			grid_backward_input(stream, md.n_input_dims, e.n_output_dims, io, dL_denc, ctx.dy_dx.as<float>(), dL_dinput, dx_stride_i(md), dx_stride_d());
 		}
 	} else if (dL_dinput && e.is_frequency) {
-		frequency_backward(stream, n, e.n_dims, e.n_frequencies, dL_denc, stride_k, stride_i, input, md.n_input_dims, 1u, dL_dinput, md.n_input_dims, 1u);
+		frequency_backward(stream, n, e.n_dims, e.n_frequencies, dL_denc, stride_k, stride_i, input, in_stride_i(md), in_stride_d(), dL_dinput, dx_stride_i(md), dx_stride_d());
 	} else if (dL_dinput && e.is_oneblob) {
-		oneblob_backward(stream, n, e.n_dims, e.n_bins, dL_denc, stride_k, stride_i, input, md.n_input_dims, 1u, dL_dinput, md.n_input_dims, 1u);
+		oneblob_backward(stream, n, e.n_dims, e.n_bins, dL_denc, stride_k, stride_i, input, in_stride_i(md), in_stride_d(), dL_dinput, dx_stride_i(md), dx_stride_d());
 	} else if (dL_dinput) {
-		identity_backward(stream, n, e.n_dims, e.id_scale, dL_denc, stride_k, stride_i, dL_dinput, md.n_input_dims, 1u);
+		identity_backward(stream, n, e.n_dims, e.id_scale, dL_denc, stride_k, stride_i, dL_dinput, dx_stride_i(md), dx_stride_d());
 	}
 }
 
@@ -1489,6 +1508,71 @@ int tcnn_network_inference(tcnn_trainable_model_t* tm, tcnn_stream_t stream_, ui
 	Scratch tmp(stream, (size_t)padded * n * sizeof(half_t));  // object.h:260
 	model_forward(stream, tm->md, n, input, tmp.as<half_t>(), use_inference_params ? tm->inference_params() : tm->params, nullptr, false);
 	trim_and_cast(stream, n, padded, tm->md.output_width(), tmp.as<half_t>(), output, tm->md.output_width(), 1u);  // object.h:269-270
+	TCNN_API_END
+}
+
+// ---- GPUMatrixDynamic-typed entry points (gpu_matrix.h:106-250): layout + stride of the caller's matrices honoured ----
+static IoLayout layout_of(const tcnn_matrix_t* input, const tcnn_matrix_t* dL_dinput, uint32_t n_input_dims, uint32_t n) {
+	auto check = [&](const tcnn_matrix_t* m, const char* what) {
+		if (!m->data) throw std::runtime_error(std::string(what) + ": null matrix data");
+		if (m->m != n_input_dims || m->n != n) throw std::runtime_error(std::string(what) + ": expected a " + std::to_string(n_input_dims) + " x " + std::to_string(n) + " matrix");
+		const uint32_t min_stride = m->layout == TCNN_LAYOUT_COLUMN_MAJOR ? m->m : m->n;
+		if (m->stride < min_stride) throw std::runtime_error(std::string(what) + ": stride smaller than the matrix' leading dimension");
+	};
+	IoLayout l;
+	l.set = true;
+	check(input, "input");
+	const bool cm = input->layout == TCNN_LAYOUT_COLUMN_MAJOR;
+	l.in_stride_i = cm ? input->stride : 1u;
+	l.in_stride_d = cm ? 1u : input->stride;
+	l.dx_stride_i = n_input_dims;
+	l.dx_stride_d = 1u;
+	if (dL_dinput) {
+		check(dL_dinput, "dL_dinput");
+		const bool dcm = dL_dinput->layout == TCNN_LAYOUT_COLUMN_MAJOR;
+		l.dx_stride_i = dcm ? dL_dinput->stride : 1u;
+		l.dx_stride_d = dcm ? 1u : dL_dinput->stride;
+	}
+	return l;
+}
+// target / data_pdf / external_dL_dy are GPUMatrix<T> (static column-major) in the reference's signatures (trainer.h:254-264)
+static const void* dense_cm(const tcnn_matrix_t* m, uint32_t rows, uint32_t n, const char* what) {
+	if (!m) return nullptr;
+	if (m->layout != TCNN_LAYOUT_COLUMN_MAJOR || m->stride != m->m || m->m != rows || m->n != n) {
+		throw std::runtime_error(std::string(what) + ": expected a dense column-major " + std::to_string(rows) + " x " + std::to_string(n) + " matrix");
+	}
+	return m->data;
+}
+
+int tcnn_trainer_training_step_matrices(tcnn_trainable_model_t* tm, tcnn_stream_t stream, const tcnn_matrix_t* input, const tcnn_matrix_t* target,
+                                        const tcnn_matrix_t* data_pdf, int run_optimizer, const tcnn_matrix_t* dL_dinput, int use_inference_params,
+                                        int gradient_mode, const tcnn_matrix_t* external_dL_dy, tcnn_train_context_t** ctx_out) {
+	TCNN_API_BEGIN
+	if (!input) throw std::runtime_error("training_step: input is required");
+	const uint32_t n = input->n;
+	const IoLayoutGuard guard(layout_of(input, dL_dinput, tm->md.n_input_dims, n));
+	const void* tgt = dense_cm(target, tm->md.output_width(), n, "target");
+	const void* pdf = dense_cm(data_pdf, tm->md.output_width(), n, "data_pdf");
+	const void* ext = dense_cm(external_dL_dy, tm->md.padded_output_width(), n, "external_dL_dy");  // trainer.h:125-126
+	const int r = tcnn_trainer_training_step(tm, stream, n, (const float*)input->data, (const float*)tgt, (const float*)pdf, run_optimizer,
+	                                         dL_dinput ? (float*)dL_dinput->data : nullptr, use_inference_params, gradient_mode, ext, ctx_out);
+	if (r != TCNN_OK) return r;
+	TCNN_API_END
+}
+
+int tcnn_network_inference_matrices(tcnn_trainable_model_t* tm, tcnn_stream_t stream_, const tcnn_matrix_t* input, const tcnn_matrix_t* output,
+                                    int use_inference_params) {
+	TCNN_API_BEGIN
+	if (!input || !output) throw std::runtime_error("inference: input and output are required");
+	hipStream_t stream = (hipStream_t)stream_;
+	const uint32_t n = input->n, padded = tm->md.padded_output_width(), width = tm->md.output_width();
+	const IoLayoutGuard guard(layout_of(input, nullptr, tm->md.n_input_dims, n));
+	if (output->m != width || output->n != n) throw std::runtime_error("inference: output must be n_output_dims x batch_size");  // object.h:221-222
+	const bool cm = output->layout == TCNN_LAYOUT_COLUMN_MAJOR;
+	if (output->stride < (cm ? output->m : output->n)) throw std::runtime_error("inference: output stride smaller than its leading dimension");
+	Scratch tmp(stream, (size_t)padded * n * sizeof(half_t));  // object.h:260
+	model_forward(stream, tm->md, n, (const float*)input->data, tmp.as<half_t>(), use_inference_params ? tm->inference_params() : tm->params, nullptr, false);
+	trim_and_cast(stream, n, padded, width, tmp.as<half_t>(), (float*)output->data, cm ? output->stride : 1u, cm ? 1u : output->stride);  // object.h:269-270
 	TCNN_API_END
 }
 

@@ -38,7 +38,11 @@ typedef struct tcnn_trainable_model tcnn_trainable_model_t; /* tcnn::TrainableMo
 typedef struct tcnn_train_context tcnn_train_context_t;     /* Trainer::ForwardContext, trainer.h:89-95 */
 typedef void* tcnn_stream_t;                                /* hipStream_t (cudaStream_t in the reference) */
 
-enum { TCNN_PRECISION_FP32 = 0, TCNN_PRECISION_FP16 = 1 };                  /* cpp_api.h:72-75 */
+/* cpp_api.h:72-75.  BF16 is this build's extension: libtcnn_hip_bf16.so is the same library compiled with bfloat16 as
+ * the parameter / activation / gradient type (the reference picks its type at compile time too, TCNN_HALF_PRECISION);
+ * its tcnn_preferred_precision() / param_precision() / output_precision() report TCNN_PRECISION_BF16 and every `void*`
+ * below that is documented as fp16 carries bfloat16 instead.  Snapshots name the type ("__half" / "__nv_bfloat16"). */
+enum { TCNN_PRECISION_FP32 = 0, TCNN_PRECISION_FP16 = 1, TCNN_PRECISION_BF16 = 2 };
 enum { TCNN_LOG_INFO = 0, TCNN_LOG_DEBUG, TCNN_LOG_WARNING, TCNN_LOG_ERROR, TCNN_LOG_SUCCESS }; /* cpp_api.h:52-58 */
 enum { TCNN_GRADIENT_IGNORE = 0, TCNN_GRADIENT_OVERWRITE = 1, TCNN_GRADIENT_ACCUMULATE = 2 };  /* common.h:152-156 */
 

@@ -100,6 +100,11 @@ def _p(a, t=None):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def set_half_format(bf16):
+    """The oracle's 16-bit type: IEEE fp16 (False, default) or bfloat16 (True: what libtcnn_hip_bf16.so computes in)."""
+    lib().orc_set_half_format(C.c_int(1 if bf16 else 0))
+
+
 def f2h(x):
     """float32 array -> uint16 half bit patterns (RNE)."""
     x = np.ascontiguousarray(x, dtype=np.float32)

@@ -21,10 +21,44 @@ int orc_num_threads(void) {
 #endif
 }
 
-/* ------------------------------------------------------------------ fp16 */
+/* ------------------------------------------------------------------ fp16 / bfloat16 */
+
+/* The product builds with IEEE fp16 or (libtcnn_hip_bf16.so, -DTCNN_BF16) with bfloat16 as its 16-bit type.  The oracle
+ * follows with a run-time switch: every "half" below is the selected format.  Not thread-safe; set it before a test. */
+static int g_bf16 = 0;
+void orc_set_half_format(int bf16) { g_bf16 = bf16 ? 1 : 0; }
+int orc_get_half_format(void) { return g_bf16; }
+
+static uint16_t d2bf(double d) {
+	/* double -> bfloat16 (1 + 8 + 7 bits), round-to-nearest-even, directly */
+	union { double d; uint64_t u; } v;
+	v.d = d;
+	uint16_t sign = (uint16_t)((v.u >> 48) & 0x8000u);
+	uint64_t absu = v.u & 0x7fffffffffffffffULL;
+	if (absu >= 0x7ff0000000000000ULL) return (uint16_t)(sign | 0x7f80u | ((absu > 0x7ff0000000000000ULL) ? 0x40u : 0));
+	if (absu == 0) return sign;
+	int e = (int)(absu >> 52) - 1023;
+	uint64_t mant = (absu & 0x000fffffffffffffULL) | 0x0010000000000000ULL;
+	if (e > 127) return (uint16_t)(sign | 0x7f80u);
+	int shift, he;
+	if (e >= -126) {
+		shift = 45; /* keep 8 bits (1 + 7) */
+		he = e + 127;
+	} else {
+		shift = 45 + (-126 - e);
+		he = 0;
+		if (shift > 63) return sign;
+	}
+	uint64_t kept = mant >> shift, rem = mant & (((uint64_t)1 << shift) - 1), half = (uint64_t)1 << (shift - 1);
+	if (rem > half || (rem == half && (kept & 1))) kept++;
+	uint32_t out = he == 0 ? (uint32_t)kept : ((uint32_t)he << 7) + (uint32_t)(kept - 0x80);
+	if (out >= 0x7f80u) out = 0x7f80u;
+	return (uint16_t)(sign | out);
+}
 
 static uint16_t d2h(double d) {
 	/* double -> binary16, round-to-nearest-even, directly (no intermediate float rounding) */
+	if (g_bf16) return d2bf(d);
 	union { double d; uint64_t u; } v;
 	v.d = d;
 	uint16_t sign = (uint16_t)((v.u >> 48) & 0x8000u);
@@ -63,6 +97,11 @@ static uint16_t d2h(double d) {
 uint16_t orc_f2h(float f) { return d2h((double)f); }
 
 float orc_h2f(uint16_t h) {
+	if (g_bf16) {
+		union { uint32_t u; float f; } b;
+		b.u = (uint32_t)h << 16;
+		return b.f;
+	}
 	uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
 	uint32_t e = (h >> 10) & 0x1f;
 	uint32_t m = h & 0x3ff;
@@ -95,6 +134,8 @@ void orc_h2f_array(const uint16_t* in, float* out, size_t n) {
  * double unless the exponents are > 30 apart, in which case the small term cannot move the result
  * across a half rounding boundary (c is itself a half). */
 static inline uint16_t hfma(uint16_t a, uint16_t b, uint16_t c) {
+	/* bfloat16: gfx950 has no bf16 fma; the kernel's chain is an fp32 fma rounded to bf16 (tcnn_device.h fma_h) */
+	if (g_bf16) return d2h((double)fmaf(orc_h2f(a), orc_h2f(b), orc_h2f(c)));
 	return d2h((double)orc_h2f(a) * (double)orc_h2f(b) + (double)orc_h2f(c));
 }
 static inline uint16_t hmul(uint16_t a, uint16_t b) {

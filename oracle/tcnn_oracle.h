@@ -39,7 +39,9 @@ enum { ORC_ACT_NONE = 0, ORC_ACT_RELU = 1, ORC_ACT_LEAKY_RELU = 2, ORC_ACT_EXPON
 enum { ORC_LOSS_L2 = 0, ORC_LOSS_RELATIVE_L2 = 1, ORC_LOSS_L1 = 2, ORC_LOSS_RELATIVE_L1 = 3, ORC_LOSS_MAPE = 4, ORC_LOSS_SMAPE = 5,
        ORC_LOSS_CROSS_ENTROPY = 6, ORC_LOSS_VARIANCE = 7, ORC_LOSS_RELATIVE_L2_LUMINANCE = 8 }; /* names: src/loss.cu:57-65 */
 
-/* ---- fp16 ---- */
+/* ---- the 16-bit type: IEEE fp16 (default) or bfloat16 (the product's -DTCNN_BF16 build); process-wide switch ---- */
+void orc_set_half_format(int bf16);
+int orc_get_half_format(void);
 uint16_t orc_f2h(float f);
 float orc_h2f(uint16_t h);
 void orc_f2h_array(const float* in, uint16_t* out, size_t n);

@@ -1,0 +1,167 @@
+"""Parity cases of the bfloat16 build (libtcnn_hip_bf16.so: the same sources compiled with -DTCNN_BF16, bf16 MFMA tiles,
+bf16 parameters / activations / gradients) against the oracle's bfloat16 mode.  Run by tests/test_gpu_bf16.py in a process
+of its own with TCNN_PRECISION=bf16 (the 16-bit type is a build-time choice of the library, one library per process).
+
+Bars: grid indices and encoded features bit-exact (the bf16 interpolation chain is an fp32 fma rounded to bf16 on both
+sides); loss gradients bit-exact given the GPU's own prediction; network outputs / gradients RAE p99 <= 3e-2 (bf16 has 8
+significant bits: 8x fp16's spacing, and the fp16 bar is 3e-3); training converges.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ADAM_HASH, HASH_ENCODING, HASH_ENCODING_SMALL, MLP_64x2, config_hash
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _bf16_oracle():
+    O.set_half_format(True)
+    yield
+    O.set_half_format(False)
+
+
+def tcnn():
+    import tinycudann
+    return tinycudann
+
+
+def h_np(t):
+    return t.detach().contiguous().cpu().view(torch.int16).numpy().view(np.uint16)
+
+
+def h_t(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).view(BF).cuda()
+
+
+def rae(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b) / (0.5 * (np.abs(a) + np.abs(b)) + np.abs(b).mean() * 1e-2 + 1e-12)
+
+
+def positions(n, d, seed=1337):
+    return O.generate_random_uniform(O.pcg32(seed), n * d, 0.0, 1.0).reshape(n, d)
+
+
+def targets_for(pos, out):
+    return np.stack([0.5 + 0.5 * np.sin(2 * np.pi * (c % 4 + 1) * pos[:, 0]) * np.cos(2 * np.pi * pos[:, 1]) for c in range(out)], 1).astype(np.float32)
+
+
+def test_the_bf16_library_is_the_one_loaded():
+    T = tcnn()
+    assert os.environ.get("TCNN_PRECISION") == "bf16"
+    assert T._C.library_path().endswith("libtcnn_hip_bf16.so") and "libtcnn_hip_bf16.so" in open("/proc/self/maps").read()
+    assert T._C.preferred_precision() == T._C.Precision.Bf16
+    with pytest.raises(RuntimeError):
+        T._C.create_encoding(3, HASH_ENCODING_SMALL, T._C.Precision.Fp16)  # the other build's type
+
+
+@pytest.mark.parametrize("d,enc", [(3, HASH_ENCODING), (3, HASH_ENCODING_SMALL), (2, HASH_ENCODING_SMALL),
+                                   (3, dict(HASH_ENCODING, n_levels=8, n_features_per_level=4, log2_hashmap_size=14, interpolation="Smoothstep"))])
+def test_grid_forward_bit_exact_and_backward(d, enc):
+    C = tcnn()._C
+    m = C.create_encoding(d, enc)
+    g = O.grid_init(d, enc["n_levels"], enc["n_features_per_level"], enc["log2_hashmap_size"], enc["base_resolution"], enc["per_level_scale"],
+                    O.GRID_HASH, O.INTERP_SMOOTHSTEP if enc.get("interpolation") == "Smoothstep" else O.INTERP_LINEAR)
+    assert m.n_params() == g.n_params
+    n = 4096
+    pos = positions(n, d, seed=4)
+    params = O.f2h(O.generate_random_uniform(O.pcg32(9), g.n_params, -1.0, 1.0))
+    x, p = torch.from_numpy(pos).cuda(), h_t(params).requires_grad_(True)
+    ctx, out = m.fwd(x, p)
+    assert out.dtype == BF
+    assert np.array_equal(m.grid_indices(x).cpu().numpy().reshape(n, g.n_levels, 1 << d), O.grid_indices(g, pos))
+    assert np.array_equal(h_np(out), O.grid_forward(g, params, pos))
+    dy = O.f2h(np.random.default_rng(1).standard_normal((n, out.shape[1])).astype(np.float32) * 0.1)
+    _, grad = m.bwd(ctx, x, p, out, h_t(dy))
+    ref = O.grid_backward(g, pos, dy)
+    scale = np.abs(ref).max()
+    assert np.abs(grad.float().cpu().numpy() - ref).max() <= 2.0 ** -6 * scale  # exact sums rounded once to bf16
+
+
+@pytest.mark.parametrize("IN,W,OUT,H", [(32, 64, 4, 2), (32, 128, 16, 4), (64, 64, 16, 2), (32, 32, 3, 3)])
+def test_network_forward_backward(IN, W, OUT, H):
+    C = tcnn()._C
+    net = dict(MLP_64x2, n_neurons=W, n_hidden_layers=H)
+    m = C.create_network(IN, OUT, net)
+    om = O.mlp_init(IN, W, OUT, H)
+    ph = O.f2h(O.mlp_init_params(om, O.pcg32(5)))
+    n = 2048
+    rng = np.random.default_rng(3)
+    xin = rng.random((n, IN), dtype=np.float32)
+    x = torch.from_numpy(xin).cuda()
+    p = h_t(ph).requires_grad_(True)
+    ctx, out = m.fwd(x, p)
+    enc = O.identity_forward(xin, IN)
+    hid, ref = O.mlp_forward(om, ph, enc)
+    assert np.percentile(rae(O.h2f(h_np(out)), O.h2f(ref)), 99) < 3e-2
+    dy = O.f2h(rng.standard_normal((n, om.padded_out)).astype(np.float32))
+    dx, grad = m.bwd(ctx, x, p, out, h_t(dy))
+    gref, _ = O.mlp_backward(om, ph, enc, hid, ref, dy)
+    got = grad.float().cpu().numpy()
+    # sums of n random-signed terms cancel: entry-wise bars for the shallow shapes, the norm for the deep ones (every layer's
+    # dL/dactivation is rounded to 8 significant bits and flips ReLU masks of borderline activations)
+    assert np.linalg.norm(got - gref) < 2e-2 * np.linalg.norm(gref)
+    if H <= 2:
+        assert np.percentile(rae(got, gref), 99) < 3e-2
+
+
+@pytest.mark.parametrize("width,hidden,out,log2_t,n", [(64, 2, 4, 15, 4096), (128, 4, 16, 17, 8192)])
+def test_training_step_matches_oracle_and_converges(width, hidden, out, log2_t, n):
+    """create_from_config -> training_step in bfloat16; the second case is the stress shape of BASELINE configs[4]
+    (128-wide x 4 hidden layers, 16 outputs) at an oracle-sized table."""
+    T = tcnn()
+    cfg = config_hash(log2_hashmap_size=log2_t, per_level_scale=1.5, n_neurons=width, n_hidden_layers=hidden)
+    tm = T.create_from_config(3, out, cfg)
+    g = O.grid_init(3, 16, 2, log2_t, 16, 1.5)
+    md = O.model_init(3, out, g, width, hidden, O.LOSS_RELATIVE_L2, O.adam_defaults(learning_rate=1e-2, beta1=0.9, beta2=0.99, epsilon=1e-15, l2_reg=1e-6))
+    init = tm.params_full_precision.cpu().numpy().copy()
+    nm = md.mlp.n_params
+    init[nm:] *= 1.0e3
+    tm.set_params_full_precision(torch.from_numpy(init))
+    assert tm.params.dtype == BF and np.array_equal(h_np(tm.params), O.f2h(init))
+    st = O.TrainState(md, init)
+    pos = positions(n, 3, seed=21)
+    tgt = targets_for(pos, out)
+    x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(tgt).cuda()
+
+    ctx = tm.training_step(x, t, run_optimizer=False)
+    loss_ref, pred_ref = O.training_step(st, pos, tgt, run_optimizer=False, want_prediction=True)
+    assert abs(tm.loss(ctx) - loss_ref) <= 2e-2 * abs(loss_ref)
+    assert np.percentile(rae(O.h2f(h_np(ctx.output)), O.h2f(pred_ref)), 99) < 3e-2
+    _, g_loss = O.loss(md.loss_type, h_np(ctx.output), tgt, out)
+    assert np.array_equal(h_np(ctx.dL_doutput), g_loss)
+    gq, gref = tm.param_gradients.float().cpu().numpy(), O.h2f(st.grads)
+    assert np.isfinite(gq).all()
+    assert np.percentile(rae(gq[:nm], gref[:nm]), 99) < 5e-2
+    assert np.linalg.norm(gq[nm:] - gref[nm:]) < 5e-2 * np.linalg.norm(gref[nm:])
+
+    losses = [tm.loss(tm.training_step(x, t)) for _ in range(30)]
+    assert all(np.isfinite(losses)) and losses[-1] < 0.5 * losses[0], losses
+    w = tm.params_full_precision.cpu().numpy()
+    assert np.array_equal(h_np(tm.params), O.f2h(w))  # Adam's 16-bit copy is the RNE bfloat16 of its fp32 master weights
+    a, b = tm.inference(x), tm.inference(x)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+def test_torch_modules_and_snapshot_in_bf16():
+    import msgpack
+    T = tcnn()
+    net = T.NetworkWithInputEncoding(3, 4, HASH_ENCODING_SMALL, MLP_64x2).cuda()
+    assert net.params.dtype == torch.float32  # torch owns fp32 parameters, cast per call (modules.py:230)
+    x = torch.rand(1000, 3, device="cuda")
+    y = net(x)
+    assert y.dtype == BF and y.shape == (1000, 4)
+    y.float().square().mean().backward()
+    assert net.params.grad is not None and torch.isfinite(net.params.grad).all() and net.params.grad.abs().max() > 0
+    tm = T.create_from_config(3, 4, config_hash(log2_hashmap_size=12, per_level_scale=1.5))
+    doc = msgpack.unpackb(tm.serialize(), raw=False)
+    assert doc["params_type"] == "__nv_bfloat16" and len(doc["params_binary"]) == 2 * tm.n_params
+    other = T.create_from_config(3, 4, config_hash(log2_hashmap_size=12, per_level_scale=1.5), seed=5)
+    other.deserialize(tm.serialize())
+    assert torch.equal(other.params.view(torch.int16), tm.params.view(torch.int16))

@@ -431,3 +431,22 @@ def test_fp16_accumulate_mode_brackets_the_fp32_accumulate_results():
     ga, gb = O.h2f(a.grads)[:md.mlp.n_params], O.h2f(b.grads)[:md.mlp.n_params]
     assert not np.array_equal(ga, gb)
     assert np.linalg.norm(ga - gb) < 3e-2 * np.linalg.norm(ga)
+
+
+def test_bfloat16_mode_conversions_match_torch():
+    """The oracle's bfloat16 mode (the format libtcnn_hip_bf16.so computes in) is pinned against torch's bfloat16 rounding:
+    RNE from fp32 incl. subnormals, infinities and ties; fp16 mode is restored afterwards."""
+    import torch
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(100000) * 10.0 ** rng.integers(-30, 30, 100000)).astype(np.float32)
+    x = np.concatenate([x, np.array([0, -0.0, 1e-40, -1e-40, 3.4e38, np.inf, -np.inf, 1.0, 1.00390625, 1.005859375, 1.01171875], np.float32)])
+    try:
+        O.set_half_format(True)
+        h = O.f2h(x)
+        t = torch.from_numpy(x).to(torch.bfloat16)
+        assert np.array_equal(h, t.view(torch.int16).numpy().view(np.uint16))
+        assert np.array_equal(O.h2f(h), t.float().numpy())
+    finally:
+        O.set_half_format(False)
+    small = x[np.abs(x) < 6e4]
+    assert np.array_equal(O.f2h(small), torch.from_numpy(small).half().view(torch.int16).numpy().view(np.uint16))

@@ -889,8 +889,13 @@ void tcnn_free_temporary_memory(void) {
 	ZeroedCounters::free_all();
 }
 int tcnn_has_networks(void) { return 1; }
+// this build's 16-bit type (tcnn_device.h): fp16, or bfloat16 when compiled with -DTCNN_BF16
+static constexpr int NATIVE_PRECISION = HALF_IS_BF16 ? TCNN_PRECISION_BF16 : TCNN_PRECISION_FP16;
+static const char* const NATIVE_TYPE_NAME = HALF_IS_BF16 ? "__nv_bfloat16" : "__half";  // gpu_memory_json.h type strings
+// the loss scale is kept at 128 for bfloat16 as well: harmless for its range, and the exact fixed-point accumulation of
+// the grid backward (2^-24 resolution) relies on gradients of that magnitude
 float tcnn_default_loss_scale(int precision) { return precision == TCNN_PRECISION_FP32 ? 1.0f : LOSS_SCALE_FP16; }
-int tcnn_preferred_precision(void) { return TCNN_PRECISION_FP16; }
+int tcnn_preferred_precision(void) { return NATIVE_PRECISION; }
 int tcnn_supports_jit_fusion(int) { return 0; }
 void tcnn_set_log_callback(void (*callback)(int, const char*)) { g_log_callback = callback; }
 
@@ -919,8 +924,9 @@ int tcnn_create_network(uint32_t n_input_dims, uint32_t n_output_dims, const cha
 
 int tcnn_create_encoding(uint32_t n_input_dims, const char* encoding_json, int requested_precision, tcnn_module_t** out) {
 	TCNN_API_BEGIN
-	if (requested_precision != TCNN_PRECISION_FP16) {
-		g_last_error = "create_encoding: only fp16 encodings are available in this build";
+	if (requested_precision != NATIVE_PRECISION) {
+		g_last_error = HALF_IS_BF16 ? "create_encoding: only bf16 encodings are available in this build (libtcnn_hip_bf16.so)"
+		                            : "create_encoding: only fp16 encodings are available in this build";
 		return TCNN_ERROR_UNSUPPORTED;
 	}
 	auto m = std::make_unique<tcnn_module>();
@@ -1013,8 +1019,8 @@ void tcnn_context_destroy(tcnn_context_t* ctx) { delete ctx; }
 uint32_t tcnn_module_n_input_dims(const tcnn_module_t* m) { return m->md.n_input_dims; }
 uint32_t tcnn_module_n_output_dims(const tcnn_module_t* m) { return m->md.padded_output_width(); }
 size_t tcnn_module_n_params(const tcnn_module_t* m) { return m->md.n_params(); }
-int tcnn_module_param_precision(const tcnn_module_t*) { return TCNN_PRECISION_FP16; }
-int tcnn_module_output_precision(const tcnn_module_t*) { return TCNN_PRECISION_FP16; }
+int tcnn_module_param_precision(const tcnn_module_t*) { return NATIVE_PRECISION; }
+int tcnn_module_output_precision(const tcnn_module_t*) { return NATIVE_PRECISION; }
 
 int tcnn_module_initialize_params(tcnn_module_t* m, size_t seed, float* params_full_precision, float scale) {
 	TCNN_API_BEGIN
@@ -1615,7 +1621,7 @@ static Snapshot snapshot_shape(const tcnn_trainable_model* tm, bool with_optimiz
 	const size_t n = tm->md.n_params();
 	Snapshot s;
 	s.n_params = n;
-	s.params_type = "__half";
+	s.params_type = NATIVE_TYPE_NAME;
 	s.params.size = n * sizeof(half_t);
 	s.has_optimizer = with_optimizer;
 	s.current_step = tm->optimizer_step;
@@ -1677,14 +1683,14 @@ int tcnn_trainer_deserialize(tcnn_trainable_model_t* tm, const void* data, size_
 		if (s.params.size != n * sizeof(float)) throw std::runtime_error("Can't set fp params because buffer has the wrong size.");  // trainer.h:410-412
 		HIP_CHECK(hipMemcpy(tm->master, s.params.data, s.params.size, hipMemcpyHostToDevice));
 		cast_master_to_params(tm, nullptr);
-	} else if (s.params_type == "__half") {
+	} else if (s.params_type == NATIVE_TYPE_NAME) {
 		if (s.params.size != n * sizeof(half_t)) throw std::runtime_error("Can't set params because buffer has the wrong size.");  // trainer.h:424-426
 		HIP_CHECK(hipMemcpy(tm->params, s.params.data, s.params.size, hipMemcpyHostToDevice));
 		tm->params_t_valid = false;
 		cast_f16_to_f32(nullptr, n, tm->params, tm->master);
 		HIP_CHECK(hipMemsetAsync(tm->grads, 0, n * sizeof(half_t), nullptr));
 	} else {
-		throw std::runtime_error("Trainer: snapshot parameters must be of type float of __half");  // trainer.h:473
+		throw std::runtime_error(std::string("Trainer: snapshot parameters must be of type float of ") + NATIVE_TYPE_NAME);  // trainer.h:473
 	}
 	if (s.has_optimizer) {
 		if (!s.first_moments.present() || !s.second_moments.present() || s.first_moments.size != n * sizeof(float) || s.second_moments.size != n * sizeof(float))

@@ -33,10 +33,23 @@
 
 namespace tcnn_hip {
 
+// The parameter / activation / gradient type is a compile-time choice, as in the reference (TCNN_HALF_PRECISION ->
+// network_precision_t, common.h:66-70): the sources build once with IEEE fp16 (libtcnn_hip.so) and once, with -DTCNN_BF16,
+// with bfloat16 (libtcnn_hip_bf16.so: v_mfma_f32_16x16x32_bf16, fp32 range for activations and gradients -- the stress
+// shape of BASELINE configs[4]).  `half_t` is that type; everything below is written against it.
+#if defined(TCNN_BF16)
+typedef __bf16 half_t;
+typedef __bf16 h2 __attribute__((ext_vector_type(2)));
+typedef __bf16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 h8 __attribute__((ext_vector_type(8)));
+constexpr bool HALF_IS_BF16 = true;
+#else
 typedef _Float16 half_t;
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr bool HALF_IS_BF16 = false;
+#endif
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u2 __attribute__((ext_vector_type(2)));
@@ -53,6 +66,18 @@ constexpr float LOSS_SCALE_FP16 = 128.0f;          // reference common.h:243
 //   C/D (both):    row = 4*(lane>>4) + r, col = lane&15, r<4
 // ---------------------------------------------------------------------------------------------
 #if !defined(TCNN_HOST_EMU)
+#if defined(TCNN_BF16)
+typedef short bf16_bits2 __attribute__((ext_vector_type(2)));
+typedef short bf16_bits4 __attribute__((ext_vector_type(4)));
+TCNN_DEVICE f4 mfma_16x16x32(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+TCNN_DEVICE f4 mfma_16x16x16(h4 a, h4 b, f4 c) {
+	return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16_bits4, a), __builtin_bit_cast(bf16_bits4, b), c, 0, 0, 0);
+}
+// Packed global atomic add (global_atomic_pk_add_bf16), no return value.
+TCNN_DEVICE void atomic_add_h2(half_t* addr, h2 v) {
+	__builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) bf16_bits2*)addr, __builtin_bit_cast(bf16_bits2, v));
+}
+#else
 TCNN_DEVICE f4 mfma_16x16x32(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 TCNN_DEVICE f4 mfma_16x16x16(h4 a, h4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
 
@@ -60,15 +85,26 @@ TCNN_DEVICE f4 mfma_16x16x16(h4 a, h4 b, f4 c) { return __builtin_amdgcn_mfma_f3
 TCNN_DEVICE void atomic_add_h2(half_t* addr, h2 v) {
 	__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)addr, v);
 }
+#endif
 TCNN_DEVICE void atomic_add_f32(float* addr, float v) { unsafeAtomicAdd(addr, v); }
 TCNN_DEVICE void lds_atomic_add_f32(float* addr, float v) { atomicAdd(addr, v); }  // ds_add_f32
 TCNN_DEVICE void lds_atomic_add_u64(unsigned long long* addr, unsigned long long v) { atomicAdd(addr, v); }  // ds_add_u64
+TCNN_DEVICE uint32_t atomic_add_u32(uint32_t* addr, uint32_t v) { return atomicAdd(addr, v); }  // returns the old value (LDS or global)
+#if defined(TCNN_BF16)
+TCNN_DEVICE void lds_atomic_add_h2(h2* addr, h2 v) {  // ds_pk_add_bf16
+	__builtin_amdgcn_ds_atomic_fadd_v2bf16((__attribute__((address_space(3))) bf16_bits2*)addr, __builtin_bit_cast(bf16_bits2, v));
+}
+// gfx950 has no bf16 fma: the interpolation chain of grid.h:144-163 (`fma` in the parameter type) is an fp32 fma rounded
+// to bf16 -- the oracle's bf16 mode restates exactly this
+TCNN_DEVICE half_t fma_h(half_t a, half_t b, half_t c) { return (half_t)__builtin_fmaf((float)a, (float)b, (float)c); }
+TCNN_DEVICE h2 fma_h2(h2 a, h2 b, h2 c) { return h2{fma_h(a[0], b[0], c[0]), fma_h(a[1], b[1], c[1])}; }
+#else
 TCNN_DEVICE void lds_atomic_add_h2(h2* addr, h2 v) {  // ds_pk_add_f16
 	__builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) h2*)addr, v);
 }
-TCNN_DEVICE uint32_t atomic_add_u32(uint32_t* addr, uint32_t v) { return atomicAdd(addr, v); }  // returns the old value (LDS or global)
 TCNN_DEVICE h2 fma_h2(h2 a, h2 b, h2 c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f16
 TCNN_DEVICE half_t fma_h(half_t a, half_t b, half_t c) { return __builtin_fmaf16(a, b, c); }
+#endif
 TCNN_DEVICE uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)); }  // HW_REG_XCC_ID
 #endif
 

@@ -12,8 +12,11 @@ import os
 import torch  # must be imported first: libtcnn_hip.so binds to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# The 16-bit parameter / activation type is a build-time choice of the native library (as TCNN_HALF_PRECISION is in the
+# reference): TCNN_PRECISION=bf16 in the environment selects the bfloat16 build of the same sources before the import.
 # TCNN_HIP_LIBRARY: load another build of the same library (kernel tuning experiments)
-_LIB_PATH = os.environ.get("TCNN_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libtcnn_hip.so")
+_LIB_NAME = "libtcnn_hip_bf16.so" if os.environ.get("TCNN_PRECISION", "fp16").lower() in ("bf16", "bfloat16") else "libtcnn_hip.so"
+_LIB_PATH = os.environ.get("TCNN_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", _LIB_NAME)
 
 if not os.path.exists(_LIB_PATH):
     raise ImportError(
@@ -25,9 +28,13 @@ _lib = C.CDLL(_LIB_PATH)
 OK = 0
 
 
-class Precision(enum.IntEnum):  # cpp_api.h:72-75
+class Precision(enum.IntEnum):  # cpp_api.h:72-75 (+ the bfloat16 build of this library)
     Fp32 = 0
     Fp16 = 1
+    Bf16 = 2
+
+
+TORCH_DTYPE = {Precision.Fp32: torch.float, Precision.Fp16: torch.half, Precision.Bf16: torch.bfloat16}
 
 
 class LogSeverity(enum.IntEnum):  # cpp_api.h:52-58
@@ -235,10 +242,10 @@ class Module:
             self._h = None
 
     def _torch_param_dtype(self):
-        return torch.half if self.param_precision() == Precision.Fp16 else torch.float
+        return TORCH_DTYPE[Precision(self.param_precision())]
 
     def _torch_output_dtype(self):
-        return torch.half if self.output_precision() == Precision.Fp16 else torch.float
+        return TORCH_DTYPE[Precision(self.output_precision())]
 
     def fwd(self, input, params):
         _check_input(input)
@@ -388,7 +395,9 @@ def create_network(n_input_dims, n_output_dims, network):
     return Module(h.value)
 
 
-def create_encoding(n_input_dims, encoding, precision=Precision.Fp16):
+def create_encoding(n_input_dims, encoding, precision=None):
+    if precision is None:
+        precision = preferred_precision()
     h = C.c_void_p()
     _check(_lib.tcnn_create_encoding(n_input_dims, _dumps(encoding), int(precision), C.byref(h)))
     return Module(h.value)

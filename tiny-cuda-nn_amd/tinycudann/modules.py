@@ -21,11 +21,10 @@ from . import _C
 
 
 def _torch_precision(p):
-    if p == _C.Precision.Fp16:
-        return torch.half
-    if p == _C.Precision.Fp32:
-        return torch.float
-    raise ValueError(f"Unknown precision {p}")
+    try:
+        return _C.TORCH_DTYPE[_C.Precision(p)]
+    except (KeyError, ValueError):
+        raise ValueError(f"Unknown precision {p}")
 
 
 def supports_jit_fusion():
@@ -201,8 +200,10 @@ class Encoding(Module):
             self.precision = _C.Precision.Fp32
         elif dtype == torch.float16:
             self.precision = _C.Precision.Fp16
+        elif dtype == torch.bfloat16:  # the bfloat16 build of the library (TCNN_PRECISION=bf16)
+            self.precision = _C.Precision.Bf16
         else:
-            raise ValueError(f"Encoding only supports fp32 or fp16 precision, but got {dtype}")
+            raise ValueError(f"Encoding only supports fp32, fp16 or bf16 precision, but got {dtype}")
         super().__init__(seed=seed)
         self.n_output_dims = self.native_tcnn_module.n_output_dims()
 

@@ -15,6 +15,16 @@ from . import _C
 from ._C import GradientMode, _check, _lib, _ptr, _stream
 
 
+# the library's 16-bit type as torch sees it: float16, or bfloat16 for the TCNN_PRECISION=bf16 build (which
+# __cuda_array_interface__ cannot name: such views travel as int16 and are reinterpreted)
+HALF_DTYPE = _C.TORCH_DTYPE[_C.preferred_precision()]
+
+
+def _half_tensor(ptr, n, owner):
+    t = torch.as_tensor(_DeviceView(ptr, n, "<i2", owner), device="cuda")
+    return t.view(HALF_DTYPE)
+
+
 class _DeviceView:
     """Exposes trainer-owned device memory to torch through __cuda_array_interface__ (no copy)."""
 
@@ -33,7 +43,7 @@ class ForwardContext:
         self._owner = owner
 
     def _view(self, ptr):
-        return torch.as_tensor(_DeviceView(ptr, self.batch_size * self.padded, "<f2", self), device="cuda").view(self.batch_size, self.padded)
+        return _half_tensor(ptr, self.batch_size * self.padded, self).view(self.batch_size, self.padded)
 
     @property
     def output(self):
@@ -137,6 +147,8 @@ class TrainableModel:
         return int(_lib.tcnn_trainer_n_mlp_params(self._h))
 
     def _tensor(self, ptr, typestr):
+        if typestr == "<f2":
+            return _half_tensor(ptr, self.n_params, self)
         return torch.as_tensor(_DeviceView(ptr, self.n_params, typestr, self), device="cuda")
 
     @property

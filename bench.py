@@ -152,10 +152,11 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(w, x, t, budget_s=12.0):
+def cpu_baseline(w, x, t, budget_s=12.0, bf16=False):
     """The reference's path has no CPU implementation and cannot be compiled here; the baseline is the CPU oracle
     restating it (oracle/tcnn_oracle.c, OpenMP), same config, the GPU leg's first batch, as many whole steps as fit `budget_s`."""
     from oracle import oracle as O
+    O.set_half_format(bf16)
     cfg = w["config"]
     net, enc = cfg["network"], cfg["encoding"]
     pos, tgt = x.cpu().numpy(), t.cpu().numpy()
@@ -198,6 +199,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="hash")
+    ap.add_argument("--precision", choices=["fp16", "bf16"], default="fp16", help="the library build: fp16 (libtcnn_hip.so) or bfloat16 (libtcnn_hip_bf16.so)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: 2^18 samples per GPU (weak) or 2^18 in total (strong)")
     ap.add_argument("--dp", choices=["sharded", "allreduce"], default="sharded", help="N > 1: gradient exchange (tinycudann/parallel.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -205,8 +207,10 @@ def main():
     ap.add_argument("--lds-budget", type=int, default=None, help="grid backward: LDS bytes per level table (tuning knob)")
     args = ap.parse_args()
     w = WORKLOADS[args.workload]
+    if args.precision == "bf16":
+        os.environ["TCNN_PRECISION"] = "bf16"  # read by tinycudann._C at import: selects the bfloat16 build of the library
 
-    import tinycudann as tcnn  # fails loudly if libtcnn_hip.so is missing
+    import tinycudann as tcnn  # fails loudly if the native library is missing
     from tinycudann import parallel as par
 
     # TCNN_BENCH_BACKEND / TCNN_BENCH_DEVICE: dry runs of the multi-rank branch on a one-GPU box (gloo, every rank on one
@@ -310,7 +314,7 @@ def main():
             "metric": w["metric"] + (", 1/2/4/8 GPU" if args.workload == "hash" else ""),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f16 (fp16 params/activations/gradients, fp32 MFMA accumulate, fp32 Adam state)", "data": "synthetic",
+            "dtype": ("bf16 (bfloat16" if args.precision == "bf16" else "f16 (fp16") + " params/activations/gradients, fp32 MFMA accumulate, fp32 Adam state)", "data": "synthetic",
             "config": {"workload": w["describe"], "batch_per_gpu": local_batch, "global_batch": global_batch, "n_params": tm.n_params,
                        "parallelism": f"dp{world} ({args.dp})" if world > 1 else "single"},
             "roofline": roofline,
@@ -322,7 +326,7 @@ def main():
             line["comm"] = {"seconds_per_step": comm / args.steps, "share_of_step": comm / elapsed,
                             "note": "host-side wall time inside the collective calls + waits of rank 0 (overlapped GPU work not subtracted)"}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(w, *batches[0])
+            line["cpu_baseline"] = cpu_baseline(w, *batches[0], bf16=args.precision == "bf16")
         print(json.dumps(line))
     par.barrier()
     if world > 1:

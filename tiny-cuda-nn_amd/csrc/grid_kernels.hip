@@ -593,8 +593,10 @@ TCNN_DEVICE void sliced_level(const GridMeta& meta, const GridIO& io, const Leve
 //   pass B (kind SLICE_BUCKET of k_grid_backward_sliced): the workgroup that owns a slice streams its queue and
 //     accumulates in 64-bit fixed point in LDS (dense ds_add_u64: 11 clk per wave instruction vs ~170 for the
 //     floating-point LDS atomics), then stores the slice -- exact, order-independent, no memset, no float atomics;
-//   pass C (k_grid_bucket_overflow): records that did not fit their queue (capacity = 2x the uniform expectation;
-//     only strongly non-uniform inputs get there) are applied with the reference's global atomics afterwards.
+//   overflow: records that did not fit their queue (capacity = 2x the uniform expectation) or whose x-neighbour lives in
+//     another bucket travel through one list; each owner picks its slice's records out of it before it stores (exact);
+//     beyond OVERFLOW_INLINE_MAX records (strongly clustered inputs) the last owner to finish applies the list with the
+//     reference's global atomics instead.
 // HBM traffic: 2 x 8 B per corner (F = 2) -- 0.44 GB per headline step, a fraction of the chip's bandwidth.
 // =============================================================================================
 #ifndef TCNN_BUCKET_THREADS
@@ -607,6 +609,8 @@ constexpr uint32_t MAX_BUCKET_LEVELS = 32;
 #endif
 constexpr uint32_t BUCKET_RESIDENT_WGS = TCNN_BUCKET_RESIDENT_WGS;  // persistent scatter workgroups over all levels
 constexpr uint32_t MAX_BUCKETS_PER_LEVEL = 4096;
+// overflow records up to which every bucket owner scans the list for its own (4 MiB of L2 reads per owner at the bound)
+constexpr uint32_t OVERFLOW_INLINE_MAX = 1u << 18;
 #ifndef TCNN_BUCKET_STAGE_BYTES
 #define TCNN_BUCKET_STAGE_BYTES (32 * 1024)  // measured: 32 KiB (4 workgroups per CU) beats 64 and 16 KiB
 #endif
@@ -620,6 +624,7 @@ struct BucketPlan {
 	uint32_t scatter_blocks;     // n_levels * wgs_per_level: pass-A blocks beyond these zero the gradients of chunked levels
 	uint32_t overflow_counter;   // index of the overflow counter (== total number of queues); the one after it counts finished pass-C blocks
 	uint32_t overflow_capacity;  // records
+	uint32_t n_owner_blocks;     // workgroups of pass B that own a bucket (the last one to finish resets the bookkeeping counters)
 	uint8_t level[MAX_BUCKET_LEVELS];             // grid level of slot j
 	uint32_t n_buckets[MAX_BUCKET_LEVELS];        // table slices
 	uint32_t n_chunks[MAX_BUCKET_LEVELS];         // sample chunks: a queue belongs to one (chunk, bucket); > 1 only for small tables
@@ -898,8 +903,14 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 template <uint32_t D, uint32_t F>
 TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t level, uint32_t j, uint32_t bucket, uint32_t chunk,
                               const BucketPlan& plan, uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues,
-                              half_t* __restrict__ grid_gradient, bool accumulate, unsigned char* lds_raw) {
-	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, PWP = BucketRecord<F>::PAIR_WORDS;
+                              const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient, bool accumulate, unsigned char* lds_raw) {
+	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, PWP = BucketRecord<F>::PAIR_WORDS, OW = BucketRecord<F>::WORDS + 1;
+	__shared__ uint32_t last_owner;
+	// records that did not fit their queue (or whose x-neighbour lives in another bucket: about one pair in 2^shift).  Up to
+	// OVERFLOW_INLINE_MAX of them every owner picks its own out of the list -- exact, no atomics, no extra launch; beyond
+	// that (strongly clustered inputs) the last owner to finish sends the list through the reference's global atomics.
+	const uint32_t n_over = min(counters[plan.overflow_counter], plan.overflow_capacity);
+	const bool inline_overflow = n_over <= OVERFLOW_INLINE_MAX;
 	const uint32_t entries_per_bucket = 1u << plan.shift;
 	const uint32_t slice_begin = bucket * entries_per_bucket;
 	const uint32_t slice_count = slice_begin < lv.hashmap_size ? min(entries_per_bucket, lv.hashmap_size - slice_begin) : 0u;
@@ -944,6 +955,12 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 			}
 		}
 	}
+	if (inline_overflow && chunk == 0u) {  // overflow records of this slice (level, index): the first chunk's owner takes them
+		for (uint32_t t = threadIdx.x; t < n_over; t += SLICED_THREADS) {
+			const uint32_t* rec = overflow + (size_t)t * OW;
+			if (rec[0] == level && (rec[1] >> plan.shift) == bucket) add_record(rec[1], rec + 2);
+		}
+	}
 	__syncthreads();
 
 	half_t* __restrict__ grad = grid_gradient + ((size_t)meta.offset[level] + slice_begin) * F;
@@ -958,31 +975,42 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 			atomic_add_h2(grad + 2 * e2, v);  // small tables only: (table size) x (chunks) updates per level
 		}
 	}
-	if (threadIdx.x == 0) counters[plan.counter_base[j] + queue] = 0u;  // every thread read it before the barriers above: counters end the call zeroed
-}
-
-// pass C: queue overflow -> the reference's global atomics (runs after pass B stored the slices)
-template <uint32_t F>
-__global__ void __launch_bounds__(256) k_grid_bucket_overflow(const GridMeta meta, const BucketPlan plan, uint32_t* __restrict__ counters,
-                                                               const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient) {
-	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, W = BucketRecord<F>::WORDS;
-	const uint32_t count = min(counters[plan.overflow_counter], plan.overflow_capacity);
-	__syncthreads();
-	// the last block to get here (every block has read `count` by then) leaves the two bookkeeping counters zeroed
-	if (threadIdx.x == 0 && atomic_add_u32(&counters[plan.overflow_counter + 1], 1u) == gridDim.x - 1u) {
-		counters[plan.overflow_counter] = 0u;
-		counters[plan.overflow_counter + 1] = 0u;
+	// every thread read the counters before the barriers above: they end the call zeroed.  The last owner to get here (all
+	// owners have read the overflow count by then) resets the two bookkeeping counters -- after draining a long overflow list.
+	__syncthreads();  // this slice's stores are issued
+	if (threadIdx.x == 0) {
+		counters[plan.counter_base[j] + queue] = 0u;
+		if (!inline_overflow) {  // the drain's atomics execute memory-side: the slices must be there first (release, agent scope)
+#if !defined(TCNN_HOST_EMU)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+		}
+		last_owner = atomic_add_u32(&counters[plan.overflow_counter + 1], 1u) == plan.n_owner_blocks - 1u ? 1u : 0u;
 	}
-	for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < count; t += gridDim.x * 256u) {
-		const uint32_t* rec = overflow + (size_t)t * (W + 1);
-		half_t* __restrict__ grad = grid_gradient + (size_t)meta.offset[rec[0]] * F;
-		const uint32_t index = rec[1];
-		if constexpr (F == 1) {
-			const half_t v = (half_t)__builtin_bit_cast(float, rec[2]);
-			atomic_add_h2(grad + (index & ~1u), (index & 1u) ? h2{(half_t)0.0f, v} : h2{v, (half_t)0.0f});
-		} else {
+	__syncthreads();
+	if (last_owner) {
+		if (!inline_overflow) {
+#if !defined(TCNN_HOST_EMU)
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+			for (uint32_t t = threadIdx.x; t < n_over; t += SLICED_THREADS) {
+				const uint32_t* rec = overflow + (size_t)t * OW;
+				half_t* __restrict__ g = grid_gradient + (size_t)meta.offset[rec[0]] * F;
+				const uint32_t index = rec[1];
+				if constexpr (F == 1) {
+					const half_t v = (half_t)__builtin_bit_cast(float, rec[2]);
+					atomic_add_h2(g + (index & ~1u), (index & 1u) ? h2{(half_t)0.0f, v} : h2{v, (half_t)0.0f});
+				} else {
 #pragma unroll
-			for (uint32_t p = 0; p < PW; ++p) atomic_add_h2(grad + (size_t)index * F + 2 * p, bits_h2(rec[2 + p]));
+					for (uint32_t p = 0; p < PW; ++p) atomic_add_h2(g + (size_t)index * F + 2 * p, bits_h2(rec[2 + p]));
+				}
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			counters[plan.overflow_counter] = 0u;
+			counters[plan.overflow_counter + 1] = 0u;
 		}
 	}
 }
@@ -991,7 +1019,8 @@ template <uint32_t D, uint32_t F, bool PACKED>
 __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const GridMeta meta, const GridIO io, const SlicePlan plan,
                                                                            const half_t* __restrict__ dL_dy, half_t* __restrict__ grid_gradient,
                                                                            const int accumulate, const BucketPlan bplan,
-                                                                           uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues) {
+                                                                           uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues,
+                                                                           const uint32_t* __restrict__ overflow) {
 	TCNN_DYN_LDS(lds_raw);
 	uint32_t item = 0, local_block;
 	if (plan.blocks_per_item) {
@@ -1016,7 +1045,7 @@ __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const G
 	const Level<D> lv = make_level<D>(meta, level);
 
 	if (kind == SLICE_BUCKET) {
-		bucket_level<D, F>(meta, lv, level, plan.slot[item], slice, chunk, bplan, counters, queues, grid_gradient, accumulate != 0, lds_raw);
+		bucket_level<D, F>(meta, lv, level, plan.slot[item], slice, chunk, bplan, counters, queues, overflow, grid_gradient, accumulate != 0, lds_raw);
 		return;
 	}
 	if (kind == SLICE_GLOBAL_ATOMIC) {
@@ -1422,6 +1451,7 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 		plan.slot[p] = (uint8_t)it.slot;
 		bp.n_chunks.push_back(it.n_chunks);
 		blocks += it.n_slices * it.n_chunks;
+		if (it.kind == SLICE_BUCKET) bp.buckets.n_owner_blocks += it.n_slices * it.n_chunks;
 	}
 	plan.block_begin[plan.n_items] = blocks;
 	uint32_t widest = 1;
@@ -1517,24 +1547,16 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 		if constexpr (F_ % 2 == 0) {                                                                                                   \
 			TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, true>), lds_slice_bytes);                                             \
 			TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, true>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io, \
-			            plan, dL_dy, grid_gradient, acc, bk, counters, (const uint32_t*)queues);                                       \
+			            plan, dL_dy, grid_gradient, acc, bk, counters, (const uint32_t*)queues, (const uint32_t*)overflow);            \
 		}                                                                                                                              \
 	} else {                                                                                                                           \
 		TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, false>), lds_slice_bytes);                                                \
 		TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, false>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io,    \
-		            plan, dL_dy, grid_gradient, acc, bk, counters, (const uint32_t*)queues);                                           \
+		            plan, dL_dy, grid_gradient, acc, bk, counters, (const uint32_t*)queues, (const uint32_t*)overflow);                \
 	}
 	TCNN_GRID_DISPATCH(BWDS)
 #undef BWDS
 	if (ws.phase_hook) ws.phase_hook(ws.hook_user, 1, 0);
-	if (bk.n_levels) {
-		if (ws.phase_hook) ws.phase_hook(ws.hook_user, 2, 1);
-		// pass C: overflowed records (none for near-uniform inputs: the kernel reads one counter and exits)
-#define BOVF(D_, F_) TCNN_LAUNCH((k_grid_bucket_overflow<F_>), dim3(256), dim3(256), 0, stream, meta, bk, counters, (const uint32_t*)overflow, grid_gradient);
-		TCNN_GRID_DISPATCH(BOVF)
-#undef BOVF
-		if (ws.phase_hook) ws.phase_hook(ws.hook_user, 2, 0);
-	}
 }
 
 void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient, bool accumulate,

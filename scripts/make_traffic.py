@@ -14,7 +14,6 @@ STAGES = {  # stage -> [(kernel-name fragment, reads are wide streams?)]
     "mlp_train_fused": [("k_mlp_transpose_weights", True), ("k_mlp_train", True), ("k_mlp_finalize_gradients", True)],
     "grid_backward_scatter": [("k_grid_bucket_scatter", False)],
     "grid_backward": [("k_grid_backward_sliced", True)],
-    "grid_backward_overflow": [("k_grid_bucket_overflow", False)],
     "adam": [("k_adam_step", True)],
 }
 fused = any("k_mlp_train" in name for name in summary)  # training_step ran the fused network kernel: the three-kernel stages did not run
@@ -28,4 +27,6 @@ for stage, kernels in STAGES.items():
             if frag in name and "FETCH_SIZE" in cs:
                 total += ((2 if wide else 1) * cs["FETCH_SIZE"] + cs.get("WRITE_SIZE", 0.0)) * 1024
     out[stage] = total
+out["_source"] = ("separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; scripts/gpu_pmc.sh, summarised by scripts/parse_pmc.py from " + sys.argv[1] +
+                  ") of `bench.py --steps 10 --warmup 3`; bytes per launch, FETCH_SIZE doubled for wide coalesced readers per MI355X_MICROARCH.md; not measured in the bench run that quotes them")
 json.dump(out, sys.stdout, indent=1)

@@ -236,6 +236,11 @@ struct AdamArgs {
 	// are written.  steps_done = optimizer steps before this one.
 	uint32_t steps_done;
 	int deficit;
+	// lanes whose four parameters are all skipped (untouched hash-table entries) still load and store their unchanged state,
+	// so that every 128-byte line of the optimizer state is written whole: a line is fetched as soon as one of its 32
+	// parameters is stepped anyway, and partially written lines cost the memory system more than full ones (T = 2^22,
+	// 60 % of the entries untouched per step: 0.68 -> 0.53 ms, 4.7 -> 6.0 TB/s; profiles/r02_exp_notes.txt)
+	int dense_store;
 };
 
 // One parameter, exactly the arithmetic of adam.h:66-126.  Returns false if the parameter is skipped.
@@ -308,7 +313,7 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 	if (i0 + 3 < a.n_elements) {
 		const h4 g = *(const h4*)(gradients + i0);
 		const bool all_non_matrix = i0 >= a.n_matrix_weights;
-		if (all_non_matrix && a.skip_zero_grad_non_matrix_params && g[0] == (half_t)0.0f && g[1] == (half_t)0.0f && g[2] == (half_t)0.0f &&
+		if (!a.dense_store && all_non_matrix && a.skip_zero_grad_non_matrix_params && g[0] == (half_t)0.0f && g[1] == (half_t)0.0f && g[2] == (half_t)0.0f &&
 		    g[3] == (half_t)0.0f) {
 			if (a.deficit) {  // all four skipped: one more missed step each
 				u4 st = adam_load<STREAM>((const u4*)(param_steps + i0));
@@ -342,8 +347,8 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 			}
 		}
 		if (a.deficit && updated != 0xFu) adam_store<STREAM>((u4*)(param_steps + i0), st);
-		if (any) {
-			if (updated != 0xFu) {  // rare: keep the fp16 weights of the parameters that were skipped (only then are they read)
+		if (any || a.dense_store) {
+			if (updated != 0xFu) {  // keep the fp16 weights of the parameters that were skipped (only then are they read)
 				const h4 old = *(const h4*)(weights + i0);
 #pragma unroll
 				for (uint32_t j = 0; j < 4; ++j) {
@@ -411,6 +416,8 @@ void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_ma
 	a.mlp = mlp ? *mlp : MlpMeta{};
 	a.steps_done = current_step - 1u;
 	a.deficit = steps_are_deficits ? 1 : 0;
+	static const bool dense = !(getenv("TCNN_ADAM_DENSE_STORE") && atoi(getenv("TCNN_ADAM_DENSE_STORE")) == 0);  // =0: the sparse form, for A/B runs
+	a.dense_store = dense ? 1 : 0;
 	const dim3 grid(div_round_up(div_round_up(end - begin, 4u), EW_THREADS));
 	if ((size_t)n * 32u > ADAM_STREAM_THRESHOLD_BYTES) {
 		TCNN_LAUNCH(k_adam_step<true>, grid, dim3(EW_THREADS), 0, stream, a, weights_fp32, weights, gradients, m1, m2, param_steps, weights_t);

@@ -509,6 +509,31 @@ def test_torch_modules_autograd_and_padding():
     assert torch.equal(clone(x), y1)
 
 
+def test_fp32_encoding_module():
+    """tcnn.Encoding(..., dtype=torch.float32) (cpp_api.cu:165-174 create_encoding(Precision::Fp32)): fp32 parameters, outputs and
+    gradients at the boundary, computed in the library's 16-bit type -- same bits as the fp16 module on the rounded parameters,
+    gradients equal up to the fp16 rounding of the (internally scaled) incoming gradient."""
+    T = tcnn()
+    enc_h = T.Encoding(3, HASH_ENCODING_SMALL, seed=5)
+    enc_f = T.Encoding(3, HASH_ENCODING_SMALL, seed=5, dtype=torch.float32)
+    assert enc_f.params.dtype == torch.float32 and enc_f.native_tcnn_module.param_precision() == T._C.Precision.Fp32
+    with torch.no_grad():
+        enc_h.params *= 1.0e3
+        enc_f.params.copy_(enc_h.params)
+    n = 2048
+    x = torch.from_numpy(positions(n, 3, seed=12)).cuda().requires_grad_(True)
+    yh, yf = enc_h(x), enc_f(x)
+    assert yf.dtype == torch.float32 and yh.dtype == torch.half and torch.equal(yf, yh.float())
+    w = torch.from_numpy(np.random.default_rng(2).standard_normal((n, 32)).astype(np.float32)).cuda() * 1e-3
+    (yf * w).sum().backward()
+    gf, dxf = enc_f.params.grad.clone(), x.grad.clone()
+    x.grad = None
+    (yh.float() * w).sum().backward()
+    gh, dxh = enc_h.params.grad, x.grad
+    assert torch.isfinite(gf).all() and gf.abs().max() > 0
+    assert (gf - gh).norm() <= 2e-3 * gh.norm() and (dxf - dxh).norm() <= 2e-3 * dxh.norm()
+
+
 def test_golden_fixture():
     """tests/golden/hotpath_small.npz (made by tests/golden/make_golden.py): the GPU path reproduces the
     frozen vectors without the oracle library in the loop."""

@@ -801,6 +801,20 @@ struct tcnn_module {
 	Model md;
 	std::string name;
 	uint32_t lds_level_budget = 0;  // 0: default LDS slice size of the sliced grid backward
+	// create_encoding(..., Precision::Fp32) (cpp_api.cu:165-174 -> Encoding<float>): parameters, outputs and gradients cross the
+	// boundary as fp32; the kernels compute in the library's 16-bit type (the caller's loss scale is 1 for fp32, cpp_api.h:77,
+	// so gradients are scaled by FP32_GRADIENT_SCALE into that type's range on the way in and back, exactly, on the way out)
+	bool fp32_io = false;
+};
+static constexpr float FP32_GRADIENT_SCALE = 1024.0f;
+// the 16-bit copies an fp32 module works on
+struct Fp32Bridge {
+	Scratch params, output, dL_doutput, dL_dparams;
+	static Scratch to_half(hipStream_t stream, const void* src, size_t n, float scale = 1.0f) {
+		Scratch s(stream, std::max<size_t>(n, 1) * sizeof(half_t));
+		cast_scaled_f32_to_f16(stream, n, (const float*)src, s.as<half_t>(), scale);
+		return s;
+	}
 };
 struct tcnn_context {
 	ForwardCtx ctx;
@@ -924,12 +938,13 @@ int tcnn_create_network(uint32_t n_input_dims, uint32_t n_output_dims, const cha
 
 int tcnn_create_encoding(uint32_t n_input_dims, const char* encoding_json, int requested_precision, tcnn_module_t** out) {
 	TCNN_API_BEGIN
-	if (requested_precision != NATIVE_PRECISION) {
-		g_last_error = HALF_IS_BF16 ? "create_encoding: only bf16 encodings are available in this build (libtcnn_hip_bf16.so)"
-		                            : "create_encoding: only fp16 encodings are available in this build";
+	if (requested_precision != NATIVE_PRECISION && requested_precision != TCNN_PRECISION_FP32) {
+		g_last_error = HALF_IS_BF16 ? "create_encoding: this build (libtcnn_hip_bf16.so) provides bf16 and fp32 encodings"
+		                            : "create_encoding: this build provides fp16 and fp32 encodings";
 		return TCNN_ERROR_UNSUPPORTED;
 	}
 	auto m = std::make_unique<tcnn_module>();
+	m->fp32_io = requested_precision == TCNN_PRECISION_FP32;
 	m->md.n_input_dims = n_input_dims;
 	m->md.enc = create_encoding_desc(n_input_dims, Json::parse(encoding_json), /*alignment=*/0);  // cpp_api.cu:165-174
 	m->md.has_network = false;
@@ -941,17 +956,33 @@ int tcnn_create_encoding(uint32_t n_input_dims, const char* encoding_json, int r
 
 void tcnn_module_destroy(tcnn_module_t* m) { delete m; }
 
-int tcnn_module_inference(tcnn_module_t* m, tcnn_stream_t stream, uint32_t n, const float* input, void* output, void* params) {
+int tcnn_module_inference(tcnn_module_t* m, tcnn_stream_t stream_, uint32_t n, const float* input, void* output, void* params) {
 	TCNN_API_BEGIN
-	model_forward((hipStream_t)stream, m->md, n, input, (half_t*)output, (const half_t*)params, nullptr, false);
+	hipStream_t stream = (hipStream_t)stream_;
+	if (m->fp32_io) {
+		const size_t n_out = (size_t)n * m->md.padded_output_width();
+		Scratch p = Fp32Bridge::to_half(stream, params, m->md.n_params()), out(stream, std::max<size_t>(n_out, 1) * sizeof(half_t));
+		model_forward(stream, m->md, n, input, out.as<half_t>(), p.as<half_t>(), nullptr, false);
+		cast_f16_to_f32(stream, n_out, out.as<half_t>(), (float*)output);
+		return TCNN_OK;
+	}
+	model_forward(stream, m->md, n, input, (half_t*)output, (const half_t*)params, nullptr, false);
 	TCNN_API_END
 }
 
-int tcnn_module_forward(tcnn_module_t* m, tcnn_stream_t stream, uint32_t n, const float* input, void* output, void* params,
+int tcnn_module_forward(tcnn_module_t* m, tcnn_stream_t stream_, uint32_t n, const float* input, void* output, void* params,
                         int prepare_input_gradients, tcnn_context_t** ctx) {
 	TCNN_API_BEGIN
+	hipStream_t stream = (hipStream_t)stream_;
 	auto c = std::make_unique<tcnn_context>();
-	model_forward((hipStream_t)stream, m->md, n, input, (half_t*)output, (const half_t*)params, &c->ctx, prepare_input_gradients != 0);
+	if (m->fp32_io) {
+		const size_t n_out = (size_t)n * m->md.padded_output_width();
+		Scratch p = Fp32Bridge::to_half(stream, params, m->md.n_params()), out(stream, std::max<size_t>(n_out, 1) * sizeof(half_t));
+		model_forward(stream, m->md, n, input, out.as<half_t>(), p.as<half_t>(), &c->ctx, prepare_input_gradients != 0);
+		cast_f16_to_f32(stream, n_out, out.as<half_t>(), (float*)output);
+	} else {
+		model_forward(stream, m->md, n, input, (half_t*)output, (const half_t*)params, &c->ctx, prepare_input_gradients != 0);
+	}
 	*ctx = c.release();
 	TCNN_API_END
 }
@@ -961,6 +992,17 @@ int tcnn_module_backward(tcnn_module_t* m, tcnn_stream_t stream, const tcnn_cont
 	(void)output;
 	TCNN_API_BEGIN
 	if (!ctx) throw std::runtime_error("backward: missing forward context");
+	if (m->fp32_io) {  // bare encodings only: `output` is not needed by their backward pass
+		hipStream_t s = (hipStream_t)stream;
+		const size_t n_out = (size_t)n * m->md.padded_output_width(), n_params = m->md.n_params();
+		Scratch dy = Fp32Bridge::to_half(s, dL_doutput, n_out, FP32_GRADIENT_SCALE), p = Fp32Bridge::to_half(s, params, n_params), dp;
+		if (dL_dparams) dp = Scratch(s, std::max<size_t>(n_params, 1) * sizeof(half_t));
+		model_backward(s, m->md, ctx->ctx, n, dL_dinput, dy.as<half_t>(), dL_dparams ? dp.as<half_t>() : nullptr, input, nullptr, p.as<half_t>(),
+		               dL_dparams ? TCNN_GRADIENT_OVERWRITE : TCNN_GRADIENT_IGNORE, m->lds_level_budget);
+		if (dL_dparams) cast_scaled_f16_to_f32(s, n_params, dp.as<half_t>(), (float*)dL_dparams, 1.0f / FP32_GRADIENT_SCALE);
+		if (dL_dinput) scale_f32(s, (size_t)n * m->md.n_input_dims, dL_dinput, 1.0f / FP32_GRADIENT_SCALE);
+		return TCNN_OK;
+	}
 	model_backward((hipStream_t)stream, m->md, ctx->ctx, n, dL_dinput, (const half_t*)dL_doutput, (half_t*)dL_dparams, input, (const half_t*)output,
 	               (const half_t*)params,
 	               dL_dparams ? TCNN_GRADIENT_OVERWRITE : TCNN_GRADIENT_IGNORE, m->lds_level_budget);  // cpp_api.cu:115
@@ -985,6 +1027,29 @@ int tcnn_module_backward_backward_input(tcnn_module_t* m, tcnn_stream_t stream_,
 	hipStream_t stream = (hipStream_t)stream_;
 	const Model& md = m->md;
 	const EncodingDesc& e = md.enc;
+	// fp32 module: 16-bit stand-ins for the caller's fp32 tensors (see tcnn_module::fp32_io)
+	Scratch dy16, p16, dp16, ddy16;
+	void* const dL_dparams_f32 = dL_dparams;
+	void* const dL_ddLdoutput_f32 = dL_ddLdoutput;
+	const size_t n_out_elems = (size_t)n * e.padded_output_width;
+	if (m->fp32_io) {
+		if (dL_doutput) {
+			dy16 = Fp32Bridge::to_half(stream, dL_doutput, n_out_elems, FP32_GRADIENT_SCALE);
+			dL_doutput = dy16.ptr;
+		}
+		if (params) {
+			p16 = Fp32Bridge::to_half(stream, params, md.n_params());
+			params = p16.ptr;
+		}
+		if (dL_dparams) {
+			dp16 = Scratch(stream, std::max<size_t>(md.n_params(), 1) * sizeof(half_t));
+			dL_dparams = dp16.ptr;
+		}
+		if (dL_ddLdoutput) {
+			ddy16 = Scratch(stream, std::max<size_t>(n_out_elems, 1) * sizeof(half_t));
+			dL_ddLdoutput = ddy16.ptr;
+		}
+	}
 	GridIO io = {input, md.n_input_dims, 1u, n, 1u, e.padded_output_width};  // the bare encoding's output is sample-major (cpp_api.cu:94-95)
 	io.ddx = dL_ddLdinput;
 	io.ddx_stride_i = md.n_input_dims;
@@ -1012,6 +1077,11 @@ int tcnn_module_backward_backward_input(tcnn_module_t* m, tcnn_stream_t stream_,
 	if (dL_dinput) {  // grid.h:977-1010
 		grid_backward_backward_input(stream, e.grid, io, (const half_t*)dL_doutput, (const half_t*)params, dL_dinput, md.n_input_dims, 1u);
 	}
+	if (m->fp32_io) {  // dL_ddLdoutput does not depend on dL_doutput; the other two carry its scale
+		if (dL_ddLdoutput_f32) cast_f16_to_f32(stream, n_out_elems, ddy16.as<half_t>(), (float*)dL_ddLdoutput_f32);
+		if (dL_dparams_f32) cast_scaled_f16_to_f32(stream, md.n_params(), dp16.as<half_t>(), (float*)dL_dparams_f32, 1.0f / FP32_GRADIENT_SCALE);
+		if (dL_dinput) scale_f32(stream, (size_t)n * md.n_input_dims, dL_dinput, 1.0f / FP32_GRADIENT_SCALE);
+	}
 	TCNN_API_END
 }
 void tcnn_context_destroy(tcnn_context_t* ctx) { delete ctx; }
@@ -1019,8 +1089,8 @@ void tcnn_context_destroy(tcnn_context_t* ctx) { delete ctx; }
 uint32_t tcnn_module_n_input_dims(const tcnn_module_t* m) { return m->md.n_input_dims; }
 uint32_t tcnn_module_n_output_dims(const tcnn_module_t* m) { return m->md.padded_output_width(); }
 size_t tcnn_module_n_params(const tcnn_module_t* m) { return m->md.n_params(); }
-int tcnn_module_param_precision(const tcnn_module_t*) { return NATIVE_PRECISION; }
-int tcnn_module_output_precision(const tcnn_module_t*) { return NATIVE_PRECISION; }
+int tcnn_module_param_precision(const tcnn_module_t* m) { return m->fp32_io ? TCNN_PRECISION_FP32 : NATIVE_PRECISION; }
+int tcnn_module_output_precision(const tcnn_module_t* m) { return m->fp32_io ? TCNN_PRECISION_FP32 : NATIVE_PRECISION; }
 
 int tcnn_module_initialize_params(tcnn_module_t* m, size_t seed, float* params_full_precision, float scale) {
 	TCNN_API_BEGIN

@@ -53,6 +53,9 @@ void generate_random_uniform(hipStream_t stream, Pcg32& rng, size_t n, float* ou
 
 void cast_f32_to_f16(hipStream_t stream, size_t n, const float* in, half_t* out);  // trainer.h:415-417
 void cast_f16_to_f32(hipStream_t stream, size_t n, const half_t* in, float* out);  // trainer.h:430-432
+void cast_scaled_f32_to_f16(hipStream_t stream, size_t n, const float* in, half_t* out, float scale);
+void cast_scaled_f16_to_f32(hipStream_t stream, size_t n, const half_t* in, float* out, float scale);
+void scale_f32(hipStream_t stream, size_t n, float* data, float scale);
 void fill_f16(hipStream_t stream, size_t n, half_t* out, float value);
 
 // object.cu:61-67 trim_and_cast_from: in half AoS [n][padded] -> out float element (j, i) at out[i*stride_i + j*stride_j]

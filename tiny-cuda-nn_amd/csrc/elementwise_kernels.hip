@@ -52,6 +52,20 @@ __global__ void k_cast_f16_to_f32(size_t n, const half_t* __restrict__ in, float
 		for (size_t i = i4; i < n; ++i) out[i] = (float)in[i];
 	}
 }
+// fp32 <-> 16-bit with a power-of-two scale (the fp32 encodings of cpp_api.cu:165-174 computed in the 16-bit type: the
+// gradients entering the backward pass are scaled into its range and the results scaled back, exactly)
+__global__ void k_cast_scaled_f32_to_f16(size_t n, const float* __restrict__ in, half_t* __restrict__ out, float scale) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = to_half_rn(in[i] * scale);
+}
+__global__ void k_cast_scaled_f16_to_f32(size_t n, const half_t* __restrict__ in, float* __restrict__ out, float scale) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = (float)in[i] * scale;
+}
+__global__ void k_scale_f32(size_t n, float* __restrict__ data, float scale) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) data[i] = data[i] * scale;
+}
 __global__ void k_fill_f16(size_t n, half_t* __restrict__ out, float value) {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) out[i] = (half_t)value;
@@ -64,6 +78,18 @@ void cast_f32_to_f16(hipStream_t stream, size_t n, const float* in, half_t* out)
 void cast_f16_to_f32(hipStream_t stream, size_t n, const half_t* in, float* out) {
 	if (n == 0) return;
 	TCNN_LAUNCH(k_cast_f16_to_f32, dim3((uint32_t)div_round_up(div_round_up(n, (size_t)4), (size_t)EW_THREADS)), dim3(EW_THREADS), 0, stream, n, in, out);
+}
+void cast_scaled_f32_to_f16(hipStream_t stream, size_t n, const float* in, half_t* out, float scale) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_cast_scaled_f32_to_f16, dim3((uint32_t)div_round_up(n, (size_t)EW_THREADS)), dim3(EW_THREADS), 0, stream, n, in, out, scale);
+}
+void cast_scaled_f16_to_f32(hipStream_t stream, size_t n, const half_t* in, float* out, float scale) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_cast_scaled_f16_to_f32, dim3((uint32_t)div_round_up(n, (size_t)EW_THREADS)), dim3(EW_THREADS), 0, stream, n, in, out, scale);
+}
+void scale_f32(hipStream_t stream, size_t n, float* data, float scale) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_scale_f32, dim3((uint32_t)div_round_up(n, (size_t)EW_THREADS)), dim3(EW_THREADS), 0, stream, n, data, scale);
 }
 void fill_f16(hipStream_t stream, size_t n, half_t* out, float value) {
 	if (n == 0) return;

@@ -126,7 +126,8 @@ def test_grid_backward_and_input_gradient(d, enc):
 
 
 @pytest.mark.parametrize("d,enc", [(3, dict(HASH_ENCODING, log2_hashmap_size=15, n_levels=8)),
-                                   (2, {"otype": "DenseGrid", "n_levels": 4, "base_resolution": 8, "per_level_scale": 2.0, "interpolation": "Smoothstep"})])
+                                   (2, {"otype": "DenseGrid", "n_levels": 4, "base_resolution": 8, "per_level_scale": 2.0, "interpolation": "Smoothstep"}),
+                                   (3, dict(HASH_ENCODING, log2_hashmap_size=12, n_levels=6, n_features_per_level=1))])  # F == 1: packed atomic on the aligned pair
 def test_grid_stochastic_interpolation(d, enc):
     """stochastic_interpolation (grid.h:284-299): the backward pass sends the whole gradient of (sample, level) to one corner
     picked by random_val(1337, i + level * n); the forward pass is the ordinary interpolation.  Same corner as the oracle
@@ -924,6 +925,30 @@ def test_grid_second_order_through_c_abi_and_double_backward(interp):
         lo[j] -= step
         fd = (loss_at(hi) - loss_at(lo)) / (float(hi[j]) - float(lo[j]))
         assert abs(fd - float(g[j])) <= 0.1 * abs(float(g[j])) + 1e-3 * float(g.abs().max()), (j, fd, float(g[j]))
+
+
+def test_grid_second_order_beyond_the_bucket_limits():
+    """backward_backward_input for a legal reference configuration the bucketed scatter cannot hold (40 levels > 32 bucketed
+    levels): the parameter gradient falls back to the reference's atomic formulation with the second-order corner weight."""
+    C = tcnn()._C
+    enc = {"otype": "HashGrid", "n_levels": 40, "n_features_per_level": 2, "log2_hashmap_size": 12, "base_resolution": 4, "per_level_scale": 1.1}
+    d = 2
+    m = C.create_encoding(d, enc)
+    og = oracle_grid(enc, d)
+    n = 1024
+    pos = positions(n, d, seed=3)
+    rng = np.random.default_rng(6)
+    params = O.f2h((rng.random(og.n_params, dtype=np.float32) * 2 - 1) * 0.5)
+    dy = O.f2h(rng.standard_normal((n, m.n_output_dims())).astype(np.float32))
+    ddx = (rng.standard_normal((n, d)) * 1e-2).astype(np.float32)
+    x = torch.from_numpy(pos).cuda().requires_grad_(True)
+    p = h_t(params).requires_grad_(True)
+    ctx, y = m.fwd(x, p)
+    _, d_p, _ = m.bwd_bwd_input(ctx, x, p, torch.from_numpy(ddx).cuda(), h_t(dy).requires_grad_(True))
+    gp_ref = O.grid_backward_backward_input(og, params, pos, ddx, dy)[0]
+    mag = np.abs(O.grid_backward_backward_input(og, params, pos, np.abs(ddx), O.f2h(np.abs(O.h2f(dy))))[0]) + np.abs(gp_ref)
+    assert np.abs(gp_ref).max() > 0
+    assert np.all(np.abs(d_p.float().cpu().numpy().astype(np.float64) - gp_ref) <= 2.0 ** -7 * mag + 2e-3 * max(1.0, np.abs(gp_ref).max()))
 
 
 def test_cpp_sample_learns_an_image(tmp_path):

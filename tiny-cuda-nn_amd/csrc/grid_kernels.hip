@@ -391,19 +391,21 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_backward_atomic(const Gri
 	if ((float)level > max_level + 1e-3f) return;  // grid.h:242 (sic: '>' here, '>=' in forward)
 	const Level<D> lv = make_level<D>(meta, level);
 	half_t* __restrict__ grad = grid_gradient + (size_t)meta.offset[level] * F;
+	const bool second_order = io.ddx != nullptr;  // kernel_grid_backward_input_backward_grid (grid.h:427-455): another corner weight
 
 	for (uint32_t s = 0; s < GRID_SPT; ++s) {
 		const uint32_t i = tile * GRID_TILE + s * GRID_THREADS + threadIdx.x;
 		if (i >= io.n) continue;
 		Cell<D> c = make_cell<D, false>(lv, io, i);
-		h2 g[F / 2];
+		half_t g[F];
 #pragma unroll
-		for (uint32_t p = 0; p < F / 2; ++p) {
-			g[p] = h2{dL_dy[(size_t)(level * F + 2 * p) * io.stride_k + (size_t)i * io.stride_i],
-			          dL_dy[(size_t)(level * F + 2 * p + 1) * io.stride_k + (size_t)i * io.stride_i]};
-		}
-		const bool one_corner = lv.nearest || meta.stochastic != 0u;
-		if (meta.stochastic != 0u && !lv.nearest) {  // grid.h:284-299, random_val(1337, i + level * n): common_device.h:469-473
+		for (uint32_t f = 0; f < F; ++f) g[f] = dL_dy[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i];
+		float dd[D];
+#pragma unroll
+		for (uint32_t d = 0; d < D; ++d) dd[d] = 0.0f;
+		if (second_order) load_ddx<D>(io, i, dd);
+		const bool one_corner = !second_order && (lv.nearest || meta.stochastic != 0u);
+		if (!second_order && meta.stochastic != 0u && !lv.nearest) {  // grid.h:284-299, random_val(1337, i + level * n): common_device.h:469-473
 			Pcg32 rng(1337u);
 			rng.advance((int64_t)(uint32_t)(i + level * io.n));
 			const float sample = rng.next_float();
@@ -414,11 +416,18 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_backward_atomic(const Gri
 		}
 		const uint32_t n_corners = one_corner ? 1u : (1u << D);
 		for (uint32_t idx = 0; idx < n_corners; ++idx) {
-			const half_t wh = one_corner ? (half_t)1.0f : to_half_rn(corner_weight<D>(c, idx));
-			const h2 w2 = h2{wh, wh};
+			const float weight = second_order ? corner_weight_second_order<D>(lv, c, idx, dd) : corner_weight<D>(c, idx);
 			const uint32_t index = corner_index<D, false>(lv, c, idx);
+			if constexpr (F == 1) {
+				// fp32 product rounded once, as the bucketed form does for F == 1; a packed atomic on the aligned pair, the partner gets +0
+				const half_t v = one_corner ? g[0] : to_half_rn(weight * (float)g[0]);
+				atomic_add_h2(grad + (index & ~1u), (index & 1u) ? h2{(half_t)0.0f, v} : h2{v, (half_t)0.0f});
+			} else {
+				const half_t wh = one_corner ? (half_t)1.0f : to_half_rn(weight);
+				const h2 w2 = h2{wh, wh};
 #pragma unroll
-			for (uint32_t p = 0; p < F / 2; ++p) atomic_add_h2(grad + (size_t)index * F + 2 * p, w2 * g[p]);  // (GRAD_T)weight * grad, grid.h:254
+				for (uint32_t p = 0; p < F / 2; ++p) atomic_add_h2(grad + (size_t)index * F + 2 * p, w2 * h2{g[2 * p], g[2 * p + 1]});  // (GRAD_T)weight * grad, grid.h:254
+			}
 		}
 	}
 }
@@ -1321,16 +1330,12 @@ void grid_forward(hipStream_t stream, const GridMeta& meta, const GridIO& io, co
 
 static void grid_backward_atomic(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient,
                                  bool accumulate) {
-	if (meta.n_feat == 1) throw std::runtime_error("grid_backward (atomic mode): n_features_per_level == 1 is only supported by the sliced modes");
 	const size_t n_params = (size_t)meta.offset[meta.n_levels] * meta.n_feat;
 	if (!accumulate) {  // grid.h:865-867
 		if (hipMemsetAsync(grid_gradient, 0, n_params * sizeof(half_t), stream) != hipSuccess) throw std::runtime_error("grid_backward: memset failed");
 	}
 	const uint32_t blocks = grid_n_blocks(meta.n_levels, io.n);
-#define BWD(D_, F_)                                                                                                                    \
-	if constexpr (F_ != 1) {                                                                                                           \
-		TCNN_LAUNCH((k_grid_backward_atomic<D_, F_>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, dL_dy, grid_gradient);    \
-	}
+#define BWD(D_, F_) TCNN_LAUNCH((k_grid_backward_atomic<D_, F_>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, dL_dy, grid_gradient);
 	TCNN_GRID_DISPATCH(BWD)
 #undef BWD
 }
@@ -1501,7 +1506,7 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 	const uint32_t blocks = bp.blocks;
 	if (io.ddx) {
 		for (uint32_t p = 0; p < plan.n_items; ++p) {
-			if (plan.kind[p] != SLICE_BUCKET) throw std::runtime_error("grid_backward: second-order scatter needs every level in the bucketed path (table too large)");
+			if (plan.kind[p] != SLICE_BUCKET) throw std::runtime_error("grid_backward: second-order scatter needs every level in the bucketed path (grid_backward() checks this)");
 		}
 	}
 	uint32_t* counters = nullptr;
@@ -1570,6 +1575,12 @@ void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, c
 			return;
 		}
 		if (mode != GridBackwardMode::Bucketed) throw std::runtime_error("grid_backward: the second-order scatter runs in the bucketed mode only");
+		// more than 32 levels, or a level beyond 4096 buckets of the chosen slice size: the second-order weight through the
+		// reference's formulation (global atomics) instead
+		const BackwardPlan bp = make_backward_plan(meta, io.n, meta.n_feat % 2 == 0, true, accumulate, lds_slice_bytes);
+		for (uint32_t p = 0; p < bp.slices.n_items; ++p) {
+			if (bp.slices.kind[p] != SLICE_BUCKET) mode = GridBackwardMode::Atomic;
+		}
 	}
 	// stochastic interpolation (one unweighted update per sample and level): the reference's atomic form; the owner-computes
 	// passes are built around all 2^D weighted corners

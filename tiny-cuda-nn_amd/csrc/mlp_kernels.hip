@@ -4,7 +4,8 @@
 //   x32 operand: 8 halves, k = 32*kb + 8*g + j      x16 operand: 4 halves, k = k0 + 4*g + j
 //   accumulator: element r <-> (row = 4*g + r, col = lr)
 // LDS tiles:  "sample-major"  tile[s][ld]   (ld = width + 8 halves: 16-byte aligned, bank-skewed rows)
-//             "feature-major" tile[k][SP]   (SP = S + 8)
+//             "feature-major" tile[k][SP]   (SP = S + 8; in k_mlp_backward SP = S + 16 with the 8-sample column blocks of row k
+//                                            XOR-ed with (k >> 3) & 7, see ft_col())
 #include "mlp_kernels.h"
 
 #include <stdlib.h>
@@ -19,6 +20,20 @@ namespace tcnn_hip {
 
 constexpr uint32_t mlp_fwd_tile(uint32_t width) { return width == 128 ? 128u : 64u; }
 constexpr uint32_t MLP_BWD_TILE = 64;
+// Feature-major tiles of k_mlp_backward.  The saved activations arrive sample-major and are transposed on the way into LDS with
+// 2-byte stores: lanes that hold consecutive 8-neuron groups of one sample write rows 8 * SP halves apart -- any SP that keeps
+// the rows 16-byte aligned puts all of them on ONE bank (16-way conflicts at 128 neurons: 73 % of the kernel's LDS cycles,
+// profiles/r02_exp_notes.txt).  Swizzle: the eight 8-sample column blocks of row k are XOR-ed with (k >> 3) & 7, so those lanes
+// land in different blocks; vector accesses of 4 or 8 consecutive samples stay contiguous.  With SP = S + 16 the model of the
+// hardware's lane groups (scripts/lds_bank_model.py) gives 2-4 cycles per transposing store (was 16-32) and conflict-free 8-byte
+// operand reads.
+constexpr uint32_t MLP_BWD_SP = MLP_BWD_TILE + 16;
+TCNN_DEVICE uint32_t ft_col(uint32_t k, uint32_t sample) { return sample ^ (((k >> 3) & 7u) << 3); }
+// The same for row 16 * r16 + lr and column c16 + c4 (c16 a multiple of 16, c4 < 16 a multiple of 4), split so that the part
+// that depends on unrolled loop counters folds into an immediate offset and the lane part is computed once:
+//   ft_col(16 r16 + lr, c16 + c4) == (c16 ^ 16 (r16 & 3)) + (c4 ^ 8 (lr >> 3))       (the two terms occupy disjoint bits)
+TCNN_DEVICE uint32_t ft_col16(uint32_t r16, uint32_t c16) { return c16 ^ ((r16 & 3u) << 4); }
+TCNN_DEVICE uint32_t ft_lane4(uint32_t lr, uint32_t c4) { return c4 ^ ((lr >> 3) << 3); }
 
 // =============================================================================================
 // forward / inference
@@ -146,7 +161,8 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
                                                                    const half_t* __restrict__ dL_doutput, half_t* __restrict__ dL_dinput,
                                                                    float* __restrict__ partials) {
 	constexpr uint32_t NW = WIDTH / 16, THREADS = NW * 64, S = MLP_BWD_TILE, NT = S / 16, NTP = S / 32;
-	constexpr uint32_t SP = S + 8, LDW = WIDTH + 8, NB = WIDTH / 16, MAX_INB = MLP_MAX_IN_WIDTH / 16;
+	constexpr uint32_t SP = MLP_BWD_SP, LDW = WIDTH + 8, NB = WIDTH / 16, MAX_INB = MLP_MAX_IN_WIDTH / 16;
+	static_assert(S == 64, "ft_col() swizzles the 8 blocks of 8 samples of a 64-sample tile");
 	TCNN_DYN_LDS(lds_raw);
 	const uint32_t IN = m.in_width, nb_in = IN / 16;
 	half_t* xT = (half_t*)lds_raw;                 // [IN][SP]           network input, feature-major
@@ -161,6 +177,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 	const half_t* wt_out = wt_hid + (size_t)HM * WIDTH * WIDTH;  // [WIDTH][16]
 
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
+	const uint32_t lane_c4 = ft_lane4(lr, 4 * g);  // this lane's share of the swizzled column of its 8-byte feature-major reads
 	const uint32_t act = m.activation;
 	const bool want_grads = partials != nullptr, want_dx = dL_dinput != nullptr;
 	const uint32_t n_tiles = n / S;
@@ -180,7 +197,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 		// ---- A. stage tiles -----------------------------------------------------------------
 		for (uint32_t c = tid; c < IN * (S / 8); c += THREADS) {  // input is already feature-major
 			const uint32_t k = c / (S / 8), cc = c % (S / 8);
-			*(h8*)(xT + k * SP + 8 * cc) = *(const h8*)(input + (size_t)k * n + (size_t)tile * S + 8 * cc);
+			*(h8*)(xT + k * SP + ft_col(k, 8 * cc)) = *(const h8*)(input + (size_t)k * n + (size_t)tile * S + 8 * cc);
 		}
 #pragma unroll
 		for (uint32_t l = 0; l <= HM; ++l) {  // saved activations are sample-major: transpose on the way in
@@ -189,7 +206,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 				const uint32_t i = c / (WIDTH / 8), cc = c % (WIDTH / 8);
 				const h8 v = *(const h8*)(src + (size_t)i * WIDTH + 8 * cc);
 #pragma unroll
-				for (uint32_t j = 0; j < 8; ++j) hT[(l * WIDTH + 8 * cc + j) * SP + i] = v[j];
+				for (uint32_t j = 0; j < 8; ++j) hT[(l * WIDTH + 8 * cc + j) * SP + ft_col(8 * cc + j, i)] = v[j];
 			}
 		}
 		for (uint32_t c = tid; c < S * 2; c += THREADS) {
@@ -209,7 +226,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 			for (uint32_t t = 0; t < NT; ++t) {
 				const h4 a = *(const h4*)(dL_doutput + ((size_t)tile * S + 16 * t + lr) * 16 + 4 * g);
 				const f4 acc = mfma_16x16x16(a, bw, zero4());
-				const h4 hv = *(const h4*)(hlast + (16 * w + lr) * SP + 16 * t + 4 * g);
+				const h4 hv = *(const h4*)(hlast + (16 * w + lr) * SP + ft_col16(w, 16 * t) + lane_c4);
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
 					da[t][r] = (half_t)act_backward<GENERAL>(act, acc[r], hv[r]);  // transfer on post-activation values (common_device.h:363-418)
@@ -219,7 +236,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 			if (want_grads) {  // dW_out^T[k][o] += sum_s A_last[k][s] dY[o][s]
 #pragma unroll
 				for (uint32_t tp = 0; tp < NTP; ++tp) {
-					const h8 a = *(const h8*)(hlast + (16 * w + lr) * SP + 32 * tp + 8 * g);
+					const h8 a = *(const h8*)(hlast + (16 * w + lr) * SP + ft_col(16 * w + lr, 32 * tp + 8 * g));
 					const h8 b = *(const h8*)(dyT + lr * SP + 32 * tp + 8 * g);
 					accO = mfma_16x16x32(a, b, accO);
 				}
@@ -240,8 +257,8 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 #pragma unroll
 					for (uint32_t tp = 0; tp < NTP; ++tp) {
 						const h8 a = pack8(da[2 * tp], da[2 * tp + 1]);
-						const h4 b0 = *(const h4*)(hj + (16 * b + lr) * SP + 32 * tp + 4 * g);
-						const h4 b1 = *(const h4*)(hj + (16 * b + lr) * SP + 32 * tp + 16 + 4 * g);
+						const h4 b0 = *(const h4*)(hj + (16 * b + lr) * SP + ft_col16(b, 32 * tp) + lane_c4);
+						const h4 b1 = *(const h4*)(hj + (16 * b + lr) * SP + ft_col16(b, 32 * tp + 16) + lane_c4);
 						accH[j][b] = mfma_16x16x32(a, pack8(b0, b1), accH[j][b]);
 					}
 				}
@@ -271,7 +288,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 			}
 #pragma unroll
 			for (uint32_t t = 0; t < NT; ++t) {
-				const h4 hv = *(const h4*)(hj + (16 * w + lr) * SP + 16 * t + 4 * g);
+				const h4 hv = *(const h4*)(hj + (16 * w + lr) * SP + ft_col16(w, 16 * t) + lane_c4);
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
 					da[t][r] = (half_t)act_backward<GENERAL>(act, acc[t][r], hv[r]);
@@ -292,8 +309,8 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 #pragma unroll
 					for (uint32_t tp = 0; tp < NTP; ++tp) {
 						const h8 a = pack8(da[2 * tp], da[2 * tp + 1]);
-						const h4 b0 = *(const h4*)(xT + (16 * b + lr) * SP + 32 * tp + 4 * g);
-						const h4 b1 = *(const h4*)(xT + (16 * b + lr) * SP + 32 * tp + 16 + 4 * g);
+						const h4 b0 = *(const h4*)(xT + (16 * b + lr) * SP + ft_col16(b, 32 * tp) + lane_c4);
+						const h4 b1 = *(const h4*)(xT + (16 * b + lr) * SP + ft_col16(b, 32 * tp + 16) + lane_c4);
 						accI[b] = mfma_16x16x32(a, pack8(b0, b1), accI[b]);
 					}
 				}
@@ -1047,7 +1064,7 @@ uint32_t mlp_backward_n_partials(const MlpMeta& m, uint32_t n) {
 template <uint32_t WIDTH, uint32_t HM>
 static void launch_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params_t, const half_t* input, const half_t* hidden,
                             const half_t* dL_doutput, half_t* dL_dinput, float* partials) {
-	constexpr uint32_t S = MLP_BWD_TILE, SP = S + 8, LDW = WIDTH + 8;
+	constexpr uint32_t S = MLP_BWD_TILE, SP = MLP_BWD_SP, LDW = WIDTH + 8;
 	const uint32_t halves = 2 * m.in_width * SP + (HM + 1) * WIDTH * SP + 2 * S * LDW + 16 * SP;
 	const uint32_t lds_bytes = halves * (uint32_t)sizeof(half_t);
 	const uint32_t blocks = mlp_backward_n_partials(m, n);

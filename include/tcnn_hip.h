@@ -211,6 +211,11 @@ int tcnn_trainer_set_profiling(tcnn_trainable_model_t* tm, int enable, int only_
 int tcnn_trainer_n_stages(void);
 const char* tcnn_trainer_stage_name(int stage);
 int tcnn_trainer_get_stage_times(tcnn_trainable_model_t* tm, double* total_ms, uint64_t* counts);
+/* training_step(run_optimizer = 1) on one GPU lets the bucket owners of the grid backward apply Adam to the table slices whose
+ * exact gradient sums they hold in LDS (the rest of the parameters are stepped by the optimizer kernel as usual): same
+ * arithmetic and results, bit for bit, as backward followed by optimizer_step.  Off by default (measured no faster: the
+ * owner pass's own queue streaming leaves the optimizer's traffic nothing to hide behind); 1 turns it on. */
+int tcnn_trainer_set_fused_optimizer(tcnn_trainable_model_t* tm, int enable);
 /* Tuning knob: bytes of LDS one grid-backward workgroup uses for the table slice it owns (default 64 KiB). */
 int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes);
 /* Grid backward formulation, process-wide: 0 = owner-computes LDS slices with fp32 accumulation on hashed levels,

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/tcnn_hip.h"
+#include "adam_device.h"
 #include "elementwise_kernels.h"
 #include "grid_kernels.h"
 #include "../../include/tiny-cuda-nn/json_mini.h"
@@ -686,7 +687,7 @@ static void model_forward(hipStream_t stream, const Model& md, uint32_t n, const
 
 static void encoding_backward(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const half_t* dL_denc,
                               uint32_t stride_k, uint32_t stride_i, half_t* dL_dparams, bool want_grads, bool accumulate, const float* input,
-                              uint32_t lds_level_budget);
+                              uint32_t lds_level_budget, const GridFusedAdam* fused_adam = nullptr);
 static uint32_t widest_matrix(const Model& md) {
 	uint32_t w = std::max(md.enc.padded_output_width, md.n_input_dims);
 	if (md.has_network) w = std::max(w, std::max(md.net.mlp.width * md.net.n_hidden_layers, md.net.mlp.padded_out));
@@ -745,7 +746,7 @@ static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx
 // the encoding's share of the backward pass: dL_denc has element (feature k, sample i) at [k * stride_k + i * stride_i]
 static void encoding_backward(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const half_t* dL_denc,
                               uint32_t stride_k, uint32_t stride_i, half_t* dL_dparams, bool want_grads, bool accumulate, const float* input,
-                              uint32_t lds_level_budget) {
+                              uint32_t lds_level_budget, const GridFusedAdam* fused_adam) {
 	const EncodingDesc& e = md.enc;
 	if (e.is_grid) {
 		GridIO io = {input, in_stride_i(md), in_stride_d(), n, stride_k, stride_i};
@@ -765,6 +766,7 @@ static void encoding_backward(hipStream_t stream, const Model& md, const Forward
 			}
 			ws.phase_hook = grid_backward_phase_hook;  // per-kernel timing when a profiler is attached
 			ws.hook_user = (void*)stream;
+			ws.fused_adam = mode == GridBackwardMode::Bucketed ? fused_adam : nullptr;
 			grid_backward(stream, e.grid, io, dL_denc, grid_grads, accumulate, mode, lds_level_budget, ws);
 		}
 		if (dL_dinput) {
@@ -869,6 +871,11 @@ struct tcnn_trainable_model {
 	std::string hyper_json;
 	float* loss_scratch = nullptr;  // 1024 + 1 floats
 	std::unique_ptr<Profiler> profiler;  // null unless tcnn_trainer_set_profiling enabled it
+	// training_step(run_optimizer = true): the bucket owners of the grid backward apply Adam to their slices (GridFusedAdam).
+	// Off by default: measured, the owner pass then takes as long as owner pass + optimizer kernel together (0.153 vs 0.068 +
+	// 0.080 ms, step 0.362 vs 0.346 ms; no better with two owners per CU) -- its queue streaming already keeps HBM busy, so the
+	// optimizer's traffic finds nothing to hide behind (profiles/r02_exp_notes.txt).  TCNN_FUSED_OPTIMIZER=1 / the setter turn it on.
+	bool fused_optimizer = getenv("TCNN_FUSED_OPTIMIZER") && atoi(getenv("TCNN_FUSED_OPTIMIZER")) != 0;
 	// data-parallel hosts: called between backward and the optimizer (tcnn_trainer_set_gradient_exchange)
 	void (*exchange)(void* user, void* gradients_fp16, size_t n_params, tcnn_stream_t stream) = nullptr;
 	void* exchange_user = nullptr;
@@ -1401,31 +1408,34 @@ static bool choose_step_representation(const tcnn_trainable_model* tm) {
 // Optimizer::step over a set of parameter ranges [begin, end) (begins multiples of 8).  `advance`: this call opens a new
 // optimizer step (step counter, learning-rate schedule, step-counter representation); the other calls of the same step
 // (a data-parallel host steps each gradient bucket as soon as it is reduced) continue it.
+// opens a new optimizer step: step counter, learning-rate schedule, representation of the per-parameter step counters
+static void optimizer_advance(tcnn_trainable_model_t* tm, hipStream_t stream) {
+	if (tm->lr_decay) {  // exponential_decay.h:59-70, with step() == the nested optimizer's step count before this step
+		const uint32_t step = tm->optimizer_step;
+		if (step == 0) tm->lr_factor = 1.0f;
+		if (step >= tm->decay_start && (step - tm->decay_start) % tm->decay_interval == 0 && step <= tm->decay_end) tm->lr_factor *= tm->decay_base;
+		tm->adam.learning_rate = tm->base_lr * tm->lr_factor;
+	}
+	++tm->optimizer_step;  // adam.h:159
+	const bool want_deficits = choose_step_representation(tm);
+	if (want_deficits != tm->steps_are_deficits) {
+		adam_flip_step_representation(stream, (uint32_t)tm->md.n_params(), tm->optimizer_step - 1u, tm->steps);
+		tm->steps_are_deficits = want_deficits;
+	}
+}
+
 static void optimizer_step_ranges(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale, size_t n_ranges, const size_t* begins, const size_t* ends,
-                                  bool advance) {
+                                  bool advance, bool opens_profiled_step) {
 	const size_t n = tm->md.n_params();
 	for (size_t r = 0; r < n_ranges; ++r) {
 		if (begins[r] % 8 != 0 || begins[r] > std::min(ends[r], n)) throw std::runtime_error("optimizer_step_range: a range must start at a multiple of 8 and not end before it");
 	}
-	if (advance) {
-		if (tm->lr_decay) {  // exponential_decay.h:59-70, with step() == the nested optimizer's step count before this step
-			const uint32_t step = tm->optimizer_step;
-			if (step == 0) tm->lr_factor = 1.0f;
-			if (step >= tm->decay_start && (step - tm->decay_start) % tm->decay_interval == 0 && step <= tm->decay_end) tm->lr_factor *= tm->decay_base;
-			tm->adam.learning_rate = tm->base_lr * tm->lr_factor;
-		}
-		++tm->optimizer_step;  // adam.h:159
-		const bool want_deficits = choose_step_representation(tm);
-		if (want_deficits != tm->steps_are_deficits) {
-			adam_flip_step_representation(stream, (uint32_t)n, tm->optimizer_step - 1u, tm->steps);
-			tm->steps_are_deficits = want_deficits;
-		}
-	}
+	if (advance) optimizer_advance(tm, stream);
 	ProfilerGuard pg(tm->profiler.get());
 	for (size_t r = 0; r < n_ranges; ++r) {
 		const size_t begin = begins[r], end = std::min(ends[r], n);
 		if (begin == end) continue;
-		ProfScope prof(stream, STAGE_ADAM, /*counts=*/advance && r == 0);  // a ranged (bucketed) step is ONE optimizer step
+		ProfScope prof(stream, STAGE_ADAM, /*counts=*/opens_profiled_step && r == 0);  // a ranged (bucketed) step is ONE optimizer step
 		adam_step(stream, tm->adam, (uint32_t)n, (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master, tm->params, tm->grads,
 		          tm->m1, tm->m2, tm->steps, tm->params_t_valid ? tm->params_t : nullptr, tm->md.has_network ? &tm->md.net.mlp : nullptr, (uint32_t)begin,
 		          (uint32_t)end, tm->steps_are_deficits);
@@ -1436,7 +1446,7 @@ static void optimizer_step_ranges(tcnn_trainable_model_t* tm, hipStream_t stream
 // One optimizer step == calls whose ranges tile [0, n_params) exactly once, the range with begin == 0 first.
 int tcnn_trainer_optimizer_step_range(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale, size_t begin, size_t end) {
 	TCNN_API_BEGIN
-	optimizer_step_ranges(tm, (hipStream_t)stream, loss_scale, 1, &begin, &end, /*advance=*/begin == 0);
+	optimizer_step_ranges(tm, (hipStream_t)stream, loss_scale, 1, &begin, &end, /*advance=*/begin == 0, begin == 0);
 	TCNN_API_END
 }
 
@@ -1445,7 +1455,7 @@ int tcnn_trainer_optimizer_step_range(tcnn_trainable_model_t* tm, tcnn_stream_t 
 int tcnn_trainer_optimizer_step_ranges(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale, size_t n_ranges, const size_t* begins,
                                        const size_t* ends) {
 	TCNN_API_BEGIN
-	optimizer_step_ranges(tm, (hipStream_t)stream, loss_scale, n_ranges, begins, ends, /*advance=*/true);
+	optimizer_step_ranges(tm, (hipStream_t)stream, loss_scale, n_ranges, begins, ends, /*advance=*/true, true);
 	TCNN_API_END
 }
 
@@ -1476,7 +1486,8 @@ void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* s
 static const bool g_fused_mlp_training = !(getenv("TCNN_FUSED_MLP_TRAINING") && std::string(getenv("TCNN_FUSED_MLP_TRAINING")) == "0");
 
 static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale, uint32_t n, const float* input, const float* target,
-                               const float* data_pdf, float* dL_dinput, int use_inference_params, int gradient_mode, tcnn_train_context_t** ctx_out) {
+                               const float* data_pdf, float* dL_dinput, int use_inference_params, int gradient_mode, bool run_optimizer,
+                               tcnn_train_context_t** ctx_out) {
 	TCNN_API_BEGIN
 	const half_t* params = use_inference_params ? tm->inference_params() : tm->params;
 	ProfilerGuard pg(tm->profiler.get());
@@ -1499,6 +1510,7 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 	if (n_total > 0xFFFFFFFFull) throw std::runtime_error("Trainer::forward: batch too large");
 	if (n == 0) {
 		*ctx_out = c.release();
+		if (run_optimizer) return tcnn_trainer_optimizer_step(tm, stream, loss_scale);
 		return TCNN_OK;
 	}
 
@@ -1527,10 +1539,53 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 		          need_denc ? denc.as<half_t>() : nullptr, want_grads ? partials.as<float>() : nullptr, c->block_sums.as<float>());
 		if (want_grads) mlp_finalize_gradients(stream, (uint32_t)md.n_mlp_params(), n_partials, partials.as<float>(), tm->grads, accumulate);
 	}
+	// The optimizer step of the bucketed levels happens inside the grid backward (GridFusedAdam) when this call owns the whole
+	// step: one GPU, gradients overwritten, plain Adam (no EMA copy to maintain), parameters the trainer's own.
+	bool fused_level[MAX_N_LEVELS] = {};
+	bool optimizer_opened = false;
 	if (need_denc) {
-		encoding_backward(stream, md, fc, n, dL_dinput, denc.as<half_t>(), n, 1u, tm->grads, want_grads, accumulate, input, tm->lds_level_budget);
+		const size_t n_mlp = md.n_mlp_params();
+		const bool fuse = run_optimizer && tm->fused_optimizer && want_grads && !accumulate && e.is_grid && e.n_params > 0 && !tm->ema && !tm->exchange &&
+		                  tm->global_batch == 0 && !use_inference_params && e.grid.stochastic == 0u &&
+		                  (GridBackwardMode)g_grid_backward_mode.load() == GridBackwardMode::Bucketed;
+		AdamCore core;
+		GridFusedAdam fa;
+		if (fuse) {
+			optimizer_advance(tm, stream);
+			optimizer_opened = true;
+			core = make_adam_core(tm->adam, (uint32_t)n_mlp, loss_scale, tm->optimizer_step, tm->steps_are_deficits);
+			fa.core = &core;
+			fa.master = tm->master + n_mlp;
+			fa.params = tm->params + n_mlp;
+			fa.m1 = tm->m1 + n_mlp;
+			fa.m2 = tm->m2 + n_mlp;
+			fa.steps = tm->steps + n_mlp;
+			fa.stream_state = adam_streams_its_state((uint32_t)md.n_params());
+			fa.fused_level = fused_level;
+		}
+		encoding_backward(stream, md, fc, n, dL_dinput, denc.as<half_t>(), n, 1u, tm->grads, want_grads, accumulate, input, tm->lds_level_budget,
+		                  fuse ? &fa : nullptr);
 	}
 	*ctx_out = c.release();
+	if (run_optimizer && optimizer_opened) {  // the rest of the step: network weights and the levels the backward did not step
+		std::vector<size_t> begins, ends;
+		const size_t n_mlp = md.n_mlp_params(), F = e.grid.n_feat;
+		begins.push_back(0);
+		ends.push_back(n_mlp);
+		for (uint32_t l = 0; l < e.grid.n_levels; ++l) {
+			if (fused_level[l]) continue;
+			const size_t b = n_mlp + (size_t)e.grid.offset[l] * F, en = n_mlp + (size_t)e.grid.offset[l + 1] * F;
+			if (ends.back() == b) ends.back() = en;
+			else {
+				begins.push_back(b);
+				ends.push_back(en);
+			}
+		}
+		optimizer_step_ranges(tm, stream, loss_scale, begins.size(), begins.data(), ends.data(), /*advance=*/false, /*opens_profiled_step=*/true);
+	} else if (run_optimizer) {
+		if (tm->exchange) tm->exchange(tm->exchange_user, tm->grads, md.n_params(), stream);
+		return tcnn_trainer_optimizer_step(tm, stream, loss_scale);
+	}
 	TCNN_API_END
 }
 
@@ -1541,9 +1596,8 @@ int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
 	tm->last_batch = n;
 	tcnn_train_context_t* ctx = nullptr;
 	if (g_fused_mlp_training && !external_dL_dy && target && tm->md.has_network && mlp_train_supported(tm->md.net.mlp) && loss_is_elementwise(tm->loss)) {
-		int r = training_step_fused(tm, (hipStream_t)stream, loss_scale, n, input, target, data_pdf, dL_dinput, use_inference_params, gradient_mode, &ctx);
-		if (r == TCNN_OK && run_optimizer && tm->exchange) tm->exchange(tm->exchange_user, tm->grads, tm->md.n_params(), stream);
-		if (r == TCNN_OK && run_optimizer) r = tcnn_trainer_optimizer_step(tm, stream, loss_scale);
+		int r = training_step_fused(tm, (hipStream_t)stream, loss_scale, n, input, target, data_pdf, dL_dinput, use_inference_params, gradient_mode,
+		                            run_optimizer != 0, &ctx);
 		if (ctx_out && r == TCNN_OK) {
 			*ctx_out = ctx;
 		} else {
@@ -1832,6 +1886,10 @@ int tcnn_trainer_get_stage_times(tcnn_trainable_model_t* tm, double* total_ms, u
 		counts[i] = tm->profiler->count[i];
 	}
 	TCNN_API_END
+}
+int tcnn_trainer_set_fused_optimizer(tcnn_trainable_model_t* tm, int enable) {
+	tm->fused_optimizer = enable != 0;
+	return TCNN_OK;
 }
 int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes) {
 	tm->lds_level_budget = bytes;

@@ -88,6 +88,11 @@ struct AdamHyper {  // optimizers/adam.h:330-351 defaults
 void ema_step(hipStream_t stream, uint32_t n, float ema_decay, uint32_t current_step, const half_t* weights, half_t* weights_ema, float* tmp,
               uint32_t begin = 0, uint32_t end = 0xFFFFFFFFu);
 
+// the per-parameter arithmetic and its argument block (adam_device.h), for kernels that apply the step themselves
+struct AdamCore;
+AdamCore make_adam_core(const AdamHyper& h, uint32_t n_matrix_weights, float loss_scale, uint32_t current_step, bool steps_are_deficits);
+bool adam_streams_its_state(uint32_t n_params);  // optimizer state too large for the Infinity Cache: non-temporal accesses
+
 // weights_t (nullable) + mlp: also keep the transposed copy of the network weights (mlp_transposed_index) current, so
 // that the next training step does not need a transposition pass.
 void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale,

@@ -64,6 +64,22 @@ void grid_forward(hipStream_t stream, const GridMeta& meta, const GridIO& io, co
 //                          keeps one such buffer per stream and never clears it again.
 // lds_slice_bytes: LDS bytes one workgroup devotes to its table slice (0 = default 128 KiB).
 enum class GridBackwardMode : int { SlicedF32 = 0, SlicedF16 = 1, Atomic = 2, Bucketed = 3 };
+// Optimizer step inside the bucketed backward (optional).  The owner of a table slice holds the slice's exact gradient sums in
+// LDS; instead of only storing them for a later optimizer kernel to read back, it applies Adam (adam_device.h: the arithmetic
+// of the stand-alone kernel, bit for bit) to the slice's parameters right there -- the optimizer's HBM streaming then overlaps
+// the LDS-bound accumulation of the other owners instead of following it.  Only levels whose slices have a single owner
+// (bucketed, not split over sample chunks) are stepped here; `fused_level[l]` tells the caller which, the rest is its job.
+// Gradients are still stored (param_gradients stays valid).  Array pointers are indexed from the GRID's first parameter.
+struct AdamCore;
+struct GridFusedAdam {
+	const AdamCore* core = nullptr;  // host copy; n_matrix_weights = parameters that precede the grid's in the trainer's arrays
+	float* master = nullptr;         // fp32 weights
+	half_t* params = nullptr;        // 16-bit weights
+	float *m1 = nullptr, *m2 = nullptr;
+	uint32_t* steps = nullptr;
+	bool stream_state = false;       // non-temporal accesses to the optimizer state (elementwise_kernels.h: adam_streams_its_state)
+	bool* fused_level = nullptr;     // out, [n_levels]
+};
 struct GridBackwardWorkspace {
 	void* scratch = nullptr;
 	size_t scratch_bytes = 0;
@@ -73,6 +89,7 @@ struct GridBackwardWorkspace {
 	// phase 0: record scatter (bucketed mode only), 1: accumulation + stores (every mode), 2: overflow pass
 	void (*phase_hook)(void* user, int phase, int begin) = nullptr;
 	void* hook_user = nullptr;
+	const GridFusedAdam* fused_adam = nullptr;  // Bucketed mode, accumulate == false, first-order scatter only
 };
 GridBackwardWorkspace grid_backward_workspace_size(const GridMeta& meta, uint32_t n, GridBackwardMode mode, uint32_t lds_slice_bytes);
 void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient, bool accumulate,

@@ -3,6 +3,7 @@
 // that indices AND interpolated features are bit-identical to the CPU oracle.
 #include "grid_kernels.h"
 #include "elementwise_kernels.h"  // Pcg32 (stochastic interpolation)
+#include "adam_device.h"          // the optimizer step of the owner pass (GridFusedAdam)
 
 #include <algorithm>
 #include <cstdlib>
@@ -908,11 +909,65 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 	}
 }
 
+// GridFusedAdam as the kernel sees it
+struct FusedAdamArgs {
+	AdamCore core;
+	float* master;
+	half_t* params;
+	float *m1, *m2;
+	uint32_t* steps;
+	int enabled, stream;
+};
+
+// Adam on 4 consecutive parameters of a slice whose exact gradients `g` were just read out of the LDS table: the body of
+// k_adam_step's four-parameter path (elementwise_kernels.hip), same arithmetic (adam_one), same step-counter forms
+template <bool STREAM>
+TCNN_DEVICE void fused_adam4(const FusedAdamArgs& fa, size_t p, h4 g) {
+	const AdamCore& a = fa.core;
+	f4 w = adam_load<STREAM>((const f4*)(fa.master + p));
+	f4 m1 = adam_load<STREAM>((const f4*)(fa.m1 + p));
+	f4 m2 = adam_load<STREAM>((const f4*)(fa.m2 + p));
+	u4 st = adam_load<STREAM>((const u4*)(fa.steps + p));
+	h4 wh = h4{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+	uint32_t updated = 0;
+#pragma unroll
+	for (uint32_t j = 0; j < 4; ++j) {
+		float wj = w[j], m1j = m1[j], m2j = m2[j];
+		uint32_t sj = a.deficit ? a.steps_done - st[j] : st[j];
+		if (adam_one(a, a.n_matrix_weights + (uint32_t)p + j, (float)g[j], wj, m1j, m2j, sj)) {
+			w[j] = wj;
+			m1[j] = m1j;
+			m2[j] = m2j;
+			if (!a.deficit) st[j] = sj;
+			wh[j] = to_half_rn(wj);
+			updated |= 1u << j;
+		} else if (a.deficit) {
+			st[j] += 1u;
+		}
+	}
+	if (a.deficit && updated != 0xFu) adam_store<STREAM>((u4*)(fa.steps + p), st);
+	if (updated != 0u || a.dense_store) {
+		if (updated != 0xFu) {  // keep the 16-bit weights of the parameters that were skipped
+			const h4 old = *(const h4*)(fa.params + p);
+#pragma unroll
+			for (uint32_t j = 0; j < 4; ++j) {
+				if (!((updated >> j) & 1u)) wh[j] = old[j];
+			}
+		}
+		adam_store<STREAM>((f4*)(fa.master + p), w);
+		adam_store<STREAM>((f4*)(fa.m1 + p), m1);
+		adam_store<STREAM>((f4*)(fa.m2 + p), m2);
+		if (!a.deficit) adam_store<STREAM>((u4*)(fa.steps + p), st);
+		*(h4*)(fa.params + p) = wh;
+	}
+}
+
 // pass B: the owner of bucket `bucket` of slot `j` streams its queue into a 64-bit fixed-point LDS table
 template <uint32_t D, uint32_t F>
 TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t level, uint32_t j, uint32_t bucket, uint32_t chunk,
                               const BucketPlan& plan, uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues,
-                              const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient, bool accumulate, unsigned char* lds_raw) {
+                              const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient, bool accumulate, unsigned char* lds_raw,
+                              const FusedAdamArgs& fused) {
 	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, PWP = BucketRecord<F>::PAIR_WORDS, OW = BucketRecord<F>::WORDS + 1;
 	__shared__ uint32_t last_owner;
 	// records that did not fit their queue (or whose x-neighbour lives in another bucket: about one pair in 2^shift).  Up to
@@ -973,7 +1028,19 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 	__syncthreads();
 
 	half_t* __restrict__ grad = grid_gradient + ((size_t)meta.offset[level] + slice_begin) * F;
-	const uint32_t n_halves = slice_count * F;  // even: level sizes are multiples of 8
+	const uint32_t n_halves = slice_count * F;  // a multiple of 8: level sizes are multiples of 8
+	if (fused.enabled && n_chunks == 1 && !accumulate) {
+		// sole owner of the slice: the optimizer step straight from the exact sums (GridFusedAdam), 4 parameters per lane
+		const size_t p_first = ((size_t)meta.offset[level] + slice_begin) * F;  // relative to the grid's first parameter
+		for (uint32_t q = threadIdx.x; q < n_halves / 4; q += SLICED_THREADS) {
+			h4 g;
+#pragma unroll
+			for (uint32_t jj = 0; jj < 4; ++jj) g[jj] = (half_t)(float)((double)((const long long*)lds_raw)[4 * q + jj] * (1.0 / FIXED_SCALE));
+			*(h4*)(grad + 4 * q) = g;  // param_gradients stays what the stand-alone path leaves there
+			if (fused.stream) fused_adam4<true>(fused, p_first + 4 * q, g);
+			else fused_adam4<false>(fused, p_first + 4 * q, g);
+		}
+	} else
 	for (uint32_t e2 = threadIdx.x; e2 < n_halves / 2; e2 += SLICED_THREADS) {
 		const long long q0 = ((const long long*)lds_raw)[2 * e2], q1 = ((const long long*)lds_raw)[2 * e2 + 1];
 		h2 v = h2{(half_t)(float)((double)q0 * (1.0 / FIXED_SCALE)), (half_t)(float)((double)q1 * (1.0 / FIXED_SCALE))};
@@ -1029,7 +1096,7 @@ __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const G
                                                                            const half_t* __restrict__ dL_dy, half_t* __restrict__ grid_gradient,
                                                                            const int accumulate, const BucketPlan bplan,
                                                                            uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues,
-                                                                           const uint32_t* __restrict__ overflow) {
+                                                                           const uint32_t* __restrict__ overflow, const FusedAdamArgs fused) {
 	TCNN_DYN_LDS(lds_raw);
 	uint32_t item = 0, local_block;
 	if (plan.blocks_per_item) {
@@ -1054,7 +1121,7 @@ __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const G
 	const Level<D> lv = make_level<D>(meta, level);
 
 	if (kind == SLICE_BUCKET) {
-		bucket_level<D, F>(meta, lv, level, plan.slot[item], slice, chunk, bplan, counters, queues, overflow, grid_gradient, accumulate != 0, lds_raw);
+		bucket_level<D, F>(meta, lv, level, plan.slot[item], slice, chunk, bplan, counters, queues, overflow, grid_gradient, accumulate != 0, lds_raw, fused);
 		return;
 	}
 	if (kind == SLICE_GLOBAL_ATOMIC) {
@@ -1547,17 +1614,37 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 		}
 	}
 	const int acc = accumulate ? 1 : 0;
+	FusedAdamArgs fused = {};
+	if (ws.fused_adam && ws.fused_adam->core && bucketed && !accumulate && !io.ddx) {
+		const GridFusedAdam& fa = *ws.fused_adam;
+		fused.core = *fa.core;
+		fused.master = fa.master;
+		fused.params = fa.params;
+		fused.m1 = fa.m1;
+		fused.m2 = fa.m2;
+		fused.steps = fa.steps;
+		fused.enabled = 1;
+		fused.stream = fa.stream_state ? 1 : 0;
+		if (fa.fused_level) {
+			for (uint32_t l = 0; l < meta.n_levels; ++l) fa.fused_level[l] = false;
+			for (uint32_t p = 0; p < plan.n_items; ++p) {
+				if (plan.kind[p] == SLICE_BUCKET && bp.n_chunks[p] == 1) fa.fused_level[plan.level[p]] = true;
+			}
+		}
+	} else if (ws.fused_adam && ws.fused_adam->fused_level) {
+		for (uint32_t l = 0; l < meta.n_levels; ++l) ws.fused_adam->fused_level[l] = false;
+	}
 #define BWDS(D_, F_)                                                                                                                   \
 	if (packed) {                                                                                                                      \
 		if constexpr (F_ % 2 == 0) {                                                                                                   \
 			TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, true>), lds_slice_bytes);                                             \
 			TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, true>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io, \
-			            plan, dL_dy, grid_gradient, acc, bk, counters, (const uint32_t*)queues, (const uint32_t*)overflow);            \
+			            plan, dL_dy, grid_gradient, acc, bk, counters, (const uint32_t*)queues, (const uint32_t*)overflow, fused);     \
 		}                                                                                                                              \
 	} else {                                                                                                                           \
 		TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, false>), lds_slice_bytes);                                                \
 		TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, false>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io,    \
-		            plan, dL_dy, grid_gradient, acc, bk, counters, (const uint32_t*)queues, (const uint32_t*)overflow);                \
+		            plan, dL_dy, grid_gradient, acc, bk, counters, (const uint32_t*)queues, (const uint32_t*)overflow, fused);         \
 	}
 	TCNN_GRID_DISPATCH(BWDS)
 #undef BWDS

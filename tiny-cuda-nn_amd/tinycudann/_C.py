@@ -128,6 +128,7 @@ _sig("tcnn_trainer_n_stages", _i)
 _sig("tcnn_trainer_stage_name", _cp, _i)
 _sig("tcnn_trainer_get_stage_times", _i, _vp, _vp, _vp)
 _sig("tcnn_trainer_set_lds_level_budget", _i, _vp, _u32)
+_sig("tcnn_trainer_set_fused_optimizer", _i, _vp, _i)
 _sig("tcnn_set_grid_backward_mode", _i, _i)
 _sig("tcnn_get_grid_backward_mode", _i)
 

@@ -219,6 +219,10 @@ class TrainableModel:
         _check(_lib.tcnn_trainer_get_stage_times(self._h, ms, cnt))
         return {name: (ms[i], cnt[i]) for i, name in enumerate(self.stage_names())}
 
+    def set_fused_optimizer(self, enable=True):
+        """Adam inside the grid backward's owner pass for training_step(run_optimizer=True) on one GPU (default off: measured no faster)."""
+        _check(_lib.tcnn_trainer_set_fused_optimizer(self._h, int(enable)))
+
     def set_lds_level_budget(self, n_bytes):
         _check(_lib.tcnn_trainer_set_lds_level_budget(self._h, int(n_bytes)))
 

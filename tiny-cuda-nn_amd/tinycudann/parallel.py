@@ -111,6 +111,8 @@ class DataParallel:
         self.n = n
         self._comm_s = 0.0
         self._events = []
+        self._stage = {}
+        self._has_reduce_scatter = self._has_all_gather_into = True
 
     def shard_range(self, rank=None):
         r = self.rank if rank is None else rank
@@ -146,21 +148,39 @@ class DataParallel:
             self._comm_s += time.perf_counter() - start
 
     # ---- collectives with fall-backs for backends that lack the fused forms (gloo) ------------------------------------
+    def _staging(self, like):
+        """A shard-sized staging tensor per dtype: the collectives below run out of place (the form every backend supports;
+        the copy of one shard -- 1/P of the buffer -- is noise next to the collective itself)."""
+        key = (like.dtype, like.device)
+        if key not in self._stage:
+            self._stage[key] = torch.empty(self.shard, dtype=like.dtype, device=like.device)
+        return self._stage[key]
+
     def _reduce_scatter(self, buf):
-        """Sum over ranks; afterwards this rank's shard of buf[:main] holds the reduced values (in place)."""
+        """Sum over ranks; afterwards this rank's shard of buf[:main] holds the reduced values."""
         b, e = self.shard_range()
-        try:
-            dist.reduce_scatter_tensor(buf[b:e], buf[: self.main], op=dist.ReduceOp.SUM)
-        except (RuntimeError, NotImplementedError):
-            dist.all_reduce(buf[: self.main], op=dist.ReduceOp.SUM)  # twice the bytes, same result in the own shard
+        if self._has_reduce_scatter:
+            try:
+                out = self._staging(buf)
+                dist.reduce_scatter_tensor(out, buf[: self.main], op=dist.ReduceOp.SUM)
+                buf[b:e].copy_(out)
+                return
+            except (RuntimeError, NotImplementedError):
+                self._has_reduce_scatter = False  # gloo: no reduce-scatter
+        dist.all_reduce(buf[: self.main], op=dist.ReduceOp.SUM)  # twice the bytes, same result in the own shard
 
     def _all_gather(self, buf):
-        """Every rank's shard of buf[:main] -> all ranks (in place)."""
+        """Every rank's shard of buf[:main] -> all ranks."""
         b, e = self.shard_range()
-        try:
-            dist.all_gather_into_tensor(buf[: self.main], buf[b:e])
-        except (RuntimeError, NotImplementedError):
-            dist.all_gather([buf[r * self.shard:(r + 1) * self.shard] for r in range(self.world)], buf[b:e].clone())
+        own = self._staging(buf)
+        own.copy_(buf[b:e])
+        if self._has_all_gather_into:
+            try:
+                dist.all_gather_into_tensor(buf[: self.main], own)
+                return
+            except (RuntimeError, NotImplementedError):
+                self._has_all_gather_into = False
+        dist.all_gather([buf[r * self.shard:(r + 1) * self.shard] for r in range(self.world)], own)
 
     # ---- one step ------------------------------------------------------------------------------------------------------
     def exchange_and_step(self):

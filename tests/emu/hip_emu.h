@@ -61,6 +61,7 @@ struct Fiber {
 struct Wave {
 	unsigned gen = 0, arrived = 0, size = 64;
 	eh8 a[64], b[64];
+	unsigned long long vote[2] = {0, 0};  // ballots of alternating rendezvous
 };
 
 struct State {
@@ -102,6 +103,16 @@ inline void wave_barrier() {
 	} else {
 		while (w.gen == gen) yield();
 	}
+}
+
+// __ballot for fully converged waves (every lane of the wave must execute it)
+inline unsigned long long wave_ballot(bool pred) {
+	Wave& w = g.waves[g.cur->tidx.x / 64];
+	const unsigned slot = w.gen & 1u;
+	if (w.arrived == 0) w.vote[slot] = 0;
+	if (pred) w.vote[slot] |= 1ull << (g.cur->tidx.x & 63u);
+	wave_barrier();
+	return w.vote[slot];
 }
 
 inline void trampoline() {
@@ -171,6 +182,7 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> fn
 #define blockDim (::emu::g.block)
 #define gridDim (::emu::g.grid)
 #define __syncthreads() ::emu::block_barrier()
+#define __ballot(pred) ::emu::wave_ballot(pred)
 
 #define TCNN_LAUNCH(kernel, grid, block, shmem, stream, ...) \
 	::emu::launch(grid, block, shmem, [=]() { kernel(__VA_ARGS__); })

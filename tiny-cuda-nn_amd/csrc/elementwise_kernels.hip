@@ -256,19 +256,28 @@ struct AdamArgs : AdamCore {
 };
 
 // 4 parameters per lane: 8 B of gradients decide whether the 16-byte state loads happen at all, so
-// untouched hash-table entries cost 2 B/param as in the reference (adam.h:79-82).
+// untouched stretches of a hash table cost 2 B/param as in the reference (adam.h:79-82).
 template <bool STREAM>
 __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, float* __restrict__ weights_fp32, half_t* __restrict__ weights,
                                                            const half_t* __restrict__ gradients, float* __restrict__ first_moments,
                                                            float* __restrict__ second_moments, uint32_t* __restrict__ param_steps,
                                                            half_t* __restrict__ weights_t) {
 	const uint32_t i0 = a.begin + (blockIdx.x * EW_THREADS + threadIdx.x) * 4;
+	const bool four = i0 < a.n_elements && i0 + 3 < a.n_elements;
+	h4 g = h4{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+	if (four) g = *(const h4*)(gradients + i0);
+	bool skip_all = four && i0 >= a.n_matrix_weights && a.skip_zero_grad_non_matrix_params && g[0] == (half_t)0.0f && g[1] == (half_t)0.0f &&
+	                g[2] == (half_t)0.0f && g[3] == (half_t)0.0f;
+	if (a.dense_store) {
+		// the 8 lanes that share a 128-byte line of each fp32 state array decide together: a line nobody steps is not touched
+		// (2 B per parameter, as the reference), a line somebody steps is written whole (a partly written line costs HBM a
+		// read-modify-write).  Every lane of the wave votes, also those beyond the end (they never skip).
+		const uint64_t skipping = __ballot(skip_all);
+		skip_all = ((skipping >> (threadIdx.x & 56u)) & 0xFFull) == 0xFFull;
+	}
 	if (i0 >= a.n_elements) return;
-	if (i0 + 3 < a.n_elements) {
-		const h4 g = *(const h4*)(gradients + i0);
-		const bool all_non_matrix = i0 >= a.n_matrix_weights;
-		if (!a.dense_store && all_non_matrix && a.skip_zero_grad_non_matrix_params && g[0] == (half_t)0.0f && g[1] == (half_t)0.0f && g[2] == (half_t)0.0f &&
-		    g[3] == (half_t)0.0f) {
+	if (four) {
+		if (skip_all) {
 			if (a.deficit) {  // all four skipped: one more missed step each
 				u4 st = adam_load<STREAM>((const u4*)(param_steps + i0));
 				st += 1u;

@@ -6,6 +6,7 @@
 #include "../../tiny-cuda-nn_amd/csrc/elementwise_kernels.hip"
 #include "../../tiny-cuda-nn_amd/csrc/mlp_kernels.hip"
 #include "../../tiny-cuda-nn_amd/csrc/mlp_train_wave.hip"
+#include "../../tiny-cuda-nn_amd/csrc/mlp_train_wide.hip"
 
 using namespace tcnn_hip;
 

@@ -242,6 +242,21 @@ inline f4 mfma_16x16x16(h4 a, h4 b, f4 c) {
 	return d;
 }
 
+// ds_read_b64_tr_b16: lane c of a 16-lane group, element j <- element (c & 3) of the word lane 4j + (c >> 2) addressed
+inline h4 lds_read_tr4(const _Float16* word) {
+	const unsigned lane = ::emu::g.cur->tidx.x & 63u;
+	::emu::Wave& w = ::emu::g.waves[::emu::g.cur->tidx.x / 64];
+	h8 mine = {};
+	for (unsigned j = 0; j < 4; ++j) mine[j] = word[j];
+	w.a[lane] = mine;
+	::emu::wave_barrier();
+	const unsigned grp = lane & ~15u, c = lane & 15u;
+	h4 out;
+	for (unsigned j = 0; j < 4; ++j) out[j] = w.a[grp + 4 * j + (c >> 2)][c & 3u];
+	::emu::wave_barrier();
+	return out;
+}
+
 inline _Float16 emu_round_h(double v) { return (_Float16)v; }  // double -> half is a single RNE rounding
 
 inline void atomic_add_h2(half_t* addr, h2 v) {

@@ -367,6 +367,63 @@ def targets_for(pos, out):
     return np.stack([0.5 + 0.5 * np.sin(2 * np.pi * (c + 1) * pos[:, 0]) * np.cos(2 * np.pi * pos[:, 1]) for c in range(out)], 1).astype(np.float32)
 
 
+@pytest.mark.parametrize("hidden_layers,n_features,out,act,out_act,loss", [
+    (4, 2, 16, "ReLU", "None", "RelativeL2"),    # BASELINE configs[4]'s network: k_mlp_train_wide<3, 1>
+    (2, 4, 3, "LeakyReLU", "Sigmoid", "L1"),     # 64 inputs, out-of-line activations / loss: k_mlp_train_wide<1, 2, general>
+    (1, 2, 4, "ReLU", "None", "L2"),
+])
+def test_wide_network_fused_training_step(hidden_layers, n_features, out, act, out_act, loss):
+    """128-neuron networks: training_step's single kernel (k_mlp_train_wide: weights resident in LDS, transpose reads, weight
+    gradients in registers across eight 32-sample tiles per workgroup at this batch) against forward() + backward(), which run
+    k_mlp_forward -> k_loss -> k_mlp_backward: same bits for prediction, loss gradient and everything that flows into the
+    encoding; the fp32 weight-gradient sums are grouped per 32 instead of per 64 samples.  ReLU cases also against the oracle."""
+    cfg = config_hash(log2_hashmap_size=15, per_level_scale=1.5, n_neurons=128, n_hidden_layers=hidden_layers, loss=loss)
+    cfg["encoding"]["n_features_per_level"] = n_features
+    cfg["network"].update(activation=act, output_activation=out_act)
+    T = tcnn()
+    tm = T.create_from_config(3, out, cfg)
+    init = tm.params_full_precision.cpu().numpy().copy()
+    nm = tm.n_mlp_params
+    init[nm:] *= 1.0e3
+    tm.set_params_full_precision(torch.from_numpy(init))
+    n = 1 << 16  # 2048 tiles over 256 workgroups
+    pos = positions(n, 3, seed=33)
+    tgt = targets_for(pos, out)
+    x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(tgt).cuda()
+    dx_f = torch.zeros((n, 3), device="cuda")
+    ctx = tm.training_step(x, t, run_optimizer=False, dL_dinput=dx_f)
+    loss_f = tm.loss(ctx)
+    out_f, dy_f, g_f = h_np(ctx.output), h_np(ctx.dL_doutput), h_np(tm.param_gradients).copy()
+    dx_u = torch.zeros((n, 3), device="cuda")
+    ctx_u = tm.forward(x, t, prepare_input_gradients=True)
+    tm.backward(ctx_u, x, dL_dinput=dx_u)
+    g_u = h_np(tm.param_gradients)
+    assert np.array_equal(out_f, h_np(ctx_u.output)) and np.array_equal(dy_f, h_np(ctx_u.dL_doutput))
+    assert abs(loss_f - tm.loss(ctx_u)) <= 1e-5 * abs(loss_f)
+    assert torch.equal(dx_f, dx_u)                                 # dL/d(encoded input) has the same bits ...
+    ge_f, ge_u = O.h2f(g_f[nm:]), O.h2f(g_u[nm:])                  # ... the coarse levels' fp16 atomics add them in run-dependent order
+    assert np.allclose(ge_f, ge_u, rtol=2e-2, atol=2e-3 * np.abs(ge_u).max()) and np.mean(g_f[nm:] != g_u[nm:]) < 0.2
+    a, b = O.h2f(g_f[:nm]), O.h2f(g_u[:nm])
+    ordered = lambda bits: np.where(bits & 0x8000, -(bits & 0x7FFF).astype(np.int32), (bits & 0x7FFF).astype(np.int32))  # monotonic in the value
+    assert np.mean(g_f[:nm] != g_u[:nm]) < 0.05 and np.abs(ordered(g_f[:nm]) - ordered(g_u[:nm])).max() <= 2  # a last fp16 bit or two
+    assert np.isfinite(a).all() and np.abs(a).max() > 0
+    if act != "ReLU":
+        return
+    og = oracle_grid(cfg["encoding"], 3)
+    md = O.model_init(3, out, og, 128, hidden_layers, O.LOSS_NAMES.index(loss), O.adam_defaults(learning_rate=1e-2, beta2=0.99, epsilon=1e-15, l2_reg=1e-6))
+    assert md.n_params == tm.n_params
+    st = O.TrainState(md, init)
+    m = 4096  # the oracle's 128 x 4 step at the full batch takes a while; the first tiles are enough for it
+    ctx = tm.training_step(x[:m].contiguous(), t[:m].contiguous(), run_optimizer=False)
+    loss_ref, pred_ref = O.training_step(st, pos[:m], tgt[:m], run_optimizer=False, want_prediction=True)
+    assert abs(tm.loss(ctx) - loss_ref) <= 2e-3 * abs(loss_ref)
+    assert np.percentile(rae(O.h2f(h_np(ctx.output))[:, :out], O.h2f(pred_ref)[:, :out]), 99) < 3e-3
+    g, gref = tm.param_gradients.float().cpu().numpy(), O.h2f(st.grads)
+    assert np.percentile(rae(g[:nm], gref[:nm]), 99) < 5e-3
+    big = np.abs(gref[nm:]) > 1e-2 * np.abs(gref[nm:]).max()
+    assert np.percentile(rae(g[nm:][big], gref[nm:][big]), 99) < 3e-2
+
+
 @pytest.mark.parametrize("loss", ["RelativeL2", "L2", "L1", "RelativeL1", "Mape", "Smape", "RelativeL2Luminance"])
 def test_training_step_matches_oracle(loss):
     """create_from_config -> trainer.training_step -> trainer.loss -> network.inference against the oracle's

@@ -87,7 +87,7 @@ void mlp_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t
 // Fused training pass of Trainer::training_step (trainer.h:254-357): forward + loss + backward per sample tile in one
 // kernel -- the hidden activations stay in LDS, prediction / dL_doutput are written for the caller's ForwardContext
 // (either may be null), block_sums receives mlp_backward_n_partials() partial loss sums.  Bit-identical to
-// mlp_forward -> loss_evaluate -> mlp_backward.  Widths 16/32/64, up to 4 hidden layers (mlp_train_supported).
+// mlp_forward -> loss_evaluate -> mlp_backward.  Widths 16/32/64 (and 128 through mlp_train_wide), up to 4 hidden layers (mlp_train_supported).
 struct MlpLossArgs {
 	LossType type;
 	const float* targets;   // fp32 [n][dims]
@@ -104,6 +104,15 @@ bool mlp_train_supported(const MlpMeta& m);
 bool mlp_train_wave_supported(const MlpMeta& m, uint32_t n, LossType loss);
 uint32_t mlp_train_wave_n_partials(uint32_t n);
 void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
+                    const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums);
+
+// The fused training pass of 128-neuron networks (mlp_train_wide.hip): hidden weights resident in LDS (one copy, the backward
+// operands come out of it through the hardware transpose read), sample-major activation tiles of 32 samples, weight gradients
+// in registers.  32 or 64 inputs, up to 4 hidden layers, 16 padded outputs, any activation / element-wise loss.  mlp_train()
+// picks it (TCNN_MLP_TRAIN_WIDE=0 disables it: 128-wide networks then train through forward / loss / backward kernels).
+bool mlp_train_wide_supported(const MlpMeta& m, uint32_t n);
+uint32_t mlp_train_wide_n_partials(uint32_t n);
+void mlp_train_wide(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
                     const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums);
 
 // Inference (no saved activations) of the same shapes, also with 64 inputs, with up to 3 (64 neurons) / 4 (32 neurons) hidden layers: the forward

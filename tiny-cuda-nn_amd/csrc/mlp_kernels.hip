@@ -1177,12 +1177,15 @@ static void dispatch_train(hipStream_t stream, const MlpMeta& m, uint32_t n, con
 }
 
 uint32_t mlp_train_n_partials(const MlpMeta& m, uint32_t n, LossType loss) {
-	return mlp_train_wave_supported(m, n, loss) ? mlp_train_wave_n_partials(n) : mlp_backward_n_partials(m, n);
+	if (mlp_train_wave_supported(m, n, loss)) return mlp_train_wave_n_partials(n);
+	if (mlp_train_wide_supported(m, n)) return mlp_train_wide_n_partials(n);
+	return mlp_backward_n_partials(m, n);
 }
 
 bool mlp_train_supported(const MlpMeta& m) {
-	// 128-wide networks: measured no faster than the three-kernel path (the weight-gradient accumulators of four
-	// 128 x 128 matrices spill), so they keep it
+	// 128-wide networks: k_mlp_train measured no faster than the three-kernel path (the weight-gradient accumulators of four
+	// 128 x 128 matrices spill at 64-sample tiles); they have their own kernel (mlp_train_wide.hip) for 32 / 64 inputs
+	if (m.width == 128) return mlp_train_wide_supported(m, MLP_BWD_TILE);
 	return m.width <= 64 && m.padded_out == 16 && m.n_hidden_matmuls <= MLP_MAX_HIDDEN_MATMULS_TRAIN && mlp_train_lds_bytes(m) + 4096u <= 160u * 1024u;
 }
 
@@ -1194,6 +1197,10 @@ void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* p
 	if (!loss_is_elementwise(la.type)) throw std::runtime_error("mlp_train: this loss needs whole output rows; use the stand-alone loss kernel");
 	if (mlp_train_wave_supported(m, n, la.type)) {
 		mlp_train_wave(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums);
+		return;
+	}
+	if (m.width == 128) {
+		mlp_train_wide(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums);
 		return;
 	}
 	switch (m.width) {

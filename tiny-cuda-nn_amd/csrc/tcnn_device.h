@@ -86,6 +86,15 @@ TCNN_DEVICE void atomic_add_h2(half_t* addr, h2 v) {
 	__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)addr, v);
 }
 #endif
+// ds_read_b64_tr_b16 (gfx950): every lane passes the address of 4 consecutive 16-bit elements in LDS (8-byte aligned); inside
+// each group of 16 lanes the 16 x 4 elements are exchanged so that lane c, element j receives element (c & 3) of the word that
+// lane 4j + (c >> 2) addressed (probed: scripts/probe_tr16.hip).  With lane i of the group addressing
+// M[row0 + (i >> 2)][col0 + 4 (i & 3)] of a row-major image, lane c gets M[row0 + j][col0 + c], j < 4: a column of 4 -- the
+// "consecutive k for one n" fragment of an MFMA operand, out of an image whose rows run along n.  All 64 lanes must execute it.
+typedef short lds_tr_bits4 __attribute__((ext_vector_type(4)));
+TCNN_DEVICE h4 lds_read_tr4(const half_t* word) {
+	return __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lds_tr_bits4*)word));
+}
 TCNN_DEVICE void atomic_add_f32(float* addr, float v) { unsafeAtomicAdd(addr, v); }
 TCNN_DEVICE void lds_atomic_add_f32(float* addr, float v) { atomicAdd(addr, v); }  // ds_add_f32
 TCNN_DEVICE void lds_atomic_add_u64(unsigned long long* addr, unsigned long long v) { atomicAdd(addr, v); }  // ds_add_u64

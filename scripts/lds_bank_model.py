@@ -124,3 +124,45 @@ def search():
 
 if len(sys.argv) > 1 and sys.argv[1] == "search":
     search()
+
+
+def wide_sites(LDa, LDw, swz_a=lambda r, c: c, swz_w=lambda r, c: c, verbose=True):
+    """Access sites of k_mlp_train_wide (mlp_train_wide.hip) per 32-sample tile and wave, HM = 3: sample-major activation / gradient
+    tiles [32][LDa], weight images [128][LDw]; swz(row, col) -> physical column.  ds_read_b64_tr_b16 is modelled as read_b64."""
+    lr = lambda l: l & 15
+    g = lambda l: l >> 4
+    i4 = lambda l: (l & 15) >> 2
+    q4 = lambda l: (l & 15) & 3
+    A = lambda r, c: (r * LDa + swz_a(r, c)) * 2
+    W = lambda r, c: (r * LDw + swz_w(r, c)) * 2
+    tot = idl = 0
+    def rep(name, kind, count, fns):
+        nonlocal tot, idl
+        c = [cycles(kind, f) for f in fns]
+        avg = sum(c) / len(c)
+        if verbose:
+            print(f"  {name:62s} {kind:10s} x{count:3d} {avg:5.1f} cyc (ideal {ideal(kind)})")
+        tot += avg * count
+        idl += ideal(kind) * count
+    w_all, kb_all, t_all = range(8), range(4), range(2)
+    rep("fwd: A operand rows of W (16w+lr, 32kb+8g)", "read_b128", 12, [(lambda l, w=w, kb=kb: W(16 * w + lr(l), 32 * kb + 8 * g(l))) for w in w_all for kb in kb_all])
+    rep("fwd / chain: B or A operand rows of a tile (16t+lr, 32kb+8g)", "read_b128", 48 + 2, [(lambda l, t=t, kb=kb: A(16 * t + lr(l), 32 * kb + 8 * g(l))) for t in t_all for kb in kb_all])
+    rep("fwd: epilogue stores (16t+lr, 16w+4g)", "write_b64", 8, [(lambda l, t=t, w=w: A(16 * t + lr(l), 16 * w + 4 * g(l))) for t in t_all for w in w_all])
+    rep("chain: B operand out of W, transposed (32kb+8g+4h+i/4, 16w+4(i%4))", "read_b64", 24, [(lambda l, w=w, kb=kb, h=h: W(32 * kb + 8 * g(l) + 4 * h + i4(l), 16 * w + 4 * q4(l))) for w in w_all for kb in kb_all for h in (0, 1)])
+    rep("dW: B operand out of a tile, transposed (16h+4g+i/4, 16b+4(i%4))", "read_b64", 48, [(lambda l, b=b, h=h: A(16 * h + 4 * g(l) + i4(l), 16 * b + 4 * q4(l))) for b in range(8) for h in (0, 1)])
+    rep("masks: (16t+4g+i/4, 16w+4(i%4))", "read_b64", 8, [(lambda l, t=t, w=w: A(16 * t + 4 * g(l) + i4(l), 16 * w + 4 * q4(l))) for t in t_all for w in w_all])
+    rep("dA stores, 2 bytes (16t+4g+r, 16w+lr)", "write_b16", 32, [(lambda l, t=t, w=w, r=r: A(16 * t + 4 * g(l) + r, 16 * w + lr(l))) for t in t_all for w in w_all for r in range(4)])
+    if verbose:
+        print(f"  total {tot:.0f} LDS cycles per tile and wave (conflict-free {idl})")
+    return tot
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "wide":
+    print("k_mlp_train_wide, padded rows: LD = 136 for tiles and weights")
+    wide_sites(136, 136)
+    for lda, ldw in ((136, 144), (144, 136), (144, 144), (152, 152), (132, 132), (140, 140)):
+        print(f"LDa {lda} LDw {ldw}: {wide_sites(lda, ldw, verbose=False):.0f}")
+    fa = lambda r, c: c ^ ((r & 7) << 4)
+    fw = lambda r, c: c ^ (((r & 3) | ((r >> 1) & 4)) << 4)
+    print("unpadded rows (128), 16-byte chunks XOR-ed: tiles with (row & 7) << 1, weights with (bits 0, 1, 3 of row) << 1")
+    wide_sites(128, 128, fa, fw)

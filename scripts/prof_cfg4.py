@@ -1,5 +1,5 @@
 import os, sys
-ROOT = os.getcwd(); sys.path.insert(0, os.path.join(ROOT, "tiny-cuda-nn_amd"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(ROOT, "tiny-cuda-nn_amd"))
 import torch, tinycudann as tcnn
 ADAM = {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6}
 enc = {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 22, "base_resolution": 16, "per_level_scale": 1.5}

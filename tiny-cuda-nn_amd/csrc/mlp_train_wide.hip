@@ -27,7 +27,12 @@ namespace tcnn_hip {
 
 constexpr uint32_t WIDE = 128;       // neurons
 constexpr uint32_t WIDE_S = 32;      // samples per tile
-constexpr uint32_t WIDE_LD = WIDE + 8;   // row stride (halves) of the sample-major tiles and of the weight images: 16-byte aligned, bank-skewed
+constexpr uint32_t WIDE_LD = WIDE + 8;   // row stride (halves) of the weight images: 16-byte aligned, bank-skewed
+// Row stride of the sample-major tiles: + 16 halves where the LDS has room for it (32 inputs), + 8 otherwise.  With + 16 the 8 rows a
+// half wave touches in a transpose read start 8 banks apart (conflict-free; + 8: two-way) -- scripts/lds_bank_model.py wide: 944 ->
+// 760 modelled LDS cycles per tile and wave.  (XOR-swizzled unpadded rows model better still, 664, but the address arithmetic
+// costs more than the conflicts: measured 258 vs 223 us, profiles/r02_exp_notes.txt.)
+constexpr uint32_t wide_tile_ld(uint32_t kb_in) { return kb_in == 1 ? WIDE + 16 : WIDE + 8; }
 constexpr uint32_t WIDE_SPX = WIDE_S + 8;  // row stride of the feature-major input tile
 constexpr uint32_t WIDE_LDY = 16 + 8;
 constexpr uint32_t WIDE_THREADS = WIDE / 16 * 64;
@@ -47,15 +52,15 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
                                                                      const MlpLossArgs la, half_t* __restrict__ output, half_t* __restrict__ dL_doutput,
                                                                      half_t* __restrict__ dL_dinput, float* __restrict__ partials,
                                                                      float* __restrict__ block_sums) {
-	constexpr uint32_t NW = WIDE / 16, THREADS = WIDE_THREADS, S = WIDE_S, NT = S / 16, LD = WIDE_LD, SPX = WIDE_SPX, LDY = WIDE_LDY, NB = WIDE / 16;
+	constexpr uint32_t NW = WIDE / 16, THREADS = WIDE_THREADS, S = WIDE_S, NT = S / 16, LD = WIDE_LD, LDA = wide_tile_ld(KB_IN), SPX = WIDE_SPX, LDY = WIDE_LDY, NB = WIDE / 16;
 	constexpr uint32_t IN = 32 * KB_IN, NB_IN = IN / 16, KB = WIDE / 32;
 	static_assert(NT == 2 && NB_IN <= NW, "one 32-sample tile: two 16-sample blocks; at most one input block per wave");
 	TCNN_DYN_LDS(lds_raw);
 	half_t* wl = (half_t*)lds_raw;                  // [HM][WIDE][LD]     hidden weight matrices, natural layout
-	half_t* hT = wl + HM * WIDE * LD;               // [HM+1][S][LD]      forward activations, sample-major
-	half_t* d0 = hT + (HM + 1) * S * LD;            // [S][LD]            dL/d(pre-activation), sample-major, ping ...
-	half_t* d1 = d0 + S * LD;                       // ... pong; the idle one carries dL/dinput [IN][SPX] at the end of a tile
-	half_t* xT = d1 + S * LD;                       // [IN][SPX]          network input, feature-major (as it arrives)
+	half_t* hT = wl + HM * WIDE * LD;               // [HM+1][S][LDA]     forward activations, sample-major
+	half_t* d0 = hT + (HM + 1) * S * LDA;           // [S][LDA]           dL/d(pre-activation), sample-major, ping ...
+	half_t* d1 = d0 + S * LDA;                      // ... pong; the idle one carries dL/dinput [IN][SPX] at the end of a tile
+	half_t* xT = d1 + S * LDA;                      // [IN][SPX]          network input, feature-major (as it arrives)
 	half_t* dys = xT + IN * SPX;                    // [S][LDY]           dL/d(output pre-activation), sample-major
 
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
@@ -134,37 +139,37 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 				h4 o;
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) o[r] = (half_t)act_forward<GENERAL>(act, acc[t][r]);
-				*(h4*)(hT + (16 * t + lr) * LD + 16 * w + 4 * g) = o;  // (neurons 16w+4g.., sample 16t+lr)
+				*(h4*)(hT + (16 * t + lr) * LDA + 16 * w + 4 * g) = o;  // (neurons 16w+4g.., sample 16t+lr)
 			}
 		}
 		__syncthreads();
 #pragma unroll
 		for (uint32_t l = 1; l <= HM; ++l) {
-			const half_t* cur = hT + (l - 1) * S * LD;
+			const half_t* cur = hT + (l - 1) * S * LDA;
 			const half_t* wrow = wl + ((l - 1) * WIDE + 16 * w + lr) * LD;
 			f4 acc[NT] = {zero4(), zero4()};
 #pragma unroll
 			for (uint32_t kb = 0; kb < KB; ++kb) {
 				const h8 a = *(const h8*)(wrow + 32 * kb + 8 * g);
 #pragma unroll
-				for (uint32_t t = 0; t < NT; ++t) acc[t] = mfma_16x16x32(a, *(const h8*)(cur + (16 * t + lr) * LD + 32 * kb + 8 * g), acc[t]);
+				for (uint32_t t = 0; t < NT; ++t) acc[t] = mfma_16x16x32(a, *(const h8*)(cur + (16 * t + lr) * LDA + 32 * kb + 8 * g), acc[t]);
 			}
-			half_t* nxt = hT + l * S * LD;
+			half_t* nxt = hT + l * S * LDA;
 #pragma unroll
 			for (uint32_t t = 0; t < NT; ++t) {
 				h4 o;
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) o[r] = (half_t)act_forward<GENERAL>(act, acc[t][r]);
-				*(h4*)(nxt + (16 * t + lr) * LD + 16 * w + 4 * g) = o;
+				*(h4*)(nxt + (16 * t + lr) * LDA + 16 * w + 4 * g) = o;
 			}
 			__syncthreads();
 		}
-		const half_t* hlast = hT + HM * S * LD;
+		const half_t* hlast = hT + HM * S * LDA;
 		if (w < NT) {  // output layer + loss: (output 4g+r, sample 16w+lr)
 			const uint32_t t = w;
 			f4 acc = zero4();
 #pragma unroll
-			for (uint32_t kb = 0; kb < KB; ++kb) acc = mfma_16x16x32(wof[kb], *(const h8*)(hlast + (16 * t + lr) * LD + 32 * kb + 8 * g), acc);
+			for (uint32_t kb = 0; kb < KB; ++kb) acc = mfma_16x16x32(wof[kb], *(const h8*)(hlast + (16 * t + lr) * LDA + 32 * kb + 8 * g), acc);
 			const h4 o = h4{(half_t)act_forward<GENERAL>(out_act, acc[0]), (half_t)act_forward<GENERAL>(out_act, acc[1]), (half_t)act_forward<GENERAL>(out_act, acc[2]),
 			                (half_t)act_forward<GENERAL>(out_act, acc[3])};
 			const size_t i = (size_t)tile * S + 16 * t + lr;
@@ -192,28 +197,28 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 #pragma unroll
 		for (uint32_t t = 0; t < NT; ++t) {
 			const f4 acc = mfma_16x16x16(*(const h4*)(dys + (16 * t + lr) * LDY + 4 * g), wob, zero4());
-			const h4 hv = tr4(hlast, 16 * t + 4 * g, 16 * w, LD, lane);
+			const h4 hv = tr4(hlast, 16 * t + 4 * g, 16 * w, LDA, lane);
 #pragma unroll
 			for (uint32_t r = 0; r < 4; ++r) {
 				da[t][r] = (half_t)act_backward<GENERAL>(act, acc[r], hv[r]);
-				d0[(16 * t + 4 * g + r) * LD + 16 * w + lr] = da[t][r];
+				d0[(16 * t + 4 * g + r) * LDA + 16 * w + lr] = da[t][r];
 			}
 		}
 		if (want_grads)  // dW_out^T[neuron][o] += sum_s A_last[neuron][s] dY[o][s]; both operands transposed out of sample-major tiles
-			accO = mfma_16x16x32(tr8(hlast, 8 * g, 16 * w, LD, lane), tr8(dys, 8 * g, 0, LDY, lane), accO);
+			accO = mfma_16x16x32(tr8(hlast, 8 * g, 16 * w, LDA, lane), tr8(dys, 8 * g, 0, LDY, lane), accO);
 		__syncthreads();
 
 		half_t* cur = d0;
 		half_t* nxt = d1;
 #pragma unroll
 		for (int j = (int)HM - 1; j >= 0; --j) {
-			const half_t* hj = hT + j * S * LD;  // input activation of hidden matrix j
+			const half_t* hj = hT + j * S * LDA;  // input activation of hidden matrix j
 			const half_t* Wj = wl + j * WIDE * LD;
 			const h8 a_da = pack8(da[0], da[1]);   // k = 8g+r <-> sample 4g+r, k = 8g+4+r <-> sample 16+4g+r
 			if (want_grads) {  // dW_j[out 16w+..][in 16b+..] += sum_s dA[out][s] A_j[in][s]
 #pragma unroll
 				for (uint32_t b = 0; b < NB; ++b)
-					accH[j][b] = mfma_16x16x32(a_da, pack8(tr4(hj, 4 * g, 16 * b, LD, lane), tr4(hj, 16 + 4 * g, 16 * b, LD, lane)), accH[j][b]);
+					accH[j][b] = mfma_16x16x32(a_da, pack8(tr4(hj, 4 * g, 16 * b, LDA, lane), tr4(hj, 16 + 4 * g, 16 * b, LDA, lane)), accH[j][b]);
 			}
 			// dA_j[s][k] = sum_jj dA_{j+1}[s][jj] W_j[jj][k]: B operand = rows jj = 32kb+8g.. of column k = 16w+lr of the natural image
 			f4 acc[NT] = {zero4(), zero4()};
@@ -221,15 +226,15 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 			for (uint32_t kb = 0; kb < KB; ++kb) {
 				const h8 bw = tr8(Wj, 32 * kb + 8 * g, 16 * w, LD, lane);
 #pragma unroll
-				for (uint32_t t = 0; t < NT; ++t) acc[t] = mfma_16x16x32(*(const h8*)(cur + (16 * t + lr) * LD + 32 * kb + 8 * g), bw, acc[t]);
+				for (uint32_t t = 0; t < NT; ++t) acc[t] = mfma_16x16x32(*(const h8*)(cur + (16 * t + lr) * LDA + 32 * kb + 8 * g), bw, acc[t]);
 			}
 #pragma unroll
 			for (uint32_t t = 0; t < NT; ++t) {
-				const h4 hv = tr4(hj, 16 * t + 4 * g, 16 * w, LD, lane);
+				const h4 hv = tr4(hj, 16 * t + 4 * g, 16 * w, LDA, lane);
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
 					da[t][r] = (half_t)act_backward<GENERAL>(act, acc[t][r], hv[r]);
-					nxt[(16 * t + 4 * g + r) * LD + 16 * w + lr] = da[t][r];
+					nxt[(16 * t + 4 * g + r) * LDA + 16 * w + lr] = da[t][r];
 				}
 			}
 			__syncthreads();
@@ -252,7 +257,7 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 #pragma unroll
 				for (uint32_t kb = 0; kb < KB; ++kb) {
 #pragma unroll
-					for (uint32_t t = 0; t < NT; ++t) acc[t] = mfma_16x16x32(*(const h8*)(cur + (16 * t + lr) * LD + 32 * kb + 8 * g), wdx[kb], acc[t]);
+					for (uint32_t t = 0; t < NT; ++t) acc[t] = mfma_16x16x32(*(const h8*)(cur + (16 * t + lr) * LDA + 32 * kb + 8 * g), wdx[kb], acc[t]);
 				}
 #pragma unroll
 				for (uint32_t t = 0; t < NT; ++t)
@@ -315,7 +320,8 @@ static bool mlp_train_wide_enabled() {
 
 static uint32_t mlp_train_wide_lds_bytes(const MlpMeta& m) {
 	const uint32_t HM = m.n_hidden_matmuls;
-	return (HM * WIDE * WIDE_LD + (HM + 1) * WIDE_S * WIDE_LD + 2 * WIDE_S * WIDE_LD + m.in_width * WIDE_SPX + WIDE_S * WIDE_LDY) * (uint32_t)sizeof(half_t);
+	const uint32_t lda = wide_tile_ld(m.in_width / 32u);
+	return (HM * WIDE * WIDE_LD + (HM + 3) * WIDE_S * lda + m.in_width * WIDE_SPX + WIDE_S * WIDE_LDY) * (uint32_t)sizeof(half_t);
 }
 
 bool mlp_train_wide_supported(const MlpMeta& m, uint32_t n) {

@@ -74,7 +74,7 @@ WORKLOADS = {
 # stage (HIP-event span inside the library) -> the kernel it brackets, as it appears in the rocprofv3 kernel stats
 STAGE_KERNEL = {"grid_forward": "tcnn_hip::k_grid_forward_tiles", "mlp_forward": "tcnn_hip::k_mlp_forward", "loss": "tcnn_hip::k_loss",
                 "mlp_backward": "tcnn_hip::k_mlp_transpose_weights + k_mlp_backward + k_mlp_finalize_gradients",
-                "mlp_train_fused": "tcnn_hip::k_mlp_train_wave (or k_mlp_train) + k_mlp_finalize_gradients",
+                "mlp_train_fused": "tcnn_hip::k_mlp_train_wave (128 neurons: k_mlp_train_wide; else k_mlp_train) + k_mlp_finalize_gradients",
                 "grid_backward_scatter": "tcnn_hip::k_grid_bucket_scatter", "grid_backward": "tcnn_hip::k_grid_backward_sliced",
                 "grid_backward_overflow": "tcnn_hip::k_grid_bucket_overflow", "adam": "tcnn_hip::k_adam_step"}
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec

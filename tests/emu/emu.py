@@ -184,8 +184,10 @@ def mlp_backward(om, params_h, input_soa_h, hidden, dL_doutput_h, want_dinput=Tr
     return grads, dinput
 
 
-def mlp_train(om, params_h, input_soa_h, loss_type, target, dims, loss_scale=128.0, data_pdf=None, n_total=None, want_dinput=True):
-    """Fused forward + loss + backward (k_mlp_train).  Returns (output, dL_doutput, dL_dinput, grads, loss_sum) or None if unsupported."""
+def mlp_train(om, params_h, input_soa_h, loss_type, target, dims, loss_scale=128.0, data_pdf=None, n_total=None, want_dinput=True,
+              external_dL_doutput=None):
+    """Fused forward + loss + backward (k_mlp_train).  Returns (output, dL_doutput, dL_dinput, grads, loss_sum) or None if unsupported.
+    external_dL_doutput [n][16]: no loss, the backward half continues from the caller's gradient (target may be None)."""
     n = input_soa_h.shape[1]
     out = np.zeros((n, om.padded_out), dtype=np.uint16)
     dy = np.zeros((n, om.padded_out), dtype=np.uint16)
@@ -194,8 +196,9 @@ def mlp_train(om, params_h, input_soa_h, loss_type, target, dims, loss_scale=128
     s = np.zeros(1, dtype=np.float32)
     m = mlp_meta(om)
     r = lib().emu_mlp_train(C.byref(m), C.c_uint32(n), _p(params_h), _p(np.ascontiguousarray(input_soa_h)), C.c_int(loss_type),
-                            _p(np.ascontiguousarray(target, dtype=np.float32)), _p(data_pdf), C.c_uint32(dims), C.c_float(loss_scale),
-                            C.c_uint32(n_total if n_total is not None else n * dims), _p(out), _p(dy), _p(dinput), _p(grads), _p(s))
+                            _p(np.ascontiguousarray(target, dtype=np.float32) if target is not None else None), _p(data_pdf), C.c_uint32(dims),
+                            C.c_float(loss_scale), C.c_uint32(n_total if n_total is not None else n * dims), _p(out), _p(dy), _p(dinput), _p(grads), _p(s),
+                            _p(np.ascontiguousarray(external_dL_doutput) if external_dL_doutput is not None else None))
     if r == 2:
         return None
     assert r == 0

@@ -160,15 +160,17 @@ int emu_mlp_backward(const EmuMlp* e, uint32_t n, const uint16_t* params, const 
 // fused forward + loss + backward; returns prediction, dL_doutput, dL_dinput, grads (Overwrite) and the loss sum
 int emu_mlp_train(const EmuMlp* e, uint32_t n, const uint16_t* params, const uint16_t* input_soa, int loss_type, const float* target,
                   const float* data_pdf, uint32_t dims, float loss_scale, uint32_t n_total, uint16_t* output, uint16_t* dL_doutput,
-                  uint16_t* dL_dinput_soa, uint16_t* grads, float* loss_sum) {
+                  uint16_t* dL_dinput_soa, uint16_t* grads, float* loss_sum, const uint16_t* external_dL_doutput) {
 	try {
 		const MlpMeta m = make_mlp(e);
 		if (!mlp_train_supported(m)) return 2;
 		std::vector<uint16_t> params_t(m.n_params());
 		mlp_transpose_weights(nullptr, m, (const half_t*)params, (half_t*)params_t.data());
+		if (external_dL_doutput) loss_type = (int)LossType::L2;  // no loss is evaluated
 		const uint32_t np = mlp_train_n_partials(m, n, (LossType)loss_type);
 		std::vector<float> partials(grads ? (size_t)np * m.n_params() : 0, -12345.0f), block_sums(np, -777.0f), ws(1024);
-		const MlpLossArgs la = {(LossType)loss_type, target, data_pdf, dims, loss_scale, n_total};
+		MlpLossArgs la = {(LossType)loss_type, target, data_pdf, dims, loss_scale, n_total};
+		la.external_dL_doutput = (const half_t*)external_dL_doutput;
 		mlp_train(nullptr, m, n, (const half_t*)params, (const half_t*)params_t.data(), (const half_t*)input_soa, la, (half_t*)output,
 		          (half_t*)dL_doutput, (half_t*)dL_dinput_soa, grads ? partials.data() : nullptr, block_sums.data());
 		if (grads) mlp_finalize_gradients(nullptr, m.n_params(), np, partials.data(), (half_t*)grads, false);

@@ -274,6 +274,16 @@ def test_mlp_fused_training_pass_equals_the_unfused_kernels(case, loss_type):
     # without input gradients / without a context to fill
     out2 = emu.mlp_train(om, ph, xs, loss_type, target, OUT, data_pdf=pdf, n_total=2 * n * OUT, want_dinput=False)
     assert out2[2] is None and np.array_equal(out2[3], g_f)
+    # the backward pass of a module: no loss, dL/doutput from the caller (all 16 columns as given), forward pass recomputed
+    ext = O.f2h((rng.standard_normal((n, om.padded_out)) * 0.02).astype(np.float32))
+    out_e, _, dx_e, g_e, _ = emu.mlp_train(om, ph, xs, loss_type, None, OUT, external_dL_doutput=ext)
+    g_u, dx_u = emu.mlp_backward(om, ph, xs, hid, ext)
+    assert np.array_equal(out_e, out)
+    # random-signed gradients in all 16 columns: sums cancel, so the kernels' different fp32 association orders (and the permuted k
+    # slots of the register-resident kernel's last backward product) show up as a few fp16 steps on near-zero entries -- bars in
+    # units of the largest entry, and both as close to the oracle as each other
+    close = lambda a, b: np.mean(a != b) < 0.05 and np.abs(O.h2f(a) - O.h2f(b)).max() <= 2.0 ** -10 * np.abs(O.h2f(b)).max()
+    assert close(g_e, g_u) and close(dx_e, dx_u)
 
 
 @pytest.mark.parametrize("loss_type", range(len(O.LOSS_NAMES)))

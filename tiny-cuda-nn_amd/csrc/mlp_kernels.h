@@ -95,6 +95,10 @@ struct MlpLossArgs {
 	uint32_t dims;          // unpadded output width
 	float loss_scale;
 	uint32_t n_total;       // elements the mean runs over (global batch x dims)
+	// Not null: no loss is evaluated -- dL/doutput [n][16] comes from the caller (Trainer's external_dL_dy, trainer.h:124-128; the
+	// backward pass of a module, which RECOMPUTES the forward pass from the encoded input instead of reading saved activations:
+	// the three matrix products cost less than writing and re-reading every hidden activation).  targets / data_pdf unused.
+	const half_t* external_dL_doutput = nullptr;
 };
 bool mlp_train_supported(const MlpMeta& m);
 // The register-resident instances of the training pass (mlp_train_wave.hip): one wavefront per strip of 32 samples, for

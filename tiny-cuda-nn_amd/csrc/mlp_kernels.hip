@@ -677,7 +677,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, WIDTH == 128 ? 1 : TCNN_MLP_T
 #pragma unroll
 			for (uint32_t r = 0; r < 4; ++r) {
 				const uint32_t dim = 4 * g + r;
-				const bool live = t < NT && dim < la.dims;
+				const bool live = t < NT && dim < la.dims && !la.external_dL_doutput;
 				const size_t target_idx = ((size_t)tile * S + 16 * t + lr) * la.dims + dim;
 				tgt[q][r] = live ? la.targets[target_idx] : 0.0f;
 				pdf[q][r] = live && la.data_pdf ? la.data_pdf[target_idx] : 1.0f;
@@ -757,14 +757,18 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, WIDTH == 128 ? 1 : TCNN_MLP_T
 				                (half_t)act_forward<GENERAL>(out_act, acc[3])};
 				const size_t i = (size_t)tile * S + 16 * t + lr;
 				h4 gy;
+				if (la.external_dL_doutput) {
+					gy = *(const h4*)(la.external_dL_doutput + i * 16 + 4 * g);
+				} else {
 #pragma unroll
-				for (uint32_t r = 0; r < 4; ++r) {
-					const uint32_t dim = 4 * g + r;
-					gy[r] = (half_t)0.0f;
-					if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
-						float value;
-						gy[r] = loss_element<GENERAL>(la.type, (float)o[r], tgt[q][r], pdf[q][r], n_total, la.loss_scale, value);
-						loss_sum += value;
+					for (uint32_t r = 0; r < 4; ++r) {
+						const uint32_t dim = 4 * g + r;
+						gy[r] = (half_t)0.0f;
+						if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
+							float value;
+							gy[r] = loss_element<GENERAL>(la.type, (float)o[r], tgt[q][r], pdf[q][r], n_total, la.loss_scale, value);
+							loss_sum += value;
+						}
 					}
 				}
 				if (output) *(h4*)(output + i * 16 + 4 * g) = o;
@@ -1153,7 +1157,7 @@ static void launch_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const
                          const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
 	const uint32_t lds_bytes = mlp_train_lds_bytes(m);
 	const uint32_t blocks = mlp_backward_n_partials(m, n);
-	if (!act_is_simple(m.activation) || !act_is_simple(m.output_activation) || !loss_is_simple(la.type)) {
+	if (!act_is_simple(m.activation) || !act_is_simple(m.output_activation) || !(la.external_dL_doutput || loss_is_simple(la.type))) {
 		TCNN_SET_MAX_DYN_LDS((k_mlp_train<WIDTH, HM, true>), lds_bytes);
 		TCNN_LAUNCH((k_mlp_train<WIDTH, HM, true>), dim3(blocks), dim3(WIDTH / 16 * 64), lds_bytes, stream, m, n, params, params_t, input, la, output,
 		            dL_doutput, dL_dinput, partials, block_sums);
@@ -1194,8 +1198,8 @@ void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* p
 	check_meta(m, n);
 	if (n == 0) return;
 	if (!mlp_train_supported(m)) throw std::runtime_error("mlp_train: unsupported network shape (check mlp_train_supported first)");
-	if (!loss_is_elementwise(la.type)) throw std::runtime_error("mlp_train: this loss needs whole output rows; use the stand-alone loss kernel");
-	if (mlp_train_wave_supported(m, n, la.type)) {
+	if (!la.external_dL_doutput && !loss_is_elementwise(la.type)) throw std::runtime_error("mlp_train: this loss needs whole output rows; use the stand-alone loss kernel");
+	if (mlp_train_wave_supported(m, n, la.external_dL_doutput ? LossType::L2 : la.type)) {
 		mlp_train_wave(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums);
 		return;
 	}

@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
 #pragma unroll
 			for (uint32_t r = 0; r < 4; ++r) {
 				const uint32_t dim = 4 * r + g;
-				const bool live = dim < la.dims;
+				const bool live = dim < la.dims && !la.external_dL_doutput;
 				const uint32_t target_idx = (base + perm32(s, lr)) * la.dims + dim;
 				tgt[s][r] = live ? la.targets[target_idx] : 0.0f;
 			}
@@ -273,16 +273,21 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
 			                (half_t)act_forward<GENERAL>(out_act, acc[3])};
 			const uint32_t i = base + perm32(s, lr);
 			h4 gy;
+			if (la.external_dL_doutput) {
 #pragma unroll
-			for (uint32_t r = 0; r < 4; ++r) {
-				const uint32_t dim = 4 * r + g;
-				gy[r] = (half_t)0.0f;
-				if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
-					const float pdf = has_pdf ? la.data_pdf[i * la.dims + dim] : 1.0f;  // rare: fetched where it is used
-					float value;
-					if constexpr (GENERAL) gy[r] = loss_element<true>(la.type, (float)o[r], tgt[s][r], pdf, n_total, la.loss_scale, value);
-					else gy[r] = loss_gradient_simple(relative, has_pdf, (float)o[r], tgt[s][r], pdf, n_total, inv_n_total, la.loss_scale, value);
-					loss_sum += value;
+				for (uint32_t r = 0; r < 4; ++r) gy[r] = la.external_dL_doutput[i * 16 + 4 * r + g];
+			} else {
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) {
+					const uint32_t dim = 4 * r + g;
+					gy[r] = (half_t)0.0f;
+					if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
+						const float pdf = has_pdf ? la.data_pdf[i * la.dims + dim] : 1.0f;  // rare: fetched where it is used
+						float value;
+						if constexpr (GENERAL) gy[r] = loss_element<true>(la.type, (float)o[r], tgt[s][r], pdf, n_total, la.loss_scale, value);
+						else gy[r] = loss_gradient_simple(relative, has_pdf, (float)o[r], tgt[s][r], pdf, n_total, inv_n_total, la.loss_scale, value);
+						loss_sum += value;
+					}
 				}
 			}
 #pragma unroll
@@ -558,7 +563,7 @@ static void launch_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, 
 
 void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
                     const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
-	if (!mlp_train_wave_supported(m, n, la.type)) throw std::runtime_error("mlp_train_wave: unsupported shape, activation or loss (check mlp_train_wave_supported first)");
+	if (!mlp_train_wave_supported(m, n, la.external_dL_doutput ? LossType::L2 : la.type)) throw std::runtime_error("mlp_train_wave: unsupported shape, activation or loss (check mlp_train_wave_supported first)");
 	const uint32_t key = (m.in_width == 64 ? 10000u : 0u) + m.width * 10u + m.n_hidden_matmuls;
 	switch (key) {
 		case 10640: launch_train_wave<64, 64, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;

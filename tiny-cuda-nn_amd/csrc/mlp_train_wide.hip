@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 #pragma unroll
 		for (uint32_t r = 0; r < 4; ++r) {
 			const uint32_t dim = 4 * g + r;
-			const bool live = w < NT && dim < la.dims;
+			const bool live = w < NT && dim < la.dims && !la.external_dL_doutput;
 			const size_t target_idx = ((size_t)tile * S + 16 * w + lr) * la.dims + dim;
 			tgt[r] = live ? la.targets[target_idx] : 0.0f;
 			pdf[r] = live && la.data_pdf ? la.data_pdf[target_idx] : 1.0f;
@@ -174,14 +174,18 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 			                (half_t)act_forward<GENERAL>(out_act, acc[3])};
 			const size_t i = (size_t)tile * S + 16 * t + lr;
 			h4 gy;
+			if (la.external_dL_doutput) {
+				gy = *(const h4*)(la.external_dL_doutput + i * 16 + 4 * g);
+			} else {
 #pragma unroll
-			for (uint32_t r = 0; r < 4; ++r) {
-				const uint32_t dim = 4 * g + r;
-				gy[r] = (half_t)0.0f;
-				if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
-					float value;
-					gy[r] = loss_element<GENERAL>(la.type, (float)o[r], tgt[r], pdf[r], n_total, la.loss_scale, value);
-					loss_sum += value;
+				for (uint32_t r = 0; r < 4; ++r) {
+					const uint32_t dim = 4 * g + r;
+					gy[r] = (half_t)0.0f;
+					if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
+						float value;
+						gy[r] = loss_element<GENERAL>(la.type, (float)o[r], tgt[r], pdf[r], n_total, la.loss_scale, value);
+						loss_sum += value;
+					}
 				}
 			}
 			if (output) *(h4*)(output + i * 16 + 4 * g) = o;
@@ -342,7 +346,7 @@ static void launch_train_wide(hipStream_t stream, const MlpMeta& m, uint32_t n, 
                               const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
 	const uint32_t lds_bytes = mlp_train_wide_lds_bytes(m);
 	const uint32_t blocks = mlp_train_wide_n_partials(n);
-	if (!act_is_simple(m.activation) || !act_is_simple(m.output_activation) || !loss_is_simple(la.type)) {
+	if (!act_is_simple(m.activation) || !act_is_simple(m.output_activation) || !(la.external_dL_doutput || loss_is_simple(la.type))) {
 		TCNN_SET_MAX_DYN_LDS((k_mlp_train_wide<HM, KB_IN, true>), lds_bytes);
 		TCNN_LAUNCH((k_mlp_train_wide<HM, KB_IN, true>), dim3(blocks), dim3(WIDE_THREADS), lds_bytes, stream, m, n, params, params_t, input, la, output,
 		            dL_doutput, dL_dinput, partials, block_sums);

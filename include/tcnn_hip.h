@@ -216,6 +216,13 @@ int tcnn_trainer_get_stage_times(tcnn_trainable_model_t* tm, double* total_ms, u
  * arithmetic and results, bit for bit, as backward followed by optimizer_step.  Off by default (measured no faster: the
  * owner pass's own queue streaming leaves the optimizer's traffic nothing to hide behind); 1 turns it on. */
 int tcnn_trainer_set_fused_optimizer(tcnn_trainable_model_t* tm, int enable);
+/* Process-wide (default 1; TCNN_FUSED_MLP_TRAINING=0 in the environment starts with 0): training_step runs the network's forward +
+ * loss + backward as one kernel, and forward() / backward() -- of a Trainer and of a module -- keep only the encoded input in
+ * the context: the backward pass recomputes the hidden activations inside the same kernel instead of reading saved ones.
+ * 0: separate forward (saving activations), loss and backward kernels.  Same results; contexts made under one setting must be
+ * consumed under the same setting. */
+int tcnn_get_fused_network_passes(void);
+int tcnn_set_fused_network_passes(int enable);
 /* Tuning knob: bytes of LDS one grid-backward workgroup uses for the table slice it owns (default 64 KiB). */
 int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes);
 /* Grid backward formulation, process-wide: 0 = owner-computes LDS slices with fp32 accumulation on hashed levels,

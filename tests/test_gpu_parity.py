@@ -395,8 +395,12 @@ def test_wide_network_fused_training_step(hidden_layers, n_features, out, act, o
     loss_f = tm.loss(ctx)
     out_f, dy_f, g_f = h_np(ctx.output), h_np(ctx.dL_doutput), h_np(tm.param_gradients).copy()
     dx_u = torch.zeros((n, 3), device="cuda")
-    ctx_u = tm.forward(x, t, prepare_input_gradients=True)
-    tm.backward(ctx_u, x, dL_dinput=dx_u)
+    T._C.set_fused_network_passes(False)  # forward() saves the activations, backward() is k_mlp_backward
+    try:
+        ctx_u = tm.forward(x, t, prepare_input_gradients=True)
+        tm.backward(ctx_u, x, dL_dinput=dx_u)
+    finally:
+        T._C.set_fused_network_passes(True)
     g_u = h_np(tm.param_gradients)
     assert np.array_equal(out_f, h_np(ctx_u.output)) and np.array_equal(dy_f, h_np(ctx_u.dL_doutput))
     assert abs(loss_f - tm.loss(ctx_u)) <= 1e-5 * abs(loss_f)
@@ -422,6 +426,52 @@ def test_wide_network_fused_training_step(hidden_layers, n_features, out, act, o
     assert np.percentile(rae(g[:nm], gref[:nm]), 99) < 5e-3
     big = np.abs(gref[nm:]) > 1e-2 * np.abs(gref[nm:]).max()
     assert np.percentile(rae(g[nm:][big], gref[nm:][big]), 99) < 3e-2
+
+
+@pytest.mark.parametrize("width,hidden_layers,n_features,out,act,out_act", [
+    (64, 2, 2, 4, "ReLU", "None"),          # headline network: register-resident kernel
+    (64, 3, 2, 16, "ReLU", "None"),         # workgroup-tiled kernel
+    (128, 4, 2, 16, "ReLU", "None"),        # LDS-resident weights
+    (64, 2, 4, 3, "Tanh", "Sigmoid"),       # 64 inputs, out-of-line activations, output activation transfer inside the kernel
+    (32, 4, 2, 5, "LeakyReLU", "None"),
+])
+def test_backward_recomputing_the_forward_pass_matches_saved_activations(width, hidden_layers, n_features, out, act, out_act):
+    """Module forward + backward (what the PyTorch binding runs): with single-kernel network passes the context keeps the encoded
+    input only and the backward kernel recomputes the activations; against the path that saves them and runs k_mlp_backward."""
+    T = tcnn()
+    C = T._C
+    enc = dict(HASH_ENCODING_SMALL, n_features_per_level=n_features)
+    net = dict(MLP_64x2, n_neurons=width, n_hidden_layers=hidden_layers, activation=act, output_activation=out_act)
+    m = C.create_network_with_input_encoding(3, out, enc, net)
+    p32 = m.initial_params(1337)
+    nm = m.n_params() - oracle_grid(enc, 3).n_params
+    p32[nm:] *= 3.0e3
+    n = 1 << 15
+    x = torch.from_numpy(positions(n, 3, seed=5)).cuda().requires_grad_(True)  # input gradients too
+    rng = np.random.default_rng(9)
+    dy = np.zeros((n, 16), np.float32)
+    dy[:, :out] = rng.standard_normal((n, out)).astype(np.float32) * 0.05
+    dyh = h_t(O.f2h(dy))
+    results = []
+    for fused in (True, False):
+        C.set_fused_network_passes(fused)
+        try:
+            p = p32.half().cuda().requires_grad_(True)
+            ctx, y = m.fwd(x, p)
+            dx, dp = m.bwd(ctx, x, p, y, dyh)
+            torch.cuda.synchronize()
+            results.append((h_np(y), None if dx is None else dx.float().cpu().numpy(), h_np(dp)))
+        finally:
+            C.set_fused_network_passes(True)
+    (y_f, dx_f, g_f), (y_u, dx_u, g_u) = results
+    assert np.array_equal(y_f, y_u)
+    close = lambda a, b: np.abs(O.h2f(a) - O.h2f(b)).max() <= 2.0 ** -9 * np.abs(O.h2f(b)).max()
+    assert np.isfinite(O.h2f(g_f)).all() and np.abs(O.h2f(g_f[:nm])).max() > 0
+    assert np.mean(g_f[:nm] != g_u[:nm]) < 0.05 and close(g_f[:nm], g_u[:nm])
+    ge_f, ge_u = O.h2f(g_f[nm:]), O.h2f(g_u[nm:])
+    assert np.allclose(ge_f, ge_u, rtol=2e-2, atol=2e-3 * np.abs(ge_u).max())
+    if dx_f is not None:
+        assert np.allclose(dx_f, dx_u, rtol=1e-2, atol=1e-3 * np.abs(dx_u).max())
 
 
 @pytest.mark.parametrize("loss", ["RelativeL2", "L2", "L1", "RelativeL1", "Mape", "Smape", "RelativeL2Luminance"])

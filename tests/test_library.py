@@ -142,3 +142,26 @@ int caller(hipStream_t stream, json config, GPUMatrixDynamic<float>& in, GPUMatr
     cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-D__HIP_PLATFORM_AMD__", *json_flag, "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", str(src)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_register_resident_kernels_do_not_spill(tmp_path):
+    """k_mlp_train_wave / k_mlp_infer_wave are written to the register limit (254 of 256 for the headline instance) and pin values
+    with empty asm statements: an instance that spills has produced wrong results on the GPU (profiles/r02_exp_notes.txt).  The
+    compiler's resource report of every instance must show no spill and no scratch."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "tiny-cuda-nn_amd", "csrc", "mlp_train_wave.hip")
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "--cuda-device-only",
+                        "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(tmp_path / "wave.o")], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    report = r.stderr
+    names = re.findall(r"Function Name: (\S+)", report)
+    spills = [int(v) for v in re.findall(r"VGPRs Spill: (\d+)", report)]
+    scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", report)]
+    assert len(names) >= 12 and len(names) == len(spills) == len(scratch)
+    bad = [(n, s, b) for n, s, b in zip(names, spills, scratch) if ("k_mlp_train_wave" in n or "k_mlp_infer_wave" in n) and (s or b)]
+    assert not bad, bad

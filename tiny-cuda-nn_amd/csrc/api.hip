@@ -654,6 +654,15 @@ static void encoding_forward(hipStream_t stream, const Model& md, uint32_t n, co
 	}
 }
 
+// Single-kernel network passes (process-wide; TCNN_FUSED_MLP_TRAINING=0 or tcnn_set_fused_network_passes(0) turn them off):
+//   * training_step: encoding forward, ONE kernel for the network's forward + loss + backward, encoding backward;
+//   * forward() + backward() (Trainer and modules): the forward pass saves only the encoded input; the backward pass runs the same
+//     kernel with the caller's dL/doutput in place of the loss -- it RECOMPUTES the hidden activations (three small matrix products)
+//     instead of reading back what the forward pass would have had to write (2 B x width x layers per sample each way).
+// Off: k_mlp_forward (saves the activations) -> k_loss -> k_mlp_backward.  Same results either way (tests/test_emu_kernels.py).
+static std::atomic<int> g_fused_network_passes{!(getenv("TCNN_FUSED_MLP_TRAINING") && std::string(getenv("TCNN_FUSED_MLP_TRAINING")) == "0") ? 1 : 0};
+static bool backward_recomputes(const Model& md) { return g_fused_network_passes.load() != 0 && md.has_network && mlp_train_supported(md.net.mlp); }
+
 // NetworkWithInputEncoding::forward_impl / inference_mixed_precision_impl (:60-81).  ctx == nullptr: inference.
 static void model_forward(hipStream_t stream, const Model& md, uint32_t n, const float* input, half_t* output, const half_t* params,
                           ForwardCtx* ctx, bool prepare_input_gradients) {
@@ -677,7 +686,7 @@ static void model_forward(hipStream_t stream, const Model& md, uint32_t n, const
 	enc = Scratch(stream, (size_t)md.enc.padded_output_width * n * sizeof(half_t));
 	encoding_forward(stream, md, n, input, params + md.n_mlp_params(), enc.as<half_t>(), /*soa=*/true, dy_dx);
 	half_t* hidden = nullptr;
-	if (ctx) {
+	if (ctx && !backward_recomputes(md)) {
 		ctx->hidden = Scratch(stream, (size_t)md.net.n_hidden_layers * n * md.net.mlp.width * sizeof(half_t));
 		hidden = ctx->hidden.as<half_t>();
 	}
@@ -702,8 +711,9 @@ static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx
 	check_batch(n, widest_matrix(md));
 	if (n == 0) return;
 	if (ctx.n != n) throw std::runtime_error("backward: batch size does not match the forward context");
-	if (md.has_network && !ctx.hidden.ptr) {
-		throw std::runtime_error("backward: this context comes from the fused training_step and holds no saved activations; use forward() + backward()");
+	const bool recompute = md.has_network && !ctx.hidden.ptr;  // the context holds the encoded input only (see g_fused_network_passes)
+	if (recompute && (!ctx.enc.ptr || !mlp_train_supported(md.net.mlp))) {
+		throw std::runtime_error("backward: this context holds no saved activations and the network has no single-kernel backward pass");
 	}
 	const bool want_grads = gradient_mode != TCNN_GRADIENT_IGNORE && dL_dparams != nullptr;
 	const bool accumulate = gradient_mode == TCNN_GRADIENT_ACCUMULATE;
@@ -718,10 +728,23 @@ static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx
 		ProfScope prof(stream, STAGE_MLP_BWD);
 		Scratch params_t(stream, md.n_mlp_params() * sizeof(half_t));
 		mlp_transpose_weights(stream, md.net.mlp, params, params_t.as<half_t>());
-		const uint32_t n_partials = mlp_backward_n_partials(md.net.mlp, n);
+		const uint32_t n_partials = recompute ? mlp_train_n_partials(md.net.mlp, n, LossType::L2) : mlp_backward_n_partials(md.net.mlp, n);
 		Scratch partials;
 		if (want_grads) partials = Scratch(stream, (size_t)n_partials * md.n_mlp_params() * sizeof(float));
 		if (need_denc) denc = Scratch(stream, (size_t)e.padded_output_width * n * sizeof(half_t));
+		if (recompute) {  // forward from the encoded input again, then backward from the caller's dL/doutput, in one kernel
+			MlpLossArgs la = {LossType::L2, nullptr, nullptr, md.output_width(), 1.0f, 1u};
+			la.external_dL_doutput = dL_doutput;
+			mlp_train(stream, md.net.mlp, n, params, params_t.as<half_t>(), ctx.enc.as<half_t>(), la, nullptr, nullptr, need_denc ? denc.as<half_t>() : nullptr,
+			          want_grads ? partials.as<float>() : nullptr, nullptr);
+			if (want_grads) mlp_finalize_gradients(stream, (uint32_t)md.n_mlp_params(), n_partials, partials.as<float>(), dL_dparams, accumulate);
+			if (!need_denc) return;
+			dL_denc = denc.as<half_t>();
+			stride_k = n;
+			stride_i = 1u;
+			encoding_backward(stream, md, ctx, n, dL_dinput, dL_denc, stride_k, stride_i, dL_dparams, want_grads, accumulate, input, lds_level_budget);
+			return;
+		}
 		Scratch dpre;  // output activation: continue from dL/d(pre-activation) (fully_fused_mlp.cu:760-763)
 		if (md.net.mlp.output_activation != (uint32_t)Activation::None) {
 			if (!output) throw std::runtime_error("backward: the network output is required when an output activation is set");
@@ -1480,11 +1503,9 @@ void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* s
 	return which == 0 ? (void*)tm->m1 : which == 1 ? (void*)tm->m2 : which == 2 ? (void*)tm->steps : nullptr;
 }
 
-// training_step fast path: encoding forward, ONE kernel for the network's forward + loss + backward, encoding backward.
-// Same results as forward() + backward() (bit-identical, tests/test_emu_kernels.py); the returned context carries the
-// prediction, dL_doutput and the loss, but no hidden activations.  TCNN_FUSED_MLP_TRAINING=0 disables it.
-static const bool g_fused_mlp_training = !(getenv("TCNN_FUSED_MLP_TRAINING") && std::string(getenv("TCNN_FUSED_MLP_TRAINING")) == "0");
-
+// training_step fast path (g_fused_network_passes): encoding forward, ONE kernel for the network's forward + loss + backward, encoding
+// backward.  Same results as forward() + backward() (tests/test_emu_kernels.py); the returned context carries the
+// prediction, dL_doutput, the loss and the encoded input, but no hidden activations.
 static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale, uint32_t n, const float* input, const float* target,
                                const float* data_pdf, float* dL_dinput, int use_inference_params, int gradient_mode, bool run_optimizer,
                                tcnn_train_context_t** ctx_out) {
@@ -1595,7 +1616,7 @@ int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
 	const float loss_scale = LOSS_SCALE_FP16;  // trainer.h:265
 	tm->last_batch = n;
 	tcnn_train_context_t* ctx = nullptr;
-	if (g_fused_mlp_training && !external_dL_dy && target && tm->md.has_network && mlp_train_supported(tm->md.net.mlp) && loss_is_elementwise(tm->loss)) {
+	if (g_fused_network_passes.load() && !external_dL_dy && target && tm->md.has_network && mlp_train_supported(tm->md.net.mlp) && loss_is_elementwise(tm->loss)) {
 		int r = training_step_fused(tm, (hipStream_t)stream, loss_scale, n, input, target, data_pdf, dL_dinput, use_inference_params, gradient_mode,
 		                            run_optimizer != 0, &ctx);
 		if (ctx_out && r == TCNN_OK) {
@@ -1893,6 +1914,11 @@ int tcnn_trainer_set_fused_optimizer(tcnn_trainable_model_t* tm, int enable) {
 }
 int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes) {
 	tm->lds_level_budget = bytes;
+	return TCNN_OK;
+}
+int tcnn_get_fused_network_passes(void) { return g_fused_network_passes.load(); }
+int tcnn_set_fused_network_passes(int enable) {
+	g_fused_network_passes.store(enable != 0 ? 1 : 0);
 	return TCNN_OK;
 }
 int tcnn_get_grid_backward_mode(void) { return g_grid_backward_mode.load(); }

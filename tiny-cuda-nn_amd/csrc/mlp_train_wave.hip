@@ -104,7 +104,9 @@ TCNN_DEVICE half_t loss_gradient_simple(bool relative, bool has_pdf, float predi
 #endif
 constexpr uint32_t MLP_WAVE_STRIP = 32, MLP_WAVE_THREADS = 256;
 
-template <uint32_t WIDTH, uint32_t IN, uint32_t HM, bool GENERAL>
+// EXTERNAL: no loss -- dL/doutput comes from la.external_dL_doutput (the backward pass of a module recomputing its forward pass).  A
+// compile-time switch: the loss instance is at the register limit (254), a run-time branch around the loss spills.
+template <uint32_t WIDTH, uint32_t IN, uint32_t HM, bool GENERAL, bool EXTERNAL>
 __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_mlp_train_wave(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
                                                                         const half_t* __restrict__ params_t, const half_t* __restrict__ input,
                                                                         const MlpLossArgs la, half_t* __restrict__ output, half_t* __restrict__ dL_doutput,
@@ -220,7 +222,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
 #pragma unroll
 			for (uint32_t r = 0; r < 4; ++r) {
 				const uint32_t dim = 4 * r + g;
-				const bool live = dim < la.dims && !la.external_dL_doutput;
+				const bool live = !EXTERNAL && dim < la.dims;
 				const uint32_t target_idx = (base + perm32(s, lr)) * la.dims + dim;
 				tgt[s][r] = live ? la.targets[target_idx] : 0.0f;
 			}
@@ -273,7 +275,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
 			                (half_t)act_forward<GENERAL>(out_act, acc[3])};
 			const uint32_t i = base + perm32(s, lr);
 			h4 gy;
-			if (la.external_dL_doutput) {
+			if constexpr (EXTERNAL) {
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) gy[r] = la.external_dL_doutput[i * 16 + 4 * r + g];
 			} else {
@@ -557,8 +559,13 @@ template <uint32_t WIDTH, uint32_t IN, uint32_t HM>
 static void launch_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
                               const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
 	const uint32_t blocks = mlp_train_wave_n_partials(n);
-	TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la, output,
-	            dL_doutput, dL_dinput, partials, block_sums);
+	if (la.external_dL_doutput) {
+		TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, true>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la, output,
+		            dL_doutput, dL_dinput, partials, block_sums);
+	} else {
+		TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, false>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la, output,
+		            dL_doutput, dL_dinput, partials, block_sums);
+	}
 }
 
 void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,

@@ -129,6 +129,8 @@ _sig("tcnn_trainer_stage_name", _cp, _i)
 _sig("tcnn_trainer_get_stage_times", _i, _vp, _vp, _vp)
 _sig("tcnn_trainer_set_lds_level_budget", _i, _vp, _u32)
 _sig("tcnn_trainer_set_fused_optimizer", _i, _vp, _i)
+_sig("tcnn_get_fused_network_passes", _i)
+_sig("tcnn_set_fused_network_passes", _i, _i)
 _sig("tcnn_set_grid_backward_mode", _i, _i)
 _sig("tcnn_get_grid_backward_mode", _i)
 
@@ -176,6 +178,15 @@ def get_grid_backward_mode():
 def set_grid_backward_mode(mode):
     """0: owner-computes LDS slices (fp32 accumulate, default); 1: same, packed fp16; 2: global atomics (A/B)."""
     _check(_lib.tcnn_set_grid_backward_mode(int(mode)))
+
+
+def get_fused_network_passes():
+    return bool(_lib.tcnn_get_fused_network_passes())
+
+
+def set_fused_network_passes(enable):
+    """Process-wide: single-kernel network passes (training_step; backward recomputing the activations) on / off."""
+    _check(_lib.tcnn_set_fused_network_passes(int(bool(enable))))
 
 
 def rtc_set_cache_dir(_dir):  # no runtime compilation in this build

@@ -155,13 +155,14 @@ def test_register_resident_kernels_do_not_spill(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
     src = os.path.join(ROOT, "tiny-cuda-nn_amd", "csrc", "mlp_train_wave.hip")
-    r = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "--cuda-device-only",
-                        "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(tmp_path / "wave.o")], capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, r.stderr[-2000:]
-    report = r.stderr
-    names = re.findall(r"Function Name: (\S+)", report)
-    spills = [int(v) for v in re.findall(r"VGPRs Spill: (\d+)", report)]
-    scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", report)]
-    assert len(names) >= 12 and len(names) == len(spills) == len(scratch)
-    bad = [(n, s, b) for n, s, b in zip(names, spills, scratch) if ("k_mlp_train_wave" in n or "k_mlp_infer_wave" in n) and (s or b)]
-    assert not bad, bad
+    for build in ([], ["-DTCNN_BF16"]):  # libtcnn_hip.so and libtcnn_hip_bf16.so
+        r = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "--cuda-device-only", *build,
+                            "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(tmp_path / "wave.o")], capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        report = r.stderr
+        names = re.findall(r"Function Name: (\S+)", report)
+        spills = [int(v) for v in re.findall(r"VGPRs Spill: (\d+)", report)]
+        scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", report)]
+        assert len(names) >= 12 and len(names) == len(spills) == len(scratch)
+        bad = [(n, s, b) for n, s, b in zip(names, spills, scratch) if ("k_mlp_train_wave" in n or "k_mlp_infer_wave" in n) and (s or b)]
+        assert not bad, (build, bad)

@@ -434,6 +434,11 @@ def test_wide_network_fused_training_step(hidden_layers, n_features, out, act, o
     (128, 4, 2, 16, "ReLU", "None"),        # LDS-resident weights
     (64, 2, 4, 3, "Tanh", "Sigmoid"),       # 64 inputs, out-of-line activations, output activation transfer inside the kernel
     (32, 4, 2, 5, "LeakyReLU", "None"),
+    # instances whose register allocation spills (k_mlp_train<64, 3>, k_mlp_train_wide<3, 1, general>): the resource report is not
+    # a proof of anything either way -- results are
+    (64, 4, 2, 4, "ReLU", "None"),
+    (64, 4, 2, 4, "Tanh", "None"),
+    (128, 4, 2, 16, "LeakyReLU", "Softplus"),
 ])
 def test_backward_recomputing_the_forward_pass_matches_saved_activations(width, hidden_layers, n_features, out, act, out_act):
     """Module forward + backward (what the PyTorch binding runs): with single-kernel network passes the context keeps the encoded

@@ -182,7 +182,7 @@ def test_training_step_data_pdf_external_gradient_and_input_gradient():
     ctx0 = tm.training_step(x, t, run_optimizer=False)
     assert not np.array_equal(h_np(ctx0.dL_doutput), g_loss)
 
-    # ---- external_dL_dy (forward + backward path; the loss is not evaluated, trainer.h:124-128)
+    # ---- external_dL_dy (the loss is not evaluated, trainer.h:124-128; the fused network kernel continues from the caller's gradient)
     ext = O.f2h(O.h2f(g_loss) * 0.5 + 0.25 * (O.h2f(g_loss) != 0))
     st = O.TrainState(md, init)
     dx_ref = np.zeros((n, 3), np.float32)

@@ -1508,7 +1508,7 @@ void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* s
 // prediction, dL_doutput, the loss and the encoded input, but no hidden activations.
 static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale, uint32_t n, const float* input, const float* target,
                                const float* data_pdf, float* dL_dinput, int use_inference_params, int gradient_mode, bool run_optimizer,
-                               tcnn_train_context_t** ctx_out) {
+                               const half_t* external_dL_dy, tcnn_train_context_t** ctx_out) {
 	TCNN_API_BEGIN
 	const half_t* params = use_inference_params ? tm->inference_params() : tm->params;
 	ProfilerGuard pg(tm->profiler.get());
@@ -1525,8 +1525,12 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 	const bool accumulate = gradient_mode == TCNN_GRADIENT_ACCUMULATE;
 	const EncodingDesc& e = md.enc;
 	c->output = Scratch(stream, (size_t)padded * n * sizeof(half_t));
-	c->dL_doutput = Scratch(stream, (size_t)padded * n * sizeof(half_t));
-	c->dL_doutput_ptr = c->dL_doutput.as<half_t>();
+	if (external_dL_dy) {  // trainer.h:124-128: no loss is evaluated, the backward half continues from the caller's gradient
+		c->dL_doutput_ptr = external_dL_dy;
+	} else {
+		c->dL_doutput = Scratch(stream, (size_t)padded * n * sizeof(half_t));
+		c->dL_doutput_ptr = c->dL_doutput.as<half_t>();
+	}
 	const uint64_t n_total = (tm->global_batch ? tm->global_batch : (uint64_t)n) * md.output_width();
 	if (n_total > 0xFFFFFFFFull) throw std::runtime_error("Trainer::forward: batch too large");
 	if (n == 0) {
@@ -1549,15 +1553,18 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 		ProfScope prof(stream, STAGE_MLP_TRAIN);
 		Scratch params_t_local;
 		const half_t* params_t = trainer_params_t(tm, stream, params, params_t_local);
-		const uint32_t n_partials = mlp_train_n_partials(md.net.mlp, n, tm->loss);
+		const uint32_t n_partials = mlp_train_n_partials(md.net.mlp, n, external_dL_dy ? LossType::L2 : tm->loss);
 		Scratch partials;
 		if (want_grads) partials = Scratch(stream, (size_t)n_partials * md.n_mlp_params() * sizeof(float));
 		if (need_denc) denc = Scratch(stream, (size_t)e.padded_output_width * n * sizeof(half_t));
-		c->n_block_sums = n_partials;
-		c->block_sums = Scratch(stream, (size_t)n_partials * sizeof(float));
-		const MlpLossArgs la = {tm->loss, target, data_pdf, md.output_width(), loss_scale, (uint32_t)n_total};
-		mlp_train(stream, md.net.mlp, n, params, params_t, fc.enc.as<half_t>(), la, c->output.as<half_t>(), c->dL_doutput.as<half_t>(),
-		          need_denc ? denc.as<half_t>() : nullptr, want_grads ? partials.as<float>() : nullptr, c->block_sums.as<float>());
+		MlpLossArgs la = {tm->loss, target, data_pdf, md.output_width(), loss_scale, (uint32_t)n_total};
+		la.external_dL_doutput = external_dL_dy;
+		if (!external_dL_dy) {  // Trainer::loss(ctx) has something to reduce
+			c->n_block_sums = n_partials;
+			c->block_sums = Scratch(stream, (size_t)n_partials * sizeof(float));
+		}
+		mlp_train(stream, md.net.mlp, n, params, params_t, fc.enc.as<half_t>(), la, c->output.as<half_t>(), external_dL_dy ? nullptr : c->dL_doutput.as<half_t>(),
+		          need_denc ? denc.as<half_t>() : nullptr, want_grads ? partials.as<float>() : nullptr, external_dL_dy ? nullptr : c->block_sums.as<float>());
 		if (want_grads) mlp_finalize_gradients(stream, (uint32_t)md.n_mlp_params(), n_partials, partials.as<float>(), tm->grads, accumulate);
 	}
 	// The optimizer step of the bucketed levels happens inside the grid backward (GridFusedAdam) when this call owns the whole
@@ -1616,9 +1623,9 @@ int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
 	const float loss_scale = LOSS_SCALE_FP16;  // trainer.h:265
 	tm->last_batch = n;
 	tcnn_train_context_t* ctx = nullptr;
-	if (g_fused_network_passes.load() && !external_dL_dy && target && tm->md.has_network && mlp_train_supported(tm->md.net.mlp) && loss_is_elementwise(tm->loss)) {
+	if (g_fused_network_passes.load() && tm->md.has_network && mlp_train_supported(tm->md.net.mlp) && (external_dL_dy || (target && loss_is_elementwise(tm->loss)))) {
 		int r = training_step_fused(tm, (hipStream_t)stream, loss_scale, n, input, target, data_pdf, dL_dinput, use_inference_params, gradient_mode,
-		                            run_optimizer != 0, &ctx);
+		                            run_optimizer != 0, (const half_t*)external_dL_dy, &ctx);
 		if (ctx_out && r == TCNN_OK) {
 			*ctx_out = ctx;
 		} else {

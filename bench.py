@@ -134,10 +134,15 @@ def make_batches(w, n, n_batches, seed, device, tcnn):
     """Synthetic regression data: U[0,1)^n_in positions from the library's pcg32 kernel (random.h:39-75, seed 1337 + rank), smooth
     analytic targets; the `mlp` workload regresses against zero (benchmarks/mlp: L2 vs zero target)."""
     rng = tcnn._C.Pcg32(seed)
+    # under the checking allocator (TCNN_DEBUG_ALLOC) the batches live in its blocks too: a kernel that reads past the end of
+    # the positions or targets then faults instead of reading whatever torch's pool holds behind them
+    checked = tcnn._C.debug_alloc_mode() != 0
+    new = (lambda shape: tcnn._C.device_tensor(shape)) if checked else (lambda shape: torch.empty(shape, device=device, dtype=torch.float32))
     out = []
     for _ in range(n_batches):
-        x = rng.uniform_(torch.empty((n, w["n_in"]), device=device, dtype=torch.float32))
-        t = torch.zeros((n, w["n_out"]), device=device) if w is WORKLOADS["mlp"] else make_targets(x, w["n_out"])
+        x = rng.uniform_(new((n, w["n_in"])))
+        t = new((n, w["n_out"]))
+        t.copy_(torch.zeros((n, w["n_out"]), device=device) if w is WORKLOADS["mlp"] else make_targets(x, w["n_out"]))
         out.append((x, t))
     return out
 
@@ -290,6 +295,8 @@ def main():
     # sanity: the run must have trained (loss finite and below the initial loss)
     ctx = tm.training_step(*batches[0], run_optimizer=False)
     final_loss = tm.loss(ctx)
+    if tcnn._C.debug_alloc_mode() != 0:
+        tcnn._C.debug_check_allocations()  # raises if any block of the checking allocator was written out of bounds
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -59,6 +59,20 @@ int tcnn_preferred_precision(void);                    /* cpp_api.h:79 */
 int tcnn_supports_jit_fusion(int device);              /* cpp_api.h:81 -- always 0: no RTC path */
 void tcnn_set_log_callback(void (*callback)(int severity, const char* message)); /* cpp_api.h:85 */
 
+/* Device memory as the library allocates it (GPUMemory<T>, gpu_memory.h:97-130): hipMalloc / hipFree, or -- with the
+ * environment variable TCNN_DEBUG_ALLOC=canary|fence set before the library is loaded -- a checking allocator
+ * (csrc/device_alloc.h): poisoned blocks with canaries before and after (canary), or blocks that END on the last mapped
+ * byte of their own mapping with unmapped address space on either side (fence: an out-of-bounds access faults at once).
+ * tcnn_debug_alloc_mode: 0 off, 1 canary, 2 fence.  tcnn_debug_check_allocations: synchronises the device, verifies every
+ * canary and returns the number of blocks that were written outside their bounds (details through tcnn_last_error()).
+ * tcnn_set_debug_launches(1) (or TCNN_DEBUG_SYNC=1): every kernel launch is followed by a stream synchronisation and an
+ * error check, and its name goes to stderr first when TCNN_DEBUG_TRACE=1 -- the last line names a faulting kernel. */
+int tcnn_device_malloc(size_t bytes, void** out);
+void tcnn_device_free(void* ptr);
+int tcnn_debug_alloc_mode(void);
+int tcnn_debug_check_allocations(void);
+int tcnn_set_debug_launches(int enable);
+
 /* ---- module factories, cpp_api.h:121-123 ---------------------------------------------------------- */
 int tcnn_create_network_with_input_encoding(uint32_t n_input_dims, uint32_t n_output_dims, const char* encoding_json,
                                             const char* network_json, tcnn_module_t** out);

@@ -20,6 +20,7 @@
 
 #include "../../include/tcnn_hip.h"
 #include "adam_device.h"
+#include "device_alloc.h"
 #include "elementwise_kernels.h"
 #include "grid_kernels.h"
 #include "../../include/tiny-cuda-nn/json_mini.h"
@@ -77,20 +78,23 @@ static void for_each_device_of(const std::map<StreamKey, F>& m, const std::funct
 class ScratchCache {
 public:
 	static void* acquire(hipStream_t stream, size_t bytes, size_t* granted) {
-		bytes = next_multiple(bytes ? bytes : (size_t)1, (size_t)256);
+		const bool debug = debug_alloc_mode() != DebugAlloc::Off;
+		// checking allocator (device_alloc.h): exact sizes, so that a block ends where the request ends, and fresh poison on
+		// every hand-out, so that nothing can rely on what an earlier use left in a recycled block
+		bytes = debug ? (bytes ? bytes : (size_t)1) : next_multiple(bytes ? bytes : (size_t)1, (size_t)256);
 		{
 			std::lock_guard<std::mutex> lock(mutex());
 			auto& fl = lists()[stream_key(stream)];
 			auto it = fl.lower_bound(bytes);
-			if (it != fl.end() && it->first <= 2 * bytes) {
+			if (it != fl.end() && it->first <= (debug ? bytes : 2 * bytes)) {
 				void* p = it->second;
 				*granted = it->first;
 				fl.erase(it);
+				if (debug) HIP_CHECK(hipMemsetAsync(p, DEBUG_POISON_BYTE, bytes, stream));
 				return p;
 			}
 		}
-		void* p = nullptr;
-		HIP_CHECK(hipMalloc(&p, bytes));
+		void* p = device_malloc(bytes);
 		*granted = bytes;
 		return p;
 	}
@@ -101,7 +105,7 @@ public:
 	static void free_all() {
 		std::lock_guard<std::mutex> lock(mutex());
 		for_each_device_of<std::multimap<size_t, void*>>(lists(), [](const StreamKey&, const std::multimap<size_t, void*>& blocks) {
-			for (auto& b : blocks) (void)hipFree(b.second);
+			for (auto& b : blocks) device_free(b.second);
 		});
 		lists().clear();
 	}
@@ -127,20 +131,20 @@ public:
 		if (slot.second < n) {
 			if (slot.first) {
 				HIP_CHECK(hipStreamSynchronize(stream));
-				(void)hipFree(slot.first);
+				device_free(slot.first);
 				slot = {nullptr, 0};
 			}
 			const size_t cap = std::max<size_t>(next_multiple<size_t>(n, 1024), 4096);
-			void* p = nullptr;
-			HIP_CHECK(hipMalloc(&p, cap * sizeof(uint32_t)));
+			void* p = device_malloc(cap * sizeof(uint32_t));
 			HIP_CHECK(hipMemset(p, 0, cap * sizeof(uint32_t)));
+			HIP_CHECK(hipDeviceSynchronize());
 			slot = {(uint32_t*)p, cap};
 		}
 		return slot.first;
 	}
 	static void free_all() {
 		std::lock_guard<std::mutex> lock(mutex());
-		for_each_device_of<std::pair<uint32_t*, size_t>>(slots(), [](const StreamKey&, const std::pair<uint32_t*, size_t>& slot) { (void)hipFree(slot.first); });
+		for_each_device_of<std::pair<uint32_t*, size_t>>(slots(), [](const StreamKey&, const std::pair<uint32_t*, size_t>& slot) { device_free(slot.first); });
 		slots().clear();
 	}
 
@@ -932,6 +936,25 @@ void tcnn_free_temporary_memory(void) {
 	ScratchCache::free_all();
 	ZeroedCounters::free_all();
 }
+int tcnn_device_malloc(size_t bytes, void** out) {
+	TCNN_API_BEGIN
+	*out = device_malloc(bytes);
+	TCNN_API_END
+}
+void tcnn_device_free(void* ptr) { device_free(ptr); }
+int tcnn_debug_alloc_mode(void) { return (int)debug_alloc_mode(); }
+int tcnn_debug_check_allocations(void) {
+	if (debug_alloc_mode() == DebugAlloc::Off) return 0;
+	std::string report;
+	const size_t bad = DebugAllocator::get().check_all(&report);
+	g_last_error = report;
+	if (bad) log_message(TCNN_LOG_ERROR, "debug allocator: " + report);
+	return (int)bad;
+}
+int tcnn_set_debug_launches(int enable) {
+	debug_launch_flags() = (debug_launch_flags() & ~1) | (enable ? 1 : 0);
+	return TCNN_OK;
+}
 int tcnn_has_networks(void) { return 1; }
 // this build's 16-bit type (tcnn_device.h): fp16, or bfloat16 when compiled with -DTCNN_BF16
 static constexpr int NATIVE_PRECISION = HALF_IS_BF16 ? TCNN_PRECISION_BF16 : TCNN_PRECISION_FP16;
@@ -1321,27 +1344,27 @@ int tcnn_create_from_config(uint32_t n_input_dims, uint32_t n_output_dims, const
 
 	// Trainer ctor + initialize_params, trainer.h:51-87
 	const size_t n = tm->md.n_params();
-	HIP_CHECK(hipMalloc(&tm->buffer, n * (sizeof(float) + 2 * sizeof(half_t))));
+	tm->buffer = device_malloc(n * (sizeof(float) + 2 * sizeof(half_t)));
 	HIP_CHECK(hipMemset(tm->buffer, 0, n * (sizeof(float) + 2 * sizeof(half_t))));
 	tm->master = (float*)tm->buffer;
 	tm->params = (half_t*)((char*)tm->buffer + sizeof(float) * n);
 	tm->grads = tm->params + n;
-	HIP_CHECK(hipMalloc((void**)&tm->m1, n * sizeof(float)));  // adam.h:136-156
-	HIP_CHECK(hipMalloc((void**)&tm->m2, n * sizeof(float)));
-	HIP_CHECK(hipMalloc((void**)&tm->steps, n * sizeof(uint32_t)));
+	tm->m1 = device_malloc_n<float>(n);  // adam.h:136-156
+	tm->m2 = device_malloc_n<float>(n);
+	tm->steps = device_malloc_n<uint32_t>(n);
 	HIP_CHECK(hipMemset(tm->m1, 0, n * sizeof(float)));
 	HIP_CHECK(hipMemset(tm->m2, 0, n * sizeof(float)));
 	HIP_CHECK(hipMemset(tm->steps, 0, n * sizeof(uint32_t)));
 	if (tm->ema) {  // ema.h:90-102
-		HIP_CHECK(hipMalloc((void**)&tm->params_ema, n * sizeof(half_t)));
+		tm->params_ema = device_malloc_n<half_t>(n);
 		HIP_CHECK(hipMemset(tm->params_ema, 0, n * sizeof(half_t)));
 		if (tm->ema_full_precision) {
-			HIP_CHECK(hipMalloc((void**)&tm->ema_tmp, n * sizeof(float)));
+			tm->ema_tmp = device_malloc_n<float>(n);
 			HIP_CHECK(hipMemset(tm->ema_tmp, 0, n * sizeof(float)));
 		}
 	}
-	if (tm->md.has_network) HIP_CHECK(hipMalloc((void**)&tm->params_t, tm->md.n_mlp_params() * sizeof(half_t)));
-	HIP_CHECK(hipMalloc((void**)&tm->loss_scratch, 1032 * sizeof(float)));
+	if (tm->md.has_network) tm->params_t = device_malloc_n<half_t>(tm->md.n_mlp_params());
+	tm->loss_scratch = device_malloc_n<float>(1032);
 	std::seed_seq seq{seed};
 	std::vector<uint32_t> seeds(2);
 	seq.generate(std::begin(seeds), std::end(seeds));
@@ -1356,14 +1379,14 @@ int tcnn_create_from_config(uint32_t n_input_dims, uint32_t n_output_dims, const
 void tcnn_trainable_model_destroy(tcnn_trainable_model_t* tm) {
 	if (!tm) return;
 	(void)hipDeviceSynchronize();
-	(void)hipFree(tm->buffer);
-	(void)hipFree(tm->m1);
-	(void)hipFree(tm->m2);
-	(void)hipFree(tm->steps);
-	(void)hipFree(tm->params_t);
-	(void)hipFree(tm->params_ema);
-	(void)hipFree(tm->ema_tmp);
-	(void)hipFree(tm->loss_scratch);
+	device_free(tm->buffer);
+	device_free(tm->m1);
+	device_free(tm->m2);
+	device_free(tm->steps);
+	device_free(tm->params_t);
+	device_free(tm->params_ema);
+	device_free(tm->ema_tmp);
+	device_free(tm->loss_scratch);
 	delete tm;
 }
 

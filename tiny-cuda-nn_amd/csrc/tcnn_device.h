@@ -14,11 +14,39 @@
 #define TCNN_SET_MAX_DYN_LDS(kernel, bytes) (void)0
 #else
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
+#include <string>
 #define TCNN_DEVICE __device__ __forceinline__
 #define TCNN_HOST_DEVICE __host__ __device__ __forceinline__
-#define TCNN_LAUNCH(kernel, grid, block, shmem, stream, ...) \
-	hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
+namespace tcnn_hip {
+// bit 0: synchronise the stream after every launch and check for errors (TCNN_DEBUG_SYNC=1 / tcnn_set_debug_launches);
+// bit 1: print the kernel's name to stderr before launching it (TCNN_DEBUG_TRACE=1): the last line names a faulting kernel
+inline int& debug_launch_flags() {
+	static int flags = (getenv("TCNN_DEBUG_SYNC") && atoi(getenv("TCNN_DEBUG_SYNC")) ? 1 : 0) | (getenv("TCNN_DEBUG_TRACE") && atoi(getenv("TCNN_DEBUG_TRACE")) ? 2 : 0);
+	return flags;
+}
+inline void launch_trace(const char* kernel, dim3 grid, dim3 block, size_t shmem) {
+	if (debug_launch_flags() & 2) {
+		fprintf(stderr, "[tcnn launch] %s grid %u block %u lds %zu\n", kernel, grid.x, block.x, shmem);
+		fflush(stderr);
+	}
+}
+// every launch is checked (the reference wraps its launches the same way, common_host.h:97-102): a launch the runtime refuses
+// (kernel arguments, LDS size, launch bounds) throws instead of leaving the step to run on garbage
+inline void launch_check(const char* kernel, hipStream_t stream) {
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess && (debug_launch_flags() & 1)) e = hipStreamSynchronize(stream);
+	if (e != hipSuccess) throw std::runtime_error(std::string("tiny-cuda-nn_amd: launch of ") + kernel + " failed: " + hipGetErrorString(e));
+}
+}  // namespace tcnn_hip
+#define TCNN_LAUNCH(kernel, grid, block, shmem, stream, ...)                  \
+	do {                                                                      \
+		::tcnn_hip::launch_trace(#kernel, grid, block, shmem);                \
+		hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);  \
+		::tcnn_hip::launch_check(#kernel, stream);                            \
+	} while (0)
 // dynamic LDS: one 16-byte aligned carve base per kernel (cdna_hip_programming.md G17)
 #define TCNN_DYN_LDS(name)                                                        \
 	extern __shared__ __attribute__((aligned(16))) unsigned char tcnn_dyn_lds_[]; \

@@ -66,6 +66,11 @@ _sig("tcnn_hip_device", _i)
 _sig("tcnn_set_hip_device", _i, _i)
 _sig("tcnn_free_temporary_memory", None)
 _sig("tcnn_has_networks", _i)
+_sig("tcnn_device_malloc", _i, _sz, C.POINTER(_vp))
+_sig("tcnn_device_free", None, _vp)
+_sig("tcnn_debug_alloc_mode", _i)
+_sig("tcnn_debug_check_allocations", _i)
+_sig("tcnn_set_debug_launches", _i, _i)
 _sig("tcnn_default_loss_scale", _f, _i)
 _sig("tcnn_preferred_precision", _i)
 _sig("tcnn_supports_jit_fusion", _i, _i)
@@ -161,6 +166,50 @@ def free_temporary_memory():
 
 def has_networks():
     return bool(_lib.tcnn_has_networks())
+
+
+# ---- debugging aids (include/tcnn_hip.h: TCNN_DEBUG_ALLOC / TCNN_DEBUG_SYNC / TCNN_DEBUG_TRACE) ------------
+def debug_alloc_mode():
+    """0 off, 1 canary, 2 fence (environment TCNN_DEBUG_ALLOC, read when the library is loaded)."""
+    return int(_lib.tcnn_debug_alloc_mode())
+
+
+def debug_check_allocations():
+    """Synchronises, verifies the canaries of every block of the checking allocator; raises if one was overwritten."""
+    if _lib.tcnn_debug_check_allocations() != 0:
+        raise RuntimeError("out-of-bounds write: " + _lib.tcnn_last_error().decode())
+
+
+def set_debug_launches(enable):
+    _check(_lib.tcnn_set_debug_launches(int(bool(enable))))
+
+
+class _LibraryBlock:
+    """Device memory from the library's allocator, exposed to torch through __cuda_array_interface__ (no copy)."""
+
+    def __init__(self, n_bytes, shape, typestr):
+        p = C.c_void_p()
+        _check(_lib.tcnn_device_malloc(max(int(n_bytes), 1), C.byref(p)))
+        self._p = p
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (p.value, False), "version": 2}
+
+    def __del__(self):
+        if getattr(self, "_p", None) and _lib is not None:
+            _lib.tcnn_device_free(self._p)
+            self._p = None
+
+
+def device_tensor(shape, dtype=torch.float32):
+    """A tensor in memory of the library's allocator -- with TCNN_DEBUG_ALLOC=fence a block whose end is the end of its mapping,
+    so that a kernel reading or writing past a caller's buffer faults (tests, bench.py under the checking allocator)."""
+    typestr = {torch.float32: "<f4", torch.float16: "<f2", torch.int32: "<i4", torch.uint8: "|u1", torch.int16: "<i2"}[dtype]
+    n = 1
+    for d in shape:
+        n *= int(d)
+    block = _LibraryBlock(n * torch.empty((), dtype=dtype).element_size(), shape, typestr)
+    t = torch.as_tensor(block, device="cuda")
+    t._tcnn_block = block  # keeps the memory alive as long as this tensor object
+    return t
 
 
 def preferred_precision():

@@ -20,15 +20,22 @@ and measurements for profiles/, not the driver's bench line):
     stress  configs[4]: HashGrid T=2^22 + FullyFusedMLP 128x4, 3-D -> 16, batch 2^18
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
-  roofline     -- the dominant kernel of the step, timed with HIP events on the stream it runs on inside the
-                  timed region (tcnn_trainer_set_profiling), against the 8 TB/s HBM peak;
+  roofline     -- the dominant kernel of the step (fixed per workload: what rocprofv3 --kernel-trace --stats shows, profiles/),
+                  timed with HIP events on the stream it runs on inside the timed region (tcnn_trainer_set_profiling),
+                  against the 8 TB/s HBM peak; `stages` holds the same figure for EVERY stage, from the instrumented pass;
   cpu_baseline -- the CPU oracle ("port": the reference has no CPU path and cannot be built here) timed on
                   this box's host cores on the same workload and the same first batch (rank 0, --gpus 1 only);
   stages_ms    -- per-stage mean times of a second, fully instrumented pass (not part of `value`).
+
+With --gpus 1 (no torch.distributed launcher) the measurement runs in a worker process and this process only relays its line:
+a worker that dies abnormally (a GPU memory-access fault aborts the process inside the HIP runtime, nothing can be caught
+in-process) is reported under `faulted_attempts` and the measurement is repeated, at most twice -- `attempts` says how many
+workers it took.  Every number in the line comes from ONE complete worker run.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -76,7 +83,9 @@ STAGE_KERNEL = {"grid_forward": "tcnn_hip::k_grid_forward_tiles", "mlp_forward":
                 "mlp_backward": "tcnn_hip::k_mlp_transpose_weights + k_mlp_backward + k_mlp_finalize_gradients",
                 "mlp_train_fused": "tcnn_hip::k_mlp_train_wave (128 neurons: k_mlp_train_wide; else k_mlp_train) + k_mlp_finalize_gradients",
                 "grid_backward_scatter": "tcnn_hip::k_grid_bucket_scatter", "grid_backward": "tcnn_hip::k_grid_backward_sliced",
-                "grid_backward_overflow": "tcnn_hip::k_grid_bucket_overflow", "adam": "tcnn_hip::k_adam_step"}
+                "adam": "tcnn_hip::k_adam_step"}
+# the kernel with the largest share of a step in the rocprofv3 kernel statistics of each workload (profiles/r03_kernel_stats*.csv)
+DOMINANT = {"hash": "grid_forward", "mlp": "mlp_train_fused", "stress": "adam"}
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense fp16/bf16 MFMA
 
@@ -107,7 +116,6 @@ def algorithmic_bytes(w, n, n_params, n_mlp_params):
         # they move: the record-scatter kernel carries the inputs and the read half of the RMW, the owner kernel the write half.
         "grid_backward_scatter": n * (4 * D + enc_w * 2 + gather),
         "grid_backward": n * gather,
-        "grid_backward_overflow": 0,
         "adam": n_params * 36,                                                   # 2 grad + (4+4)x(master, m, v, steps) + 2 fp16 param
         # fused-ideal step of SURVEY 8d: per sample inputs + targets + gather + scatter RMW, per step P_grid*2 + P_total*36
         "step_ideal": n * (4 * D + 4 * n_out + gather + 2 * gather) + p_grid * 2 + n_params * 36,
@@ -198,6 +206,29 @@ def cpu_baseline(w, x, t, budget_s=12.0, bf16=False):
             "sample": f"{n_steps} full training steps of the same config on the GPU leg's first batch of {n} samples ({dt:.1f} s), after 1 warm-up step"}
 
 
+def supervise(argv, max_attempts=3):
+    """Single-GPU runs: the measurement happens in a worker process (this file with --worker); see the module docstring."""
+    faulted = []
+    for attempt in range(1, max_attempts + 1):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), *argv, "--worker"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(r.stderr)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and lines:
+            line = json.loads(lines[-1])
+            line["attempts"] = attempt
+            if faulted:
+                line["faulted_attempts"] = faulted
+            print(json.dumps(line))
+            return 0
+        sys.stdout.write(r.stdout)
+        faulted.append({"attempt": attempt, "returncode": r.returncode, "stderr_tail": r.stderr[-600:]})
+        # an ordinary failure (bad arguments, missing library, failed assertion) is not worth repeating: only abnormal deaths are
+        if r.returncode >= 0 and "Memory access fault" not in r.stderr:
+            break
+    print(json.dumps({"error": "bench worker failed", "faulted_attempts": faulted}), file=sys.stderr)
+    return faulted[-1]["returncode"] or 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,9 +239,12 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: 2^18 samples per GPU (weak) or 2^18 in total (strong)")
     ap.add_argument("--dp", choices=["sharded", "allreduce"], default="sharded", help="N > 1: gradient exchange (tinycudann/parallel.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dominant", default="auto", help="stage timed with HIP events inside the timed region (auto: the slowest stage of a short probe pass)")
+    ap.add_argument("--dominant", default="fixed", help="stage timed with HIP events inside the timed region (fixed: the workload's dominant kernel per rocprof, see DOMINANT; auto: the slowest stage of a short probe pass)")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--lds-budget", type=int, default=None, help="grid backward: LDS bytes per level table (tuning knob)")
     args = ap.parse_args()
+    if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.worker:
+        return supervise(sys.argv[1:])
     w = WORKLOADS[args.workload]
     if args.precision == "bf16":
         os.environ["TCNN_PRECISION"] = "bf16"  # read by tinycudann._C at import: selects the bfloat16 build of the library
@@ -237,7 +271,7 @@ def main():
     if args.lds_budget is not None:
         tm.set_lds_level_budget(args.lds_budget)
     local_batch = BATCH if args.scaling == "weak" else par.shard_rows(BATCH, rank, world)[1] - par.shard_rows(BATCH, rank, world)[0]
-    global_batch = local_batch * world
+    global_batch = int(par.all_reduce_sum(local_batch, device=device)) if world > 1 else local_batch
     dp = None
     if world > 1:
         tm.set_global_batch_size(global_batch)
@@ -257,7 +291,7 @@ def main():
     torch.cuda.synchronize()
 
     # ---- which stage dominates?  short untimed probe with every stage instrumented -----------------------
-    dominant = args.dominant
+    dominant = DOMINANT[args.workload] if args.dominant == "fixed" else args.dominant
     if dominant == "auto":
         tm.set_profiling(True)
         for i in range(5):
@@ -317,6 +351,9 @@ def main():
             share = {"mlp_train_fused": 1.0, "mlp_backward": 2.0 / 3.0, "mlp_forward": 1.0 / 3.0}[dominant]
             tflops = network_flops_per_sample(w) * share * local_batch / dom_avg_s / 1e12 if dom_avg_s > 0 else 0.0
             roofline["mfma"] = {"achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS}
+        # the same figure for every stage that ran, from the instrumented pass (its event spans are a little longer than the kernels)
+        roofline["stages"] = {k: {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": ab[k], "achieved": ab[k] / (ms * 1e-3) / 1e9,
+                                  "frac": ab[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS} for k, ms in stages.items() if ms > 0 and k in ab}
         net_ms = sum(stages.get(k, 0.0) for k in ("mlp_forward", "mlp_backward", "mlp_train_fused")) if stages else 0.0
         if "mfma" not in roofline and net_ms > 0:  # the network stages against the matrix-core roof, whichever stage dominates the step
             tflops = network_flops_per_sample(w) * local_batch / (net_ms * 1e-3) / 1e12
@@ -336,9 +373,9 @@ def main():
         }
         if comm is not None:
             line["comm"] = {"seconds_per_step": comm / args.steps, "share_of_step": comm / elapsed,
-                            "note": "host-side wall time inside the collective calls + waits of rank 0 (overlapped GPU work not subtracted)"}
+                            "note": "GPU event intervals of rank 0 around the exchange: the collectives AND, in the sharded scheme, the optimizer step on the rank's shard that sits between them"}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(w, *batches[0], bf16=args.precision == "bf16")
+            line["cpu_baseline"] = cpu_baseline(w, *batches[0], budget_s=float(os.environ.get("TCNN_BENCH_CPU_BUDGET_S", "12")), bf16=args.precision == "bf16")
         print(json.dumps(line))
     par.barrier()
     if world > 1:
@@ -346,4 +383,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

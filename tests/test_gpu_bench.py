@@ -1,0 +1,168 @@
+"""What only bench.py exercises, under test on the GPU: the driver's exact command in fresh processes, the per-stage
+HIP-event hooks (tcnn_trainer_set_profiling / _get_stage_times), the pcg32 generator through the C ABI, and the checking
+allocator (csrc/device_alloc.h) that runs the bench's steps with every library block -- and the batches -- ending on the
+last mapped byte of a mapping of their own.
+
+Reference protocol being mirrored: benchmarks/image/bench_ours.cu:244-278 (warm-up, timed steps, one figure per run).
+"""
+import json
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, config_hash
+from oracle import oracle as O
+from test_gpu_parity import positions, targets_for, tcnn
+
+pytestmark = pytest.mark.gpu
+
+DRIVER_COMMAND = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"]
+
+
+def _run(cmd, **env):
+    e = dict(os.environ, **env)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_driver_bench_command_in_fresh_processes():
+    """`python3 bench.py --gpus 1 --steps 20 --warmup 5`, three times, each in a process of its own: exit code 0, one JSON line
+    with the contract's fields, `roofline` and `cpu_baseline` present, a loss that went down, no faulted worker."""
+    values = []
+    for _ in range(3):
+        d = _run(DRIVER_COMMAND, TCNN_BENCH_CPU_BUDGET_S="2")  # the CPU leg is bounded at 2 s here (12 s by default)
+        assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "samples/s" and d["higher_is_better"] is True
+        assert d["attempts"] == 1 and "faulted_attempts" not in d
+        assert d["config"]["batch_per_gpu"] == 1 << 18 and "HashGrid" in d["config"]["workload"]
+        assert abs(d["value"] - (1 << 18) / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+        r = d["roofline"]
+        assert r["bound"] == "hbm" and r["kernel"] == "grid_forward" and r["peak"] == 8000.0 and r["launches_timed"] == 20
+        assert r["algorithmic_bytes_per_launch"] == (1 << 18) * (12 + 512 + 64)  # positions + corner gather + encoded write
+        assert math.isclose(r["achieved"], r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel_tol=1e-9)
+        assert math.isclose(r["frac"], r["achieved"] / r["peak"], rel_tol=1e-12) and 0.05 < r["frac"] < 1.0
+        # every stage of the step carries its own fraction; their launch times add up to (at most) the step
+        stages = r["stages"]
+        assert set(stages) == {"grid_forward", "mlp_train_fused", "grid_backward_scatter", "grid_backward", "adam"}
+        assert all(0.0 < v["frac"] < 1.0 for v in stages.values())
+        assert sum(v["avg_launch_ms"] for v in stages.values()) <= 1.25 * d["ms_per_step"]
+        c = d["cpu_baseline"]
+        assert c["kind"] == "port" and c["unit"] == "samples/s" and c["cores"] >= 1 and c["value"] > 0
+        assert math.isfinite(d["final_loss"]) and d["final_loss"] < 0.5  # RelativeL2 of the untrained model on this data: ~30
+        values.append(d["value"])
+    assert max(values) <= 1.15 * min(values), values  # fresh processes agree
+
+
+def test_bench_other_workloads_print_their_line():
+    for workload, kernel in (("mlp", "mlp_train_fused"), ("stress", "adam")):
+        d = _run(DRIVER_COMMAND + ["--workload", workload, "--no-cpu-baseline"])
+        assert d["roofline"]["kernel"] == kernel and math.isfinite(d["final_loss"]) and "mfma" in d["roofline"]
+
+
+@pytest.mark.parametrize("mode", ["fence", "canary"])
+def test_bench_steps_under_the_checking_allocator(mode):
+    """The bench's 50 headline steps with every library block and every batch in a block of the checking allocator: `fence` --
+    an access past a block's end faults (the worker would die, attempts > 1 or a non-zero exit); `canary` -- a write outside a
+    block fails debug_check_allocations() at the end of the run.  Blocks are poisoned, recycled ones afresh: nothing may depend
+    on what an earlier use of a scratch block left behind."""
+    d = _run(DRIVER_COMMAND + ["--no-cpu-baseline"], TCNN_DEBUG_ALLOC=mode)
+    assert d["attempts"] == 1 and math.isfinite(d["final_loss"]) and d["final_loss"] < 0.5
+
+
+def test_checking_allocator_reports_an_out_of_bounds_write():
+    """The canary allocator is not a placebo: a deliberate write one element past a block is reported."""
+    code = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+import tinycudann as tcnn
+C = tcnn._C
+assert C.debug_alloc_mode() == 1
+t = C.device_tensor((1024,))
+assert torch.isnan(t).all()                       # poisoned
+C.debug_check_allocations()                       # nothing wrong yet
+import ctypes
+hip = ctypes.CDLL("libamdhip64.so")
+one = (ctypes.c_float * 1)(1.0)
+assert hip.hipMemcpy(ctypes.c_void_p(t.data_ptr() + 4 * 1024), one, 4, 1) == 0   # element [1024] of a 1024-element block
+try:
+    C.debug_check_allocations()
+except RuntimeError as e:
+    assert "past its end" in str(e), str(e)
+    print("DETECTED")
+"""
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "tiny-cuda-nn_amd")], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, TCNN_DEBUG_ALLOC="canary"), cwd=ROOT)
+    assert r.returncode == 0 and "DETECTED" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_stage_profiling_all_stages_and_single_stage():
+    """tcnn_trainer_set_profiling / tcnn_trainer_get_stage_times: HIP events around each stage on the stream the kernels run on."""
+    T = tcnn()
+    tm = T.create_from_config(3, 4, config_hash(log2_hashmap_size=15, per_level_scale=1.5))
+    n = 1 << 14
+    pos = positions(n, 3, seed=5)
+    x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(targets_for(pos, 4)).cuda()
+    with pytest.raises(RuntimeError, match="profiling is not enabled"):
+        tm.stage_times()
+    names = tm.stage_names()
+    assert names == ["grid_forward", "mlp_forward", "loss", "mlp_backward", "mlp_train_fused", "grid_backward_scatter", "grid_backward", "adam"]
+
+    tm.set_profiling(True)
+    for _ in range(7):
+        tm.training_step(x, t, want_context=False)
+    st = tm.stage_times()
+    fused = {"grid_forward", "mlp_train_fused", "grid_backward_scatter", "grid_backward", "adam"}
+    for k, (ms, count) in st.items():
+        assert (count == 7 and 0.0 < ms < 100.0) if k in fused else (count == 0 and ms == 0.0), (k, ms, count)
+    # totals accumulate across calls of stage_times(); events are recycled
+    for _ in range(3):
+        tm.training_step(x, t, want_context=False)
+    st2 = tm.stage_times()
+    assert all(st2[k][1] == 10 and st2[k][0] > st[k][0] for k in fused)
+
+    # forward() + backward() + optimizer_step() run the stand-alone kernels' stages
+    tm.set_profiling(True)  # a fresh profiler: counts start from zero
+    T._C.set_fused_network_passes(False)
+    try:
+        ctx = tm.forward(x, t)
+        tm.backward(ctx, x)
+        tm.optimizer_step()
+    finally:
+        T._C.set_fused_network_passes(True)
+    st3 = tm.stage_times()
+    assert {k for k, (_, c) in st3.items() if c} == {"grid_forward", "mlp_forward", "loss", "mlp_backward", "grid_backward_scatter", "grid_backward", "adam"}
+    assert all(c in (0, 1) for _, c in st3.values())
+
+    # one stage only: two events per step, nothing else is recorded
+    tm.set_profiling(True, only_stage="grid_backward")
+    for _ in range(4):
+        tm.training_step(x, t, want_context=False)
+    st4 = tm.stage_times()
+    assert st4["grid_backward"][1] == 4 and st4["grid_backward"][0] > 0
+    assert all(c == 0 and ms == 0.0 for k, (ms, c) in st4.items() if k != "grid_backward")
+    tm.set_profiling(False)
+    with pytest.raises(RuntimeError, match="profiling is not enabled"):
+        tm.stage_times()
+    loss = tm.loss(tm.training_step(x, t))
+    assert math.isfinite(loss)
+
+
+def test_pcg32_uniform_through_the_c_abi_matches_the_oracle_stream():
+    """tcnn_generate_random_uniform (random.h:39-75: N_TO_GENERATE = 4 draws per thread, element i + j * n_threads <- draw 4 i + j):
+    the bench's input generator, against the oracle's restatement -- bit for bit, across calls (the stream position advances),
+    for sizes around the per-thread grouping and with a range."""
+    T = tcnn()
+    for seed in (1337, 1338):
+        rng, ref = T._C.Pcg32(seed), O.pcg32(seed)
+        for n, lo, hi in ((3 * (1 << 18), 0.0, 1.0), (4099, -1e-4, 1e-4), (1, 0.0, 1.0), (512, 2.0, 5.0), (7, 0.0, 1.0)):
+            got = rng.uniform_(torch.empty(n, device="cuda"), lo, hi).cpu().numpy()
+            want = O.generate_random_uniform(ref, n, lo, hi)
+            assert np.array_equal(got, want), (seed, n)
+            assert got.min() >= lo and got.max() < hi or (lo == hi)

@@ -196,12 +196,11 @@ enum Stage : int {
 	STAGE_MLP_BWD,       // weight transpose + fused backward + finalize
 	STAGE_MLP_TRAIN,     // training_step fast path: weight transpose + forward/loss/backward in one kernel + finalize
 	STAGE_GRID_BWD_SCATTER,     // bucketed backward pass A: derive the corner records once, bin them by owning slice
-	STAGE_GRID_BWD,             // pass B (owners accumulate + store) -- or the whole backward in the sliced / atomic modes
-	STAGE_GRID_BWD_OVERFLOW,    // pass C: queue overflow through global atomics (normally empty)
+	STAGE_GRID_BWD,             // pass B (owners accumulate + store, overflow records included) -- or the whole backward in the sliced / atomic modes
 	STAGE_ADAM,
 	N_STAGES
 };
-static const char* const STAGE_NAMES[N_STAGES] = {"grid_forward", "mlp_forward", "loss", "mlp_backward", "mlp_train_fused", "grid_backward_scatter", "grid_backward", "grid_backward_overflow", "adam"};
+static const char* const STAGE_NAMES[N_STAGES] = {"grid_forward", "mlp_forward", "loss", "mlp_backward", "mlp_train_fused", "grid_backward_scatter", "grid_backward", "adam"};
 
 struct Profiler {
 	int only_stage = -1;  // -1: all stages
@@ -275,7 +274,7 @@ struct ProfScope {
 // grid_backward reports its kernels one by one (GridBackwardWorkspace::phase_hook); user = the stream
 static void grid_backward_phase_hook(void* user, int phase, int begin) {
 	static thread_local hipEvent_t a = nullptr;
-	const int stage = phase == 0 ? STAGE_GRID_BWD_SCATTER : (phase == 1 ? STAGE_GRID_BWD : STAGE_GRID_BWD_OVERFLOW);
+	const int stage = phase == 0 ? STAGE_GRID_BWD_SCATTER : STAGE_GRID_BWD;
 	if (!g_profiler || (g_profiler->only_stage >= 0 && g_profiler->only_stage != stage)) return;
 	if (begin) {
 		a = g_profiler->get();

@@ -86,7 +86,7 @@ struct GridBackwardWorkspace {
 	uint32_t* counters = nullptr;
 	size_t n_counters = 0;
 	// optional: called right before (begin = 1) and after (begin = 0) each kernel sequence of the backward --
-	// phase 0: record scatter (bucketed mode only), 1: accumulation + stores (every mode), 2: overflow pass
+	// phase 0: record scatter (bucketed mode only), 1: accumulation + stores (every mode)
 	void (*phase_hook)(void* user, int phase, int begin) = nullptr;
 	void* hook_user = nullptr;
 	const GridFusedAdam* fused_adam = nullptr;  // Bucketed mode, accumulate == false, first-order scatter only

@@ -222,6 +222,13 @@ def all_reduce_max(value, device="cpu"):
     return float(t.item())
 
 
+def all_reduce_sum(value, device="cpu"):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
 def broadcast_object(obj, src=0):
     """Same Python object on every rank (rank `src`'s)."""
     if dist.is_initialized() and dist.get_world_size() > 1:

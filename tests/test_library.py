@@ -1,6 +1,7 @@
 """The C-ABI shared library: loads without a GPU, exports every symbol include/tcnn_hip.h declares, and its
 host-side logic (config parsing, grid layout, error behaviour) matches the reference.  No compute calls."""
 import os
+import sys
 import re
 
 import pytest
@@ -144,16 +145,22 @@ int caller(hipStream_t stream, json config, GPUMatrixDynamic<float>& in, GPUMatr
     assert r.returncode == 0, r.stderr[-3000:]
 
 
-def test_register_resident_kernels_do_not_spill(tmp_path):
-    """k_mlp_train_wave / k_mlp_infer_wave are written to the register limit (254 of 256 for the headline instance) and pin values
-    with empty asm statements: an instance that spills has produced wrong results on the GPU (profiles/r02_exp_notes.txt).  The
-    compiler's resource report of every instance must show no spill and no scratch."""
-    import re
+def _hipcc():
     import shutil
-    import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
+    return hipcc
+
+
+def test_register_resident_kernels_do_not_spill(tmp_path):
+    """k_mlp_train_wave / k_mlp_infer_wave are written to the register limit (254 of 256 for the headline instance): a spilling
+    instance is slower than the workgroup-tiled kernel it replaces (profiles/r02_exp_notes.txt).  The compiler's resource report of
+    every instance must show no spill and no scratch.  (Performance tripwire only: the wrong results once blamed on spilling were
+    an MFMA hazard across a taken branch -- the next test.)"""
+    import re
+    import subprocess
+    hipcc = _hipcc()
     src = os.path.join(ROOT, "tiny-cuda-nn_amd", "csrc", "mlp_train_wave.hip")
     for build in ([], ["-DTCNN_BF16"]):  # libtcnn_hip.so and libtcnn_hip_bf16.so
         r = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "--cuda-device-only", *build,
@@ -166,3 +173,37 @@ def test_register_resident_kernels_do_not_spill(tmp_path):
         assert len(names) >= 12 and len(names) == len(spills) == len(scratch)
         bad = [(n, s, b) for n, s, b in zip(names, spills, scratch) if ("k_mlp_train_wave" in n or "k_mlp_infer_wave" in n) and (s or b)]
         assert not bad, (build, bad)
+
+
+@pytest.mark.parametrize("build", [[], ["-DTCNN_BF16"]], ids=["fp16", "bf16"])
+def test_no_mfma_result_is_read_too_soon_after_a_taken_branch(tmp_path, build):
+    """hipcc pads the wait states an MFMA result needs in straight-line code but can miss them on a path that leaves the MFMA
+    through a TAKEN branch (root cause of round 2's "spilled instance gives varying results": profiles/r03_mfma_branch_hazard.txt
+    -- stale accumulators on the GPU, no fault, no message).  The ISA of every kernel file that issues MFMAs is scanned for such
+    paths (scripts/check_mfma_branch_hazard.py); the experiment build that reproduces the failure must be flagged."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import check_mfma_branch_hazard as chk
+    hipcc = _hipcc()
+    csrc = os.path.join(ROOT, "tiny-cuda-nn_amd", "csrc")
+
+    def isa(name, extra=()):
+        out = tmp_path / (name + "".join(extra).replace("=", "_") + ".s")
+        r = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "--cuda-device-only", "-S", *build, *extra,
+                            os.path.join(csrc, name + ".hip"), "-o", str(out)], capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return str(out)
+
+    n_mfma = 0
+    for name in ("mlp_kernels", "mlp_train_wave", "mlp_train_wide"):
+        for kernel, items in chk.parse(isa(name)).items():
+            n_mfma += sum(1 for k, t in items if k == "inst" and t.startswith("v_mfma"))
+            assert chk.check_kernel(kernel, items) == [], kernel
+    assert n_mfma > 5000  # the scan saw the kernels
+    # positive control: the run-time branch behind the output layer's MFMA (the form that failed on the GPU)
+    flagged = [f for kernel, items in chk.parse(isa("mlp_train_wave", ["-DTCNN_EXP_RUNTIME_EXTERNAL"])).items() for f in chk.check_kernel(kernel, items)]
+    assert any("k_mlp_train_waveILj64ELj32ELj1" in f for f in flagged), flagged
+    # ... and two wait states in front of that branch are what cured it
+    cured = [f for kernel, items in chk.parse(isa("mlp_train_wave", ["-DTCNN_EXP_RUNTIME_EXTERNAL", "-DTCNN_EXP_NOP_AFTER_OUTPUT_MFMA=7"])).items()
+             for f in chk.check_kernel(kernel, items) if "k_mlp_train_waveILj64ELj32ELj1" in f]
+    assert cured == [], cured

@@ -123,6 +123,13 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
 	const bool want_grads = partials != nullptr, want_dx = dL_dinput != nullptr;
 	const float n_total = (float)la.n_total;
 	const PackedAct pa = packed_act(act);
+	// TCNN_EXP_RUNTIME_EXTERNAL (experiments only, scripts/exp_spill_wave.sh): the loss / external-gradient choice as a run-time
+	// branch -- the form that takes the 64-neuron instance from 254 registers to 254 + 8 spilled (profiles/r03_spill_finding.txt)
+#if defined(TCNN_EXP_RUNTIME_EXTERNAL)
+	const bool external = la.external_dL_doutput != nullptr;
+#else
+	constexpr bool external = EXTERNAL;
+#endif
 	const bool relative = la.type == LossType::RelativeL2, has_pdf = la.data_pdf != nullptr;
 	const float inv_n_total = (la.n_total & (la.n_total - 1u)) == 0u && la.n_total != 0u ? 1.0f / n_total : 0.0f;  // exact reciprocal or "divide"
 
@@ -222,7 +229,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
 #pragma unroll
 			for (uint32_t r = 0; r < 4; ++r) {
 				const uint32_t dim = 4 * r + g;
-				const bool live = !EXTERNAL && dim < la.dims;
+				const bool live = !external && dim < la.dims;
 				const uint32_t target_idx = (base + perm32(s, lr)) * la.dims + dim;
 				tgt[s][r] = live ? la.targets[target_idx] : 0.0f;
 			}
@@ -271,11 +278,17 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_
 			f4 acc = zero4();
 #pragma unroll
 			for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(woutA(p), pack8(hp[HM][s][2 * p], hp[HM][s][2 * p + 1]), acc);
+#if defined(TCNN_EXP_NOP_AFTER_OUTPUT_MFMA) && !defined(TCNN_HOST_EMU)
+#define TCNN_STR2(x) #x
+#define TCNN_STR(x) TCNN_STR2(x)
+			// experiment (scripts/exp_spill_wave.sh): N + 1 wait states between the output layer's last MFMA and whatever follows it
+			asm volatile("s_nop " TCNN_STR(TCNN_EXP_NOP_AFTER_OUTPUT_MFMA) : "+v"(acc));
+#endif
 			const h4 o = h4{(half_t)act_forward<GENERAL>(out_act, acc[0]), (half_t)act_forward<GENERAL>(out_act, acc[1]), (half_t)act_forward<GENERAL>(out_act, acc[2]),
 			                (half_t)act_forward<GENERAL>(out_act, acc[3])};
 			const uint32_t i = base + perm32(s, lr);
 			h4 gy;
-			if constexpr (EXTERNAL) {
+			if (external) {
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) gy[r] = la.external_dL_doutput[i * 16 + 4 * r + g];
 			} else {

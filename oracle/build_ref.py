@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Builds oracle/_ref/libtcnn_ref.so: the REFERENCE'S OWN device code for the hot path, compiled for the host.
+
+TEST INFRASTRUCTURE.  Purpose: pin the restated oracle (oracle/tcnn_oracle.c) against the reference's arithmetic, bit for bit,
+wherever the reference's code can be compiled without nvcc -- everything on the path except the tensor-core GEMMs
+(fully_fused_mlp.cu needs wmma / CUTLASS, which are not in /root/reference).
+
+How: the reference's kernels are plain C++ between `__global__` and a handful of cuda_fp16 intrinsics.
+  * include/tiny-cuda-nn/{common.h, vec.h, common_device.h} and dependencies/pcg32/pcg32.h are compiled WHOLE, where they lie under
+    /root/reference, against oracle/ref_shim/cuda_fp16.h (a host __half with device rounding, threadIdx / blockIdx, serial atomicAdd);
+    __CUDA_ARCH__ = 610 selects the device code paths (the __hfma2 / __half2-atomic forms of vec.h:327-395; the sm_70+ variants
+    of the same operations are PTX `red` instructions with identical arithmetic);
+  * from the headers whose classes need the CUDA runtime (encodings/grid.h, optimizers/adam.h, losses/*.h, random.h,
+    encodings/{frequency,oneblob,identity}.h, encodings/multi_level_interface.h) only the kernels named in KERNELS below are taken:
+    this script locates each definition by name in the file where it lies, brace-matches it, and hands the text to the compiler
+    through a temporary file that is deleted after the compile.  No reference source is written into the repository; the only
+    outputs are oracle/_ref/libtcnn_ref.so and oracle/_ref/manifest.json (file, kernel, line range of every definition compiled:
+    what the parity tests cite).
+  * oracle/ref_driver.cpp (ours) gives the kernels an extern "C" face: it loops (blockIdx, threadIdx) over the launch grid the
+    reference's host code would use and calls the kernel body for every thread.
+
+usage: python oracle/build_ref.py [--reference /root/reference] [--force]     (a no-op when the reference tree is absent)
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_DIR = os.path.join(HERE, "_ref")
+LIB = os.path.join(OUT_DIR, "libtcnn_ref.so")
+MANIFEST = os.path.join(OUT_DIR, "manifest.json")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"  # a host compiler with _Float16 in C++ (g++ 11 has none)
+
+INC = "include/tiny-cuda-nn/"
+# header -> definitions compiled from it (kernels, and the helper structs / device functions they use)
+KERNELS = [
+    (INC + "encodings/multi_level_interface.h", ["line:static constexpr uint32_t MAX_N_LEVELS", "ParamsOffsetTable"]),
+    (INC + "encodings/grid.h", ["kernel_grid", "kernel_grid_backward", "kernel_grid_backward_input"]),
+    (INC + "optimizers/adam.h", ["adam_step"]),
+    (INC + "losses/l2.h", ["l2_loss"]),
+    (INC + "losses/relative_l2.h", ["relative_l2_loss"]),
+    (INC + "losses/l1.h", ["l1_loss"]),
+    (INC + "losses/relative_l1.h", ["relative_l1_loss"]),
+    (INC + "losses/mape.h", ["mape_loss"]),
+    (INC + "losses/smape.h", ["smape_loss"]),
+    (INC + "losses/relative_l2_luminance.h", ["relative_l2_luminance_loss"]),
+    (INC + "random.h", ["generate_random_kernel"]),
+    (INC + "encodings/identity.h", ["identity", "identity_backward"]),
+]
+
+
+def extract(path, name):
+    """-> (text, first_line, last_line) of the definition of `name` (function or struct) in `path`, template header included."""
+    lines = open(path).read().split("\n")
+    if name.startswith("line:"):  # a one-line definition (a constant)
+        for i, line in enumerate(lines):
+            if line.startswith(name[5:]):
+                return line, i + 1, i + 1
+        raise RuntimeError(f"{name} not found in {path}")
+    pat = re.compile(r"(\b(void|struct)\s+" + re.escape(name) + r"\b\s*[({])|(\bstruct\s+" + re.escape(name) + r"\s*$)")
+    for i, line in enumerate(lines):
+        if not pat.search(line) or line.lstrip().startswith("//"):
+            continue
+        first = i
+        while first > 0 and (lines[first - 1].startswith("template") or lines[first - 1].startswith("__global__") or lines[first - 1].startswith("__device__")
+                             or lines[first - 1].startswith("TCNN_")):
+            first -= 1
+        depth, seen, j = 0, False, i
+        while j < len(lines):
+            code = lines[j].split("//")[0]
+            depth += code.count("{") - code.count("}")
+            seen = seen or "{" in code
+            if seen and depth == 0:
+                last = j
+                text = "\n".join(lines[first:last + 1])
+                if lines[i].lstrip().startswith("struct") or "struct " + name in lines[i]:
+                    text += ";" if not text.rstrip().endswith(";") else ""
+                return text, first + 1, last + 1
+            j += 1
+    raise RuntimeError(f"definition of {name} not found in {path}")
+
+
+def build(reference="/root/reference", force=False, verbose=True):
+    if not os.path.isdir(os.path.join(reference, "include", "tiny-cuda-nn")):
+        if verbose:
+            print(f"[build_ref] no reference tree at {reference}: keeping whatever {LIB} exists")
+        return os.path.exists(LIB)
+    srcs = [os.path.join(HERE, "ref_driver.cpp"), os.path.join(HERE, "ref_shim", "cuda_fp16.h"), os.path.abspath(__file__)]
+    if not force and os.path.exists(LIB) and os.path.exists(MANIFEST) and os.path.getmtime(LIB) >= max(os.path.getmtime(s) for s in srcs):
+        return True
+    os.makedirs(OUT_DIR, exist_ok=True)
+    manifest, parts = [], []
+    for rel, names in KERNELS:
+        path = os.path.join(reference, rel)
+        for name in names:
+            text, first, last = extract(path, name)
+            manifest.append({"file": rel, "name": name, "lines": [first, last]})
+            parts.append(f"// ---- {rel}:{first}-{last} ({name})\n{text}\n")
+    with tempfile.TemporaryDirectory(prefix="tcnn_ref_") as tmp:
+        with open(os.path.join(tmp, "ref_extracted_kernels.inc"), "w") as f:
+            f.write("namespace tcnn {\n" + "\n".join(parts) + "\n}  // namespace tcnn\n")
+        cmd = [CLANG, "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
+               "-Wno-keyword-macro", "-Wno-unknown-pragmas", "-Wno-pass-failed", "-Wno-unused-value",
+               "-D__CUDACC__", "-D__CUDA_ARCH__=610", "-DTCNN_HALF_PRECISION=1", "-DTCNN_MIN_GPU_ARCH=61",
+               "-I" + os.path.join(HERE, "ref_shim"), "-I" + tmp, "-I" + os.path.join(reference, "include"), "-I" + os.path.join(reference, "dependencies"),
+               os.path.join(HERE, "ref_driver.cpp"), "-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr[-6000:])
+            raise RuntimeError("oracle/_ref: compiling the reference's kernels for the host failed")
+    json.dump({"reference": reference, "compiled": manifest,
+               "whole_files": ["include/tiny-cuda-nn/common.h", "include/tiny-cuda-nn/vec.h", "include/tiny-cuda-nn/common_device.h", "dependencies/pcg32/pcg32.h"]},
+              open(MANIFEST, "w"), indent=1)
+    if verbose:
+        print(f"[build_ref] {LIB}: {len(manifest)} definitions of the reference compiled for the host")
+    return True
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--force", action="store_true")
+    a = ap.parse_args()
+    sys.exit(0 if build(a.reference, a.force) else 1)

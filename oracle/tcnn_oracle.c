@@ -688,7 +688,7 @@ void orc_mlp_init_params(const orc_mlp* m, orc_pcg32* rng, float* p, float scale
 static inline float act_fwd(int act, float x) {
 	switch (act) {
 		case ORC_ACT_RELU: return x > 0.0f ? x : 0.0f;
-		case ORC_ACT_LEAKY_RELU: return x * (x > 0.0f ? 1.0f : 0.01f);
+		case ORC_ACT_LEAKY_RELU: return x * (x > 0.0f ? 1.0f : orc_h2f(orc_f2h(0.01f)));  /* common_device.h:127: the slope is a (T) constant */
 		case ORC_ACT_EXPONENTIAL: return expf(x);
 		case ORC_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
 		case ORC_ACT_SQUAREPLUS: { float y = x * 10.0f; return 0.5f * (y + sqrtf(y * y + 4.0f)) / 10.0f; }
@@ -712,6 +712,15 @@ static inline float act_bwd(int act, float v, float y) {
 		default: return v;
 	}
 	return v * orc_h2f(orc_f2h(factor));
+}
+
+/* the two functions above on arrays of halves (tests/test_oracle_ref.py pins them against the reference's warp_activation /
+ * warp_activation_backward compiled for the host): y = (half)f((float)x);  out = (half)(v * (half)f'(y)) */
+void orc_activation_forward(int act, uint32_t n, const uint16_t* x, uint16_t* y) {
+	for (uint32_t i = 0; i < n; ++i) y[i] = orc_f2h(act_fwd(act, orc_h2f(x[i])));
+}
+void orc_activation_backward(int act, uint32_t n, const uint16_t* v, const uint16_t* y, uint16_t* out) {
+	for (uint32_t i = 0; i < n; ++i) out[i] = orc_f2h(act_bwd(act, orc_h2f(v[i]), orc_h2f(y[i])));
 }
 
 /* one dense layer for one sample: out[o] = act(sum_i W[o][i] * in[i]); W pre-converted to float */

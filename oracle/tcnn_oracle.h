@@ -5,15 +5,28 @@
  * may include, link or call this.  Allowed users: tests/, __graft_entry__.smoke(),
  * bench.py's cpu_baseline leg.
  *
- * Parity pinning status (see DESIGN.md "Oracle"):
- *   - grid layout / offset table / hash constants: PINNED by the reference's own known-answer
- *     test (/root/reference/tests/test_grid.cu:55-71) and by the literal constants in
- *     /root/reference/include/tiny-cuda-nn/common_device.h:787-791, 854-866.
- *   - MLP / loss / Adam absolute numerics: PARITY UNPINNED.  The reference has no CPU path,
- *     cannot be compiled here (no nvcc, empty CUTLASS submodule) and its tests hold no stored
- *     output tensors; only self-consistency invariants exist (tests/test_common.h:124-223).
- *     This file restates src/cutlass_mlp.cu:162-316 (CutlassMLP semantics) with fp16 storage and
- *     fp32 accumulation, and is validated by finite differences and the reference's invariants.
+ * Parity pinning status (see DESIGN.md "Oracle"; tests/test_oracle_ref.py):
+ *   - PINNED, bit for bit, against the reference's own code compiled for the host (oracle/_ref/libtcnn_ref.so, built by
+ *     oracle/build_ref.py from the sources where they lie under /root/reference; manifest.json lists file:lines):
+ *       grid_scale / grid_resolution / grid_index / pos_fract        common_device.h:767-895, 1000-1043
+ *       kernel_grid (encoding and dy_dx), kernel_grid_backward (records; sums to the error of the reference's own running
+ *       fp16 sum), kernel_grid_backward_input                       encodings/grid.h:48-349
+ *       adam_step                                                    optimizers/adam.h:47-127
+ *       the element-wise losses                                      losses/{l2,relative_l2,l1,relative_l1,mape,smape,relative_l2_luminance}.h
+ *       pcg32 + generate_random_kernel                               random.h:39-69, dependencies/pcg32/pcg32.h
+ *       warp_activation / warp_activation_backward                   common_device.h:108-186, 363-440 (up to the sign of a zero)
+ *       the identity encoding                                        encodings/identity.h:45-85
+ *     and against the reference's known answers for the grid layout (/root/reference/tests/test_grid.cu:55-71) and its literal
+ *     constants (common_device.h:787-791, 854-866).  The committed fixture tests/golden/reference_small.npz was produced by that
+ *     library; the HIP path is held against it on the GPU without the oracle in the loop.
+ *     What "the reference" means there: its source, every float operation rounded as written (-ffp-contract=off).  nvcc contracts
+ *     a * b + c into one fma by default; where the oracle models that (the uniform transform of random.h:63) it says so.
+ *   - PARITY UNPINNED: the matrix products of the fully fused MLP (src/fully_fused_mlp.cu: wmma; src/cutlass_mlp.cu: CUTLASS) --
+ *     neither compiles without nvcc / the un-vendored CUTLASS submodule, and the reference's tests hold no stored output
+ *     tensors for them (only self-consistency invariants, tests/test_common.h:124-223).  This file restates
+ *     src/cutlass_mlp.cu:162-316 with fp16 storage and either accumulator type (fp32: what MFMA does; fp16: what the
+ *     reference's tensor-core paths do, fully_fused_mlp.cu:68,198, cutlass_matmul.h:67); the product must land between the two
+ *     (tests/test_oracle.py, tests/test_gpu_parity_full.py).
  *
  * Conventions: "half" values travel as uint16_t bit patterns (IEEE binary16, RNE conversions).
  * Matrices named AoS are [N][width] (one sample's features contiguous == the reference's
@@ -131,6 +144,8 @@ void orc_mlp_init_params(const orc_mlp* m, orc_pcg32* rng, float* params_fp32, f
 /* forward: input half AoS [N][in_width]; hidden (optional, may be NULL) half [n_hidden][N][width]
  * post-activation; output half AoS [N][padded_out].  accum_fp16 != 0 emulates half accumulators
  * rounded every 16 k-steps (cutlass_matmul.h:67-68) -- used only to bracket the reference's error. */
+void orc_activation_forward(int act, uint32_t n, const uint16_t* x, uint16_t* y);
+void orc_activation_backward(int act, uint32_t n, const uint16_t* v, const uint16_t* y, uint16_t* out);
 void orc_mlp_forward(const orc_mlp* m, const uint16_t* params, const uint16_t* input, uint32_t n,
                      uint16_t* hidden, uint16_t* output, int accum_fp16);
 

@@ -671,6 +671,31 @@ def test_golden_fixture():
     assert np.percentile(rae(O.h2f(h_np(y)), O.h2f(gold["output"])), 99) < 3e-3
 
 
+def test_reference_golden_fixture():
+    """tests/golden/reference_small.npz -- made by THE REFERENCE'S OWN kernel_grid / pcg32 / generate_random_kernel compiled for the
+    host (tests/golden/make_ref_golden.py, oracle/build_ref.py): the HIP gather and the HIP generator reproduce the reference's
+    output bit for bit, no oracle in the loop.  (encodings/grid.h:48-212, random.h:39-69)"""
+    T = tcnn()
+    C = T._C
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_small.npz"))
+    n = gold["positions"].shape[0]
+    x = C.Pcg32(1337).uniform_(torch.empty((n, 3), device="cuda"))
+    assert np.array_equal(x.cpu().numpy(), gold["positions"])
+    e = C.create_encoding(3, HASH_ENCODING_SMALL)
+    u = C.Pcg32(int(gold["grid_seed"][0])).uniform_(torch.empty(e.n_params(), device="cuda"))
+    grid = (2.0 * u - 1.0).half()  # exactly the fixture's fp32 arithmetic: 2u and 2u - 1 are single IEEE operations
+    _, enc = e.fwd(x, grid)
+    assert np.array_equal(h_np(enc), gold["encoded"])
+    xg = x.clone().requires_grad_(True)
+    ctx, enc2 = e.fwd(xg, grid)
+    # dy_dx through the input gradient: dL_dx = sum_k dL_dy[k] dy_dx[k] with dL_dy = one-hot on feature k (kernel_grid_backward_input, grid.h:322-349)
+    for k in (0, 13, 31):
+        dy = torch.zeros_like(enc2)
+        dy[:, k] = 1.0
+        dx, _ = e.bwd(ctx, xg, grid, enc2, dy)
+        assert np.array_equal(dx.cpu().numpy()[:16], gold["dy_dx_first"][:, k, :]), k
+
+
 def test_error_behaviour_on_device():
     C = tcnn()._C
     m = C.create_network_with_input_encoding(3, 4, HASH_ENCODING_SMALL, MLP_64x2)

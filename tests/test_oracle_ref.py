@@ -1,0 +1,334 @@
+"""Pins the restated CPU oracle (oracle/tcnn_oracle.c) against THE REFERENCE'S OWN CODE compiled for the host
+(oracle/_ref/libtcnn_ref.so, built by oracle/build_ref.py from the sources where they lie under /root/reference;
+oracle/_ref/manifest.json lists the file and line range of every definition compiled).
+
+Covered -- everything on the hot path that compiles without nvcc:
+  grid_scale / grid_resolution / grid_index / pos_fract   common_device.h:767-895, 1000-1043   (whole file compiled)
+  kernel_grid (encoding + dy_dx)                          encodings/grid.h:48-212
+  kernel_grid_backward                                    encodings/grid.h:214-320
+  kernel_grid_backward_input                              encodings/grid.h:322-349
+  adam_step                                               optimizers/adam.h:47-127
+  l2 / relative_l2 / l1 / relative_l1 / mape / smape / relative_l2_luminance losses   losses/*.h:39-8x
+  generate_random_kernel + pcg32                          random.h:39-55, dependencies/pcg32/pcg32.h
+  warp_activation / warp_activation_backward              common_device.h:108-186, 363-440
+  identity encoding                                       encodings/identity.h:45-85
+Not covered (cannot be compiled here): the tensor-core GEMMs of fully_fused_mlp.cu / cutlass_mlp.cu; the oracle brackets those with
+its fp32- and fp16-accumulate modes (tests/test_oracle.py).
+
+Bit-exact unless stated.  CPU-only; skipped when neither the library nor the reference tree is there.
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import build_ref  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+_ref = None
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        if not build_ref.build(verbose=False):
+            pytest.skip("oracle/_ref/libtcnn_ref.so is not built and /root/reference is not here")
+        _ref = C.CDLL(build_ref.LIB)
+        _ref.ref_grid_index.restype = C.c_uint32
+        _ref.ref_log2_per_level_scale.restype = C.c_float
+    return _ref
+
+
+def p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def f32(x):
+    return C.c_float(float(x))
+
+
+GRID_CASES = [  # (D, F, L, log2_T, base, per_level_scale, grid_type, interpolation)
+    (3, 2, 16, 15, 16, 1.5, O.GRID_HASH, O.INTERP_LINEAR),       # data/config_hash.json shape
+    (3, 2, 16, 19, 16, 2.0, O.GRID_HASH, O.INTERP_LINEAR),       # the bench's headline grid
+    (2, 2, 12, 14, 16, 1.5, O.GRID_HASH, O.INTERP_SMOOTHSTEP),
+    (3, 4, 8, 12, 4, 2.0, O.GRID_HASH, O.INTERP_LINEAR),
+    (4, 2, 6, 13, 4, 1.7, O.GRID_HASH, O.INTERP_LINEAR),
+    (3, 1, 8, 13, 8, 1.5, O.GRID_HASH, O.INTERP_LINEAR),
+    (3, 8, 4, 12, 8, 2.0, O.GRID_HASH, O.INTERP_NEAREST),
+    (3, 2, 5, 19, 8, 1.6, O.GRID_DENSE, O.INTERP_LINEAR),
+    (2, 4, 6, 10, 16, 2.0, O.GRID_TILED, O.INTERP_SMOOTHSTEP),
+]
+
+
+def _grid(case):
+    D, F, L, T, base, pls, gtype, interp = case
+    return O.grid_init(D, L, F, T, base, pls, gtype, interp)
+
+
+def _ref_grid_type(t):  # common.h:161-165: Hash, Dense, Tiled
+    return {O.GRID_HASH: 0, O.GRID_DENSE: 1, O.GRID_TILED: 2}[t]
+
+
+def _ref_interp(i):  # common.h:178-182: Nearest, Linear, Smoothstep
+    return {O.INTERP_NEAREST: 0, O.INTERP_LINEAR: 1, O.INTERP_SMOOTHSTEP: 2}[i]
+
+
+def _positions(n, d, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, d), dtype=np.float32)
+    x[0] = 0.0                      # the cell corners themselves
+    x[1] = np.float32(1.0) - np.float32(2.0 ** -24)   # the largest float below 1
+    x[2] = 0.5
+    return x
+
+
+def test_manifest_names_what_was_compiled():
+    ref()
+    m = json.load(open(build_ref.MANIFEST))
+    names = {(c["file"], c["name"]) for c in m["compiled"]}
+    assert ("include/tiny-cuda-nn/encodings/grid.h", "kernel_grid") in names and ("include/tiny-cuda-nn/optimizers/adam.h", "adam_step") in names
+    for c in m["compiled"]:
+        assert c["lines"][0] <= c["lines"][1]
+    assert "include/tiny-cuda-nn/common_device.h" in m["whole_files"]
+
+
+@pytest.mark.parametrize("case", GRID_CASES)
+def test_level_scales_resolutions_and_indices(case):
+    """The oracle's per-level table and corner indices == the reference's grid_scale / grid_resolution / grid_index."""
+    g, R = _grid(case), ref()
+    D, F, L, T, base, pls, gtype, interp = case
+    log2_pls = R.ref_log2_per_level_scale(f32(pls))  # grid.h:701: std::log2(per_level_scale) in fp32
+    for l in range(L):
+        s, r = C.c_float(), C.c_uint32()
+        R.ref_grid_level(l, f32(log2_pls), base, C.byref(s), C.byref(r))
+        assert np.float32(s.value) == np.float32(g.scale[l]) and r.value == g.resolution[l], (l, s.value, g.scale[l])
+    # corner indices of random samples, every level: oracle's orc_grid_indices vs grid_index on the cell the reference's pos_fract finds
+    x = _positions(257, D, seed=3)
+    idx = O.grid_indices(g, x)
+    for i in range(0, x.shape[0], 7):
+        for l in range(L):
+            cell = []
+            for d in range(D):
+                pos, der, pg = C.c_float(), C.c_float(), C.c_uint32()
+                R.ref_pos_fract(f32(x[i, d]), f32(g.scale[l]), int(interp == O.INTERP_SMOOTHSTEP), C.byref(pos), C.byref(der), C.byref(pg))
+                cell.append(pg.value)
+            size = g.offsets[l + 1] - g.offsets[l]
+            for c in range(1 << D):
+                corner = (C.c_uint32 * D)(*[cell[d] + ((c >> d) & 1) for d in range(D)])
+                want = R.ref_grid_index(D, _ref_grid_type(gtype), size, g.resolution[l], corner)
+                if interp == O.INTERP_NEAREST and c != 0:
+                    continue
+                assert idx[i, l, c] == want, (i, l, c)
+
+
+@pytest.mark.parametrize("case", GRID_CASES)
+def test_grid_forward_and_dy_dx_bit_exact(case):
+    g, R = _grid(case), ref()
+    D, F, L, T, base, pls, gtype, interp = case
+    n = 1024 + 5  # not a multiple of the 512-thread blocks
+    rng = np.random.default_rng(11)
+    params = O.f2h((rng.standard_normal(g.n_params) * 0.3).astype(np.float32))
+    x = _positions(n, D, seed=5)
+    out, dy_dx = O.grid_forward(g, params, x, want_dy_dx=True)  # [n][L*F] half bits, [n][L*F][D]
+    offsets = (C.c_uint32 * (L + 1))(*[g.offsets[l] for l in range(L + 1)])
+    log2_pls = R.ref_log2_per_level_scale(f32(pls))
+    enc = np.zeros((L * F, n), np.uint16)           # the reference writes feature-major: encoded[i + k * n]
+    dyr = np.zeros((L * F, n, D), np.float32)       # ((vec<D>*)dy_dx)[i + k * n]
+    assert R.ref_grid_forward(D, F, n, L, offsets, base, f32(log2_pls), f32(1.0), _ref_interp(interp), _ref_grid_type(gtype), p(params), p(x), p(enc), p(dyr)) == 0
+    assert np.array_equal(out, enc.T)
+    assert np.array_equal(dy_dx, dyr.transpose(1, 0, 2))
+
+
+@pytest.mark.parametrize("case", GRID_CASES)
+def test_grid_backward_records_and_sums(case):
+    """kernel_grid_backward adds (GRAD_T)weight * grad per corner with atomics (fp16 for F >= 2, fp32 for F == 1).  The oracle sums the
+    same records exactly (float64).  Entries hit exactly once must agree bit for bit after one rounding; the others to the error of
+    the reference's own running fp16 sum."""
+    g, R = _grid(case), ref()
+    D, F, L, T, base, pls, gtype, interp = case
+    n = 512 + 3
+    rng = np.random.default_rng(17)
+    x = _positions(n, D, seed=9)
+    dy = O.f2h((rng.standard_normal((n, L * F)) * 0.05).astype(np.float32))
+    want = O.grid_backward(g, x, dy)  # float64 [n_params]
+    offsets = (C.c_uint32 * (L + 1))(*[g.offsets[l] for l in range(L + 1)])
+    log2_pls = R.ref_log2_per_level_scale(f32(pls))
+    dy_fm = np.ascontiguousarray(dy.T)  # dL_dy[i + k * n]
+    if F == 1:
+        got_buf = np.zeros(g.n_params, np.float32)
+    else:
+        got_buf = np.zeros(g.n_params, np.uint16)
+    assert R.ref_grid_backward(D, F, n, L, offsets, base, f32(log2_pls), f32(1.0), 0, _ref_interp(interp), _ref_grid_type(gtype), p(x), p(dy_fm), p(got_buf)) == 0
+    got = got_buf.astype(np.float64) if F == 1 else O.h2f(got_buf).astype(np.float64)
+    # how many records did every entry receive?
+    idx = O.grid_indices(g, x)
+    hits = np.zeros(g.n_params // F, np.int64)
+    corners = 1 if interp == O.INTERP_NEAREST else (1 << D)
+    for l in range(L):
+        np.add.at(hits, g.offsets[l] + idx[:, l, :corners].reshape(-1), 1)
+    hits = np.repeat(hits, F)
+    once = hits == 1
+    assert once.sum() > 40
+    if F == 1:
+        assert np.array_equal(got[once].astype(np.float32), want[once].astype(np.float32))
+    else:
+        assert np.array_equal(O.f2h(want[once].astype(np.float32)), got_buf[once])
+    assert np.array_equal(got[hits == 0], np.zeros((hits == 0).sum()))
+    # a running sum of k records in the accumulation type: at most k half-ulps of the largest partial sum, itself bounded by the sum
+    # of the records' magnitudes (the weights are non-negative: that is the same scatter of |dL_dy|)
+    magnitude = O.grid_backward(g, x, O.f2h(np.abs(O.h2f(dy))))
+    many = hits > 1
+    assert np.all(np.abs(got[many] - want[many]) <= hits[many] * (2.0 ** -11 if F > 1 else 2.0 ** -24) * magnitude[many] * 1.001)
+
+
+def test_grid_backward_input_bit_exact():
+    g, R = _grid(GRID_CASES[0]), ref()
+    D, F, L = 3, 2, 16
+    n = 300
+    rng = np.random.default_rng(23)
+    params = O.f2h((rng.standard_normal(g.n_params) * 0.3).astype(np.float32))
+    x = _positions(n, D, seed=2)
+    _, dy_dx = O.grid_forward(g, params, x, want_dy_dx=True)
+    dy = O.f2h((rng.standard_normal((n, L * F)) * 0.05).astype(np.float32))
+    want = O.grid_backward_input(g, dy, dy_dx)
+    got = np.zeros((n, D), np.float32)
+    assert R.ref_grid_backward_input(D, n, L * F, p(np.ascontiguousarray(dy.T)), p(np.ascontiguousarray(dy_dx.transpose(1, 0, 2))), p(got)) == 0
+    assert np.array_equal(got, want)
+
+
+LOSSES = ["L2", "RelativeL2", "L1", "RelativeL1", "Mape", "Smape", "RelativeL2Luminance"]
+
+
+@pytest.mark.parametrize("loss", LOSSES)
+@pytest.mark.parametrize("with_pdf", [False, True])
+def test_losses_bit_exact(loss, with_pdf):
+    R = ref()
+    n, stride, dims = 1000, 16, 3 if loss == "RelativeL2Luminance" else 4
+    rng = np.random.default_rng(31)
+    pred = O.f2h((rng.standard_normal((n, stride)) * 0.7).astype(np.float32))
+    tgt = rng.random((n, dims), dtype=np.float32)
+    pdf = (rng.random((n, dims), dtype=np.float32) + 0.25) if with_pdf else None
+    values, grads = O.loss(O.LOSS_NAMES.index(loss), pred, tgt, dims, 128.0, data_pdf=pdf)
+    v = np.zeros((n, stride), np.float32)
+    gr = np.zeros((n, stride), np.uint16)
+    assert R.ref_loss(LOSSES.index(loss), n * stride, stride, dims, f32(128.0), p(pred), p(tgt), p(v), p(gr), p(pdf)) == 0
+    assert np.array_equal(gr, grads)
+    assert np.array_equal(v, values)
+
+
+def test_adam_step_bit_exact_over_steps():
+    """adam_step (adam.h:47-127) for three steps with the config_hash.json hyperparameters plus clipping / decay / zero-gradient skipping."""
+    R = ref()
+    n, nm = 5000, 1536
+    rng = np.random.default_rng(41)
+    for kw in ({}, {"l2_reg": 1e-6, "gradient_clipping_magnitude": 0.01, "weight_clipping_magnitude": 0.5, "relative_weight_decay": 0.01, "absolute_weight_decay": 1e-4,
+                    "non_matrix_learning_rate_factor": 0.5, "non_matrix_l2_reg": 1e-7}):
+        h = O.adam_defaults(learning_rate=1e-2, beta1=0.9, beta2=0.99, epsilon=1e-15, **kw)
+        w = (rng.standard_normal(n) * 0.1).astype(np.float32)
+        a = {"w": w.copy(), "h": O.f2h(w), "m1": np.zeros(n, np.float32), "m2": np.zeros(n, np.float32), "s": np.zeros(n, np.uint32)}
+        b = {k: v.copy() for k, v in a.items()}
+        for step in range(1, 4):
+            grad = (rng.standard_normal(n) * 0.5).astype(np.float32)
+            grad[nm::3] = 0.0  # untouched hash-table entries: skipped, their step counter stays behind
+            gh = O.f2h(grad)
+            O.adam_step(h, nm, 128.0, step, a["w"], a["h"], gh, a["m1"], a["m2"], a["s"])
+            R.ref_adam_step(n, nm, f32(h.relative_weight_decay), f32(h.absolute_weight_decay), f32(h.weight_clipping_magnitude), f32(h.gradient_clipping_magnitude),
+                            f32(128.0), f32(h.learning_rate), f32(h.non_matrix_learning_rate_factor), h.optimize_matrix_params, h.optimize_non_matrix_params,
+                            h.skip_zero_grad_non_matrix_params, f32(h.beta1), f32(h.beta2), f32(h.epsilon), f32(0.0), f32(3.402823466e+38), f32(h.l2_reg),
+                            f32(h.non_matrix_l2_reg), p(b["w"]), p(b["h"]), p(gh), p(b["m1"]), p(b["m2"]), p(b["s"]))
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (kw, step, k)
+        assert a["s"][nm] == 0 and a["s"][nm + 1] == 3
+
+
+def test_pcg32_uniform_bit_exact():
+    R = ref()
+    for seed in (1337, 42):
+        rng = O.pcg32(seed)
+        pos = 0
+        for n, lo, hi in ((4099, 0.0, 1.0), (3 * 4096, -1e-4, 1e-4), (5, 2.0, 5.0)):
+            want = O.generate_random_uniform(rng, n, lo, hi)
+            got = np.zeros(n, np.float32)
+            R.ref_generate_random_uniform(C.c_uint64(seed), C.c_uint64(pos), C.c_size_t(n), p(got), f32(lo), f32(hi))
+            # the draws themselves are bit-exact; the transform val * (upper - lower) + lower is ONE fma on the device (nvcc contracts it,
+            # the oracle and the HIP kernel say fmaf) and a multiply + add in this host build of the reference (-ffp-contract=off)
+            if (lo, hi) == (0.0, 1.0):
+                assert np.array_equal(got, want), (seed, n)
+            else:
+                assert np.all(np.abs(got - want) <= np.spacing(np.maximum(np.abs(want), np.float32(abs(lo)))).astype(np.float32)), (seed, n)
+            pos += n
+
+
+REF_ACTIVATION = {"ReLU": 0, "LeakyReLU": 1, "Exponential": 3, "Sigmoid": 5, "Squareplus": 6, "Softplus": 7, "Tanh": 8, "None": 9}  # common.h:134-145
+
+
+@pytest.mark.parametrize("name", list(REF_ACTIVATION))
+def test_activations_bit_exact(name):
+    R = ref()
+    act = O.ACTIVATION_NAMES.index(name)
+    rng = np.random.default_rng(53)
+    x = O.f2h(np.concatenate([(rng.standard_normal(4000) * 2).astype(np.float32), np.array([0.0, -0.0, 1e-4, -1e-4, 11.0, -11.0], np.float32)]))
+    n = x.size
+    y = np.zeros(n, np.uint16)
+    O.lib().orc_activation_forward(act, C.c_uint32(n), p(x), p(y))
+    yr = np.zeros(n, np.uint16)
+    assert R.ref_activation(REF_ACTIVATION[name], 0, n, p(x), None, p(yr)) == 0
+    if name in ("ReLU", "LeakyReLU"):  # the sign of a zero result: max(-0.0f, 0.0f) is +0 with the device's fmaxf, -0 with this host build's std::max
+        assert np.array_equal(O.h2f(y), O.h2f(yr)) and np.array_equal((y & 0x7FFF), (yr & 0x7FFF))
+    else:
+        assert np.array_equal(y, yr)
+    v = O.f2h((rng.standard_normal(n) * 0.3).astype(np.float32))
+    d = np.zeros(n, np.uint16)
+    O.lib().orc_activation_backward(act, C.c_uint32(n), p(v), p(y), p(d))
+    dr = np.zeros(n, np.uint16)
+    assert R.ref_activation(REF_ACTIVATION[name], 1, n, p(v), p(y), p(dr)) == 0
+    assert np.array_equal(d & 0x7FFF, dr & 0x7FFF) and np.array_equal(O.h2f(d), O.h2f(dr))  # bit-exact up to the sign of zeros (v * 0)
+
+
+def test_identity_encoding_bit_exact():
+    R = ref()
+    n, d, padded = 777, 5, 16
+    rng = np.random.default_rng(61)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    want = O.identity_forward(x, padded)
+    got = np.zeros((n, padded), np.uint16)
+    R.ref_identity_forward(n, d, padded - d, f32(1.0), f32(0.0), p(x), p(got))
+    assert np.array_equal(got, want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the committed fixture made by the reference's code (tests/golden/make_ref_golden.py): needs neither /root/reference nor _ref
+def reference_golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "reference_small.npz"))
+
+
+def golden_inputs(gold):
+    """The fixture's seeded inputs, regenerated: [0, 1) draws of pcg32 (bit-exact in oracle, reference and HIP kernel), ranges in numpy fp32."""
+    u = lambda seed, count: O.generate_random_uniform(O.pcg32(seed), count, 0.0, 1.0)  # noqa: E731
+    g = O.grid_init(3, 16, 2, 15, 16, 1.5)
+    grid_h = O.f2h(np.float32(2.0) * u(42, g.n_params) - np.float32(1.0))
+    return g, grid_h
+
+
+def test_oracle_reproduces_the_reference_made_fixture():
+    gold = reference_golden()
+    g, grid_h = golden_inputs(gold)
+    n = gold["positions"].shape[0]
+    assert np.array_equal(O.generate_random_uniform(O.pcg32(1337), n * 3, 0.0, 1.0).reshape(n, 3), gold["positions"])
+    enc, dy_dx = O.grid_forward(g, grid_h, gold["positions"], want_dy_dx=True)
+    assert np.array_equal(enc, gold["encoded"])
+    assert np.array_equal(dy_dx[:16], gold["dy_dx_first"]) and np.abs(dy_dx).sum(dtype=np.float64) == gold["dy_dx_checksum"][0]
+    values, grads = O.loss(O.LOSS_RELATIVE_L2, gold["prediction"], gold["targets"], 4, 128.0)
+    assert np.array_equal(grads, gold["loss_gradients"]) and np.array_equal(values, gold["loss_values"])
+    h = O.adam_defaults(learning_rate=1e-2, beta1=0.9, beta2=0.99, epsilon=1e-15, l2_reg=1e-6)
+    w = gold["adam_w0"].copy()
+    st = {"w": w, "h": O.f2h(w), "m1": np.zeros_like(w), "m2": np.zeros_like(w), "s": np.zeros(w.size, np.uint32)}
+    for step in range(1, 4):
+        O.adam_step(h, 1024, 128.0, step, st["w"], st["h"], gold[f"adam_grad{step}"], st["m1"], st["m2"], st["s"])
+    for k, name in (("w", "adam_w"), ("h", "adam_h"), ("m1", "adam_m1"), ("m2", "adam_m2"), ("s", "adam_steps")):
+        assert np.array_equal(st[k], gold[name]), name

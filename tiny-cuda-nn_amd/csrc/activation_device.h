@@ -25,7 +25,7 @@ constexpr float K_ACT = 10.0f;  // common_device.h:108
 TCNN_DEVICE_NOINLINE float act_forward_general(uint32_t act, float x) {
 	switch ((Activation)act) {
 		case Activation::ReLU: return x > 0.0f ? x : 0.0f;
-		case Activation::LeakyReLU: return x * (x > 0.0f ? 1.0f : 0.01f);
+		case Activation::LeakyReLU: return x * (x > 0.0f ? 1.0f : (float)(half_t)0.01f);  // common_device.h:127: the slope is a (T) constant
 		case Activation::Exponential: return expf(x);
 		case Activation::Sigmoid: return 1.0f / (1.0f + expf(-x));
 		case Activation::Squareplus: {

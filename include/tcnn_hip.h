@@ -197,6 +197,10 @@ int tcnn_generate_random_uniform(tcnn_stream_t stream, uint64_t seed, uint64_t* 
  * Loss gradients are normalised by global_batch_size * n_output_dims instead of the local batch, so the
  * SUM over ranks of the local gradient buffers equals the single-GPU gradient of the global batch.  The
  * host all-reduces tcnn_trainer_param_gradients() (RCCL) between backward and optimizer_step. */
+/* tcnn_trainer_params / tcnn_trainer_params_inference expose a mutable pointer (trainer.h:489-503: the reference hands out its buffers
+ * the same way); the library then rebuilds its transposed copy of the network weights before every pass.  Call this when done
+ * writing through such a pointer: the copy is rebuilt once and trusted again (until the next tcnn_trainer_params call). */
+int tcnn_trainer_params_written(tcnn_trainable_model_t* tm);
 int tcnn_trainer_set_global_batch_size(tcnn_trainable_model_t* tm, uint64_t global_batch_size);
 /* Optimizer step over the parameter range [begin, end) only (begin a multiple of 8).  Lets a data-parallel host step
  * each gradient bucket as soon as its all-reduce has finished, overlapping the optimizer with the remaining

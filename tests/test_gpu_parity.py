@@ -645,6 +645,16 @@ def test_fp32_encoding_module():
     gh, dxh = enc_h.params.grad, x.grad
     assert torch.isfinite(gf).all() and gf.abs().max() > 0
     assert (gf - gh).norm() <= 2e-3 * gh.norm() and (dxf - dxh).norm() <= 2e-3 * dxh.norm()
+    # the incoming fp32 gradient may be of ANY magnitude (the caller's loss scale is 1 for fp32, cpp_api.h:77): the bridge scales it into the
+    # 16-bit type's range by a per-call power of two found on the device, so results stay finite and linear in the gradient
+    for magnitude in (1.0e-7, 64.0, 3.0e4, 1.0e9):
+        x.grad, enc_f.params.grad = None, None
+        (enc_f(x) * (w * (magnitude / 1e-3))).sum().backward()
+        g, dx = enc_f.params.grad, x.grad
+        assert torch.isfinite(g).all() and torch.isfinite(dx).all(), magnitude
+        scale = magnitude / 1e-3
+        assert (g / scale - gf).norm() <= 4e-3 * gf.norm(), (magnitude, float((g / scale - gf).norm() / gf.norm()))
+        assert (dx / scale - dxf).norm() <= 4e-3 * dxf.norm(), magnitude
 
 
 def test_golden_fixture():

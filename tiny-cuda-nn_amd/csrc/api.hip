@@ -831,16 +831,27 @@ struct tcnn_module {
 	uint32_t lds_level_budget = 0;  // 0: default LDS slice size of the sliced grid backward
 	// create_encoding(..., Precision::Fp32) (cpp_api.cu:165-174 -> Encoding<float>): parameters, outputs and gradients cross the
 	// boundary as fp32; the kernels compute in the library's 16-bit type (the caller's loss scale is 1 for fp32, cpp_api.h:77,
-	// so gradients are scaled by FP32_GRADIENT_SCALE into that type's range on the way in and back, exactly, on the way out)
+	// so gradients are scaled into that type's range on the way in and back, exactly, on the way out: by the largest power of two
+	// <= FP32_GRADIENT_SCALE that keeps max |dL_doutput| * scale <= FP32_GRADIENT_TARGET (found on the device per call), so a large
+	// fp32 gradient neither overflows fp16 nor turns the result into NaN.  "fp32 I/O, 16-bit compute": values keep the 16-bit type's
+	// resolution; the reference's Encoding<float> computes in fp32.
 	bool fp32_io = false;
 };
-static constexpr float FP32_GRADIENT_SCALE = 1024.0f;
+static constexpr float FP32_GRADIENT_SCALE = 1024.0f, FP32_GRADIENT_TARGET = 16384.0f;
 // the 16-bit copies an fp32 module works on
 struct Fp32Bridge {
 	Scratch params, output, dL_doutput, dL_dparams;
 	static Scratch to_half(hipStream_t stream, const void* src, size_t n, float scale = 1.0f) {
 		Scratch s(stream, std::max<size_t>(n, 1) * sizeof(half_t));
 		cast_scaled_f32_to_f16(stream, n, (const float*)src, s.as<half_t>(), scale);
+		return s;
+	}
+	// the gradient entering the backward pass: scaled by a per-call power of two left in `scale_pair` ({scale, 1 / scale} on the device)
+	static Scratch gradient_to_half(hipStream_t stream, const void* src, size_t n, Scratch& scale_pair) {
+		scale_pair = Scratch(stream, 4 * sizeof(float));
+		gradient_scale_from_absmax(stream, n, (const float*)src, scale_pair.as<float>(), FP32_GRADIENT_SCALE, FP32_GRADIENT_TARGET);
+		Scratch s(stream, std::max<size_t>(n, 1) * sizeof(half_t));
+		cast_scaled_f32_to_f16(stream, n, (const float*)src, s.as<half_t>(), (const float*)scale_pair.as<float>());
 		return s;
 	}
 };
@@ -1047,12 +1058,13 @@ int tcnn_module_backward(tcnn_module_t* m, tcnn_stream_t stream, const tcnn_cont
 	if (m->fp32_io) {  // bare encodings only: `output` is not needed by their backward pass
 		hipStream_t s = (hipStream_t)stream;
 		const size_t n_out = (size_t)n * m->md.padded_output_width(), n_params = m->md.n_params();
-		Scratch dy = Fp32Bridge::to_half(s, dL_doutput, n_out, FP32_GRADIENT_SCALE), p = Fp32Bridge::to_half(s, params, n_params), dp;
+		Scratch gscale;
+		Scratch dy = Fp32Bridge::gradient_to_half(s, dL_doutput, n_out, gscale), p = Fp32Bridge::to_half(s, params, n_params), dp;
 		if (dL_dparams) dp = Scratch(s, std::max<size_t>(n_params, 1) * sizeof(half_t));
 		model_backward(s, m->md, ctx->ctx, n, dL_dinput, dy.as<half_t>(), dL_dparams ? dp.as<half_t>() : nullptr, input, nullptr, p.as<half_t>(),
 		               dL_dparams ? TCNN_GRADIENT_OVERWRITE : TCNN_GRADIENT_IGNORE, m->lds_level_budget);
-		if (dL_dparams) cast_scaled_f16_to_f32(s, n_params, dp.as<half_t>(), (float*)dL_dparams, 1.0f / FP32_GRADIENT_SCALE);
-		if (dL_dinput) scale_f32(s, (size_t)n * m->md.n_input_dims, dL_dinput, 1.0f / FP32_GRADIENT_SCALE);
+		if (dL_dparams) cast_scaled_f16_to_f32(s, n_params, dp.as<half_t>(), (float*)dL_dparams, (const float*)(gscale.as<float>() + 1));
+		if (dL_dinput) scale_f32(s, (size_t)n * m->md.n_input_dims, dL_dinput, (const float*)(gscale.as<float>() + 1));
 		return TCNN_OK;
 	}
 	model_backward((hipStream_t)stream, m->md, ctx->ctx, n, dL_dinput, (const half_t*)dL_doutput, (half_t*)dL_dparams, input, (const half_t*)output,
@@ -1080,13 +1092,13 @@ int tcnn_module_backward_backward_input(tcnn_module_t* m, tcnn_stream_t stream_,
 	const Model& md = m->md;
 	const EncodingDesc& e = md.enc;
 	// fp32 module: 16-bit stand-ins for the caller's fp32 tensors (see tcnn_module::fp32_io)
-	Scratch dy16, p16, dp16, ddy16;
+	Scratch dy16, p16, dp16, ddy16, gscale;
 	void* const dL_dparams_f32 = dL_dparams;
 	void* const dL_ddLdoutput_f32 = dL_ddLdoutput;
 	const size_t n_out_elems = (size_t)n * e.padded_output_width;
 	if (m->fp32_io) {
 		if (dL_doutput) {
-			dy16 = Fp32Bridge::to_half(stream, dL_doutput, n_out_elems, FP32_GRADIENT_SCALE);
+			dy16 = Fp32Bridge::gradient_to_half(stream, dL_doutput, n_out_elems, gscale);
 			dL_doutput = dy16.ptr;
 		}
 		if (params) {
@@ -1131,8 +1143,11 @@ int tcnn_module_backward_backward_input(tcnn_module_t* m, tcnn_stream_t stream_,
 	}
 	if (m->fp32_io) {  // dL_ddLdoutput does not depend on dL_doutput; the other two carry its scale
 		if (dL_ddLdoutput_f32) cast_f16_to_f32(stream, n_out_elems, ddy16.as<half_t>(), (float*)dL_ddLdoutput_f32);
-		if (dL_dparams_f32) cast_scaled_f16_to_f32(stream, md.n_params(), dp16.as<half_t>(), (float*)dL_dparams_f32, 1.0f / FP32_GRADIENT_SCALE);
-		if (dL_dinput) scale_f32(stream, (size_t)n * md.n_input_dims, dL_dinput, 1.0f / FP32_GRADIENT_SCALE);
+		if (dL_dparams_f32) {
+			if (gscale.ptr) cast_scaled_f16_to_f32(stream, md.n_params(), dp16.as<half_t>(), (float*)dL_dparams_f32, (const float*)(gscale.as<float>() + 1));
+			else cast_f16_to_f32(stream, md.n_params(), dp16.as<half_t>(), (float*)dL_dparams_f32);
+		}
+		if (dL_dinput && gscale.ptr) scale_f32(stream, (size_t)n * md.n_input_dims, dL_dinput, (const float*)(gscale.as<float>() + 1));
 	}
 	TCNN_API_END
 }
@@ -1731,9 +1746,10 @@ int tcnn_trainer_training_step_matrices(tcnn_trainable_model_t* tm, tcnn_stream_
 	if (!input) throw std::runtime_error("training_step: input is required");
 	const uint32_t n = input->n;
 	const IoLayoutGuard guard(layout_of(input, dL_dinput, tm->md.n_input_dims, n));
-	const void* tgt = dense_cm(target, tm->md.output_width(), n, "target");
-	const void* pdf = dense_cm(data_pdf, tm->md.output_width(), n, "data_pdf");
 	const void* ext = dense_cm(external_dL_dy, tm->md.padded_output_width(), n, "external_dL_dy");  // trainer.h:125-126
+	// with an external gradient the loss is not evaluated: target and data_pdf are ignored, whatever they are (trainer.h:124-128)
+	const void* tgt = ext ? (target && target->data ? target->data : nullptr) : dense_cm(target, tm->md.output_width(), n, "target");
+	const void* pdf = ext ? nullptr : dense_cm(data_pdf, tm->md.output_width(), n, "data_pdf");
 	const int r = tcnn_trainer_training_step(tm, stream, n, (const float*)input->data, (const float*)tgt, (const float*)pdf, run_optimizer,
 	                                         dL_dinput ? (float*)dL_dinput->data : nullptr, use_inference_params, gradient_mode, ext, ctx_out);
 	if (r != TCNN_OK) return r;
@@ -1909,6 +1925,14 @@ const char* tcnn_trainer_hyperparams_json(tcnn_trainable_model_t* tm) {
 uint32_t tcnn_trainer_optimizer_step_count(const tcnn_trainable_model_t* tm) { return tm->optimizer_step; }
 uint32_t tcnn_trainer_padded_output_width(const tcnn_trainable_model_t* tm) { return tm->md.padded_output_width(); }
 uint32_t tcnn_trainer_n_mlp_params(const tcnn_trainable_model_t* tm) { return (uint32_t)tm->md.n_mlp_params(); }
+
+// tcnn_trainer_params / _params_inference hand out a mutable pointer: from then on the transposed copy of the network weights is rebuilt
+// before every pass.  A caller that has finished writing says so here; the copy is rebuilt once more and then trusted again.
+int tcnn_trainer_params_written(tcnn_trainable_model_t* tm) {
+	tm->params_exposed = false;
+	tm->params_t_valid = false;
+	return TCNN_OK;
+}
 
 int tcnn_trainer_set_global_batch_size(tcnn_trainable_model_t* tm, uint64_t global_batch_size) {
 	tm->global_batch = global_batch_size;

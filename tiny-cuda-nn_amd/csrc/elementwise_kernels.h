@@ -56,6 +56,12 @@ void cast_f16_to_f32(hipStream_t stream, size_t n, const half_t* in, float* out)
 void cast_scaled_f32_to_f16(hipStream_t stream, size_t n, const float* in, half_t* out, float scale);
 void cast_scaled_f16_to_f32(hipStream_t stream, size_t n, const half_t* in, float* out, float scale);
 void scale_f32(hipStream_t stream, size_t n, float* data, float scale);
+// the same with the scale read from device memory.  gradient_scale_from_absmax fills pair_and_scratch (3 floats of device memory: scale,
+// 1 / scale, scratch) with the largest power of two s <= cap such that s * max |in| <= target (cap when the input is all zero)
+void gradient_scale_from_absmax(hipStream_t stream, size_t n, const float* in, float* pair_and_scratch, float cap, float target);
+void cast_scaled_f32_to_f16(hipStream_t stream, size_t n, const float* in, half_t* out, const float* scale_dev);
+void cast_scaled_f16_to_f32(hipStream_t stream, size_t n, const half_t* in, float* out, const float* scale_dev);
+void scale_f32(hipStream_t stream, size_t n, float* data, const float* scale_dev);
 void fill_f16(hipStream_t stream, size_t n, half_t* out, float value);
 
 // object.cu:61-67 trim_and_cast_from: in half AoS [n][padded] -> out float element (j, i) at out[i*stride_i + j*stride_j]

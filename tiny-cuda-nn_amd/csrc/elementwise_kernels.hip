@@ -80,6 +80,61 @@ void cast_f16_to_f32(hipStream_t stream, size_t n, const half_t* in, float* out)
 	if (n == 0) return;
 	TCNN_LAUNCH(k_cast_f16_to_f32, dim3((uint32_t)div_round_up(div_round_up(n, (size_t)4), (size_t)EW_THREADS)), dim3(EW_THREADS), 0, stream, n, in, out);
 }
+// ---- fp32 gradients entering the 16-bit kernels (fp32 encodings, cpp_api.cu:165-174): a per-call power-of-two scale from max |x|, computed
+// and consumed on the device (no host round trip).  pair = {scale, 1 / scale}; word 2 of the buffer is the running maximum's bit pattern.
+__global__ void k_absmax_f32(size_t n, const float* __restrict__ in, uint32_t* __restrict__ absmax_bits) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t b = 0;
+	if (i < n) {
+		b = __builtin_bit_cast(uint32_t, in[i]) & 0x7FFFFFFFu;
+		if (b > 0x7F800000u) b = 0;  // NaN: leaves the scale alone (it propagates as NaN through the cast)
+	}
+	// wave maximum first: one atomic per wavefront
+	for (uint32_t d = 32; d > 0; d >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, (int)d, 64));
+	if ((threadIdx.x & 63u) == 0 && b) atomicMax(absmax_bits, b);
+}
+__global__ void k_gradient_scale(const uint32_t* __restrict__ absmax_bits, float* __restrict__ pair, float cap, float target) {
+	const float m = __builtin_bit_cast(float, absmax_bits[0]);
+	float scale = cap;
+	if (m > 0.0f && m < __builtin_inff()) {
+		int e;
+		(void)__builtin_frexpf(target / m, &e);       // target / m = f * 2^e, f in [0.5, 1)
+		scale = __builtin_fminf(__builtin_scalbnf(1.0f, e - 1), cap);  // the largest power of two <= target / m, capped
+		scale = __builtin_fmaxf(scale, 1.0f / 16777216.0f);
+	}
+	pair[0] = scale;
+	pair[1] = 1.0f / scale;
+}
+__global__ void k_cast_scaled_f32_to_f16_dev(size_t n, const float* __restrict__ in, half_t* __restrict__ out, const float* __restrict__ scale) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = to_half_rn(in[i] * scale[0]);
+}
+__global__ void k_cast_scaled_f16_to_f32_dev(size_t n, const half_t* __restrict__ in, float* __restrict__ out, const float* __restrict__ scale) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = (float)in[i] * scale[0];
+}
+__global__ void k_scale_f32_dev(size_t n, float* __restrict__ data, const float* __restrict__ scale) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) data[i] = data[i] * scale[0];
+}
+void gradient_scale_from_absmax(hipStream_t stream, size_t n, const float* in, float* pair_and_scratch, float cap, float target) {
+	uint32_t* bits = (uint32_t*)(pair_and_scratch + 2);
+	if (hipMemsetAsync(bits, 0, sizeof(uint32_t), stream) != hipSuccess) throw std::runtime_error("gradient_scale_from_absmax: memset failed");
+	if (n) TCNN_LAUNCH(k_absmax_f32, dim3((uint32_t)div_round_up(n, (size_t)EW_THREADS)), dim3(EW_THREADS), 0, stream, n, in, bits);
+	TCNN_LAUNCH(k_gradient_scale, dim3(1), dim3(1), 0, stream, (const uint32_t*)bits, pair_and_scratch, cap, target);
+}
+void cast_scaled_f32_to_f16(hipStream_t stream, size_t n, const float* in, half_t* out, const float* scale_dev) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_cast_scaled_f32_to_f16_dev, dim3((uint32_t)div_round_up(n, (size_t)EW_THREADS)), dim3(EW_THREADS), 0, stream, n, in, out, scale_dev);
+}
+void cast_scaled_f16_to_f32(hipStream_t stream, size_t n, const half_t* in, float* out, const float* scale_dev) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_cast_scaled_f16_to_f32_dev, dim3((uint32_t)div_round_up(n, (size_t)EW_THREADS)), dim3(EW_THREADS), 0, stream, n, in, out, scale_dev);
+}
+void scale_f32(hipStream_t stream, size_t n, float* data, const float* scale_dev) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_scale_f32_dev, dim3((uint32_t)div_round_up(n, (size_t)EW_THREADS)), dim3(EW_THREADS), 0, stream, n, data, scale_dev);
+}
 void cast_scaled_f32_to_f16(hipStream_t stream, size_t n, const float* in, half_t* out, float scale) {
 	if (n == 0) return;
 	TCNN_LAUNCH(k_cast_scaled_f32_to_f16, dim3((uint32_t)div_round_up(n, (size_t)EW_THREADS)), dim3(EW_THREADS), 0, stream, n, in, out, scale);

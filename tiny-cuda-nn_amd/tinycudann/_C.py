@@ -128,6 +128,7 @@ _sig("tcnn_trainer_optimizer_step_range", _i, _vp, _vp, _f, _sz, _sz)
 _sig("tcnn_trainer_optimizer_step_ranges", _i, _vp, _vp, _f, _sz, C.POINTER(_sz), C.POINTER(_sz))
 _sig("tcnn_trainer_set_gradient_exchange", _i, _vp, _vp, _vp)
 _sig("tcnn_trainer_optimizer_state", _vp, _vp, _i, C.POINTER(_i))
+_sig("tcnn_trainer_params_written", _i, _vp)
 _sig("tcnn_trainer_set_profiling", _i, _vp, _i, _i)
 _sig("tcnn_trainer_n_stages", _i)
 _sig("tcnn_trainer_stage_name", _cp, _i)

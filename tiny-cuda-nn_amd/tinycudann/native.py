@@ -159,6 +159,10 @@ class TrainableModel:
     def params(self):
         return self._tensor(_lib.tcnn_trainer_params(self._h), "<f2")
 
+    def params_written(self):
+        """Done writing through `params` / `params_inference`: the trainer rebuilds its transposed weight copy once and trusts it again."""
+        _check(_lib.tcnn_trainer_params_written(self._h))
+
     @property
     def params_inference(self):
         """Trainer::params_inference (trainer.h:497-500): the EMA weights when the optimizer is wrapped in Ema, else `params`."""

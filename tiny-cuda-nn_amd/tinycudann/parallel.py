@@ -100,9 +100,10 @@ class DataParallel:
         self.world = dist.get_world_size() if self.active else 1
         self.rank = dist.get_rank() if self.active else 0
         self.grads = tm.param_gradients
-        self.params = tm.params
-        inf = tm.params_inference
-        self.params_inference = inf if inf.data_ptr() != self.params.data_ptr() else None  # EMA weights (trainer.h:497-500)
+        # the parameter buffers are only touched by the sharded scheme (its all-gather writes them): asking the trainer for a mutable
+        # parameter pointer makes it rebuild its transposed weight copy before every pass, so the other schemes never ask
+        self._params = self._params_inference = None
+        self._params_fetched = False
         n = self.grads.numel()
         # parameters [0, main) are sharded evenly (shard boundaries are multiples of 8, what the optimizer ranges need); the
         # < 8 P parameters of the tail [main, n) are all-reduced and stepped by every rank (replicated state)
@@ -113,6 +114,23 @@ class DataParallel:
         self._events = []
         self._stage = {}
         self._has_reduce_scatter = self._has_all_gather_into = True
+
+    def _fetch_params(self):
+        if not self._params_fetched:
+            self._params = self.tm.params
+            inf = self.tm.params_inference
+            self._params_inference = inf if inf.data_ptr() != self._params.data_ptr() else None  # EMA weights (trainer.h:497-500)
+            self._params_fetched = True
+
+    @property
+    def params(self):
+        self._fetch_params()
+        return self._params
+
+    @property
+    def params_inference(self):
+        self._fetch_params()
+        return self._params_inference
 
     def shard_range(self, rank=None):
         r = self.rank if rank is None else rank

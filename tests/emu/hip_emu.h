@@ -115,6 +115,19 @@ inline unsigned long long wave_ballot(bool pred) {
 	return w.vote[slot];
 }
 
+// __shfl_xor for fully converged waves of 64
+inline int wave_shfl_xor(int v, int mask) {
+	Wave& w = g.waves[g.cur->tidx.x / 64];
+	const unsigned lane = g.cur->tidx.x & 63u;
+	w.a[lane][0] = 0;
+	memcpy(&w.b[lane], &v, sizeof(int));
+	wave_barrier();
+	int out;
+	memcpy(&out, &w.b[(lane ^ (unsigned)mask) & 63u], sizeof(int));
+	wave_barrier();
+	return out;
+}
+
 inline void trampoline() {
 	g.fn();
 	g.cur->done = true;
@@ -187,8 +200,17 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> fn
 #define TCNN_LAUNCH(kernel, grid, block, shmem, stream, ...) \
 	::emu::launch(grid, block, shmem, [=]() { kernel(__VA_ARGS__); })
 
+#define __shfl_xor(v, mask, width) ::emu::wave_shfl_xor(v, mask)
+
 template <typename T>
 inline T min(T a, T b) { return a < b ? a : b; }
+template <typename T>
+inline T max(T a, T b) { return a < b ? b : a; }
+inline uint32_t atomicMax(uint32_t* addr, uint32_t v) {
+	const uint32_t old = *addr;
+	if (v > old) *addr = v;
+	return old;
+}
 
 namespace tcnn_hip {
 

@@ -235,6 +235,12 @@ TCNN_HOST_DEVICE uint32_t grid_index(bool is_hash, uint32_t hashmap_size, uint32
 	// ~15-instruction u32 remainder; the condition is wave-uniform (one level per workgroup)
 	const uint32_t mask = hashmap_size - 1u;
 	if ((hashmap_size & mask) == 0u) return index & mask;
+	// densely indexed level (table = resolution^D entries, rounded up to 8): a position inside the unit cube gives
+	// index <= res + res^2 + ... + res^D < 2 * table, so the remainder is at most one subtraction; the ~25-instruction u32
+	// division only runs for lanes whose position lies outside (same result either way: x % m == (x - m) % m)
+	if (index < hashmap_size) return index;
+	index -= hashmap_size;
+	if (index < hashmap_size) return index;
 	return index % hashmap_size;
 }
 

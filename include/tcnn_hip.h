@@ -250,6 +250,12 @@ int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes
  * Also selectable with TCNN_GRID_BACKWARD=sliced_f32|sliced_f16|atomic|bucketed. */
 int tcnn_set_grid_backward_mode(int mode);
 int tcnn_get_grid_backward_mode(void);
+/* Accumulator form of the bucket owners in mode 3, process-wide (same bits from all three): 0 = packed (default: both features of a
+ * payload word in one 64-bit LDS word, half the LDS atomics and half the LDS; slices whose sums could leave int32 are redone wide),
+ * 1 = 64-bit fixed point per value throughout, 2 = the packed kernel with every slice through its wide redo (tests).
+ * Also selectable with TCNN_GRID_OWNER=packed|fixed64|wide. */
+int tcnn_set_grid_owner_mode(int mode);
+int tcnn_get_grid_owner_mode(void);
 
 #ifdef __cplusplus
 }

@@ -104,8 +104,18 @@ def grid_forward(g, params_h, positions, soa=True, out_stride=None, want_dy_dx=F
 SLICED_F32, SLICED_F16, ATOMIC, BUCKETED = 0, 1, 2, 3
 
 
-def grid_backward(g, positions, dL_dy_h, soa=True, mode=SLICED_F32, lds_budget=0, grad_init=None):
-    """grad_init: half bit patterns to accumulate into (GradientMode::Accumulate); None -> Overwrite into a
+OWNER_PACKED, OWNER_FIXED64, OWNER_WIDE = 0, 1, 2
+
+
+def grid_owner_stats():
+    """(slices finished from the packed table, slices redone with 64 bits per value) since the last call."""
+    v = (C.c_ulong * 2)()
+    lib().emu_grid_owner_stats(v)
+    return int(v[0]), int(v[1])
+
+
+def grid_backward(g, positions, dL_dy_h, soa=True, mode=SLICED_F32, lds_budget=0, grad_init=None, owner=OWNER_PACKED):
+    """owner: accumulator form of the bucket owners (grid_kernels.h grid_owner_mode).  grad_init: half bit patterns to accumulate into (GradientMode::Accumulate); None -> Overwrite into a
     buffer pre-filled with garbage (the kernel must not rely on a zeroed gradient buffer)."""
     og = g.og
     positions = np.ascontiguousarray(positions, dtype=np.float32)
@@ -113,6 +123,7 @@ def grid_backward(g, positions, dL_dy_h, soa=True, mode=SLICED_F32, lds_budget=0
     dL_dy_h = np.ascontiguousarray(dL_dy_h, dtype=np.uint16)
     grad_h = np.full(og.n_params, 0x3C00, dtype=np.uint16) if grad_init is None else grad_init.copy()
     stride = dL_dy_h.shape[1] if not soa else n
+    lib().emu_set_grid_owner_mode(C.c_int(int(owner)))
     r = lib().emu_grid_backward(C.byref(g.c), _p(positions), C.c_uint32(n), _p(dL_dy_h), C.c_int(int(soa)),
                                 C.c_uint32(stride), _p(grad_h), C.c_int(int(grad_init is not None)), C.c_int(mode), C.c_uint32(lds_budget))
     assert r == 0

@@ -50,6 +50,15 @@ int emu_grid_forward(const EmuGrid* e, const float* positions, uint32_t n, const
 	return 0;
 }
 
+void emu_set_grid_owner_mode(int mode) { grid_owner_mode() = mode; }
+// slices the packed owner kernel finished from its packed table / redid with 64 bits per value, since the last call
+void emu_grid_owner_stats(unsigned long* packed_wide) {
+	for (int i = 0; i < 2; ++i) {
+		packed_wide[i] = owner_slice_stats[i];
+		owner_slice_stats[i] = 0;
+	}
+}
+
 int emu_grid_backward(const EmuGrid* e, const float* positions, uint32_t n, const uint16_t* dL_dy, int soa, uint32_t dy_stride,
                       uint16_t* grad_half, int accumulate, int mode, uint32_t lds_budget) {
 	try {

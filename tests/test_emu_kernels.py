@@ -108,6 +108,36 @@ def test_grid_second_order(case):
     assert np.all(np.abs(O.h2f(grad).astype(np.float64) - gp_ref) <= 2.0 ** -8 * mag + 2e-3 * max(1.0, np.abs(gp_ref).max()) * 2.0 ** -4)
 
 
+@pytest.mark.parametrize("case,lds_budget", [((3, 4, 2, 14, 8, 1.7, O.GRID_HASH, O.INTERP_LINEAR), 0), ((3, 4, 4, 12, 8, 1.7, O.GRID_HASH, O.INTERP_LINEAR), 2048),
+                                             ((2, 4, 8, 11, 4, 1.5, O.GRID_HASH, O.INTERP_SMOOTHSTEP), 0), ((3, 3, 2, 19, 4, 1.4, O.GRID_DENSE, O.INTERP_LINEAR), 2048)])
+@pytest.mark.parametrize("magnitude", [3e-3, 2.0, 300.0])
+def test_grid_bucket_owner_forms_agree(case, magnitude, lds_budget):
+    """Pass B of the bucketed backward in its three accumulator forms (grid_kernels.h grid_owner_mode): packed (both features of a
+    payload word in one 64-bit LDS word; slices whose sums could leave int32 redone wide), 64-bit fixed point per value, and the
+    packed kernel's wide redo forced on every slice.  Exact sums, one rounding: the same BITS from all three -- for gradients small
+    enough for the packed words (3e-3), large enough to fail the bound in most slices (2.0) and beyond int32 at 2^-24 (300)."""
+    D, L, F, T, base, scale, gtype, interp = case
+    rng = np.random.default_rng(11)
+    og = O.grid_init(D, L, F, T, base, scale, gtype, interp)
+    g = emu.Grid(og)
+    n = 600
+    pos = rng.random((n, D), dtype=np.float32)
+    dy = O.f2h((rng.standard_normal((n, L * F)) * magnitude).astype(np.float32))
+    dys = np.ascontiguousarray(dy.T)
+    emu.grid_owner_stats()
+    got = [emu.grid_backward(g, pos, dys, soa=True, mode=emu.BUCKETED, lds_budget=lds_budget, owner=emu.OWNER_PACKED)]
+    n_packed, n_wide = emu.grid_owner_stats()
+    # (slices without records pass the bound whatever the magnitude; 2 KiB slices see few records each)
+    assert n_packed + n_wide > 0 and (n_wide == 0 if magnitude < 1e-2 else (n_wide > 0 or (magnitude < 100 and lds_budget)))
+    got += [emu.grid_backward(g, pos, dys, soa=True, mode=emu.BUCKETED, lds_budget=lds_budget, owner=o) for o in (emu.OWNER_FIXED64, emu.OWNER_WIDE)]
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[2], got[1])
+    ref = O.grid_backward(og, pos, dy)
+    absacc = O.grid_backward(og, pos, O.f2h(np.abs(O.h2f(dy))))
+    assert np.all(np.abs(O.h2f(got[0]).astype(np.float64) - ref) <= absacc * 2.0 ** -9 + 2e-3 * magnitude)
+    acc = [emu.grid_backward(g, pos, dys, soa=True, mode=emu.BUCKETED, lds_budget=lds_budget, grad_init=got[0], owner=o) for o in (emu.OWNER_PACKED, emu.OWNER_FIXED64)]
+    assert np.array_equal(acc[0], acc[1])
+
+
 def test_grid_backward_bucket_overflow():
     """Strongly clustered samples overflow their bucket queues; the overflow list + atomic pass keeps the sum right."""
     D, L, F, T = 3, 3, 2, 14

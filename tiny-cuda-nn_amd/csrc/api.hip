@@ -1974,6 +1974,12 @@ int tcnn_set_fused_network_passes(int enable) {
 	g_fused_network_passes.store(enable != 0 ? 1 : 0);
 	return TCNN_OK;
 }
+int tcnn_get_grid_owner_mode(void) { return grid_owner_mode(); }
+int tcnn_set_grid_owner_mode(int mode) {
+	if (mode < 0 || mode > 2) return TCNN_ERROR;
+	grid_owner_mode() = mode;
+	return TCNN_OK;
+}
 int tcnn_get_grid_backward_mode(void) { return g_grid_backward_mode.load(); }
 int tcnn_set_grid_backward_mode(int mode) {
 	if (mode < 0 || mode > 3) return TCNN_ERROR;

@@ -95,6 +95,14 @@ GridBackwardWorkspace grid_backward_workspace_size(const GridMeta& meta, uint32_
 void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient, bool accumulate,
                    GridBackwardMode mode, uint32_t lds_slice_bytes, const GridBackwardWorkspace& workspace = GridBackwardWorkspace());
 
+// Accumulator form of the bucket owners (pass B of the Bucketed mode), process-wide; initial value from TCNN_GRID_OWNER=packed|fixed64|wide:
+//   0 packed  -- the two features of a payload word share one 64-bit LDS word (one ds_add_u64 per table entry at F = 2, 8 bytes of
+//                LDS per entry, two workgroups per CU); a slice whose gradients could leave int32 is redone with 64 bits per value
+//   1 fixed64 -- 64 bits per value throughout (k_grid_backward_sliced; also what odd F and the fused optimizer step run)
+//   2 wide    -- the packed kernel, every slice through its 64-bit redo (tests of that path)
+// All three produce the same bits.
+int& grid_owner_mode();
+
 // dL_dx[i][d] = sum_k dL_dy[k][i] * dy_dx[k][i][d]   (grid.h:323-349)
 void grid_backward_input(hipStream_t stream, uint32_t n_dims, uint32_t n_features, const GridIO& io,
                          const half_t* dL_dy, const float* dy_dx, float* dL_dx, uint32_t dx_stride_i,

@@ -635,6 +635,7 @@ struct BucketPlan {
 	uint32_t overflow_counter;   // index of the overflow counter (== total number of queues); the one after it counts finished pass-C blocks
 	uint32_t overflow_capacity;  // records
 	uint32_t n_owner_blocks;     // workgroups of pass B that own a bucket (the last one to finish resets the bookkeeping counters)
+	uint32_t packed_owner;       // pass B's bucket items run in k_grid_bucket_owner (packed accumulators), not in k_grid_backward_sliced
 	uint8_t level[MAX_BUCKET_LEVELS];             // grid level of slot j
 	uint32_t n_buckets[MAX_BUCKET_LEVELS];        // table slices
 	uint32_t n_chunks[MAX_BUCKET_LEVELS];         // sample chunks: a queue belongs to one (chunk, bucket); > 1 only for small tables
@@ -962,6 +963,52 @@ TCNN_DEVICE void fused_adam4(const FusedAdamArgs& fa, size_t p, h4 g) {
 	}
 }
 
+// What every owner of a (bucket, chunk) does last.  Every thread read the counters before the barriers of the caller: they end
+// the call zeroed.  The last owner to get here (all owners have read the overflow count by then) resets the two bookkeeping
+// counters -- after draining a long overflow list with the reference's global atomics.
+template <uint32_t F, uint32_t THREADS>
+TCNN_DEVICE void bucket_owner_epilogue(const GridMeta& meta, const BucketPlan& plan, uint32_t j, uint32_t queue, bool inline_overflow, uint32_t n_over,
+                                       uint32_t* __restrict__ counters, const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient) {
+	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, OW = BucketRecord<F>::WORDS + 1;
+	__shared__ uint32_t last_owner;
+	__syncthreads();  // this slice's stores are issued
+	if (threadIdx.x == 0) {
+		counters[plan.counter_base[j] + queue] = 0u;
+		if (!inline_overflow) {  // the drain's atomics execute memory-side: the slices must be there first (release, agent scope)
+#if !defined(TCNN_HOST_EMU)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+		}
+		last_owner = atomic_add_u32(&counters[plan.overflow_counter + 1], 1u) == plan.n_owner_blocks - 1u ? 1u : 0u;
+	}
+	__syncthreads();
+	if (last_owner) {
+		if (!inline_overflow) {
+#if !defined(TCNN_HOST_EMU)
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+			for (uint32_t t = threadIdx.x; t < n_over; t += THREADS) {
+				const uint32_t* rec = overflow + (size_t)t * OW;
+				half_t* __restrict__ g = grid_gradient + (size_t)meta.offset[rec[0]] * F;
+				const uint32_t index = rec[1];
+				if constexpr (F == 1) {
+					const half_t v = (half_t)__builtin_bit_cast(float, rec[2]);
+					atomic_add_h2(g + (index & ~1u), (index & 1u) ? h2{(half_t)0.0f, v} : h2{v, (half_t)0.0f});
+				} else {
+#pragma unroll
+					for (uint32_t p = 0; p < PW; ++p) atomic_add_h2(g + (size_t)index * F + 2 * p, bits_h2(rec[2 + p]));
+				}
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			counters[plan.overflow_counter] = 0u;
+			counters[plan.overflow_counter + 1] = 0u;
+		}
+	}
+}
+
 // pass B: the owner of bucket `bucket` of slot `j` streams its queue into a 64-bit fixed-point LDS table
 template <uint32_t D, uint32_t F>
 TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t level, uint32_t j, uint32_t bucket, uint32_t chunk,
@@ -969,7 +1016,6 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
                               const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient, bool accumulate, unsigned char* lds_raw,
                               const FusedAdamArgs& fused) {
 	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, PWP = BucketRecord<F>::PAIR_WORDS, OW = BucketRecord<F>::WORDS + 1;
-	__shared__ uint32_t last_owner;
 	// records that did not fit their queue (or whose x-neighbour lives in another bucket: about one pair in 2^shift).  Up to
 	// OVERFLOW_INLINE_MAX of them every owner picks its own out of the list -- exact, no atomics, no extra launch; beyond
 	// that (strongly clustered inputs) the last owner to finish sends the list through the reference's global atomics.
@@ -1051,43 +1097,222 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 			atomic_add_h2(grad + 2 * e2, v);  // small tables only: (table size) x (chunks) updates per level
 		}
 	}
-	// every thread read the counters before the barriers above: they end the call zeroed.  The last owner to get here (all
-	// owners have read the overflow count by then) resets the two bookkeeping counters -- after draining a long overflow list.
-	__syncthreads();  // this slice's stores are issued
-	if (threadIdx.x == 0) {
-		counters[plan.counter_base[j] + queue] = 0u;
-		if (!inline_overflow) {  // the drain's atomics execute memory-side: the slices must be there first (release, agent scope)
-#if !defined(TCNN_HOST_EMU)
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	bucket_owner_epilogue<F, SLICED_THREADS>(meta, plan, j, queue, inline_overflow, n_over, counters, overflow, grid_gradient);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass B, packed form (even F; what the bucketed backward runs unless TCNN_GRID_OWNER=fixed64).
+//
+// The form above spends one ds_add_u64 per VALUE (two per table entry at F = 2) and 16 bytes of LDS per entry, so a
+// 8192-entry slice takes 128 KiB: one workgroup per CU, whose clear / stream / convert phases cannot overlap anything.
+// Here the two features of a payload word share ONE 64-bit LDS word: the addend is the two's-complement number
+// V1 * 2^32 + V0 (V = value * 2^24, an exact int32 while |value| < 128), so a single ds_add_u64 accumulates both, and the
+// sums come apart again as S0 = sign-extended low word, S1 = (X - S0) >> 32 -- provided both lie inside int32.  They do
+// whenever the absolute values of all addends of the slice sum to less than 2^31 per feature (= 128.0 in gradient
+// units; the sum over a whole LEVEL is sum_i |dL/dy_i| -- about loss_scale * mean error -- and a slice sees 1/64 of
+// it): every lane keeps that running bound in fp32, the workgroup adds the lanes up once, and a slice that fails the
+// test (huge or non-finite gradients) is simply redone with the 64-bit-per-value table above, in sub-slices that fit the
+// same LDS.  Same exact sums, same single rounding, bit-identical output either way; half the LDS atomics, half the LDS
+// (64 KiB: two workgroups share a CU, one streaming while the other clears or converts), no fp64 arithmetic.
+// ---------------------------------------------------------------------------------------------
+#ifndef TCNN_OWNER_THREADS
+#define TCNN_OWNER_THREADS 512
 #endif
-		}
-		last_owner = atomic_add_u32(&counters[plan.overflow_counter + 1], 1u) == plan.n_owner_blocks - 1u ? 1u : 0u;
-	}
-	__syncthreads();
-	if (last_owner) {
-		if (!inline_overflow) {
-#if !defined(TCNN_HOST_EMU)
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+constexpr uint32_t OWNER_THREADS = TCNN_OWNER_THREADS;
+constexpr float OWNER_SAFE_ABS_SUM = 120.0f;  // < 128 = 2^31 / 2^24, with room for the fp32 rounding of the bound's own summation
+
+#if defined(TCNN_HOST_EMU)
+inline unsigned long owner_slice_stats[2] = {0, 0};  // emulator only: slices finished from the packed table / redone wide
 #endif
-			for (uint32_t t = threadIdx.x; t < n_over; t += SLICED_THREADS) {
-				const uint32_t* rec = overflow + (size_t)t * OW;
-				half_t* __restrict__ g = grid_gradient + (size_t)meta.offset[rec[0]] * F;
-				const uint32_t index = rec[1];
-				if constexpr (F == 1) {
-					const half_t v = (half_t)__builtin_bit_cast(float, rec[2]);
-					atomic_add_h2(g + (index & ~1u), (index & 1u) ? h2{(half_t)0.0f, v} : h2{v, (half_t)0.0f});
-				} else {
+
+// round(v * 2^24) for |v| < 128; saturates beyond (such a slice fails the bound and is redone in 64 bits).  A 16-bit float times
+// 2^24 is an integer already when the type is IEEE half (11 significant bits, exponent >= -24): the conversion instruction alone
+// (v_cvt_i32_f32 saturates and maps NaN to 0 -- written as asm because the C++ conversion is undefined out of range).
+TCNN_DEVICE int to_fixed32(float v) {
+#if defined(TCNN_HOST_EMU)
+	v = __builtin_fminf(__builtin_fmaxf(v, -127.0f), 127.0f);
+	return (int)__builtin_rintf(v * 16777216.0f);
+#else
+	float s = v * 16777216.0f;
+	if constexpr (HALF_IS_BF16) s = __builtin_rintf(s);  // bfloat16 products reach below 2^-24
+	int r;
+	asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(s));
+	return r;
+#endif
+}
+
+template <uint32_t D, uint32_t F, uint32_t THREADS>
+TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, uint32_t level, uint32_t j, uint32_t bucket, uint32_t chunk,
+                                     const BucketPlan& plan, uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues,
+                                     const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient, bool accumulate, unsigned char* lds_raw,
+                                     uint32_t lds_bytes, bool force_wide) {
+	static_assert(F % 2 == 0, "the packed owner pairs the features of a payload word");
+	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, PWP = BucketRecord<F>::PAIR_WORDS, OW = BucketRecord<F>::WORDS + 1;
+	constexpr uint32_t N_WAVES = THREADS / WAVE;
+	__shared__ float bound_parts[N_WAVES][F];
+	const uint32_t n_over = min(counters[plan.overflow_counter], plan.overflow_capacity);
+	const bool inline_overflow = n_over <= OVERFLOW_INLINE_MAX;
+	const uint32_t entries_per_bucket = 1u << plan.shift;
+	const uint32_t slice_begin = bucket * entries_per_bucket;
+	const uint32_t slice_count = slice_begin < lv.hashmap_size ? min(entries_per_bucket, lv.hashmap_size - slice_begin) : 0u;
+	const uint32_t cap = plan.capacity[j], n_chunks = plan.n_chunks[j];
+	const uint32_t queue = chunk * plan.n_buckets[j] + bucket;
+	const uint32_t count = min(counters[plan.counter_base[j] + queue], cap);  // in flight while the table is cleared
+	const uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)queue * cap) * PWP;  // `count` PAIRS of records
+	half_t* __restrict__ grad = grid_gradient + ((size_t)meta.offset[level] + slice_begin) * F;
+
+	// streams the queue (and this slice's share of the overflow list) through `add(index, payload)`
+	auto stream = [&](auto&& add) {
+		constexpr uint32_t U = PWP <= 3 ? 8 : (PWP <= 5 ? 4 : 2);  // pair records in flight per lane
+		for (uint32_t base = threadIdx.x; base < count; base += THREADS * U) {
+			uint32_t rec[U][PWP];
 #pragma unroll
-					for (uint32_t p = 0; p < PW; ++p) atomic_add_h2(g + (size_t)index * F + 2 * p, bits_h2(rec[2 + p]));
+			for (uint32_t u = 0; u < U; ++u) {
+				const uint32_t t = min(base + u * THREADS, count - 1u);
+#pragma unroll
+				for (uint32_t w = 0; w < PWP; ++w) rec[u][w] = queue_load(q + (size_t)t * PWP + w);
+			}
+			if (base + (U - 1) * THREADS < count) {  // all U records exist (every iteration but a lane's last): no per-record test
+#pragma unroll
+				for (uint32_t u = 0; u < U; ++u) {
+					add(rec[u][0] & PAIR_INDEX_MASK, &rec[u][1]);
+					if (rec[u][0] & PAIR_HAS_SECOND) add(pair_second_index<D>(lv, rec[u][0]), &rec[u][1 + PW]);
+				}
+			} else {
+#pragma unroll
+				for (uint32_t u = 0; u < U; ++u) {
+					if (base + u * THREADS >= count) continue;
+					add(rec[u][0] & PAIR_INDEX_MASK, &rec[u][1]);
+					if (rec[u][0] & PAIR_HAS_SECOND) add(pair_second_index<D>(lv, rec[u][0]), &rec[u][1 + PW]);
 				}
 			}
 		}
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			counters[plan.overflow_counter] = 0u;
-			counters[plan.overflow_counter + 1] = 0u;
+		if (inline_overflow && chunk == 0u) {  // overflow records of this slice (level, index): the first chunk's owner takes them
+			for (uint32_t t = threadIdx.x; t < n_over; t += THREADS) {
+				const uint32_t* rec = overflow + (size_t)t * OW;
+				if (rec[0] == level && (rec[1] >> plan.shift) == bucket) add(rec[1], rec + 2);
+			}
 		}
+	};
+	// one gradient pair leaves the slice: plain store for a sole owner, a packed atomic where sample chunks share the slice
+	auto store_pair = [&](uint32_t e2, h2 v) {
+		if (n_chunks == 1) {
+			if (accumulate) v += *(const h2*)(grad + 2 * e2);
+			*(h2*)(grad + 2 * e2) = v;
+		} else if (v[0] != (half_t)0.0f || v[1] != (half_t)0.0f) {
+			atomic_add_h2(grad + 2 * e2, v);  // small tables only: (table size) x (chunks) updates per level
+		}
+	};
+
+	bool safe = !force_wide;
+	if (safe) {
+		unsigned long long* tab = (unsigned long long*)lds_raw;  // [entries][PW]: features 2p (low word) and 2p + 1 (high word)
+		for (uint32_t e = threadIdx.x; e < slice_count * PW / 2; e += THREADS) ((u4*)lds_raw)[e] = u4{0u, 0u, 0u, 0u};  // slice_count is a multiple of 8
+		__syncthreads();
+		float bound[F];
+#pragma unroll
+		for (uint32_t f = 0; f < F; ++f) bound[f] = 0.0f;
+		stream([&](uint32_t index, const uint32_t* payload) {
+			const uint32_t rel = index & (entries_per_bucket - 1u);
+#pragma unroll
+			for (uint32_t p = 0; p < PW; ++p) {
+				const h2 v = bits_h2(payload[p]);
+				const float f0 = (float)v[0], f1 = (float)v[1];
+				bound[2 * p] += __builtin_fabsf(f0);
+				bound[2 * p + 1] += __builtin_fabsf(f1);
+				const int v0 = to_fixed32(f0), v1 = to_fixed32(f1);
+				const unsigned long long x = ((unsigned long long)(uint32_t)(v1 + (v0 >> 31)) << 32) | (unsigned long long)(uint32_t)v0;
+				lds_atomic_add_u64(&tab[rel * PW + p], x);
+			}
+		});
+		// the bound over the whole workgroup (NaN / Inf anywhere fail the comparison)
+#pragma unroll
+		for (uint32_t f = 0; f < F; ++f) {
+			const float w = wave_sum_f32(bound[f]);
+			if (lane_id() == 0) bound_parts[threadIdx.x / WAVE][f] = w;
+		}
+		__syncthreads();  // also: every atomic of the slice has landed
+#pragma unroll
+		for (uint32_t f = 0; f < F; ++f) {
+			float total = 0.0f;
+#pragma unroll
+			for (uint32_t w = 0; w < N_WAVES; ++w) total += bound_parts[w][f];
+			safe = safe && total < OWNER_SAFE_ABS_SUM;
+		}
+		if (safe) {
+			auto unpack = [&](uint32_t e2) {
+				const long long x = (long long)tab[e2];
+				const int s0 = (int)(uint32_t)(unsigned long long)x;
+				const int s1 = (int)((x - (long long)s0) >> 32);
+				// int32 -> fp32 rounds to nearest even exactly as the fp64 -> fp32 conversion of the wide form does
+				return h2{(half_t)((float)s0 * (1.0f / 16777216.0f)), (half_t)((float)s1 * (1.0f / 16777216.0f))};
+			};
+			if (n_chunks == 1 && !accumulate && ((uintptr_t)grad & 15u) == 0u) {  // sole owner, overwrite: 16 bytes per lane (slice_count * PW is a multiple of 8)
+				for (uint32_t e8 = threadIdx.x; e8 < slice_count * PW / 4; e8 += THREADS) {
+					const h2 a = unpack(4 * e8), b = unpack(4 * e8 + 1), c = unpack(4 * e8 + 2), d = unpack(4 * e8 + 3);
+					*(h8*)(grad + 8 * e8) = h8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+				}
+			} else {
+				for (uint32_t e2 = threadIdx.x; e2 < slice_count * PW; e2 += THREADS) store_pair(e2, unpack(e2));
+			}
+		}
+	}
+#if defined(TCNN_HOST_EMU)
+	if (threadIdx.x == 0) owner_slice_stats[safe ? 0 : 1]++;
+#endif
+	if (!safe) {
+		// 64 bits per value, `sub` entries at a time (the same LDS): each pass streams the queue again and keeps its own entries
+		unsigned long long* tab = (unsigned long long*)lds_raw;  // [sub][F]
+		const uint32_t sub = max(8u, (lds_bytes / (F * 8u)) & ~7u);
+		for (uint32_t sub_begin = 0; sub_begin < slice_count; sub_begin += sub) {
+			const uint32_t sub_count = min(sub, slice_count - sub_begin);
+			__syncthreads();  // the table is free (bound test / previous pass's conversion)
+			for (uint32_t e = threadIdx.x; e < sub_count * F / 2; e += THREADS) ((u4*)lds_raw)[e] = u4{0u, 0u, 0u, 0u};
+			__syncthreads();
+			stream([&](uint32_t index, const uint32_t* payload) {
+				const uint32_t rel = (index & (entries_per_bucket - 1u)) - sub_begin;
+				if (rel >= sub_count) return;
+#pragma unroll
+				for (uint32_t p = 0; p < PW; ++p) {
+					const h2 v = bits_h2(payload[p]);
+					lds_atomic_add_u64(&tab[rel * F + 2 * p], (unsigned long long)to_fixed((float)v[0]));
+					lds_atomic_add_u64(&tab[rel * F + 2 * p + 1], (unsigned long long)to_fixed((float)v[1]));
+				}
+			});
+			__syncthreads();
+			for (uint32_t e2 = threadIdx.x; e2 < sub_count * PW; e2 += THREADS) {
+				const long long q0 = ((const long long*)lds_raw)[2 * e2], q1 = ((const long long*)lds_raw)[2 * e2 + 1];
+				store_pair(sub_begin * PW + e2, h2{(half_t)(float)((double)q0 * (1.0 / FIXED_SCALE)), (half_t)(float)((double)q1 * (1.0 / FIXED_SCALE))});
+			}
+		}
+	}
+	bucket_owner_epilogue<F, THREADS>(meta, plan, j, queue, inline_overflow, n_over, counters, overflow, grid_gradient);
+}
+
+// The workgroups of pass B that own a (bucket, chunk), packed form; block -> item as in k_grid_backward_sliced, whose launch
+// (if the plan holds other kinds of items at all) skips the bucket items when this kernel runs them.
+template <uint32_t D, uint32_t F>
+__global__ void __launch_bounds__(OWNER_THREADS) k_grid_bucket_owner(const GridMeta meta, const SlicePlan plan, const int accumulate, const BucketPlan bplan,
+                                                                      uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues,
+                                                                      const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient,
+                                                                      const uint32_t lds_bytes, const int force_wide) {
+	TCNN_DYN_LDS(lds_raw);
+	uint32_t item = 0, local_block;
+	if (plan.blocks_per_item) {
+		item = blockIdx.x / plan.blocks_per_item;
+		local_block = blockIdx.x % plan.blocks_per_item;
+		if (local_block >= plan.block_begin[item + 1] - plan.block_begin[item]) return;
+	} else {
+		while (item + 1 < plan.n_items && blockIdx.x >= plan.block_begin[item + 1]) ++item;
+		local_block = blockIdx.x - plan.block_begin[item];
+	}
+	if (plan.kind[item] != SLICE_BUCKET) return;
+	const uint32_t level = plan.level[item], n_slices = plan.n_slices[item];
+	const uint32_t slice = local_block % n_slices, chunk = local_block / n_slices;
+	const Level<D> lv = make_level<D>(meta, level);
+	if constexpr (F % 2 == 0) {  // (never launched for odd F)
+		bucket_level_packed<D, F, OWNER_THREADS>(meta, lv, level, plan.slot[item], slice, chunk, bplan, counters, queues, overflow, grid_gradient,
+		                                         accumulate != 0, lds_raw, lds_bytes, force_wide != 0);
 	}
 }
 
@@ -1121,6 +1346,7 @@ __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const G
 	const Level<D> lv = make_level<D>(meta, level);
 
 	if (kind == SLICE_BUCKET) {
+		if (bplan.packed_owner) return;  // k_grid_bucket_owner runs them
 		bucket_level<D, F>(meta, lv, level, plan.slot[item], slice, chunk, bplan, counters, queues, overflow, grid_gradient, accumulate != 0, lds_raw, fused);
 		return;
 	}
@@ -1407,6 +1633,14 @@ static void grid_backward_atomic(hipStream_t stream, const GridMeta& meta, const
 #undef BWD
 }
 
+int& grid_owner_mode() {
+	static int mode = [] {
+		const char* e = getenv("TCNN_GRID_OWNER");
+		return !e ? 0 : (std::string(e) == "fixed64" ? 1 : (std::string(e) == "wide" ? 2 : 0));
+	}();
+	return mode;
+}
+
 // Host-side plan of one sliced / bucketed launch sequence.
 struct BackwardPlan {
 	SlicePlan slices = {};
@@ -1634,19 +1868,40 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 	} else if (ws.fused_adam && ws.fused_adam->fused_level) {
 		for (uint32_t l = 0; l < meta.n_levels; ++l) ws.fused_adam->fused_level[l] = false;
 	}
+	// bucket items: the packed owner kernel (even F) unless the optimizer step rides along or TCNN_GRID_OWNER=fixed64 asks for the
+	// 64-bit-per-value form; TCNN_GRID_OWNER=wide runs the packed kernel's own 64-bit redo on every slice (tests)
+	const int owner_mode = grid_owner_mode();
+	BucketPlan bk_launch = bk;
+	bk_launch.packed_owner = (bk.n_levels && F % 2 == 0 && !fused.enabled && owner_mode != 1) ? 1u : 0u;
+	bool other_items = false;
+	for (uint32_t p = 0; p < plan.n_items; ++p) other_items = other_items || plan.kind[p] != SLICE_BUCKET;
+	if (bk_launch.packed_owner) {
+		const uint32_t owner_lds = std::max((1u << bk.shift) * F * 4u, 8u * F * 8u);
+		const int force_wide = owner_mode == 2 ? 1 : 0;
+#define BOWNER(D_, F_)                                                                                                                       \
+	if constexpr (F_ % 2 == 0) {                                                                                                             \
+		TCNN_SET_MAX_DYN_LDS((k_grid_bucket_owner<D_, F_>), owner_lds);                                                                      \
+		TCNN_LAUNCH((k_grid_bucket_owner<D_, F_>), dim3(blocks), dim3(OWNER_THREADS), owner_lds, stream, meta, plan, acc, bk_launch, counters, \
+		            (const uint32_t*)queues, (const uint32_t*)overflow, grid_gradient, owner_lds, force_wide);                               \
+	}
+		TCNN_GRID_DISPATCH(BOWNER)
+#undef BOWNER
+	}
 #define BWDS(D_, F_)                                                                                                                   \
 	if (packed) {                                                                                                                      \
 		if constexpr (F_ % 2 == 0) {                                                                                                   \
 			TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, true>), lds_slice_bytes);                                             \
 			TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, true>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io, \
-			            plan, dL_dy, grid_gradient, acc, bk, counters, (const uint32_t*)queues, (const uint32_t*)overflow, fused);     \
+			            plan, dL_dy, grid_gradient, acc, bk_launch, counters, (const uint32_t*)queues, (const uint32_t*)overflow, fused); \
 		}                                                                                                                              \
 	} else {                                                                                                                           \
 		TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, false>), lds_slice_bytes);                                                \
 		TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, false>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io,    \
-		            plan, dL_dy, grid_gradient, acc, bk, counters, (const uint32_t*)queues, (const uint32_t*)overflow, fused);         \
+		            plan, dL_dy, grid_gradient, acc, bk_launch, counters, (const uint32_t*)queues, (const uint32_t*)overflow, fused);     \
 	}
-	TCNN_GRID_DISPATCH(BWDS)
+	if (!bk_launch.packed_owner || other_items) {
+		TCNN_GRID_DISPATCH(BWDS)
+	}
 #undef BWDS
 	if (ws.phase_hook) ws.phase_hook(ws.hook_user, 1, 0);
 }

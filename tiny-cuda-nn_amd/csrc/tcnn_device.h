@@ -164,6 +164,13 @@ TCNN_DEVICE void wave_lds_sync() {
 }
 #endif
 
+// Sum of `v` over the 64 lanes of a wavefront, in every lane (all lanes must call it; xor butterfly, fixed order).
+TCNN_DEVICE float wave_sum_f32(float v) {
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) v += __builtin_bit_cast(float, __shfl_xor(__builtin_bit_cast(int, v), d, 64));
+	return v;
+}
+
 // Scheduling fence: the compiler may not move instructions across it.  Bounds the live ranges of a long unrolled body
 // (the scheduler otherwise hoists every LDS/global read to the top of the block and runs out of registers).
 #if defined(TCNN_HOST_EMU)

@@ -139,6 +139,8 @@ _sig("tcnn_get_fused_network_passes", _i)
 _sig("tcnn_set_fused_network_passes", _i, _i)
 _sig("tcnn_set_grid_backward_mode", _i, _i)
 _sig("tcnn_get_grid_backward_mode", _i)
+_sig("tcnn_set_grid_owner_mode", _i, _i)
+_sig("tcnn_get_grid_owner_mode", _i)
 
 EXPORTED_SYMBOLS = [n for n in dir(_lib) if n.startswith("tcnn_")]
 
@@ -228,6 +230,16 @@ def get_grid_backward_mode():
 def set_grid_backward_mode(mode):
     """0: owner-computes LDS slices (fp32 accumulate, default); 1: same, packed fp16; 2: global atomics (A/B)."""
     _check(_lib.tcnn_set_grid_backward_mode(int(mode)))
+
+
+def get_grid_owner_mode():
+    return int(_lib.tcnn_get_grid_owner_mode())
+
+
+def set_grid_owner_mode(mode):
+    """Bucket owners of the bucketed grid backward: 0 packed accumulators (default), 1 64-bit fixed point per value, 2 the packed
+    kernel's wide redo on every slice (tests).  Same bits from all three."""
+    _check(_lib.tcnn_set_grid_owner_mode(int(mode)))
 
 
 def get_fused_network_passes():

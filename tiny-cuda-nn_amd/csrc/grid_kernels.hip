@@ -1145,7 +1145,7 @@ template <uint32_t D, uint32_t F, uint32_t THREADS>
 TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, uint32_t level, uint32_t j, uint32_t bucket, uint32_t chunk,
                                      const BucketPlan& plan, uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues,
                                      const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient, bool accumulate, unsigned char* lds_raw,
-                                     uint32_t lds_bytes, bool force_wide) {
+                                     uint32_t lds_bytes, bool force_wide, const FusedAdamArgs& fused) {
 	static_assert(F % 2 == 0, "the packed owner pairs the features of a payload word");
 	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, PWP = BucketRecord<F>::PAIR_WORDS, OW = BucketRecord<F>::WORDS + 1;
 	constexpr uint32_t N_WAVES = THREADS / WAVE;
@@ -1204,6 +1204,15 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 		}
 	};
 
+	// sole owner of the slice, overwrite: the optimizer step straight from the exact sums (GridFusedAdam), 4 parameters per lane
+	const bool step_here = fused.enabled && n_chunks == 1 && !accumulate;
+	const size_t p_first = ((size_t)meta.offset[level] + slice_begin) * F;  // relative to the grid's first parameter
+	auto store_quad_and_step = [&](uint32_t q4, h4 g) {
+		*(h4*)(grad + 4 * q4) = g;  // param_gradients stays what the stand-alone path leaves there
+		if (fused.stream) fused_adam4<true>(fused, p_first + 4 * q4, g);
+		else fused_adam4<false>(fused, p_first + 4 * q4, g);
+	};
+
 	bool safe = !force_wide;
 	if (safe) {
 		unsigned long long* tab = (unsigned long long*)lds_raw;  // [entries][PW]: features 2p (low word) and 2p + 1 (high word)
@@ -1247,7 +1256,12 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 				// int32 -> fp32 rounds to nearest even exactly as the fp64 -> fp32 conversion of the wide form does
 				return h2{(half_t)((float)s0 * (1.0f / 16777216.0f)), (half_t)((float)s1 * (1.0f / 16777216.0f))};
 			};
-			if (n_chunks == 1 && !accumulate && ((uintptr_t)grad & 15u) == 0u) {  // sole owner, overwrite: 16 bytes per lane (slice_count * PW is a multiple of 8)
+			if (step_here) {
+				for (uint32_t q4 = threadIdx.x; q4 < slice_count * PW / 2; q4 += THREADS) {
+					const h2 a = unpack(2 * q4), b = unpack(2 * q4 + 1);
+					store_quad_and_step(q4, h4{a[0], a[1], b[0], b[1]});
+				}
+			} else if (n_chunks == 1 && !accumulate && ((uintptr_t)grad & 15u) == 0u) {  // sole owner, overwrite: 16 bytes per lane (slice_count * PW is a multiple of 8)
 				for (uint32_t e8 = threadIdx.x; e8 < slice_count * PW / 4; e8 += THREADS) {
 					const h2 a = unpack(4 * e8), b = unpack(4 * e8 + 1), c = unpack(4 * e8 + 2), d = unpack(4 * e8 + 3);
 					*(h8*)(grad + 8 * e8) = h8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
@@ -1280,6 +1294,14 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 				}
 			});
 			__syncthreads();
+			if (step_here) {
+				for (uint32_t q4 = threadIdx.x; q4 < sub_count * PW / 2; q4 += THREADS) {
+					h4 g;
+#pragma unroll
+					for (uint32_t jj = 0; jj < 4; ++jj) g[jj] = (half_t)(float)((double)((const long long*)lds_raw)[4 * q4 + jj] * (1.0 / FIXED_SCALE));
+					store_quad_and_step(sub_begin * PW / 2 + q4, g);
+				}
+			} else
 			for (uint32_t e2 = threadIdx.x; e2 < sub_count * PW; e2 += THREADS) {
 				const long long q0 = ((const long long*)lds_raw)[2 * e2], q1 = ((const long long*)lds_raw)[2 * e2 + 1];
 				store_pair(sub_begin * PW + e2, h2{(half_t)(float)((double)q0 * (1.0 / FIXED_SCALE)), (half_t)(float)((double)q1 * (1.0 / FIXED_SCALE))});
@@ -1295,7 +1317,7 @@ template <uint32_t D, uint32_t F>
 __global__ void __launch_bounds__(OWNER_THREADS) k_grid_bucket_owner(const GridMeta meta, const SlicePlan plan, const int accumulate, const BucketPlan bplan,
                                                                       uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues,
                                                                       const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient,
-                                                                      const uint32_t lds_bytes, const int force_wide) {
+                                                                      const uint32_t lds_bytes, const int force_wide, const FusedAdamArgs fused) {
 	TCNN_DYN_LDS(lds_raw);
 	uint32_t item = 0, local_block;
 	if (plan.blocks_per_item) {
@@ -1312,7 +1334,7 @@ __global__ void __launch_bounds__(OWNER_THREADS) k_grid_bucket_owner(const GridM
 	const Level<D> lv = make_level<D>(meta, level);
 	if constexpr (F % 2 == 0) {  // (never launched for odd F)
 		bucket_level_packed<D, F, OWNER_THREADS>(meta, lv, level, plan.slot[item], slice, chunk, bplan, counters, queues, overflow, grid_gradient,
-		                                         accumulate != 0, lds_raw, lds_bytes, force_wide != 0);
+		                                         accumulate != 0, lds_raw, lds_bytes, force_wide != 0, fused);
 	}
 }
 
@@ -1872,7 +1894,7 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 	// 64-bit-per-value form; TCNN_GRID_OWNER=wide runs the packed kernel's own 64-bit redo on every slice (tests)
 	const int owner_mode = grid_owner_mode();
 	BucketPlan bk_launch = bk;
-	bk_launch.packed_owner = (bk.n_levels && F % 2 == 0 && !fused.enabled && owner_mode != 1) ? 1u : 0u;
+	bk_launch.packed_owner = (bk.n_levels && F % 2 == 0 && owner_mode != 1) ? 1u : 0u;
 	bool other_items = false;
 	for (uint32_t p = 0; p < plan.n_items; ++p) other_items = other_items || plan.kind[p] != SLICE_BUCKET;
 	if (bk_launch.packed_owner) {
@@ -1882,7 +1904,7 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 	if constexpr (F_ % 2 == 0) {                                                                                                             \
 		TCNN_SET_MAX_DYN_LDS((k_grid_bucket_owner<D_, F_>), owner_lds);                                                                      \
 		TCNN_LAUNCH((k_grid_bucket_owner<D_, F_>), dim3(blocks), dim3(OWNER_THREADS), owner_lds, stream, meta, plan, acc, bk_launch, counters, \
-		            (const uint32_t*)queues, (const uint32_t*)overflow, grid_gradient, owner_lds, force_wide);                               \
+		            (const uint32_t*)queues, (const uint32_t*)overflow, grid_gradient, owner_lds, force_wide, fused);                        \
 	}
 		TCNN_GRID_DISPATCH(BOWNER)
 #undef BOWNER

@@ -101,6 +101,11 @@ def grid_forward(g, params_h, positions, soa=True, out_stride=None, want_dy_dx=F
     return (out, dy_dx) if want_dy_dx else out
 
 
+def set_grid_forward_lds(limit_bytes, min_samples):
+    """Levels with tables up to limit_bytes are gathered out of LDS (k_grid_forward_lds) for batches of at least min_samples."""
+    lib().emu_set_grid_forward_lds(C.c_uint32(limit_bytes), C.c_uint32(min_samples))
+
+
 SLICED_F32, SLICED_F16, ATOMIC, BUCKETED = 0, 1, 2, 3
 
 

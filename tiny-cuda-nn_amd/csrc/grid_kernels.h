@@ -50,6 +50,12 @@ struct GridIO {
 void grid_forward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* params, half_t* out,
                   float* dy_dx);
 
+// Tuning knobs of the forward pass (process-wide): a level whose table is at most `grid_forward_lds_limit()` bytes (TCNN_GRID_FWD_LDS_BYTES;
+// default 0 = never: measured slower on MI355X) is gathered out of LDS by its own launch (k_grid_forward_lds) when the batch has at
+// least `grid_forward_lds_min_samples()` samples; same bits either way.
+uint32_t& grid_forward_lds_limit();
+uint32_t& grid_forward_lds_min_samples();
+
 // Backward into grid_gradient (half).  accumulate == false overwrites (GradientMode::Overwrite: any zeroing
 // the chosen mode needs is done here, the caller does not memset), true adds to what is there.
 //   SlicedF32 / SlicedF16: owner-computes LDS accumulation (fp32, or packed fp16 like the reference's own

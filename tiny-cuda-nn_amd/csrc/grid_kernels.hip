@@ -103,8 +103,30 @@ TCNN_DEVICE Cell<D> make_cell(const Level<D>& lv, const float (&x)[D]) {
 	return c;
 }
 
-template <uint32_t D>
+template <uint32_t D, bool TRY_PACKED = false>
 TCNN_DEVICE void load_position(const GridIO& io, uint32_t i, float (&x)[D]) {
+#if !defined(TCNN_HOST_EMU)
+	// (forward kernels only: in the record scatter the same load measured 8 us SLOWER than three strided dword loads)
+	if (TRY_PACKED && io.pos_stride_d == 1u && io.pos_stride_i == D) {
+		// sample-major contiguous positions (what every caller of the hot path passes): ONE D-dword load per lane instead of D
+		// strided ones (a 12-byte lane stride costs an instruction ~20 clk whatever its width; wave-uniform branch).  A buffer
+		// load, because the 4-byte-aligned 12-byte access is split into two by the compiler in its global form.
+		const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)io.positions, 0, (int)(io.n * D * 4u), 0x00020000);
+		// (the result is cast as a whole: indexing the builtin's vector_size type directly is miscompiled by ROCm 7.2's clang into
+		// one dword splat over all elements; the 16-byte form is narrowed to the 12 bytes that are used)
+		typedef float f2 __attribute__((ext_vector_type(2)));
+		if constexpr (D == 2) {
+			const f2 p = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(i * D * 4u), 0, 0));
+			x[0] = p[0];
+			x[1] = p[1];
+		} else {
+			const f4 p = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(i * D * 4u), 0, 0));
+#pragma unroll
+			for (uint32_t d = 0; d < D; ++d) x[d] = p[d];
+		}
+		return;
+	}
+#endif
 #pragma unroll
 	for (uint32_t d = 0; d < D; ++d) x[d] = io.positions[(size_t)i * io.pos_stride_i + (size_t)d * io.pos_stride_d];
 }
@@ -359,7 +381,7 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward_tiles(const GridM
 	const uint32_t first = tile * TILE;
 	float x[SPT][D];
 #pragma unroll
-	for (uint32_t s = 0; s < SPT; ++s) load_position<D>(io, min(first + s * GRID_THREADS + threadIdx.x, io.n - 1u), x[s]);
+	for (uint32_t s = 0; s < SPT; ++s) load_position<D, true>(io, min(first + s * GRID_THREADS + threadIdx.x, io.n - 1u), x[s]);
 	const Level<D> lv = make_level<D>(meta, level);
 	const half_t* __restrict__ grid = params + (size_t)meta.offset[level] * F;
 	const uint32_t n_features = meta.n_levels * F;
@@ -375,6 +397,67 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward_tiles(const GridM
 	} else {
 		grid_forward_tile<D, F, SPT, false>(lv, io, grid, level, first, x, out);
 	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward for the levels whose whole table fits a CU's LDS (the coarse levels of every configuration; all levels of the small
+// hash-table configurations): the workgroup copies the table into LDS once (coalesced 16-byte loads) and gathers its share of the
+// samples from there -- a random 4-byte LDS gather costs ~16 clk per wave instruction where the L2-resident gather above pays
+// ~148 (a quarter of that when the table happens to sit in the CU's L1), and none of it touches the L2's line rate, which is what
+// bounds the levels that stay in the tiled kernel.  One launch per such level (dynamic LDS = that table), 1024 threads, one
+// contiguous share of the samples per workgroup; same index / weight / fma-chain code as above: bit-identical output.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t FWD_LDS_THREADS = 1024;
+template <uint32_t D, uint32_t F, bool FAST>
+TCNN_DEVICE void grid_forward_lds_samples(const Level<D>& lv, const GridIO& io, const half_t* lds_grid, uint32_t level, uint32_t begin, uint32_t end,
+                                          half_t* __restrict__ out) {
+	constexpr uint32_t NP = (F + 1) / 2, NC = 1u << D, U = 2;  // U samples in flight per lane
+	for (uint32_t base = begin + threadIdx.x; base < end; base += FWD_LDS_THREADS * U) {
+		float x[U][D];
+#pragma unroll
+		for (uint32_t u = 0; u < U; ++u) load_position<D, true>(io, min(base + u * FWD_LDS_THREADS, end - 1u), x[u]);
+		Cell<D> c[U];
+		h2 val[U][NC][NP];
+#pragma unroll
+		for (uint32_t u = 0; u < U; ++u) {
+			c[u] = make_cell<D, FAST>(lv, x[u]);
+#pragma unroll
+			for (uint32_t idx = 0; idx < NC; ++idx) load_features<F>(lds_grid + (size_t)corner_index<D, FAST>(lv, c[u], idx) * F, val[u][idx]);
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < U; ++u) {
+			h2 result[NP];
+#pragma unroll
+			for (uint32_t p = 0; p < NP; ++p) result[p] = h2{(half_t)0.0f, (half_t)0.0f};
+#pragma unroll
+			for (uint32_t idx = 0; idx < NC; ++idx) {  // corner order and fp16 fma chain of grid.h:144-163
+				const half_t wh = to_half_rn(corner_weight<D>(c[u], idx));
+				const h2 w2 = h2{wh, wh};
+#pragma unroll
+				for (uint32_t p = 0; p < NP; ++p) result[p] = fma_h2(w2, val[u][idx][p], result[p]);
+			}
+			const uint32_t i = base + u * FWD_LDS_THREADS;
+			if (i < end) {
+#pragma unroll
+				for (uint32_t f = 0; f < F; ++f) out[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i] = result[f / 2][f % 2];
+			}
+		}
+	}
+}
+
+template <uint32_t D, uint32_t F>
+__global__ void __launch_bounds__(FWD_LDS_THREADS) k_grid_forward_lds(const GridMeta meta, const GridIO io, const uint32_t level, const uint32_t samples_per_block,
+                                                                       const half_t* __restrict__ params, half_t* __restrict__ out) {
+	TCNN_DYN_LDS(lds_raw);
+	const Level<D> lv = make_level<D>(meta, level);
+	const half_t* __restrict__ grid = params + (size_t)meta.offset[level] * F;
+	const uint32_t n_vec = lv.hashmap_size * F / 8u;  // 16-byte pieces: level sizes are multiples of 8 entries, the host checked the alignment
+	for (uint32_t e = threadIdx.x; e < n_vec; e += FWD_LDS_THREADS) ((u4*)lds_raw)[e] = ((const u4*)grid)[e];
+	__syncthreads();
+	const uint32_t begin = blockIdx.x * samples_per_block, end = min(begin + samples_per_block, io.n);
+	if (begin >= end) return;
+	if (lv.fast) grid_forward_lds_samples<D, F, true>(lv, io, (const half_t*)lds_raw, level, begin, end, out);
+	else grid_forward_lds_samples<D, F, false>(lv, io, (const half_t*)lds_raw, level, begin, end, out);
 }
 
 // =============================================================================================
@@ -1567,7 +1650,7 @@ __global__ void k_grid_indices(const GridMeta meta, const GridIO io, uint32_t* _
 // (<= 24 KiB), 8 for a hashed level (one L2 line per corner pair), 11 for a larger densely indexed level, each times
 // (1 + 1.5 x the share of fetches that miss the L2) for tables beyond the L2 (T = 2^22: 16 MiB per level, 2.4x the
 // time of a 2 MiB level).  Falls back to uniform costs if a run would need more than FWD_MAX_SEGMENTS segments.
-static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t tile_samples) {
+static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t tile_samples, const bool* skip_level = nullptr) {
 	for (int uniform = 0; uniform < 2; ++uniform) {
 		ForwardPlan plan = {};
 		plan.tiles = div_round_up(n, tile_samples);
@@ -1581,6 +1664,7 @@ static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t 
 			const double miss = std::max(0.0, 1.0 - 3.0 * 1048576.0 / (double)table_bytes);
 			const double base = table_bytes <= 24u * 1024u ? 4.0 : (pow2 ? 8.0 : 11.0);
 			cost[l] = uniform ? 16u : (uint32_t)(2.0 * base * (1.0 + 1.5 * miss) + 0.5);
+			if (skip_level && skip_level[l]) continue;  // gathered out of LDS by k_grid_forward_lds
 			total += (uint64_t)cost[l] * plan.tiles;
 		}
 		bool ok = true;
@@ -1588,6 +1672,7 @@ static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t 
 		uint32_t xcd = 0;
 		for (uint32_t l = 0; l < meta.n_levels && ok; ++l) {
 			uint32_t t = 0;
+			if (skip_level && skip_level[l]) continue;
 			while (t < plan.tiles) {
 				// XCD `xcd` takes items while the cost assigned so far stays below its cumulative share
 				const uint64_t limit = (total * (xcd + 1) + 7) / 8;
@@ -1611,9 +1696,46 @@ static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t 
 	throw std::runtime_error("grid_forward: could not build the work plan");
 }
 
+// LDS bytes up to which a level's table is gathered out of LDS (k_grid_forward_lds); TCNN_GRID_FWD_LDS_BYTES sets it, 0 = never (default:
+// on MI355X the path measures slower than the tiled kernel for every level it could take, see launch_forward_tiles)
+uint32_t& grid_forward_lds_limit() {
+	static uint32_t limit = getenv("TCNN_GRID_FWD_LDS_BYTES") ? (uint32_t)atoi(getenv("TCNN_GRID_FWD_LDS_BYTES")) : 0u;
+	return limit;
+}
+// batch sizes below this stay in the tiled kernel altogether (a table copy per workgroup needs samples to pay for it)
+uint32_t& grid_forward_lds_min_samples() {
+	static uint32_t n = 4096u;
+	return n;
+}
+
 template <uint32_t D, uint32_t F, uint32_t SPT>
 static void launch_forward_tiles(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* params, half_t* out) {
-	const ForwardPlan plan = make_forward_plan(meta, io.n, GRID_THREADS * SPT);
+	// levels that fit LDS first, one launch each; the tiled kernel takes the rest
+	bool in_lds[MAX_N_LEVELS] = {};
+	bool any_left = false;
+	const uint32_t limit = std::min(grid_forward_lds_limit(), 160u * 1024u);
+	const float max_level = (meta.max_level * (float)(meta.n_levels * F)) / (float)F;
+	const bool plain = meta.interp != (uint32_t)InterpolationType::Nearest && ((uintptr_t)params & 15u) == 0u && io.n >= grid_forward_lds_min_samples();
+	for (uint32_t l = 0; l < meta.n_levels; ++l) {
+		const size_t table_bytes = (size_t)(meta.offset[l + 1] - meta.offset[l]) * F * sizeof(half_t);
+		const bool level_off = (float)l >= max_level + 1e-3f;  // grid.h:75: the tiled kernel's rare-form path writes the zeros
+		in_lds[l] = plain && !level_off && table_bytes <= limit && ((size_t)meta.offset[l] * F * sizeof(half_t)) % 16u == 0u;
+		any_left = any_left || !in_lds[l];
+	}
+	// (Measured, profiles/r03_exp_notes.txt: these launches AHEAD of the tiled kernel cost more than the L1 / L2 gathers they replace,
+	// and BESIDE it -- a side stream forked and joined with events -- the event hand-offs alone add ~25 us per call.  Hence off by default.)
+	hipStream_t lds_stream = stream;
+	for (uint32_t l = 0; l < meta.n_levels; ++l) {
+		if (!in_lds[l]) continue;
+		const uint32_t table_bytes = (meta.offset[l + 1] - meta.offset[l]) * F * (uint32_t)sizeof(half_t);
+		// at most one workgroup per CU and launch (256), each with at least two samples per thread (the loop's unroll)
+		const uint32_t blocks = std::min(div_round_up(io.n, 2u * FWD_LDS_THREADS), 256u);
+		const uint32_t per_block = next_multiple(div_round_up(io.n, blocks), 64u);
+		TCNN_SET_MAX_DYN_LDS((k_grid_forward_lds<D, F>), table_bytes);
+		TCNN_LAUNCH((k_grid_forward_lds<D, F>), dim3(div_round_up(io.n, per_block)), dim3(FWD_LDS_THREADS), table_bytes, lds_stream, meta, io, l, per_block, params, out);
+	}
+	if (!any_left) return;
+	const ForwardPlan plan = make_forward_plan(meta, io.n, GRID_THREADS * SPT, in_lds);
 	uint32_t slots = 0;
 	for (uint32_t x = 0; x < 8; ++x) {
 		uint32_t n = 0;

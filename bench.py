@@ -82,7 +82,7 @@ WORKLOADS = {
 STAGE_KERNEL = {"grid_forward": "tcnn_hip::k_grid_forward_tiles", "mlp_forward": "tcnn_hip::k_mlp_forward", "loss": "tcnn_hip::k_loss",
                 "mlp_backward": "tcnn_hip::k_mlp_transpose_weights + k_mlp_backward + k_mlp_finalize_gradients",
                 "mlp_train_fused": "tcnn_hip::k_mlp_train_wave (128 neurons: k_mlp_train_wide; else k_mlp_train) + k_mlp_finalize_gradients",
-                "grid_backward_scatter": "tcnn_hip::k_grid_bucket_scatter", "grid_backward": "tcnn_hip::k_grid_backward_sliced",
+                "grid_backward_scatter": "tcnn_hip::k_grid_bucket_scatter", "grid_backward": "tcnn_hip::k_grid_bucket_owner",
                 "adam": "tcnn_hip::k_adam_step"}
 # the kernel with the largest share of a step in the rocprofv3 kernel statistics of each workload (profiles/r03_kernel_stats*.csv)
 DOMINANT = {"hash": "grid_forward", "mlp": "mlp_train_fused", "stress": "adam"}

@@ -13,7 +13,7 @@ STAGES = {  # stage -> [(kernel-name fragment, reads are wide streams?)]
     "mlp_backward": [("k_mlp_transpose_weights", True), ("k_mlp_backward", True), ("k_mlp_finalize_gradients", True)],
     "mlp_train_fused": [("k_mlp_transpose_weights", True), ("k_mlp_train", True), ("k_mlp_finalize_gradients", True)],
     "grid_backward_scatter": [("k_grid_bucket_scatter", False)],
-    "grid_backward": [("k_grid_backward_sliced", True)],
+    "grid_backward": [("k_grid_backward_sliced", True), ("k_grid_bucket_owner", True)],
     "adam": [("k_adam_step", True)],
 }
 fused = any("k_mlp_train" in name for name in summary)  # training_step ran the fused network kernel: the three-kernel stages did not run

@@ -1946,6 +1946,11 @@ int tcnn_trainer_set_profiling(tcnn_trainable_model_t* tm, int enable, int only_
 	} else {
 		tm->profiler = std::make_unique<Profiler>();
 		tm->profiler->only_stage = only_stage;
+		// events for the first steps exist before the caller's timed region begins (hipEventCreate costs host time: created on
+		// first use they slowed a 20-step measurement by ~5 %)
+		const size_t ahead = only_stage >= 0 ? 512 : 2048;
+		for (size_t i = 0; i < ahead; ++i) (void)tm->profiler->get();
+		tm->profiler->next = 0;
 	}
 	TCNN_API_END
 }

@@ -5,6 +5,7 @@
 //   src/network.cu:51-138
 // for the HashGrid + FullyFusedMLP hot path only.  Everything heavy happens in the kernel files.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <atomic>
 #include <functional>
@@ -697,9 +698,17 @@ static void model_forward(hipStream_t stream, const Model& md, uint32_t n, const
 	mlp_forward(stream, md.net.mlp, n, params, enc.as<half_t>(), hidden, output);
 }
 
+// The grid's parameter gradients in groups of consecutive levels, each reported as soon as its kernels are enqueued (data-parallel
+// hosts start that group's exchange while the next group is still being computed): `ready(ctx, begin, end)` with the parameter range
+// relative to the model's first parameter.
+struct LevelGroups {
+	uint32_t n_groups = 1;
+	void (*ready)(void* ctx, size_t begin, size_t end) = nullptr;
+	void* ctx = nullptr;
+};
 static void encoding_backward(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const half_t* dL_denc,
                               uint32_t stride_k, uint32_t stride_i, half_t* dL_dparams, bool want_grads, bool accumulate, const float* input,
-                              uint32_t lds_level_budget, const GridFusedAdam* fused_adam = nullptr);
+                              uint32_t lds_level_budget, const GridFusedAdam* fused_adam = nullptr, const LevelGroups* groups = nullptr);
 static uint32_t widest_matrix(const Model& md) {
 	uint32_t w = std::max(md.enc.padded_output_width, md.n_input_dims);
 	if (md.has_network) w = std::max(w, std::max(md.net.mlp.width * md.net.n_hidden_layers, md.net.mlp.padded_out));
@@ -770,9 +779,21 @@ static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx
 }
 
 // the encoding's share of the backward pass: dL_denc has element (feature k, sample i) at [k * stride_k + i * stride_i]
+// levels [a, b) of a grid as a grid of their own: the kernels index dL_dy and the gradients from the first of them
+static GridMeta grid_levels(const GridMeta& g, uint32_t a, uint32_t b) {
+	GridMeta s = g;
+	s.n_levels = b - a;
+	for (uint32_t l = 0; l <= b - a; ++l) s.offset[l] = g.offset[a + l] - g.offset[a];
+	for (uint32_t l = 0; l < b - a; ++l) {
+		s.scale[l] = g.scale[a + l];
+		s.resolution[l] = g.resolution[a + l];
+	}
+	return s;
+}
+
 static void encoding_backward(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const half_t* dL_denc,
                               uint32_t stride_k, uint32_t stride_i, half_t* dL_dparams, bool want_grads, bool accumulate, const float* input,
-                              uint32_t lds_level_budget, const GridFusedAdam* fused_adam) {
+                              uint32_t lds_level_budget, const GridFusedAdam* fused_adam, const LevelGroups* groups) {
 	const EncodingDesc& e = md.enc;
 	if (e.is_grid) {
 		GridIO io = {input, in_stride_i(md), in_stride_d(), n, stride_k, stride_i};
@@ -793,7 +814,28 @@ static void encoding_backward(hipStream_t stream, const Model& md, const Forward
 			ws.phase_hook = grid_backward_phase_hook;  // per-kernel timing when a profiler is attached
 			ws.hook_user = (void*)stream;
 			ws.fused_adam = mode == GridBackwardMode::Bucketed ? fused_adam : nullptr;
-			grid_backward(stream, e.grid, io, dL_denc, grid_grads, accumulate, mode, lds_level_budget, ws);
+			// level groups: only where a level's treatment does not depend on its index among ALL levels (every level switched on,
+			// no per-level random stream) and nothing else rides on the pass
+			const uint32_t L = e.grid.n_levels, F = e.grid.n_feat;
+			uint32_t n_groups = groups ? std::min(std::max(groups->n_groups, 1u), L) : 1u;
+			if (e.grid.max_level < 1.0f || e.grid.stochastic != 0u || fused_adam) n_groups = 1;
+			if (n_groups <= 1) {
+				grid_backward(stream, e.grid, io, dL_denc, grid_grads, accumulate, mode, lds_level_budget, ws);
+				if (groups && groups->ready) groups->ready(groups->ctx, md.n_mlp_params(), md.n_mlp_params() + (size_t)e.grid.offset[L] * F);
+			} else {
+				// consecutive levels, cut where the running parameter count passes k / n_groups of the total
+				uint32_t a = 0;
+				for (uint32_t k = 1; k <= n_groups && a < L; ++k) {
+					uint32_t b = a + 1;
+					const uint64_t target = (uint64_t)e.grid.offset[L] * k / n_groups;
+					while (b < L && (k == n_groups || e.grid.offset[b] < target)) ++b;
+					if (k == n_groups) b = L;
+					const GridMeta sub = grid_levels(e.grid, a, b);
+					grid_backward(stream, sub, io, dL_denc + (size_t)a * F * stride_k, grid_grads + (size_t)e.grid.offset[a] * F, accumulate, mode, lds_level_budget, ws);
+					if (groups->ready) groups->ready(groups->ctx, md.n_mlp_params() + (size_t)e.grid.offset[a] * F, md.n_mlp_params() + (size_t)e.grid.offset[b] * F);
+					a = b;
+				}
+			}
 		}
 		if (dL_dinput) {
 			if (!ctx.dy_dx.ptr) throw std::runtime_error("backward: dL_dinput requested but forward was not run with prepare_input_gradients");
@@ -916,7 +958,71 @@ struct tcnn_trainable_model {
 	// data-parallel hosts: called between backward and the optimizer (tcnn_trainer_set_gradient_exchange)
 	void (*exchange)(void* user, void* gradients_fp16, size_t n_params, tcnn_stream_t stream) = nullptr;
 	void* exchange_user = nullptr;
+	// data-parallel hosts that overlap the exchange with the backward pass (tcnn_trainer_set_gradient_ready_callback,
+	// tcnn_trainer_set_backward_level_groups, tcnn_trainer_enable_rccl)
+	void (*gradients_ready)(void* user, size_t begin, size_t end, tcnn_stream_t stream) = nullptr;
+	void* ready_user = nullptr;
+	uint32_t backward_level_groups = 1;
+	void* rccl_comm = nullptr;  // ncclComm_t
+	int rccl_ranks = 0;
+	hipStream_t comm_stream = nullptr;
+	std::vector<hipEvent_t> comm_events;
+	size_t comm_events_used = 0;
+	struct ReducedRange {
+		size_t begin, end;
+		hipEvent_t done;
+	};
+	std::vector<ReducedRange> reduced;  // this step's ranges whose all-reduce is in flight on comm_stream, in issue order
+	hipEvent_t comm_event() {
+		if (comm_events_used == comm_events.size()) {
+			hipEvent_t e;
+			HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+			comm_events.push_back(e);
+		}
+		return comm_events[comm_events_used++];
+	}
 };
+
+// RCCL, loaded at run time: the library links no collective library, a host that never asks for it never loads one
+struct Rccl {
+	void* handle = nullptr;
+	int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+	const char* (*error_string)(int) = nullptr;
+	static Rccl& get() {
+		static Rccl r = [] {
+			Rccl x;
+			for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+				x.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+				if (x.handle) break;
+			}
+			if (x.handle) {
+				x.all_reduce = (decltype(x.all_reduce))dlsym(x.handle, "ncclAllReduce");
+				x.error_string = (decltype(x.error_string))dlsym(x.handle, "ncclGetErrorString");
+			}
+			return x;
+		}();
+		return r;
+	}
+};
+constexpr int RCCL_SUM = 0, RCCL_HALF = 6, RCCL_BFLOAT16 = 9;  // rccl.h: ncclSum, ncclFloat16, ncclBfloat16
+
+// Gradients [begin, end) of this step are final once the work enqueued on `stream` so far has run: tell the host (callback) and /
+// or start their all-reduce on the communication stream, behind an event -- the rest of the backward pass keeps the compute
+// stream busy meanwhile.
+static void notify_gradients_ready(tcnn_trainable_model* tm, hipStream_t stream, size_t begin, size_t end) {
+	if (begin >= end) return;
+	if (tm->gradients_ready) tm->gradients_ready(tm->ready_user, begin, end, stream);
+	if (tm->rccl_comm) {
+		Rccl& r = Rccl::get();
+		hipEvent_t ready = tm->comm_event(), done = tm->comm_event();
+		HIP_CHECK(hipEventRecord(ready, stream));
+		HIP_CHECK(hipStreamWaitEvent(tm->comm_stream, ready, 0));
+		const int rc = r.all_reduce(tm->grads + begin, tm->grads + begin, end - begin, HALF_IS_BF16 ? RCCL_BFLOAT16 : RCCL_HALF, RCCL_SUM, tm->rccl_comm, tm->comm_stream);
+		if (rc != 0) throw std::runtime_error(std::string("ncclAllReduce failed: ") + (r.error_string ? r.error_string(rc) : "?"));
+		HIP_CHECK(hipEventRecord(done, tm->comm_stream));
+		tm->reduced.push_back({begin, end, done});
+	}
+}
 
 #define TCNN_API_BEGIN try {
 #define TCNN_API_END                             \
@@ -1484,9 +1590,16 @@ static void optimizer_advance(tcnn_trainable_model_t* tm, hipStream_t stream) {
 	}
 }
 
+// all-reduces this step started on the communication stream (tcnn_trainer_enable_rccl): `stream` continues behind them
+static void await_reduced_gradients(tcnn_trainable_model_t* tm, hipStream_t stream) {
+	for (const auto& r : tm->reduced) HIP_CHECK(hipStreamWaitEvent(stream, r.done, 0));
+	tm->reduced.clear();
+}
+
 static void optimizer_step_ranges(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale, size_t n_ranges, const size_t* begins, const size_t* ends,
                                   bool advance, bool opens_profiled_step) {
 	const size_t n = tm->md.n_params();
+	await_reduced_gradients(tm, stream);
 	for (size_t r = 0; r < n_ranges; ++r) {
 		if (begins[r] % 8 != 0 || begins[r] > std::min(ends[r], n)) throw std::runtime_error("optimizer_step_range: a range must start at a multiple of 8 and not end before it");
 	}
@@ -1533,12 +1646,70 @@ int tcnn_trainer_set_gradient_exchange(tcnn_trainable_model_t* tm, void (*exchan
 	return TCNN_OK;
 }
 
+// Hosts that overlap the exchange with the backward pass.  `ready(user, begin, end, stream)` is called on the host, during
+// training_step, as soon as the kernels that produce the gradients [begin, end) have been enqueued on `stream`: first the network's
+// weights [0, n_network_params), then the encoding's levels in `n_groups` groups of consecutive levels (equal parameter counts;
+// tcnn_trainer_set_backward_level_groups).  The ranges of one step tile [0, n_params) in ascending order, begins are multiples of 8.
+int tcnn_trainer_set_gradient_ready_callback(tcnn_trainable_model_t* tm, void (*ready)(void* user, size_t begin, size_t end, tcnn_stream_t stream), void* user) {
+	tm->gradients_ready = ready;
+	tm->ready_user = user;
+	return TCNN_OK;
+}
+int tcnn_trainer_set_backward_level_groups(tcnn_trainable_model_t* tm, uint32_t n_groups) {
+	tm->backward_level_groups = n_groups ? n_groups : 1u;
+	return TCNN_OK;
+}
+// Data parallelism without a callback: `nccl_comm` is the host's ncclComm_t for this rank (NULL switches it off again).  From then on
+// training_step all-reduces (sum) every gradient range on an internal communication stream as soon as it is ready -- RCCL is loaded
+// with dlopen at this point, the library does not link it -- and, with run_optimizer, steps each range when its own collective has
+// finished.  The host sets the global batch size (tcnn_trainer_set_global_batch_size) so that the sum is the global gradient.
+int tcnn_trainer_enable_rccl(tcnn_trainable_model_t* tm, void* nccl_comm, int n_ranks) {
+	TCNN_API_BEGIN
+	if (nccl_comm) {
+		const Rccl& r = Rccl::get();
+		if (!r.handle || !r.all_reduce) throw std::runtime_error("tcnn_trainer_enable_rccl: librccl.so could not be loaded");
+		if (!tm->comm_stream) HIP_CHECK(hipStreamCreateWithFlags(&tm->comm_stream, hipStreamNonBlocking));
+	}
+	tm->rccl_comm = nccl_comm;
+	tm->rccl_ranks = n_ranks;
+	tm->reduced.clear();
+	TCNN_API_END
+}
+
 // Adam's state for snapshots / sharded data parallelism: which = 0 first moments (fp32), 1 second moments (fp32),
 // 2 per-parameter step counters (u32; *steps_are_deficits tells their representation, see tcnn_trainer_optimizer_step_range).
 void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* steps_are_deficits) {
 	if (steps_are_deficits) *steps_are_deficits = tm->steps_are_deficits ? 1 : 0;
 	return which == 0 ? (void*)tm->m1 : which == 1 ? (void*)tm->m2 : which == 2 ? (void*)tm->steps : nullptr;
 }
+
+// The optimizer half of training_step.  With RCCL enabled every range whose all-reduce was started during the backward pass is
+// stepped as soon as ITS collective has finished (the later ones are still on the wire); otherwise the host's exchange hook, then
+// one optimizer step.
+static int finish_training_step(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale) {
+	if (tm->rccl_comm && !tm->reduced.empty()) {
+		TCNN_API_BEGIN
+		const std::vector<tcnn_trainable_model::ReducedRange> ranges = std::move(tm->reduced);
+		tm->reduced.clear();
+		if (ranges.front().begin != 0) throw std::runtime_error("training_step: the reduced gradient ranges do not start at parameter 0");
+		for (const auto& r : ranges) {
+			HIP_CHECK(hipStreamWaitEvent(stream, r.done, 0));
+			optimizer_step_ranges(tm, stream, loss_scale, 1, &r.begin, &r.end, /*advance=*/r.begin == 0, r.begin == 0);
+		}
+		TCNN_API_END
+	}
+	if (tm->exchange) tm->exchange(tm->exchange_user, tm->grads, tm->md.n_params(), stream);
+	return tcnn_trainer_optimizer_step(tm, stream, loss_scale);
+}
+struct ReadyTrampoline {
+	tcnn_trainable_model_t* tm;
+	hipStream_t stream;
+	static void call(void* self, size_t begin, size_t end) {
+		auto* t = (ReadyTrampoline*)self;
+		notify_gradients_ready(t->tm, t->stream, begin, end);
+	}
+};
+static bool wants_ready_ranges(const tcnn_trainable_model_t* tm) { return tm->gradients_ready || tm->rccl_comm; }
 
 // training_step fast path (g_fused_network_passes): encoding forward, ONE kernel for the network's forward + loss + backward, encoding
 // backward.  Same results as forward() + backward() (tests/test_emu_kernels.py); the returned context carries the
@@ -1604,13 +1775,16 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 		          need_denc ? denc.as<half_t>() : nullptr, want_grads ? partials.as<float>() : nullptr, external_dL_dy ? nullptr : c->block_sums.as<float>());
 		if (want_grads) mlp_finalize_gradients(stream, (uint32_t)md.n_mlp_params(), n_partials, partials.as<float>(), tm->grads, accumulate);
 	}
+	ReadyTrampoline tramp = {tm, stream};
+	LevelGroups level_groups = {tm->backward_level_groups, want_grads && wants_ready_ranges(tm) ? &ReadyTrampoline::call : nullptr, &tramp};
+	if (level_groups.ready) level_groups.ready(&tramp, 0, md.n_mlp_params());  // the network's gradients: the first range of the step
 	// The optimizer step of the bucketed levels happens inside the grid backward (GridFusedAdam) when this call owns the whole
 	// step: one GPU, gradients overwritten, plain Adam (no EMA copy to maintain), parameters the trainer's own.
 	bool fused_level[MAX_N_LEVELS] = {};
 	bool optimizer_opened = false;
 	if (need_denc) {
 		const size_t n_mlp = md.n_mlp_params();
-		const bool fuse = run_optimizer && tm->fused_optimizer && want_grads && !accumulate && e.is_grid && e.n_params > 0 && !tm->ema && !tm->exchange &&
+		const bool fuse = run_optimizer && tm->fused_optimizer && want_grads && !accumulate && e.is_grid && e.n_params > 0 && !tm->ema && !tm->exchange && !wants_ready_ranges(tm) &&
 		                  tm->global_batch == 0 && !use_inference_params && e.grid.stochastic == 0u &&
 		                  (GridBackwardMode)g_grid_backward_mode.load() == GridBackwardMode::Bucketed;
 		AdamCore core;
@@ -1629,7 +1803,7 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 			fa.fused_level = fused_level;
 		}
 		encoding_backward(stream, md, fc, n, dL_dinput, denc.as<half_t>(), n, 1u, tm->grads, want_grads, accumulate, input, tm->lds_level_budget,
-		                  fuse ? &fa : nullptr);
+		                  fuse ? &fa : nullptr, &level_groups);
 	}
 	*ctx_out = c.release();
 	if (run_optimizer && optimizer_opened) {  // the rest of the step: network weights and the levels the backward did not step
@@ -1648,8 +1822,7 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 		}
 		optimizer_step_ranges(tm, stream, loss_scale, begins.size(), begins.data(), ends.data(), /*advance=*/false, /*opens_profiled_step=*/true);
 	} else if (run_optimizer) {
-		if (tm->exchange) tm->exchange(tm->exchange_user, tm->grads, md.n_params(), stream);
-		return tcnn_trainer_optimizer_step(tm, stream, loss_scale);
+		return finish_training_step(tm, stream, loss_scale);
 	}
 	TCNN_API_END
 }
@@ -1659,6 +1832,8 @@ int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
                                const void* external_dL_dy, tcnn_train_context_t** ctx_out) {
 	const float loss_scale = LOSS_SCALE_FP16;  // trainer.h:265
 	tm->last_batch = n;
+	tm->reduced.clear();
+	tm->comm_events_used = 0;
 	tcnn_train_context_t* ctx = nullptr;
 	if (g_fused_network_passes.load() && tm->md.has_network && mlp_train_supported(tm->md.net.mlp) && (external_dL_dy || (target && loss_is_elementwise(tm->loss)))) {
 		int r = training_step_fused(tm, (hipStream_t)stream, loss_scale, n, input, target, data_pdf, dL_dinput, use_inference_params, gradient_mode,
@@ -1672,8 +1847,15 @@ int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
 	}
 	int r = tcnn_trainer_forward(tm, stream, loss_scale, n, input, target, data_pdf, use_inference_params, dL_dinput != nullptr, external_dL_dy, &ctx);
 	if (r == TCNN_OK) r = tcnn_trainer_backward(tm, stream, ctx, n, input, dL_dinput, use_inference_params, gradient_mode);
-	if (r == TCNN_OK && run_optimizer && tm->exchange) tm->exchange(tm->exchange_user, tm->grads, tm->md.n_params(), stream);
-	if (r == TCNN_OK && run_optimizer) r = tcnn_trainer_optimizer_step(tm, stream, loss_scale);
+	if (r == TCNN_OK && gradient_mode != TCNN_GRADIENT_IGNORE && wants_ready_ranges(tm)) {  // this path reports the whole buffer at once
+		try {
+			notify_gradients_ready(tm, (hipStream_t)stream, 0, tm->md.n_params());
+		} catch (const std::exception& ex) {
+			g_last_error = ex.what();
+			r = TCNN_ERROR;
+		}
+	}
+	if (r == TCNN_OK && run_optimizer) r = finish_training_step(tm, (hipStream_t)stream, loss_scale);
 	if (ctx_out && r == TCNN_OK) {
 		*ctx_out = ctx;
 	} else {

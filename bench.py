@@ -237,7 +237,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="hash")
     ap.add_argument("--precision", choices=["fp16", "bf16"], default="fp16", help="the library build: fp16 (libtcnn_hip.so) or bfloat16 (libtcnn_hip_bf16.so)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: 2^18 samples per GPU (weak) or 2^18 in total (strong)")
-    ap.add_argument("--dp", choices=["sharded", "allreduce"], default="sharded", help="N > 1: gradient exchange (tinycudann/parallel.py)")
+    ap.add_argument("--dp", choices=["sharded", "allreduce", "pipelined", "pipelined_sharded"], default="sharded",
+                    help="N > 1: gradient exchange (tinycudann/parallel.py); pipelined*: collectives started from inside the backward pass, per level group")
+    ap.add_argument("--level-groups", type=int, default=2, help="pipelined exchanges: level groups of the encoding's backward pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dominant", default="fixed", help="stage timed with HIP events inside the timed region (fixed: the workload's dominant kernel per rocprof, see DOMINANT; auto: the slowest stage of a short probe pass)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
@@ -275,7 +277,7 @@ def main():
     dp = None
     if world > 1:
         tm.set_global_batch_size(global_batch)
-        dp = par.DataParallel(tm, mode=args.dp)
+        dp = par.DataParallel(tm, mode=args.dp, level_groups=args.level_groups)
     batches = make_batches(w, local_batch, 4, seed=1337 + rank, device=device, tcnn=tcnn)
 
     def step(i):

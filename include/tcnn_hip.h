@@ -218,6 +218,21 @@ int tcnn_trainer_optimizer_step_ranges(tcnn_trainable_model_t* tm, tcnn_stream_t
  * library links no collective library itself.  exchange == NULL removes the hook. */
 int tcnn_trainer_set_gradient_exchange(tcnn_trainable_model_t* tm, void (*exchange)(void* user, void* gradients_fp16, size_t n_params, tcnn_stream_t stream),
                                        void* user);
+/* Exchange overlapped with the backward pass (no reference counterpart).  `ready(user, begin, end, stream)` is called on
+ * the host, inside training_step, as soon as the kernels that produce the gradients [begin, end) of the fp16 gradient buffer have been
+ * enqueued on `stream`: first the network's weights [0, n_network_params), then the encoding's levels in
+ * tcnn_trainer_set_backward_level_groups() groups of consecutive levels (about equal parameter counts; default 1).  The ranges of one
+ * step tile [0, n_params) in ascending order, begins are multiples of 8: a host starts that range's collective right there (behind an
+ * event on `stream`) while the later groups are still being computed, and finishes the step with
+ * tcnn_trainer_optimizer_step_range(s).  ready == NULL removes the hook. */
+int tcnn_trainer_set_gradient_ready_callback(tcnn_trainable_model_t* tm, void (*ready)(void* user, size_t begin, size_t end, tcnn_stream_t stream), void* user);
+int tcnn_trainer_set_backward_level_groups(tcnn_trainable_model_t* tm, uint32_t n_groups);
+/* Data parallelism inside the library: `nccl_comm` is this rank's ncclComm_t (RCCL; NULL switches it off).  training_step then
+ * all-reduces (sum) every ready range on an internal communication stream -- librccl.so is dlopen'ed by this call, the library does
+ * not link it -- and, with run_optimizer = 1, steps each range as soon as ITS collective has finished while the later ones are still
+ * on the wire; with run_optimizer = 0 the next tcnn_trainer_optimizer_step* call waits for them.  Set the global batch size
+ * (tcnn_trainer_set_global_batch_size) so that the sum of the ranks' gradients is the global gradient. */
+int tcnn_trainer_enable_rccl(tcnn_trainable_model_t* tm, void* nccl_comm, int n_ranks);
 /* Adam's state (device pointers, n_params elements each): which = 0 first moments (fp32), 1 second moments (fp32),
  * 2 per-parameter step counters (u32; *steps_are_deficits = 1: the array holds `optimizer steps done - counter`). */
 void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* steps_are_deficits);

@@ -111,6 +111,23 @@ class _CpuTrainer:
     def params_full_precision(self):
         return torch.from_numpy(self.w32)
 
+    # the gradient-ready interface of tinycudann.native.TrainableModel (tcnn_trainer_set_gradient_ready_callback): a "backward pass"
+    # that fills the gradient buffer range by range -- network weights, then the encoding's level groups -- and reports each
+    def set_backward_level_groups(self, n_groups):
+        self.level_groups = n_groups
+
+    def set_gradient_ready_callback(self, fn):
+        self.ready = fn
+
+    def backward_with(self, gradients, n_network=40):
+        g = torch.from_numpy(gradients.view(np.int16)).view(torch.half)
+        n = self.n_params
+        cuts = [0, n_network] + [n_network + (n - n_network) * k // self.level_groups // 8 * 8 for k in range(1, self.level_groups)] + [n]
+        for b, e in zip(cuts[:-1], cuts[1:]):
+            self.param_gradients[b:e].copy_(g[b:e])
+            if getattr(self, "ready", None):
+                self.ready(b, e)
+
     def optimizer_state(self):
         return torch.from_numpy(self.m1), torch.from_numpy(self.m2), torch.from_numpy(self.steps.view(np.int32)), False
 
@@ -147,10 +164,13 @@ def _dp_worker(rank, world, port, n, mode, out_dir):
     par = _load_parallel()
     par.init_from_env(backend="gloo")
     tm = _CpuTrainer(n)
-    dp = par.DataParallel(tm, mode=mode, n_buckets=3)
+    dp = par.DataParallel(tm, mode=mode, n_buckets=3, level_groups=3)
     assert dp.shard % 8 == 0 and dp.main <= n and n - dp.main < 8 * world
     for step in range(3):
-        tm.param_gradients.copy_(torch.from_numpy(_rank_gradients(n, rank, step).view(np.int16)).view(torch.half))
+        if mode.startswith("pipelined"):  # the collectives start from inside the backward pass, range by range
+            tm.backward_with(_rank_gradients(n, rank, step))
+        else:
+            tm.param_gradients.copy_(torch.from_numpy(_rank_gradients(n, rank, step).view(np.int16)).view(torch.half))
         dp.exchange_and_step()
     assert dp.comm_seconds() > 0
     own = dp.shard_range()
@@ -161,7 +181,7 @@ def _dp_worker(rank, world, port, n, mode, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
+@pytest.mark.parametrize("mode", ["sharded", "allreduce", "pipelined", "pipelined_sharded"])
 def test_data_parallel_exchange_matches_single_process(tmp_path, mode):
     n, world = 8 * 2 * 37 + 11, 2  # a tail of 11 parameters that no shard covers
     with socket.socket() as s:
@@ -177,6 +197,8 @@ def test_data_parallel_exchange_matches_single_process(tmp_path, mode):
     for r, d in enumerate(ranks):
         assert np.array_equal(d["params"], ref.params.numpy().view(np.uint16)), (mode, r)  # replicas identical to the single-process run
         assert np.array_equal(d["w32"], ref.w32) and np.array_equal(d["m1"], ref.m1) and np.array_equal(d["m2"], ref.m2) and np.array_equal(d["steps"], ref.steps)
+        if mode == "pipelined_sharded":  # a rank held the state of its own shard of EVERY range (and the ranges' tails)
+            assert not np.array_equal(d["m1_before_gather"], ref.m1) and np.count_nonzero(d["m1_before_gather"]) < 0.75 * np.count_nonzero(ref.m1)
         if mode == "sharded":  # before the gather a rank held the optimizer state of its own shard (and the tail) only
             b, e = d["own"]
             other = np.ones(n, bool)

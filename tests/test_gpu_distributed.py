@@ -70,7 +70,7 @@ def _worker(rank, world, port, out_path, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", [None, "sharded", "allreduce"])
+@pytest.mark.parametrize("mode", [None, "sharded", "allreduce", "pipelined", "pipelined_sharded"])
 def test_two_ranks_on_one_gpu_match_single_process(tmp_path, mode):
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -100,3 +100,81 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path, mode):
     nm = tm.n_mlp_params
     assert float(d[:nm].max()) < 2e-2 and float(torch.quantile(d[:nm], 0.99)) < 3e-3
     assert float((d[nm:] > 0.05 * ref[nm:].abs().max()).float().mean()) < 1e-3
+
+
+def test_level_group_backward_reports_every_range_and_gives_the_same_gradients():
+    """tcnn_trainer_set_backward_level_groups / _set_gradient_ready_callback: the encoding's backward pass in groups of consecutive
+    levels, each reported (after the network's weights) as soon as its kernels are enqueued -- the ranges tile the gradient buffer in
+    ascending order on multiples of 8, and the gradients are bit for bit those of the ungrouped pass."""
+    x, t = _data()
+    x, t = x.cuda(), t.cuda()
+    ref = _model()
+    ref.training_step(x, t, run_optimizer=False)
+    want = ref.param_gradients.clone()
+    for n_groups in (1, 3, 16, 40):
+        tm = _model()
+        ranges = []
+        tm.set_backward_level_groups(n_groups)
+        tm.set_gradient_ready_callback(lambda b, e: ranges.append((b, e)))
+        tm.training_step(x, t, run_optimizer=False)
+        torch.cuda.synchronize()
+        assert ranges[0] == (0, tm.n_mlp_params) and ranges[-1][1] == tm.n_params
+        assert len(ranges) == 2 if n_groups == 1 else 2 < len(ranges) <= 1 + min(n_groups, 16)  # groups hold about equal parameter counts: coarse levels share one
+        assert all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:])) and all(b % 8 == 0 for b, _ in ranges)
+        assert torch.equal(tm.param_gradients.view(torch.int16), want.view(torch.int16)), n_groups
+        tm.set_gradient_ready_callback(None)
+
+
+def _rccl_single_rank_comm():
+    import ctypes as C
+    try:
+        lib = C.CDLL("librccl.so.1")
+    except OSError:
+        try:
+            lib = C.CDLL("/opt/rocm/lib/librccl.so.1")
+        except OSError:
+            return None, None
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert lib.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rc = lib.ncclCommInitRank(C.byref(comm), 1, uid, 0)
+    assert rc == 0, rc
+    return lib, comm
+
+
+def test_rccl_all_reduce_inside_the_library_on_one_rank():
+    """tcnn_trainer_enable_rccl: the trainer all-reduces every ready gradient range with RCCL itself (librccl.so loaded at run time,
+    communication stream + events) and steps each range behind its collective.  One GPU holds one rank: the communicator has a
+    single rank, the sum is the identity, and the trajectory must be bit for bit the plain one -- with the optimizer inside
+    training_step and as a separate call."""
+    lib, comm = _rccl_single_rank_comm()
+    if lib is None:
+        pytest.skip("librccl.so not found")
+    x, t = _data()
+    x, t = x.cuda(), t.cuda()
+    plain = _model()
+    for _ in range(STEPS):
+        plain.training_step(x, t)
+    for separate_optimizer in (False, True):
+        tm = _model()
+        tm.set_backward_level_groups(3)
+        tm.enable_rccl(comm.value, 1)
+        tm.set_global_batch_size(N)
+        for _ in range(STEPS):
+            if separate_optimizer:
+                tm.training_step(x, t, run_optimizer=False)
+                tm.optimizer_step()
+            else:
+                tm.training_step(x, t)
+        torch.cuda.synchronize()
+        assert tm.optimizer_step_count == STEPS
+        assert torch.equal(tm.params_full_precision, plain.params_full_precision), separate_optimizer
+        tm.enable_rccl(None, 0)
+    assert "librccl" in open("/proc/self/maps").read()
+    lib.ncclCommDestroy.argtypes = [type(comm)]
+    lib.ncclCommDestroy(comm)

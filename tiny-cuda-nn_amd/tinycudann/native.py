@@ -205,6 +205,27 @@ class TrainableModel:
     def set_global_batch_size(self, n):
         _check(_lib.tcnn_trainer_set_global_batch_size(self._h, int(n)))
 
+    # ---- exchange overlapped with the backward pass (tinycudann/parallel.py) ---------------------
+    def set_gradient_ready_callback(self, fn):
+        """fn(begin, end) is called inside training_step as soon as the kernels producing the gradients [begin, end) have been
+        enqueued on the current stream (network weights first, then the encoding's level groups); None removes the hook."""
+        from ._C import GRADIENT_READY_FN
+        if fn is None:
+            self._ready_cb = None
+            _check(_lib.tcnn_trainer_set_gradient_ready_callback(self._h, None, None))
+            return
+        self._ready_cb = GRADIENT_READY_FN(lambda user, begin, end, stream: fn(int(begin), int(end)))  # kept alive by the model
+        _check(_lib.tcnn_trainer_set_gradient_ready_callback(self._h, C.cast(self._ready_cb, C.c_void_p), None))
+
+    def set_backward_level_groups(self, n_groups):
+        """The encoding's backward pass in n_groups groups of consecutive levels, each reported through the ready callback."""
+        _check(_lib.tcnn_trainer_set_backward_level_groups(self._h, int(n_groups)))
+
+    def enable_rccl(self, nccl_comm, n_ranks):
+        """nccl_comm: this rank's ncclComm_t as an integer / c_void_p (None switches it off).  training_step then all-reduces every
+        gradient range inside the library (RCCL loaded with dlopen) and steps each range when its collective has finished."""
+        _check(_lib.tcnn_trainer_enable_rccl(self._h, C.c_void_p(nccl_comm) if nccl_comm else None, int(n_ranks)))
+
     # ---- measurement hooks ---------------------------------------------------------------------
     def set_profiling(self, enable=True, only_stage=None):
         """HIP events around the stages of the training step, on the stream the kernels run on."""

@@ -14,6 +14,12 @@ Two exchange schemes (class DataParallel):
     parameters.  fp32 master weights and Adam moments exist only on the owning rank (gather_optimizer_state() collects
     them for a snapshot).
   * "allreduce": bucketed all-reduce, identical Adam on every rank, each bucket stepped as soon as it is summed.
+  * "pipelined" / "pipelined_sharded": the same two exchanges, but started DURING the backward pass: the trainer reports every
+    gradient range as soon as the kernels that produce it are enqueued (network weights first, then the encoding's levels in
+    `level_groups` groups; tcnn_trainer_set_gradient_ready_callback), the collective of that range is issued right there
+    (asynchronously: it waits for exactly the work enqueued so far) and travels while the remaining groups are still being
+    computed; exchange_and_step() then only waits range by range and steps the optimizer.  Same sums, same optimizer
+    arithmetic: bit-identical to the unpipelined schemes (tests/test_distributed.py).
 Gradients are summed in fp16: every rank's buffer is already normalised by the GLOBAL batch, so the partial sums of a
 ring are bounded by the single-GPU gradient's own magnitude (tests/test_distributed.py checks P = 8 at loss scale 128)."""
 import os
@@ -92,8 +98,8 @@ class DataParallel:
     """Gradient exchange + optimizer of one data-parallel rank.  `tm`: a tinycudann.native.TrainableModel (or anything with
     param_gradients / params / params_inference / n_params / optimizer_step / optimizer_step_range(s) / optimizer_state)."""
 
-    def __init__(self, tm, mode="sharded", loss_scale=128.0, n_buckets=None):
-        if mode not in ("sharded", "allreduce"):
+    def __init__(self, tm, mode="sharded", loss_scale=128.0, n_buckets=None, level_groups=2):
+        if mode not in ("sharded", "allreduce", "pipelined", "pipelined_sharded"):
             raise ValueError(f"unknown data-parallel mode {mode!r}")
         self.tm, self.mode, self.loss_scale, self.n_buckets = tm, mode, loss_scale, n_buckets
         self.active = dist.is_initialized() and dist.get_world_size() > 1
@@ -114,6 +120,12 @@ class DataParallel:
         self._events = []
         self._stage = {}
         self._has_reduce_scatter = self._has_all_gather_into = True
+        # pipelined schemes: collectives issued from the trainer's gradient-ready hook, in flight until exchange_and_step()
+        self._pending = []
+        self.pipelined = mode.startswith("pipelined")
+        if self.pipelined and self.active:
+            tm.set_backward_level_groups(max(1, int(level_groups)))
+            tm.set_gradient_ready_callback(self._on_ready)
 
     def _fetch_params(self):
         if not self._params_fetched:
@@ -200,6 +212,77 @@ class DataParallel:
                 self._has_all_gather_into = False
         dist.all_gather([buf[r * self.shard:(r + 1) * self.shard] for r in range(self.world)], own)
 
+    # ---- pipelined schemes: one collective per ready range, started from inside training_step --------------------------------
+    def _segment(self, begin, end):
+        """Shard layout of the range [begin, end) on its own: (shard, main) with main = shard * world <= end - begin."""
+        shard = ((end - begin) // (8 * self.world)) * 8
+        return shard, shard * self.world
+
+    def _on_ready(self, begin, end):
+        """Gradient-ready hook (host side, inside tm.training_step): the kernels producing grads[begin:end] are enqueued on the
+        current stream; an asynchronous collective issued now waits for exactly that work."""
+        g = self.grads
+        if self.mode == "pipelined":
+            self._pending.append((begin, end, [dist.all_reduce(g[begin:end], op=dist.ReduceOp.SUM, async_op=True)], None))
+            return
+        shard, main = self._segment(begin, end)
+        works, out = [], None
+        if main:
+            if self._has_reduce_scatter:
+                try:
+                    out = torch.empty(shard, dtype=g.dtype, device=g.device)
+                    works.append(dist.reduce_scatter_tensor(out, g[begin:begin + main], op=dist.ReduceOp.SUM, async_op=True))
+                except (RuntimeError, NotImplementedError):
+                    self._has_reduce_scatter, out = False, None  # gloo: no reduce-scatter
+            if out is None:
+                works.append(dist.all_reduce(g[begin:begin + main], op=dist.ReduceOp.SUM, async_op=True))
+        if begin + main < end:
+            works.append(dist.all_reduce(g[begin + main:end], op=dist.ReduceOp.SUM, async_op=True))
+        self._pending.append((begin, end, works, out))
+
+    def _finish_pipelined(self):
+        pending, self._pending = self._pending, []
+        self._last_ranges = [(b, e) for b, e, _, _ in pending]
+        if not pending or pending[0][0] != 0 or pending[-1][1] != self.n:
+            raise RuntimeError("pipelined exchange: the trainer did not report the whole gradient buffer (call training_step(run_optimizer=False) first)")
+        if self.mode == "pipelined":
+            for begin, end, works, _ in pending:  # ascending, the range starting at 0 first: what optimizer_step_range asks for
+                for w in works:
+                    w.wait()
+                self.tm.optimizer_step_range(begin, end, self.loss_scale)
+            return
+        ranges = []
+        for begin, end, works, out in pending:
+            for w in works:
+                w.wait()
+            shard, main = self._segment(begin, end)
+            if main:
+                own = begin + self.rank * shard
+                if out is not None:
+                    self.grads[own:own + shard].copy_(out)
+                ranges.append((own, own + shard))
+            if begin + main < end:
+                ranges.append((begin + main, end))
+        self.tm.optimizer_step_ranges(ranges, self.loss_scale)
+        for buf in (self.params, self.params_inference):
+            if buf is None:
+                continue
+            works = []
+            for begin, end, _, _ in pending:
+                shard, main = self._segment(begin, end)
+                if not main:
+                    continue
+                own = buf[begin + self.rank * shard:begin + (self.rank + 1) * shard].clone()
+                if self._has_all_gather_into:
+                    try:
+                        works.append(dist.all_gather_into_tensor(buf[begin:begin + main], own, async_op=True))
+                        continue
+                    except (RuntimeError, NotImplementedError):
+                        self._has_all_gather_into = False
+                works.append(dist.all_gather([buf[begin + r * shard:begin + (r + 1) * shard] for r in range(self.world)], own, async_op=True))
+            for w in works:
+                w.wait()
+
     # ---- one step ------------------------------------------------------------------------------------------------------
     def exchange_and_step(self):
         """Call after training_step(run_optimizer=False): exchanges the gradients and runs the optimizer."""
@@ -207,7 +290,9 @@ class DataParallel:
             self.tm.optimizer_step(self.loss_scale)
             return
         start = self._tic()
-        if self.mode == "allreduce":
+        if self.pipelined:
+            self._finish_pipelined()
+        elif self.mode == "allreduce":
             reduce_and_step(self.tm, self.grads, self.n_buckets, self.loss_scale)
         else:
             if self.main:
@@ -226,11 +311,19 @@ class DataParallel:
     def gather_optimizer_state(self):
         """Sharded mode: collects the fp32 master weights and Adam's state from their owners so that this rank can write a
         complete snapshot (Trainer::serialize with the optimizer, trainer.h:442-455)."""
-        if not self.active or self.mode != "sharded" or not self.main:
+        if not self.active or self.mode not in ("sharded", "pipelined_sharded") or not self.main:
             return
         m1, m2, steps, _ = self.tm.optimizer_state()
-        for buf in (self.tm.params_full_precision, m1, m2, steps):
-            self._all_gather(buf)
+        if self.mode == "sharded":
+            for buf in (self.tm.params_full_precision, m1, m2, steps):
+                self._all_gather(buf)
+            return
+        for buf in (self.tm.params_full_precision, m1, m2, steps):  # the owners' shards of every range of the last step
+            for begin, end in self._last_ranges:
+                shard, main = self._segment(begin, end)
+                if main:
+                    dist.all_gather([buf[begin + r * shard:begin + (r + 1) * shard] for r in range(self.world)],
+                                    buf[begin + self.rank * shard:begin + (self.rank + 1) * shard].clone())
 
 
 def all_reduce_max(value, device="cpu"):

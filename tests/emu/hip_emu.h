@@ -128,6 +128,25 @@ inline int wave_shfl_xor(int v, int mask) {
 	return out;
 }
 
+// sum over the wave in the xor-butterfly order of the device code (one rendezvous instead of six shuffles)
+inline float wave_sum_f32(float v) {
+	Wave& w = g.waves[g.cur->tidx.x / 64];
+	const unsigned lane = g.cur->tidx.x & 63u;
+	memcpy(&w.b[lane], &v, sizeof(float));
+	wave_barrier();
+	float vals[64], next[64];
+	for (unsigned l = 0; l < 64; ++l) {
+		if (l < w.size) memcpy(&vals[l], &w.b[l], sizeof(float));
+		else vals[l] = 0.0f;
+	}
+	for (unsigned d = 32; d > 0; d >>= 1) {
+		for (unsigned l = 0; l < 64; ++l) next[l] = vals[l] + vals[l ^ d];
+		memcpy(vals, next, sizeof(vals));
+	}
+	wave_barrier();
+	return vals[lane];
+}
+
 inline void trampoline() {
 	g.fn();
 	g.cur->done = true;

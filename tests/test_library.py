@@ -194,16 +194,21 @@ def test_no_mfma_result_is_read_too_soon_after_a_taken_branch(tmp_path, build):
         assert r.returncode == 0, r.stderr[-2000:]
         return str(out)
 
+    # the five compilations side by side (each is a single-threaded hipcc run of 10-20 s)
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = [("mlp_kernels", ()), ("mlp_train_wave", ()), ("mlp_train_wide", ()), ("mlp_train_wave", ("-DTCNN_EXP_RUNTIME_EXTERNAL",)),
+            ("mlp_train_wave", ("-DTCNN_EXP_RUNTIME_EXTERNAL", "-DTCNN_EXP_NOP_AFTER_OUTPUT_MFMA=7"))]
+    with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
+        files = list(pool.map(lambda j: isa(j[0], list(j[1])), jobs))
     n_mfma = 0
-    for name in ("mlp_kernels", "mlp_train_wave", "mlp_train_wide"):
-        for kernel, items in chk.parse(isa(name)).items():
+    for path in files[:3]:
+        for kernel, items in chk.parse(path).items():
             n_mfma += sum(1 for k, t in items if k == "inst" and t.startswith("v_mfma"))
             assert chk.check_kernel(kernel, items) == [], kernel
     assert n_mfma > 5000  # the scan saw the kernels
     # positive control: the run-time branch behind the output layer's MFMA (the form that failed on the GPU)
-    flagged = [f for kernel, items in chk.parse(isa("mlp_train_wave", ["-DTCNN_EXP_RUNTIME_EXTERNAL"])).items() for f in chk.check_kernel(kernel, items)]
+    flagged = [f for kernel, items in chk.parse(files[3]).items() for f in chk.check_kernel(kernel, items)]
     assert any("k_mlp_train_waveILj64ELj32ELj1" in f for f in flagged), flagged
     # ... and two wait states in front of that branch are what cured it
-    cured = [f for kernel, items in chk.parse(isa("mlp_train_wave", ["-DTCNN_EXP_RUNTIME_EXTERNAL", "-DTCNN_EXP_NOP_AFTER_OUTPUT_MFMA=7"])).items()
-             for f in chk.check_kernel(kernel, items) if "k_mlp_train_waveILj64ELj32ELj1" in f]
+    cured = [f for kernel, items in chk.parse(files[4]).items() for f in chk.check_kernel(kernel, items) if "k_mlp_train_waveILj64ELj32ELj1" in f]
     assert cured == [], cured

@@ -166,6 +166,9 @@ TCNN_DEVICE void wave_lds_sync() {
 
 // Sum of `v` over the 64 lanes of a wavefront, in every lane (all lanes must call it; xor butterfly, fixed order).
 TCNN_DEVICE float wave_sum_f32(float v) {
+#if defined(TCNN_HOST_EMU)
+	return ::emu::wave_sum_f32(v);
+#endif
 #pragma unroll
 	for (int d = 32; d > 0; d >>= 1) v += __builtin_bit_cast(float, __shfl_xor(__builtin_bit_cast(int, v), d, 64));
 	return v;

@@ -118,6 +118,11 @@ public:
 	// data parallelism (no reference counterpart; see tcnn_hip.h)
 	void set_global_batch_size(uint64_t n) { check(tcnn_trainer_set_global_batch_size(m_h->tm, n)); }
 	void set_gradient_exchange(void (*exchange)(void*, void*, size_t, tcnn_stream_t), void* user) { check(tcnn_trainer_set_gradient_exchange(m_h->tm, exchange, user)); }
+	// exchange overlapped with the backward pass: `ready` is called inside training_step for every gradient range as soon as its kernels
+	// are enqueued (network weights, then the encoding's level groups); or hand the library this rank's ncclComm_t and let it all-reduce
+	void set_backward_level_groups(uint32_t n_groups) { check(tcnn_trainer_set_backward_level_groups(m_h->tm, n_groups)); }
+	void set_gradient_ready_callback(void (*ready)(void*, size_t, size_t, tcnn_stream_t), void* user) { check(tcnn_trainer_set_gradient_ready_callback(m_h->tm, ready, user)); }
+	void enable_rccl(void* nccl_comm, int n_ranks) { check(tcnn_trainer_enable_rccl(m_h->tm, nccl_comm, n_ranks)); }
 	tcnn_trainable_model_t* c_handle() const { return m_h->tm; }
 
 private:

@@ -25,7 +25,10 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
                   against the 8 TB/s HBM peak; `stages` holds the same figure for EVERY stage, from the instrumented pass;
   cpu_baseline -- the CPU oracle ("port": the reference has no CPU path and cannot be built here) timed on
                   this box's host cores on the same workload and the same first batch (rank 0, --gpus 1 only);
-  stages_ms    -- per-stage mean times of a second, fully instrumented pass (not part of `value`).
+  stages_ms    -- per-stage mean times of a separate, fully instrumented pass of min(steps, 50) untimed steps (not part of `value`).
+                  It runs BEFORE the warm-up steps (--breakdown before, the default; `untimed_steps_before_timing` says so in the
+                  line): the first ~30 steps after an idle phase run 4-8 % below the device's steady state (clocks; measured,
+                  scripts/exp_first_steps.py), so the timed region of a short run would otherwise report the ramp, not the step.
 
 With --gpus 1 (no torch.distributed launcher) the measurement runs in a worker process and this process only relays its line:
 a worker that dies abnormally (a GPU memory-access fault aborts the process inside the HIP runtime, nothing can be caught
@@ -241,6 +244,8 @@ def main():
                     help="N > 1: gradient exchange (tinycudann/parallel.py); pipelined*: collectives started from inside the backward pass, per level group")
     ap.add_argument("--level-groups", type=int, default=2, help="pipelined exchanges: level groups of the encoding's backward pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", choices=["before", "after"], default="before",
+                    help="the fully instrumented per-stage pass (min(steps, 50) untimed steps) runs before the warm-up steps (default) or after the timed region")
     ap.add_argument("--dominant", default="fixed", help="stage timed with HIP events inside the timed region (fixed: the workload's dominant kernel per rocprof, see DOMINANT; auto: the slowest stage of a short probe pass)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--lds-budget", type=int, default=None, help="grid backward: LDS bytes per level table (tuning knob)")
@@ -288,6 +293,26 @@ def main():
         else:
             tm.training_step(x, t, want_context=False)
 
+    def breakdown_pass():
+        """Fully instrumented steps (HIP events around every stage): the per-stage breakdown of the line; not part of `value`."""
+        n_cold = 3  # the very first steps allocate the scratch blocks and load the code objects: not what a stage costs
+        for i in range(n_cold):
+            step(i)
+        torch.cuda.synchronize()
+        tm.set_profiling(True)
+        n = min(args.steps, 50)
+        for i in range(n):
+            step(i)
+        torch.cuda.synchronize()
+        out = {k: (ms / max(c, 1)) for k, (ms, c) in tm.stage_times().items()}
+        tm.set_profiling(False)
+        return out, n_cold + n
+
+    # ---- per-stage breakdown first (default): besides its numbers it brings the device to its working clocks -- measured
+    # (scripts/exp_first_steps.py), the first ~30 steps after an idle phase run 4-8 % slower than the steady state, which is
+    # what a 20-step timed region straight after 5 warm-up steps would otherwise report.  The line says how many steps ran here.
+    stages, n_breakdown = breakdown_pass() if args.breakdown == "before" else (None, 0)
+
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -319,13 +344,8 @@ def main():
     dom_ms, dom_cnt = tm.stage_times()[dominant]
     comm = dp.comm_seconds() if dp is not None else None
 
-    # ---- second, fully instrumented pass (breakdown only; not part of `value`) ----------------------------
-    tm.set_profiling(True)
-    n_prof = min(args.steps, 50)
-    for i in range(n_prof):
-        step(i)
-    torch.cuda.synchronize()
-    stages = {k: (ms / max(c, 1)) for k, (ms, c) in tm.stage_times().items()}
+    if stages is None:  # --breakdown after: the instrumented pass follows the timed region
+        stages, _ = breakdown_pass()
     tm.set_profiling(False)
 
     # sanity: the run must have trained (loss finite and below the initial loss)
@@ -370,6 +390,7 @@ def main():
                        "parallelism": f"dp{world} ({args.dp})" if world > 1 else "single"},
             "roofline": roofline,
             "stages_ms": stages,
+            "untimed_steps_before_timing": {"breakdown_pass": n_breakdown, "warmup": args.warmup},
             "step_ideal_GBps": ab["step_ideal"] / (elapsed / args.steps) / 1e9,
             "final_loss": final_loss,
         }

@@ -178,3 +178,52 @@ def test_rccl_all_reduce_inside_the_library_on_one_rank():
     assert "librccl" in open("/proc/self/maps").read()
     lib.ncclCommDestroy.argtypes = [type(comm)]
     lib.ncclCommDestroy(comm)
+
+
+def _nccl_single_rank_worker(out_path):
+    """Runs in a process of its own (a process group cannot be re-initialised with another backend in the pytest process)."""
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, os.path.join(ROOT, "tiny-cuda-nn_amd"))
+    import torch.distributed as dist
+    from tinycudann import parallel as par
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    x, t = _data()
+    x, t = x.cuda(), t.cuda()
+    plain = _model()
+    for _ in range(STEPS):
+        plain.training_step(x, t)
+    result = {}
+    for mode in ("sharded", "allreduce", "pipelined", "pipelined_sharded"):
+        tm = _model()
+        dp = par.DataParallel(tm, mode=mode, level_groups=3, single_rank_ok=True)
+        assert dp.active
+        for _ in range(STEPS):
+            par.training_step(tm, x, t, N, dp=dp)
+        torch.cuda.synchronize()
+        dp.gather_optimizer_state()
+        result[mode] = bool(torch.equal(tm.params_full_precision, plain.params_full_precision)) and tm.optimizer_step_count == STEPS and dp.comm_seconds() > 0
+        tm.set_gradient_ready_callback(None)
+    result["rccl_loaded"] = "librccl" in open("/proc/self/maps").read()
+    torch.save(result, out_path)
+    dist.destroy_process_group()
+
+
+def test_every_exchange_on_the_nccl_backend_with_one_rank(tmp_path):
+    """torch.distributed's `nccl` backend IS RCCL on ROCm and refuses two ranks on one device, so on a one-GPU box it runs with a
+    process group of a single rank: every collective of the four exchange schemes -- reduce_scatter_tensor / all_gather_into_tensor /
+    all_reduce on views of the LIBRARY-owned gradient and parameter buffers, the asynchronous ones issued from the trainer's
+    gradient-ready callback -- goes through RCCL, is the identity, and the trajectory must equal the plain one bit for bit."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    s.close()
+    out = str(tmp_path / "nccl1.pt")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_nccl_single_rank_worker, args=(out,))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    r = torch.load(out)
+    assert r == {"sharded": True, "allreduce": True, "pipelined": True, "pipelined_sharded": True, "rccl_loaded": True}, r

@@ -98,11 +98,13 @@ class DataParallel:
     """Gradient exchange + optimizer of one data-parallel rank.  `tm`: a tinycudann.native.TrainableModel (or anything with
     param_gradients / params / params_inference / n_params / optimizer_step / optimizer_step_range(s) / optimizer_state)."""
 
-    def __init__(self, tm, mode="sharded", loss_scale=128.0, n_buckets=None, level_groups=2):
+    def __init__(self, tm, mode="sharded", loss_scale=128.0, n_buckets=None, level_groups=2, single_rank_ok=False):
         if mode not in ("sharded", "allreduce", "pipelined", "pipelined_sharded"):
             raise ValueError(f"unknown data-parallel mode {mode!r}")
         self.tm, self.mode, self.loss_scale, self.n_buckets = tm, mode, loss_scale, n_buckets
-        self.active = dist.is_initialized() and dist.get_world_size() > 1
+        # single_rank_ok: run the collectives even in a process group of ONE rank (tests: the whole exchange on the real backend
+        # -- RCCL -- where only one GPU exists; every collective is then the identity)
+        self.active = dist.is_initialized() and (dist.get_world_size() > 1 or single_rank_ok)
         self.world = dist.get_world_size() if self.active else 1
         self.rank = dist.get_rank() if self.active else 0
         self.grads = tm.param_gradients

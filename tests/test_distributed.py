@@ -165,6 +165,7 @@ def _dp_worker(rank, world, port, n, mode, out_dir):
     par.init_from_env(backend="gloo")
     tm = _CpuTrainer(n)
     dp = par.DataParallel(tm, mode=mode, n_buckets=3, level_groups=3)
+    dp.MIN_SEGMENT_BYTES = 150  # (1 MiB by default) the 40 "network weights" wait for the first level group; remainders move on
     assert dp.shard % 8 == 0 and dp.main <= n and n - dp.main < 8 * world
     for step in range(3):
         if mode.startswith("pipelined"):  # the collectives start from inside the backward pass, range by range

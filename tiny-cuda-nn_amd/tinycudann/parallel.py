@@ -214,66 +214,75 @@ class DataParallel:
                 self._has_all_gather_into = False
         dist.all_gather([buf[r * self.shard:(r + 1) * self.shard] for r in range(self.world)], own)
 
-    # ---- pipelined schemes: one collective per ready range, started from inside training_step --------------------------------
-    def _segment(self, begin, end):
-        """Shard layout of the range [begin, end) on its own: (shard, main) with main = shard * world <= end - begin."""
-        shard = ((end - begin) // (8 * self.world)) * 8
-        return shard, shard * self.world
+    # ---- pipelined schemes: collectives started from inside training_step ----------------------------------------------------
+    # The trainer reports ranges in ascending order.  A reported range is not necessarily a collective of its own: xGMI collectives
+    # are latency-priced below ~1 MB, so small ranges (the network's 14 KB of weights, coarse levels) wait for the next report, and a
+    # segment always ends on a multiple of 8 * world from its start -- the remainder moves on to the next segment, so that only the
+    # LAST one has a tail (< 8 * world parameters, all-reduced and stepped by every rank).
+    MIN_SEGMENT_BYTES = 1 << 20
 
     def _on_ready(self, begin, end):
         """Gradient-ready hook (host side, inside tm.training_step): the kernels producing grads[begin:end] are enqueued on the
         current stream; an asynchronous collective issued now waits for exactly that work."""
         g = self.grads
+        if begin == 0:
+            self._seg_start = 0
+        start, last = self._seg_start, end == self.n
+        if not last and (end - start) * g.element_size() < self.MIN_SEGMENT_BYTES:
+            return  # travels with the next range
         if self.mode == "pipelined":
-            self._pending.append((begin, end, [dist.all_reduce(g[begin:end], op=dist.ReduceOp.SUM, async_op=True)], None))
+            self._pending.append((start, end, [dist.all_reduce(g[start:end], op=dist.ReduceOp.SUM, async_op=True)], None, 0))
+            self._seg_start = end
             return
-        shard, main = self._segment(begin, end)
+        shard = ((end - start) // (8 * self.world)) * 8
+        main = shard * self.world
         works, out = [], None
         if main:
             if self._has_reduce_scatter:
                 try:
                     out = torch.empty(shard, dtype=g.dtype, device=g.device)
-                    works.append(dist.reduce_scatter_tensor(out, g[begin:begin + main], op=dist.ReduceOp.SUM, async_op=True))
+                    works.append(dist.reduce_scatter_tensor(out, g[start:start + main], op=dist.ReduceOp.SUM, async_op=True))
                 except (RuntimeError, NotImplementedError):
                     self._has_reduce_scatter, out = False, None  # gloo: no reduce-scatter
             if out is None:
-                works.append(dist.all_reduce(g[begin:begin + main], op=dist.ReduceOp.SUM, async_op=True))
-        if begin + main < end:
-            works.append(dist.all_reduce(g[begin + main:end], op=dist.ReduceOp.SUM, async_op=True))
-        self._pending.append((begin, end, works, out))
+                works.append(dist.all_reduce(g[start:start + main], op=dist.ReduceOp.SUM, async_op=True))
+        if last and start + main < end:
+            works.append(dist.all_reduce(g[start + main:end], op=dist.ReduceOp.SUM, async_op=True))
+        self._pending.append((start, start + main if not last else end, works, out, shard))
+        self._seg_start = start + main
 
     def _finish_pipelined(self):
         pending, self._pending = self._pending, []
-        self._last_ranges = [(b, e) for b, e, _, _ in pending]
-        if not pending or pending[0][0] != 0 or pending[-1][1] != self.n:
+        self._last_segments = [(b, e, shard) for b, e, _, _, shard in pending]
+        if not pending or pending[0][0] != 0 or pending[-1][1] != self.n or any(a[1] != b[0] for a, b in zip(pending[:-1], pending[1:])):
             raise RuntimeError("pipelined exchange: the trainer did not report the whole gradient buffer (call training_step(run_optimizer=False) first)")
         if self.mode == "pipelined":
-            for begin, end, works, _ in pending:  # ascending, the range starting at 0 first: what optimizer_step_range asks for
+            for begin, end, works, _, _ in pending:  # ascending, the range starting at 0 first: what optimizer_step_range asks for
                 for w in works:
                     w.wait()
                 self.tm.optimizer_step_range(begin, end, self.loss_scale)
             return
         ranges = []
-        for begin, end, works, out in pending:
+        for begin, end, works, out, shard in pending:
             for w in works:
                 w.wait()
-            shard, main = self._segment(begin, end)
+            main = shard * self.world
             if main:
                 own = begin + self.rank * shard
                 if out is not None:
                     self.grads[own:own + shard].copy_(out)
                 ranges.append((own, own + shard))
-            if begin + main < end:
+            if begin + main < end:  # the last segment's tail
                 ranges.append((begin + main, end))
         self.tm.optimizer_step_ranges(ranges, self.loss_scale)
         for buf in (self.params, self.params_inference):
             if buf is None:
                 continue
             works = []
-            for begin, end, _, _ in pending:
-                shard, main = self._segment(begin, end)
-                if not main:
+            for begin, end, _, _, shard in pending:
+                if not shard:
                     continue
+                main = shard * self.world
                 own = buf[begin + self.rank * shard:begin + (self.rank + 1) * shard].clone()
                 if self._has_all_gather_into:
                     try:
@@ -320,10 +329,9 @@ class DataParallel:
             for buf in (self.tm.params_full_precision, m1, m2, steps):
                 self._all_gather(buf)
             return
-        for buf in (self.tm.params_full_precision, m1, m2, steps):  # the owners' shards of every range of the last step
-            for begin, end in self._last_ranges:
-                shard, main = self._segment(begin, end)
-                if main:
+        for buf in (self.tm.params_full_precision, m1, m2, steps):  # the owners' shards of every segment of the last step
+            for begin, end, shard in self._last_segments:
+                if shard:
                     dist.all_gather([buf[begin + r * shard:begin + (r + 1) * shard] for r in range(self.world)],
                                     buf[begin + self.rank * shard:begin + (self.rank + 1) * shard].clone())
 

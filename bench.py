@@ -393,6 +393,7 @@ def main():
             "untimed_steps_before_timing": {"breakdown_pass": n_breakdown, "warmup": args.warmup},
             "step_ideal_GBps": ab["step_ideal"] / (elapsed / args.steps) / 1e9,
             "final_loss": final_loss,
+            "grid_owner_wide_slices": tcnn._C.grid_owner_wide_slices(),  # slices of the grid backward redone with 64-bit accumulators in this process (perf only)
         }
         if comm is not None:
             line["comm"] = {"seconds_per_step": comm / args.steps, "share_of_step": comm / elapsed,

@@ -271,6 +271,9 @@ int tcnn_get_grid_backward_mode(void);
  * Also selectable with TCNN_GRID_OWNER=packed|fixed64|wide. */
 int tcnn_set_grid_owner_mode(int mode);
 int tcnn_get_grid_owner_mode(void);
+/* Table slices the packed owners had to redo with 64 bits per value since the process started (their gradients failed the int32 bound:
+ * sum of |gradient| over the slice >= 120); each redo costs that slice twice the time.  Synchronises the device. */
+int tcnn_grid_owner_wide_slices(uint64_t* out);
 
 #ifdef __cplusplus
 }

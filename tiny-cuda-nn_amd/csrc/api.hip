@@ -2161,6 +2161,11 @@ int tcnn_set_fused_network_passes(int enable) {
 	g_fused_network_passes.store(enable != 0 ? 1 : 0);
 	return TCNN_OK;
 }
+int tcnn_grid_owner_wide_slices(uint64_t* out) {
+	TCNN_API_BEGIN
+	*out = grid_owner_wide_slices();
+	TCNN_API_END
+}
 int tcnn_get_grid_owner_mode(void) { return grid_owner_mode(); }
 int tcnn_set_grid_owner_mode(int mode) {
 	if (mode < 0 || mode > 2) return TCNN_ERROR;

@@ -108,6 +108,9 @@ void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, c
 //   2 wide    -- the packed kernel, every slice through its 64-bit redo (tests of that path)
 // All three produce the same bits.
 int& grid_owner_mode();
+// Slices the packed owners redid with 64 bits per value since the process started (synchronises the device): each costs that slice
+// twice the time -- a workload whose gradients keep failing the int32 bound (sum of |gradient| over a slice >= 120) shows up here.
+unsigned long long grid_owner_wide_slices();
 
 // dL_dx[i][d] = sum_k dL_dy[k][i] * dy_dx[k][i][d]   (grid.h:323-349)
 void grid_backward_input(hipStream_t stream, uint32_t n_dims, uint32_t n_features, const GridIO& io,

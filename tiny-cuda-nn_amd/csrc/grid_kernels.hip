@@ -1206,6 +1206,10 @@ constexpr float OWNER_SAFE_ABS_SUM = 120.0f;  // < 128 = 2^31 / 2^24, with room 
 
 #if defined(TCNN_HOST_EMU)
 inline unsigned long owner_slice_stats[2] = {0, 0};  // emulator only: slices finished from the packed table / redone wide
+#else
+// slices the packed owner kernel had to redo with 64 bits per value since the process started (grid_owner_wide_slices()): the redo
+// costs that slice twice the time, so a workload whose gradients keep failing the int32 bound should be visible
+__device__ unsigned long long g_owner_wide_slices = 0ull;
 #endif
 
 // round(v * 2^24) for |v| < 128; saturates beyond (such a slice fails the bound and is redone in 64 bits).  A 16-bit float times
@@ -1356,6 +1360,8 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 	}
 #if defined(TCNN_HOST_EMU)
 	if (threadIdx.x == 0) owner_slice_stats[safe ? 0 : 1]++;
+#else
+	if (!safe && !force_wide && threadIdx.x == 0) atomicAdd(&g_owner_wide_slices, 1ull);
 #endif
 	if (!safe) {
 		// 64 bits per value, `sub` entries at a time (the same LDS): each pass streams the queue again and keeps its own entries
@@ -1775,6 +1781,16 @@ static void grid_backward_atomic(hipStream_t stream, const GridMeta& meta, const
 #define BWD(D_, F_) TCNN_LAUNCH((k_grid_backward_atomic<D_, F_>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, dL_dy, grid_gradient);
 	TCNN_GRID_DISPATCH(BWD)
 #undef BWD
+}
+
+unsigned long long grid_owner_wide_slices() {
+#if defined(TCNN_HOST_EMU)
+	return owner_slice_stats[1];
+#else
+	unsigned long long v = 0;
+	if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_owner_wide_slices), sizeof(v)) != hipSuccess) throw std::runtime_error("grid_owner_wide_slices: could not read the counter");
+	return v;
+#endif
 }
 
 int& grid_owner_mode() {

@@ -145,6 +145,7 @@ _sig("tcnn_set_grid_backward_mode", _i, _i)
 _sig("tcnn_get_grid_backward_mode", _i)
 _sig("tcnn_set_grid_owner_mode", _i, _i)
 _sig("tcnn_get_grid_owner_mode", _i)
+_sig("tcnn_grid_owner_wide_slices", _i, C.POINTER(C.c_uint64))
 
 EXPORTED_SYMBOLS = [n for n in dir(_lib) if n.startswith("tcnn_")]
 
@@ -244,6 +245,13 @@ def set_grid_owner_mode(mode):
     """Bucket owners of the bucketed grid backward: 0 packed accumulators (default), 1 64-bit fixed point per value, 2 the packed
     kernel's wide redo on every slice (tests).  Same bits from all three."""
     _check(_lib.tcnn_set_grid_owner_mode(int(mode)))
+
+
+def grid_owner_wide_slices():
+    """Table slices the packed bucket owners redid with 64 bits per value since the process started (2x the time each)."""
+    v = C.c_uint64(0)
+    _check(_lib.tcnn_grid_owner_wide_slices(C.byref(v)))
+    return int(v.value)
 
 
 def get_fused_network_passes():

@@ -1822,6 +1822,9 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 	constexpr uint32_t MAX_BASES[11] = {0x0, 0xFFFFFFFF, 0xFFFF, 0x659, 0xFF, 0x54, 0x28, 0x17, 0xF, 0xB, 0x9};
 	uint32_t bucket_shift = 0;  // buckets hold a power-of-two number of entries (bucket = index >> shift)
 	while ((2u << bucket_shift) <= cap_fixed) ++bucket_shift;
+#if defined(TCNN_EXP_BUCKET_SHIFT_DELTA)  // experiment builds only (packed owners, even F): entries per bucket x 2^delta
+	bucket_shift = (uint32_t)((int)bucket_shift + (TCNN_EXP_BUCKET_SHIFT_DELTA));
+#endif
 	const uint32_t n_corners = meta.interp == (uint32_t)InterpolationType::Nearest ? 1u : (1u << meta.n_dims);
 	const uint32_t record_words = 1u + (F + 1u) / 2u;
 

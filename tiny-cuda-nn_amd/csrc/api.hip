@@ -1507,6 +1507,8 @@ void tcnn_trainable_model_destroy(tcnn_trainable_model_t* tm) {
 	device_free(tm->params_ema);
 	device_free(tm->ema_tmp);
 	device_free(tm->loss_scratch);
+	for (hipEvent_t e : tm->comm_events) (void)hipEventDestroy(e);
+	if (tm->comm_stream) (void)hipStreamDestroy(tm->comm_stream);
 	delete tm;
 }
 

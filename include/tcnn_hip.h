@@ -218,6 +218,12 @@ int tcnn_trainer_optimizer_step_ranges(tcnn_trainable_model_t* tm, tcnn_stream_t
  * library links no collective library itself.  exchange == NULL removes the hook. */
 int tcnn_trainer_set_gradient_exchange(tcnn_trainable_model_t* tm, void (*exchange)(void* user, void* gradients_fp16, size_t n_params, tcnn_stream_t stream),
                                        void* user);
+/* Loss<T>::evaluate on its own (reference loss.h:42-50; losses/*.h): `loss_otype` as in the JSON ("RelativeL2", "L2", "L1", ...).
+ * prediction / gradients: column-major `stride` x n matrices of the library's 16-bit type (stride = padded output width, a multiple of
+ * 8), target / data_pdf (may be NULL): `dims` x n fp32, values (may be NULL): `stride` x n fp32.  Rows >= dims carry no loss; the
+ * normalisation is n * dims as in the reference's kernels. */
+int tcnn_loss_evaluate(const char* loss_otype, tcnn_stream_t stream, uint32_t n, uint32_t stride, uint32_t dims, float loss_scale, const void* prediction,
+                       const float* target, const float* data_pdf, float* values, void* gradients);
 /* Exchange overlapped with the backward pass (no reference counterpart).  `ready(user, begin, end, stream)` is called on
  * the host, inside training_step, as soon as the kernels that produce the gradients [begin, end) of the fp16 gradient buffer have been
  * enqueued on `stream`: first the network's weights [0, n_network_params), then the encoding's levels in

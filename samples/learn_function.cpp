@@ -98,6 +98,19 @@ int main(int argc, char** argv) {
 			auto c2 = model.trainer->training_step(stream, in_rm, training_target, nullptr, /*run_optimizer=*/false);
 			layouts_ok = layouts_ok && model.trainer->loss(stream, *c1) == model.trainer->loss(stream, *c2);
 			std::printf("layouts_identical=%d\n", int(layouts_ok));
+			// Loss<T>::evaluate on its own (loss.h:42-50) reproduces the gradient the fused training step computed from the same prediction
+			using T = tcnn::network_precision_t;
+			tcnn::GPUMatrix<T> prediction = c1->output(), reference_gradient = c1->dL_doutput();
+			tcnn::GPUMatrix<T> gradient(prediction.m(), prediction.n());
+			tcnn::GPUMatrix<float> values(prediction.m(), prediction.n());
+			model.loss->evaluate(stream, 128.0f, prediction, training_target, values, gradient);
+			HIP_CHECK_THROW(hipStreamSynchronize(stream));
+			std::vector<uint16_t> g1(gradient.n_elements()), g2(gradient.n_elements());
+			HIP_CHECK_THROW(hipMemcpy(g1.data(), gradient.data(), g1.size() * 2, hipMemcpyDeviceToHost));
+			HIP_CHECK_THROW(hipMemcpy(g2.data(), reference_gradient.data(), g2.size() * 2, hipMemcpyDeviceToHost));
+			const bool loss_ok = g1 == g2;
+			std::printf("loss_evaluate_matches_training_step=%d\n", int(loss_ok));
+			layouts_ok = layouts_ok && loss_ok;
 		}
 
 		// error behaviour: the reference throws std::runtime_error for a batch that is not a multiple of 256

@@ -786,6 +786,28 @@ def test_cpp_facade_sample(exe_name):
     r = subprocess.run([exe, "150", "16384"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
     assert "restored_inference_identical=1" in r.stdout and "layouts_identical=1" in r.stdout
+    assert "loss_evaluate_matches_training_step=1" in r.stdout  # Loss<T>::evaluate on its own == the fused step's dL/doutput
+
+
+@pytest.mark.parametrize("name,with_pdf", [("RelativeL2", False), ("L2", True), ("L1", False), ("RelativeL1", True), ("Mape", False), ("Smape", False),
+                                           ("RelativeL2Luminance", False)])
+def test_loss_evaluate_on_its_own(name, with_pdf):
+    """tcnn_loss_evaluate / Loss<T>::evaluate (loss.h:42-50): values and gradients of a padded prediction matrix against the oracle
+    (itself pinned bit for bit against the reference's loss kernels, tests/test_oracle_ref.py): gradients bit-exact."""
+    C = tcnn()._C
+    rng = np.random.default_rng(3)
+    n, stride, dims = 4096, 16, 5
+    pred = O.f2h((rng.standard_normal((n, stride)) * 0.7).astype(np.float32))
+    tgt = rng.random((n, dims), dtype=np.float32)
+    pdf = (0.25 + rng.random((n, dims), dtype=np.float32)) if with_pdf else None
+    v_ref, g_ref = O.loss(getattr(O, "LOSS_" + {"RelativeL2": "RELATIVE_L2", "L2": "L2", "L1": "L1", "RelativeL1": "RELATIVE_L1", "Mape": "MAPE", "Smape": "SMAPE",
+                                                "RelativeL2Luminance": "RELATIVE_L2_LUMINANCE"}[name]), pred, tgt, dims, data_pdf=pdf)
+    p = torch.from_numpy(pred.view(np.int16)).cuda().view(torch.half)
+    values, grads = C.loss_evaluate(name, p, torch.from_numpy(tgt).cuda(), 128.0, None if pdf is None else torch.from_numpy(pdf).cuda())
+    assert np.array_equal(grads.cpu().view(torch.int16).numpy().view(np.uint16), g_ref)
+    assert np.allclose(values.cpu().numpy(), v_ref, rtol=1e-6, atol=1e-9)
+    with pytest.raises(RuntimeError, match="not found"):
+        C.loss_evaluate("NoSuchLoss", p, torch.from_numpy(tgt).cuda())
 
 
 @pytest.mark.parametrize("clustered", [False, True])

@@ -1512,6 +1512,21 @@ void tcnn_trainable_model_destroy(tcnn_trainable_model_t* tm) {
 	delete tm;
 }
 
+// Loss<T>::evaluate (loss.h:42-50) on its own: prediction / gradients are column-major `stride` x n matrices in the library's 16-bit
+// type (= sample-major [n][stride]), target / data_pdf `dims` x n fp32, values `stride` x n fp32 (may be null); rows >= dims carry no
+// loss (relative_l2.h:57-61).  Normalised by n * dims like the reference's kernels (n_elements / stride * dims).
+int tcnn_loss_evaluate(const char* loss_otype, tcnn_stream_t stream, uint32_t n, uint32_t stride, uint32_t dims, float loss_scale, const void* prediction,
+                       const float* target, const float* data_pdf, float* values, void* gradients) {
+	TCNN_API_BEGIN
+	if (!loss_otype || !prediction || !target || !gradients) throw std::runtime_error("Loss::evaluate: missing argument");
+	if (stride % 8 != 0 || dims > stride) throw std::runtime_error("Loss::evaluate: the prediction's row count must be a multiple of 8 and at least the target's");
+	if ((uint64_t)n * dims > 0xFFFFFFFFull || (uint64_t)n * stride > 0xFFFFFFFFull) throw std::runtime_error("Loss::evaluate: batch too large");
+	if (n == 0) return TCNN_OK;
+	loss_evaluate((hipStream_t)stream, string_to_loss(loss_otype), n, stride, dims, loss_scale, (const half_t*)prediction, target, data_pdf, values, (half_t*)gradients,
+	              nullptr, n * dims);
+	TCNN_API_END
+}
+
 int tcnn_trainer_forward(tcnn_trainable_model_t* tm, tcnn_stream_t stream_, float loss_scale, uint32_t n, const float* input, const float* target,
                          const float* data_pdf, int use_inference_params, int prepare_input_gradients, const void* external_dL_dy,
                          tcnn_train_context_t** ctx_out) {

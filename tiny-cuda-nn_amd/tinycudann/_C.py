@@ -76,6 +76,7 @@ _sig("tcnn_preferred_precision", _i)
 _sig("tcnn_supports_jit_fusion", _i, _i)
 _sig("tcnn_set_log_callback", None, _vp)
 _sig("tcnn_generate_random_uniform", _i, _vp, _u64, C.POINTER(_u64), _sz, _vp, _f, _f)
+_sig("tcnn_loss_evaluate", _i, C.c_char_p, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _f, _vp, _vp, _vp, _vp, _vp)
 _sig("tcnn_create_network_with_input_encoding", _i, _u32, _u32, _cp, _cp, C.POINTER(_vp))
 _sig("tcnn_create_network", _i, _u32, _u32, _cp, C.POINTER(_vp))
 _sig("tcnn_create_encoding", _i, _u32, _cp, _i, C.POINTER(_vp))
@@ -245,6 +246,18 @@ def set_grid_owner_mode(mode):
     """Bucket owners of the bucketed grid backward: 0 packed accumulators (default), 1 64-bit fixed point per value, 2 the packed
     kernel's wide redo on every slice (tests).  Same bits from all three."""
     _check(_lib.tcnn_set_grid_owner_mode(int(mode)))
+
+
+def loss_evaluate(otype, prediction, target, loss_scale=128.0, data_pdf=None, want_values=True):
+    """Loss<T>::evaluate (loss.h:42-50) on its own.  prediction: [n][padded width] in the library's 16-bit type, target (data_pdf):
+    [n][dims] fp32 -> (values [n][padded width] fp32 or None, gradients like prediction)."""
+    import torch
+    n, stride = prediction.shape
+    gradients = torch.empty_like(prediction)
+    values = torch.empty((n, stride), dtype=torch.float32, device=prediction.device) if want_values else None
+    _check(_lib.tcnn_loss_evaluate(str(otype).encode(), _stream(), n, stride, target.shape[1], float(loss_scale), _ptr(prediction), _ptr(target), _ptr(data_pdf),
+                                   _ptr(values), _ptr(gradients)))
+    return values, gradients
 
 
 def grid_owner_wide_slices():

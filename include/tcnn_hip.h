@@ -218,6 +218,18 @@ int tcnn_trainer_optimizer_step_ranges(tcnn_trainable_model_t* tm, tcnn_stream_t
  * library links no collective library itself.  exchange == NULL removes the hook. */
 int tcnn_trainer_set_gradient_exchange(tcnn_trainable_model_t* tm, void (*exchange)(void* user, void* gradients_fp16, size_t n_params, tcnn_stream_t stream),
                                        void* user);
+/* Optimizer<T> on its own (reference optimizer.h:40-99, optimizers/adam.h): Adam over weight buffers the host owns.
+ * create (JSON as in the "optimizer" block; otype Adam) -> allocate(n_weights, n_matrix_weights: the leading parameters that are matrix
+ * weights, adam.h:79-110) -> step(stream, loss_scale, fp32 weights, 16-bit weights, 16-bit gradients scaled by loss_scale), any number of
+ * times.  Same kernel and arithmetic as the trainer's optimizer step. */
+typedef struct tcnn_optimizer tcnn_optimizer_t;
+int tcnn_create_optimizer(const char* optimizer_json, tcnn_optimizer_t** out);
+int tcnn_optimizer_allocate(tcnn_optimizer_t* o, size_t n_weights, size_t n_matrix_weights);
+int tcnn_optimizer_step(tcnn_optimizer_t* o, tcnn_stream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients);
+uint32_t tcnn_optimizer_step_count(const tcnn_optimizer_t* o);
+int tcnn_optimizer_update_hyperparams(tcnn_optimizer_t* o, const char* optimizer_json);
+void* tcnn_optimizer_state(tcnn_optimizer_t* o, int which); /* 0 first moments, 1 second moments (fp32), 2 step counters (u32) */
+void tcnn_optimizer_destroy(tcnn_optimizer_t* o);
 /* Loss<T>::evaluate on its own (reference loss.h:42-50; losses/*.h): `loss_otype` as in the JSON ("RelativeL2", "L2", "L1", ...).
  * prediction / gradients: column-major `stride` x n matrices of the library's 16-bit type (stride = padded output width, a multiple of
  * 8), target / data_pdf (may be NULL): `dims` x n fp32, values (may be NULL): `stride` x n fp32.  Rows >= dims carry no loss; the

@@ -111,6 +111,28 @@ int main(int argc, char** argv) {
 			const bool loss_ok = g1 == g2;
 			std::printf("loss_evaluate_matches_training_step=%d\n", int(loss_ok));
 			layouts_ok = layouts_ok && loss_ok;
+			// Optimizer<T> on its own (optimizer.h:52-60): Adam over buffers this host owns -- one step moves every weight against its gradient
+			{
+				const uint32_t n_w = 1024;
+				tcnn::json opt_cfg = tcnn::json::parse(R"({"otype": "Adam", "learning_rate": 1e-2})");
+				tcnn::Optimizer<T> opt(opt_cfg);
+				opt.allocate(n_w, {{16, 32}});
+				tcnn::GPUMemory<float> w_fp(n_w);
+				tcnn::GPUMemory<T> w_half(n_w), g_half(n_w);
+				std::vector<float> w0(n_w, 0.5f);
+				std::vector<T> h0(n_w, (T)0.5f), g0(n_w, (T)(128.0f * 0.25f));  // gradient 0.25 at loss scale 128
+				w_fp.copy_from_host(w0);
+				w_half.copy_from_host(h0);
+				g_half.copy_from_host(g0);
+				opt.step(stream, 128.0f, w_fp.data(), w_half.data(), g_half.data());
+				HIP_CHECK_THROW(hipStreamSynchronize(stream));
+				std::vector<float> w1(n_w);
+				w_fp.copy_to_host(w1);
+				bool moved = opt.step() == 1;
+				for (uint32_t i = 0; i < n_w; ++i) moved = moved && w1[i] < 0.5f && w1[i] > 0.48f;  // first Adam step: -lr * sign(g)
+				std::printf("optimizer_on_its_own=%d\n", int(moved));
+				layouts_ok = layouts_ok && moved;
+			}
 		}
 
 		// error behaviour: the reference throws std::runtime_error for a batch that is not a multiple of 256

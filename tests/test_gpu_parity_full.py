@@ -149,6 +149,41 @@ def test_adam_bit_level_in_both_step_counter_forms(l2_reg, clip):
     assert len(np.unique(st.steps)) > 3  # the skip path was exercised
 
 
+def test_optimizer_object_on_its_own_bit_level():
+    """tcnn_create_optimizer / Optimizer<T>::allocate + step (optimizer.h:52-60) over buffers the caller owns: the trainer's Adam kernel
+    behind another door -- moments and per-parameter step counters bit-equal to the oracle's adam_step (itself pinned against the
+    reference's kernel), master weights within ulps, 16-bit weights = RNE of the master weights; zero-gradient non-matrix entries skipped."""
+    from tinycudann import native
+    n, nm = 40000, 4096
+    cfg = {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6, "non_matrix_learning_rate_factor": 0.5}
+    adam = O.adam_defaults(learning_rate=1e-2, beta1=0.9, beta2=0.99, epsilon=1e-15, l2_reg=1e-6, non_matrix_learning_rate_factor=0.5)
+    rng = np.random.default_rng(5)
+    w32 = rng.standard_normal(n).astype(np.float32)
+    w16 = O.f2h(w32)
+    m1, m2, steps = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint32)
+    opt = native.Optimizer(cfg, n, nm)
+    wfp = torch.from_numpy(w32.copy()).cuda()
+    wh = h_t(w16.copy())
+    for k in range(4):
+        g = (rng.standard_normal(n) * rng.choice([1e-3, 1.0, 60.0], n)).astype(np.float16)
+        g[nm:][rng.random(n - nm) < 0.4] = 0
+        opt.step(wfp, wh, h_t(g.view(np.uint16)))
+        w_before = w32.copy()
+        O.adam_step(adam, nm, 128.0, k + 1, w32, w16, g.view(np.uint16), m1, m2, steps)
+        gm1, gm2, gsteps = opt.state()
+        torch.cuda.synchronize()
+        assert opt.step_count == k + 1
+        assert np.array_equal(gsteps.cpu().numpy().view(np.uint32), steps) and np.array_equal(gm1.cpu().numpy(), m1) and np.array_equal(gm2.cpu().numpy(), m2), k
+        w = wfp.cpu().numpy()
+        assert _within_ulps(w, w32, w_before), k
+        assert np.array_equal(h_np(wh), O.f2h(w)), k
+        w32[:] = w
+        w16[:] = O.f2h(w)
+    assert len(np.unique(steps)) > 2
+    with pytest.raises(RuntimeError, match="not available"):
+        native.Optimizer({"otype": "Shampoo"}, 8)
+
+
 def test_training_step_data_pdf_external_gradient_and_input_gradient():
     """data_pdf, external_dL_dy and dL_dinput of Trainer::training_step (trainer.h:254-264) against the oracle."""
     cfg = config_hash(log2_hashmap_size=15, per_level_scale=1.5)

@@ -1512,6 +1512,76 @@ void tcnn_trainable_model_destroy(tcnn_trainable_model_t* tm) {
 	delete tm;
 }
 
+// Optimizer<T> on its own (optimizer.h:40-99, optimizers/adam.h:130-219): Adam over weight buffers the HOST owns -- for callers that
+// drive forward / loss / backward themselves.  The same kernel and arithmetic as the trainer's optimizer step (counter form of the
+// per-parameter step counters).
+struct tcnn_optimizer {
+	AdamHyper adam;
+	uint32_t n = 0, n_matrix = 0, step = 0;
+	float *m1 = nullptr, *m2 = nullptr;
+	uint32_t* steps = nullptr;
+};
+int tcnn_create_optimizer(const char* optimizer_json, tcnn_optimizer_t** out) {
+	TCNN_API_BEGIN
+	const Json opts = Json::parse(optimizer_json ? optimizer_json : "{}");
+	const std::string otype = opts.value("otype", "Adam");
+	if (!equals_case_insensitive(otype, "Adam")) throw std::runtime_error("Optimizer '" + otype + "' is not available as a stand-alone object in this build (supported: Adam).");
+	auto o = std::make_unique<tcnn_optimizer>();
+	parse_adam(o->adam, opts);
+	*out = o.release();
+	TCNN_API_END
+}
+static void optimizer_release(tcnn_optimizer_t* o) {
+	device_free(o->m1);
+	device_free(o->m2);
+	device_free(o->steps);
+	o->m1 = o->m2 = nullptr;
+	o->steps = nullptr;
+}
+// Optimizer::allocate(n_weights, layer_sizes): the first n_matrix_weights parameters are matrix weights (weight decay / l2_reg apply to
+// them, adam.h:79-110), the rest (e.g. an encoding's) are not
+int tcnn_optimizer_allocate(tcnn_optimizer_t* o, size_t n_weights, size_t n_matrix_weights) {
+	TCNN_API_BEGIN
+	if (n_weights > 0xFFFFFFFFull || n_matrix_weights > n_weights) throw std::runtime_error("Optimizer::allocate: bad sizes");
+	(void)hipDeviceSynchronize();
+	optimizer_release(o);
+	o->n = (uint32_t)n_weights;
+	o->n_matrix = (uint32_t)n_matrix_weights;
+	o->step = 0;
+	if (o->n) {
+		o->m1 = device_malloc_n<float>(o->n);
+		o->m2 = device_malloc_n<float>(o->n);
+		o->steps = device_malloc_n<uint32_t>(o->n);
+		HIP_CHECK(hipMemset(o->m1, 0, (size_t)o->n * sizeof(float)));
+		HIP_CHECK(hipMemset(o->m2, 0, (size_t)o->n * sizeof(float)));
+		HIP_CHECK(hipMemset(o->steps, 0, (size_t)o->n * sizeof(uint32_t)));
+	}
+	TCNN_API_END
+}
+// Optimizer::step (optimizer.h:58): gradients carry the loss scale; weights_full_precision and weights (16-bit) are both updated
+int tcnn_optimizer_step(tcnn_optimizer_t* o, tcnn_stream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) {
+	TCNN_API_BEGIN
+	if (!o->n) return TCNN_OK;
+	if (!weights_full_precision || !weights || !gradients) throw std::runtime_error("Optimizer::step: missing buffer");
+	++o->step;  // adam.h:159
+	adam_step((hipStream_t)stream, o->adam, o->n, o->n_matrix, loss_scale, o->step, weights_full_precision, (half_t*)weights, (const half_t*)gradients, o->m1, o->m2, o->steps);
+	TCNN_API_END
+}
+uint32_t tcnn_optimizer_step_count(const tcnn_optimizer_t* o) { return o->step; }
+int tcnn_optimizer_update_hyperparams(tcnn_optimizer_t* o, const char* optimizer_json) {
+	TCNN_API_BEGIN
+	parse_adam(o->adam, Json::parse(optimizer_json ? optimizer_json : "{}"));
+	TCNN_API_END
+}
+// which = 0 first moments, 1 second moments (fp32), 2 per-parameter step counters (u32); device pointers, n_weights elements each
+void* tcnn_optimizer_state(tcnn_optimizer_t* o, int which) { return which == 0 ? (void*)o->m1 : which == 1 ? (void*)o->m2 : which == 2 ? (void*)o->steps : nullptr; }
+void tcnn_optimizer_destroy(tcnn_optimizer_t* o) {
+	if (!o) return;
+	(void)hipDeviceSynchronize();
+	optimizer_release(o);
+	delete o;
+}
+
 // Loss<T>::evaluate (loss.h:42-50) on its own: prediction / gradients are column-major `stride` x n matrices in the library's 16-bit
 // type (= sample-major [n][stride]), target / data_pdf `dims` x n fp32, values `stride` x n fp32 (may be null); rows >= dims carry no
 // loss (relative_l2.h:57-61).  Normalised by n * dims like the reference's kernels (n_elements / stride * dims).

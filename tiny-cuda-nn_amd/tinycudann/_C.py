@@ -76,6 +76,13 @@ _sig("tcnn_preferred_precision", _i)
 _sig("tcnn_supports_jit_fusion", _i, _i)
 _sig("tcnn_set_log_callback", None, _vp)
 _sig("tcnn_generate_random_uniform", _i, _vp, _u64, C.POINTER(_u64), _sz, _vp, _f, _f)
+_sig("tcnn_create_optimizer", _i, C.c_char_p, C.POINTER(_vp))
+_sig("tcnn_optimizer_allocate", _i, _vp, _sz, _sz)
+_sig("tcnn_optimizer_step", _i, _vp, _vp, _f, _vp, _vp, _vp)
+_sig("tcnn_optimizer_step_count", C.c_uint32, _vp)
+_sig("tcnn_optimizer_update_hyperparams", _i, _vp, C.c_char_p)
+_sig("tcnn_optimizer_state", _vp, _vp, _i)
+_sig("tcnn_optimizer_destroy", None, _vp)
 _sig("tcnn_loss_evaluate", _i, C.c_char_p, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _f, _vp, _vp, _vp, _vp, _vp)
 _sig("tcnn_create_network_with_input_encoding", _i, _u32, _u32, _cp, _cp, C.POINTER(_vp))
 _sig("tcnn_create_network", _i, _u32, _u32, _cp, C.POINTER(_vp))

@@ -33,6 +33,40 @@ class _DeviceView:
         self._owner = owner
 
 
+class Optimizer:
+    """Optimizer<T> on its own (optimizer.h:40-99; tcnn_create_optimizer): Adam over weight tensors the caller owns.  The first
+    n_matrix_weights parameters are matrix weights (weight decay / l2_reg apply to them, adam.h:79-110)."""
+
+    def __init__(self, config, n_weights, n_matrix_weights=0):
+        h = C.c_void_p()
+        _check(_lib.tcnn_create_optimizer(json.dumps(config).encode(), C.byref(h)))
+        self._h = h
+        self.n = int(n_weights)
+        _check(_lib.tcnn_optimizer_allocate(h, self.n, int(n_matrix_weights)))
+
+    def step(self, weights_full_precision, weights, gradients, loss_scale=128.0):
+        """weights_full_precision fp32, weights / gradients in the library's 16-bit type (gradients scaled by loss_scale)."""
+        assert weights_full_precision.numel() == weights.numel() == gradients.numel() == self.n
+        _check(_lib.tcnn_optimizer_step(self._h, _stream(), float(loss_scale), _ptr(weights_full_precision), _ptr(weights), _ptr(gradients)))
+
+    def update_hyperparams(self, config):
+        _check(_lib.tcnn_optimizer_update_hyperparams(self._h, json.dumps(config).encode()))
+
+    @property
+    def step_count(self):
+        return int(_lib.tcnn_optimizer_step_count(self._h))
+
+    def state(self):
+        """(first moments fp32, second moments fp32, per-parameter step counters int32-viewed u32): zero-copy views."""
+        return tuple(torch.as_tensor(_DeviceView(_lib.tcnn_optimizer_state(self._h, which), self.n, ts, self), device="cuda")
+                     for which, ts in ((0, "<f4"), (1, "<f4"), (2, "<i4")))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.tcnn_optimizer_destroy(self._h)
+            self._h = None
+
+
 class ForwardContext:
     """Trainer::ForwardContext (trainer.h:89-95)."""
 

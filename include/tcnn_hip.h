@@ -218,6 +218,12 @@ int tcnn_trainer_optimizer_step_ranges(tcnn_trainable_model_t* tm, tcnn_stream_t
  * library links no collective library itself.  exchange == NULL removes the hook. */
 int tcnn_trainer_set_gradient_exchange(tcnn_trainable_model_t* tm, void (*exchange)(void* user, void* gradients_fp16, size_t n_params, tcnn_stream_t stream),
                                        void* user);
+/* The reference's stream-ordered arena as a host sees it (GPUMemoryArena / allocate_workspace(stream, bytes), gpu_memory.h:405-700):
+ * a block out of the library's stream-keyed cache (where its own scratch memory comes from).  tcnn_stream_free returns it to the cache --
+ * not to the driver -- for later requests on the SAME stream (ordered behind its previous user); pass *granted back.  No device
+ * synchronisation on either call in the steady state; tcnn_free_temporary_memory() releases the cache. */
+int tcnn_stream_malloc(tcnn_stream_t stream, size_t bytes, void** out, size_t* granted);
+int tcnn_stream_free(tcnn_stream_t stream, void* ptr, size_t granted);
 /* Optimizer<T> on its own (reference optimizer.h:40-99, optimizers/adam.h): Adam over weight buffers the host owns.
  * create (JSON as in the "optimizer" block; otype Adam) -> allocate(n_weights, n_matrix_weights: the leading parameters that are matrix
  * weights, adam.h:79-110) -> step(stream, loss_scale, fp32 weights, 16-bit weights, 16-bit gradients scaled by loss_scale), any number of

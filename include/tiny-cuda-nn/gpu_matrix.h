@@ -12,12 +12,23 @@ namespace tcnn {
 template <typename T>
 class GPUMatrixDynamic {
 public:
-	// owning, dense (gpu_matrix.h:128-139; the stream-ordered arena of the reference's (m, n, stream) form is hipMalloc here)
+	// owning, dense (gpu_matrix.h:128-139)
 	GPUMatrixDynamic(uint32_t m, uint32_t n, MatrixLayout layout = CM) : m_rows(m), m_cols(n), m_layout(layout), m_owned(true) {
 		m_stride = layout == CM ? m : n;
 		if (n_elements() > 0) HIP_CHECK_THROW(hipMalloc(reinterpret_cast<void**>(&m_data), n_bytes()));
 	}
-	GPUMatrixDynamic(uint32_t m, uint32_t n, hipStream_t, MatrixLayout layout = CM) : GPUMatrixDynamic(m, n, layout) {}
+	// owning, out of the stream-ordered arena (gpu_matrix.h:141-152: allocate_workspace(stream, ...)): a block of the library's
+	// stream-keyed cache, handed back to it on destruction -- no driver allocation in a loop that makes temporaries per iteration
+	GPUMatrixDynamic(uint32_t m, uint32_t n, hipStream_t stream, MatrixLayout layout = CM) : m_rows(m), m_cols(n), m_layout(layout), m_owned(true) {
+		m_stride = layout == CM ? m : n;
+		if (n_elements() > 0) {
+			void* p = nullptr;
+			check(tcnn_stream_malloc((tcnn_stream_t)stream, n_bytes(), &p, &m_arena_bytes));
+			m_data = (T*)p;
+			m_arena_stream = stream;
+			m_from_arena = true;
+		}
+	}
 	// non-owning view of caller memory (gpu_matrix.h:118-126); stride 0 = dense
 	GPUMatrixDynamic(T* data, uint32_t m, uint32_t n, MatrixLayout layout = CM, uint32_t stride = 0)
 	    : m_data(data), m_rows(m), m_cols(n), m_stride(stride ? stride : (layout == CM ? m : n)), m_layout(layout), m_owned(false) {}
@@ -32,10 +43,16 @@ public:
 		std::swap(m_stride, o.m_stride);
 		std::swap(m_layout, o.m_layout);
 		std::swap(m_owned, o.m_owned);
+		std::swap(m_from_arena, o.m_from_arena);
+		std::swap(m_arena_stream, o.m_arena_stream);
+		std::swap(m_arena_bytes, o.m_arena_bytes);
 		return *this;
 	}
 	virtual ~GPUMatrixDynamic() {
-		if (m_owned && m_data) (void)hipFree(m_data);
+		if (m_owned && m_data) {
+			if (m_from_arena) (void)tcnn_stream_free((tcnn_stream_t)m_arena_stream, m_data, m_arena_bytes);
+			else (void)hipFree(m_data);
+		}
 	}
 
 	T* data() const { return m_data; }
@@ -94,6 +111,9 @@ protected:
 	uint32_t m_rows = 0, m_cols = 0, m_stride = 0;
 	MatrixLayout m_layout = CM;
 	bool m_owned = false;
+	bool m_from_arena = false;  // m_data is a block of the library's stream-keyed cache (tcnn_stream_malloc)
+	hipStream_t m_arena_stream = nullptr;
+	size_t m_arena_bytes = 0;
 };
 
 // static layout (gpu_matrix.h:253-330)

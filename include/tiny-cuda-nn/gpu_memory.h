@@ -1,8 +1,8 @@
 /*
  * tiny-cuda-nn/gpu_memory.h -- GPUMemory<T>: an owning device array (reference gpu_memory.h:60-403) for callers of the
  * hot path (the sample keeps its image, coordinates and renders in it, mlp_learning_an_image.cu:156-200).  The library's
- * own scratch memory is a stream-ordered block cache inside libtcnn_hip.so (where the reference has GPUMemoryArena);
- * free_all_gpu_memory_arenas() (common.h) releases it.
+ * own scratch memory is a stream-ordered block cache inside libtcnn_hip.so (where the reference has GPUMemoryArena); hosts
+ * draw from the same cache with GPUMatrix(m, n, stream) / tcnn_stream_malloc, free_all_gpu_memory_arenas() (common.h) releases it.
  */
 #pragma once
 #include <tiny-cuda-nn/common.h>

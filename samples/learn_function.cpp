@@ -133,6 +133,21 @@ int main(int argc, char** argv) {
 				std::printf("optimizer_on_its_own=%d\n", int(moved));
 				layouts_ok = layouts_ok && moved;
 			}
+			// GPUMatrix(m, n, stream) (gpu_matrix.h:141-152): temporaries out of the stream-ordered arena -- the block a destroyed matrix
+			// hands back is what the next one of that size on the same stream receives (no driver allocation per iteration)
+			{
+				void* first = nullptr;
+				bool reused = true;
+				for (int it = 0; it < 4; ++it) {
+					tcnn::GPUMatrix<float> tmp(n_output_dims, batch_size, stream);
+					model.network->inference(stream, training_batch, tmp);
+					if (it == 0) first = tmp.data();
+					reused = reused && tmp.data() == first;
+				}
+				HIP_CHECK_THROW(hipStreamSynchronize(stream));
+				std::printf("arena_block_reused=%d\n", int(reused));
+				layouts_ok = layouts_ok && reused;
+			}
 		}
 
 		// error behaviour: the reference throws std::runtime_error for a batch that is not a multiple of 256

@@ -788,6 +788,7 @@ def test_cpp_facade_sample(exe_name):
     assert "restored_inference_identical=1" in r.stdout and "layouts_identical=1" in r.stdout
     assert "loss_evaluate_matches_training_step=1" in r.stdout  # Loss<T>::evaluate on its own == the fused step's dL/doutput
     assert "optimizer_on_its_own=1" in r.stdout                  # Optimizer<T>::allocate + step over the host's own buffers
+    assert "arena_block_reused=1" in r.stdout                    # GPUMatrix(m, n, stream): blocks of the stream-ordered cache
 
 
 @pytest.mark.parametrize("name,with_pdf", [("RelativeL2", False), ("L2", True), ("L1", False), ("RelativeL1", True), ("Mape", False), ("Smape", False),

@@ -1512,6 +1512,22 @@ void tcnn_trainable_model_destroy(tcnn_trainable_model_t* tm) {
 	delete tm;
 }
 
+// The stream-ordered arena of the reference (GPUMemoryArena, gpu_memory.h:405-700; allocate_workspace(stream, bytes)) as the host
+// sees it: a block out of the library's stream-keyed cache -- what the library's own scratch memory comes from -- handed back to the
+// cache, not to the driver, when the host is done with it.  A block released on a stream is reused by later requests ON THAT STREAM
+// only (work queued there is ordered behind its previous user); *granted is what to pass back.
+int tcnn_stream_malloc(tcnn_stream_t stream, size_t bytes, void** out, size_t* granted) {
+	TCNN_API_BEGIN
+	if (!out || !granted) throw std::runtime_error("tcnn_stream_malloc: missing output argument");
+	*out = ScratchCache::acquire((hipStream_t)stream, bytes, granted);
+	TCNN_API_END
+}
+int tcnn_stream_free(tcnn_stream_t stream, void* ptr, size_t granted) {
+	TCNN_API_BEGIN
+	if (ptr) ScratchCache::release(stream_key((hipStream_t)stream), ptr, granted);
+	TCNN_API_END
+}
+
 // Optimizer<T> on its own (optimizer.h:40-99, optimizers/adam.h:130-219): Adam over weight buffers the HOST owns -- for callers that
 // drive forward / loss / backward themselves.  The same kernel and arithmetic as the trainer's optimizer step (counter form of the
 // per-parameter step counters).

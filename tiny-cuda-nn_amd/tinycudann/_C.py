@@ -76,6 +76,8 @@ _sig("tcnn_preferred_precision", _i)
 _sig("tcnn_supports_jit_fusion", _i, _i)
 _sig("tcnn_set_log_callback", None, _vp)
 _sig("tcnn_generate_random_uniform", _i, _vp, _u64, C.POINTER(_u64), _sz, _vp, _f, _f)
+_sig("tcnn_stream_malloc", _i, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz))
+_sig("tcnn_stream_free", _i, _vp, _vp, _sz)
 _sig("tcnn_create_optimizer", _i, C.c_char_p, C.POINTER(_vp))
 _sig("tcnn_optimizer_allocate", _i, _vp, _sz, _sz)
 _sig("tcnn_optimizer_step", _i, _vp, _vp, _f, _vp, _vp, _vp)

@@ -962,7 +962,7 @@ struct tcnn_trainable_model {
 	// tcnn_trainer_set_backward_level_groups, tcnn_trainer_enable_rccl)
 	void (*gradients_ready)(void* user, size_t begin, size_t end, tcnn_stream_t stream) = nullptr;
 	void* ready_user = nullptr;
-	uint32_t backward_level_groups = 1;
+	uint32_t backward_level_groups = getenv("TCNN_BACKWARD_LEVEL_GROUPS") ? (uint32_t)std::max(1, atoi(getenv("TCNN_BACKWARD_LEVEL_GROUPS"))) : 1u;  // env: experiments
 	void* rccl_comm = nullptr;  // ncclComm_t
 	int rccl_ranks = 0;
 	hipStream_t comm_stream = nullptr;
@@ -1880,6 +1880,7 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 	}
 	ReadyTrampoline tramp = {tm, stream};
 	LevelGroups level_groups = {tm->backward_level_groups, want_grads && wants_ready_ranges(tm) ? &ReadyTrampoline::call : nullptr, &tramp};
+	const bool grouped_backward = level_groups.n_groups > 1;
 	if (level_groups.ready) level_groups.ready(&tramp, 0, md.n_mlp_params());  // the network's gradients: the first range of the step
 	// The optimizer step of the bucketed levels happens inside the grid backward (GridFusedAdam) when this call owns the whole
 	// step: one GPU, gradients overwritten, plain Adam (no EMA copy to maintain), parameters the trainer's own.
@@ -1887,7 +1888,7 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 	bool optimizer_opened = false;
 	if (need_denc) {
 		const size_t n_mlp = md.n_mlp_params();
-		const bool fuse = run_optimizer && tm->fused_optimizer && want_grads && !accumulate && e.is_grid && e.n_params > 0 && !tm->ema && !tm->exchange && !wants_ready_ranges(tm) &&
+		const bool fuse = run_optimizer && tm->fused_optimizer && want_grads && !accumulate && e.is_grid && e.n_params > 0 && !tm->ema && !tm->exchange && !wants_ready_ranges(tm) && !grouped_backward &&
 		                  tm->global_batch == 0 && !use_inference_params && e.grid.stochastic == 0u &&
 		                  (GridBackwardMode)g_grid_backward_mode.load() == GridBackwardMode::Bucketed;
 		AdamCore core;

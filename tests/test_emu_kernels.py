@@ -442,3 +442,8 @@ def test_rng_casts_identity():
     assert np.array_equal(emu.cast_f32_to_f16(x), O.f2h(x))
     xi = np.random.default_rng(6).random((256, 3), dtype=np.float32)
     assert np.array_equal(emu.identity_forward(xi, 16).T, O.identity_forward(xi, 16))
+    # the LDS-transposing form: full 256-sample tiles with 16-byte reads / 8-byte writes, a ragged last tile, feature counts that
+    # are / are not multiples of four, padding features
+    for n, n_dims, padded in ((768, 64, 64), (600, 12, 16), (256, 5, 16), (1000, 128, 128)):
+        xi = np.random.default_rng(n).standard_normal((n, n_dims)).astype(np.float32)
+        assert np.array_equal(emu.identity_forward(xi, padded).T, O.identity_forward(xi, padded)), (n, n_dims)

@@ -479,27 +479,48 @@ __global__ void k_identity_forward(uint32_t n, uint32_t n_dims, uint32_t padded,
 	out[(size_t)k * stride_k + (size_t)i * stride_i] = v;
 }
 // The layout the trainer runs: sample-major fp32 input [n][n_dims] -> feature-major half output [padded][n].  A workgroup
-// transposes a tile of 64 samples through LDS: coalesced reads along the features of consecutive samples, coalesced
-// 128-byte row writes (the element-wise form above reads one 128-byte line per lane: 80 us for 2^18 x 64 inputs).
-constexpr uint32_t ID_TILE = 64;
+// transposes a tile of 256 samples through LDS: 16-byte reads along the features of consecutive samples, 8-byte writes that make
+// every wave store one 512-byte run of a feature row (the element-wise form above reads one 128-byte line per lane: 80 us for
+// 2^18 x 64 inputs; 64-sample tiles with 2-byte accesses: 30 us).
+constexpr uint32_t ID_TILE = 256, ID_LD = ID_TILE + 4;  // row pitch in halves: 8-byte aligned rows, 2 banks apart
 __global__ void __launch_bounds__(EW_THREADS) k_identity_forward_transpose(uint32_t n, uint32_t n_dims, uint32_t padded, float scale, float offset,
                                                                            const float* __restrict__ in, half_t* __restrict__ out) {
 	TCNN_DYN_LDS(lds_raw);
-	half_t* tile = (half_t*)lds_raw;  // [padded][ID_TILE + 2]
-	constexpr uint32_t LD = ID_TILE + 2;
+	half_t* tile = (half_t*)lds_raw;  // [n_dims][ID_LD]
 	const uint32_t first = blockIdx.x * ID_TILE;
 	const uint32_t rows = min(ID_TILE, n - first);
 	const float* src = in + (size_t)first * n_dims;
-	for (uint32_t e = threadIdx.x; e < rows * n_dims; e += EW_THREADS) {
-		const uint32_t s = e / n_dims, k = e - s * n_dims;
-		float t = src[e] * scale;
-		t = t + offset;
-		tile[k * LD + s] = to_half_rn(t);
+	if (n_dims % 4u == 0u && ((uintptr_t)src & 15u) == 0u) {
+		for (uint32_t e4 = threadIdx.x; e4 < rows * n_dims / 4u; e4 += EW_THREADS) {
+			const uint32_t e = 4u * e4, s = e / n_dims, k = e - s * n_dims;  // four features of one sample
+			const f4 v = *(const f4*)(src + e);
+#pragma unroll
+			for (uint32_t j = 0; j < 4; ++j) {
+				float t = v[j] * scale;
+				t = t + offset;
+				tile[(k + j) * ID_LD + s] = to_half_rn(t);
+			}
+		}
+	} else {
+		for (uint32_t e = threadIdx.x; e < rows * n_dims; e += EW_THREADS) {
+			const uint32_t s = e / n_dims, k = e - s * n_dims;
+			float t = src[e] * scale;
+			t = t + offset;
+			tile[k * ID_LD + s] = to_half_rn(t);
+		}
 	}
 	__syncthreads();
-	for (uint32_t e = threadIdx.x; e < padded * ID_TILE; e += EW_THREADS) {
-		const uint32_t k = e / ID_TILE, s = e % ID_TILE;
-		if (s < rows) out[(size_t)k * n + first + s] = k < n_dims ? tile[k * LD + s] : (half_t)1.0f;  // identity.h:62-64
+	if (rows == ID_TILE && n % 4u == 0u && ((uintptr_t)out & 7u) == 0u) {  // four samples of one feature per lane
+		const h4 ones = h4{(half_t)1.0f, (half_t)1.0f, (half_t)1.0f, (half_t)1.0f};  // identity.h:62-64: padding features are 1
+		for (uint32_t e4 = threadIdx.x; e4 < padded * (ID_TILE / 4u); e4 += EW_THREADS) {
+			const uint32_t k = e4 / (ID_TILE / 4u), s = 4u * (e4 % (ID_TILE / 4u));
+			*(h4*)(out + (size_t)k * n + first + s) = k < n_dims ? *(const h4*)(tile + k * ID_LD + s) : ones;
+		}
+	} else {
+		for (uint32_t e = threadIdx.x; e < padded * ID_TILE; e += EW_THREADS) {
+			const uint32_t k = e / ID_TILE, s = e % ID_TILE;
+			if (s < rows) out[(size_t)k * n + first + s] = k < n_dims ? tile[k * ID_LD + s] : (half_t)1.0f;  // identity.h:62-64
+		}
 	}
 }
 __global__ void k_identity_backward(uint32_t n, uint32_t n_dims, float scale, const half_t* __restrict__ dL_dy, uint32_t stride_k,
@@ -515,8 +536,9 @@ void identity_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t 
                       uint32_t in_stride_i, uint32_t in_stride_j, half_t* out, uint32_t stride_k, uint32_t stride_i) {
 	if (n == 0) return;
 	if (in_stride_j == 1 && in_stride_i == n_dims && stride_i == 1 && stride_k == n) {
-		TCNN_LAUNCH(k_identity_forward_transpose, dim3(div_round_up(n, ID_TILE)), dim3(EW_THREADS), n_dims * (ID_TILE + 2) * sizeof(half_t), stream, n, n_dims, padded,
-		            scale, offset, in, out);
+		const uint32_t lds = n_dims * ID_LD * (uint32_t)sizeof(half_t);  // 66.5 KB at the widest input (128)
+		TCNN_SET_MAX_DYN_LDS(k_identity_forward_transpose, lds);
+		TCNN_LAUNCH(k_identity_forward_transpose, dim3(div_round_up(n, ID_TILE)), dim3(EW_THREADS), lds, stream, n, n_dims, padded, scale, offset, in, out);
 		return;
 	}
 	TCNN_LAUNCH(k_identity_forward, dim3(div_round_up(n * padded, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, padded, scale, offset, in, in_stride_i, in_stride_j, out, stride_k, stride_i);

@@ -367,17 +367,19 @@ def targets_for(pos, out):
     return np.stack([0.5 + 0.5 * np.sin(2 * np.pi * (c + 1) * pos[:, 0]) * np.cos(2 * np.pi * pos[:, 1]) for c in range(out)], 1).astype(np.float32)
 
 
-@pytest.mark.parametrize("hidden_layers,n_features,out,act,out_act,loss", [
-    (4, 2, 16, "ReLU", "None", "RelativeL2"),    # BASELINE configs[4]'s network: k_mlp_train_wide<3, 1>
-    (2, 4, 3, "LeakyReLU", "Sigmoid", "L1"),     # 64 inputs, out-of-line activations / loss: k_mlp_train_wide<1, 2, general>
-    (1, 2, 4, "ReLU", "None", "L2"),
+@pytest.mark.parametrize("width,hidden_layers,n_features,out,act,out_act,loss", [
+    (128, 4, 2, 16, "ReLU", "None", "RelativeL2"),    # BASELINE configs[4]'s network: k_mlp_train_wide<3, 1>
+    (128, 2, 4, 3, "LeakyReLU", "Sigmoid", "L1"),     # 64 inputs, out-of-line activations / loss: k_mlp_train_wide<1, 2, general>
+    (128, 1, 2, 4, "ReLU", "None", "L2"),
+    (64, 2, 4, 4, "ReLU", "None", "RelativeL2"),      # BASELINE configs[1]'s network shape (64 inputs, 64 x 2): k_mlp_train_wave<64, 64, 1> at one wave per SIMD
+    (64, 1, 4, 16, "ReLU", "None", "L2"),             # k_mlp_train_wave<64, 64, 0>
 ])
-def test_wide_network_fused_training_step(hidden_layers, n_features, out, act, out_act, loss):
-    """128-neuron networks: training_step's single kernel (k_mlp_train_wide: weights resident in LDS, transpose reads, weight
+def test_wide_network_fused_training_step(width, hidden_layers, n_features, out, act, out_act, loss):
+    """128-neuron networks (and the 64-input instances of the register-resident kernel): training_step's single kernel (k_mlp_train_wide: weights resident in LDS, transpose reads, weight
     gradients in registers across eight 32-sample tiles per workgroup at this batch) against forward() + backward(), which run
     k_mlp_forward -> k_loss -> k_mlp_backward: same bits for prediction, loss gradient and everything that flows into the
     encoding; the fp32 weight-gradient sums are grouped per 32 instead of per 64 samples.  ReLU cases also against the oracle."""
-    cfg = config_hash(log2_hashmap_size=15, per_level_scale=1.5, n_neurons=128, n_hidden_layers=hidden_layers, loss=loss)
+    cfg = config_hash(log2_hashmap_size=15, per_level_scale=1.5, n_neurons=width, n_hidden_layers=hidden_layers, loss=loss)
     cfg["encoding"]["n_features_per_level"] = n_features
     cfg["network"].update(activation=act, output_activation=out_act)
     T = tcnn()
@@ -404,7 +406,10 @@ def test_wide_network_fused_training_step(hidden_layers, n_features, out, act, o
     g_u = h_np(tm.param_gradients)
     assert np.array_equal(out_f, h_np(ctx_u.output)) and np.array_equal(dy_f, h_np(ctx_u.dL_doutput))
     assert abs(loss_f - tm.loss(ctx_u)) <= 1e-5 * abs(loss_f)
-    assert torch.equal(dx_f, dx_u)                                 # dL/d(encoded input) has the same bits ...
+    if width == 128:
+        assert torch.equal(dx_f, dx_u)                             # dL/d(encoded input) has the same bits ...
+    else:  # the register-resident kernel sums dL/d(encoded input) in another association order: a last fp16 bit in ~1e-5 of its entries
+        assert torch.allclose(dx_f, dx_u, rtol=1e-2, atol=1e-3 * float(dx_u.abs().max()))
     ge_f, ge_u = O.h2f(g_f[nm:]), O.h2f(g_u[nm:])                  # ... the coarse levels' fp16 atomics add them in run-dependent order
     assert np.allclose(ge_f, ge_u, rtol=2e-2, atol=2e-3 * np.abs(ge_u).max())
     a, b = O.h2f(g_f[:nm]), O.h2f(g_u[:nm])
@@ -414,7 +419,7 @@ def test_wide_network_fused_training_step(hidden_layers, n_features, out, act, o
     if act != "ReLU":
         return
     og = oracle_grid(cfg["encoding"], 3)
-    md = O.model_init(3, out, og, 128, hidden_layers, O.LOSS_NAMES.index(loss), O.adam_defaults(learning_rate=1e-2, beta2=0.99, epsilon=1e-15, l2_reg=1e-6))
+    md = O.model_init(3, out, og, width, hidden_layers, O.LOSS_NAMES.index(loss), O.adam_defaults(learning_rate=1e-2, beta2=0.99, epsilon=1e-15, l2_reg=1e-6))
     assert md.n_params == tm.n_params
     st = O.TrainState(md, init)
     m = 4096  # the oracle's 128 x 4 step at the full batch takes a while; the first tiles are enough for it
@@ -433,6 +438,7 @@ def test_wide_network_fused_training_step(hidden_layers, n_features, out, act, o
     (64, 3, 2, 16, "ReLU", "None"),         # workgroup-tiled kernel
     (128, 4, 2, 16, "ReLU", "None"),        # LDS-resident weights
     (64, 2, 4, 3, "Tanh", "Sigmoid"),       # 64 inputs, out-of-line activations, output activation transfer inside the kernel
+    (64, 2, 4, 4, "ReLU", "None"),          # 64 inputs, 64 x 2: the one-wave-per-SIMD instance of the register-resident kernel (external dL/doutput)
     (32, 4, 2, 5, "LeakyReLU", "None"),
     # instances whose register allocation spills (k_mlp_train<64, 3>, k_mlp_train_wide<3, 1, general>): the resource report is not
     # a proof of anything either way -- results are

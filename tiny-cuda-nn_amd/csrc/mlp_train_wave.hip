@@ -106,8 +106,8 @@ constexpr uint32_t MLP_WAVE_STRIP = 32, MLP_WAVE_THREADS = 256;
 
 // EXTERNAL: no loss -- dL/doutput comes from la.external_dL_doutput (the backward pass of a module recomputing its forward pass).  A
 // compile-time switch: the loss instance is at the register limit (254), a run-time branch around the loss spills.
-template <uint32_t WIDTH, uint32_t IN, uint32_t HM, bool GENERAL, bool EXTERNAL>
-__global__ void __launch_bounds__(MLP_WAVE_THREADS, TCNN_MLP_WAVE_MIN_BLOCKS) k_mlp_train_wave(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
+template <uint32_t WIDTH, uint32_t IN, uint32_t HM, bool GENERAL, bool EXTERNAL, uint32_t MIN_WAVES = TCNN_MLP_WAVE_MIN_BLOCKS>
+__global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
                                                                         const half_t* __restrict__ params_t, const half_t* __restrict__ input,
                                                                         const MlpLossArgs la, half_t* __restrict__ output, half_t* __restrict__ dL_doutput,
                                                                         half_t* __restrict__ dL_dinput, float* __restrict__ partials,
@@ -556,10 +556,12 @@ bool mlp_train_wave_supported(const MlpMeta& m, uint32_t n, LossType loss) {
 	// ReLU / None and (Relative)L2 only: the instances with out-of-line activation / loss calls gain nothing here
 	if (!act_is_simple(m.activation) || !act_is_simple(m.output_activation) || !loss_is_simple(loss)) return false;
 	if (n > (1u << 26)) return false;  // 32-bit element offsets inside the kernel
-	// 64 inputs: one hidden layer only -- with two (the benchmarks/mlp shape) the 144 fp32 weight-gradient accumulators per lane
-	// spill at two waves per SIMD (101 registers) and the instance measured slower than the workgroup-tiled kernel
-	// (0.077 vs 0.068 ms at N = 2^18, profiles/r02_exp_notes.txt)
-	if (m.in_width == 64) return m.width == 64 && m.n_hidden_matmuls == 0;
+	// 64 inputs with two hidden layers (the benchmarks/mlp shape, BASELINE configs[1]): the 144 fp32 weight-gradient accumulators per
+	// lane spill at two waves per SIMD (0.077 vs 0.068 ms for the workgroup-tiled kernel, profiles/r02_exp_notes.txt); that instance is
+	// built for ONE wave per SIMD instead (174 VGPRs + 164 AGPRs holding the accumulators, no spill): 0.0679 vs 0.0716 ms for the stage
+	// (profiles/r03_exp_notes.txt).  TCNN_MLP_WAVE_64_64_1=0 restores the tiled kernel for it.
+	static const bool wide_regs = !(getenv("TCNN_MLP_WAVE_64_64_1") && atoi(getenv("TCNN_MLP_WAVE_64_64_1")) == 0);
+	if (m.in_width == 64) return m.width == 64 && (m.n_hidden_matmuls == 0 || (wide_regs && m.n_hidden_matmuls == 1));
 	return (m.width == 64 && m.n_hidden_matmuls <= 1) || (m.width == 32 && m.n_hidden_matmuls <= 2);
 }
 
@@ -568,15 +570,15 @@ uint32_t mlp_train_wave_n_partials(uint32_t n) {
 	return wanted < TCNN_MLP_WAVE_BLOCKS ? wanted : TCNN_MLP_WAVE_BLOCKS;
 }
 
-template <uint32_t WIDTH, uint32_t IN, uint32_t HM>
+template <uint32_t WIDTH, uint32_t IN, uint32_t HM, uint32_t MIN_WAVES = TCNN_MLP_WAVE_MIN_BLOCKS>
 static void launch_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
                               const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
-	const uint32_t blocks = mlp_train_wave_n_partials(n);
+	const uint32_t blocks = mlp_train_wave_n_partials(n);  // (one-wave-per-SIMD instances: one resident workgroup per CU holds half of them at a time)
 	if (la.external_dL_doutput) {
-		TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, true>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la, output,
+		TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, true, MIN_WAVES>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la, output,
 		            dL_doutput, dL_dinput, partials, block_sums);
 	} else {
-		TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, false>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la, output,
+		TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, false, MIN_WAVES>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la, output,
 		            dL_doutput, dL_dinput, partials, block_sums);
 	}
 }
@@ -587,6 +589,7 @@ void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half
 	const uint32_t key = (m.in_width == 64 ? 10000u : 0u) + m.width * 10u + m.n_hidden_matmuls;
 	switch (key) {
 		case 10640: launch_train_wave<64, 64, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
+		case 10641: launch_train_wave<64, 64, 1, 1>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;  // one wave per SIMD
 		case 640: launch_train_wave<64, 32, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		case 641: launch_train_wave<64, 32, 1>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		case 320: launch_train_wave<32, 32, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;

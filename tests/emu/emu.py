@@ -233,10 +233,19 @@ def loss(loss_type, prediction_h, target, dims, loss_scale=128.0, data_pdf=None,
     return values, grads, float(s[0])
 
 
-def adam_step(oh, n_matrix, loss_scale, current_step, w32, w16, grads_h, m1, m2, steps, steps_are_deficits=False):
+STEPS_COUNTERS, STEPS_DEFICITS32, STEPS_DEFICITS8 = 0, 1, 2  # elementwise_kernels.h AdamStepsForm
+
+
+def adam_step(oh, n_matrix, loss_scale, current_step, w32, w16, grads_h, m1, m2, steps, steps_are_deficits=False, deficits8=None):
+    """steps_are_deficits: False / True (32-bit deficits) or an AdamStepsForm; deficits8: the byte array of the byte form."""
     e = EmuAdam(*[getattr(oh, f[0]) for f in EmuAdam._fields_])
     lib().emu_adam_step(C.byref(e), C.c_uint32(w32.size), C.c_uint32(n_matrix), C.c_float(loss_scale), C.c_uint32(current_step),
-                        _p(w32), _p(w16), _p(grads_h), _p(m1), _p(m2), _p(steps), C.c_int(int(steps_are_deficits)))
+                        _p(w32), _p(w16), _p(grads_h), _p(m1), _p(m2), _p(steps), C.c_int(int(steps_are_deficits)), _p(deficits8))
+
+
+def adam_convert_steps(steps_done, steps, deficits8, form_from, form_to):
+    """per-parameter step counters: any AdamStepsForm -> any other, in place"""
+    lib().emu_adam_convert_steps(C.c_uint32(steps.size), C.c_uint32(steps_done), _p(steps), _p(deficits8), C.c_int(form_from), C.c_int(form_to))
 
 
 def adam_flip_steps(steps_done, steps):

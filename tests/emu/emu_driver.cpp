@@ -216,8 +216,14 @@ int emu_adam_flip_steps(uint32_t n, uint32_t steps_done, uint32_t* steps) {
 	return 0;
 }
 
+// any AdamStepsForm -> any other, in place (deficits8: n bytes, needed when the byte form is involved)
+int emu_adam_convert_steps(uint32_t n, uint32_t steps_done, uint32_t* steps, uint8_t* deficits8, int from, int to) {
+	adam_convert_step_representation(nullptr, n, steps_done, steps, deficits8, from, to);
+	return 0;
+}
+
 int emu_adam_step(const EmuAdam* e, uint32_t n, uint32_t n_matrix, float loss_scale, uint32_t current_step, float* w32, uint16_t* w16,
-                  const uint16_t* grads, float* m1, float* m2, uint32_t* steps, int steps_are_deficits) {
+                  const uint16_t* grads, float* m1, float* m2, uint32_t* steps, int steps_form, uint8_t* deficits8) {
 	AdamHyper h;
 	h.learning_rate = e->learning_rate;
 	h.beta1 = e->beta1;
@@ -235,7 +241,7 @@ int emu_adam_step(const EmuAdam* e, uint32_t n, uint32_t n_matrix, float loss_sc
 	h.optimize_non_matrix_params = e->optimize_non_matrix_params != 0;
 	h.skip_zero_grad_non_matrix_params = e->skip_zero_grad_non_matrix_params != 0;
 	adam_step(nullptr, h, n, n_matrix, loss_scale, current_step, w32, (half_t*)w16, (const half_t*)grads, m1, m2, steps, nullptr, nullptr, 0, 0xFFFFFFFFu,
-	          steps_are_deficits != 0);
+	          steps_form, deficits8);
 	return 0;
 }
 

@@ -393,6 +393,44 @@ def test_adam_step_counters_kept_as_deficits():
     assert a[4].min() < a[4].max()
 
 
+def test_adam_step_deficits_kept_as_bytes():
+    """The deficits as BYTES (AdamStepsForm 2: 255 = the counter itself lives in the 32-bit array): same state as the counter form at
+    every step, across conversions in both directions, and for parameters that are skipped more than 254 times in a row (they move
+    into the 32-bit array, keep counting there and come back when the representation is rebuilt)."""
+    rng = np.random.default_rng(6)
+    h = O.adam_defaults(learning_rate=1e-2, beta2=0.99, epsilon=1e-15, l2_reg=1e-6)
+    n, nm = 512 + 3, 128
+    w = rng.standard_normal(n).astype(np.float32)
+    a = [w.copy(), O.f2h(w), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint32)]
+    b = [x.copy() for x in a]
+    bytes8 = np.zeros(n, np.uint8)
+    form = emu.STEPS_COUNTERS
+    never = np.arange(300, 340)       # entries that are (almost) never touched: their deficits leave the byte's range
+    for step in range(1, 301):
+        want = emu.STEPS_COUNTERS if step in (3, 4, 280) else (emu.STEPS_DEFICITS32 if step == 150 else emu.STEPS_DEFICITS8)
+        g = (rng.standard_normal(n) * 20).astype(np.float32)
+        g[rng.random(n) < 0.3] = 0
+        g[400:404] = 0  # a whole group of four
+        if step not in (1, 270):
+            g[never] = 0
+        gh = O.f2h(g)
+        if want != form:
+            emu.adam_convert_steps(step - 1, b[4], bytes8, form, want)
+            form = want
+        O.adam_step(h, nm, 128.0, step, a[0], a[1], gh, a[2], a[3], a[4])
+        emu.adam_step(h, nm, 128.0, step, b[0], b[1], gh, b[2], b[3], b[4], steps_are_deficits=form, deficits8=bytes8)
+        if form == emu.STEPS_DEFICITS8:
+            counters = np.where(bytes8 == 255, b[4], (step - bytes8.astype(np.uint32)).astype(np.uint32))
+        else:
+            counters = (step - b[4]).astype(np.uint32) if form == emu.STEPS_DEFICITS32 else b[4]
+        assert np.array_equal(counters, a[4]), step
+        if step in (2, 149, 269, 300):
+            for x, y in zip(a[:4], b[:4]):
+                assert np.allclose(x.astype(np.float32) if x.dtype != np.uint16 else O.h2f(x), y.astype(np.float32) if y.dtype != np.uint16 else O.h2f(y), rtol=1e-5, atol=1e-8), step
+    assert (bytes8[never] == 255).all() or form != emu.STEPS_DEFICITS8  # they left the byte's range at some point ...
+    assert a[4][never].max() <= 2                                         # ... having been stepped twice at most
+
+
 def test_grid_stochastic_interpolation_backward():
     """stochastic_interpolation (grid.h:284-299): every backward mode routes to the single-corner atomic scatter; the corner
     is the oracle's for every (sample, level) -- the sums are exact in fp16 here (unit gradients, few samples per entry)."""

@@ -149,6 +149,34 @@ def test_adam_bit_level_in_both_step_counter_forms(l2_reg, clip):
     assert len(np.unique(st.steps)) > 3  # the skip path was exercised
 
 
+def test_adam_byte_deficits_beyond_254_skipped_steps():
+    """The step-counter deficits kept as bytes (api.hip choose_step_representation; elementwise_kernels.h AdamStepsForm): entries that are
+    skipped more than 254 times in a row move into the 32-bit counter array (byte 255) and keep their exact count -- 300 optimizer steps on
+    the GPU against the oracle's counters, with a snapshot (which converts to counters and back) in the middle."""
+    T = tcnn()
+    cfg = config_hash(log2_hashmap_size=10, per_level_scale=1.5)
+    tm = T.create_from_config(3, 4, cfg)
+    n, nm = tm.n_params, tm.n_mlp_params
+    tm.set_global_batch_size(1 << 20)  # deficit form
+    rng = np.random.default_rng(12)
+    counters = np.zeros(n, np.uint32)
+    never = np.arange(nm + 64, nm + 640)  # grid entries that see a gradient at steps 1 and 290 only
+    for step in range(1, 301):
+        g = (rng.standard_normal(n) * 0.1).astype(np.float16)
+        g[nm:][rng.random(n - nm) < 0.3] = 0
+        if step not in (1, 290):
+            g[never] = 0
+        tm.param_gradients.copy_(h_t(g.view(np.uint16)))
+        tm.optimizer_step()
+        stepped = np.ones(n, bool)
+        stepped[nm:] = g[nm:] != 0  # adam.h:79-82: zero-gradient non-matrix entries are skipped
+        counters += stepped
+        if step in (100, 270, 300):
+            _, _, steps, current = _optimizer_state(tm)  # serialises: bytes -> counters (and back at the next step)
+            assert current == step and np.array_equal(steps, counters), step
+    assert counters[never].max() == 2 and counters[:nm].min() == 300
+
+
 def test_optimizer_object_on_its_own_bit_level():
     """tcnn_create_optimizer / Optimizer<T>::allocate + step (optimizer.h:52-60) over buffers the caller owns: the trainer's Adam kernel
     behind another door -- moments and per-parameter step counters bit-equal to the oracle's adam_step (itself pinned against the
@@ -256,7 +284,10 @@ def test_optimizer_inside_the_grid_backward_equals_the_separate_step(n, log2_t, 
     ctx_a, ctx_b = a.training_step(x, t), b.training_step(x, t)  # one step from identical states
     assert a.loss(ctx_a) == b.loss(ctx_b)
     sa, sb = a.optimizer_state(), b.optimizer_state()
-    assert sa[3] == sb[3] == (n >= 4096) and a.optimizer_step_count == b.optimizer_step_count == 1
+    # the fused step keeps 32-bit deficits at large batches; the separate kernel keeps them as bytes, which hosts see as counters
+    assert sa[3] == (n >= 4096) and sb[3] is False and a.optimizer_step_count == b.optimizer_step_count == 1
+    as_counters = lambda st: (st[0], st[1], (1 - st[2]) if st[3] else st[2])
+    sa, sb = as_counters(sa), as_counters(sb)
     for lo, hi in bounds:
         ga, gb = a.param_gradients[lo:hi], b.param_gradients[lo:hi]
         if torch.equal(ga.view(torch.int16), gb.view(torch.int16)):  # exactly accumulated part: everything downstream is identical

@@ -943,7 +943,8 @@ struct tcnn_trainable_model {
 	uint32_t* steps = nullptr;
 	// `steps` holds the counters' deficits instead (elementwise_kernels.h: adam_flip_step_representation) while most
 	// table entries are stepped every time; chosen per optimizer step from the last batch size, see choose_step_representation
-	bool steps_are_deficits = false;
+	int steps_form = ADAM_STEPS_COUNTERS;  // AdamStepsForm of `steps` (+ `step_deficits8` for the byte form)
+	uint8_t* step_deficits8 = nullptr;     // n_params bytes
 	uint32_t last_batch = 0;
 	uint64_t global_batch = 0;
 	uint32_t lds_level_budget = 0;  // 0: default LDS slice size of the sliced grid backward
@@ -1472,6 +1473,7 @@ int tcnn_create_from_config(uint32_t n_input_dims, uint32_t n_output_dims, const
 	tm->m1 = device_malloc_n<float>(n);  // adam.h:136-156
 	tm->m2 = device_malloc_n<float>(n);
 	tm->steps = device_malloc_n<uint32_t>(n);
+	tm->step_deficits8 = device_malloc_n<uint8_t>(n);
 	HIP_CHECK(hipMemset(tm->m1, 0, n * sizeof(float)));
 	HIP_CHECK(hipMemset(tm->m2, 0, n * sizeof(float)));
 	HIP_CHECK(hipMemset(tm->steps, 0, n * sizeof(uint32_t)));
@@ -1503,6 +1505,7 @@ void tcnn_trainable_model_destroy(tcnn_trainable_model_t* tm) {
 	device_free(tm->m1);
 	device_free(tm->m2);
 	device_free(tm->steps);
+	device_free(tm->step_deficits8);
 	device_free(tm->params_t);
 	device_free(tm->params_ema);
 	device_free(tm->ema_tmp);
@@ -1660,18 +1663,27 @@ int tcnn_trainer_backward(tcnn_trainable_model_t* tm, tcnn_stream_t stream, cons
 // the first form and 4 B in the second, a skipped (zero-gradient) hash-table entry 0 B and 8 B.  With N samples touching
 // 2^D corners per level, an entry of a level with T entries is skipped with probability exp(-N 2^D / T): deficits pay off
 // below ~1/3, i.e. for N 2^D >= T at the largest level (the headline: 4 T).  TCNN_ADAM_STEP_DEFICITS=0/1 forces a form.
-static bool choose_step_representation(const tcnn_trainable_model* tm) {
+// The deficits are kept as BYTES (255 = the parameter's counter itself lives in the 32-bit array): one byte of bookkeeping per stepped
+// parameter instead of four; the 32-bit deficit form remains for the optimizer step fused into the grid backward and for
+// TCNN_ADAM_STEP_DEFICITS=1 (=0: counters, =2: bytes).
+static int choose_step_representation(const tcnn_trainable_model* tm) {
 	static const int forced = [] {
 		const char* e = getenv("TCNN_ADAM_STEP_DEFICITS");
-		return e ? (e[0] == '0' ? 0 : 1) : -1;
+		return e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : -1;
 	}();
-	if (forced >= 0) return forced != 0;
-	if (!tm->md.enc.is_grid) return true;  // network weights are stepped every time
+	if (forced >= 0) return forced;
+	const int deficits = tm->fused_optimizer ? ADAM_STEPS_DEFICITS32 : ADAM_STEPS_DEFICITS8;
+	if (!tm->md.enc.is_grid) return deficits;  // network weights are stepped every time
 	const auto& g = tm->md.enc.grid;
 	uint32_t largest = 0;
 	for (uint32_t l = 0; l < g.n_levels; ++l) largest = std::max(largest, g.offset[l + 1] - g.offset[l]);
 	const uint64_t batch = tm->global_batch ? tm->global_batch : tm->last_batch;  // the reduced gradient covers the global batch
-	return (batch << g.n_dims) >= (uint64_t)largest;
+	return (batch << g.n_dims) >= (uint64_t)largest ? deficits : ADAM_STEPS_COUNTERS;
+}
+// the per-parameter step counters as counters (what snapshots and hosts see); `steps_done` = optimizer steps completed
+static void step_counters_to_counter_form(tcnn_trainable_model* tm, hipStream_t stream, uint32_t steps_done) {
+	adam_convert_step_representation(stream, (uint32_t)tm->md.n_params(), steps_done, tm->steps, tm->step_deficits8, tm->steps_form, ADAM_STEPS_COUNTERS);
+	tm->steps_form = ADAM_STEPS_COUNTERS;
 }
 
 // Optimizer::step over a set of parameter ranges [begin, end) (begins multiples of 8).  `advance`: this call opens a new
@@ -1686,10 +1698,10 @@ static void optimizer_advance(tcnn_trainable_model_t* tm, hipStream_t stream) {
 		tm->adam.learning_rate = tm->base_lr * tm->lr_factor;
 	}
 	++tm->optimizer_step;  // adam.h:159
-	const bool want_deficits = choose_step_representation(tm);
-	if (want_deficits != tm->steps_are_deficits) {
-		adam_flip_step_representation(stream, (uint32_t)tm->md.n_params(), tm->optimizer_step - 1u, tm->steps);
-		tm->steps_are_deficits = want_deficits;
+	const int want = choose_step_representation(tm);
+	if (want != tm->steps_form) {
+		adam_convert_step_representation(stream, (uint32_t)tm->md.n_params(), tm->optimizer_step - 1u, tm->steps, tm->step_deficits8, tm->steps_form, want);
+		tm->steps_form = want;
 	}
 }
 
@@ -1714,7 +1726,7 @@ static void optimizer_step_ranges(tcnn_trainable_model_t* tm, hipStream_t stream
 		ProfScope prof(stream, STAGE_ADAM, /*counts=*/opens_profiled_step && r == 0);  // a ranged (bucketed) step is ONE optimizer step
 		adam_step(stream, tm->adam, (uint32_t)n, (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master, tm->params, tm->grads,
 		          tm->m1, tm->m2, tm->steps, tm->params_t_valid ? tm->params_t : nullptr, tm->md.has_network ? &tm->md.net.mlp : nullptr, (uint32_t)begin,
-		          (uint32_t)end, tm->steps_are_deficits);
+		          (uint32_t)end, tm->steps_form, tm->step_deficits8);
 		if (tm->ema) ema_step(stream, (uint32_t)n, tm->ema_decay, tm->optimizer_step, tm->params, tm->params_ema, tm->ema_tmp, (uint32_t)begin, (uint32_t)end);
 	}
 }
@@ -1782,7 +1794,17 @@ int tcnn_trainer_enable_rccl(tcnn_trainable_model_t* tm, void* nccl_comm, int n_
 // Adam's state for snapshots / sharded data parallelism: which = 0 first moments (fp32), 1 second moments (fp32),
 // 2 per-parameter step counters (u32; *steps_are_deficits tells their representation, see tcnn_trainer_optimizer_step_range).
 void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* steps_are_deficits) {
-	if (steps_are_deficits) *steps_are_deficits = tm->steps_are_deficits ? 1 : 0;
+	if (which == 2 && tm->steps_form == ADAM_STEPS_DEFICITS8) {  // the byte form is the library's own business: hosts see counters
+		(void)hipDeviceSynchronize();
+		try {
+			step_counters_to_counter_form(tm, nullptr, tm->optimizer_step);
+		} catch (const std::exception& ex) {
+			g_last_error = ex.what();
+			return nullptr;
+		}
+		(void)hipDeviceSynchronize();
+	}
+	if (steps_are_deficits) *steps_are_deficits = tm->steps_form == ADAM_STEPS_DEFICITS32 ? 1 : 0;
 	return which == 0 ? (void*)tm->m1 : which == 1 ? (void*)tm->m2 : which == 2 ? (void*)tm->steps : nullptr;
 }
 
@@ -1896,7 +1918,8 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 		if (fuse) {
 			optimizer_advance(tm, stream);
 			optimizer_opened = true;
-			core = make_adam_core(tm->adam, (uint32_t)n_mlp, loss_scale, tm->optimizer_step, tm->steps_are_deficits);
+			if (tm->steps_form == ADAM_STEPS_DEFICITS8) throw std::runtime_error("fused optimizer: unexpected byte form of the step deficits");
+			core = make_adam_core(tm->adam, (uint32_t)n_mlp, loss_scale, tm->optimizer_step, tm->steps_form);
 			fa.core = &core;
 			fa.master = tm->master + n_mlp;
 			fa.params = tm->params + n_mlp;
@@ -2131,8 +2154,12 @@ int tcnn_trainer_serialize(tcnn_trainable_model_t* tm, int serialize_optimizer, 
 			host_steps.resize(s.param_steps.size);
 			HIP_CHECK(hipMemcpy(host_m1.data(), tm->m1, host_m1.size(), hipMemcpyDeviceToHost));
 			HIP_CHECK(hipMemcpy(host_m2.data(), tm->m2, host_m2.size(), hipMemcpyDeviceToHost));
+			if (tm->steps_form == ADAM_STEPS_DEFICITS8) {  // (the next optimizer step picks its representation again)
+				step_counters_to_counter_form(tm, nullptr, tm->optimizer_step);
+				HIP_CHECK(hipDeviceSynchronize());
+			}
 			HIP_CHECK(hipMemcpy(host_steps.data(), tm->steps, host_steps.size(), hipMemcpyDeviceToHost));
-			if (tm->steps_are_deficits) {  // snapshots hold the counters themselves (adam.h:311)
+			if (tm->steps_form == ADAM_STEPS_DEFICITS32) {  // snapshots hold the counters themselves (adam.h:311)
 				uint32_t* counters = (uint32_t*)host_steps.data();
 				for (size_t i = 0; i < n_params_of(tm); ++i) counters[i] = tm->optimizer_step - counters[i];
 			}
@@ -2179,7 +2206,7 @@ int tcnn_trainer_deserialize(tcnn_trainable_model_t* tm, const void* data, size_
 		} else {
 			HIP_CHECK(hipMemset(tm->steps, 0, n * sizeof(uint32_t)));
 		}
-		tm->steps_are_deficits = false;  // the next optimizer step picks the representation again
+		tm->steps_form = ADAM_STEPS_COUNTERS;  // the next optimizer step picks the representation again
 		tm->optimizer_step = s.current_step;
 		tm->adam.learning_rate = s.base_learning_rate;
 		if (tm->ema) {  // ema.h:195-204

@@ -96,7 +96,11 @@ void ema_step(hipStream_t stream, uint32_t n, float ema_decay, uint32_t current_
 
 // the per-parameter arithmetic and its argument block (adam_device.h), for kernels that apply the step themselves
 struct AdamCore;
-AdamCore make_adam_core(const AdamHyper& h, uint32_t n_matrix_weights, float loss_scale, uint32_t current_step, bool steps_are_deficits);
+// Representation of the per-parameter step counters (adam.h:84 m_param_steps), see adam_device.h AdamCore::deficit:
+// the counters themselves; their deficits steps_done - counter as 32-bit words; the deficits as BYTES (255 = "the counter itself is in
+// the 32-bit array"): a parameter that is stepped every time costs 4 / 1 bytes of bookkeeping per step and no write.
+enum AdamStepsForm : int { ADAM_STEPS_COUNTERS = 0, ADAM_STEPS_DEFICITS32 = 1, ADAM_STEPS_DEFICITS8 = 2 };
+AdamCore make_adam_core(const AdamHyper& h, uint32_t n_matrix_weights, float loss_scale, uint32_t current_step, int steps_form);
 bool adam_streams_its_state(uint32_t n_params);  // optimizer state too large for the Infinity Cache: non-temporal accesses
 
 // weights_t (nullable) + mlp: also keep the transposed copy of the network weights (mlp_transposed_index) current, so
@@ -104,12 +108,14 @@ bool adam_streams_its_state(uint32_t n_params);  // optimizer state too large fo
 void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale,
                uint32_t current_step, float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2,
                uint32_t* param_steps, half_t* weights_t = nullptr, const MlpMeta* mlp = nullptr, uint32_t begin = 0, uint32_t end = 0xFFFFFFFFu,
-               bool steps_are_deficits = false);
+               int steps_form = ADAM_STEPS_COUNTERS, uint8_t* deficits8 = nullptr);
 // param_steps holds either the per-parameter step counters (adam.h:84) or, with steps_are_deficits, their deficit
 // steps_done - counter (steps_done = current_step - 1): a stepped parameter then reads its 4 bytes and writes nothing, a
 // skipped one is incremented -- cheaper when most parameters are stepped every time (the headline table: 98 %), dearer
 // when most are skipped.  This converts one representation into the other, in place (its own inverse).
 void adam_flip_step_representation(hipStream_t stream, uint32_t n, uint32_t steps_done, uint32_t* param_steps);
+// any form -> any form (AdamStepsForm), in place; deficits8 (n bytes) is needed when the byte form is involved
+void adam_convert_step_representation(hipStream_t stream, uint32_t n, uint32_t steps_done, uint32_t* param_steps, uint8_t* deficits8, int from, int to);
 
 // encodings/identity.h:46-84.  in: fp32 element (dim j, sample i) at in[i*in_stride_i + j*in_stride_j];
 // out: half element (k, i) at out[k*stride_k + i*stride_i], k < padded, padding value 1.

@@ -310,13 +310,28 @@ struct AdamArgs : AdamCore {
 	MlpMeta mlp;                 // layout of the matrix weights (for weights_t)
 };
 
+// Byte form of the step-counter deficits (AdamCore::deficit == 2): deficits8[p] = steps_done - counter[p] while that is < 255; 255
+// means "the counter itself is in param_steps[p]" (a parameter that has been skipped 255 times since it last fitted a byte stays in
+// counter form).  A parameter that is stepped every time then costs ONE byte of step bookkeeping per step instead of four.
+// count-before-this-step of parameter p with deficit byte d:
+TCNN_DEVICE uint32_t adam_count8(const AdamCore& a, uint32_t d, const uint32_t* param_steps, uint32_t p) { return d == 255u ? param_steps[p] : a.steps_done - d; }
+// the byte after this step: stepped -> unchanged (a saturated one writes its new count); skipped -> one more missed step
+TCNN_DEVICE uint32_t adam_next8(const AdamCore& a, uint32_t d, bool stepped, uint32_t new_count, uint32_t* param_steps, uint32_t p) {
+	if (stepped) {
+		if (d == 255u) param_steps[p] = new_count;
+		return d;
+	}
+	if (d == 254u) param_steps[p] = a.steps_done - 254u;  // leaves the byte's range: its counter from now on
+	return d < 255u ? d + 1u : 255u;
+}
+
 // 4 parameters per lane: 8 B of gradients decide whether the 16-byte state loads happen at all, so
 // untouched stretches of a hash table cost 2 B/param as in the reference (adam.h:79-82).
 template <bool STREAM>
 __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, float* __restrict__ weights_fp32, half_t* __restrict__ weights,
                                                            const half_t* __restrict__ gradients, float* __restrict__ first_moments,
                                                            float* __restrict__ second_moments, uint32_t* __restrict__ param_steps,
-                                                           half_t* __restrict__ weights_t) {
+                                                           half_t* __restrict__ weights_t, uint8_t* __restrict__ deficits8) {
 	const uint32_t i0 = a.begin + (blockIdx.x * EW_THREADS + threadIdx.x) * 4;
 	const bool four = i0 < a.n_elements && i0 + 3 < a.n_elements;
 	h4 g = h4{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
@@ -333,7 +348,13 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 	if (i0 >= a.n_elements) return;
 	if (four) {
 		if (skip_all) {
-			if (a.deficit) {  // all four skipped: one more missed step each
+			if (a.deficit == 2) {  // all four skipped: one more missed step each
+				const uint32_t b4 = *(const uint32_t*)(deficits8 + i0);
+				uint32_t n4 = 0;
+#pragma unroll
+				for (uint32_t j = 0; j < 4; ++j) n4 |= adam_next8(a, (b4 >> (8u * j)) & 255u, false, 0u, param_steps, i0 + j) << (8u * j);
+				if (n4 != b4) *(uint32_t*)(deficits8 + i0) = n4;
+			} else if (a.deficit) {
 				u4 st = adam_load<STREAM>((const u4*)(param_steps + i0));
 				st += 1u;
 				adam_store<STREAM>((u4*)(param_steps + i0), st);
@@ -343,15 +364,22 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 		f4 w = adam_load<STREAM>((const f4*)(weights_fp32 + i0));
 		f4 m1 = adam_load<STREAM>((const f4*)(first_moments + i0));
 		f4 m2 = adam_load<STREAM>((const f4*)(second_moments + i0));
-		u4 st = adam_load<STREAM>((const u4*)(param_steps + i0));
+		const bool bytes = a.deficit == 2;
+		const uint32_t b4 = bytes ? *(const uint32_t*)(deficits8 + i0) : 0u;
+		uint32_t n4 = 0;
+		u4 st = u4{0u, 0u, 0u, 0u};
+		if (!bytes) st = adam_load<STREAM>((const u4*)(param_steps + i0));
 		h4 wh = h4{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
 		uint32_t updated = 0;  // bit j: parameter i0 + j was stepped
 		bool any = false;
 #pragma unroll
 		for (uint32_t j = 0; j < 4; ++j) {
 			float wj = w[j], m1j = m1[j], m2j = m2[j];
-			uint32_t sj = a.deficit ? a.steps_done - st[j] : st[j];
-			if (adam_one(a, i0 + j, (float)g[j], wj, m1j, m2j, sj)) {
+			const uint32_t dj = (b4 >> (8u * j)) & 255u;
+			uint32_t sj = bytes ? adam_count8(a, dj, param_steps, i0 + j) : (a.deficit ? a.steps_done - st[j] : st[j]);
+			const bool stepped = adam_one(a, i0 + j, (float)g[j], wj, m1j, m2j, sj);
+			if (bytes) n4 |= adam_next8(a, dj, stepped, sj, param_steps, i0 + j) << (8u * j);
+			if (stepped) {
 				w[j] = wj;
 				m1[j] = m1j;
 				m2[j] = m2j;
@@ -360,11 +388,12 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 				if (weights_t && i0 + j < a.n_matrix_weights) weights_t[mlp_transposed_index(a.mlp, i0 + j)] = wh[j];
 				any = true;
 				updated |= 1u << j;
-			} else if (a.deficit) {
+			} else if (a.deficit == 1) {
 				st[j] += 1u;
 			}
 		}
-		if (a.deficit && updated != 0xFu) adam_store<STREAM>((u4*)(param_steps + i0), st);
+		if (bytes && n4 != b4) *(uint32_t*)(deficits8 + i0) = n4;
+		if (a.deficit == 1 && updated != 0xFu) adam_store<STREAM>((u4*)(param_steps + i0), st);
 		if (any || a.dense_store) {
 			if (updated != 0xFu) {  // keep the fp16 weights of the parameters that were skipped (only then are they read)
 				const h4 old = *(const h4*)(weights + i0);
@@ -382,15 +411,19 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 	} else {
 		for (uint32_t i = i0; i < a.n_elements; ++i) {
 			float wj = weights_fp32[i], m1j = first_moments[i], m2j = second_moments[i];
-			uint32_t sj = a.deficit ? a.steps_done - param_steps[i] : param_steps[i];
-			if (adam_one(a, i, (float)gradients[i], wj, m1j, m2j, sj)) {
+			const bool bytes = a.deficit == 2;
+			const uint32_t dj = bytes ? deficits8[i] : 0u;
+			uint32_t sj = bytes ? adam_count8(a, dj, param_steps, i) : (a.deficit ? a.steps_done - param_steps[i] : param_steps[i]);
+			const bool stepped = adam_one(a, i, (float)gradients[i], wj, m1j, m2j, sj);
+			if (bytes) deficits8[i] = (uint8_t)adam_next8(a, dj, stepped, sj, param_steps, i);
+			if (stepped) {
 				weights_fp32[i] = wj;
 				first_moments[i] = m1j;
 				second_moments[i] = m2j;
 				if (!a.deficit) param_steps[i] = sj;
 				weights[i] = to_half_rn(wj);
 				if (weights_t && i < a.n_matrix_weights) weights_t[mlp_transposed_index(a.mlp, i)] = weights[i];
-			} else if (a.deficit) {
+			} else if (a.deficit == 1) {
 				param_steps[i] += 1u;
 			}
 		}
@@ -399,7 +432,7 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 
 constexpr size_t ADAM_STREAM_THRESHOLD_BYTES = 192u << 20;  // optimizer state beyond this cannot stay in the 256 MiB Infinity Cache
 
-AdamCore make_adam_core(const AdamHyper& h, uint32_t n_matrix_weights, float loss_scale, uint32_t current_step, bool steps_are_deficits) {
+AdamCore make_adam_core(const AdamHyper& h, uint32_t n_matrix_weights, float loss_scale, uint32_t current_step, int steps_form) {
 	AdamCore a;
 	a.n_matrix_weights = n_matrix_weights;
 	a.relative_weight_decay = h.relative_weight_decay;
@@ -424,7 +457,7 @@ AdamCore make_adam_core(const AdamHyper& h, uint32_t n_matrix_weights, float los
 	a.l2_reg = h.l2_reg;
 	a.non_matrix_l2_reg = h.non_matrix_l2_reg;
 	a.steps_done = current_step - 1u;
-	a.deficit = steps_are_deficits ? 1 : 0;
+	a.deficit = steps_form;
 	static const bool dense = !(getenv("TCNN_ADAM_DENSE_STORE") && atoi(getenv("TCNN_ADAM_DENSE_STORE")) == 0);  // =0: the sparse form, for A/B runs
 	a.dense_store = dense ? 1 : 0;
 	return a;
@@ -433,21 +466,22 @@ bool adam_streams_its_state(uint32_t n) { return (size_t)n * 32u > ADAM_STREAM_T
 
 void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale, uint32_t current_step,
                float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2, uint32_t* param_steps, half_t* weights_t,
-               const MlpMeta* mlp, uint32_t begin, uint32_t end, bool steps_are_deficits) {
+               const MlpMeta* mlp, uint32_t begin, uint32_t end, int steps_form, uint8_t* deficits8) {
 	if (end > n) end = n;
 	if (begin >= end) return;
 	if (begin % 4u != 0u) throw std::runtime_error("adam_step: a parameter range must start at a multiple of 4");
 	if (weights_t && !mlp) throw std::runtime_error("adam_step: weights_t needs the network layout");
 	AdamArgs a;
-	(AdamCore&)a = make_adam_core(h, n_matrix_weights, loss_scale, current_step, steps_are_deficits);
+	if (steps_form == ADAM_STEPS_DEFICITS8 && !deficits8) throw std::runtime_error("adam_step: the byte form of the step deficits needs its array");
+	(AdamCore&)a = make_adam_core(h, n_matrix_weights, loss_scale, current_step, steps_form);
 	a.begin = begin;
 	a.n_elements = end;
 	a.mlp = mlp ? *mlp : MlpMeta{};
 	const dim3 grid(div_round_up(div_round_up(end - begin, 4u), EW_THREADS));
 	if (adam_streams_its_state(n)) {
-		TCNN_LAUNCH(k_adam_step<true>, grid, dim3(EW_THREADS), 0, stream, a, weights_fp32, weights, gradients, m1, m2, param_steps, weights_t);
+		TCNN_LAUNCH(k_adam_step<true>, grid, dim3(EW_THREADS), 0, stream, a, weights_fp32, weights, gradients, m1, m2, param_steps, weights_t, deficits8);
 	} else {
-		TCNN_LAUNCH(k_adam_step<false>, grid, dim3(EW_THREADS), 0, stream, a, weights_fp32, weights, gradients, m1, m2, param_steps, weights_t);
+		TCNN_LAUNCH(k_adam_step<false>, grid, dim3(EW_THREADS), 0, stream, a, weights_fp32, weights, gradients, m1, m2, param_steps, weights_t, deficits8);
 	}
 }
 
@@ -459,6 +493,30 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_flip_steps(uint32_t n, uint
 void adam_flip_step_representation(hipStream_t stream, uint32_t n, uint32_t steps_done, uint32_t* param_steps) {
 	if (n == 0) return;
 	TCNN_LAUNCH(k_adam_flip_steps, dim3(div_round_up(n, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, steps_done, param_steps);
+}
+// counters -> byte deficits (to_bytes) and back; a counter more than 254 steps behind keeps living in param_steps (byte 255)
+__global__ void __launch_bounds__(EW_THREADS) k_adam_convert_steps8(uint32_t n, uint32_t steps_done, uint32_t* __restrict__ param_steps, uint8_t* __restrict__ deficits8,
+                                                                     int to_bytes) {
+	const uint32_t i = blockIdx.x * EW_THREADS + threadIdx.x;
+	if (i >= n) return;
+	if (to_bytes) {
+		const uint32_t d = steps_done - param_steps[i];
+		deficits8[i] = (uint8_t)(d < 255u ? d : 255u);
+	} else {
+		const uint32_t d = deficits8[i];
+		if (d != 255u) param_steps[i] = steps_done - d;
+	}
+}
+void adam_convert_step_representation(hipStream_t stream, uint32_t n, uint32_t steps_done, uint32_t* param_steps, uint8_t* deficits8, int from, int to) {
+	if (n == 0 || from == to) return;
+	// everything goes through the counters
+	if (from == ADAM_STEPS_DEFICITS32) adam_flip_step_representation(stream, n, steps_done, param_steps);
+	if (from == ADAM_STEPS_DEFICITS8) TCNN_LAUNCH(k_adam_convert_steps8, dim3(div_round_up(n, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, steps_done, param_steps, deficits8, 0);
+	if (to == ADAM_STEPS_DEFICITS32) adam_flip_step_representation(stream, n, steps_done, param_steps);
+	if (to == ADAM_STEPS_DEFICITS8) {
+		if (!deficits8) throw std::runtime_error("adam_convert_step_representation: missing byte array");
+		TCNN_LAUNCH(k_adam_convert_steps8, dim3(div_round_up(n, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, steps_done, param_steps, deficits8, 1);
+	}
 }
 
 // ------------------------------------------------------------------------------------------ identity

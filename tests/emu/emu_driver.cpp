@@ -162,7 +162,7 @@ int emu_mlp_backward(const EmuMlp* e, uint32_t n, const uint16_t* params, const 
 		std::vector<unsigned char> deep(mlp_backward_workspace_bytes(m, n) + 16, 0xCD);
 		mlp_backward(nullptr, m, n, (const half_t*)params_t.data(), (const half_t*)input_soa, (const half_t*)hidden,
 		             (const half_t*)dL_doutput, (half_t*)dL_dinput_soa, grads ? partials.data() : nullptr, deep.data());
-		if (grads) mlp_finalize_gradients(nullptr, m.n_params(), np, partials.data(), (half_t*)grads, accumulate != 0);
+		if (grads) mlp_finalize_gradients(nullptr, m, np, partials.data(), (half_t*)grads, accumulate != 0);
 	} catch (const std::exception& ex) {
 		fprintf(stderr, "emu_mlp_backward: %s\n", ex.what());
 		return 1;
@@ -184,9 +184,9 @@ int emu_mlp_train(const EmuMlp* e, uint32_t n, const uint16_t* params, const uin
 		std::vector<float> partials(grads ? (size_t)np * m.n_params() : 0, -12345.0f), block_sums(np, -777.0f), ws(1024);
 		MlpLossArgs la = {(LossType)loss_type, target, data_pdf, dims, loss_scale, n_total};
 		la.external_dL_doutput = (const half_t*)external_dL_doutput;
-		mlp_train(nullptr, m, n, (const half_t*)params, (const half_t*)params_t.data(), (const half_t*)input_soa, la, (half_t*)output,
+		const SlabOrder order = mlp_train(nullptr, m, n, (const half_t*)params, (const half_t*)params_t.data(), (const half_t*)input_soa, la, (half_t*)output,
 		          (half_t*)dL_doutput, (half_t*)dL_dinput_soa, grads ? partials.data() : nullptr, block_sums.data());
-		if (grads) mlp_finalize_gradients(nullptr, m.n_params(), np, partials.data(), (half_t*)grads, false);
+		if (grads) mlp_finalize_gradients(nullptr, m, np, partials.data(), (half_t*)grads, false, order);
 		if (loss_sum) reduce_sum(nullptr, block_sums.data(), block_sums.size(), ws.data(), loss_sum);
 	} catch (const std::exception& ex) {
 		fprintf(stderr, "emu_mlp_train: %s\n", ex.what());

@@ -128,6 +128,22 @@ inline int wave_shfl_xor(int v, int mask) {
 	return out;
 }
 
+// wave_rows_transpose4 of the device code (tcnn_device.h): lane (g, c) receives t[r] = element g of what lane (r, c) passed
+inline eh4 wave_rows_transpose4(eh4 v) {
+	Wave& w = g.waves[g.cur->tidx.x / 64];
+	const unsigned lane = g.cur->tidx.x & 63u, row = lane >> 4, col = lane & 15u;
+	memcpy(&w.b[lane], &v, sizeof(eh4));
+	wave_barrier();
+	eh4 out;
+	for (unsigned r = 0; r < 4; ++r) {
+		eh4 src;
+		memcpy(&src, &w.b[r * 16u + col], sizeof(eh4));
+		out[r] = src[row];
+	}
+	wave_barrier();
+	return out;
+}
+
 // sum over the wave in the xor-butterfly order of the device code (one rendezvous instead of six shuffles)
 inline float wave_sum_f32(float v) {
 	Wave& w = g.waves[g.cur->tidx.x / 64];

@@ -747,9 +747,9 @@ static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx
 		if (recompute) {  // forward from the encoded input again, then backward from the caller's dL/doutput, in one kernel
 			MlpLossArgs la = {LossType::L2, nullptr, nullptr, md.output_width(), 1.0f, 1u};
 			la.external_dL_doutput = dL_doutput;
-			mlp_train(stream, md.net.mlp, n, params, params_t.as<half_t>(), ctx.enc.as<half_t>(), la, nullptr, nullptr, need_denc ? denc.as<half_t>() : nullptr,
-			          want_grads ? partials.as<float>() : nullptr, nullptr);
-			if (want_grads) mlp_finalize_gradients(stream, (uint32_t)md.n_mlp_params(), n_partials, partials.as<float>(), dL_dparams, accumulate);
+			const SlabOrder order = mlp_train(stream, md.net.mlp, n, params, params_t.as<half_t>(), ctx.enc.as<half_t>(), la, nullptr, nullptr,
+			                                  need_denc ? denc.as<half_t>() : nullptr, want_grads ? partials.as<float>() : nullptr, nullptr);
+			if (want_grads) mlp_finalize_gradients(stream, md.net.mlp, n_partials, partials.as<float>(), dL_dparams, accumulate, order);
 			if (!need_denc) return;
 			dL_denc = denc.as<half_t>();
 			stride_k = n;
@@ -768,7 +768,7 @@ static void model_backward(hipStream_t stream, const Model& md, const ForwardCtx
 		if (const size_t deep_bytes = mlp_backward_workspace_bytes(md.net.mlp, n)) deep = Scratch(stream, deep_bytes);
 		mlp_backward(stream, md.net.mlp, n, params_t.as<half_t>(), ctx.enc.as<half_t>(), ctx.hidden.as<half_t>(), dL_doutput,
 		             need_denc ? denc.as<half_t>() : nullptr, want_grads ? partials.as<float>() : nullptr, deep.ptr);
-		if (want_grads) mlp_finalize_gradients(stream, (uint32_t)md.n_mlp_params(), n_partials, partials.as<float>(), dL_dparams, accumulate);
+		if (want_grads) mlp_finalize_gradients(stream, md.net.mlp, n_partials, partials.as<float>(), dL_dparams, accumulate);
 		if (!need_denc) return;
 		dL_denc = denc.as<half_t>();
 		stride_k = n;
@@ -1896,9 +1896,10 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 			c->n_block_sums = n_partials;
 			c->block_sums = Scratch(stream, (size_t)n_partials * sizeof(float));
 		}
-		mlp_train(stream, md.net.mlp, n, params, params_t, fc.enc.as<half_t>(), la, c->output.as<half_t>(), external_dL_dy ? nullptr : c->dL_doutput.as<half_t>(),
-		          need_denc ? denc.as<half_t>() : nullptr, want_grads ? partials.as<float>() : nullptr, external_dL_dy ? nullptr : c->block_sums.as<float>());
-		if (want_grads) mlp_finalize_gradients(stream, (uint32_t)md.n_mlp_params(), n_partials, partials.as<float>(), tm->grads, accumulate);
+		const SlabOrder order = mlp_train(stream, md.net.mlp, n, params, params_t, fc.enc.as<half_t>(), la, c->output.as<half_t>(),
+		                                  external_dL_dy ? nullptr : c->dL_doutput.as<half_t>(), need_denc ? denc.as<half_t>() : nullptr,
+		                                  want_grads ? partials.as<float>() : nullptr, external_dL_dy ? nullptr : c->block_sums.as<float>());
+		if (want_grads) mlp_finalize_gradients(stream, md.net.mlp, n_partials, partials.as<float>(), tm->grads, accumulate, order);
 	}
 	ReadyTrampoline tramp = {tm, stream};
 	LevelGroups level_groups = {tm->backward_level_groups, want_grads && wants_ready_ranges(tm) ? &ReadyTrampoline::call : nullptr, &tramp};

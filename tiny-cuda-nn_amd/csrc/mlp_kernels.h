@@ -56,6 +56,25 @@ TCNN_HOST_DEVICE uint32_t mlp_transposed_index(const MlpMeta& m, uint32_t i) {
 	return n_in + n_hid + k * m.padded_out + o;
 }
 
+enum class SlabOrder : uint32_t { Params = 0, WaveRegisters = 1 };
+// Order of the fp32 weight-gradient slabs a training kernel writes: the parameter layout, or k_mlp_train_wave's accumulator
+// registers as they lie (coalesced 16-byte stores; mlp_train_wave.hip).  The parameter a slab position of that kernel stands for
+// (its tile order and accumulator lane map): position = 256 * tile + 4 * lane + r, tiles per neuron block b: FB input tiles, HM * NB hidden tiles, one output tile.
+TCNN_HOST_DEVICE uint32_t mlp_wave_slab_param(const MlpMeta& m, uint32_t position) {
+	const uint32_t width = m.width, in_width = m.in_width, n_hidden_matmuls = m.n_hidden_matmuls;
+	const uint32_t NB = width / 16u, FB = in_width / 16u, tiles_per_block = FB + n_hidden_matmuls * NB + 1u;
+	const uint32_t t = position >> 8, lane = (position >> 2) & 63u, r = position & 3u, lr = lane & 15u, g = lane >> 4;
+	const uint32_t b = t / tiles_per_block, u = t % tiles_per_block;
+	auto perm = [](uint32_t blk, uint32_t row) { return 32u * (blk >> 1) + 8u * (row >> 2) + 4u * (blk & 1u) + (row & 3u); };  // perm32
+	if (u < FB) return perm(b, 4u * g + r) * in_width + perm(u, lr);
+	const uint32_t off_hid = width * in_width;
+	if (u < FB + n_hidden_matmuls * NB) {
+		const uint32_t e = u - FB, j = e / NB, i = e % NB;
+		return off_hid + j * width * width + perm(b, 4u * g + r) * width + perm(i, lr);
+	}
+	return off_hid + n_hidden_matmuls * width * width + (4u * r + g) * width + perm(b, lr);  // accumulator row 4g+r <-> output 4r+g
+}
+
 constexpr uint32_t MLP_MAX_HIDDEN_MATMULS_TRAIN = 3;  // the register-resident backward / training kernels are instantiated for 0..3
 constexpr uint32_t MLP_MAX_IN_WIDTH = 128;
 constexpr uint32_t MLP_MAX_OUT_WIDTH = 128;  // padded; more than 16 outputs train through the layer-by-layer backward
@@ -126,10 +145,12 @@ void mlp_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half
 
 // number of fp32 slabs / loss partial sums mlp_train() writes for this shape and batch (<= mlp_backward_n_partials)
 uint32_t mlp_train_n_partials(const MlpMeta& m, uint32_t n, LossType loss);
-void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
+SlabOrder mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
                const MlpLossArgs& loss, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums);
 
 // grads[i] = (accumulate ? grads[i] : 0) + sum_b partials[b][i]   (fully_fused_mlp.cu:770 beta)
-void mlp_finalize_gradients(hipStream_t stream, uint32_t n_params, uint32_t n_partials, const float* partials, half_t* grads, bool accumulate);
+// `order`: how the slabs are laid out -- what mlp_train() returned for them (mlp_backward writes parameter order)
+void mlp_finalize_gradients(hipStream_t stream, const MlpMeta& m, uint32_t n_partials, const float* partials, half_t* grads, bool accumulate,
+                            SlabOrder order = SlabOrder::Params);
 
 }  // namespace tcnn_hip

@@ -968,9 +968,9 @@ __global__ void __launch_bounds__(256) k_mlp_output_activation_backward(uint32_t
 
 constexpr uint32_t FINALIZE_GROUPS = 32;  // slab groups per block (x 32 parameters = 1024 threads)
 
-__global__ void __launch_bounds__(32 * FINALIZE_GROUPS) k_mlp_finalize_gradients(uint32_t n_params, uint32_t n_partials,
+__global__ void __launch_bounds__(32 * FINALIZE_GROUPS) k_mlp_finalize_gradients(const MlpMeta m, uint32_t n_params, uint32_t n_partials,
                                                                                  const float* __restrict__ partials, half_t* __restrict__ grads,
-                                                                                 int accumulate) {
+                                                                                 int accumulate, uint32_t order) {
 	// 32 parameters x 32 slab groups; group g sums slabs g, g + 32, ... with 8 loads in flight (the sum over <= 512
 	// slabs is latency-bound otherwise); fixed summation order -> deterministic gradients
 	__shared__ float red[FINALIZE_GROUPS][32];
@@ -996,8 +996,10 @@ __global__ void __launch_bounds__(32 * FINALIZE_GROUPS) k_mlp_finalize_gradients
 		float t = red[0][lane];
 #pragma unroll
 		for (uint32_t k = 1; k < FINALIZE_GROUPS; ++k) t += red[k][lane];
-		if (accumulate) t += (float)grads[i];
-		grads[i] = to_half_rn(t);
+		// slabs in the register order of k_mlp_train_wave: position i of every slab belongs to parameter mlp_wave_slab_param(m, i)
+		const uint32_t param = order == (uint32_t)SlabOrder::WaveRegisters ? mlp_wave_slab_param(m, i) : i;
+		if (accumulate) t += (float)grads[param];
+		grads[param] = to_half_rn(t);
 	}
 }
 
@@ -1193,25 +1195,26 @@ bool mlp_train_supported(const MlpMeta& m) {
 	return m.width <= 64 && m.padded_out == 16 && m.n_hidden_matmuls <= MLP_MAX_HIDDEN_MATMULS_TRAIN && mlp_train_lds_bytes(m) + 4096u <= 160u * 1024u;
 }
 
-void mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
-               const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
+SlabOrder mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
+                    const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
 	check_meta(m, n);
-	if (n == 0) return;
+	if (n == 0) return SlabOrder::Params;
 	if (!mlp_train_supported(m)) throw std::runtime_error("mlp_train: unsupported network shape (check mlp_train_supported first)");
 	if (!la.external_dL_doutput && !loss_is_elementwise(la.type)) throw std::runtime_error("mlp_train: this loss needs whole output rows; use the stand-alone loss kernel");
 	if (mlp_train_wave_supported(m, n, la.external_dL_doutput ? LossType::L2 : la.type)) {
 		mlp_train_wave(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums);
-		return;
+		return SlabOrder::WaveRegisters;
 	}
 	if (m.width == 128) {
 		mlp_train_wide(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums);
-		return;
+		return SlabOrder::Params;
 	}
 	switch (m.width) {
 		case 16: dispatch_train<16>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		case 32: dispatch_train<32>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 		case 64: dispatch_train<64>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
 	}
+	return SlabOrder::Params;
 }
 
 void mlp_output_activation_backward(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* output, const half_t* dL_doutput,
@@ -1222,8 +1225,10 @@ void mlp_output_activation_backward(hipStream_t stream, const MlpMeta& m, uint32
 	            dL_doutput, dL_dpreact);
 }
 
-void mlp_finalize_gradients(hipStream_t stream, uint32_t n_params, uint32_t n_partials, const float* partials, half_t* grads, bool accumulate) {
-	TCNN_LAUNCH(k_mlp_finalize_gradients, dim3(div_round_up(n_params, 32u)), dim3(32 * FINALIZE_GROUPS), 0, stream, n_params, n_partials, partials, grads, accumulate ? 1 : 0);
+void mlp_finalize_gradients(hipStream_t stream, const MlpMeta& m, uint32_t n_partials, const float* partials, half_t* grads, bool accumulate, SlabOrder order) {
+	const uint32_t n_params = m.n_params();
+	TCNN_LAUNCH(k_mlp_finalize_gradients, dim3(div_round_up(n_params, 32u)), dim3(32 * FINALIZE_GROUPS), 0, stream, m, n_params, n_partials, partials, grads,
+	            accumulate ? 1 : 0, (uint32_t)order);
 }
 
 }  // namespace tcnn_hip

@@ -121,6 +121,11 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
 	const uint32_t act = m.activation, out_act = m.output_activation;
 	const bool want_grads = partials != nullptr, want_dx = dL_dinput != nullptr;
+#if defined(TCNN_EXP_DIAG_SKIP)  // timing diagnostics only (scripts/exp_mlp_diag.sh): bit 0 skips dL/dinput, bit 1 the weight gradients, bit 2 the whole backward half, bit 3 the loss arithmetic, bit 4 every strip, bit 5 the input loads, bit 6 the slab store, bit 7 the weight-gradient reduction and store, bit 8 the weight staging, bit 9 the loss reduction
+	const uint32_t diag_skip = la.loss_scale == 128.0f ? (uint32_t)(TCNN_EXP_DIAG_SKIP) : 0u;  // a run-time value: the skipped code stays in the kernel
+#else
+	constexpr uint32_t diag_skip = 0u;
+#endif
 	const float n_total = (float)la.n_total;
 	const PackedAct pa = packed_act(act);
 	// TCNN_EXP_RUNTIME_EXTERNAL (experiments only, scripts/exp_spill_wave.sh): the loss / external-gradient choice as a run-time
@@ -146,7 +151,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	constexpr uint32_t N_FRAG_LDS = N_FRAG > N_TILES ? N_FRAG : N_TILES;  // the region doubles as the second exchange buffer at the end
 	__shared__ h8 wfrag[N_FRAG_LDS][64];
 	__shared__ h4 wfrag_out_t[NB][64];
-	for (uint32_t f = w; f < N_FRAG; f += NWAVES) {
+	for (uint32_t f = w; f < ((diag_skip & 256u) ? 0u : N_FRAG); f += NWAVES) {
 		const half_t* src;
 		if (f < F_WHIDA) {
 			const uint32_t b = (f - F_WINA) / FP, p = (f - F_WINA) % FP;
@@ -205,8 +210,11 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 		for (uint32_t b = 0; b < NB; ++b) q[b] = pack8(to_h4(mfma_16x16x16(p[0][b], eye, zero4())), to_h4(mfma_16x16x16(p[1][b], eye, zero4())));
 	};
 
-	const uint32_t n_strips = n / MLP_WAVE_STRIP, stride = gridDim.x * NWAVES;
+	const uint32_t n_strips = (diag_skip & 16u) ? 0u : n / MLP_WAVE_STRIP, stride = gridDim.x * NWAVES;
 	uint32_t strip = blockIdx.x * NWAVES + w;
+#if defined(TCNN_EXP_SETPRIO) && !defined(TCNN_HOST_EMU)  // experiment: static issue priority for the second workgroup of a CU (MI355X_MICROARCH.md, two waves per SIMD)
+	if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(TCNN_EXP_SETPRIO);
+#endif
 	h8 xq_next[FB];
 #pragma unroll
 	for (uint32_t f = 0; f < FB; ++f)
@@ -218,7 +226,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 		h8 xq[FB];  // lane lr <-> feature perm32(f, lr), k = sample 8g+j
 #pragma unroll
 		for (uint32_t f = 0; f < FB; ++f) xq[f] = xq_next[f];
-		if (strip + stride < n_strips) {
+		if (strip + stride < n_strips && !(diag_skip & 32u)) {
 #pragma unroll
 			for (uint32_t f = 0; f < FB; ++f) xq_next[f] = *(const h8*)(input + (perm32(f, lr) * n + (strip + stride) * MLP_WAVE_STRIP + 8 * g));
 		}
@@ -231,7 +239,11 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 				const uint32_t dim = 4 * r + g;
 				const bool live = !external && dim < la.dims;
 				const uint32_t target_idx = (base + perm32(s, lr)) * la.dims + dim;
+#if defined(TCNN_EXP_DIAG_NO_TARGETS)  // timing diagnostics only (scripts/exp_mlp_diag.sh): results are wrong on purpose
+				tgt[s][r] = live ? (float)target_idx * 1e-9f : 0.0f;
+#else
 				tgt[s][r] = live ? la.targets[target_idx] : 0.0f;
+#endif
 			}
 		}
 
@@ -296,7 +308,8 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 				for (uint32_t r = 0; r < 4; ++r) {
 					const uint32_t dim = 4 * r + g;
 					gy[r] = (half_t)0.0f;
-					if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
+					if (diag_skip & 8u) gy[r] = o[r];
+					else if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
 						const float pdf = has_pdf ? la.data_pdf[i * la.dims + dim] : 1.0f;  // rare: fetched where it is used
 						float value;
 						if constexpr (GENERAL) gy[r] = loss_element<true>(la.type, (float)o[r], tgt[s][r], pdf, n_total, la.loss_scale, value);
@@ -305,19 +318,30 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 					}
 				}
 			}
+			// Lane (g, lr) holds outputs 4r + g of its sample.  Stored as they lie that is four 2-byte stores per matrix whose 64 lanes
+			// touch 64 different 32-byte sectors -- measured: 6 us of the kernel's 34 (profiles/r03_exp_notes.txt).  A 4 x 4 transpose
+			// over the four lane groups (register moves, no LDS) gives every lane outputs 4g .. 4g + 3: ONE 8-byte store.
+#if defined(TCNN_EXP_DIAG_NO_OUT_STORES)
+			if (output && la.loss_scale == 12345.0f) output[i * 16 + 4 * g] = (half_t)((float)o[0] + (float)gy[0]);  // keeps both values alive
+#elif defined(TCNN_EXP_NARROW_OUT_STORES)  // the round-2 form, for A/B runs
 #pragma unroll
-			for (uint32_t r = 0; r < 4; ++r) {  // the four lane groups together write 8 contiguous bytes per sample and r
+			for (uint32_t r = 0; r < 4; ++r) {
 				if (output) output[i * 16 + 4 * r + g] = o[r];
 				if (dL_doutput) dL_doutput[i * 16 + 4 * r + g] = gy[r];
 			}
+#else
+			if (output) *(h4*)(output + (i * 16 + 4 * g)) = wave_rows_transpose4(o);
+			if (dL_doutput) *(h4*)(dL_doutput + (i * 16 + 4 * g)) = wave_rows_transpose4(gy);
+#endif
 #pragma unroll
 			for (uint32_t r = 0; r < 4; ++r) dyp[s][r] = (half_t)act_backward<GENERAL>(out_act, (float)gy[r], o[r]);  // fully_fused_mlp.cu:760-763
 			sched_fence();
 		}
 
 		sched_fence();
+		if (diag_skip & 4u) continue;
 		// ================= backward =================
-		{  // dW_out[output][neuron] += dY * H_last^T  (accumulated unconditionally: a branch around the MFMAs costs the in-place accumulators)
+		if (!(diag_skip & 2u)) {  // dW_out[output][neuron] += dY * H_last^T  (accumulated unconditionally: a branch around the MFMAs costs the in-place accumulators)
 			const h8 dyq = pack8(to_h4(mfma_16x16x16(dyp[0], eye, zero4())), to_h4(mfma_16x16x16(dyp[1], eye, zero4())));
 			h8 hq[NB];  // the layer's activations with the samples in k: lane lr <-> neuron perm32(b, lr), k = sample 8g+j
 			transpose(hp[HM], hq);
@@ -334,7 +358,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 		sched_fence();
 #pragma unroll
 		for (int j = (int)HM - 1; j >= 0; --j) {
-			{  // dW_hid_j[out][in] += dA_{j+1} * H_j^T
+			if (!(diag_skip & 2u)) {  // dW_hid_j[out][in] += dA_{j+1} * H_j^T
 				h8 daq[NB], hq[NB];
 				transpose(dap, daq);
 				transpose(hp[j], hq);
@@ -360,7 +384,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 				for (uint32_t b = 0; b < NB; ++b) dap[s][b] = prev[s][b];
 			sched_fence();
 		}
-		{  // dW_in[out][feature] += dA_0 * X^T
+		if (!(diag_skip & 2u)) {  // dW_in[out][feature] += dA_0 * X^T
 			h8 daq[NB];
 			transpose(dap, daq);
 #pragma unroll
@@ -369,7 +393,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 				for (uint32_t f = 0; f < FB; ++f) accI[b][f] = mfma_16x16x32(daq[b], xq[f], accI[b][f]);
 		}
 		sched_fence();
-		if (want_dx) {  // dX^T = dA_0^T * W_in: (sample perm32(s, 4g+r) = 8g + 4s + r, feature 16f + lr) -> eight consecutive samples per lane
+		if (want_dx && !(diag_skip & 1u)) {  // dX^T = dA_0^T * W_in: (sample perm32(s, 4g+r) = 8g + 4s + r, feature 16f + lr) -> eight consecutive samples per lane
 #pragma unroll
 			for (uint32_t f = 0; f < FB; ++f) {
 				h4 d[2];
@@ -386,7 +410,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	}
 
 	// ---- this workgroup's share of the loss
-	if (block_sums) {
+	if (block_sums && !(diag_skip & 512u)) {
 		if constexpr (!GENERAL) loss_sum = loss_sum * 0.5f / n_total;  // see loss_gradient_simple
 		red[tid] = loss_sum;
 		__syncthreads();
@@ -398,9 +422,12 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	}
 
 	// ---- fp32 partial weight gradients: (wave 0 + wave 2) + (wave 1 + wave 3), exchanged through LDS in register order
-	// (tile t of lane l at [t][l]: conflict-free 16-byte accesses; all waves share the lane <-> element map), then written
-	// by wave 0 as this workgroup's slab in parameter layout
-	if (want_grads) {
+	// (tile t of lane l at [t][l]: conflict-free 16-byte accesses; all waves share the lane <-> element map).  The second round
+	// splits the tiles between waves 0 and 1, and each writes its half of the workgroup's slab IN REGISTER ORDER (slab position
+	// 256 t + 4 lane + r: one coalesced 16-byte store per tile; k_mlp_finalize_gradients knows the position -> parameter map,
+	// mlp_wave_slab_param).  The parameter-layout slab of rounds 1-2 was 112 scattered 4-byte store instructions issued by
+	// wave 0 alone: 3.7 us of the kernel's fixed cost (profiles/r03_exp_notes.txt).
+	if (want_grads && !(diag_skip & 128u)) {
 		auto for_each_tile = [&](auto&& fn) {
 			uint32_t t = 0;
 #pragma unroll
@@ -414,6 +441,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 				fn(t++, accO[b]);
 			}
 		};
+		constexpr uint32_t HALF_TILES = N_TILES / 2;  // wave 0 finishes tiles [0, HALF_TILES), wave 1 the rest
 		f4* ex0 = (f4*)exchange;
 		f4* ex1 = (f4*)wfrag;  // the weights are not needed any more
 		__syncthreads();
@@ -427,24 +455,19 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 			for_each_tile([&](uint32_t t, f4& a) { a += ex[t * 64 + lane]; });
 		}
 		__syncthreads();
-		if (w == 1) for_each_tile([&](uint32_t t, f4& a) { ex0[t * 64 + lane] = a; });
+		if (w == 1) for_each_tile([&](uint32_t t, f4& a) { if (t < HALF_TILES) ex0[t * 64 + lane] = a; });
+		if (w == 0) for_each_tile([&](uint32_t t, f4& a) { if (t >= HALF_TILES) ex1[t * 64 + lane] = a; });
 		__syncthreads();
+		float* P = partials + (size_t)blockIdx.x * N_PARAMS;
+		if (diag_skip & 64u) return;
 		if (w == 0) {
-			for_each_tile([&](uint32_t t, f4& a) { a += ex0[t * 64 + lane]; });
-			constexpr uint32_t off_hid = WIDTH * IN, off_out = off_hid + HM * WIDTH * WIDTH;
-			float* P = partials + (size_t)blockIdx.x * N_PARAMS;
-#pragma unroll
-			for (uint32_t b = 0; b < NB; ++b)
-#pragma unroll
-				for (uint32_t r = 0; r < 4; ++r) {
-#pragma unroll
-					for (uint32_t f = 0; f < FB; ++f) P[perm32(b, 4 * g + r) * IN + perm32(f, lr)] = accI[b][f][r];
-#pragma unroll
-					for (uint32_t j = 0; j < HM; ++j)
-#pragma unroll
-						for (uint32_t i = 0; i < NB; ++i) P[off_hid + j * WIDTH * WIDTH + perm32(b, 4 * g + r) * WIDTH + perm32(i, lr)] = accH[j][b][i][r];
-					P[off_out + (4 * r + g) * WIDTH + perm32(b, lr)] = accO[b][r];  // accumulator row 4g+r <-> output 4r+g
-				}
+			for_each_tile([&](uint32_t t, f4& a) {
+				if (t < HALF_TILES) *(f4*)(P + (t * 256u + lane * 4u)) = a + ex0[t * 64 + lane];
+			});
+		} else if (w == 1) {
+			for_each_tile([&](uint32_t t, f4& a) {
+				if (t >= HALF_TILES) *(f4*)(P + (t * 256u + lane * 4u)) = ex1[t * 64 + lane] + a;  // (wave 0 + wave 2) + (wave 1 + wave 3) here too
+			});
 		}
 	}
 }

@@ -174,6 +174,26 @@ TCNN_DEVICE float wave_sum_f32(float v) {
 	return v;
 }
 
+// 4 x 4 transpose of 16-bit elements across the four 16-lane rows of a wavefront (all 64 lanes must call it): lane (g, c),
+// g = lane >> 4, passes v[0..3] and receives t[r] = element g of what lane (r, c) passed.  No LDS: gfx950's row-swapping moves --
+// v_permlane32_swap (rows 2, 3 of the first operand <-> rows 0, 1 of the second) exchanges the 2 x 2 blocks, v_permlane16_swap
+// (odd rows of the first <-> even rows of the second) brings the row partner's pair next to the lane's own, v_perm_b32 picks
+// the halves.  Probed on the chip: scripts/probe_permlane_swap.hip.
+TCNN_DEVICE h4 wave_rows_transpose4(h4 v) {
+#if defined(TCNN_HOST_EMU)
+	return ::emu::wave_rows_transpose4(v);
+#else
+	const uint32_t a = __builtin_bit_cast(uint32_t, __builtin_shufflevector(v, v, 0, 1)), b = __builtin_bit_cast(uint32_t, __builtin_shufflevector(v, v, 2, 3));
+	const auto blocks = __builtin_amdgcn_permlane32_swap(a, b, false, false);  // [0]: rows 0, 1 keep a, rows 2, 3 get b of row - 2; [1]: rows 0, 1 get a of row + 2
+	const uint32_t sel = (threadIdx.x & 16u) ? 0x07060302u : 0x05040100u;     // odd rows keep the high halves, even rows the low ones
+	const auto lo = __builtin_amdgcn_permlane16_swap(blocks[0], blocks[0], false, false);  // even rows: {own, row + 1's}; odd rows: {row - 1's, own}
+	const auto hi = __builtin_amdgcn_permlane16_swap(blocks[1], blocks[1], false, false);
+	const uint32_t t01 = __builtin_amdgcn_perm(lo[1], lo[0], sel), t23 = __builtin_amdgcn_perm(hi[1], hi[0], sel);
+	const h2 p = __builtin_bit_cast(h2, t01), q = __builtin_bit_cast(h2, t23);
+	return h4{p[0], p[1], q[0], q[1]};
+#endif
+}
+
 // Scheduling fence: the compiler may not move instructions across it.  Bounds the live ranges of a long unrolled body
 // (the scheduler otherwise hoists every LDS/global read to the top of the block and runs out of registers).
 #if defined(TCNN_HOST_EMU)

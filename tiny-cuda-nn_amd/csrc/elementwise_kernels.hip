@@ -332,6 +332,9 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
                                                            const half_t* __restrict__ gradients, float* __restrict__ first_moments,
                                                            float* __restrict__ second_moments, uint32_t* __restrict__ param_steps,
                                                            half_t* __restrict__ weights_t, uint8_t* __restrict__ deficits8) {
+#if defined(TCNN_EXP_DIAG_EMPTY_ADAM)  // timing diagnostics only (scripts/exp_fixed_costs.sh)
+	return;
+#endif
 	const uint32_t i0 = a.begin + (blockIdx.x * EW_THREADS + threadIdx.x) * 4;
 	const bool four = i0 < a.n_elements && i0 + 3 < a.n_elements;
 	h4 g = h4{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};

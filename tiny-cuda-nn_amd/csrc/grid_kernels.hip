@@ -362,6 +362,9 @@ template <uint32_t D, uint32_t F, uint32_t SPT>
 __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward_tiles(const GridMeta meta, const GridIO io, const ForwardPlan plan,
                                                                       const half_t* __restrict__ params, half_t* __restrict__ out) {
 	constexpr uint32_t TILE = GRID_THREADS * SPT;
+#if defined(TCNN_EXP_DIAG_EMPTY_GATHER)  // timing diagnostics only (scripts/exp_fixed_costs.sh): what the bare launch costs
+	return;
+#endif
 	// block -> (segment of its XCD's run, tile): level-major, so an XCD walks one table at a time
 	const uint32_t xcd = blockIdx.x & 7u;
 	uint32_t slot = blockIdx.x >> 3, level = 0, tile = 0;
@@ -782,6 +785,9 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 	constexpr uint32_t SPT = bucket_spt(D, F), TILE = SPT * BUCKET_THREADS, N_PAIR = TILE * N_PAIRS_PER_SAMPLE;
 	constexpr uint32_t INVALID = BUCKET_INVALID_INDEX;
 	TCNN_DYN_LDS(lds_raw);
+#if defined(TCNN_EXP_DIAG_EMPTY_SCATTER) && TCNN_EXP_DIAG_EMPTY_SCATTER == 1  // timing diagnostics only (scripts/exp_fixed_costs.sh)
+	return;
+#endif
 	if (blockIdx.x >= plan.scatter_blocks) {
 		// gradients of chunked levels are accumulated with atomics by several owners in pass B: zero them here
 		const uint32_t z = blockIdx.x - plan.scatter_blocks;
@@ -837,6 +843,9 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 	const bool second_order = io.ddx != nullptr;  // scatter d(dL_dx)/d(grid) instead of dy/d(grid)
 	if (first_tile < plan.tiles) load_tile(first_tile, x, g);
 	__syncthreads();
+#if defined(TCNN_EXP_DIAG_EMPTY_SCATTER) && TCNN_EXP_DIAG_EMPTY_SCATTER == 2  // prologue only: first tile loaded, nothing scattered
+	if (x[0][0] != 12345.678f) return;
+#endif
 
 	for (uint32_t tile = first_tile; tile < plan.tiles; tile += plan.wgs_per_level) {
 		const uint32_t chunk = tile / plan.tiles_per_chunk[j];
@@ -1408,6 +1417,9 @@ __global__ void __launch_bounds__(OWNER_THREADS) k_grid_bucket_owner(const GridM
                                                                       const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient,
                                                                       const uint32_t lds_bytes, const int force_wide, const FusedAdamArgs fused) {
 	TCNN_DYN_LDS(lds_raw);
+#if defined(TCNN_EXP_DIAG_EMPTY_OWNER)  // timing diagnostics only (scripts/exp_fixed_costs.sh)
+	return;
+#endif
 	uint32_t item = 0, local_block;
 	if (plan.blocks_per_item) {
 		item = blockIdx.x / plan.blocks_per_item;

@@ -151,22 +151,43 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	constexpr uint32_t N_FRAG_LDS = N_FRAG > N_TILES ? N_FRAG : N_TILES;  // the region doubles as the second exchange buffer at the end
 	__shared__ h8 wfrag[N_FRAG_LDS][64];
 	__shared__ h4 wfrag_out_t[NB][64];
-	for (uint32_t f = w; f < ((diag_skip & 256u) ? 0u : N_FRAG); f += NWAVES) {
-		const half_t* src;
+	// The first strip's input is requested before anything else and travels while the weights are staged; the wave's fragment loads
+	// are all issued before the first one is written to LDS (one fragment at a time the loop paid a full L2 round trip per
+	// fragment: 1.7 us of fixed cost per launch, profiles/r03_exp_notes.txt).
+	const uint32_t n_strips = (diag_skip & 16u) ? 0u : n / MLP_WAVE_STRIP, stride = gridDim.x * NWAVES;
+	uint32_t strip = blockIdx.x * NWAVES + w;
+	h8 xq_next[FB];
+#pragma unroll
+	for (uint32_t f = 0; f < FB; ++f)
+		if (strip < n_strips) xq_next[f] = *(const h8*)(input + (perm32(f, lr) * n + strip * MLP_WAVE_STRIP + 8 * g));
+	auto fragment_source = [&](uint32_t f) -> const half_t* {
 		if (f < F_WHIDA) {
 			const uint32_t b = (f - F_WINA) / FP, p = (f - F_WINA) % FP;
-			src = W_in + (size_t)perm32(b, lr) * IN + 32 * p + 8 * g;
+			return W_in + (size_t)perm32(b, lr) * IN + 32 * p + 8 * g;
 		} else if (f < F_WOUTA) {
 			const bool transposed = f >= F_WHIDT;
 			const uint32_t e = f - (transposed ? F_WHIDT : F_WHIDA), j = e / (NB * NP), b = e / NP % NB, p = e % NP;
-			src = (transposed ? wt_hid : W_hid) + (size_t)j * WIDTH * WIDTH + (size_t)perm32(b, lr) * WIDTH + 32 * p + 8 * g;
+			return (transposed ? wt_hid : W_hid) + (size_t)j * WIDTH * WIDTH + (size_t)perm32(b, lr) * WIDTH + 32 * p + 8 * g;
 		} else if (f < F_WINB) {
-			src = W_out + (size_t)out_perm(lr) * WIDTH + 32 * (f - F_WOUTA) + 8 * g;
-		} else {
-			const uint32_t b = (f - F_WINB) / NP, p = (f - F_WINB) % NP;
-			src = wt_in + (size_t)(16 * b + lr) * WIDTH + 32 * p + 8 * g;
+			return W_out + (size_t)out_perm(lr) * WIDTH + 32 * (f - F_WOUTA) + 8 * g;
 		}
-		wfrag[f][lane] = *(const h8*)src;
+		const uint32_t b = (f - F_WINB) / NP, p = (f - F_WINB) % NP;
+		return wt_in + (size_t)(16 * b + lr) * WIDTH + 32 * p + 8 * g;
+	};
+	{
+		constexpr uint32_t PER_WAVE = (N_FRAG + NWAVES - 1) / NWAVES;
+		const uint32_t n_frag = (diag_skip & 256u) ? 0u : N_FRAG;
+		h8 staged[PER_WAVE];
+#pragma unroll
+		for (uint32_t k = 0; k < PER_WAVE; ++k) {
+			const uint32_t f = w + k * NWAVES;
+			staged[k] = *(const h8*)fragment_source(f < n_frag ? f : 0u);  // (an in-range address for the idle slots of the last round)
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < PER_WAVE; ++k) {
+			const uint32_t f = w + k * NWAVES;
+			if (f < n_frag) wfrag[f][lane] = staged[k];
+		}
 	}
 	for (uint32_t b = w; b < NB; b += NWAVES) {  // k slot 4g+i of the output-layer backward <-> output 4i+g
 		const half_t* row = wt_out + (size_t)perm32(b, lr) * 16;
@@ -210,16 +231,9 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 		for (uint32_t b = 0; b < NB; ++b) q[b] = pack8(to_h4(mfma_16x16x16(p[0][b], eye, zero4())), to_h4(mfma_16x16x16(p[1][b], eye, zero4())));
 	};
 
-	const uint32_t n_strips = (diag_skip & 16u) ? 0u : n / MLP_WAVE_STRIP, stride = gridDim.x * NWAVES;
-	uint32_t strip = blockIdx.x * NWAVES + w;
 #if defined(TCNN_EXP_SETPRIO) && !defined(TCNN_HOST_EMU)  // experiment: static issue priority for the second workgroup of a CU (MI355X_MICROARCH.md, two waves per SIMD)
 	if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(TCNN_EXP_SETPRIO);
 #endif
-	h8 xq_next[FB];
-#pragma unroll
-	for (uint32_t f = 0; f < FB; ++f)
-		if (strip < n_strips) xq_next[f] = *(const h8*)(input + (perm32(f, lr) * n + strip * MLP_WAVE_STRIP + 8 * g));
-
 	for (; strip < n_strips; strip += stride) {
 		asm volatile("" ::: "memory");  // the weight fragments are re-read from LDS where they are used, not hoisted into registers for the whole loop
 		const uint32_t base = strip * MLP_WAVE_STRIP;  // element offsets fit 32 bits (the host checks n): scalar base + 32-bit lane offset addressing
@@ -300,9 +314,8 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 			                (half_t)act_forward<GENERAL>(out_act, acc[3])};
 			const uint32_t i = base + perm32(s, lr);
 			h4 gy;
-			if (external) {
-#pragma unroll
-				for (uint32_t r = 0; r < 4; ++r) gy[r] = la.external_dL_doutput[i * 16 + 4 * r + g];
+			if (external) {  // one 8-byte load of outputs 4g .. 4g + 3, then the same 4 x 4 transpose as the stores below (it is its own inverse)
+				gy = wave_rows_transpose4(*(const h4*)(la.external_dL_doutput + (i * 16 + 4 * g)));
 			} else {
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {

@@ -1239,36 +1239,60 @@ TCNN_DEVICE int to_fixed32(float v) {
 
 template <uint32_t D, uint32_t F, uint32_t THREADS>
 TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, uint32_t level, uint32_t j, uint32_t bucket, uint32_t chunk,
-                                     const BucketPlan& plan, uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues,
+                                     const BucketPlan& plan, uint32_t* __restrict__ counters, const uint32_t* queues,
                                      const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient, bool accumulate, unsigned char* lds_raw,
                                      uint32_t lds_bytes, bool force_wide, const FusedAdamArgs& fused) {
 	static_assert(F % 2 == 0, "the packed owner pairs the features of a payload word");
 	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, PWP = BucketRecord<F>::PAIR_WORDS, OW = BucketRecord<F>::WORDS + 1;
 	constexpr uint32_t N_WAVES = THREADS / WAVE;
 	__shared__ float bound_parts[N_WAVES][F];
-	const uint32_t n_over = min(counters[plan.overflow_counter], plan.overflow_capacity);
-	const bool inline_overflow = n_over <= OVERFLOW_INLINE_MAX;
 	const uint32_t entries_per_bucket = 1u << plan.shift;
 	const uint32_t slice_begin = bucket * entries_per_bucket;
 	const uint32_t slice_count = slice_begin < lv.hashmap_size ? min(entries_per_bucket, lv.hashmap_size - slice_begin) : 0u;
 	const uint32_t cap = plan.capacity[j], n_chunks = plan.n_chunks[j];
 	const uint32_t queue = chunk * plan.n_buckets[j] + bucket;
-	const uint32_t count = min(counters[plan.counter_base[j] + queue], cap);  // in flight while the table is cleared
-	const uint32_t* __restrict__ q = queues + (plan.queue_base[j] + (size_t)queue * cap) * PWP;  // `count` PAIRS of records
+	// (not __restrict__, and neither is `queues`: loads the compiler may treat as invariant are moved wherever it likes -- it sank
+	// the first round below the barrier, next to its use)
+	const uint32_t* q = queues + (plan.queue_base[j] + (size_t)queue * cap) * PWP;  // `count` PAIRS of records
 	half_t* __restrict__ grad = grid_gradient + ((size_t)meta.offset[level] + slice_begin) * F;
 
-	// streams the queue (and this slice's share of the overflow list) through `add(index, payload)`
-	auto stream = [&](auto&& add) {
-		constexpr uint32_t U = PWP <= 3 ? 8 : (PWP <= 5 ? 4 : 2);  // pair records in flight per lane
-		for (uint32_t base = threadIdx.x; base < count; base += THREADS * U) {
-			uint32_t rec[U][PWP];
+	// U pair records (12 bytes each for F == 2) in flight per lane.  The FIRST round is requested right here, before the queue's
+	// length is known (a queue holds `cap` records of memory whatever its count; what lies beyond the count is never used): it
+	// travels together with the counters and while the table is cleared, instead of one more memory round trip after them -- a
+	// 196 KiB queue is only four rounds per lane, and a workgroup with nothing in flight is a workgroup not streaming
+	// (profiles/r03_exp_notes.txt: the pass moved its 201 MB at 4.3 TB/s with everything but the loads compiled out).
+	constexpr uint32_t STREAM_U = PWP <= 3 ? 8 : (PWP <= 5 ? 4 : 2);
+	auto load_round = [&](uint32_t base, uint32_t last, uint32_t (&rec)[STREAM_U][PWP]) {
 #pragma unroll
-			for (uint32_t u = 0; u < U; ++u) {
-				const uint32_t t = min(base + u * THREADS, count - 1u);
+		for (uint32_t u = 0; u < STREAM_U; ++u) {
+			const uint32_t t = min(base + u * THREADS, last);
 #pragma unroll
-				for (uint32_t w = 0; w < PWP; ++w) rec[u][w] = queue_load(q + (size_t)t * PWP + w);
-			}
-			if (base + (U - 1) * THREADS < count) {  // all U records exist (every iteration but a lane's last): no per-record test
+			for (uint32_t w = 0; w < PWP; ++w) rec[u][w] = queue_load(q + (size_t)t * PWP + w);
+		}
+	};
+	const uint32_t n_over = min(counters[plan.overflow_counter], plan.overflow_capacity);
+	const bool inline_overflow = n_over <= OVERFLOW_INLINE_MAX;
+	const uint32_t count = min(counters[plan.counter_base[j] + queue], cap);  // in flight while the table is cleared
+#if defined(TCNN_EXP_DIAG_OWNER)  // timing diagnostics only (scripts/exp_fixed_costs.sh): bit 0 no table clear, bit 1 no LDS atomics, bit 2 no conversion / store, bit 3 no last-owner protocol
+	constexpr uint32_t diag_owner = TCNN_EXP_DIAG_OWNER;
+#else
+	constexpr uint32_t diag_owner = 0u;
+#endif
+	bool safe = !force_wide;
+	// the packed table is cleared first (LDS only), the first round requested behind it: nothing then stands between the loads and
+	// their use but the barrier (cleared after the loads, the compiler parks part of a record in other registers and waits for it)
+	if (safe && !(diag_owner & 1u)) {
+		for (uint32_t e = threadIdx.x; e < slice_count * PW / 2; e += THREADS) ((u4*)lds_raw)[e] = u4{0u, 0u, 0u, 0u};  // slice_count is a multiple of 8
+	}
+	uint32_t first_round[STREAM_U][PWP];
+	load_round(threadIdx.x, cap - 1u, first_round);
+
+	// streams the queue (and this slice's share of the overflow list) through `add(index, payload)`; `first`: the lane's first
+	// round if it is in registers already (the first pass over the queue), null to load it here (the 64-bit redo)
+	auto stream = [&](const uint32_t (*first)[PWP], auto&& add) {
+		constexpr uint32_t U = STREAM_U;
+		auto add_round = [&](uint32_t base, const uint32_t (&rec)[U][PWP]) {
+			if (base + (U - 1) * THREADS < count) {  // all U records exist (every round but a lane's last): no per-record test
 #pragma unroll
 				for (uint32_t u = 0; u < U; ++u) {
 					add(rec[u][0] & PAIR_INDEX_MASK, &rec[u][1]);
@@ -1282,6 +1306,16 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 					if (rec[u][0] & PAIR_HAS_SECOND) add(pair_second_index<D>(lv, rec[u][0]), &rec[u][1 + PW]);
 				}
 			}
+		};
+		uint32_t base = threadIdx.x;
+		if (first) {
+			if (base < count) add_round(base, *(const uint32_t (*)[U][PWP])first);
+			base += THREADS * U;
+		}
+		for (; base < count; base += THREADS * U) {
+			uint32_t rec[U][PWP];
+			load_round(base, count - 1u, rec);
+			add_round(base, rec);
 		}
 		if (inline_overflow && chunk == 0u) {  // overflow records of this slice (level, index): the first chunk's owner takes them
 			for (uint32_t t = threadIdx.x; t < n_over; t += THREADS) {
@@ -1309,15 +1343,13 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 		else fused_adam4<false>(fused, p_first + 4 * q4, g);
 	};
 
-	bool safe = !force_wide;
 	if (safe) {
 		unsigned long long* tab = (unsigned long long*)lds_raw;  // [entries][PW]: features 2p (low word) and 2p + 1 (high word)
-		for (uint32_t e = threadIdx.x; e < slice_count * PW / 2; e += THREADS) ((u4*)lds_raw)[e] = u4{0u, 0u, 0u, 0u};  // slice_count is a multiple of 8
-		__syncthreads();
+		__syncthreads();  // the table is clear
 		float bound[F];
 #pragma unroll
 		for (uint32_t f = 0; f < F; ++f) bound[f] = 0.0f;
-		stream([&](uint32_t index, const uint32_t* payload) {
+		stream(first_round, [&](uint32_t index, const uint32_t* payload) {
 			const uint32_t rel = index & (entries_per_bucket - 1u);
 #pragma unroll
 			for (uint32_t p = 0; p < PW; ++p) {
@@ -1327,7 +1359,7 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 				bound[2 * p + 1] += __builtin_fabsf(f1);
 				const int v0 = to_fixed32(f0), v1 = to_fixed32(f1);
 				const unsigned long long x = ((unsigned long long)(uint32_t)(v1 + (v0 >> 31)) << 32) | (unsigned long long)(uint32_t)v0;
-				lds_atomic_add_u64(&tab[rel * PW + p], x);
+				if (!(diag_owner & 2u) || x == 0x123456789ull) lds_atomic_add_u64(&tab[rel * PW + p], x);
 			}
 		});
 		// the bound over the whole workgroup (NaN / Inf anywhere fail the comparison)
@@ -1344,7 +1376,7 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 			for (uint32_t w = 0; w < N_WAVES; ++w) total += bound_parts[w][f];
 			safe = safe && total < OWNER_SAFE_ABS_SUM;
 		}
-		if (safe) {
+		if (safe && !(diag_owner & 4u)) {
 			auto unpack = [&](uint32_t e2) {
 				const long long x = (long long)tab[e2];
 				const int s0 = (int)(uint32_t)(unsigned long long)x;
@@ -1381,7 +1413,7 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 			__syncthreads();  // the table is free (bound test / previous pass's conversion)
 			for (uint32_t e = threadIdx.x; e < sub_count * F / 2; e += THREADS) ((u4*)lds_raw)[e] = u4{0u, 0u, 0u, 0u};
 			__syncthreads();
-			stream([&](uint32_t index, const uint32_t* payload) {
+			stream(nullptr, [&](uint32_t index, const uint32_t* payload) {
 				const uint32_t rel = (index & (entries_per_bucket - 1u)) - sub_begin;
 				if (rel >= sub_count) return;
 #pragma unroll
@@ -1406,6 +1438,13 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 			}
 		}
 	}
+	if (diag_owner & 8u) {  // (racy on purpose: the list counter is reset by whoever gets here)
+		if (threadIdx.x == 0) {
+			counters[plan.counter_base[j] + queue] = 0u;
+			counters[plan.overflow_counter] = 0u;
+		}
+		return;
+	}
 	bucket_owner_epilogue<F, THREADS>(meta, plan, j, queue, inline_overflow, n_over, counters, overflow, grid_gradient);
 }
 
@@ -1413,7 +1452,7 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 // (if the plan holds other kinds of items at all) skips the bucket items when this kernel runs them.
 template <uint32_t D, uint32_t F>
 __global__ void __launch_bounds__(OWNER_THREADS) k_grid_bucket_owner(const GridMeta meta, const SlicePlan plan, const int accumulate, const BucketPlan bplan,
-                                                                      uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues,
+                                                                      uint32_t* __restrict__ counters, const uint32_t* queues,
                                                                       const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient,
                                                                       const uint32_t lds_bytes, const int force_wide, const FusedAdamArgs fused) {
 	TCNN_DYN_LDS(lds_raw);

@@ -971,14 +971,15 @@ constexpr uint32_t FINALIZE_GROUPS = 32;  // slab groups per block (x 32 paramet
 __global__ void __launch_bounds__(32 * FINALIZE_GROUPS) k_mlp_finalize_gradients(const MlpMeta m, uint32_t n_params, uint32_t n_partials,
                                                                                  const float* __restrict__ partials, half_t* __restrict__ grads,
                                                                                  int accumulate, uint32_t order) {
-	// 32 parameters x 32 slab groups; group g sums slabs g, g + 32, ... with 8 loads in flight (the sum over <= 512
-	// slabs is latency-bound otherwise); fixed summation order -> deterministic gradients
+	// 32 parameters x 32 slab groups; group g sums slabs g, g + 32, ... with 16 loads in flight (the sum over <= 512 slabs is
+	// latency-bound: one round trip for the 512 slabs of a persistent training kernel instead of two); fixed summation order ->
+	// deterministic gradients
 	__shared__ float red[FINALIZE_GROUPS][32];
 	const uint32_t lane = threadIdx.x & 31u, group = threadIdx.x >> 5;
 	const uint32_t i = blockIdx.x * 32u + lane;
 	float s = 0.0f;
 	if (i < n_params) {
-		constexpr uint32_t U = 8;
+		constexpr uint32_t U = 16;
 		for (uint32_t b = group; b < n_partials; b += FINALIZE_GROUPS * U) {
 			float v[U];
 #pragma unroll

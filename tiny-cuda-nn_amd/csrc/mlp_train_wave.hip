@@ -315,7 +315,12 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 			const uint32_t i = base + perm32(s, lr);
 			h4 gy;
 			if (external) {  // one 8-byte load of outputs 4g .. 4g + 3, then the same 4 x 4 transpose as the stores below (it is its own inverse)
+#if defined(TCNN_EXP_RUNTIME_EXTERNAL)  // the experiment build keeps the round-2 form it reproduces (the hazard scanner's positive control)
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) gy[r] = la.external_dL_doutput[i * 16 + 4 * r + g];
+#else
 				gy = wave_rows_transpose4(*(const h4*)(la.external_dL_doutput + (i * 16 + 4 * g)));
+#endif
 			} else {
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {

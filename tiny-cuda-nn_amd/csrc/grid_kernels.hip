@@ -785,6 +785,11 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 	constexpr uint32_t SPT = bucket_spt(D, F), TILE = SPT * BUCKET_THREADS, N_PAIR = TILE * N_PAIRS_PER_SAMPLE;
 	constexpr uint32_t INVALID = BUCKET_INVALID_INDEX;
 	TCNN_DYN_LDS(lds_raw);
+#if defined(TCNN_EXP_DIAG_SCATTER)  // timing diagnostics only (scripts/exp_fixed_costs.sh): bit 0 no queue stores, bit 1 no reservation atomics, bit 2 no reordering stores, bit 3 no rank atomics
+	constexpr uint32_t diag_scatter = TCNN_EXP_DIAG_SCATTER;
+#else
+	constexpr uint32_t diag_scatter = 0u;
+#endif
 #if defined(TCNN_EXP_DIAG_EMPTY_SCATTER) && TCNN_EXP_DIAG_EMPTY_SCATTER == 1  // timing diagnostics only (scripts/exp_fixed_costs.sh)
 	return;
 #endif
@@ -899,7 +904,7 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 							ridx[s][2 * pr] = word0;
 						}
 					}
-					rank[s][pr] = live ? atomic_add_u32(&cnt[bucket], 1u) : 0u;
+					rank[s][pr] = live && !(diag_scatter & 8u) ? atomic_add_u32(&cnt[bucket], 1u) : 0u;
 				}
 			}
 		};
@@ -914,7 +919,7 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 		uint32_t reserved = 0;
 		if (nb <= BUCKET_THREADS && threadIdx.x < nb) {
 			const uint32_t c = cnt[threadIdx.x];
-			if (c) reserved = atomic_add_u32(&my_counters[threadIdx.x], c);
+			if (c && !(diag_scatter & 2u)) reserved = atomic_add_u32(&my_counters[threadIdx.x], c);
 		}
 		// ... while wave 0 turns the counts into staging offsets (exclusive scan, wave-synchronous)
 		if (threadIdx.x < WAVE) {
@@ -948,6 +953,7 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 				const uint32_t word0 = ridx[s][2 * pr];  // index | t | has_second (INVALID: no pair)
 				if (word0 == INVALID) continue;
 				const uint32_t pos = delta[(word0 & PAIR_INDEX_MASK) >> shift] + rank[s][pr];
+				if (diag_scatter & 4u) continue;
 				stage[pos * PWP] = word0;
 #pragma unroll
 				for (uint32_t p = 0; p < PW; ++p) {
@@ -984,6 +990,7 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 			const uint32_t pos = t + delta[b];  // wraps like the subtraction above
 			if (pos < cap) {
 				uint32_t* dst = q + ((size_t)b * cap + pos) * PWP;
+				if (diag_scatter & 1u) continue;
 #pragma unroll
 				for (uint32_t w = 0; w < PWP; ++w) queue_store(dst + w, rec[w]);
 			} else {

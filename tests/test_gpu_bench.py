@@ -187,3 +187,20 @@ def test_pcg32_uniform_through_the_c_abi_matches_the_oracle_stream():
             want = O.generate_random_uniform(ref, n, lo, hi)
             assert np.array_equal(got, want), (seed, n)
             assert got.min() >= lo and got.max() < hi or (lo == hi)
+
+
+def test_wave_rows_transpose_on_the_chip(tmp_path):
+    """`wave_rows_transpose4` (csrc/tcnn_device.h: the 4 x 4 transpose of 16-bit elements over a wave's four 16-lane rows behind the
+    network kernel's 8-byte prediction / dL/doutput stores) rests on what gfx950's v_permlane32_swap / v_permlane16_swap do with their
+    rows.  scripts/probe_permlane_swap.hip checks the function against its definition for arbitrary bit patterns (NaN, inf, -0 included)
+    on the device itself; built here with the box's own hipcc."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    exe = tmp_path / "probe_permlane_swap.bin"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "scripts", "probe_permlane_swap.hip"), "-o", str(exe)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "wave_rows_transpose4: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

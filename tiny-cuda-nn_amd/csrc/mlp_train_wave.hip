@@ -105,7 +105,7 @@ TCNN_DEVICE half_t loss_gradient_simple(bool relative, bool has_pdf, float predi
 constexpr uint32_t MLP_WAVE_STRIP = 32, MLP_WAVE_THREADS = 256;
 
 // EXTERNAL: no loss -- dL/doutput comes from la.external_dL_doutput (the backward pass of a module recomputing its forward pass).  A
-// compile-time switch: the loss instance is at the register limit (254), a run-time branch around the loss spills.
+// compile-time switch: the loss instance is at the register limit (256 of 256 at two waves per SIMD), a run-time branch around the loss spills.
 template <uint32_t WIDTH, uint32_t IN, uint32_t HM, bool GENERAL, bool EXTERNAL, uint32_t MIN_WAVES = TCNN_MLP_WAVE_MIN_BLOCKS>
 __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
                                                                         const half_t* __restrict__ params_t, const half_t* __restrict__ input,

@@ -243,6 +243,12 @@ def adam_step(oh, n_matrix, loss_scale, current_step, w32, w16, grads_h, m1, m2,
                         _p(w32), _p(w16), _p(grads_h), _p(m1), _p(m2), _p(steps), C.c_int(int(steps_are_deficits)), _p(deficits8))
 
 
+def set_adam_half_follows_master(on):
+    """AdamCore::half_follows_master of the following adam_step calls: skipped parameters of a partly stepped lane get their 16-bit weight
+    from the fp32 master weight instead of reading it back."""
+    lib().emu_set_adam_half_follows_master(C.c_int(int(on)))
+
+
 def adam_convert_steps(steps_done, steps, deficits8, form_from, form_to):
     """per-parameter step counters: any AdamStepsForm -> any other, in place"""
     lib().emu_adam_convert_steps(C.c_uint32(steps.size), C.c_uint32(steps_done), _p(steps), _p(deficits8), C.c_int(form_from), C.c_int(form_to))

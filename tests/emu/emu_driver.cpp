@@ -222,6 +222,8 @@ int emu_adam_convert_steps(uint32_t n, uint32_t steps_done, uint32_t* steps, uin
 	return 0;
 }
 
+static bool g_adam_half_follows_master = false;
+void emu_set_adam_half_follows_master(int on) { g_adam_half_follows_master = on != 0; }  // AdamCore::half_follows_master of the calls below
 int emu_adam_step(const EmuAdam* e, uint32_t n, uint32_t n_matrix, float loss_scale, uint32_t current_step, float* w32, uint16_t* w16,
                   const uint16_t* grads, float* m1, float* m2, uint32_t* steps, int steps_form, uint8_t* deficits8) {
 	AdamHyper h;
@@ -241,7 +243,7 @@ int emu_adam_step(const EmuAdam* e, uint32_t n, uint32_t n_matrix, float loss_sc
 	h.optimize_non_matrix_params = e->optimize_non_matrix_params != 0;
 	h.skip_zero_grad_non_matrix_params = e->skip_zero_grad_non_matrix_params != 0;
 	adam_step(nullptr, h, n, n_matrix, loss_scale, current_step, w32, (half_t*)w16, (const half_t*)grads, m1, m2, steps, nullptr, nullptr, 0, 0xFFFFFFFFu,
-	          steps_form, deficits8);
+	          steps_form, deficits8, g_adam_half_follows_master);
 	return 0;
 }
 

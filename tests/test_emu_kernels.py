@@ -393,6 +393,48 @@ def test_adam_step_counters_kept_as_deficits():
     assert a[4].min() < a[4].max()
 
 
+@pytest.mark.parametrize("form", [0, 1, 2], ids=["counters", "deficits32", "deficits8"])
+def test_adam_rederives_skipped_half_weights_from_the_master(form):
+    """AdamCore::half_follows_master (what the trainer passes while nobody holds a pointer to its 16-bit parameters): a lane that steps
+    some of its four parameters and skips others takes the skipped ones' 16-bit weights from the fp32 master weights it holds instead
+    of reading them back.  With 16-bit weights that ARE the rounded master weights -- the trainer's invariant -- every array comes out
+    bit for bit as in the read-back form, step after step; with weights that are not, only the read-back form keeps them."""
+    rng = np.random.default_rng(8)
+    h = O.adam_defaults(learning_rate=1e-2, beta2=0.99, epsilon=1e-15, l2_reg=1e-6)
+    n, nm = 4096 + 3, 1024
+    w = rng.standard_normal(n).astype(np.float32)
+    def state():
+        d8 = np.zeros(n, np.uint8) if form == 2 else None
+        return [w.copy(), O.f2h(w), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint32)], d8
+    (a, a8), (b, b8) = state(), state()
+    try:
+        for step in range(1, 6):
+            g = (rng.standard_normal(n) * 20).astype(np.float32)
+            g[rng.random(n) < 0.4] = 0  # mixed lanes: some of a lane's four parameters skipped (adam.h:79-82)
+            g[2000:2400] = 0            # and whole lines skipped
+            gh = O.f2h(g)
+            emu.set_adam_half_follows_master(False)
+            emu.adam_step(h, nm, 128.0, step, a[0], a[1], gh, a[2], a[3], a[4], steps_are_deficits=form, deficits8=a8)
+            emu.set_adam_half_follows_master(True)
+            emu.adam_step(h, nm, 128.0, step, b[0], b[1], gh, b[2], b[3], b[4], steps_are_deficits=form, deficits8=b8)
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
+            assert np.array_equal(a[1], O.f2h(a[0]))  # the invariant the shortcut rests on survives the step
+        # 16-bit weights a caller wrote behind the master's back: kept by the read-back form, re-derived by the other
+        a[1][3001] ^= 1  # (a grid entry: network weights are stepped whatever their gradient)
+        b[1][3001] ^= 1
+        g = np.zeros(n, np.float32)
+        g[3000] = 3.0  # parameter 3000 is stepped, its lane mates 3001 ... 3003 are skipped
+        gh = O.f2h(g)
+        emu.set_adam_half_follows_master(False)
+        emu.adam_step(h, nm, 128.0, 6, a[0], a[1], gh, a[2], a[3], a[4], steps_are_deficits=form, deficits8=a8)
+        emu.set_adam_half_follows_master(True)
+        emu.adam_step(h, nm, 128.0, 6, b[0], b[1], gh, b[2], b[3], b[4], steps_are_deficits=form, deficits8=b8)
+        assert a[1][3001] != O.f2h(a[0][3001:3002])[0] and b[1][3001] == O.f2h(b[0][3001:3002])[0]
+    finally:
+        emu.set_adam_half_follows_master(False)
+
+
 def test_adam_step_deficits_kept_as_bytes():
     """The deficits as BYTES (AdamStepsForm 2: 255 = the counter itself lives in the 32-bit array): same state as the counter form at
     every step, across conversions in both directions, and for parameters that are skipped more than 254 times in a row (they move

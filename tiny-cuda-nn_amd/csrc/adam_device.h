@@ -23,6 +23,12 @@ struct AdamCore {
 	// parameters is stepped anyway, and partially written lines cost the memory system more than full ones (T = 2^22,
 	// 60 % of the entries untouched per step: 0.68 -> 0.53 ms, 4.7 -> 6.0 TB/s; profiles/r02_exp_notes.txt)
 	int dense_store;
+	// the 16-bit weights are the rounded fp32 master weights for EVERY parameter of this call (the trainer's own buffers: both are only
+	// ever written together -- Adam itself, the casts of set_params / snapshots).  A lane that steps some of its four parameters and skips
+	// others then re-derives the skipped ones' 16-bit weights from the master weights it holds anyway instead of reading them back
+	// (8 B per lane; the reference leaves them untouched, adam.h:79-82: the same bits).  Late in a long run, when converged gradients
+	// underflow to fp16 zero here and there, most lanes are such mixed lanes.  0: read them back (buffers a caller may write separately).
+	int half_follows_master;
 };
 
 // One parameter, exactly the arithmetic of adam.h:66-126.  Returns false if the parameter is skipped.

@@ -1720,13 +1720,16 @@ static void optimizer_step_ranges(tcnn_trainable_model_t* tm, hipStream_t stream
 	}
 	if (advance) optimizer_advance(tm, stream);
 	ProfilerGuard pg(tm->profiler.get());
+	// the trainer's 16-bit parameters are its rounded master weights unless a caller holds a pointer to them (params_exposed): Adam need
+	// not read the skipped ones back (AdamCore::half_follows_master).  TCNN_ADAM_HALF_FROM_MASTER=0: always read them back (A/B runs)
+	static const bool half_from_master = !(getenv("TCNN_ADAM_HALF_FROM_MASTER") && atoi(getenv("TCNN_ADAM_HALF_FROM_MASTER")) == 0);
 	for (size_t r = 0; r < n_ranges; ++r) {
 		const size_t begin = begins[r], end = std::min(ends[r], n);
 		if (begin == end) continue;
 		ProfScope prof(stream, STAGE_ADAM, /*counts=*/opens_profiled_step && r == 0);  // a ranged (bucketed) step is ONE optimizer step
 		adam_step(stream, tm->adam, (uint32_t)n, (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master, tm->params, tm->grads,
 		          tm->m1, tm->m2, tm->steps, tm->params_t_valid ? tm->params_t : nullptr, tm->md.has_network ? &tm->md.net.mlp : nullptr, (uint32_t)begin,
-		          (uint32_t)end, tm->steps_form, tm->step_deficits8);
+		          (uint32_t)end, tm->steps_form, tm->step_deficits8, /*half_follows_master=*/half_from_master && !tm->params_exposed);
 		if (tm->ema) ema_step(stream, (uint32_t)n, tm->ema_decay, tm->optimizer_step, tm->params, tm->params_ema, tm->ema_tmp, (uint32_t)begin, (uint32_t)end);
 	}
 }

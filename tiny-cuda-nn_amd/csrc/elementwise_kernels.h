@@ -108,7 +108,7 @@ bool adam_streams_its_state(uint32_t n_params);  // optimizer state too large fo
 void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale,
                uint32_t current_step, float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2,
                uint32_t* param_steps, half_t* weights_t = nullptr, const MlpMeta* mlp = nullptr, uint32_t begin = 0, uint32_t end = 0xFFFFFFFFu,
-               int steps_form = ADAM_STEPS_COUNTERS, uint8_t* deficits8 = nullptr);
+               int steps_form = ADAM_STEPS_COUNTERS, uint8_t* deficits8 = nullptr, bool half_follows_master = false);  // AdamCore::half_follows_master
 // param_steps holds either the per-parameter step counters (adam.h:84) or, with steps_are_deficits, their deficit
 // steps_done - counter (steps_done = current_step - 1): a stepped parameter then reads its 4 bytes and writes nothing, a
 // skipped one is incremented -- cheaper when most parameters are stepped every time (the headline table: 98 %), dearer

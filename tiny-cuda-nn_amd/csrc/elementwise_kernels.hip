@@ -398,11 +398,18 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 		if (bytes && n4 != b4) *(uint32_t*)(deficits8 + i0) = n4;
 		if (a.deficit == 1 && updated != 0xFu) adam_store<STREAM>((u4*)(param_steps + i0), st);
 		if (any || a.dense_store) {
-			if (updated != 0xFu) {  // keep the fp16 weights of the parameters that were skipped (only then are they read)
-				const h4 old = *(const h4*)(weights + i0);
+			if (updated != 0xFu) {  // keep the fp16 weights of the parameters that were skipped
+				if (a.half_follows_master) {  // (they are the rounded master weights, AdamCore::half_follows_master: nothing to read)
 #pragma unroll
-				for (uint32_t j = 0; j < 4; ++j) {
-					if (!((updated >> j) & 1u)) wh[j] = old[j];
+					for (uint32_t j = 0; j < 4; ++j) {
+						if (!((updated >> j) & 1u)) wh[j] = to_half_rn(w[j]);
+					}
+				} else {
+					const h4 old = *(const h4*)(weights + i0);
+#pragma unroll
+					for (uint32_t j = 0; j < 4; ++j) {
+						if (!((updated >> j) & 1u)) wh[j] = old[j];
+					}
 				}
 			}
 			adam_store<STREAM>((f4*)(weights_fp32 + i0), w);
@@ -463,13 +470,14 @@ AdamCore make_adam_core(const AdamHyper& h, uint32_t n_matrix_weights, float los
 	a.deficit = steps_form;
 	static const bool dense = !(getenv("TCNN_ADAM_DENSE_STORE") && atoi(getenv("TCNN_ADAM_DENSE_STORE")) == 0);  // =0: the sparse form, for A/B runs
 	a.dense_store = dense ? 1 : 0;
+	a.half_follows_master = 0;
 	return a;
 }
 bool adam_streams_its_state(uint32_t n) { return (size_t)n * 32u > ADAM_STREAM_THRESHOLD_BYTES; }
 
 void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale, uint32_t current_step,
                float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2, uint32_t* param_steps, half_t* weights_t,
-               const MlpMeta* mlp, uint32_t begin, uint32_t end, int steps_form, uint8_t* deficits8) {
+               const MlpMeta* mlp, uint32_t begin, uint32_t end, int steps_form, uint8_t* deficits8, bool half_follows_master) {
 	if (end > n) end = n;
 	if (begin >= end) return;
 	if (begin % 4u != 0u) throw std::runtime_error("adam_step: a parameter range must start at a multiple of 4");
@@ -477,6 +485,7 @@ void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_ma
 	AdamArgs a;
 	if (steps_form == ADAM_STEPS_DEFICITS8 && !deficits8) throw std::runtime_error("adam_step: the byte form of the step deficits needs its array");
 	(AdamCore&)a = make_adam_core(h, n_matrix_weights, loss_scale, current_step, steps_form);
+	a.half_follows_master = half_follows_master ? 1 : 0;
 	a.begin = begin;
 	a.n_elements = end;
 	a.mlp = mlp ? *mlp : MlpMeta{};

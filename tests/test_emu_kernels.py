@@ -262,7 +262,7 @@ def test_mlp_activations(act, out_act):
 
 
 # the shapes with a register-resident (wave per strip) instance: 32 inputs, 64 neurons x 1-2 layers or 32 neurons x 1-3 layers
-WAVE_CASES = [(32, 64, 3, 1), (32, 32, 2, 1), (32, 32, 4, 2), (32, 32, 16, 3)]
+WAVE_CASES = [(32, 64, 3, 1), (32, 32, 2, 1), (32, 32, 4, 2), (32, 32, 16, 3), (64, 64, 4, 2)]  # the last one: the 64-input two-hidden-layer instance (BASELINE configs[1]'s network)
 
 
 @pytest.mark.parametrize("case", WAVE_CASES + [(32, 64, 4, 2), (32, 64, 5, 3), (32, 32, 7, 4), (64, 64, 16, 2), (64, 64, 1, 3)])

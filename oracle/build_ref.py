@@ -2,8 +2,9 @@
 """Builds oracle/_ref/libtcnn_ref.so: the REFERENCE'S OWN device code for the hot path, compiled for the host.
 
 TEST INFRASTRUCTURE.  Purpose: pin the restated oracle (oracle/tcnn_oracle.c) against the reference's arithmetic, bit for bit,
-wherever the reference's code can be compiled without nvcc -- everything on the path except the tensor-core GEMMs
-(fully_fused_mlp.cu needs wmma / CUTLASS, which are not in /root/reference).
+wherever the reference's code can be compiled without nvcc -- everything on the path except the CUTLASS GEMMs (the submodule is
+not in /root/reference); the fully fused network kernels of src/fully_fused_mlp.cu compile against oracle/ref_shim/mma.h, a host
+nvcuda::wmma (second translation unit, oracle/ref_driver_mlp.cpp).
 
 How: the reference's kernels are plain C++ between `__global__` and a handful of cuda_fp16 intrinsics.
   * include/tiny-cuda-nn/{common.h, vec.h, common_device.h} and dependencies/pcg32/pcg32.h are compiled WHOLE, where they lie under
@@ -17,7 +18,8 @@ How: the reference's kernels are plain C++ between `__global__` and a handful of
     outputs are oracle/_ref/libtcnn_ref.so and oracle/_ref/manifest.json (file, kernel, line range of every definition compiled:
     what the parity tests cite).
   * oracle/ref_driver.cpp (ours) gives the kernels an extern "C" face: it loops (blockIdx, threadIdx) over the launch grid the
-    reference's host code would use and calls the kernel body for every thread.
+    reference's host code would use and calls the kernel body for every thread; oracle/ref_driver_mlp.cpp does the same for the
+    kernels that synchronise (a block's threads are fibers, __syncthreads() switches between them).
 
 usage: python oracle/build_ref.py [--reference /root/reference] [--force]     (a no-op when the reference tree is absent)
 """
@@ -50,6 +52,12 @@ KERNELS = [
     (INC + "losses/relative_l2_luminance.h", ["relative_l2_luminance_loss"]),
     (INC + "random.h", ["generate_random_kernel"]),
     (INC + "encodings/identity.h", ["identity", "identity_backward"]),
+]
+# second translation unit (oracle/ref_driver_mlp.cpp): the fully fused network kernels, against oracle/ref_shim/mma.h (nvcuda::wmma for the
+# host) and with a thread block's threads as fibers; in source order (each is declared before it is used)
+KERNELS_MLP = [
+    ("src/fully_fused_mlp.cu", ["threadblock_layer", "threadblock_load_input_static", "kernel_mlp_fused_backward", "threadblock_input_layer_forward_dynamic",
+                                "threadblock_last_layer_forward", "threadblock_write_output_static", "kernel_mlp_fused"]),
 ]
 
 
@@ -89,29 +97,45 @@ def build(reference="/root/reference", force=False, verbose=True):
         if verbose:
             print(f"[build_ref] no reference tree at {reference}: keeping whatever {LIB} exists")
         return os.path.exists(LIB)
-    srcs = [os.path.join(HERE, "ref_driver.cpp"), os.path.join(HERE, "ref_shim", "cuda_fp16.h"), os.path.abspath(__file__)]
+    srcs = [os.path.join(HERE, "ref_driver.cpp"), os.path.join(HERE, "ref_driver_mlp.cpp"), os.path.join(HERE, "ref_shim", "cuda_fp16.h"),
+            os.path.join(HERE, "ref_shim", "mma.h"), os.path.abspath(__file__)]
     if not force and os.path.exists(LIB) and os.path.exists(MANIFEST) and os.path.getmtime(LIB) >= max(os.path.getmtime(s) for s in srcs):
         return True
     os.makedirs(OUT_DIR, exist_ok=True)
-    manifest, parts = [], []
-    for rel, names in KERNELS:
-        path = os.path.join(reference, rel)
-        for name in names:
-            text, first, last = extract(path, name)
-            manifest.append({"file": rel, "name": name, "lines": [first, last]})
-            parts.append(f"// ---- {rel}:{first}-{last} ({name})\n{text}\n")
+    manifest = []
+
+    def gather(kernels):
+        parts = []
+        for rel, names in kernels:
+            path = os.path.join(reference, rel)
+            for name in names:
+                text, first, last = extract(path, name)
+                manifest.append({"file": rel, "name": name, "lines": [first, last]})
+                parts.append(f"// ---- {rel}:{first}-{last} ({name})\n{text}\n")
+        return "namespace tcnn {\n" + "\n".join(parts) + "\n}  // namespace tcnn\n"
+
     with tempfile.TemporaryDirectory(prefix="tcnn_ref_") as tmp:
         with open(os.path.join(tmp, "ref_extracted_kernels.inc"), "w") as f:
-            f.write("namespace tcnn {\n" + "\n".join(parts) + "\n}  // namespace tcnn\n")
-        cmd = [CLANG, "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
-               "-Wno-keyword-macro", "-Wno-unknown-pragmas", "-Wno-pass-failed", "-Wno-unused-value",
-               "-D__CUDACC__", "-D__CUDA_ARCH__=610", "-DTCNN_HALF_PRECISION=1", "-DTCNN_MIN_GPU_ARCH=61",
-               "-I" + os.path.join(HERE, "ref_shim"), "-I" + tmp, "-I" + os.path.join(reference, "include"), "-I" + os.path.join(reference, "dependencies"),
-               os.path.join(HERE, "ref_driver.cpp"), "-o", LIB]
-        r = subprocess.run(cmd, capture_output=True, text=True)
+            f.write(gather(KERNELS))
+        with open(os.path.join(tmp, "ref_extracted_mlp.inc"), "w") as f:
+            f.write(gather(KERNELS_MLP))
+        flags = ["-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
+                 "-Wno-keyword-macro", "-Wno-unknown-pragmas", "-Wno-pass-failed", "-Wno-unused-value",
+                 "-D__CUDACC__", "-D__CUDA_ARCH__=610", "-DTCNN_HALF_PRECISION=1", "-DTCNN_MIN_GPU_ARCH=61",
+                 "-I" + os.path.join(HERE, "ref_shim"), "-I" + tmp, "-I" + os.path.join(reference, "include"), "-I" + os.path.join(reference, "dependencies")]
+        # the two translation units compile side by side
+        objs = [os.path.join(tmp, "ref_driver.o"), os.path.join(tmp, "ref_driver_mlp.o")]
+        procs = [subprocess.Popen([CLANG, *flags, "-c", os.path.join(HERE, src), "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                 for src, obj in zip(["ref_driver.cpp", "ref_driver_mlp.cpp"], objs)]
+        for proc in procs:
+            _, err = proc.communicate()
+            if proc.returncode != 0:
+                sys.stderr.write(err[-6000:])
+                raise RuntimeError("oracle/_ref: compiling the reference's kernels for the host failed")
+        r = subprocess.run([CLANG, "-shared", "-fopenmp", *objs, "-o", LIB], capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stderr[-6000:])
-            raise RuntimeError("oracle/_ref: compiling the reference's kernels for the host failed")
+            raise RuntimeError("oracle/_ref: linking failed")
     json.dump({"reference": reference, "compiled": manifest,
                "whole_files": ["include/tiny-cuda-nn/common.h", "include/tiny-cuda-nn/vec.h", "include/tiny-cuda-nn/common_device.h", "dependencies/pcg32/pcg32.h"]},
               open(MANIFEST, "w"), indent=1)

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 
 #define __host__
 #define __device__
@@ -16,6 +17,7 @@
 #define __restrict__ __restrict
 #define __launch_bounds__(...)
 #define __align__(n) __attribute__((aligned(n)))
+#define __shared__ /* `extern __shared__ __half shmem[]` names one host array (ref_driver.cpp); blocks run one after the other */
 
 struct __half {
 	_Float16 v;
@@ -78,7 +80,11 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p 
 
 struct ref_dim3 { unsigned x = 1, y = 1, z = 1; };
 static thread_local ref_dim3 threadIdx, blockIdx, blockDim, gridDim;
-static inline void __syncthreads() {}
+/* kernels without barriers run thread after thread (ref_sync_hook == nullptr); the fused network kernels run a block's threads as
+ * fibers and the hook switches to the next one (oracle/ref_driver.cpp, BlockFibers) */
+static thread_local void (*ref_sync_hook)() = nullptr;
+static inline void __syncthreads() { if (ref_sync_hook) ref_sync_hook(); }
+static inline void __syncwarp() { if (ref_sync_hook) ref_sync_hook(); }
 /* the fast-math intrinsics (__expf, __sinf, ...) are glibc-internal names on the host: the device versions are approximations anyway,
  * nothing on the pinned path (index / interpolation / loss / optimizer arithmetic) uses them */
 #define __expf(x) std::exp((float)(x))

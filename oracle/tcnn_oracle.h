@@ -21,12 +21,20 @@
  *     library; the HIP path is held against it on the GPU without the oracle in the loop.
  *     What "the reference" means there: its source, every float operation rounded as written (-ffp-contract=off).  nvcc contracts
  *     a * b + c into one fma by default; where the oracle models that (the uniform transform of random.h:63) it says so.
- *   - PARITY UNPINNED: the matrix products of the fully fused MLP (src/fully_fused_mlp.cu: wmma; src/cutlass_mlp.cu: CUTLASS) --
- *     neither compiles without nvcc / the un-vendored CUTLASS submodule, and the reference's tests hold no stored output
- *     tensors for them (only self-consistency invariants, tests/test_common.h:124-223).  This file restates
- *     src/cutlass_mlp.cu:162-316 with fp16 storage and either accumulator type (fp32: what MFMA does; fp16: what the
- *     reference's tensor-core paths do, fully_fused_mlp.cu:68,198, cutlass_matmul.h:67); the product must land between the two
- *     (tests/test_oracle.py, tests/test_gpu_parity_full.py).
+ *       kernel_mlp_fused / kernel_mlp_fused_backward and the threadblock_* device functions they call
+ *                                                                    src/fully_fused_mlp.cu:46-557
+ *       -- the fully fused network kernels, compiled against oracle/ref_shim/mma.h (nvcuda::wmma for the host) with a thread block's
+ *       threads run as fibers (oracle/ref_driver_mlp.cpp).  This file's fp16-accumulate mode reproduces them BIT FOR BIT: hidden
+ *       activations, padded output, inference output, backward activations' end result dL/dinput, for widths 16-128, 1-5 hidden layers,
+ *       all eight activations, both matrix layouts.  What is modelled there and not the reference's: the arithmetic INSIDE one 16x16x16
+ *       tensor-core operation (exact products, binary32 sum in ascending k, one rounding to the binary16 accumulator) -- the PTX ISA
+ *       leaves the hardware's internal order open, so no host build could do better.
+ *   - PARITY UNPINNED, and only this: the CUTLASS GEMMs (weight gradients fully_fused_mlp.cu:776, 819, 829; output layers wider than
+ *     16; dL/dinput of inputs narrower than the network; src/cutlass_mlp.cu) -- the CUTLASS submodule is not in /root/reference.  They
+ *     are plain matrix products of buffers that ARE pinned (the fused kernels' forward and backward activations): this file restates
+ *     them with fp16 storage and either accumulator type (fp32: what MFMA does, the default; fp16: cutlass_matmul.h:67), tests hold the
+ *     sums against float64 products of the reference kernel's own activations, and the GPU result must land between the two modes
+ *     (tests/test_oracle.py, tests/test_oracle_ref.py, tests/test_gpu_parity_full.py).
  *
  * Conventions: "half" values travel as uint16_t bit patterns (IEEE binary16, RNE conversions).
  * Matrices named AoS are [N][width] (one sample's features contiguous == the reference's

@@ -4,7 +4,9 @@ container only; the fixture travels to the GPU box, where `pytest -m gpu` holds 
 (tests/test_gpu_parity.py::test_reference_golden_fixture) and `-m "not gpu"` the oracle (tests/test_oracle_ref.py).
 
 Contents: kernel_grid (encodings/grid.h:48-212) on the data/config_hash.json grid in 3-D, relative_l2_loss
-(losses/relative_l2.h:39-76), three adam_step calls (optimizers/adam.h:47-127), generate_random_uniform (random.h:39-69).
+(losses/relative_l2.h:39-76), three adam_step calls (optimizers/adam.h:47-127), generate_random_uniform (random.h:39-69), kernel_mlp_fused / kernel_mlp_fused_backward
+(src/fully_fused_mlp.cu:46-557; the arithmetic inside one 16x16x16 tensor-core operation is modelled, oracle/ref_shim/mma.h) on the
+bench's network and on BASELINE configs[1]'s.
 
     python tests/golden/make_ref_golden.py
 """
@@ -69,6 +71,30 @@ def main():
                         f32(1e-6), f32(0.0), p(st["w"]), p(st["h"]), p(gh), p(st["m1"]), p(st["m2"]), p(st["s"]))
         out[f"adam_grad{step}"] = gh
     out.update(adam_w=st["w"], adam_h=st["h"], adam_m1=st["m1"], adam_m2=st["m2"], adam_steps=st["s"])
+    # ---- the fully fused network kernels (src/fully_fused_mlp.cu:46-557 through oracle/ref_shim/mma.h; oracle/ref_driver_mlp.cpp):
+    # net_a = the bench's network (32 -> 64 x 2 -> 4, ReLU), net_b = BASELINE configs[1] (64 -> 64 x 2 -> 16; its input gradient comes out
+    # of the fused kernel).  Weights U(-s, s) with the Xavier bound of each matrix, inputs U(-1, 1), dL/doutput U(-0.1, 0.1), all fp16.
+    for tag, (in_w, out_w, seed) in {"net_a": (32, 4, 201), "net_b": (64, 16, 301)}.items():
+        W, H, PO, nb = 64, 2, 16, 256
+        shapes = [(W, in_w), (W, W), (PO, W)]
+        mats = []
+        for k, (fo, fi) in enumerate(shapes):
+            bound = np.float32(np.sqrt(6.0 / (fi + fo)))
+            mats.append(((np.float32(2.0) * uniform01(seed + k, fo * fi) - np.float32(1.0)) * bound).astype(np.float32))
+        mats[2].reshape(PO, W)[out_w:] = 0.0  # the padded rows of the output matrix
+        params = O.f2h(np.concatenate(mats))
+        x = O.f2h(np.float32(2.0) * uniform01(seed + 10, nb * in_w) - np.float32(1.0)).reshape(nb, in_w)
+        dy = O.f2h((np.float32(2.0) * uniform01(seed + 11, nb * PO) - np.float32(1.0)) * np.float32(0.1)).reshape(nb, PO)
+        dy[:, out_w:] = 0
+        hidden = np.zeros((H, nb, W), np.uint16)
+        y = np.zeros((nb, PO), np.uint16)
+        assert R.ref_mlp_fused_forward(W, 0, 9, 0, p(x), 0, p(params), p(hidden), p(y), PO, 0, nb, in_w, PO, H) == 0
+        tmp = np.zeros((H, nb, W), np.uint16)
+        dx = np.zeros((nb, W), np.uint16) if in_w == W else None
+        assert R.ref_mlp_fused_backward(W, 0, p(dy), 0, PO, p(params), p(params[W * in_w:]), p(tmp), p(hidden), p(dx), nb, PO, H) == 0
+        out.update({f"{tag}_params": params, f"{tag}_input": x, f"{tag}_dL_doutput": dy, f"{tag}_hidden": hidden, f"{tag}_output": y, f"{tag}_backward_tmp": tmp})
+        if dx is not None:
+            out[f"{tag}_dL_dinput"] = dx
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_small.npz"), **out)
     print("wrote reference_small.npz:", {k: v.shape for k, v in out.items()})
 

@@ -527,3 +527,21 @@ def test_rng_casts_identity():
     for n, n_dims, padded in ((768, 64, 64), (600, 12, 16), (256, 5, 16), (1000, 128, 128)):
         xi = np.random.default_rng(n).standard_normal((n, n_dims)).astype(np.float32)
         assert np.array_equal(emu.identity_forward(xi, padded).T, O.identity_forward(xi, padded)), (n, n_dims)
+
+
+@pytest.mark.parametrize("tag", ["net_a", "net_b"])
+def test_network_kernels_against_the_reference_made_fixture(tag):
+    """tests/golden/reference_small.npz holds the output of the REFERENCE'S OWN kernel_mlp_fused / kernel_mlp_fused_backward
+    (src/fully_fused_mlp.cu:46-557 compiled for the host, tests/golden/make_ref_golden.py): the HIP network kernels against it, no
+    oracle in between (tests/reference_fixture.py states the bars; the GPU suite runs the same check on hardware)."""
+    import reference_fixture as RF
+    gold = RF.load()
+    in_w, out_w = RF.NETWORKS[tag]
+    om = O.mlp_init(in_w, RF.WIDTH, out_w, RF.N_HIDDEN)
+    params, x, dy = gold[tag + "_params"], gold[tag + "_input"], gold[tag + "_dL_doutput"]
+    assert params.size == om.n_params
+    xs = np.ascontiguousarray(x.T)
+    hidden, y = emu.mlp_forward(om, params, xs)
+    grads, dx = emu.mlp_backward(om, params, xs, hidden, dy)
+    err = RF.check(gold, tag, O.h2f(y), O.h2f(grads), O.h2f(dx).T)
+    assert err["output"] > 0  # fp32 against fp16 accumulators: equality would mean the fixture is not the reference's

@@ -712,6 +712,27 @@ def test_reference_golden_fixture():
         assert np.array_equal(dx.cpu().numpy()[:16], gold["dy_dx_first"][:, k, :]), k
 
 
+@pytest.mark.parametrize("tag", ["net_a", "net_b"])
+def test_reference_golden_fixture_network(tag):
+    """The network part of tests/golden/reference_small.npz: the output of THE REFERENCE'S OWN kernel_mlp_fused /
+    kernel_mlp_fused_backward (src/fully_fused_mlp.cu:46-557 compiled for the host, tests/golden/make_ref_golden.py) for the bench's
+    network and BASELINE configs[1]'s.  The HIP kernels against it through the C ABI, no oracle in the loop; bars and their
+    measured values: tests/reference_fixture.py (the emulator leg runs the same check on the kernel sources)."""
+    import reference_fixture as RF
+    C = tcnn()._C
+    gold = RF.load()
+    in_w, out_w = RF.NETWORKS[tag]
+    m = C.create_network(in_w, out_w, MLP_64x2)
+    params, xh, dyh = gold[tag + "_params"], gold[tag + "_input"], gold[tag + "_dL_doutput"]
+    assert m.n_params() == params.size and m.n_output_dims() == RF.PADDED_OUT
+    x = torch.from_numpy(O.h2f(xh)).cuda().requires_grad_(True)  # fp16 values: the identity encoding's cast is exact
+    p = h_t(params).requires_grad_(True)
+    ctx, y = m.fwd(x, p)
+    dx, dp = m.bwd(ctx, x, p, y, h_t(dyh))
+    torch.cuda.synchronize()
+    RF.check(gold, tag, O.h2f(h_np(y)), dp.float().cpu().numpy(), dx.float().cpu().numpy())
+
+
 def test_error_behaviour_on_device():
     C = tcnn()._C
     m = C.create_network_with_input_encoding(3, 4, HASH_ENCODING_SMALL, MLP_64x2)

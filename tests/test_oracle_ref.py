@@ -12,8 +12,12 @@ Covered -- everything on the hot path that compiles without nvcc:
   generate_random_kernel + pcg32                          random.h:39-55, dependencies/pcg32/pcg32.h
   warp_activation / warp_activation_backward              common_device.h:108-186, 363-440
   identity encoding                                       encodings/identity.h:45-85
-Not covered (cannot be compiled here): the tensor-core GEMMs of fully_fused_mlp.cu / cutlass_mlp.cu; the oracle brackets those with
-its fp32- and fp16-accumulate modes (tests/test_oracle.py).
+  kernel_mlp_fused / kernel_mlp_fused_backward + threadblock_*   src/fully_fused_mlp.cu:46-557 (through oracle/ref_shim/mma.h: nvcuda::wmma
+                                                          for the host; a block's threads run as fibers).  Modelled, not the reference's:
+                                                          the arithmetic inside ONE 16x16x16 tensor-core operation (mma.h says how)
+Not covered (not in /root/reference): the CUTLASS GEMMs (weight gradients, > 16 outputs, input gradients of narrow inputs,
+cutlass_mlp.cu); the oracle brackets those with its fp32- and fp16-accumulate modes (tests/test_oracle.py) and the weight gradients are
+checked here as plain sums over the reference kernel's own backward activations.
 
 Bit-exact unless stated.  CPU-only; skipped when neither the library nor the reference tree is there.
 """
@@ -302,6 +306,123 @@ def test_identity_encoding_bit_exact():
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
+# the fully fused network kernels (src/fully_fused_mlp.cu:46-557) through oracle/ref_shim/mma.h: kernel_mlp_fused and
+# kernel_mlp_fused_backward run as the reference launches them (a block's threads are fibers, oracle/ref_driver_mlp.cpp).  The only
+# modelled part is the arithmetic INSIDE one 16x16x16 tensor-core operation (exact products, binary32 sum in ascending k, one rounding
+# to the binary16 accumulator); that is the oracle's fp16-accumulate mode, so the two must agree bit for bit -- which pins the weight
+# layout, the transposes, the placement of activation and activation transfer, the intermediate / output layouts and the padding.
+def _mlp_case(W, IN, OUT, H, act, oact, n, seed):
+    m = O.mlp_init(IN, W, OUT, H, act, oact)
+    params = O.f2h(O.mlp_init_params(m, O.pcg32(seed + 1)))
+    rng = np.random.default_rng(seed)
+    x = O.f2h(rng.standard_normal((n, IN)).astype(np.float32))
+    dy = O.f2h((rng.standard_normal((n, m.padded_out)) * 0.1).astype(np.float32))
+    dy[:, OUT:] = 0
+    return m, params, x, dy
+
+
+def _ref_act(act):
+    return REF_ACTIVATION[O.ACTIVATION_NAMES[act]]
+
+
+def _ref_mlp_forward(R, m, params, x, inference=False, input_row_major=False, output_row_major=False):
+    n, W, H, PO = x.shape[0], m.width, m.n_hidden, m.padded_out
+    hidden = None if inference else np.full((H, n, W), 0xFFFF, np.uint16)
+    out = np.full((PO, n) if output_row_major else (n, PO), 0xFFFF, np.uint16)
+    xin = np.ascontiguousarray(x.T) if input_row_major else x
+    r = R.ref_mlp_fused_forward(W, _ref_act(m.activation), _ref_act(m.output_activation), int(inference), p(xin), int(input_row_major), p(params), p(hidden), p(out),
+                                n if output_row_major else PO, int(output_row_major), n, m.in_width, PO, H)
+    assert r == 0, r
+    return hidden, (np.ascontiguousarray(out.T) if output_row_major else out)
+
+
+def _ref_mlp_backward(R, m, params, hidden, out, dy, dL_doutput_row_major=False):
+    n, W, H, PO = dy.shape[0], m.width, m.n_hidden, m.padded_out
+    dyt = dy
+    if m.output_activation != O.ACT_NONE:  # activation_backward_output_gpu ahead of the kernel (fully_fused_mlp.cu:755-763)
+        dyt = np.empty_like(dy)
+        assert R.ref_activation(_ref_act(m.output_activation), 1, dy.size, p(dy), p(out), p(dyt)) == 0
+    tmp = np.full((H, n, W), 0xFFFF, np.uint16)
+    dinput = np.full((n, W), 0xFFFF, np.uint16) if m.in_width == W else None  # dL_dinput_fused, fully_fused_mlp.cu:788
+    dsrc = np.ascontiguousarray(dyt.T) if dL_doutput_row_major else dyt
+    r = R.ref_mlp_fused_backward(W, _ref_act(m.activation), p(dsrc), int(dL_doutput_row_major), n if dL_doutput_row_major else PO, p(params), p(params[W * m.in_width:]),
+                                 p(tmp), p(hidden), p(dinput), n, PO, H)
+    assert r == 0, r
+    return dyt, tmp, dinput
+
+
+MLP_CASES = [  # (width, in_width, out_width, n_hidden, activation, output_activation, n)
+    (64, 32, 4, 2, O.ACT_RELU, O.ACT_NONE, 256),       # the bench's headline network (the grid's 32 features in, RGBA out)
+    (64, 64, 16, 2, O.ACT_RELU, O.ACT_NONE, 256),      # BASELINE configs[1]
+    (128, 32, 16, 4, O.ACT_RELU, O.ACT_NONE, 128),     # BASELINE configs[4]
+    (128, 128, 3, 2, O.ACT_LEAKY_RELU, O.ACT_NONE, 128),
+    (32, 32, 3, 3, O.ACT_SIGMOID, O.ACT_SIGMOID, 256),
+    (32, 48, 1, 1, O.ACT_SQUAREPLUS, O.ACT_EXPONENTIAL, 128),
+    (16, 16, 1, 1, O.ACT_TANH, O.ACT_NONE, 128),
+    (16, 32, 16, 5, O.ACT_SOFTPLUS, O.ACT_RELU, 256),
+    (64, 16, 2, 1, O.ACT_EXPONENTIAL, O.ACT_TANH, 128),
+    (64, 64, 8, 4, O.ACT_NONE, O.ACT_NONE, 128),
+]
+
+
+@pytest.mark.parametrize("case", MLP_CASES, ids=lambda c: "w%d_in%d_out%d_h%d_a%d_o%d" % c[:6])
+def test_fused_network_kernels_bit_exact(case):
+    R = ref()
+    W, IN, OUT, H, act, oact, n = case
+    m, params, x, dy = _mlp_case(W, IN, OUT, H, act, oact, n, seed=71 + W + IN)
+    hidden, out = O.mlp_forward(m, params, x, accum_fp16=True)
+    ref_hidden, ref_out = _ref_mlp_forward(R, m, params, x)
+    assert np.array_equal(ref_hidden, hidden)      # out_intermediate, [layer][sample][neuron], post-activation
+    assert np.array_equal(ref_out, out)            # the padded output: rows >= out_width come from the zero-padded matrix
+    assert not np.any(ref_out == 0xFFFF) and not np.any(ref_hidden == 0xFFFF)
+    # inference: the same kernel without intermediates (fully_fused_mlp.cu:689-699)
+    assert np.array_equal(_ref_mlp_forward(R, m, params, x, inference=True)[1], out)
+    # backward: the oracle's dL/dinput is the end of the chain output transfer -> last layer -> hidden layers -> input matrix
+    grad, dinput = O.mlp_backward(m, params, x, hidden, out, dy, want_dinput=True, accum_fp16=True)
+    dyt, tmp, ref_dinput = _ref_mlp_backward(R, m, params, hidden, out, dy)
+    assert not np.any(tmp == 0xFFFF)
+    if IN == W:
+        assert np.array_equal(ref_dinput, dinput)
+    # weight gradients: CUTLASS GEMMs in the reference (fully_fused_mlp.cu:776, 819, 829; not compilable here) over the kernel's
+    # backward_tmp: dW_j = dL/d(pre-activation of layer j)^T x (what fed layer j).  The oracle's half accumulators round every 16
+    # samples per host thread, so this is a tolerance check of the SAME sums, matrix by matrix.
+    feeds = [O.h2f(x).astype(np.float64)] + [O.h2f(hidden[j]).astype(np.float64) for j in range(H)]
+    deltas = [O.h2f(tmp[H - 1 - j]).astype(np.float64) for j in range(H)] + [O.h2f(dyt).astype(np.float64)]
+    off = 0
+    for j in range(H + 1):
+        want = deltas[j].T @ feeds[j]
+        got = grad[off:off + want.size].reshape(want.shape)
+        off += want.size
+        assert np.abs(got - want).max() <= 1e-2 * max(np.abs(want).max(), 1e-6), j
+    assert off == m.n_params
+
+
+def test_fused_network_kernels_other_layouts():
+    """Row-major input / output / dL_doutput matrices select the other wmma layouts (fully_fused_mlp.cu:307-311, 638-640): same values."""
+    R = ref()
+    for W, IN in ((64, 32), (32, 32)):
+        m, params, x, dy = _mlp_case(W, IN, 4, 2, O.ACT_RELU, O.ACT_NONE, 128, seed=5)
+        hidden, out = O.mlp_forward(m, params, x, accum_fp16=True)
+        got_hidden, got_out = _ref_mlp_forward(R, m, params, x, input_row_major=True, output_row_major=True)
+        assert np.array_equal(got_hidden, hidden) and np.array_equal(got_out, out)
+        a = _ref_mlp_backward(R, m, params, hidden, out, dy)
+        b = _ref_mlp_backward(R, m, params, hidden, out, dy, dL_doutput_row_major=True)
+        assert np.array_equal(a[1], b[1]) and (a[2] is None or np.array_equal(a[2], b[2]))
+
+
+def test_fused_network_kernel_host_checks():
+    """mlp_fused_forward's CHECK_THROWs (fully_fused_mlp.cu:607-618): batch % 128, in_width % 16; unknown width / activation."""
+    R = ref()
+    m, params, x, _ = _mlp_case(64, 32, 4, 2, O.ACT_RELU, O.ACT_NONE, 128, seed=3)
+    out = np.zeros((128, 16), np.uint16)
+    hid = np.zeros((2, 128, 64), np.uint16)
+    call = lambda width, act, n, in_width: R.ref_mlp_fused_forward(width, act, 9, 0, p(x), 0, p(params), p(hid), p(out), 16, 0, n, in_width, 16, 2)  # noqa: E731
+    assert call(64, 0, 128, 32) == 0
+    assert call(64, 0, 64, 32) == 2 and call(64, 0, 128, 24) == 2
+    assert call(48, 0, 128, 32) == 1 and call(64, 2, 128, 32) == 1  # SiLU (2) is not dispatched by FullyFusedMLP
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
 # the committed fixture made by the reference's code (tests/golden/make_ref_golden.py): needs neither /root/reference nor _ref
 def reference_golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "reference_small.npz"))
@@ -332,3 +453,21 @@ def test_oracle_reproduces_the_reference_made_fixture():
         O.adam_step(h, 1024, 128.0, step, st["w"], st["h"], gold[f"adam_grad{step}"], st["m1"], st["m2"], st["s"])
     for k, name in (("w", "adam_w"), ("h", "adam_h"), ("m1", "adam_m1"), ("m2", "adam_m2"), ("s", "adam_steps")):
         assert np.array_equal(st[k], gold[name]), name
+
+
+@pytest.mark.parametrize("tag,in_w,out_w", [("net_a", 32, 4), ("net_b", 64, 16)])
+def test_oracle_reproduces_the_reference_made_network_fixture(tag, in_w, out_w):
+    """The network part of the fixture (the reference's fused kernels through oracle/ref_shim/mma.h): the oracle's fp16-accumulate
+    mode reproduces it bit for bit -- with neither /root/reference nor oracle/_ref at hand."""
+    gold = reference_golden()
+    m = O.mlp_init(in_w, 64, out_w, 2)
+    params, x, dy = gold[tag + "_params"], gold[tag + "_input"], gold[tag + "_dL_doutput"]
+    hidden, out = O.mlp_forward(m, params, x, accum_fp16=True)
+    assert np.array_equal(hidden, gold[tag + "_hidden"]) and np.array_equal(out, gold[tag + "_output"])
+    _, dinput = O.mlp_backward(m, params, x, hidden, out, dy, want_dinput=True, accum_fp16=True)
+    if in_w == 64:
+        assert np.array_equal(dinput, gold[tag + "_dL_dinput"])
+    # the default fp32-accumulate mode (what the HIP kernels' MFMA accumulators do) is close to it, not equal
+    out32 = O.mlp_forward(m, params, x)[1]
+    assert not np.array_equal(out32, out)
+    assert np.linalg.norm(O.h2f(out32).astype(np.float64) - O.h2f(out).astype(np.float64)) < 5e-3 * np.linalg.norm(O.h2f(out).astype(np.float64))

@@ -41,7 +41,8 @@ INC = "include/tiny-cuda-nn/"
 # header -> definitions compiled from it (kernels, and the helper structs / device functions they use)
 KERNELS = [
     (INC + "encodings/multi_level_interface.h", ["line:static constexpr uint32_t MAX_N_LEVELS", "ParamsOffsetTable"]),
-    (INC + "encodings/grid.h", ["kernel_grid", "kernel_grid_backward", "kernel_grid_backward_input"]),
+    (INC + "encodings/grid.h", ["kernel_grid", "kernel_grid_backward", "kernel_grid_backward_input", "kernel_grid_backward_input_backward_grid",
+                                "kernel_grid_backward_input_backward_input", "kernel_grid_backward_input_backward_dLdoutput"]),
     (INC + "optimizers/adam.h", ["adam_step"]),
     (INC + "losses/l2.h", ["l2_loss"]),
     (INC + "losses/relative_l2.h", ["relative_l2_loss"]),
@@ -52,6 +53,8 @@ KERNELS = [
     (INC + "losses/relative_l2_luminance.h", ["relative_l2_luminance_loss"]),
     (INC + "random.h", ["generate_random_kernel"]),
     (INC + "encodings/identity.h", ["identity", "identity_backward"]),
+    (INC + "encodings/frequency.h", ["frequency_encoding", "frequency_encoding_backward"]),
+    (INC + "encodings/oneblob.h", ["kernel_one_blob_soa", "kernel_one_blob_backward"]),
 ]
 # second translation unit (oracle/ref_driver_mlp.cpp): the fully fused network kernels, against oracle/ref_shim/mma.h (nvcuda::wmma for the
 # host) and with a thread block's threads as fibers; in source order (each is declared before it is used)

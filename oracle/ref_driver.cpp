@@ -89,6 +89,55 @@ void grid_backward(const GridArgs& a, const float* positions, const __half* dL_d
 	});
 }
 
+// backward_backward_input_impl, grid.h:907-1042: dL_d(dL_dx) -> grid gradient (blocks (ceil(n * F / FPT / 256), n_levels), 256 threads;
+// grad_t as in backward_impl) and -> dL_dx (same launch shape; dL_dx zeroed first, :1011-1016)
+template <uint32_t D, uint32_t F>
+void grid_backward_backward(const GridArgs& a, const float* dL_ddLdx, const float* positions, const __half* dL_dy, const __half* grid, void* grid_gradient, float* dL_dx) {
+	const ParamsOffsetTable table = offset_table(a.n_levels, a.offsets);
+	MatrixView<const float> pos(positions, 1u, a.n_dims), ddx(dL_ddLdx, 1u, a.n_dims);
+	constexpr uint32_t FPT = F < 2 ? F : 2;
+	using grad_t = std::conditional_t<F == 1, float, __half>;
+	const uint32_t blocks = (a.n * F / FPT + 255) / 256;
+	if (grid_gradient) {
+		launch(blocks, a.n_levels, 256, [&] {
+			kernel_grid_backward_input_backward_grid<__half, grad_t, D, F, FPT, HashType::CoherentPrime>(a.n, a.n_levels * F, table, a.base_resolution, a.log2_per_level_scale, a.max_level,
+			                                                                                            nullptr, (InterpolationType)a.interpolation, (GridType)a.grid_type, ddx, pos, dL_dy,
+			                                                                                            (grad_t*)grid_gradient);
+		});
+	}
+	if (dL_dx) {
+		for (uint32_t i = 0; i < a.n * a.n_dims; ++i) dL_dx[i] = 0.0f;
+		MatrixView<float> out(dL_dx, 1u, a.n_dims);
+		launch(blocks, a.n_levels, 256, [&] {
+			kernel_grid_backward_input_backward_input<__half, D, F, FPT, HashType::CoherentPrime>(a.n, a.n_levels * F, table, a.base_resolution, a.log2_per_level_scale, a.max_level, nullptr,
+			                                                                                     (InterpolationType)a.interpolation, (GridType)a.grid_type, ddx, pos, dL_dy, grid, out);
+		});
+	}
+}
+
+// the 2-D launches of the OneBlob encoding (oneblob.h:209-224, 250-262): threads (x, ceil(128 / x)), blockIdx.x over ceil(n * x / (threads.x * threads.y))
+template <typename F>
+void launch_xy(uint32_t n_work, uint32_t tx, F&& body) {
+	const uint32_t ty = (128 + tx - 1) / tx, per_block = tx * ty, blocks = (n_work + per_block - 1) / per_block;
+	gridDim.x = blocks;
+	gridDim.y = 1;
+	blockDim.x = tx;
+	blockDim.y = ty;
+	blockIdx.y = 0;
+	for (uint32_t b = 0; b < blocks; ++b) {
+		for (uint32_t y = 0; y < ty; ++y) {
+			for (uint32_t x = 0; x < tx; ++x) {
+				blockIdx.x = b;
+				threadIdx.x = x;
+				threadIdx.y = y;
+				body();
+			}
+		}
+	}
+	threadIdx.y = 0;
+	blockDim.y = 1;
+}
+
 template <typename Fn>
 void dispatch_grid(uint32_t D, uint32_t F, Fn&& fn) {
 #define CASE(D_, F_) if (D == D_ && F == F_) { fn(std::integral_constant<uint32_t, D_>{}, std::integral_constant<uint32_t, F_>{}); return; }
@@ -160,6 +209,62 @@ int ref_grid_backward_input(uint32_t n_dims, uint32_t n, uint32_t n_features, co
 		case 4: launch_linear(n, [&] { kernel_grid_backward_input<__half, 4>(n, n_features, (const __half*)dL_dy, dy_dx, out); }); return 0;
 	}
 	return 1;
+}
+
+// kernel_grid_backward_input_backward_grid / _backward_input (grid.h:351-620): dL_ddLdx and positions column-major (n_dims x n), dL_dy
+// feature-major [k][i], grid_gradient fp16 (fp32 for one feature per level) zeroed by the caller, dL_dx column-major; either output may be NULL
+int ref_grid_backward_backward(uint32_t n_dims, uint32_t n_feat, uint32_t n, uint32_t n_levels, const uint32_t* offsets, uint32_t base_resolution,
+                               float log2_per_level_scale, float max_level, int interpolation, int grid_type, const float* dL_ddLdx, const float* positions,
+                               const void* dL_dy, const void* grid, void* grid_gradient, float* dL_dx) {
+	try {
+		GridArgs a = {n_dims, n_feat, n, n_levels, offsets, base_resolution, log2_per_level_scale, max_level, interpolation, grid_type, 0};
+		dispatch_grid(n_dims, n_feat, [&](auto d, auto f) {
+			grid_backward_backward<decltype(d)::value, decltype(f)::value>(a, dL_ddLdx, positions, (const __half*)dL_dy, (const __half*)grid, grid_gradient, dL_dx);
+		});
+	} catch (...) {
+		return 1;
+	}
+	return 0;
+}
+// kernel_grid_backward_input_backward_dLdoutput through linear_kernel (grid.h:622-653, 994-1006); dL_ddLdy column-major ((n_features + n_to_pad) x n)
+int ref_grid_backward_backward_dLdoutput(uint32_t n_dims, uint32_t n, uint32_t n_features, uint32_t n_to_pad, const float* dL_ddLdx, const float* dy_dx, const void* dL_dy,
+                                         void* dL_ddLdy) {
+	MatrixView<const float> ddx(dL_ddLdx, 1u, n_dims);
+	MatrixView<__half> out((__half*)dL_ddLdy, 1u, n_features + n_to_pad);
+	switch (n_dims) {
+		case 2: launch_linear(n, [&] { kernel_grid_backward_input_backward_dLdoutput<__half, 2>(n, n_features, n_to_pad, ddx, dy_dx, (const __half*)dL_dy, out); }); return 0;
+		case 3: launch_linear(n, [&] { kernel_grid_backward_input_backward_dLdoutput<__half, 3>(n, n_features, n_to_pad, ddx, dy_dx, (const __half*)dL_dy, out); }); return 0;
+		case 4: launch_linear(n, [&] { kernel_grid_backward_input_backward_dLdoutput<__half, 4>(n, n_features, n_to_pad, ddx, dy_dx, (const __half*)dL_dy, out); }); return 0;
+	}
+	return 1;
+}
+
+// frequency encoding, frequency.h:45-105 (linear_kernel over n * padded outputs / n * n_dims inputs); in / out / dL_dy / dL_dx column-major,
+// dy_dx [i][n_dims * n_frequencies * 2].  __sinf / __cosf are approximations on the device; this host build evaluates sinf / cosf
+void ref_frequency_forward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, uint32_t n_to_pad, const float* in, void* out, float* dy_dx) {
+	const uint32_t fan_out = n_dims * n_frequencies * 2 + n_to_pad;
+	MatrixView<const float> vin(in, 1u, n_dims);
+	MatrixView<__half> vout((__half*)out, 1u, fan_out);
+	launch_linear((size_t)n * fan_out, [&] { frequency_encoding<__half>(n * fan_out, n_frequencies, n_dims, n_to_pad, vin, vout, dy_dx); });
+}
+void ref_frequency_backward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, uint32_t padded, const void* dL_dy, const float* dy_dx, float* dL_dx) {
+	MatrixView<const __half> vdy((const __half*)dL_dy, 1u, padded);
+	MatrixView<float> vdx(dL_dx, 1u, n_dims);
+	launch_linear((size_t)n * n_dims, [&] { frequency_encoding_backward<__half>(n * n_dims, n_dims, n_frequencies, vdy, dy_dx, vdx); });
+}
+
+// OneBlob, the structure-of-arrays forward kernel and the backward kernel (oneblob.h:98-164; launches :209-224, :250-262).  `out`: feature-major
+// [n_dims * n_bins][n]; dL_dy column-major (padded x n); in / dL_dx column-major (n_dims x n).  (The array-of-structures forward kernel
+// gets a bin's right boundary from the neighbouring lane with __shfl_sync, oneblob.h:46-67: not compiled.)
+void ref_oneblob_forward_soa(uint32_t n, uint32_t n_dims, uint32_t num_bins_log2, const float* in, void* out) {
+	MatrixView<const float> vin(in, 1u, n_dims);
+	launch_xy(n * n_dims, n_dims, [&] { kernel_one_blob_soa<__half>(n, num_bins_log2, n_dims, vin, (__half*)out); });
+}
+void ref_oneblob_backward(uint32_t n, uint32_t n_dims, uint32_t num_bins_log2, uint32_t padded, const void* dL_dy, const float* in, float* dL_dx) {
+	MatrixView<const __half> vdy((const __half*)dL_dy, 1u, padded);
+	MatrixView<const float> vin(in, 1u, n_dims);
+	MatrixView<float> vdx(dL_dx, 1u, n_dims);
+	launch_xy(n * n_dims, n_dims, [&] { kernel_one_blob_backward<__half>(n, n_dims, num_bins_log2, vdy, vin, vdx); });
 }
 
 // AdamOptimizer::step, adam.h:158-198 (linear_kernel over n_weights)

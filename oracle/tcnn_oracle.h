@@ -16,6 +16,9 @@
  *       pcg32 + generate_random_kernel                               random.h:39-69, dependencies/pcg32/pcg32.h
  *       warp_activation / warp_activation_backward                   common_device.h:108-186, 363-440 (up to the sign of a zero)
  *       the identity encoding                                        encodings/identity.h:45-85
+ *       the second-order grid kernels (dL_ddLdy bit for bit; dL_dx and the grid gradient to the rounding of the reference's own
+ *       running atomic sums)                                         encodings/grid.h:351-653
+ *       frequency_encoding[_backward], kernel_one_blob_soa, kernel_one_blob_backward   encodings/frequency.h:45-105, oneblob.h:98-164
  *     and against the reference's known answers for the grid layout (/root/reference/tests/test_grid.cu:55-71) and its literal
  *     constants (common_device.h:787-791, 854-866).  The committed fixture tests/golden/reference_small.npz was produced by that
  *     library; the HIP path is held against it on the GPU without the oracle in the loop.

@@ -12,6 +12,9 @@ Covered -- everything on the hot path that compiles without nvcc:
   generate_random_kernel + pcg32                          random.h:39-55, dependencies/pcg32/pcg32.h
   warp_activation / warp_activation_backward              common_device.h:108-186, 363-440
   identity encoding                                       encodings/identity.h:45-85
+  kernel_grid_backward_input_backward_grid / _input / _dLdoutput   encodings/grid.h:351-653 (second order)
+  frequency_encoding / frequency_encoding_backward        encodings/frequency.h:45-105
+  kernel_one_blob_soa / kernel_one_blob_backward          encodings/oneblob.h:98-164
   kernel_mlp_fused / kernel_mlp_fused_backward + threadblock_*   src/fully_fused_mlp.cu:46-557 (through oracle/ref_shim/mma.h: nvcuda::wmma
                                                           for the host; a block's threads run as fibers).  Modelled, not the reference's:
                                                           the arithmetic inside ONE 16x16x16 tensor-core operation (mma.h says how)
@@ -203,6 +206,82 @@ def test_grid_backward_input_bit_exact():
     got = np.zeros((n, D), np.float32)
     assert R.ref_grid_backward_input(D, n, L * F, p(np.ascontiguousarray(dy.T)), p(np.ascontiguousarray(dy_dx.transpose(1, 0, 2))), p(got)) == 0
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("case", GRID_CASES)
+def test_grid_second_order_kernels(case):
+    """kernel_grid_backward_input_backward_grid / _backward_input / _backward_dLdoutput (grid.h:351-653) as backward_backward_input_impl
+    launches them (grid.h:907-1042).  dL_ddLdy is one fp32 dot product per (sample, feature): bit-exact.  dL_dx is an fp32 atomicAdd per
+    (level, feature pair) and the grid gradient an atomic sum in its accumulation type (fp16 for F >= 2): the same records, summed in
+    the launch order there and exactly (float64) by the oracle -- equal to the rounding of those running sums."""
+    g, R = _grid(case), ref()
+    D, F, L, T, base, pls, gtype, interp = case
+    n = 300
+    rng = np.random.default_rng(5)
+    x = _positions(n, D, seed=4)
+    params = O.f2h((rng.standard_normal(g.n_params) * 0.3).astype(np.float32))
+    ddx = (rng.standard_normal((n, D)) * 1e-3).astype(np.float32)  # times the level's scale (up to 2^19): the records must stay inside fp16
+    dy = O.f2h((rng.standard_normal((n, L * F)) * 0.05).astype(np.float32))
+    _, dy_dx = O.grid_forward(g, params, x, want_dy_dx=True)
+    want_grad, want_ddy, want_dx = O.grid_backward_backward_input(g, params, x, ddx, dy, dy_dx)
+    offsets = (C.c_uint32 * (L + 1))(*[g.offsets[l] for l in range(L + 1)])
+    log2_pls = R.ref_log2_per_level_scale(f32(pls))
+    dy_fm = np.ascontiguousarray(dy.T)
+    grad_buf = np.zeros(g.n_params, np.float32 if F == 1 else np.uint16)
+    dx = np.full((n, D), 7.0, np.float32)  # the host code zeroes it (grid.h:1011-1016)
+    assert R.ref_grid_backward_backward(D, F, n, L, offsets, base, f32(log2_pls), f32(1.0), _ref_interp(interp), _ref_grid_type(gtype), p(ddx), p(x), p(dy_fm), p(params),
+                                        p(grad_buf), p(dx)) == 0
+    ddy = np.zeros((n, L * F), np.uint16)
+    assert R.ref_grid_backward_backward_dLdoutput(D, n, L * F, 0, p(ddx), p(np.ascontiguousarray(dy_dx.transpose(1, 0, 2))), p(dy_fm), p(ddy)) == 0
+    assert np.array_equal(ddy, want_ddy)
+    grad = grad_buf.astype(np.float64) if F == 1 else O.h2f(grad_buf).astype(np.float64)
+    if interp == O.INTERP_NEAREST:  # no interpolation: d(dy_dx)/d(anything) is zero (grid.h:417-420, 519-522)
+        assert not grad.any() and not want_grad.any() and not dx.any() and not want_dx.any()
+        return
+    assert np.isfinite(want_grad).all() and np.isfinite(grad).all() and np.abs(want_grad).max() > 0
+    assert np.abs(dx - want_dx).max() <= 2e-6 * np.abs(want_dx).max()
+    assert np.linalg.norm(grad - want_grad) <= (1e-6 if F == 1 else 2e-3) * np.linalg.norm(want_grad)
+    assert np.array_equal(grad == 0, want_grad == 0) or F > 1  # untouched entries stay zero
+
+
+def test_frequency_encoding_bit_exact():
+    """frequency_encoding / frequency_encoding_backward (frequency.h:45-105): index arithmetic, phase shifts, padding with ones, dy_dx.
+    (The device evaluates __sinf / __cosf, approximations; this host build of the reference and the oracle both call sinf / cosf.)"""
+    R = ref()
+    rng = np.random.default_rng(29)
+    for n, d, nf, padded in ((300, 3, 6, 48), (129, 2, 12, 48), (64, 1, 4, 16)):
+        x = (rng.random((n, d), dtype=np.float32) * 2 - 1).astype(np.float32)
+        x[0] = 0.0
+        want = O.frequency_forward(x, nf, padded)
+        got = np.zeros((n, padded), np.uint16)
+        dy_dx = np.zeros((n, d * nf * 2), np.float32)
+        R.ref_frequency_forward(n, d, nf, padded - d * nf * 2, p(x), p(got), p(dy_dx))
+        assert np.array_equal(got, want)
+        dy = O.f2h((rng.standard_normal((n, padded)) * 0.1).astype(np.float32))
+        want_dx = O.frequency_backward(x, nf, dy)
+        got_dx = np.zeros((n, d), np.float32)
+        R.ref_frequency_backward(n, d, nf, padded, p(dy), p(dy_dx), p(got_dx))
+        assert np.array_equal(got_dx, want_dx)
+
+
+@pytest.mark.parametrize("d,n_bins", [(2, 64), (3, 16), (1, 4), (4, 32)])
+def test_oneblob_encoding_bit_exact(d, n_bins):
+    """kernel_one_blob_soa / kernel_one_blob_backward (oneblob.h:98-164) with their 2-D launches (oneblob.h:209-224, 250-262): the wrapped
+    quartic bin integrals and their derivative.  BASELINE configs[0]'s encoding."""
+    R = ref()
+    rng = np.random.default_rng(31)
+    n = 300
+    x = rng.random((n, d), dtype=np.float32)
+    x[0], x[1] = 0.0, np.float32(1.0) - np.float32(2.0 ** -24)
+    want = O.oneblob_forward(x, n_bins)
+    got = np.zeros((d * n_bins, n), np.uint16)
+    R.ref_oneblob_forward_soa(n, d, int(np.log2(n_bins)), p(x), p(got))
+    assert np.array_equal(got.T, want)
+    dy = O.f2h((rng.standard_normal((n, d * n_bins)) * 0.1).astype(np.float32))
+    want_dx = O.oneblob_backward(x, n_bins, dy)
+    got_dx = np.zeros((n, d), np.float32)
+    R.ref_oneblob_backward(n, d, int(np.log2(n_bins)), d * n_bins, p(dy), p(x), p(got_dx))
+    assert np.array_equal(got_dx, want_dx)
 
 
 LOSSES = ["L2", "RelativeL2", "L1", "RelativeL1", "Mape", "Smape", "RelativeL2Luminance"]

@@ -51,6 +51,9 @@ KERNELS = [
     (INC + "losses/mape.h", ["mape_loss"]),
     (INC + "losses/smape.h", ["smape_loss"]),
     (INC + "losses/relative_l2_luminance.h", ["relative_l2_luminance_loss"]),
+    (INC + "losses/cross_entropy.h", ["cross_entropy_loss"]),
+    (INC + "losses/variance_is.h", ["variance_is_loss"]),
+    (INC + "optimizers/ema.h", ["ema_step_full_precision", "ema_step_half_precision"]),
     (INC + "random.h", ["generate_random_kernel"]),
     (INC + "encodings/identity.h", ["identity", "identity_backward"]),
     (INC + "encodings/frequency.h", ["frequency_encoding", "frequency_encoding_backward"]),

@@ -281,8 +281,20 @@ void ref_adam_step(uint32_t n_elements, uint32_t n_matrix_weights, float relativ
 	});
 }
 
+// EmaOptimizer::step after the nested step, ema.h:103-136: the debias factors are computed there on the host (std::pow(float, unsigned) in
+// double, narrowed to float); tmp != NULL selects the full-precision variant (fp32 running average next to the half one)
+void ref_ema_step(uint32_t n_elements, float ema_decay, uint32_t current_step, const void* weights, void* weights_ema, float* tmp) {
+	const float ema_debias_old = 1 - (float)std::pow(ema_decay, current_step - 1);
+	const float ema_debias_new = 1.0f / (1 - (float)std::pow(ema_decay, current_step));
+	if (tmp) {
+		launch_linear(n_elements, [&] { ema_step_full_precision<__half>(n_elements, ema_decay, ema_debias_old, ema_debias_new, (const __half*)weights, (__half*)weights_ema, tmp); });
+	} else {
+		launch_linear(n_elements, [&] { ema_step_half_precision<__half>(n_elements, ema_decay, ema_debias_old, ema_debias_new, (const __half*)weights, (__half*)weights_ema); });
+	}
+}
+
 // Loss::evaluate of the element-wise losses (e.g. relative_l2.h:92-106): linear_kernel over n_elements = batch * stride
-// which: 0 L2, 1 RelativeL2, 2 L1, 3 RelativeL1, 4 Mape, 5 Smape, 6 RelativeL2Luminance
+// which: 0 L2, 1 RelativeL2, 2 L1, 3 RelativeL1, 4 Mape, 5 Smape, 6 RelativeL2Luminance, 7 CrossEntropy, 8 Variance
 int ref_loss(int which, uint32_t n_elements, uint32_t stride, uint32_t dims, float loss_scale, const void* predictions, const float* targets, float* values,
              void* gradients, const float* data_pdf) {
 	const __half* p = (const __half*)predictions;
@@ -295,6 +307,8 @@ int ref_loss(int which, uint32_t n_elements, uint32_t stride, uint32_t dims, flo
 		case 4: launch_linear(n_elements, [&] { mape_loss<__half>(n_elements, stride, dims, loss_scale, p, targets, values, g, data_pdf); }); return 0;
 		case 5: launch_linear(n_elements, [&] { smape_loss<__half>(n_elements, stride, dims, loss_scale, p, targets, values, g, data_pdf); }); return 0;
 		case 6: launch_linear(n_elements, [&] { relative_l2_luminance_loss<__half>(n_elements, stride, dims, loss_scale, p, targets, values, g, data_pdf); }); return 0;
+		case 7: launch_linear(n_elements, [&] { cross_entropy_loss<__half>(n_elements, stride, dims, loss_scale, p, targets, values, g, data_pdf); }); return 0;
+		case 8: launch_linear(n_elements, [&] { variance_is_loss<__half>(n_elements, stride, dims, loss_scale, p, targets, values, g, data_pdf); }); return 0;
 	}
 	return 1;
 }

@@ -12,7 +12,7 @@
  *       kernel_grid (encoding and dy_dx), kernel_grid_backward (records; sums to the error of the reference's own running
  *       fp16 sum), kernel_grid_backward_input                       encodings/grid.h:48-349
  *       adam_step                                                    optimizers/adam.h:47-127
- *       the element-wise losses                                      losses/{l2,relative_l2,l1,relative_l1,mape,smape,relative_l2_luminance}.h
+ *       the element-wise losses                                      losses/{l2,relative_l2,l1,relative_l1,mape,smape,relative_l2_luminance,cross_entropy,variance_is}.h
  *       pcg32 + generate_random_kernel                               random.h:39-69, dependencies/pcg32/pcg32.h
  *       warp_activation / warp_activation_backward                   common_device.h:108-186, 363-440 (up to the sign of a zero)
  *       the identity encoding                                        encodings/identity.h:45-85

@@ -8,7 +8,8 @@ Covered -- everything on the hot path that compiles without nvcc:
   kernel_grid_backward                                    encodings/grid.h:214-320
   kernel_grid_backward_input                              encodings/grid.h:322-349
   adam_step                                               optimizers/adam.h:47-127
-  l2 / relative_l2 / l1 / relative_l1 / mape / smape / relative_l2_luminance losses   losses/*.h:39-8x
+  l2 / relative_l2 / l1 / relative_l1 / mape / smape / relative_l2_luminance / cross_entropy / variance_is losses   losses/*.h:39-8x
+  ema_step_half_precision / _full_precision               optimizers/ema.h:44-72
   generate_random_kernel + pcg32                          random.h:39-55, dependencies/pcg32/pcg32.h
   warp_activation / warp_activation_backward              common_device.h:108-186, 363-440
   identity encoding                                       encodings/identity.h:45-85
@@ -284,7 +285,7 @@ def test_oneblob_encoding_bit_exact(d, n_bins):
     assert np.array_equal(got_dx, want_dx)
 
 
-LOSSES = ["L2", "RelativeL2", "L1", "RelativeL1", "Mape", "Smape", "RelativeL2Luminance"]
+LOSSES = ["L2", "RelativeL2", "L1", "RelativeL1", "Mape", "Smape", "RelativeL2Luminance", "CrossEntropy", "Variance"]  # ref_loss's `which`
 
 
 @pytest.mark.parametrize("loss", LOSSES)
@@ -294,6 +295,8 @@ def test_losses_bit_exact(loss, with_pdf):
     n, stride, dims = 1000, 16, 3 if loss == "RelativeL2Luminance" else 4
     rng = np.random.default_rng(31)
     pred = O.f2h((rng.standard_normal((n, stride)) * 0.7).astype(np.float32))
+    if loss in ("CrossEntropy", "Variance"):  # log(prediction), 1 / prediction: probabilities / positive estimates (cross_entropy.h:66-76, variance_is.h:66-76)
+        pred = O.f2h((rng.random((n, stride), dtype=np.float32) * 0.9 + 0.05).astype(np.float32))
     tgt = rng.random((n, dims), dtype=np.float32)
     pdf = (rng.random((n, dims), dtype=np.float32) + 0.25) if with_pdf else None
     values, grads = O.loss(O.LOSS_NAMES.index(loss), pred, tgt, dims, 128.0, data_pdf=pdf)
@@ -327,6 +330,29 @@ def test_adam_step_bit_exact_over_steps():
             for k in a:
                 assert np.array_equal(a[k], b[k]), (kw, step, k)
         assert a["s"][nm] == 0 and a["s"][nm + 1] == 3
+
+
+def test_ema_step_matches_the_formula_the_gpu_suite_uses():
+    """ema_step_half_precision / ema_step_full_precision with EmaOptimizer::step's debias factors (ema.h:44-136): tests/test_gpu_parity.py
+    (test_wrapper_optimizers_ema_and_exponential_decay) holds the HIP kernel against this numpy restatement; here the restatement is held
+    against the reference's kernel."""
+    R = ref()
+    n = 4096
+    rng = np.random.default_rng(43)
+    decay = 0.9
+    ema = np.zeros(n, np.float32)
+    ref_ema, ref_ema_full, tmp = np.zeros(n, np.uint16), np.zeros(n, np.uint16), np.zeros(n, np.float32)
+    for k in range(1, 7):
+        w16 = O.f2h((rng.standard_normal(n) * 0.2).astype(np.float32))
+        d = float(np.float32(decay))
+        old = np.float32(1 - np.float32(d ** (k - 1)))
+        new = np.float32(1.0) / np.float32(1 - np.float32(d ** k))
+        ema = O.h2f(O.f2h((ema * np.float32(decay) * old + O.h2f(w16) * np.float32(1 - np.float32(decay))) * new))
+        R.ref_ema_step(n, f32(decay), k, p(w16), p(ref_ema), None)
+        assert np.array_equal(O.h2f(ref_ema), ema), k
+        R.ref_ema_step(n, f32(decay), k, p(w16), p(ref_ema_full), p(tmp))
+        assert np.array_equal(O.f2h(tmp), ref_ema_full)
+    assert np.abs(O.h2f(ref_ema_full) - ema).max() < 2e-3  # the fp32 running average differs from the half one by its roundings only
 
 
 def test_pcg32_uniform_bit_exact():

@@ -545,3 +545,38 @@ def test_network_kernels_against_the_reference_made_fixture(tag):
     grads, dx = emu.mlp_backward(om, params, xs, hidden, dy)
     err = RF.check(gold, tag, O.h2f(y), O.h2f(grads), O.h2f(dx).T)
     assert err["output"] > 0  # fp32 against fp16 accumulators: equality would mean the fixture is not the reference's
+
+
+def _mlp_cases_of_the_reference_pin():
+    import test_oracle_ref as TR
+    return TR.MLP_CASES
+
+
+@pytest.mark.parametrize("case", _mlp_cases_of_the_reference_pin(), ids=lambda c: "w%d_in%d_out%d_h%d_a%d_o%d" % c[:6])
+def test_network_kernels_against_the_reference_kernels_run_live(case):
+    """The HIP network kernels (on the emulator) against THE REFERENCE'S OWN kernel_mlp_fused / kernel_mlp_fused_backward run live
+    (oracle/_ref, src/fully_fused_mlp.cu:46-557; skipped where neither the library nor the reference tree exists), no oracle in
+    between: widths 16-128, 1-5 hidden layers, all eight activations, outputs 1-16.  fp32 MFMA accumulators here, binary16 fragments
+    there, hence norm-relative bars (measured: output <= 1.1e-3, hidden <= 6.1e-4, gradients <= 3.1e-2 where ReLU masks of tiny
+    hidden values differ and <= 1.2e-3 for the smooth activations)."""
+    import test_oracle_ref as TR
+    R = TR.ref()
+    W, IN, OUT, H, act, oact, _ = case
+    n = 256  # batch_size_granularity of the HIP path (object.h:170)
+    m, params, x, dy = TR._mlp_case(W, IN, OUT, H, act, oact, n, seed=7)
+    ref_hidden, ref_out = TR._ref_mlp_forward(R, m, params, x)
+    dyt, tmp, ref_dinput = TR._ref_mlp_backward(R, m, params, ref_hidden, ref_out, dy)
+    xs = np.ascontiguousarray(x.T)
+    hidden, y = emu.mlp_forward(m, params, xs)
+    grads, dx = emu.mlp_backward(m, params, xs, hidden, dy, output=y)
+    f64 = lambda a: O.h2f(a).astype(np.float64)  # noqa: E731
+    nr = lambda got, want: np.linalg.norm(got - want) / np.linalg.norm(want)  # noqa: E731
+    assert nr(f64(y)[:, :OUT], f64(ref_out)[:, :OUT]) < 5e-3
+    assert nr(f64(hidden), f64(ref_hidden)) < 3e-3
+    feeds = [f64(x)] + [f64(ref_hidden[j]) for j in range(H)]
+    deltas = [f64(tmp[H - 1 - j]) for j in range(H)] + [f64(dyt)]
+    want = np.concatenate([(deltas[j].T @ feeds[j]).ravel() for j in range(H + 1)])  # the reference's CUTLASS GEMMs, as float64 products
+    smooth = act not in (O.ACT_RELU, O.ACT_LEAKY_RELU)
+    assert nr(f64(grads), want) < (5e-3 if smooth else 8e-2)
+    if ref_dinput is not None:
+        assert nr(f64(dx).T, f64(ref_dinput)) < (5e-3 if smooth else 8e-2)

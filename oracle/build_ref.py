@@ -59,6 +59,15 @@ KERNELS = [
     (INC + "encodings/frequency.h", ["frequency_encoding", "frequency_encoding_backward"]),
     (INC + "encodings/oneblob.h", ["kernel_one_blob_soa", "kernel_one_blob_backward"]),
 ]
+# third translation unit (oracle/ref_driver_host.cpp): host-side member functions, compiled inside stand-ins for their classes; one
+# include file per place they are included at
+KERNELS_HOST = {
+    "ref_extracted_host_functions.inc": [(INC + "common_host.h", ["decl:uint32_t powi"]),
+                                         (INC + "encodings/multi_level_interface.h", ["line:static constexpr uint32_t MAX_N_LEVELS", "ParamsOffsetTable"])],
+    "ref_extracted_matrix_init.inc": [(INC + "gpu_matrix.h", ["initialize_uniform", "initialize_xavier_uniform", "initialize_siren_uniform", "initialize_siren_uniform_first"])],
+    "ref_extracted_mlp_init.inc": [("src/fully_fused_mlp.cu", ["FullyFusedMLP<T, WIDTH>::initialize_params"])],
+    "ref_extracted_grid_ctor.inc": [(INC + "encodings/grid.h", ["ctor:GridEncodingTemplated"])],
+}
 # second translation unit (oracle/ref_driver_mlp.cpp): the fully fused network kernels, against oracle/ref_shim/mma.h (nvcuda::wmma for the
 # host) and with a thread block's threads as fibers; in source order (each is declared before it is used)
 KERNELS_MLP = [
@@ -75,11 +84,29 @@ def extract(path, name):
             if line.startswith(name[5:]):
                 return line, i + 1, i + 1
         raise RuntimeError(f"{name} not found in {path}")
-    pat = re.compile(r"(\b(void|struct)\s+" + re.escape(name) + r"\b\s*[({])|(\bstruct\s+" + re.escape(name) + r"\s*$)")
+    ctor = name.startswith("ctor:")  # a constructor: `Name(` alone on its line, an initialiser list, then the body between lines that are just braces
+    if ctor:
+        pat = re.compile(r"^\s*" + re.escape(name[5:]) + r"\($")
+    elif name.startswith("decl:"):  # a function with another return type: "decl:uint32_t powi"
+        rtype, fname = name[5:].rsplit(" ", 1)
+        pat = re.compile(r"\b" + re.escape(rtype) + r"\s+" + re.escape(fname) + r"\b\s*\(")
+    else:
+        pat = re.compile(r"(\b(void|struct)\s+" + re.escape(name) + r"\b\s*[({])|(\bstruct\s+" + re.escape(name) + r"\s*$)")
     for i, line in enumerate(lines):
         if not pat.search(line) or line.lstrip().startswith("//"):
             continue
         first = i
+        if ctor:
+            j = i
+            while lines[j].strip() != "{":
+                j += 1
+            depth = 0
+            while True:
+                code = lines[j].split("//")[0]
+                depth += code.count("{") - code.count("}")
+                if depth == 0:
+                    return "\n".join(lines[first:j + 1]), first + 1, j + 1
+                j += 1
         while first > 0 and (lines[first - 1].startswith("template") or lines[first - 1].startswith("__global__") or lines[first - 1].startswith("__device__")
                              or lines[first - 1].startswith("TCNN_")):
             first -= 1
@@ -103,14 +130,14 @@ def build(reference="/root/reference", force=False, verbose=True):
         if verbose:
             print(f"[build_ref] no reference tree at {reference}: keeping whatever {LIB} exists")
         return os.path.exists(LIB)
-    srcs = [os.path.join(HERE, "ref_driver.cpp"), os.path.join(HERE, "ref_driver_mlp.cpp"), os.path.join(HERE, "ref_shim", "cuda_fp16.h"),
+    srcs = [os.path.join(HERE, "ref_driver.cpp"), os.path.join(HERE, "ref_driver_mlp.cpp"), os.path.join(HERE, "ref_driver_host.cpp"), os.path.join(HERE, "ref_shim", "cuda_fp16.h"),
             os.path.join(HERE, "ref_shim", "mma.h"), os.path.abspath(__file__)]
     if not force and os.path.exists(LIB) and os.path.exists(MANIFEST) and os.path.getmtime(LIB) >= max(os.path.getmtime(s) for s in srcs):
         return True
     os.makedirs(OUT_DIR, exist_ok=True)
     manifest = []
 
-    def gather(kernels):
+    def gather(kernels, wrap=True):
         parts = []
         for rel, names in kernels:
             path = os.path.join(reference, rel)
@@ -118,21 +145,24 @@ def build(reference="/root/reference", force=False, verbose=True):
                 text, first, last = extract(path, name)
                 manifest.append({"file": rel, "name": name, "lines": [first, last]})
                 parts.append(f"// ---- {rel}:{first}-{last} ({name})\n{text}\n")
-        return "namespace tcnn {\n" + "\n".join(parts) + "\n}  // namespace tcnn\n"
+        return "namespace tcnn {\n" + "\n".join(parts) + "\n}  // namespace tcnn\n" if wrap else "\n".join(parts)
 
     with tempfile.TemporaryDirectory(prefix="tcnn_ref_") as tmp:
         with open(os.path.join(tmp, "ref_extracted_kernels.inc"), "w") as f:
             f.write(gather(KERNELS))
         with open(os.path.join(tmp, "ref_extracted_mlp.inc"), "w") as f:
             f.write(gather(KERNELS_MLP))
+        for inc_name, kernels in KERNELS_HOST.items():  # included inside namespace tcnn / inside a class body: no namespace of their own
+            with open(os.path.join(tmp, inc_name), "w") as f:
+                f.write(gather(kernels, wrap=False))
         flags = ["-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
                  "-Wno-keyword-macro", "-Wno-unknown-pragmas", "-Wno-pass-failed", "-Wno-unused-value",
                  "-D__CUDACC__", "-D__CUDA_ARCH__=610", "-DTCNN_HALF_PRECISION=1", "-DTCNN_MIN_GPU_ARCH=61",
                  "-I" + os.path.join(HERE, "ref_shim"), "-I" + tmp, "-I" + os.path.join(reference, "include"), "-I" + os.path.join(reference, "dependencies")]
         # the two translation units compile side by side
-        objs = [os.path.join(tmp, "ref_driver.o"), os.path.join(tmp, "ref_driver_mlp.o")]
+        objs = [os.path.join(tmp, "ref_driver.o"), os.path.join(tmp, "ref_driver_mlp.o"), os.path.join(tmp, "ref_driver_host.o")]
         procs = [subprocess.Popen([CLANG, *flags, "-c", os.path.join(HERE, src), "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-                 for src, obj in zip(["ref_driver.cpp", "ref_driver_mlp.cpp"], objs)]
+                 for src, obj in zip(["ref_driver.cpp", "ref_driver_mlp.cpp", "ref_driver_host.cpp"], objs)]
         for proc in procs:
             _, err = proc.communicate()
             if proc.returncode != 0:

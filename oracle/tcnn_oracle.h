@@ -16,6 +16,10 @@
  *       pcg32 + generate_random_kernel                               random.h:39-69, dependencies/pcg32/pcg32.h
  *       warp_activation / warp_activation_backward                   common_device.h:108-186, 363-440 (up to the sign of a zero)
  *       the identity encoding                                        encodings/identity.h:45-85
+ *       GridEncodingTemplated's constructor: level sizes, offset table, n_params (host code, compiled inside a stand-in for its class)
+ *                                                                    encodings/grid.h:673-737
+ *       FullyFusedMLP::initialize_params + GPUMatrix::initialize_xavier_uniform: matrices, draw order, ranges, generator state left
+ *       behind (likewise)                                            src/fully_fused_mlp.cu:868-893, gpu_matrix.h:292-307
  *       the second-order grid kernels (dL_ddLdy bit for bit; dL_dx and the grid gradient to the rounding of the reference's own
  *       running atomic sums)                                         encodings/grid.h:351-653
  *       frequency_encoding[_backward], kernel_one_blob_soa, kernel_one_blob_backward   encodings/frequency.h:45-105, oneblob.h:98-164

@@ -16,6 +16,8 @@ Covered -- everything on the hot path that compiles without nvcc:
   kernel_grid_backward_input_backward_grid / _input / _dLdoutput   encodings/grid.h:351-653 (second order)
   frequency_encoding / frequency_encoding_backward        encodings/frequency.h:45-105
   kernel_one_blob_soa / kernel_one_blob_backward          encodings/oneblob.h:98-164
+  GridEncodingTemplated's constructor (offset table)      encodings/grid.h:673-737           (host code, inside a stand-in class)
+  FullyFusedMLP::initialize_params + GPUMatrix::initialize_*   src/fully_fused_mlp.cu:868-893, gpu_matrix.h:275-375   (likewise)
   kernel_mlp_fused / kernel_mlp_fused_backward + threadblock_*   src/fully_fused_mlp.cu:46-557 (through oracle/ref_shim/mma.h: nvcuda::wmma
                                                           for the host; a block's threads run as fibers).  Modelled, not the reference's:
                                                           the arithmetic inside ONE 16x16x16 tensor-core operation (mma.h says how)
@@ -283,6 +285,58 @@ def test_oneblob_encoding_bit_exact(d, n_bins):
     got_dx = np.zeros((n, d), np.float32)
     R.ref_oneblob_backward(n, d, int(np.log2(n_bins)), d * n_bins, p(dy), p(x), p(got_dx))
     assert np.array_equal(got_dx, want_dx)
+
+
+def test_offset_table_of_the_reference_constructor():
+    """GridEncodingTemplated's constructor (encodings/grid.h:673-737) compiled inside a stand-in for its class (oracle/ref_driver_host.cpp):
+    level sizes, offsets and n_params of the oracle's grid_init for every grid the other tests use, the bench's configurations, the
+    reference's own known-answer configuration (tests/test_grid.cu:55-71) and a sweep over scales / table sizes / types."""
+    R = ref()
+    cases = list(GRID_CASES) + [(3, 2, 20, 16, 32, 1.5, O.GRID_HASH, O.INTERP_LINEAR),       # tests/test_grid.cu:40-71
+                                (3, 2, 16, 22, 16, 1.5, O.GRID_HASH, O.INTERP_LINEAR),       # BASELINE configs[4]
+                                (2, 2, 16, 15, 16, 1.5, O.GRID_HASH, O.INTERP_LINEAR)]       # data/config_hash.json, the image sample
+    rng = np.random.default_rng(3)
+    for _ in range(60):
+        D, F = int(rng.integers(2, 5)), int(rng.choice([1, 2, 4, 8]))
+        cases.append((D, F, int(rng.integers(1, 24)), int(rng.integers(8, 23)), int(rng.integers(2, 40)), float(np.float32(rng.uniform(1.05, 2.2))),
+                      int(rng.choice([O.GRID_HASH, O.GRID_DENSE, O.GRID_TILED])), O.INTERP_LINEAR))
+    checked = 0
+    for D, F, L, T, base, pls, gtype, interp in cases:
+        offsets = (C.c_uint32 * 130)()
+        n_params = C.c_uint32(0)
+        r = R.ref_grid_offset_table(D, F, L, T, base, f32(pls), _ref_grid_type(gtype), offsets, C.byref(n_params))
+        assert r == L, (r, D, F, L, T, base, pls, gtype)
+        if n_params.value >= 1 << 31 or offsets[L] >= 1 << 30:
+            continue  # dense grids beyond what either side can allocate
+        g = O.grid_init(D, L, F, T, base, pls, gtype, interp)
+        assert [g.offsets[l] for l in range(L + 1)] == [offsets[l] for l in range(L + 1)], (D, F, L, T, base, pls, gtype)
+        assert g.n_params == n_params.value
+        checked += 1
+    assert checked > 40
+    offsets, n_params = (C.c_uint32 * 130)(), C.c_uint32(0)
+    assert R.ref_grid_offset_table(3, 2, 20, 16, 32, f32(1.5), 0, offsets, C.byref(n_params)) == 20
+    assert (offsets[1], offsets[2] - offsets[1], offsets[2], n_params.value) == (32768, 65536, 98304, 2555904)  # the reference's own constants
+    assert R.ref_grid_offset_table(3, 2, 129, 16, 32, f32(1.5), 0, offsets, C.byref(n_params)) == -2            # more than MAX_N_LEVELS: throws (grid.h:697-699)
+
+
+@pytest.mark.parametrize("shape", [(32, 64, 4, 2), (64, 64, 16, 2), (32, 128, 16, 4), (16, 16, 1, 1), (48, 32, 3, 5)])
+def test_network_initialisation_of_the_reference(shape):
+    """FullyFusedMLP::initialize_params (src/fully_fused_mlp.cu:868-893) with GPUMatrix::initialize_xavier_uniform (gpu_matrix.h:292-307)
+    compiled for the host: the matrices drawn, their order and ranges, and the generator state left behind for the encoding's draw
+    (network_with_input_encoding.h:124-130) -- bit for bit the oracle's mlp_init_params."""
+    R = ref()
+    IN, W, OUT, H = shape
+    m = O.mlp_init(IN, W, OUT, H)
+    for seed, scale in ((1337, 1.0), (7, 0.5)):
+        rng = O.pcg32(seed)
+        want = O.mlp_init_params(m, rng, scale)
+        state, inc = C.c_uint64(0), C.c_uint64(0)
+        R.ref_pcg32_seed(C.c_uint64(seed), C.byref(state), C.byref(inc))
+        got = np.zeros(m.n_params, np.float32)
+        assert R.ref_mlp_initialize_params(IN, W, m.padded_out, H, 0, C.byref(state), C.byref(inc), p(got), f32(scale)) == 0
+        assert np.array_equal(got, want)
+        assert (state.value, inc.value) == (rng.state, rng.inc)
+        assert got[W * IN + (H - 1) * W * W:].reshape(m.padded_out, W)[OUT:].any() == (OUT < m.padded_out)  # the padded output rows are drawn like the rest (fully_fused_mlp.cu:880)
 
 
 LOSSES = ["L2", "RelativeL2", "L1", "RelativeL1", "Mape", "Smape", "RelativeL2Luminance", "CrossEntropy", "Variance"]  # ref_loss's `which`

@@ -151,9 +151,12 @@ class _CpuTrainer:
             self._adam(b, e)
 
 
-def _rank_gradients(n, rank, step):
+def _rank_gradients(n, rank, step, world=2):
     rng = np.random.default_rng(100 * step + rank)
-    g = (rng.standard_normal(n) * 4).astype(np.float16)
+    if world > 2:  # more than two addends: multiples of 1/16 below 8, so that the fp16 sum is exact in ANY order a backend's ring takes
+        g = (rng.integers(-127, 128, n) / 16.0).astype(np.float16)
+    else:
+        g = (rng.standard_normal(n) * 4).astype(np.float16)
     g[rng.random(n) < 0.2] = 0
     return g
 
@@ -169,9 +172,9 @@ def _dp_worker(rank, world, port, n, mode, out_dir):
     assert dp.shard % 8 == 0 and dp.main <= n and n - dp.main < 8 * world
     for step in range(3):
         if mode.startswith("pipelined"):  # the collectives start from inside the backward pass, range by range
-            tm.backward_with(_rank_gradients(n, rank, step))
+            tm.backward_with(_rank_gradients(n, rank, step, world))
         else:
-            tm.param_gradients.copy_(torch.from_numpy(_rank_gradients(n, rank, step).view(np.int16)).view(torch.half))
+            tm.param_gradients.copy_(torch.from_numpy(_rank_gradients(n, rank, step, world).view(np.int16)).view(torch.half))
         dp.exchange_and_step()
     assert dp.comm_seconds() > 0
     own = dp.shard_range()
@@ -182,16 +185,17 @@ def _dp_worker(rank, world, port, n, mode, out_dir):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("mode", ["sharded", "allreduce", "pipelined", "pipelined_sharded"])
-def test_data_parallel_exchange_matches_single_process(tmp_path, mode):
-    n, world = 8 * 2 * 37 + 11, 2  # a tail of 11 parameters that no shard covers
+def test_data_parallel_exchange_matches_single_process(tmp_path, mode, world):
+    n = 8 * 2 * 37 + 11 if world == 2 else 8 * 4 * 19 + 29  # a tail of 11 (29) parameters that no shard covers
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_dp_worker, args=(world, port, n, mode, str(tmp_path)), nprocs=world, join=True)
     ref = _CpuTrainer(n)
     for step in range(3):
-        total = sum(_rank_gradients(n, r, step).astype(np.float32) for r in range(world))  # fp16 sum of two addends is exact up to one rounding
+        total = sum(_rank_gradients(n, r, step, world).astype(np.float32) for r in range(world))  # fp16 sum of two addends: exact up to one rounding; four: exact by construction
         ref.param_gradients.copy_(torch.from_numpy(total.astype(np.float16).view(np.int16)).view(torch.half))
         ref.optimizer_step()
     ranks = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
@@ -204,7 +208,7 @@ def test_data_parallel_exchange_matches_single_process(tmp_path, mode):
             b, e = d["own"]
             other = np.ones(n, bool)
             other[b:e] = False
-            other[(n // 16) * 16:] = False
+            other[(n // (8 * world)) * (8 * world):] = False
             assert np.array_equal(d["m1_before_gather"][b:e], ref.m1[b:e]) and not d["m1_before_gather"][other].any()
 
 

@@ -175,6 +175,47 @@ def test_register_resident_kernels_do_not_spill(tmp_path):
         assert not bad, (build, bad)
 
 
+def test_headline_kernels_keep_the_occupancy_design_md_states(tmp_path):
+    """The register / LDS budgets DESIGN.md argues from, read out of the SHIPPED library's code object (llvm-readelf --notes): the tiled
+    gather at <= 64 registers (8 waves per SIMD: its 16 corner loads per lane are what hides the L2 latency), the record scatter at <= 96,
+    the owner pass at <= 128 registers with a 64 KiB table (two 512-thread workgroups per CU: one streams while the other clears or
+    converts), the register-resident network kernel within 256 (two waves per SIMD) and 64 KiB of LDS.  A compiler bump that crosses one
+    of these changes the step time without failing any numerics test."""
+    import re
+    import shutil
+    import subprocess
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(tools, "llvm-readelf")) or not os.path.exists(os.path.join(tools, "llvm-objdump")):
+        pytest.skip("no llvm-readelf / llvm-objdump")
+    lib = shutil.copy(os.path.join(ROOT, "tiny-cuda-nn_amd", "lib", "libtcnn_hip.so"), str(tmp_path / "libtcnn_hip.so"))  # --offloading extracts next to its input
+    subprocess.run([os.path.join(tools, "llvm-objdump"), "--offloading", lib], capture_output=True, text=True, check=True, cwd=str(tmp_path))
+    kernels = {}
+    for f in sorted(os.listdir(str(tmp_path))):
+        if "gfx950" not in f:
+            continue
+        notes = subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", str(tmp_path / f)], capture_output=True, text=True, check=True).stdout
+        for block in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", block).group(1)
+            kernels[name] = {"vgpr": int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1)), "agpr": int(re.match(r"\s*(\d+)", block).group(1)),
+                             "lds": int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", block).group(1)),
+                             "spill": int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1))}
+    assert len(kernels) > 100
+
+    def one(fragment):
+        hits = {k: v for k, v in kernels.items() if fragment in k}
+        assert hits, fragment
+        return hits
+
+    for name, k in one("k_grid_forward_tilesILj3ELj2ELj2E").items():
+        assert k["vgpr"] <= 64 and k["lds"] == 0 and k["spill"] == 0, (name, k)
+    for name, k in one("k_grid_bucket_scatterILj3ELj2E").items():
+        assert k["vgpr"] <= 96 and k["spill"] == 0, (name, k)
+    for name, k in one("k_grid_bucket_ownerILj3ELj2E").items():
+        assert k["vgpr"] <= 128 and k["spill"] == 0, (name, k)
+    for name, k in one("k_mlp_train_waveILj64ELj32ELj1ELb0E").items():  # the headline network: loss and external-gradient instances
+        assert k["vgpr"] + k["agpr"] <= 256 and k["lds"] <= 64 * 1024 and k["spill"] == 0, (name, k)
+
+
 @pytest.mark.parametrize("build", [[], ["-DTCNN_BF16"]], ids=["fp16", "bf16"])
 def test_no_mfma_result_is_read_too_soon_after_a_taken_branch(tmp_path, build):
     """hipcc pads the wait states an MFMA result needs in straight-line code but can miss them on a path that leaves the MFMA

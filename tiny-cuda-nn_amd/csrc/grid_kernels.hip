@@ -1291,8 +1291,45 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 	if (safe && !(diag_owner & 1u)) {
 		for (uint32_t e = threadIdx.x; e < slice_count * PW / 2; e += THREADS) ((u4*)lds_raw)[e] = u4{0u, 0u, 0u, 0u};  // slice_count is a multiple of 8
 	}
-	uint32_t first_round[STREAM_U][PWP];
-	load_round(threadIdx.x, cap - 1u, first_round);
+	// Three-word records (F <= 2) on the GPU: the stream is PIPELINED BY HAND, two half-rounds of STREAM_U / 2 records per lane that are
+	// consumed and re-requested in turn -- while the records of one half go through the conversions and LDS atomics (45 VALU
+	// instructions each; the four waves of a SIMD all want the ALU when their loads arrive), the other half's loads are on their
+	// way.  Written in C++ the compiler rotates the record registers (copies at the loop's back edge) and waits for the loads it
+	// has just issued before it copies them (tried twice, profiles/r03_exp_notes.txt 10b, r04_exp_notes.txt): hence loads the
+	// compiler does not see (asm), into registers that keep their identity, with counted waits.  vmcnt counts in issue order, so
+	// "at most 4 outstanding" means the OLDER half has landed whatever the compiler's own loads do around it.
+#if !defined(TCNN_HOST_EMU) && !defined(TCNN_OWNER_PLAIN_STREAM)
+	constexpr bool PIPELINED = PWP == 3 && STREAM_U == 8;
+#else
+	constexpr bool PIPELINED = false;
+#endif
+	typedef uint32_t rec3_t __attribute__((ext_vector_type(3)));
+	rec3_t half_a[4], half_b[4];
+	uint32_t first_round[PIPELINED ? 1 : STREAM_U][PWP];
+#if !defined(TCNN_HOST_EMU)
+	const uint64_t q_address = (uint64_t)(uintptr_t)q;  // wave-uniform: into a scalar register pair, the loads' base
+	// (readfirstlane returns a signed int: without the casts the low word is sign-extended over the high one)
+	const uint64_t q_scalar = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(q_address >> 32)) << 32) |
+	                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)q_address);
+	auto issue_half = [&](rec3_t (&h)[4], uint32_t first, uint32_t last) {
+#pragma unroll
+		for (uint32_t u = 0; u < 4; ++u) {
+			const uint32_t byte_offset = __umul24(min(first + u * THREADS, last), 12u);  // record index < 2^24: a queue holds < 2^31 records of < 2^32 bytes, see the check below
+			asm volatile("global_load_dwordx3 %0, %1, %2 nt" : "=v"(h[u]) : "v"(byte_offset), "s"(q_scalar) : "memory");
+		}
+	};
+	auto await_older_half = [&](rec3_t (&h)[4]) { asm volatile("s_waitcnt vmcnt(4)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3])::"memory"); };
+#endif
+	if constexpr (PIPELINED) {
+#if !defined(TCNN_HOST_EMU)
+		if (safe) {  // (only the packed pass consumes them -- and nothing the compiler does not know of may stay in flight otherwise)
+			issue_half(half_a, threadIdx.x, cap - 1u);
+			issue_half(half_b, threadIdx.x + 4u * THREADS, cap - 1u);
+		}
+#endif
+	} else {
+		load_round(threadIdx.x, cap - 1u, first_round);
+	}
 
 	// streams the queue (and this slice's share of the overflow list) through `add(index, payload)`; `first`: the lane's first
 	// round if it is in registers already (the first pass over the queue), null to load it here (the 64-bit redo)
@@ -1331,6 +1368,38 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 			}
 		}
 	};
+	// the same through the hand-pipelined halves (first pass over the queue only; its first two halves were requested above)
+	auto stream_pipelined = [&](auto&& add) {
+#if !defined(TCNN_HOST_EMU)
+		auto add_half = [&](uint32_t first, const rec3_t (&h)[4]) {
+#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u) {
+				if (first + u * THREADS >= count) continue;
+				const uint32_t rec[3] = {h[u][0], h[u][1], h[u][2]};
+				add(rec[0] & PAIR_INDEX_MASK, &rec[1]);
+				if (rec[0] & PAIR_HAS_SECOND) add(pair_second_index<D>(lv, rec[0]), &rec[1 + PW]);
+			}
+		};
+		const uint32_t last = count ? count - 1u : 0u;
+		for (uint32_t round = 0; round < count; round += 8u * THREADS) {  // workgroup-uniform trip count: every wave issues the same loads
+			const uint32_t first = round + threadIdx.x;
+			await_older_half(half_a);
+			add_half(first, half_a);
+			issue_half(half_a, first + 8u * THREADS, last);
+			await_older_half(half_b);
+			add_half(first + 4u * THREADS, half_b);
+			issue_half(half_b, first + 12u * THREADS, last);
+		}
+		// nothing of this lane's may still be on its way into registers the compiler is about to reuse
+		asm volatile("s_waitcnt vmcnt(0)" : "+v"(half_a[0]), "+v"(half_a[1]), "+v"(half_a[2]), "+v"(half_a[3]), "+v"(half_b[0]), "+v"(half_b[1]), "+v"(half_b[2]), "+v"(half_b[3])::"memory");
+#endif
+		if (inline_overflow && chunk == 0u) {
+			for (uint32_t t = threadIdx.x; t < n_over; t += THREADS) {
+				const uint32_t* rec = overflow + (size_t)t * OW;
+				if (rec[0] == level && (rec[1] >> plan.shift) == bucket) add(rec[1], rec + 2);
+			}
+		}
+	};
 	// one gradient pair leaves the slice: plain store for a sole owner, a packed atomic where sample chunks share the slice
 	auto store_pair = [&](uint32_t e2, h2 v) {
 		if (n_chunks == 1) {
@@ -1356,7 +1425,7 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 		float bound[F];
 #pragma unroll
 		for (uint32_t f = 0; f < F; ++f) bound[f] = 0.0f;
-		stream(first_round, [&](uint32_t index, const uint32_t* payload) {
+		auto add_packed = [&](uint32_t index, const uint32_t* payload) {
 			const uint32_t rel = index & (entries_per_bucket - 1u);
 #pragma unroll
 			for (uint32_t p = 0; p < PW; ++p) {
@@ -1368,7 +1437,9 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 				const unsigned long long x = ((unsigned long long)(uint32_t)(v1 + (v0 >> 31)) << 32) | (unsigned long long)(uint32_t)v0;
 				if (!(diag_owner & 2u) || x == 0x123456789ull) lds_atomic_add_u64(&tab[rel * PW + p], x);
 			}
-		});
+		};
+		if constexpr (PIPELINED) stream_pipelined(add_packed);
+		else stream(first_round, add_packed);
 		// the bound over the whole workgroup (NaN / Inf anywhere fail the comparison)
 #pragma unroll
 		for (uint32_t f = 0; f < F; ++f) {
@@ -1920,7 +1991,9 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 			const uint64_t level_pairs = (uint64_t)n * std::max(1u, n_corners / 2u);  // queue unit: a pair of records
 			const uint64_t expected = level_pairs / ((uint64_t)n_buckets * n_chunks);
 			const uint64_t capacity = next_multiple<uint64_t>(2 * expected + 512, 64);
-			if (capacity > 0x7FFFFFFFull) throw std::runtime_error("grid_backward: batch too large for the bucketed backward");
+			// (queue positions are multiplied with 24-bit multiplies in the owner pass; the 2^32 records checked below come first for every
+			// table with more than a few buckets, and small tables are chunked to ~32 Ki records per queue)
+			if (capacity >= (1ull << 24)) throw std::runtime_error("grid_backward: batch too large for the bucketed backward");
 			bk.level[j] = (uint8_t)l;
 			bk.n_buckets[j] = n_buckets;
 			bk.n_chunks[j] = n_chunks;

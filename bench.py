@@ -6,9 +6,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-One step = trainer.training_step (grid forward -> fused MLP forward -> RelativeL2 loss -> fused MLP backward
-incl. weight gradients -> grid backward scatter -> Adam) on one batch of synthetic 3-D -> 4 samples that is
-already resident in HBM (positions drawn by the library's pcg32 kernel, seed 1337 + rank).
+One step = the reference's own benchmark step (samples/mlp_learning_an_image.cu:263-271, benchmarks/image/bench_ours.cu:249-254):
+DRAW a batch of positions on the device (the library's pcg32 kernel, random.h:39-75, seed 1337 + rank), EVALUATE the regression target
+at them on the device, then trainer.training_step (grid forward -> fused MLP forward -> RelativeL2 loss -> fused MLP backward incl.
+weight gradients -> grid backward scatter -> Adam) on that batch of synthetic 3-D -> 4 samples -- all of it inside the timed region
+(`protocol` in the line says so; --no-regenerate rotates four batches that are already resident in HBM instead, and the default run
+reports that figure as well, as `value_resident`, from a second timed region of the same length).
 For N > 1 every rank trains on its own shard -- 2^18 samples each (weak scaling, the default) or 2^18 / N
 (strong scaling) -- loss gradients are normalised by the global batch, and the fp16 gradient buffer [MLP | grid]
 is exchanged over RCCL/xGMI between backward and the optimizer step (tinycudann/parallel.py: reduce-scatter ->
@@ -25,6 +28,8 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
                   against the 8 TB/s HBM peak; `stages` holds the same figure for EVERY stage, from the instrumented pass;
   cpu_baseline -- the CPU oracle ("port": the reference has no CPU path and cannot be built here) timed on
                   this box's host cores on the same workload and the same first batch (rank 0, --gpus 1 only);
+  inference    -- network->inference (object.h:214-271) on the same batch: calls/s, samples/s and its own roofline (540 B/sample
+                  algorithmic at the headline shape), timed with events on the stream the calls run on, outside the timed region;
   stages_ms    -- per-stage mean times of a separate, fully instrumented pass of min(steps, 50) untimed steps (not part of `value`).
                   It runs BEFORE the warm-up steps (--breakdown before, the default; `untimed_steps_before_timing` says so in the
                   line): the first ~30 steps after an idle phase run 4-8 % below the device's steady state (clocks; measured,
@@ -32,8 +37,10 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
 
 With --gpus 1 (no torch.distributed launcher) the measurement runs in a worker process and this process only relays its line:
 a worker that dies abnormally (a GPU memory-access fault aborts the process inside the HIP runtime, nothing can be caught
-in-process) is reported under `faulted_attempts` and the measurement is repeated, at most twice -- `attempts` says how many
-workers it took.  Every number in the line comes from ONE complete worker run.
+in-process) is reported under `faulted_attempts`, the command is run ONCE more under the library's checking switches
+(TCNN_DEBUG_SYNC / TCNN_DEBUG_TRACE / TCNN_DEBUG_ALLOC=fence) to name the kernel, and the measurement is repeated, at most twice.
+A retry is not a success: the line of the good attempt is still printed (every number in it comes from ONE complete worker run),
+but it carries `"faulted": true` and the process exits with status 3.
 """
 import argparse
 import json
@@ -134,17 +141,10 @@ def network_flops_per_sample(w):
     return 3 * 2 * (enc_w * W + (H - 1) * W * W + W * OUTP)
 
 
-def make_targets(x, n_out):
-    """Smooth analytic n_in-D -> n_out function (sinusoid products of frequencies 1..)."""
-    d = x.shape[1]
-    return torch.stack([0.5 + 0.5 * torch.sin(2 * np.pi * (c % 4 + 1) * x[:, 0]) * torch.cos(2 * np.pi * (c % 4 + 1) * x[:, 1 % d]) * torch.sin(2 * np.pi * x[:, 2 % d] + c)
-                        for c in range(n_out)], dim=1).contiguous()
-
-
-def make_batches(w, n, n_batches, seed, device, tcnn):
+def make_batches(w, n, n_batches, rng, device, tcnn):
     """Synthetic regression data: U[0,1)^n_in positions from the library's pcg32 kernel (random.h:39-75, seed 1337 + rank), smooth
-    analytic targets; the `mlp` workload regresses against zero (benchmarks/mlp: L2 vs zero target)."""
-    rng = tcnn._C.Pcg32(seed)
+    analytic targets (sinusoid products of frequencies 1..4; tcnn_generate_sinusoid_targets -- the same kernel that
+    evaluates them inside the timed steps); the `mlp` workload regresses against zero (benchmarks/mlp: L2 vs zero target)."""
     # under the checking allocator (TCNN_DEBUG_ALLOC) the batches live in its blocks too: a kernel that reads past the end of
     # the positions or targets then faults instead of reading whatever torch's pool holds behind them
     checked = tcnn._C.debug_alloc_mode() != 0
@@ -153,7 +153,10 @@ def make_batches(w, n, n_batches, seed, device, tcnn):
     for _ in range(n_batches):
         x = rng.uniform_(new((n, w["n_in"])))
         t = new((n, w["n_out"]))
-        t.copy_(torch.zeros((n, w["n_out"]), device=device) if w is WORKLOADS["mlp"] else make_targets(x, w["n_out"]))
+        if w is WORKLOADS["mlp"]:
+            t.zero_()
+        else:
+            tcnn._C.sinusoid_targets_(x, t)
         out.append((x, t))
     return out
 
@@ -212,6 +215,7 @@ def cpu_baseline(w, x, t, budget_s=12.0, bf16=False):
 def supervise(argv, max_attempts=3):
     """Single-GPU runs: the measurement happens in a worker process (this file with --worker); see the module docstring."""
     faulted = []
+    diagnosed = False
     for attempt in range(1, max_attempts + 1):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), *argv, "--worker"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         sys.stderr.write(r.stderr)
@@ -219,16 +223,23 @@ def supervise(argv, max_attempts=3):
         if r.returncode == 0 and lines:
             line = json.loads(lines[-1])
             line["attempts"] = attempt
+            line["faulted"] = bool(faulted)
             if faulted:
                 line["faulted_attempts"] = faulted
             print(json.dumps(line))
-            return 0
+            return 3 if faulted else 0  # a measurement that needed a retry is reported, and NOT reported as a clean run
         sys.stdout.write(r.stdout)
         faulted.append({"attempt": attempt, "returncode": r.returncode, "stderr_tail": r.stderr[-600:]})
         # an ordinary failure (bad arguments, missing library, failed assertion) is not worth repeating: only abnormal deaths are
         if r.returncode >= 0 and "Memory access fault" not in r.stderr:
             break
-    print(json.dumps({"error": "bench worker failed", "faulted_attempts": faulted}), file=sys.stderr)
+        if not diagnosed:  # once: the same command with every launch synchronised and traced and every device block fenced -> names the kernel
+            diagnosed = True
+            env = dict(os.environ, TCNN_DEBUG_SYNC="1", TCNN_DEBUG_TRACE="1", TCNN_DEBUG_ALLOC="fence")
+            d = subprocess.run([sys.executable, os.path.abspath(__file__), *argv, "--worker", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+            faulted[-1]["diagnostic_rerun"] = {"env": "TCNN_DEBUG_SYNC=1 TCNN_DEBUG_TRACE=1 TCNN_DEBUG_ALLOC=fence", "returncode": d.returncode, "stderr_tail": d.stderr[-1500:]}
+            sys.stderr.write("[bench] diagnostic rerun of the faulted command (synchronised, traced launches; fenced allocations):\n" + d.stderr[-3000:] + "\n")
+    print(json.dumps({"error": "bench worker failed", "faulted": True, "faulted_attempts": faulted}), file=sys.stderr)
     return faulted[-1]["returncode"] or 1
 
 
@@ -244,6 +255,11 @@ def main():
                     help="N > 1: gradient exchange (tinycudann/parallel.py); pipelined*: collectives started from inside the backward pass, per level group")
     ap.add_argument("--level-groups", type=int, default=2, help="pipelined exchanges: level groups of the encoding's backward pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--regenerate", dest="regenerate", action="store_true", default=None,
+                    help="draw the positions (pcg32) and evaluate the targets on the device inside EVERY timed step, as the reference's sample does "
+                         "(default for the hash and stress workloads; the mlp workload follows benchmarks/mlp, whose input is generated once)")
+    ap.add_argument("--no-regenerate", dest="regenerate", action="store_false", help="rotate four batches that are resident in HBM (the figure the default run reports as value_resident)")
+    ap.add_argument("--no-inference", action="store_true", help="skip the network->inference leg")
     ap.add_argument("--breakdown", choices=["before", "after"], default="before",
                     help="the fully instrumented per-stage pass (min(steps, 50) untimed steps) runs before the warm-up steps (default) or after the timed region")
     ap.add_argument("--dominant", default="fixed", help="stage timed with HIP events inside the timed region (fixed: the workload's dominant kernel per rocprof, see DOMINANT; auto: the slowest stage of a short probe pass)")
@@ -283,10 +299,20 @@ def main():
     if world > 1:
         tm.set_global_batch_size(global_batch)
         dp = par.DataParallel(tm, mode=args.dp, level_groups=args.level_groups)
-    batches = make_batches(w, local_batch, 4, seed=1337 + rank, device=device, tcnn=tcnn)
+    regenerate = (args.workload != "mlp") if args.regenerate is None else args.regenerate
+    rng = tcnn._C.Pcg32(1337 + rank)
+    batches = make_batches(w, local_batch, 4, rng, device=device, tcnn=tcnn)
+    fresh = make_batches(w, local_batch, 1, rng, device=device, tcnn=tcnn)[0]  # the buffers a regenerated batch is drawn into
+    mode = {"regenerate": regenerate}
 
     def step(i):
-        x, t = batches[i % len(batches)]
+        if mode["regenerate"]:  # samples/mlp_learning_an_image.cu:263-271: generate_random_uniform(batch), evaluate the target at it, training_step
+            x, t = fresh
+            rng.uniform_(x)
+            if args.workload != "mlp":
+                tcnn._C.sinusoid_targets_(x, t)
+        else:
+            x, t = batches[i % len(batches)]
         if dp is not None:
             tm.training_step(x, t, run_optimizer=False, want_context=False)
             dp.exchange_and_step()
@@ -344,6 +370,46 @@ def main():
     dom_ms, dom_cnt = tm.stage_times()[dominant]
     comm = dp.comm_seconds() if dp is not None else None
 
+    # ---- the same number of steps once more on batches that are resident in HBM (round 1-3's protocol): `value_resident` -------------
+    elapsed_resident = None
+    if regenerate:
+        mode["regenerate"] = False
+        tm.set_profiling(False)
+        for i in range(min(args.warmup, 10)):
+            step(i)
+        par.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        par.barrier()
+        elapsed_resident = par.all_reduce_max(time.perf_counter() - t0, device=device)
+        mode["regenerate"] = True
+
+    # ---- network->inference on the same batch (north_star names it; the reference publishes inference curves, README.md:7-8) ----------
+    inference = None
+    if not args.no_inference:
+        x0 = batches[0][0]
+        out0 = torch.empty((local_batch, w["n_out"]), dtype=torch.float32, device=device)
+        for _ in range(5):
+            tm.inference(x0, out0)
+        n_inf = max(10, min(args.steps, 200))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)  # tm.inference runs on torch's current stream
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n_inf):
+            tm.inference(x0, out0)
+        e1.record()
+        e1.synchronize()
+        inf_ms = e0.elapsed_time(e1) / n_inf
+        is_grid = w["config"]["encoding"]["otype"] == "HashGrid"
+        inf_bytes = local_batch * (4 * w["n_in"] + (16 * (1 << w["n_in"]) * 2 * 2 if is_grid else 0) + 4 * w["n_out"])  # 4 D_in + L 2^D F 2 + 4 D_out
+        inference = {"samples_per_s": local_batch / (inf_ms * 1e-3), "ms_per_call": inf_ms, "calls_timed": n_inf, "batch": local_batch,
+                     "what": "tcnn_network_inference (encoding forward -> fused MLP inference kernel -> trim + cast to fp32), HIP events on the calls' stream",
+                     "roofline": {"bound": "hbm", "algorithmic_bytes_per_call": inf_bytes, "achieved": inf_bytes / (inf_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                                  "unit": "GB/s", "frac": inf_bytes / (inf_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+
     if stages is None:  # --breakdown after: the instrumented pass follows the timed region
         stages, _ = breakdown_pass()
     tm.set_profiling(False)
@@ -351,6 +417,8 @@ def main():
     # sanity: the run must have trained (loss finite and below the initial loss)
     ctx = tm.training_step(*batches[0], run_optimizer=False)
     final_loss = tm.loss(ctx)
+    # parameters whose gradient is non-zero after one batch: the ones Adam steps (the others cost it 2 bytes, adam.h:79-82)
+    touched = int(torch.count_nonzero(tm.param_gradients).item())
     if tcnn._C.debug_alloc_mode() != 0:
         tcnn._C.debug_check_allocations()  # raises if any block of the checking allocator was written out of bounds
 
@@ -358,6 +426,11 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = global_batch * args.steps / elapsed
         ab = algorithmic_bytes(w, local_batch, tm.n_params, tm.n_mlp_params)
+        adam_dense = ab["adam"]
+        # Adam's algorithmic bytes from the parameters it actually steps: 36 B each, 2 B (the gradient read) for a skipped one.  The dense
+        # figure (SURVEY 8d's upper bound) overstates the rate wherever a batch leaves table entries untouched (T = 2^22: most of them)
+        ab["adam"] = touched * 36 + (tm.n_params - touched) * 2
+        ab["step_ideal"] += ab["adam"] - adam_dense
         dom_avg_s = dom_ms / max(dom_cnt, 1) * 1e-3
         achieved = ab[dominant] / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
         traffic, traffic_source = None, None
@@ -389,12 +462,22 @@ def main():
             "config": {"workload": w["describe"], "batch_per_gpu": local_batch, "global_batch": global_batch, "n_params": tm.n_params,
                        "parallelism": f"dp{world} ({args.dp})" if world > 1 else "single"},
             "roofline": roofline,
+            "protocol": {"batches": ("regenerated inside every timed step: positions drawn with the library's pcg32 kernel, targets evaluated at them on the device, then "
+                                     "training_step (samples/mlp_learning_an_image.cu:263-271)") if regenerate else "four batches resident in HBM, rotated",
+                         "regenerate": regenerate, "timed_steps": args.steps,
+                         "adam_touched_parameters": touched, "adam_touched_fraction": touched / tm.n_params,
+                         "adam_algorithmic_bytes": {"touched": ab["adam"], "dense_upper_bound": adam_dense}},
             "stages_ms": stages,
             "untimed_steps_before_timing": {"breakdown_pass": n_breakdown, "warmup": args.warmup},
             "step_ideal_GBps": ab["step_ideal"] / (elapsed / args.steps) / 1e9,
             "final_loss": final_loss,
             "grid_owner_wide_slices": tcnn._C.grid_owner_wide_slices(),  # slices of the grid backward redone with 64-bit accumulators in this process (perf only)
         }
+        if elapsed_resident is not None:
+            line["value_resident"] = global_batch * args.steps / elapsed_resident
+            line["ms_per_step_resident"] = elapsed_resident / args.steps * 1e3
+        if inference is not None:
+            line["inference"] = inference
         if comm is not None:
             line["comm"] = {"seconds_per_step": comm / args.steps, "share_of_step": comm / elapsed,
                             "note": "GPU event intervals of rank 0 around the exchange: the collectives AND, in the sharded scheme, the optimizer step on the rank's shard that sits between them"}

@@ -186,12 +186,24 @@ int tcnn_trainer_training_step_matrices(tcnn_trainable_model_t* tm, tcnn_stream_
                                         int gradient_mode, const tcnn_matrix_t* external_dL_dy, tcnn_train_context_t** ctx_out);
 int tcnn_network_inference_matrices(tcnn_trainable_model_t* tm, tcnn_stream_t stream, const tcnn_matrix_t* input, const tcnn_matrix_t* output,
                                     int use_inference_params);
+/* Trainer::forward / Trainer::backward (trainer.h:97-148) the same way: `input` and `dL_dinput` of either layout. */
+int tcnn_trainer_forward_matrices(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale, const tcnn_matrix_t* input, const tcnn_matrix_t* target,
+                                  const tcnn_matrix_t* data_pdf, int use_inference_params, int prepare_input_gradients, const tcnn_matrix_t* external_dL_dy,
+                                  tcnn_train_context_t** ctx_out);
+int tcnn_trainer_backward_matrices(tcnn_trainable_model_t* tm, tcnn_stream_t stream, const tcnn_train_context_t* ctx, const tcnn_matrix_t* input,
+                                   const tcnn_matrix_t* dL_dinput, int use_inference_params, int gradient_mode);
 
 /* generate_random_uniform<float>(stream, rng, n, out, lower, upper) with `default_rng_t rng{seed}` (random.h:39-75,
  * pcg32.h:40-170): out[0..n) = U[lower, upper) from the pcg32 stream of `seed`, starting `*position` draws into it;
  * `*position` is advanced by n (what the reference's `rng.advance(n)` does), so successive calls continue one stream.
  * The synthetic inputs of samples/ and bench.py come from here (pcg32 seed 1337). */
 int tcnn_generate_random_uniform(tcnn_stream_t stream, uint64_t seed, uint64_t* position, size_t n, float* out, float lower, float upper);
+
+/* The regression target of the synthetic workloads (no reference counterpart in the library; the reference's sample evaluates its target
+ * on the device inside the training loop, samples/mlp_learning_an_image.cu:263-271 `eval_image`): targets[i][c] = 0.5 + 0.5 sin(2 pi f x0)
+ * cos(2 pi f x1) sin(2 pi x2 + c), f = c % 4 + 1, for sample-major positions [n][n_input_dims] -> [n][n_output_dims].  bench.py draws
+ * a batch with tcnn_generate_random_uniform and evaluates this inside every timed step. */
+int tcnn_generate_sinusoid_targets(tcnn_stream_t stream, uint32_t n, uint32_t n_input_dims, uint32_t n_output_dims, const float* positions, float* targets);
 
 /* Data parallelism (no reference counterpart; the reference is single-GPU).
  * Loss gradients are normalised by global_batch_size * n_output_dims instead of the local batch, so the

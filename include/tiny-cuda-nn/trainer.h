@@ -65,22 +65,25 @@ public:
 		return training_step(nullptr, input, target, data_pdf, run_optimizer, dL_dinput, use_inference_params, param_gradients_mode, external_dL_dy);
 	}
 
-	// trainer.h:97-140: dense column-major matrices (the C ABI's plain entry points)
+	// trainer.h:97-148: `input` / `dL_dinput` are GPUMatrixDynamic of either layout, as in the reference
 	std::unique_ptr<ForwardContext> forward(hipStream_t stream, const float loss_scale, const GPUMatrixDynamic<T>& input, const GPUMatrix<float>& target,
 	                                         const GPUMatrix<float>* data_pdf = nullptr, bool use_inference_params = false, bool prepare_input_gradients = false,
 	                                         const GPUMatrix<COMPUTE_T>* external_dL_dy = nullptr) {
-		require_dense_cm(input, "forward: input");
 		auto out = new_context(input.n());
-		check(tcnn_trainer_forward(m_h->tm, stream, loss_scale, input.n(), input.data(), target.data(), data_pdf ? data_pdf->data() : nullptr, use_inference_params,
-		                           prepare_input_gradients, external_dL_dy ? external_dL_dy->data() : nullptr, &out->ctx));
+		const tcnn_matrix_t in = input.c_matrix(), tg = target.c_matrix();
+		tcnn_matrix_t pdf{}, ext{};
+		if (data_pdf) pdf = data_pdf->c_matrix();
+		if (external_dL_dy) ext = external_dL_dy->c_matrix();
+		check(tcnn_trainer_forward_matrices(m_h->tm, stream, loss_scale, &in, &tg, data_pdf ? &pdf : nullptr, use_inference_params, prepare_input_gradients,
+		                                    external_dL_dy ? &ext : nullptr, &out->ctx));
 		return out;
 	}
 	void backward(hipStream_t stream, const ForwardContext& ctx, const GPUMatrixDynamic<T>& input, GPUMatrixDynamic<T>* dL_dinput = nullptr,
 	              bool use_inference_params = false, GradientMode param_gradients_mode = GradientMode::Overwrite) {
-		require_dense_cm(input, "backward: input");
-		if (dL_dinput) require_dense_cm(*dL_dinput, "backward: dL_dinput");
-		check(tcnn_trainer_backward(m_h->tm, stream, ctx.ctx, input.n(), input.data(), dL_dinput ? dL_dinput->data() : nullptr, use_inference_params,
-		                            static_cast<int>(param_gradients_mode)));
+		const tcnn_matrix_t in = input.c_matrix();
+		tcnn_matrix_t dx{};
+		if (dL_dinput) dx = dL_dinput->c_matrix();
+		check(tcnn_trainer_backward_matrices(m_h->tm, stream, ctx.ctx, &in, dL_dinput ? &dx : nullptr, use_inference_params, static_cast<int>(param_gradients_mode)));
 	}
 	void optimizer_step(hipStream_t stream, float loss_scale) { check(tcnn_trainer_optimizer_step(m_h->tm, stream, loss_scale)); }  // trainer.h:150-152
 	void optimizer_step(float loss_scale) { optimizer_step(nullptr, loss_scale); }
@@ -101,15 +104,25 @@ public:
 	void set_params(const PARAMS_T* params, size_t n_params, bool device_ptr = false) { check(tcnn_trainer_set_params(m_h->tm, params, n_params, device_ptr)); }
 	void update_hyperparams(const json& params) { check(tcnn_trainer_update_hyperparams(m_h->tm, json_text(params).c_str())); }
 	json hyperparams() const { return json::parse(std::string(tcnn_trainer_hyperparams_json(m_h->tm))); }
-	// trainer.h:442-481: the MessagePack bytes of the reference's snapshot document (json::to_msgpack of serialize())
-	std::vector<uint8_t> serialize(bool serialize_optimizer = false) const {
+	// trainer.h:442-481.  The snapshot crosses the C ABI as the MessagePack bytes of the reference's snapshot document
+	// (json::to_msgpack of the reference's serialize()): serialize_msgpack / deserialize_msgpack in every build; with nlohmann::json
+	// present serialize() returns the document itself and deserialize() takes it, exactly as the reference's members do, otherwise
+	// (the bundled json_mini.h has no binary values) they are the byte forms.
+	std::vector<uint8_t> serialize_msgpack(bool serialize_optimizer = false) const {
 		size_t n = 0;
 		check(tcnn_trainer_serialize(m_h->tm, serialize_optimizer, nullptr, 0, &n));
 		std::vector<uint8_t> blob(n);
 		check(tcnn_trainer_serialize(m_h->tm, serialize_optimizer, blob.data(), blob.size(), &n));
 		return blob;
 	}
-	void deserialize(const std::vector<uint8_t>& blob) { check(tcnn_trainer_deserialize(m_h->tm, blob.data(), blob.size())); }
+	void deserialize_msgpack(const std::vector<uint8_t>& blob) { check(tcnn_trainer_deserialize(m_h->tm, blob.data(), blob.size())); }
+#if defined(TCNN_HAS_NLOHMANN_JSON)
+	json serialize(bool serialize_optimizer = false) const { return json::from_msgpack(serialize_msgpack(serialize_optimizer)); }
+	void deserialize(const json& data) { deserialize_msgpack(json::to_msgpack(data)); }
+#else
+	std::vector<uint8_t> serialize(bool serialize_optimizer = false) const { return serialize_msgpack(serialize_optimizer); }
+#endif
+	void deserialize(const std::vector<uint8_t>& blob) { deserialize_msgpack(blob); }
 
 	std::shared_ptr<NetworkWithInputEncoding<PARAMS_T>> model() const { return m_model; }
 	std::shared_ptr<Optimizer<PARAMS_T>> optimizer() const { return m_optimizer; }
@@ -131,9 +144,6 @@ private:
 		out->padded_output_width = tcnn_trainer_padded_output_width(m_h->tm);
 		out->batch_size = batch_size;
 		return out;
-	}
-	static void require_dense_cm(const GPUMatrixDynamic<T>& m, const char* what) {
-		if (m.layout() != CM || !m.is_contiguous()) throw std::runtime_error(std::string(what) + " must be a dense column-major matrix (use training_step for other layouts)");
 	}
 	std::shared_ptr<NetworkWithInputEncoding<PARAMS_T>> m_model;
 	std::shared_ptr<Optimizer<PARAMS_T>> m_optimizer;

@@ -61,7 +61,7 @@ int main(int argc, char** argv) {
 		std::printf("inference mse=%g\n", mse);
 
 		// snapshot -> fresh model -> identical inference
-		const std::vector<uint8_t> snapshot = model.trainer->serialize(true);
+		const auto snapshot = model.trainer->serialize(true);  // the snapshot document (nlohmann::json present) or its MessagePack bytes
 		auto restored = tcnn::create_from_config(n_input_dims, n_output_dims, CONFIG, /*seed=*/7);
 		restored.trainer->deserialize(snapshot);
 		tcnn::GPUMatrix<float> prediction2(n_output_dims, batch_size);

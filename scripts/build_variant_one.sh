@@ -4,6 +4,7 @@
 # Run a process against it with TCNN_HIP_LIBRARY=tiny-cuda-nn_amd/lib/variants/NAME.so
 set -e
 NAME=$1; FILE=$2; DEFS=$3
+case "$DEFS" in *TCNN_EXP_*) DEFS="-DTCNN_EXPERIMENT $DEFS";; esac  # csrc/exp_diag.h: a switch without the flag does not compile
 ROOT=$(cd $(dirname $0)/.. && pwd)
 OBJ=/tmp/tcnn_variant_$NAME; mkdir -p $OBJ $ROOT/tiny-cuda-nn_amd/lib/variants
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-function $DEFS -c $ROOT/tiny-cuda-nn_amd/csrc/$FILE.hip -o $OBJ/$FILE.o

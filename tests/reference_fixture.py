@@ -8,7 +8,8 @@ kernels in the MFMA's fp32 accumulators, so the comparison is a tolerance, state
     measured on the emulator   output 6.1e-4 / 7.5e-4, weight gradients 6.7e-3 / 8.0e-3, dL/dinput 1.2e-2
     (the gradients inherit the handful of ReLU masks that differ where a hidden value is a tiny positive number in one
     implementation and zero in the other)
-    bars                       output 5e-3, weight gradients 4e-2, dL/dinput 5e-2
+    bars (2 x the measured values: a regression that doubles an error fails)
+                               output 1.5e-3, weight gradients 1.6e-2, dL/dinput 2.4e-2
 """
 import os
 
@@ -16,7 +17,7 @@ import numpy as np
 
 NETWORKS = {"net_a": (32, 4), "net_b": (64, 16)}  # tag -> (input width, output width); 64 neurons x 2 hidden layers, ReLU, no output activation
 WIDTH, N_HIDDEN, PADDED_OUT = 64, 2, 16
-BAR_OUTPUT, BAR_WEIGHT_GRADIENTS, BAR_DL_DINPUT = 5e-3, 4e-2, 5e-2
+BAR_OUTPUT, BAR_WEIGHT_GRADIENTS, BAR_DL_DINPUT = 1.5e-3, 1.6e-2, 2.4e-2
 
 
 def load():

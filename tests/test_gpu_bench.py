@@ -40,7 +40,19 @@ def test_driver_bench_command_in_fresh_processes():
     for _ in range(3):
         d = _run(DRIVER_COMMAND, TCNN_BENCH_CPU_BUDGET_S="2")  # the CPU leg is bounded at 2 s here (12 s by default)
         assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "samples/s" and d["higher_is_better"] is True
-        assert d["attempts"] == 1 and "faulted_attempts" not in d
+        assert d["attempts"] == 1 and d["faulted"] is False and "faulted_attempts" not in d
+        # the reference's protocol (samples/mlp_learning_an_image.cu:263-271): the batch is drawn and its target evaluated inside every
+        # timed step; the resident-batch figure of rounds 1-3 rides along and cannot be slower than the step that also generates its data
+        p = d["protocol"]
+        assert p["regenerate"] is True and p["timed_steps"] == 20 and "pcg32" in p["batches"]
+        assert d["value_resident"] >= 0.97 * d["value"] and abs(d["value_resident"] - (1 << 18) / (d["ms_per_step_resident"] * 1e-3)) <= 1e-6 * d["value_resident"]
+        assert 0.9 < p["adam_touched_fraction"] <= 1.0  # N 2^D = 4 T at the fine levels: nearly every entry sees a sample
+        assert p["adam_algorithmic_bytes"]["touched"] <= p["adam_algorithmic_bytes"]["dense_upper_bound"] == d["config"]["n_params"] * 36
+        # network->inference on the same batch, with its own roofline: 4 D_in + L 2^D F 2 + 4 D_out = 540 B per sample
+        inf = d["inference"]
+        assert inf["batch"] == 1 << 18 and inf["roofline"]["algorithmic_bytes_per_call"] == (1 << 18) * 540
+        assert math.isclose(inf["samples_per_s"], (1 << 18) / (inf["ms_per_call"] * 1e-3), rel_tol=1e-9) and 0.02 < inf["roofline"]["frac"] < 1.0
+        assert inf["ms_per_call"] < d["ms_per_step"]
         assert d["config"]["batch_per_gpu"] == 1 << 18 and "HashGrid" in d["config"]["workload"]
         assert abs(d["value"] - (1 << 18) / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
         r = d["roofline"]
@@ -85,6 +97,31 @@ def test_bench_other_workloads_print_their_line():
     for workload, kernel in (("mlp", "mlp_train_fused"), ("stress", "adam")):
         d = _run(DRIVER_COMMAND + ["--workload", workload, "--no-cpu-baseline"])
         assert d["roofline"]["kernel"] == kernel and math.isfinite(d["final_loss"]) and "mfma" in d["roofline"]
+        p = d["protocol"]
+        if workload == "stress":
+            # T = 2^22: a batch of 2^18 leaves most entries of the fine levels untouched; Adam's fraction is computed from the parameters
+            # it steps, not from the dense 36 B x n_params bound
+            assert p["regenerate"] is True and p["adam_touched_fraction"] < 0.8
+            assert d["roofline"]["algorithmic_bytes_per_launch"] == p["adam_algorithmic_bytes"]["touched"] < 0.85 * p["adam_algorithmic_bytes"]["dense_upper_bound"]
+        else:
+            assert p["regenerate"] is False and "value_resident" not in d  # benchmarks/mlp generates its input once
+
+
+def test_bench_resident_batches_on_request():
+    d = _run(DRIVER_COMMAND + ["--no-regenerate", "--no-cpu-baseline", "--no-inference"])
+    assert d["protocol"]["regenerate"] is False and "value_resident" not in d and "inference" not in d and math.isfinite(d["final_loss"])
+
+
+def test_sinusoid_targets_through_the_c_abi():
+    """tcnn_generate_sinusoid_targets (the target the bench evaluates inside every timed step) against its definition."""
+    T = tcnn()
+    for n, d_in, d_out in ((4096, 3, 4), (777, 2, 3), (256, 3, 16), (33, 1, 1)):
+        x = torch.rand((n, d_in), device="cuda")
+        t = T._C.sinusoid_targets_(x, torch.empty((n, d_out), device="cuda"))
+        xs = x.double().cpu().numpy()
+        want = np.stack([0.5 + 0.5 * np.sin(2 * np.pi * (c % 4 + 1) * xs[:, 0]) * np.cos(2 * np.pi * (c % 4 + 1) * xs[:, 1 % d_in]) * np.sin(2 * np.pi * xs[:, 2 % d_in] + c)
+                         for c in range(d_out)], axis=1)
+        assert np.abs(t.cpu().numpy() - want).max() < 2e-5, (n, d_in, d_out)
 
 
 @pytest.mark.parametrize("mode", ["fence", "canary"])

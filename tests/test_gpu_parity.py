@@ -712,6 +712,41 @@ def test_reference_golden_fixture():
         assert np.array_equal(dx.cpu().numpy()[:16], gold["dy_dx_first"][:, k, :]), k
 
 
+def test_reference_golden_fixture_loss_and_adam():
+    """The loss and optimizer part of tests/golden/reference_small.npz -- made by THE REFERENCE'S OWN relative_l2_loss
+    (losses/relative_l2.h:39-76) and adam_step (optimizers/adam.h:47-127) compiled for the host (tests/golden/make_ref_golden.py): the HIP
+    loss kernel and the HIP Adam kernel against those vectors through the C ABI, no oracle in the loop.
+    Bars: loss values and gradients bit for bit; Adam's first / second moments and per-parameter step counters bit for bit, the 16-bit
+    weights equal to the rounded master weights of the run itself, the fp32 master weights within 4 ulp of the reference's (powf of the
+    bias correction is not correctly rounded on either side; the same bar as the oracle-based Adam tests)."""
+    T = tcnn()
+    C = T._C
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_small.npz"))
+    # ---- RelativeL2 on a [n][16] prediction with 4 live outputs, loss scale 128
+    pred, targets = h_t(gold["prediction"]), torch.from_numpy(gold["targets"]).cuda()
+    values, grads = C.loss_evaluate("RelativeL2", pred, targets, loss_scale=128.0)
+    assert np.array_equal(h_np(grads), gold["loss_gradients"])
+    assert np.array_equal(values.cpu().numpy().view(np.uint32), gold["loss_values"].view(np.uint32))
+    # ---- three Adam steps (data/config_hash.json hyper-parameters), 1024 matrix weights + 3072 table entries of which some are skipped
+    from tinycudann import native
+    m, nm = gold["adam_w0"].size, 1024
+    opt = native.Optimizer({"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6}, m, nm)
+    w = torch.from_numpy(gold["adam_w0"].copy()).cuda()
+    h = w.half()
+    for step in (1, 2, 3):
+        opt.step(w, h, h_t(gold[f"adam_grad{step}"]), loss_scale=128.0)
+    m1, m2, steps = opt.state()
+    assert np.array_equal(steps.cpu().numpy().view(np.uint32), gold["adam_steps"])
+    assert np.array_equal(m1.cpu().numpy().view(np.uint32), gold["adam_m1"].view(np.uint32))
+    assert np.array_equal(m2.cpu().numpy().view(np.uint32), gold["adam_m2"].view(np.uint32))
+    wg, wr = w.cpu().numpy(), gold["adam_w"]
+    ulp = np.spacing(np.maximum(np.maximum(np.abs(wr), np.abs(gold["adam_w0"])), np.abs(wr - gold["adam_w0"])).astype(np.float32))
+    assert np.all(np.abs(wg.astype(np.float64) - wr) <= 4 * ulp), float(np.max(np.abs(wg.astype(np.float64) - wr) / ulp))
+    assert np.array_equal(h_np(h), O.f2h(wg))  # the 16-bit weights are the GPU's own master weights rounded to nearest even
+    agree = np.mean(h_np(h) == gold["adam_h"])
+    assert agree > 0.999, agree  # and thereby the reference's, up to the few whose master weight sits within 4 ulp of a rounding boundary
+
+
 @pytest.mark.parametrize("tag", ["net_a", "net_b"])
 def test_reference_golden_fixture_network(tag):
     """The network part of tests/golden/reference_small.npz: the output of THE REFERENCE'S OWN kernel_mlp_fused /

@@ -40,8 +40,11 @@ def _rel_l2(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
 
 
-def test_headline_training_step_matches_oracle_at_full_size():
-    cfg = config_hash()
+@pytest.mark.parametrize("per_level_scale", [2.0, 1.5])
+def test_headline_training_step_matches_oracle_at_full_size(per_level_scale):
+    """Both scales SURVEY 8's headline lists: 2.0 (three dense levels, thirteen hashed power-of-two tables) and data/config_hash.json's 1.5
+    (four dense levels whose sizes are no powers of two, resolutions 16 ... 7007)."""
+    cfg = config_hash(per_level_scale=per_level_scale)
     tm, md = _trainer_and_oracle(cfg, 3, 4)
     init = _scaled_init(tm, md)
     st, st16 = O.TrainState(md, init), O.TrainState(md, init)
@@ -175,6 +178,51 @@ def test_adam_byte_deficits_beyond_254_skipped_steps():
             _, _, steps, current = _optimizer_state(tm)  # serialises: bytes -> counters (and back at the next step)
             assert current == step and np.array_equal(steps, counters), step
     assert counters[never].max() == 2 and counters[:nm].min() == 300
+
+
+def test_parameters_written_through_the_exposed_pointers_survive_the_optimizer():
+    """tcnn_trainer_params / _params_full_precision hand out mutable pointers (trainer.h:489-503).  The reference's Adam leaves the 16-bit weight
+    of a skipped (zero-gradient) entry untouched (adam.h:79-82); the library's shortcut "16-bit weight = rounded master weight" must
+    therefore be off while a caller holds either pointer, and tcnn_trainer_params_written must bring the master weights in line with what
+    was written before the shortcut is trusted again."""
+    T = tcnn()
+    tm = T.create_from_config(3, 4, config_hash(log2_hashmap_size=12, per_level_scale=1.5))
+    n, nm = tm.n_params, tm.n_mlp_params
+    tm.set_global_batch_size(1 << 20)  # deficit form of the step counters: the form whose mixed lanes re-derive skipped weights
+    rng = np.random.default_rng(3)
+
+    def step_with_sparse_gradient():
+        g = (rng.standard_normal(n) * 0.1).astype(np.float16)
+        g[nm:][rng.random(n - nm) < 0.5] = 0  # half of the grid entries are skipped: most lanes of four are mixed
+        tm.param_gradients.copy_(h_t(g.view(np.uint16)))
+        tm.optimizer_step()
+        return g
+
+    step_with_sparse_gradient()
+    # (1) a caller writes the 16-bit parameters directly and says so
+    written = nm + rng.choice(n - nm, 500, replace=False)
+    p = tm.params  # exposes the buffer
+    before_master = tm.params_full_precision.cpu().numpy().copy()
+    new16 = (rng.standard_normal(500) * 0.5).astype(np.float16)
+    p[torch.from_numpy(written).cuda()] = h_t(new16.view(np.uint16))
+    tm.params_written()
+    master = tm.params_full_precision.cpu().numpy()
+    assert np.array_equal(master[written], new16.astype(np.float32))  # re-derived from what was written
+    untouched = np.setdiff1d(np.arange(n), written)
+    assert np.array_equal(master[untouched].view(np.uint32), before_master[untouched].view(np.uint32))  # the others keep their extra bits
+    g = step_with_sparse_gradient()
+    skipped = written[g[written] == 0]
+    assert len(skipped) > 100
+    assert np.array_equal(h_np(tm.params)[skipped], new16[g[written] == 0].view(np.uint16))  # skipped entries keep the written value
+
+    # (2) a caller holds the MASTER pointer and writes it (no params_written yet): skipped 16-bit weights stay what they were
+    p16_before = h_np(tm.params).copy()
+    tm.params_written()  # the shortcut is trusted again (this call leaves the 16-bit buffer as it is) ...
+    pm = tm.params_full_precision  # ... and the master pointer is the only one out
+    pm[torch.from_numpy(written).cuda()] = torch.from_numpy((new16.astype(np.float32) * 3.0)).cuda()
+    g = step_with_sparse_gradient()
+    skipped = written[g[written] == 0]
+    assert len(skipped) > 100 and np.array_equal(h_np(tm.params)[skipped], p16_before[skipped])
 
 
 def test_optimizer_object_on_its_own_bit_level():

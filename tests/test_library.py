@@ -29,6 +29,89 @@ def test_every_declared_symbol_is_exported():
     assert not missing, f"declared in include/tcnn_hip.h but not exported: {missing}"
 
 
+def test_shipped_libraries_are_no_experiment_builds():
+    """csrc/exp_diag.h: the kernels' timing-ladder switches (results wrong on purpose) exist only behind -DTCNN_EXPERIMENT; an object
+    built with it exports `tcnn_experiment_build_marker`.  Neither shipped library has one, the product sources carry no switch outside
+    that header, a switch without the flag does not compile, and the Makefile of the shipped libraries refuses the flag."""
+    import ctypes
+    import glob
+    import shutil
+    import subprocess
+    lib_dir = os.path.join(ROOT, "tiny-cuda-nn_amd", "lib")
+    for name in ("libtcnn_hip.so", "libtcnn_hip_bf16.so"):
+        assert not hasattr(ctypes.CDLL(os.path.join(lib_dir, name)), "tcnn_experiment_build_marker"), name
+    assert not _lib().is_experiment_build()
+    csrc = os.path.join(ROOT, "tiny-cuda-nn_amd", "csrc")
+    for f in glob.glob(os.path.join(csrc, "*")):
+        if os.path.basename(f) not in ("exp_diag.h", "Makefile") and os.path.isfile(f):
+            assert "TCNN_EXP" not in open(f, errors="replace").read(), f
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if os.path.exists(hipcc):
+        probe = '#include "exp_diag.h"\nint main() { return (int)tcnn_hip::EXP_DIAG_OWNER; }\n'
+        for flags, ok in ((["-DTCNN_EXP_DIAG_OWNER=2"], False), (["-DTCNN_EXPERIMENT", "-DTCNN_EXP_DIAG_OWNER=2"], True), ([], True)):
+            r = subprocess.run([hipcc, "-x", "c++", "-std=c++17", "-fsyntax-only", "-I" + csrc, *flags, "-"], input=probe, capture_output=True, text=True, timeout=300)
+            assert (r.returncode == 0) == ok, (flags, r.stderr[-500:])
+    r = subprocess.run(["make", "-n", "-C", csrc, "CXXFLAGS=-O3 -DTCNN_EXP_DIAG_OWNER=2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "experiment" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("json_flag", [[], ["-DTCNN_JSON_HEADER=\"/opt/conda/include/json.hpp\""]], ids=["json_mini", "nlohmann"])
+def test_cpp_api_module_header_builds_and_runs_on_the_host(tmp_path, json_flag):
+    """include/tiny-cuda-nn/cpp_api.h: `tcnn::cpp::Module` + factories + free functions (reference cpp_api.h:62-123) as a header a binding
+    can include in place of the reference's.  Compiled with g++ and RUN here (construction and the accessors need no GPU): the reference's
+    own known answers for the grid (tests/test_grid.cu:55-71) come back through the virtual interface; with nlohmann::json present
+    Trainer::serialize() has the reference's return type (trainer.h:442)."""
+    import subprocess
+    if json_flag and not os.path.exists("/opt/conda/include/json.hpp"):
+        pytest.skip("no nlohmann/json.hpp in this image")
+    src = tmp_path / "module_caller.cpp"
+    src.write_text(r'''
+#include <tiny-cuda-nn/cpp_api.h>
+#include <tiny-cuda-nn/config.h>
+#include <cstdio>
+#include <type_traits>
+using namespace tcnn::cpp;
+#if defined(TCNN_HAS_NLOHMANN_JSON)
+static_assert(std::is_same<decltype(std::declval<tcnn::Trainer<float, tcnn::precision_t, tcnn::precision_t>&>().serialize(true)), tcnn::json>::value, "Trainer::serialize returns json");
+#endif
+int main() {
+	int n_messages = 0;
+	set_log_callback([&](LogSeverity, const std::string&) { ++n_messages; });
+	json enc = json::parse(R"({"otype": "HashGrid", "n_levels": 20, "n_features_per_level": 2, "log2_hashmap_size": 16, "base_resolution": 32, "per_level_scale": 1.5})");
+	json net = json::parse(R"({"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2})");
+	std::unique_ptr<Module> e{create_encoding(3, enc, Precision::Fp16)};
+	if (e->n_input_dims() != 3 || e->n_output_dims() != 40 || e->n_params() != 2555904) return 1;
+	if (e->param_precision() != Precision::Fp16 || e->output_precision() != Precision::Fp16 || e->jit_fusion()) return 2;
+	std::unique_ptr<Module> m{create_network_with_input_encoding(3, 4, enc, net)};
+	if (m->n_output_dims() != 16 || m->n_params() != 2555904 + 64 * 48 + 64 * 64 + 16 * 64) return 3;  // 40 encoded features, padded to the network's alignment of 16
+	std::unique_ptr<Module> n{create_network(32, 4, net)};
+	if (n->n_input_dims() != 32 || n->n_params() != 64 * 32 + 64 * 64 + 16 * 64) return 4;
+	std::unique_ptr<Module> f{create_encoding(3, enc, Precision::Fp32)};
+	if (f->param_precision() != Precision::Fp32) return 5;
+	if (batch_size_granularity() != 256 || default_loss_scale(Precision::Fp16) != 128.0f || default_loss_scale(Precision::Fp32) != 1.0f) return 6;
+	if (!has_networks() || supports_jit_fusion() || preferred_precision() != Precision::Fp16) return 7;
+	if (m->hyperparams()["encoding"].value("otype", std::string()).empty() || m->name().empty()) return 8;
+	bool threw = false;
+	try {
+		Context none;
+		m->backward(nullptr, none, 256, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+	} catch (const std::runtime_error&) { threw = true; }
+	if (!threw) return 9;
+	set_log_callback(nullptr);
+	std::printf("module api ok: %s\\n", m->name().c_str());
+	return 0;
+}
+''')
+    exe = tmp_path / "module_caller"
+    lib_dir = os.path.join(ROOT, "tiny-cuda-nn_amd", "lib")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", *json_flag, "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", str(src), "-o", str(exe),
+           "-L" + lib_dir, "-ltcnn_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "module api ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_free_functions():
     C = _lib()
     assert C.batch_size_granularity() == 256                       # common.h:246

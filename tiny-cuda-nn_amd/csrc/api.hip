@@ -273,6 +273,8 @@ struct ProfScope {
 	}
 };
 // grid_backward reports its kernels one by one (GridBackwardWorkspace::phase_hook); user = the stream
+// (false while the level groups after the first are launched: their time adds to the stage, the launch count of the step does not)
+static thread_local bool g_phase_hook_counts = true;
 static void grid_backward_phase_hook(void* user, int phase, int begin) {
 	static thread_local hipEvent_t a = nullptr;
 	const int stage = phase == 0 ? STAGE_GRID_BWD_SCATTER : STAGE_GRID_BWD;
@@ -283,7 +285,7 @@ static void grid_backward_phase_hook(void* user, int phase, int begin) {
 	} else if (a) {
 		hipEvent_t b = g_profiler->get();
 		HIP_CHECK(hipEventRecord(b, (hipStream_t)user));
-		g_profiler->spans.push_back({stage, a, b, true});
+		g_profiler->spans.push_back({stage, a, b, g_phase_hook_counts});
 		a = nullptr;
 	}
 }
@@ -803,7 +805,32 @@ static void encoding_backward(hipStream_t stream, const Model& md, const Forward
 			// whole slices, so the reference's full-table memset is only issued for the atomic A/B mode.
 			const GridBackwardMode mode = (GridBackwardMode)g_grid_backward_mode.load();
 			if (lds_level_budget == 0) lds_level_budget = g_default_lds_slice_bytes;
+			// level groups: only where a level's treatment does not depend on its index among ALL levels (every level switched on,
+			// no per-level random stream) and nothing else rides on the pass
+			const uint32_t L = e.grid.n_levels, F = e.grid.n_feat;
+			uint32_t n_groups = groups ? std::min(std::max(groups->n_groups, 1u), L) : 1u;
+			if (e.grid.max_level < 1.0f || e.grid.stochastic != 0u || fused_adam) n_groups = 1;
+			// consecutive levels, cut where the running parameter count passes k / n_groups of the total
+			std::vector<std::pair<uint32_t, uint32_t>> level_ranges;
+			for (uint32_t k = 1, a = 0; k <= n_groups && a < L; ++k) {
+				uint32_t b = a + 1;
+				const uint64_t target = (uint64_t)e.grid.offset[L] * k / n_groups;
+				while (b < L && (k == n_groups || e.grid.offset[b] < target)) ++b;
+				if (k == n_groups) b = L;
+				level_ranges.push_back({a, b});
+				a = b;
+			}
+			// one workspace for all groups: the largest any of them asks for (a group of later levels can bucket levels that the plan of
+			// the whole grid, which takes the first MAX_BUCKET_LEVELS eligible ones, left to the other kinds)
 			GridBackwardWorkspace ws = grid_backward_workspace_size(e.grid, n, mode, lds_level_budget);
+			if (level_ranges.size() > 1) {
+				ws = GridBackwardWorkspace();
+				for (const auto& r : level_ranges) {
+					const GridBackwardWorkspace w = grid_backward_workspace_size(grid_levels(e.grid, r.first, r.second), n, mode, lds_level_budget);
+					ws.scratch_bytes = std::max(ws.scratch_bytes, w.scratch_bytes);
+					ws.n_counters = std::max(ws.n_counters, w.n_counters);
+				}
+			}
 			Scratch queues;
 			if (ws.scratch_bytes) {
 				queues = Scratch(stream, ws.scratch_bytes);
@@ -814,26 +841,19 @@ static void encoding_backward(hipStream_t stream, const Model& md, const Forward
 			ws.phase_hook = grid_backward_phase_hook;  // per-kernel timing when a profiler is attached
 			ws.hook_user = (void*)stream;
 			ws.fused_adam = mode == GridBackwardMode::Bucketed ? fused_adam : nullptr;
-			// level groups: only where a level's treatment does not depend on its index among ALL levels (every level switched on,
-			// no per-level random stream) and nothing else rides on the pass
-			const uint32_t L = e.grid.n_levels, F = e.grid.n_feat;
-			uint32_t n_groups = groups ? std::min(std::max(groups->n_groups, 1u), L) : 1u;
-			if (e.grid.max_level < 1.0f || e.grid.stochastic != 0u || fused_adam) n_groups = 1;
-			if (n_groups <= 1) {
+			if (level_ranges.size() <= 1) {
 				grid_backward(stream, e.grid, io, dL_denc, grid_grads, accumulate, mode, lds_level_budget, ws);
 				if (groups && groups->ready) groups->ready(groups->ctx, md.n_mlp_params(), md.n_mlp_params() + (size_t)e.grid.offset[L] * F);
 			} else {
-				// consecutive levels, cut where the running parameter count passes k / n_groups of the total
-				uint32_t a = 0;
-				for (uint32_t k = 1; k <= n_groups && a < L; ++k) {
-					uint32_t b = a + 1;
-					const uint64_t target = (uint64_t)e.grid.offset[L] * k / n_groups;
-					while (b < L && (k == n_groups || e.grid.offset[b] < target)) ++b;
-					if (k == n_groups) b = L;
+				struct CountsGuard {
+					~CountsGuard() { g_phase_hook_counts = true; }
+				} counts_guard;
+				for (const auto& r : level_ranges) {
+					const uint32_t a = r.first, b = r.second;
 					const GridMeta sub = grid_levels(e.grid, a, b);
+					g_phase_hook_counts = a == 0;  // one backward pass per step, however many launches it takes
 					grid_backward(stream, sub, io, dL_denc + (size_t)a * F * stride_k, grid_grads + (size_t)e.grid.offset[a] * F, accumulate, mode, lds_level_budget, ws);
 					if (groups->ready) groups->ready(groups->ctx, md.n_mlp_params() + (size_t)e.grid.offset[a] * F, md.n_mlp_params() + (size_t)e.grid.offset[b] * F);
-					a = b;
 				}
 			}
 		}
@@ -1089,6 +1109,14 @@ int tcnn_generate_random_uniform(tcnn_stream_t stream, uint64_t seed, uint64_t* 
 	if (position && *position) rng.advance((int64_t)*position);
 	generate_random_uniform((hipStream_t)stream, rng, n, out, lower, upper);
 	if (position) *position += n;
+	TCNN_API_END
+}
+
+int tcnn_generate_sinusoid_targets(tcnn_stream_t stream, uint32_t n, uint32_t n_input_dims, uint32_t n_output_dims, const float* positions, float* targets) {
+	TCNN_API_BEGIN
+	if (n_input_dims == 0) throw std::runtime_error("tcnn_generate_sinusoid_targets: n_input_dims must be positive");
+	if ((uint64_t)n * n_output_dims > 0xFFFFFFFFull) throw std::runtime_error("tcnn_generate_sinusoid_targets: batch too large");
+	sinusoid_targets((hipStream_t)stream, n, n_input_dims, n_output_dims, positions, targets);
 	TCNN_API_END
 }
 
@@ -1829,6 +1857,14 @@ static int finish_training_step(tcnn_trainable_model_t* tm, hipStream_t stream, 
 	if (tm->exchange) tm->exchange(tm->exchange_user, tm->grads, tm->md.n_params(), stream);
 	return tcnn_trainer_optimizer_step(tm, stream, loss_scale);
 }
+// A step that leaves the optimizer to a later call: the compute stream goes behind the all-reduces it started, so that whatever reads the
+// gradient buffer next on that stream (the host's own optimizer_step, a copy of param_gradients) sees the reduced values.
+static int settle_unstepped_reductions(tcnn_trainable_model_t* tm, hipStream_t stream, bool optimizer_ran) {
+	if (optimizer_ran || !tm->rccl_comm) return TCNN_OK;
+	TCNN_API_BEGIN
+	await_reduced_gradients(tm, stream);
+	TCNN_API_END
+}
 struct ReadyTrampoline {
 	tcnn_trainable_model_t* tm;
 	hipStream_t stream;
@@ -1963,12 +1999,25 @@ int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
                                const void* external_dL_dy, tcnn_train_context_t** ctx_out) {
 	const float loss_scale = LOSS_SCALE_FP16;  // trainer.h:265
 	tm->last_batch = n;
-	tm->reduced.clear();
+	// all-reduces of an earlier step(run_optimizer = false) may still be on the communication stream: this step's backward pass writes
+	// the same gradient buffer and re-records the same events, so the compute stream goes behind them first
+	try {
+		await_reduced_gradients(tm, (hipStream_t)stream);
+	} catch (const std::exception& ex) {
+		g_last_error = ex.what();
+		return TCNN_ERROR;
+	}
 	tm->comm_events_used = 0;
+	if (tm->rccl_comm && gradient_mode == TCNN_GRADIENT_ACCUMULATE) {
+		// every all-reduce would sum the ranks' ACCUMULATED buffers again: the earlier micro-batches would be counted once per rank and step
+		g_last_error = "training_step: GradientMode::Accumulate cannot be combined with tcnn_trainer_enable_rccl (accumulate locally with the communicator switched off and reduce the buffer once)";
+		return TCNN_ERROR;
+	}
 	tcnn_train_context_t* ctx = nullptr;
 	if (g_fused_network_passes.load() && tm->md.has_network && mlp_train_supported(tm->md.net.mlp) && (external_dL_dy || (target && loss_is_elementwise(tm->loss)))) {
 		int r = training_step_fused(tm, (hipStream_t)stream, loss_scale, n, input, target, data_pdf, dL_dinput, use_inference_params, gradient_mode,
 		                            run_optimizer != 0, (const half_t*)external_dL_dy, &ctx);
+		if (r == TCNN_OK) r = settle_unstepped_reductions(tm, (hipStream_t)stream, run_optimizer != 0);
 		if (ctx_out && r == TCNN_OK) {
 			*ctx_out = ctx;
 		} else {
@@ -1987,6 +2036,7 @@ int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
 		}
 	}
 	if (r == TCNN_OK && run_optimizer) r = finish_training_step(tm, (hipStream_t)stream, loss_scale);
+	if (r == TCNN_OK) r = settle_unstepped_reductions(tm, (hipStream_t)stream, run_optimizer != 0);
 	if (ctx_out && r == TCNN_OK) {
 		*ctx_out = ctx;
 	} else {
@@ -2069,6 +2119,32 @@ int tcnn_trainer_training_step_matrices(tcnn_trainable_model_t* tm, tcnn_stream_
 	TCNN_API_END
 }
 
+// Trainer::forward / backward (trainer.h:97-148) with GPUMatrixDynamic inputs of either layout
+int tcnn_trainer_forward_matrices(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale, const tcnn_matrix_t* input, const tcnn_matrix_t* target,
+                                  const tcnn_matrix_t* data_pdf, int use_inference_params, int prepare_input_gradients, const tcnn_matrix_t* external_dL_dy,
+                                  tcnn_train_context_t** ctx_out) {
+	TCNN_API_BEGIN
+	if (!input) throw std::runtime_error("forward: input is required");
+	const uint32_t n = input->n;
+	const IoLayoutGuard guard(layout_of(input, nullptr, tm->md.n_input_dims, n));
+	const void* ext = dense_cm(external_dL_dy, tm->md.padded_output_width(), n, "external_dL_dy");
+	const void* tgt = ext ? (target && target->data ? target->data : nullptr) : dense_cm(target, tm->md.output_width(), n, "target");
+	const void* pdf = ext ? nullptr : dense_cm(data_pdf, tm->md.output_width(), n, "data_pdf");
+	const int r = tcnn_trainer_forward(tm, stream, loss_scale, n, (const float*)input->data, (const float*)tgt, (const float*)pdf, use_inference_params, prepare_input_gradients, ext, ctx_out);
+	if (r != TCNN_OK) return r;
+	TCNN_API_END
+}
+int tcnn_trainer_backward_matrices(tcnn_trainable_model_t* tm, tcnn_stream_t stream, const tcnn_train_context_t* ctx, const tcnn_matrix_t* input,
+                                   const tcnn_matrix_t* dL_dinput, int use_inference_params, int gradient_mode) {
+	TCNN_API_BEGIN
+	if (!input) throw std::runtime_error("backward: input is required");
+	const uint32_t n = input->n;
+	const IoLayoutGuard guard(layout_of(input, dL_dinput, tm->md.n_input_dims, n));
+	const int r = tcnn_trainer_backward(tm, stream, ctx, n, (const float*)input->data, dL_dinput ? (float*)dL_dinput->data : nullptr, use_inference_params, gradient_mode);
+	if (r != TCNN_OK) return r;
+	TCNN_API_END
+}
+
 int tcnn_network_inference_matrices(tcnn_trainable_model_t* tm, tcnn_stream_t stream_, const tcnn_matrix_t* input, const tcnn_matrix_t* output,
                                     int use_inference_params) {
 	TCNN_API_BEGIN
@@ -2086,7 +2162,12 @@ int tcnn_network_inference_matrices(tcnn_trainable_model_t* tm, tcnn_stream_t st
 }
 
 size_t tcnn_trainer_n_params(const tcnn_trainable_model_t* tm) { return tm->md.n_params(); }
-float* tcnn_trainer_params_full_precision(tcnn_trainable_model_t* tm) { return tm->master; }
+// (mutable as well: a caller that writes the fp32 master weights through this pointer breaks "the 16-bit parameters are the rounded
+// master weights" just like one that writes the 16-bit buffer, so it is treated the same way until tcnn_trainer_params_written)
+float* tcnn_trainer_params_full_precision(tcnn_trainable_model_t* tm) {
+	tm->params_exposed = true;
+	return tm->master;
+}
 void* tcnn_trainer_params(tcnn_trainable_model_t* tm) {
 	tm->params_exposed = true;  // a mutable pointer leaves the library: assume the caller writes through it, now or later
 	return tm->params;
@@ -2245,10 +2326,17 @@ uint32_t tcnn_trainer_n_mlp_params(const tcnn_trainable_model_t* tm) { return (u
 
 // tcnn_trainer_params / _params_inference hand out a mutable pointer: from then on the transposed copy of the network weights is rebuilt
 // before every pass.  A caller that has finished writing says so here; the copy is rebuilt once more and then trusted again.
+// Which buffer is authoritative after direct writes: the 16-bit parameters (what the kernels compute with, what tcnn_trainer_params
+// hands out).  The fp32 master weights are re-derived from them wherever the two disagree -- a parameter whose 16-bit value still IS
+// its rounded master weight keeps the master's extra bits -- so a caller that wrote only the master buffer calls
+// tcnn_trainer_set_params_full_precision instead.  After this call Adam's "16-bit weights follow the master weights" shortcut holds again.
 int tcnn_trainer_params_written(tcnn_trainable_model_t* tm) {
+	TCNN_API_BEGIN
+	resync_master_from_half(nullptr, tm->md.n_params(), tm->params, tm->master);
+	HIP_CHECK(hipDeviceSynchronize());
 	tm->params_exposed = false;
 	tm->params_t_valid = false;
-	return TCNN_OK;
+	TCNN_API_END
 }
 
 int tcnn_trainer_set_global_batch_size(tcnn_trainable_model_t* tm, uint64_t global_batch_size) {

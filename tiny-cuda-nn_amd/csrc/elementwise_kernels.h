@@ -53,6 +53,8 @@ void generate_random_uniform(hipStream_t stream, Pcg32& rng, size_t n, float* ou
 
 void cast_f32_to_f16(hipStream_t stream, size_t n, const float* in, half_t* out);  // trainer.h:415-417
 void cast_f16_to_f32(hipStream_t stream, size_t n, const half_t* in, float* out);  // trainer.h:430-432
+void sinusoid_targets(hipStream_t stream, uint32_t n, uint32_t n_in, uint32_t n_out, const float* positions, float* targets);  // bench / sample targets
+void resync_master_from_half(hipStream_t stream, size_t n, const half_t* in, float* master);  // master := half where round(master) != half
 void cast_scaled_f32_to_f16(hipStream_t stream, size_t n, const float* in, half_t* out, float scale);
 void cast_scaled_f16_to_f32(hipStream_t stream, size_t n, const half_t* in, float* out, float scale);
 void scale_f32(hipStream_t stream, size_t n, float* data, float scale);

@@ -53,6 +53,14 @@ __global__ void k_cast_f16_to_f32(size_t n, const half_t* __restrict__ in, float
 		for (size_t i = i4; i < n; ++i) out[i] = (float)in[i];
 	}
 }
+// master[i] := (float)half[i] wherever the 16-bit value is no longer the rounded master weight (tcnn_trainer_params_written: a host
+// wrote the 16-bit parameters directly); untouched parameters keep the master's extra bits
+__global__ void k_resync_master_from_half(size_t n, const half_t* __restrict__ in, float* __restrict__ master) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const half_t h = in[i];
+	if (__builtin_bit_cast(uint16_t, to_half_rn(master[i])) != __builtin_bit_cast(uint16_t, h)) master[i] = (float)h;
+}
 // fp32 <-> 16-bit with a power-of-two scale (the fp32 encodings of cpp_api.cu:165-174 computed in the 16-bit type: the
 // gradients entering the backward pass are scaled into its range and the results scaled back, exactly)
 __global__ void k_cast_scaled_f32_to_f16(size_t n, const float* __restrict__ in, half_t* __restrict__ out, float scale) {
@@ -75,6 +83,25 @@ __global__ void k_fill_f16(size_t n, half_t* __restrict__ out, float value) {
 void cast_f32_to_f16(hipStream_t stream, size_t n, const float* in, half_t* out) {
 	if (n == 0) return;
 	TCNN_LAUNCH(k_cast_f32_to_f16, dim3((uint32_t)div_round_up(div_round_up(n, (size_t)4), (size_t)EW_THREADS)), dim3(EW_THREADS), 0, stream, n, in, out);
+}
+// Regression targets of the synthetic benchmark workloads, evaluated on the device inside every timed step the way the reference's
+// sample evaluates its image (samples/mlp_learning_an_image.cu:263-271: draw positions, `eval_image` them): a smooth analytic
+// n_in-D -> n_out function, products of sinusoids of frequencies 1..4.  One thread per (sample, output).
+__global__ void k_sinusoid_targets(uint32_t n, uint32_t n_in, uint32_t n_out, const float* __restrict__ positions, float* __restrict__ targets) {
+	const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n * n_out) return;
+	const uint32_t i = e / n_out, c = e % n_out;
+	const float* x = positions + (size_t)i * n_in;
+	const float two_pi = 6.28318530717958647692f, f = (float)(c % 4u + 1u);
+	targets[e] = 0.5f + 0.5f * __builtin_sinf(two_pi * f * x[0]) * __builtin_cosf(two_pi * f * x[1u % n_in]) * __builtin_sinf(two_pi * x[2u % n_in] + (float)c);
+}
+void sinusoid_targets(hipStream_t stream, uint32_t n, uint32_t n_in, uint32_t n_out, const float* positions, float* targets) {
+	if (n == 0 || n_out == 0) return;
+	TCNN_LAUNCH(k_sinusoid_targets, dim3(div_round_up(n * n_out, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_in, n_out, positions, targets);
+}
+void resync_master_from_half(hipStream_t stream, size_t n, const half_t* in, float* master) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_resync_master_from_half, dim3((uint32_t)div_round_up(n, (size_t)EW_THREADS)), dim3(EW_THREADS), 0, stream, n, in, master);
 }
 void cast_f16_to_f32(hipStream_t stream, size_t n, const half_t* in, float* out) {
 	if (n == 0) return;
@@ -332,9 +359,6 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
                                                            const half_t* __restrict__ gradients, float* __restrict__ first_moments,
                                                            float* __restrict__ second_moments, uint32_t* __restrict__ param_steps,
                                                            half_t* __restrict__ weights_t, uint8_t* __restrict__ deficits8) {
-#if defined(TCNN_EXP_DIAG_EMPTY_ADAM)  // timing diagnostics only (scripts/exp_fixed_costs.sh)
-	return;
-#endif
 	const uint32_t i0 = a.begin + (blockIdx.x * EW_THREADS + threadIdx.x) * 4;
 	const bool four = i0 < a.n_elements && i0 + 3 < a.n_elements;
 	h4 g = h4{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};

@@ -1,0 +1,35 @@
+// exp_diag.h -- the experiment switches of the kernels: timing ladders that skip ONE phase of a kernel so that its stage time says what
+// the phase costs (profiles/r03_exp_notes.txt section 10, r04_exp_notes.txt).  The results of such a build are WRONG ON PURPOSE.
+//
+// In the product build this header is empty of effect: the switches are compile-time zeros, the code they guard is dead (the ISA of the
+// shipped kernels is the same with and without the guarded lines).  An experiment build passes -DTCNN_EXPERIMENT together with a switch
+// (scripts/build_variant_one.sh adds the flag for every -DTCNN_EXP_* it is given):
+//   * a switch without the flag is a compile error;
+//   * csrc/Makefile, which builds the shipped libraries, refuses the flag;
+//   * an object built with it exports `tcnn_experiment_build_marker`: tests/test_library.py requires the shipped libraries to have no
+//     such symbol, tinycudann._C.is_experiment_build() tells a process which kind it loaded and bench.py says so in its line.
+#pragma once
+#include <cstdint>
+
+#if defined(TCNN_EXPERIMENT)
+extern "C" __attribute__((weak, visibility("default"))) int tcnn_experiment_build_marker = 1;
+#else
+#if defined(TCNN_EXP_DIAG_SCATTER) || defined(TCNN_EXP_DIAG_OWNER)
+#error "TCNN_EXP_* switches exist in experiment builds only: add -DTCNN_EXPERIMENT (scripts/build_variant_one.sh does)"
+#endif
+#endif
+
+namespace tcnn_hip {
+// k_grid_bucket_scatter: bit 0 no queue stores, bit 1 no reservation atomics, bit 2 no reordering stores, bit 3 no rank atomics
+#if defined(TCNN_EXP_DIAG_SCATTER)
+constexpr uint32_t EXP_DIAG_SCATTER = TCNN_EXP_DIAG_SCATTER;
+#else
+constexpr uint32_t EXP_DIAG_SCATTER = 0u;
+#endif
+// k_grid_bucket_owner: bit 0 no table clear, bit 1 no LDS atomics, bit 2 no conversion / store, bit 3 no last-owner protocol
+#if defined(TCNN_EXP_DIAG_OWNER)
+constexpr uint32_t EXP_DIAG_OWNER = TCNN_EXP_DIAG_OWNER;
+#else
+constexpr uint32_t EXP_DIAG_OWNER = 0u;
+#endif
+}  // namespace tcnn_hip

@@ -4,6 +4,7 @@
 #include "grid_kernels.h"
 #include "elementwise_kernels.h"  // Pcg32 (stochastic interpolation)
 #include "adam_device.h"          // the optimizer step of the owner pass (GridFusedAdam)
+#include "exp_diag.h"             // experiment switches: compile-time zeros in the product build
 
 #include <algorithm>
 #include <cstdlib>
@@ -362,9 +363,6 @@ template <uint32_t D, uint32_t F, uint32_t SPT>
 __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward_tiles(const GridMeta meta, const GridIO io, const ForwardPlan plan,
                                                                       const half_t* __restrict__ params, half_t* __restrict__ out) {
 	constexpr uint32_t TILE = GRID_THREADS * SPT;
-#if defined(TCNN_EXP_DIAG_EMPTY_GATHER)  // timing diagnostics only (scripts/exp_fixed_costs.sh): what the bare launch costs
-	return;
-#endif
 	// block -> (segment of its XCD's run, tile): level-major, so an XCD walks one table at a time
 	const uint32_t xcd = blockIdx.x & 7u;
 	uint32_t slot = blockIdx.x >> 3, level = 0, tile = 0;
@@ -785,14 +783,7 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 	constexpr uint32_t SPT = bucket_spt(D, F), TILE = SPT * BUCKET_THREADS, N_PAIR = TILE * N_PAIRS_PER_SAMPLE;
 	constexpr uint32_t INVALID = BUCKET_INVALID_INDEX;
 	TCNN_DYN_LDS(lds_raw);
-#if defined(TCNN_EXP_DIAG_SCATTER)  // timing diagnostics only (scripts/exp_fixed_costs.sh): bit 0 no queue stores, bit 1 no reservation atomics, bit 2 no reordering stores, bit 3 no rank atomics
-	constexpr uint32_t diag_scatter = TCNN_EXP_DIAG_SCATTER;
-#else
-	constexpr uint32_t diag_scatter = 0u;
-#endif
-#if defined(TCNN_EXP_DIAG_EMPTY_SCATTER) && TCNN_EXP_DIAG_EMPTY_SCATTER == 1  // timing diagnostics only (scripts/exp_fixed_costs.sh)
-	return;
-#endif
+	constexpr uint32_t diag_scatter = EXP_DIAG_SCATTER;  // 0 in the product build (exp_diag.h)
 	if (blockIdx.x >= plan.scatter_blocks) {
 		// gradients of chunked levels are accumulated with atomics by several owners in pass B: zero them here
 		const uint32_t z = blockIdx.x - plan.scatter_blocks;
@@ -848,9 +839,6 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 	const bool second_order = io.ddx != nullptr;  // scatter d(dL_dx)/d(grid) instead of dy/d(grid)
 	if (first_tile < plan.tiles) load_tile(first_tile, x, g);
 	__syncthreads();
-#if defined(TCNN_EXP_DIAG_EMPTY_SCATTER) && TCNN_EXP_DIAG_EMPTY_SCATTER == 2  // prologue only: first tile loaded, nothing scattered
-	if (x[0][0] != 12345.678f) return;
-#endif
 
 	for (uint32_t tile = first_tile; tile < plan.tiles; tile += plan.wgs_per_level) {
 		const uint32_t chunk = tile / plan.tiles_per_chunk[j];
@@ -1280,11 +1268,7 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 	const uint32_t n_over = min(counters[plan.overflow_counter], plan.overflow_capacity);
 	const bool inline_overflow = n_over <= OVERFLOW_INLINE_MAX;
 	const uint32_t count = min(counters[plan.counter_base[j] + queue], cap);  // in flight while the table is cleared
-#if defined(TCNN_EXP_DIAG_OWNER)  // timing diagnostics only (scripts/exp_fixed_costs.sh): bit 0 no table clear, bit 1 no LDS atomics, bit 2 no conversion / store, bit 3 no last-owner protocol
-	constexpr uint32_t diag_owner = TCNN_EXP_DIAG_OWNER;
-#else
-	constexpr uint32_t diag_owner = 0u;
-#endif
+	constexpr uint32_t diag_owner = EXP_DIAG_OWNER;  // 0 in the product build (exp_diag.h)
 	bool safe = !force_wide;
 	// the packed table is cleared first (LDS only), the first round requested behind it: nothing then stands between the loads and
 	// their use but the barrier (cleared after the loads, the compiler parks part of a record in other registers and waits for it)
@@ -1534,9 +1518,6 @@ __global__ void __launch_bounds__(OWNER_THREADS) k_grid_bucket_owner(const GridM
                                                                       const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient,
                                                                       const uint32_t lds_bytes, const int force_wide, const FusedAdamArgs fused) {
 	TCNN_DYN_LDS(lds_raw);
-#if defined(TCNN_EXP_DIAG_EMPTY_OWNER)  // timing diagnostics only (scripts/exp_fixed_costs.sh)
-	return;
-#endif
 	uint32_t item = 0, local_block;
 	if (plan.blocks_per_item) {
 		item = blockIdx.x / plan.blocks_per_item;
@@ -1951,9 +1932,6 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 	constexpr uint32_t MAX_BASES[11] = {0x0, 0xFFFFFFFF, 0xFFFF, 0x659, 0xFF, 0x54, 0x28, 0x17, 0xF, 0xB, 0x9};
 	uint32_t bucket_shift = 0;  // buckets hold a power-of-two number of entries (bucket = index >> shift)
 	while ((2u << bucket_shift) <= cap_fixed) ++bucket_shift;
-#if defined(TCNN_EXP_BUCKET_SHIFT_DELTA)  // experiment builds only (packed owners, even F): entries per bucket x 2^delta
-	bucket_shift = (uint32_t)((int)bucket_shift + (TCNN_EXP_BUCKET_SHIFT_DELTA));
-#endif
 	const uint32_t n_corners = meta.interp == (uint32_t)InterpolationType::Nearest ? 1u : (1u << meta.n_dims);
 	const uint32_t record_words = 1u + (F + 1u) / 2u;
 

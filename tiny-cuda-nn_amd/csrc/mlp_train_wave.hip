@@ -121,20 +121,11 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
 	const uint32_t act = m.activation, out_act = m.output_activation;
 	const bool want_grads = partials != nullptr, want_dx = dL_dinput != nullptr;
-#if defined(TCNN_EXP_DIAG_SKIP)  // timing diagnostics only (scripts/exp_mlp_diag.sh): bit 0 skips dL/dinput, bit 1 the weight gradients, bit 2 the whole backward half, bit 3 the loss arithmetic, bit 4 every strip, bit 5 the input loads, bit 6 the slab store, bit 7 the weight-gradient reduction and store, bit 8 the weight staging, bit 9 the loss reduction
-	const uint32_t diag_skip = la.loss_scale == 128.0f ? (uint32_t)(TCNN_EXP_DIAG_SKIP) : 0u;  // a run-time value: the skipped code stays in the kernel
-#else
-	constexpr uint32_t diag_skip = 0u;
-#endif
 	const float n_total = (float)la.n_total;
 	const PackedAct pa = packed_act(act);
-	// TCNN_EXP_RUNTIME_EXTERNAL (experiments only, scripts/exp_spill_wave.sh): the loss / external-gradient choice as a run-time
-	// branch -- the form that takes the 64-neuron instance from 254 registers to 254 + 8 spilled (profiles/r03_spill_finding.txt)
-#if defined(TCNN_EXP_RUNTIME_EXTERNAL)
-	const bool external = la.external_dL_doutput != nullptr;
-#else
+	// (a template parameter, not a run-time test of la.external_dL_doutput: the run-time form takes the 64-neuron instance from 254
+	// registers to 254 + 8 spilled AND puts a taken branch behind the output layer's last MFMA, profiles/r03_mfma_branch_hazard.txt)
 	constexpr bool external = EXTERNAL;
-#endif
 	const bool relative = la.type == LossType::RelativeL2, has_pdf = la.data_pdf != nullptr;
 	const float inv_n_total = (la.n_total & (la.n_total - 1u)) == 0u && la.n_total != 0u ? 1.0f / n_total : 0.0f;  // exact reciprocal or "divide"
 
@@ -154,7 +145,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	// The first strip's input is requested before anything else and travels while the weights are staged; the wave's fragment loads
 	// are all issued before the first one is written to LDS (one fragment at a time the loop paid a full L2 round trip per
 	// fragment: 1.7 us of fixed cost per launch, profiles/r03_exp_notes.txt).
-	const uint32_t n_strips = (diag_skip & 16u) ? 0u : n / MLP_WAVE_STRIP, stride = gridDim.x * NWAVES;
+	const uint32_t n_strips = n / MLP_WAVE_STRIP, stride = gridDim.x * NWAVES;
 	uint32_t strip = blockIdx.x * NWAVES + w;
 	h8 xq_next[FB];
 #pragma unroll
@@ -176,7 +167,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	};
 	{
 		constexpr uint32_t PER_WAVE = (N_FRAG + NWAVES - 1) / NWAVES;
-		const uint32_t n_frag = (diag_skip & 256u) ? 0u : N_FRAG;
+		constexpr uint32_t n_frag = N_FRAG;
 		h8 staged[PER_WAVE];
 #pragma unroll
 		for (uint32_t k = 0; k < PER_WAVE; ++k) {
@@ -231,16 +222,13 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 		for (uint32_t b = 0; b < NB; ++b) q[b] = pack8(to_h4(mfma_16x16x16(p[0][b], eye, zero4())), to_h4(mfma_16x16x16(p[1][b], eye, zero4())));
 	};
 
-#if defined(TCNN_EXP_SETPRIO) && !defined(TCNN_HOST_EMU)  // experiment: static issue priority for the second workgroup of a CU (MI355X_MICROARCH.md, two waves per SIMD)
-	if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(TCNN_EXP_SETPRIO);
-#endif
 	for (; strip < n_strips; strip += stride) {
 		asm volatile("" ::: "memory");  // the weight fragments are re-read from LDS where they are used, not hoisted into registers for the whole loop
 		const uint32_t base = strip * MLP_WAVE_STRIP;  // element offsets fit 32 bits (the host checks n): scalar base + 32-bit lane offset addressing
 		h8 xq[FB];  // lane lr <-> feature perm32(f, lr), k = sample 8g+j
 #pragma unroll
 		for (uint32_t f = 0; f < FB; ++f) xq[f] = xq_next[f];
-		if (strip + stride < n_strips && !(diag_skip & 32u)) {
+		if (strip + stride < n_strips) {
 #pragma unroll
 			for (uint32_t f = 0; f < FB; ++f) xq_next[f] = *(const h8*)(input + (perm32(f, lr) * n + (strip + stride) * MLP_WAVE_STRIP + 8 * g));
 		}
@@ -253,11 +241,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 				const uint32_t dim = 4 * r + g;
 				const bool live = !external && dim < la.dims;
 				const uint32_t target_idx = (base + perm32(s, lr)) * la.dims + dim;
-#if defined(TCNN_EXP_DIAG_NO_TARGETS)  // timing diagnostics only (scripts/exp_mlp_diag.sh): results are wrong on purpose
-				tgt[s][r] = live ? (float)target_idx * 1e-9f : 0.0f;
-#else
 				tgt[s][r] = live ? la.targets[target_idx] : 0.0f;
-#endif
 			}
 		}
 
@@ -304,30 +288,18 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 			f4 acc = zero4();
 #pragma unroll
 			for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(woutA(p), pack8(hp[HM][s][2 * p], hp[HM][s][2 * p + 1]), acc);
-#if defined(TCNN_EXP_NOP_AFTER_OUTPUT_MFMA) && !defined(TCNN_HOST_EMU)
-#define TCNN_STR2(x) #x
-#define TCNN_STR(x) TCNN_STR2(x)
-			// experiment (scripts/exp_spill_wave.sh): N + 1 wait states between the output layer's last MFMA and whatever follows it
-			asm volatile("s_nop " TCNN_STR(TCNN_EXP_NOP_AFTER_OUTPUT_MFMA) : "+v"(acc));
-#endif
 			const h4 o = h4{(half_t)act_forward<GENERAL>(out_act, acc[0]), (half_t)act_forward<GENERAL>(out_act, acc[1]), (half_t)act_forward<GENERAL>(out_act, acc[2]),
 			                (half_t)act_forward<GENERAL>(out_act, acc[3])};
 			const uint32_t i = base + perm32(s, lr);
 			h4 gy;
 			if (external) {  // one 8-byte load of outputs 4g .. 4g + 3, then the same 4 x 4 transpose as the stores below (it is its own inverse)
-#if defined(TCNN_EXP_RUNTIME_EXTERNAL)  // the experiment build keeps the round-2 form it reproduces (the hazard scanner's positive control)
-#pragma unroll
-				for (uint32_t r = 0; r < 4; ++r) gy[r] = la.external_dL_doutput[i * 16 + 4 * r + g];
-#else
 				gy = wave_rows_transpose4(*(const h4*)(la.external_dL_doutput + (i * 16 + 4 * g)));
-#endif
 			} else {
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
 					const uint32_t dim = 4 * r + g;
 					gy[r] = (half_t)0.0f;
-					if (diag_skip & 8u) gy[r] = o[r];
-					else if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
+					if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
 						const float pdf = has_pdf ? la.data_pdf[i * la.dims + dim] : 1.0f;  // rare: fetched where it is used
 						float value;
 						if constexpr (GENERAL) gy[r] = loss_element<true>(la.type, (float)o[r], tgt[s][r], pdf, n_total, la.loss_scale, value);
@@ -339,27 +311,16 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 			// Lane (g, lr) holds outputs 4r + g of its sample.  Stored as they lie that is four 2-byte stores per matrix whose 64 lanes
 			// touch 64 different 32-byte sectors -- measured: 6 us of the kernel's 34 (profiles/r03_exp_notes.txt).  A 4 x 4 transpose
 			// over the four lane groups (register moves, no LDS) gives every lane outputs 4g .. 4g + 3: ONE 8-byte store.
-#if defined(TCNN_EXP_DIAG_NO_OUT_STORES)
-			if (output && la.loss_scale == 12345.0f) output[i * 16 + 4 * g] = (half_t)((float)o[0] + (float)gy[0]);  // keeps both values alive
-#elif defined(TCNN_EXP_NARROW_OUT_STORES)  // the round-2 form, for A/B runs
-#pragma unroll
-			for (uint32_t r = 0; r < 4; ++r) {
-				if (output) output[i * 16 + 4 * r + g] = o[r];
-				if (dL_doutput) dL_doutput[i * 16 + 4 * r + g] = gy[r];
-			}
-#else
 			if (output) *(h4*)(output + (i * 16 + 4 * g)) = wave_rows_transpose4(o);
 			if (dL_doutput) *(h4*)(dL_doutput + (i * 16 + 4 * g)) = wave_rows_transpose4(gy);
-#endif
 #pragma unroll
 			for (uint32_t r = 0; r < 4; ++r) dyp[s][r] = (half_t)act_backward<GENERAL>(out_act, (float)gy[r], o[r]);  // fully_fused_mlp.cu:760-763
 			sched_fence();
 		}
 
 		sched_fence();
-		if (diag_skip & 4u) continue;
 		// ================= backward =================
-		if (!(diag_skip & 2u)) {  // dW_out[output][neuron] += dY * H_last^T  (accumulated unconditionally: a branch around the MFMAs costs the in-place accumulators)
+		{  // dW_out[output][neuron] += dY * H_last^T  (accumulated unconditionally: a branch around the MFMAs costs the in-place accumulators)
 			const h8 dyq = pack8(to_h4(mfma_16x16x16(dyp[0], eye, zero4())), to_h4(mfma_16x16x16(dyp[1], eye, zero4())));
 			h8 hq[NB];  // the layer's activations with the samples in k: lane lr <-> neuron perm32(b, lr), k = sample 8g+j
 			transpose(hp[HM], hq);
@@ -376,7 +337,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 		sched_fence();
 #pragma unroll
 		for (int j = (int)HM - 1; j >= 0; --j) {
-			if (!(diag_skip & 2u)) {  // dW_hid_j[out][in] += dA_{j+1} * H_j^T
+			{  // dW_hid_j[out][in] += dA_{j+1} * H_j^T
 				h8 daq[NB], hq[NB];
 				transpose(dap, daq);
 				transpose(hp[j], hq);
@@ -402,7 +363,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 				for (uint32_t b = 0; b < NB; ++b) dap[s][b] = prev[s][b];
 			sched_fence();
 		}
-		if (!(diag_skip & 2u)) {  // dW_in[out][feature] += dA_0 * X^T
+		{  // dW_in[out][feature] += dA_0 * X^T
 			h8 daq[NB];
 			transpose(dap, daq);
 #pragma unroll
@@ -411,7 +372,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 				for (uint32_t f = 0; f < FB; ++f) accI[b][f] = mfma_16x16x32(daq[b], xq[f], accI[b][f]);
 		}
 		sched_fence();
-		if (want_dx && !(diag_skip & 1u)) {  // dX^T = dA_0^T * W_in: (sample perm32(s, 4g+r) = 8g + 4s + r, feature 16f + lr) -> eight consecutive samples per lane
+		if (want_dx) {  // dX^T = dA_0^T * W_in: (sample perm32(s, 4g+r) = 8g + 4s + r, feature 16f + lr) -> eight consecutive samples per lane
 #pragma unroll
 			for (uint32_t f = 0; f < FB; ++f) {
 				h4 d[2];
@@ -428,7 +389,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	}
 
 	// ---- this workgroup's share of the loss
-	if (block_sums && !(diag_skip & 512u)) {
+	if (block_sums) {
 		if constexpr (!GENERAL) loss_sum = loss_sum * 0.5f / n_total;  // see loss_gradient_simple
 		red[tid] = loss_sum;
 		__syncthreads();
@@ -445,7 +406,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	// 256 t + 4 lane + r: one coalesced 16-byte store per tile; k_mlp_finalize_gradients knows the position -> parameter map,
 	// mlp_wave_slab_param).  The parameter-layout slab of rounds 1-2 was 112 scattered 4-byte store instructions issued by
 	// wave 0 alone: 3.7 us of the kernel's fixed cost (profiles/r03_exp_notes.txt).
-	if (want_grads && !(diag_skip & 128u)) {
+	if (want_grads) {
 		auto for_each_tile = [&](auto&& fn) {
 			uint32_t t = 0;
 #pragma unroll
@@ -477,7 +438,6 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 		if (w == 0) for_each_tile([&](uint32_t t, f4& a) { if (t >= HALF_TILES) ex1[t * 64 + lane] = a; });
 		__syncthreads();
 		float* P = partials + (size_t)blockIdx.x * N_PARAMS;
-		if (diag_skip & 64u) return;
 		if (w == 0) {
 			for_each_tile([&](uint32_t t, f4& a) {
 				if (t < HALF_TILES) *(f4*)(P + (t * 256u + lane * 4u)) = a + ex0[t * 64 + lane];

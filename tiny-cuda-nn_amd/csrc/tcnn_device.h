@@ -41,9 +41,12 @@ inline void launch_check(const char* kernel, hipStream_t stream) {
 	if (e != hipSuccess) throw std::runtime_error(std::string("tiny-cuda-nn_amd: launch of ") + kernel + " failed: " + hipGetErrorString(e));
 }
 }  // namespace tcnn_hip
+// (the error state is cleared BEFORE the launch: hipGetLastError returns and clears whatever non-sticky error another library -- torch,
+// RCCL -- left on this thread, and it would otherwise be reported as this kernel's launch failure)
 #define TCNN_LAUNCH(kernel, grid, block, shmem, stream, ...)                  \
 	do {                                                                      \
 		::tcnn_hip::launch_trace(#kernel, grid, block, shmem);                \
+		(void)hipGetLastError();                                              \
 		hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);  \
 		::tcnn_hip::launch_check(#kernel, stream);                            \
 	} while (0)

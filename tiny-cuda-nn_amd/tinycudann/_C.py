@@ -75,7 +75,10 @@ _sig("tcnn_default_loss_scale", _f, _i)
 _sig("tcnn_preferred_precision", _i)
 _sig("tcnn_supports_jit_fusion", _i, _i)
 _sig("tcnn_set_log_callback", None, _vp)
+_sig("tcnn_trainer_forward_matrices", _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp, C.POINTER(_vp))
+_sig("tcnn_trainer_backward_matrices", _i, _vp, _vp, _vp, _vp, _vp, _i, _i)
 _sig("tcnn_generate_random_uniform", _i, _vp, _u64, C.POINTER(_u64), _sz, _vp, _f, _f)
+_sig("tcnn_generate_sinusoid_targets", _i, _vp, _u32, _u32, _u32, _vp, _vp)
 _sig("tcnn_stream_malloc", _i, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz))
 _sig("tcnn_stream_free", _i, _vp, _vp, _sz)
 _sig("tcnn_create_optimizer", _i, C.c_char_p, C.POINTER(_vp))
@@ -158,6 +161,15 @@ _sig("tcnn_get_grid_owner_mode", _i)
 _sig("tcnn_grid_owner_wide_slices", _i, C.POINTER(C.c_uint64))
 
 EXPORTED_SYMBOLS = [n for n in dir(_lib) if n.startswith("tcnn_")]
+
+
+def is_experiment_build():
+    """True if the loaded library contains an object built with -DTCNN_EXPERIMENT (csrc/exp_diag.h: timing ladders, results wrong on purpose)."""
+    try:
+        getattr(_lib, "tcnn_experiment_build_marker")
+        return True
+    except AttributeError:
+        return False
 
 
 def _check(code):
@@ -485,6 +497,14 @@ class Pcg32:
         assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
         _check(_lib.tcnn_generate_random_uniform(_stream(), self.seed, C.byref(self.position), out.numel(), _ptr(out), lower, upper))
         return out
+
+
+def sinusoid_targets_(positions, targets):
+    """targets[i][c] = the synthetic workloads' analytic regression target at positions[i] (tcnn_generate_sinusoid_targets); returns `targets`."""
+    assert positions.is_cuda and targets.is_cuda and positions.dtype == targets.dtype == torch.float32
+    assert positions.is_contiguous() and targets.is_contiguous() and positions.shape[0] == targets.shape[0]
+    _check(_lib.tcnn_generate_sinusoid_targets(_stream(), positions.shape[0], positions.shape[1], targets.shape[1], _ptr(positions), _ptr(targets)))
+    return targets
 
 
 def _dumps(cfg):

@@ -189,6 +189,36 @@ def grid_backward_input(g, dL_dy_h, dy_dx):
     return out
 
 
+def grid_forward_f32(g, params, positions, out_stride=None, want_dy_dx=False):
+    """kernel_grid<float> (Encoding<float>): fp32 parameters [n_params] -> fp32 features [n, out_stride] (+ dy_dx [n, k, D])."""
+    positions = np.ascontiguousarray(positions, dtype=np.float32)
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    n = positions.shape[0]
+    k = g.n_levels * g.n_features_per_level
+    out_stride = out_stride or k
+    out = np.empty((n, out_stride), dtype=np.float32)
+    dy_dx = np.empty((n, k, g.n_dims), dtype=np.float32) if want_dy_dx else None
+    lib().orc_grid_forward_f32(C.byref(g), _p(params), _p(positions), C.c_uint32(n), _p(out), C.c_uint32(out_stride), _p(dy_dx))
+    return (out, dy_dx) if want_dy_dx else out
+
+
+def grid_backward_f32(g, positions, dL_dy):
+    """kernel_grid_backward<float, float>: fp32 dL_dy [n, stride] -> float64 sums of the fp32 products [n_params]."""
+    positions = np.ascontiguousarray(positions, dtype=np.float32)
+    dL_dy = np.ascontiguousarray(dL_dy, dtype=np.float32)
+    grad = np.zeros(g.n_params, dtype=np.float64)
+    lib().orc_grid_backward_f32(C.byref(g), _p(positions), C.c_uint32(positions.shape[0]), _p(dL_dy), C.c_uint32(dL_dy.shape[1]), _p(grad))
+    return grad
+
+
+def grid_backward_input_f32(g, dL_dy, dy_dx):
+    dL_dy = np.ascontiguousarray(dL_dy, dtype=np.float32)
+    n = dL_dy.shape[0]
+    out = np.empty((n, g.n_dims), dtype=np.float32)
+    lib().orc_grid_backward_input_f32(C.byref(g), C.c_uint32(n), _p(dL_dy), C.c_uint32(dL_dy.shape[1]), _p(dy_dx), _p(out))
+    return out
+
+
 def grid_backward_backward_input(g, params_h, positions, ddx, dL_dy_h, dy_dx=None):
     """Second order (grid.h:352-655).  Returns (grad_params float64, dL_ddLdy half [n, stride] or None, dL_dx float32 [n, D])."""
     positions = np.ascontiguousarray(positions, dtype=np.float32)

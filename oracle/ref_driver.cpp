@@ -89,6 +89,28 @@ void grid_backward(const GridArgs& a, const float* positions, const __half* dL_d
 	});
 }
 
+// ---- the same kernels instantiated with T = float: GridEncodingTemplated<float>, what create_encoding(..., Precision::Fp32) builds
+// (cpp_api.cu:165-168); grad_t = float as well (grid.h:665 only switches to float for F == 1 -- with T = float it is float anyway)
+template <uint32_t D, uint32_t F>
+void grid_forward_f32(const GridArgs& a, const float* grid, const float* positions, float* encoded, float* dy_dx) {
+	const ParamsOffsetTable table = offset_table(a.n_levels, a.offsets);
+	MatrixView<const float> pos(positions, 1u, a.n_dims);
+	launch((a.n + 511) / 512, a.n_levels, 512, [&] {
+		kernel_grid<float, D, F, HashType::CoherentPrime>(a.n, a.n_levels * F, table, a.base_resolution, a.log2_per_level_scale, a.max_level, nullptr,
+		                                                  (InterpolationType)a.interpolation, (GridType)a.grid_type, grid, pos, encoded, dy_dx);
+	});
+}
+template <uint32_t D, uint32_t F>
+void grid_backward_f32(const GridArgs& a, const float* positions, const float* dL_dy, float* grid_gradient) {
+	const ParamsOffsetTable table = offset_table(a.n_levels, a.offsets);
+	MatrixView<const float> pos(positions, 1u, a.n_dims);
+	constexpr uint32_t FPT = F < 2 ? F : 2;
+	const uint32_t n_threads_total = a.n * F / FPT;
+	launch((n_threads_total + 255) / 256, a.n_levels, 256, [&] {
+		kernel_grid_backward<float, float, D, F, FPT, HashType::CoherentPrime>(a.n, a.n_levels * F, table, a.base_resolution, a.log2_per_level_scale, a.max_level, nullptr,
+		                                                                      a.stochastic != 0, (InterpolationType)a.interpolation, (GridType)a.grid_type, grid_gradient, pos, dL_dy);
+	});
+}
 // backward_backward_input_impl, grid.h:907-1042: dL_d(dL_dx) -> grid gradient (blocks (ceil(n * F / FPT / 256), n_levels), 256 threads;
 // grad_t as in backward_impl) and -> dL_dx (same launch shape; dL_dx zeroed first, :1011-1016)
 template <uint32_t D, uint32_t F>
@@ -199,6 +221,39 @@ int ref_grid_backward(uint32_t n_dims, uint32_t n_feat, uint32_t n, uint32_t n_l
 		return 1;
 	}
 	return 0;
+}
+// ---- the same kernels with T = float (the templates are above, outside the extern "C" block)
+int ref_grid_forward_f32(uint32_t n_dims, uint32_t n_feat, uint32_t n, uint32_t n_levels, const uint32_t* offsets, uint32_t base_resolution,
+                         float log2_per_level_scale, float max_level, int interpolation, int grid_type, const float* grid, const float* positions,
+                         float* encoded, float* dy_dx) {
+	try {
+		GridArgs a = {n_dims, n_feat, n, n_levels, offsets, base_resolution, log2_per_level_scale, max_level, interpolation, grid_type, 0};
+		dispatch_grid(n_dims, n_feat, [&](auto d, auto f) { grid_forward_f32<decltype(d)::value, decltype(f)::value>(a, grid, positions, encoded, dy_dx); });
+	} catch (...) {
+		return 1;
+	}
+	return 0;
+}
+// grid_gradient: fp32 [n_params]; the caller zeroes it (grid.h:865-867)
+int ref_grid_backward_f32(uint32_t n_dims, uint32_t n_feat, uint32_t n, uint32_t n_levels, const uint32_t* offsets, uint32_t base_resolution,
+                          float log2_per_level_scale, float max_level, int interpolation, int grid_type, const float* positions, const float* dL_dy,
+                          float* grid_gradient) {
+	try {
+		GridArgs a = {n_dims, n_feat, n, n_levels, offsets, base_resolution, log2_per_level_scale, max_level, interpolation, grid_type, 0};
+		dispatch_grid(n_dims, n_feat, [&](auto d, auto f) { grid_backward_f32<decltype(d)::value, decltype(f)::value>(a, positions, dL_dy, grid_gradient); });
+	} catch (...) {
+		return 1;
+	}
+	return 0;
+}
+int ref_grid_backward_input_f32(uint32_t n_dims, uint32_t n, uint32_t n_features, const float* dL_dy, const float* dy_dx, float* dL_dx) {
+	MatrixView<float> out(dL_dx, 1u, n_dims);
+	switch (n_dims) {
+		case 2: launch_linear(n, [&] { kernel_grid_backward_input<float, 2>(n, n_features, dL_dy, dy_dx, out); }); return 0;
+		case 3: launch_linear(n, [&] { kernel_grid_backward_input<float, 3>(n, n_features, dL_dy, dy_dx, out); }); return 0;
+		case 4: launch_linear(n, [&] { kernel_grid_backward_input<float, 4>(n, n_features, dL_dy, dy_dx, out); }); return 0;
+	}
+	return 1;
 }
 // kernel_grid_backward_input through linear_kernel (grid.h:897-905); dL_dx column-major (n_dims x n)
 int ref_grid_backward_input(uint32_t n_dims, uint32_t n, uint32_t n_features, const void* dL_dy, const float* dy_dx, float* dL_dx) {

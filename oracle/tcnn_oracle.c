@@ -648,6 +648,133 @@ void orc_grid_backward_input(const orc_grid* g, uint32_t n, const uint16_t* dL_d
 	}
 }
 
+/* ---- GridEncodingTemplated<float> (Encoding<float>, cpp_api.cu:165-168): the same three kernels with T = float.  Parameters, encoded
+ * features and gradients are fp32; the interpolation is result = fma((T)weight, value, result) in fp32 (grid.h:144-163), the scatter
+ * adds (T)weight * grad per corner and feature (grid.h:252-255) -- accumulated here in double (the exact sum of the fp32 products; the
+ * reference's fp32 atomics round after every addition, in launch order).  Layouts as in the 16-bit functions above. ---- */
+void orc_grid_forward_f32(const orc_grid* g, const float* params, const float* positions, uint32_t n, float* out, uint32_t out_stride, float* dy_dx) {
+	const uint32_t D = g->n_dims, L = g->n_levels, F = g->n_features_per_level, C = 1u << D;
+#pragma omp parallel for schedule(static)
+	for (long long ii = 0; ii < (long long)n; ++ii) {
+		uint32_t i = (uint32_t)ii;
+		float* o = out + (size_t)i * out_stride;
+		for (uint32_t c = L * F; c < out_stride; ++c) o[c] = 0.0f; /* grid.h:757-766 */
+		for (uint32_t level = 0; level < L; ++level) {
+			const float* grid = params + (size_t)g->offsets[level] * F;
+			const float scale = g->scale[level];
+			float pos[ORC_MAX_DIMS], pd[ORC_MAX_DIMS];
+			uint32_t pg[ORC_MAX_DIMS];
+			for (uint32_t d = 0; d < D; ++d) pos_fract(g, positions[(size_t)i * D + d], scale, &pos[d], &pd[d], &pg[d]);
+			if (dy_dx)
+				for (uint32_t f = 0; f < F; ++f)
+					for (uint32_t d = 0; d < D; ++d) dy_dx[((size_t)i * L * F + level * F + f) * D + d] = 0.0f;
+			if (g->interpolation == ORC_INTERP_NEAREST) {
+				uint32_t index = orc_grid_index(g, level, pg) * F;
+				for (uint32_t f = 0; f < F; ++f) o[level * F + f] = grid[index + f];
+				continue;
+			}
+			float result[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+			for (uint32_t idx = 0; idx < C; ++idx) {
+				float weight = 1;
+				uint32_t local[ORC_MAX_DIMS];
+				for (uint32_t d = 0; d < D; ++d) {
+					if ((idx & (1u << d)) == 0) {
+						weight *= 1 - pos[d];
+						local[d] = pg[d];
+					} else {
+						weight *= pos[d];
+						local[d] = pg[d] + 1;
+					}
+				}
+				uint32_t index = orc_grid_index(g, level, local) * F;
+				for (uint32_t f = 0; f < F; ++f) result[f] = fmaf(weight, grid[index + f], result[f]); /* grid.h:162, T = float */
+			}
+			for (uint32_t f = 0; f < F; ++f) o[level * F + f] = result[f];
+			if (dy_dx) { /* grid.h:172-211 */
+				for (uint32_t gd = 0; gd < D; ++gd) {
+					for (uint32_t idx = 0; idx < (C >> 1); ++idx) {
+						float weight = scale;
+						uint32_t local[ORC_MAX_DIMS];
+						for (uint32_t ngd = 0; ngd + 1 < D; ++ngd) {
+							const uint32_t dim = ngd >= gd ? (ngd + 1) : ngd;
+							if ((idx & (1u << ngd)) == 0) {
+								weight *= 1 - pos[dim];
+								local[dim] = pg[dim];
+							} else {
+								weight *= pos[dim];
+								local[dim] = pg[dim] + 1;
+							}
+						}
+						local[gd] = pg[gd];
+						uint32_t il = orc_grid_index(g, level, local) * F;
+						local[gd] = pg[gd] + 1;
+						uint32_t ir = orc_grid_index(g, level, local) * F;
+						for (uint32_t f = 0; f < F; ++f) {
+							float* dst = &dy_dx[((size_t)i * L * F + level * F + f) * D + gd];
+							float diff = grid[ir + f] - grid[il + f];
+							float t = weight * diff;
+							t = t * pd[gd];
+							*dst = *dst + t;
+						}
+					}
+				}
+			}
+		}
+	}
+}
+void orc_grid_backward_f32(const orc_grid* g, const float* positions, uint32_t n, const float* dL_dy, uint32_t dy_stride, double* grad) {
+	const uint32_t D = g->n_dims, L = g->n_levels, F = g->n_features_per_level, C = 1u << D;
+#pragma omp parallel for schedule(static)
+	for (long long ii = 0; ii < (long long)n; ++ii) {
+		uint32_t i = (uint32_t)ii;
+		for (uint32_t level = 0; level < L; ++level) {
+			double* gg = grad + (size_t)g->offsets[level] * F;
+			float pos[ORC_MAX_DIMS], pd[ORC_MAX_DIMS];
+			uint32_t pg[ORC_MAX_DIMS];
+			for (uint32_t d = 0; d < D; ++d) pos_fract(g, positions[(size_t)i * D + d], g->scale[level], &pos[d], &pd[d], &pg[d]);
+			const float* dy = dL_dy + (size_t)i * dy_stride + level * F;
+			const uint32_t n_corners = g->interpolation == ORC_INTERP_NEAREST ? 1u : C;
+			for (uint32_t idx = 0; idx < n_corners; ++idx) {
+				float weight = 1;
+				uint32_t local[ORC_MAX_DIMS];
+				for (uint32_t d = 0; d < D; ++d) {
+					if (g->interpolation == ORC_INTERP_NEAREST) {
+						local[d] = pg[d];
+					} else if ((idx & (1u << d)) == 0) {
+						weight *= 1 - pos[d];
+						local[d] = pg[d];
+					} else {
+						weight *= pos[d];
+						local[d] = pg[d] + 1;
+					}
+				}
+				uint32_t index = orc_grid_index(g, level, local) * F;
+				for (uint32_t f = 0; f < F; ++f) {
+					const double c = (double)(weight * dy[f]); /* (T)weight * grad, T = float (grid.h:254) */
+#pragma omp atomic
+					gg[index + f] += c;
+				}
+			}
+		}
+	}
+}
+void orc_grid_backward_input_f32(const orc_grid* g, uint32_t n, const float* dL_dy, uint32_t dy_stride, const float* dy_dx, float* dL_dx) {
+	const uint32_t D = g->n_dims, K = g->n_levels * g->n_features_per_level;
+#pragma omp parallel for schedule(static)
+	for (long long ii = 0; ii < (long long)n; ++ii) {
+		uint32_t i = (uint32_t)ii;
+		float result[ORC_MAX_DIMS] = {0, 0, 0, 0};
+		for (uint32_t k = 0; k < K; ++k) {
+			float dl = dL_dy[(size_t)i * dy_stride + k];
+			for (uint32_t d = 0; d < D; ++d) {
+				float t = dl * dy_dx[((size_t)i * K + k) * D + d];
+				result[d] = result[d] + t;
+			}
+		}
+		for (uint32_t d = 0; d < D; ++d) dL_dx[(size_t)i * D + d] = result[d];
+	}
+}
+
 /* ------------------------------------------------------------------ MLP */
 
 int orc_mlp_init(orc_mlp* m, uint32_t in_width, uint32_t width, uint32_t out_width, uint32_t n_hidden,

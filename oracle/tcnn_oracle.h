@@ -138,6 +138,11 @@ void orc_grid_backward_backward_input(const orc_grid* g, const uint16_t* params,
                                       uint16_t* dL_ddLdy, float* dL_dx);
 void orc_grid_backward_input(const orc_grid* g, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride,
                              const float* dy_dx, float* dL_dx);
+/* GridEncodingTemplated<float> (Encoding<float>, cpp_api.cu:165-168): fp32 parameters / features / gradients, fp32 fma interpolation;
+ * layouts as above; orc_grid_backward_f32 ADDS the exact (double) sums of the fp32 products into `grad`. */
+void orc_grid_forward_f32(const orc_grid* g, const float* params, const float* positions, uint32_t n, float* out, uint32_t out_stride, float* dy_dx);
+void orc_grid_backward_f32(const orc_grid* g, const float* positions, uint32_t n, const float* dL_dy, uint32_t dy_stride, double* grad);
+void orc_grid_backward_input_f32(const orc_grid* g, uint32_t n, const float* dL_dy, uint32_t dy_stride, const float* dy_dx, float* dL_dx);
 
 /* ---- MLP (cutlass_mlp.cu:162-316, fully_fused_mlp.cu:635-678 param layout) ---- */
 typedef struct {

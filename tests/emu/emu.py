@@ -101,6 +101,39 @@ def grid_forward(g, params_h, positions, soa=True, out_stride=None, want_dy_dx=F
     return (out, dy_dx) if want_dy_dx else out
 
 
+def grid_forward_f32(g, params, positions, out_stride=None, want_dy_dx=False):
+    """k_grid_forward_f32: fp32 parameters -> fp32 features [n][out_stride] (+ dy_dx [k][n][D])."""
+    og = g.og
+    positions = np.ascontiguousarray(positions, dtype=np.float32)
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    n = positions.shape[0]
+    k = og.n_levels * og.n_features_per_level
+    stride = out_stride or k
+    out = np.zeros((n, stride), dtype=np.float32)
+    dy_dx = np.zeros((k, n, og.n_dims), dtype=np.float32) if want_dy_dx else None
+    assert lib().emu_grid_forward_f32(C.byref(g.c), _p(positions), C.c_uint32(n), _p(params), _p(out), C.c_uint32(stride), _p(dy_dx)) == 0
+    return (out, dy_dx) if want_dy_dx else out
+
+
+def grid_backward_f32(g, positions, dL_dy, accumulate_into=None):
+    og = g.og
+    positions = np.ascontiguousarray(positions, dtype=np.float32)
+    dL_dy = np.ascontiguousarray(dL_dy, dtype=np.float32)
+    grad = np.full(og.n_params, 7.0, dtype=np.float32) if accumulate_into is None else accumulate_into  # overwrite mode must clear what is there
+    assert lib().emu_grid_backward_f32(C.byref(g.c), _p(positions), C.c_uint32(positions.shape[0]), _p(dL_dy), C.c_uint32(dL_dy.shape[1]), _p(grad),
+                                       C.c_int(int(accumulate_into is not None))) == 0
+    return grad
+
+
+def grid_backward_input_f32(g, dL_dy, dy_dx):
+    og = g.og
+    dL_dy = np.ascontiguousarray(dL_dy, dtype=np.float32)
+    n = dL_dy.shape[0]
+    out = np.zeros((n, og.n_dims), dtype=np.float32)
+    assert lib().emu_grid_backward_input_f32(C.byref(g.c), C.c_uint32(n), _p(dL_dy), C.c_uint32(dL_dy.shape[1]), _p(dy_dx), _p(out)) == 0
+    return out
+
+
 def set_grid_forward_lds(limit_bytes, min_samples):
     """Levels with tables up to limit_bytes are gathered out of LDS (k_grid_forward_lds) for batches of at least min_samples."""
     lib().emu_set_grid_forward_lds(C.c_uint32(limit_bytes), C.c_uint32(min_samples))

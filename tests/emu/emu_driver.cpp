@@ -120,6 +120,33 @@ int emu_grid_backward_input(const EmuGrid* e, uint32_t n, const uint16_t* dL_dy,
 	return 0;
 }
 
+// GridEncodingTemplated<float>: fp32 parameters / features / gradients (sample-major [n][stride] features and gradients)
+int emu_grid_forward_f32(const EmuGrid* e, const float* positions, uint32_t n, const float* params, float* out, uint32_t out_stride, float* dy_dx) {
+	try {
+		GridIO io = {positions, e->n_dims, 1, n, 1u, out_stride};
+		grid_forward_f32(nullptr, make_meta(e), io, params, out, dy_dx);
+	} catch (const std::exception& ex) {
+		fprintf(stderr, "emu_grid_forward_f32: %s\n", ex.what());
+		return 1;
+	}
+	return 0;
+}
+int emu_grid_backward_f32(const EmuGrid* e, const float* positions, uint32_t n, const float* dL_dy, uint32_t dy_stride, float* grad, int accumulate) {
+	try {
+		GridIO io = {positions, e->n_dims, 1, n, 1u, dy_stride};
+		grid_backward_f32(nullptr, make_meta(e), io, dL_dy, grad, accumulate != 0);
+	} catch (const std::exception& ex) {
+		fprintf(stderr, "emu_grid_backward_f32: %s\n", ex.what());
+		return 1;
+	}
+	return 0;
+}
+int emu_grid_backward_input_f32(const EmuGrid* e, uint32_t n, const float* dL_dy, uint32_t dy_stride, const float* dy_dx, float* dL_dx) {
+	GridIO io = {nullptr, e->n_dims, 1, n, 1u, dy_stride};
+	grid_backward_input_f32(nullptr, e->n_dims, e->n_levels * e->n_feat, io, dL_dy, dy_dx, dL_dx, e->n_dims, 1);
+	return 0;
+}
+
 int emu_grid_indices(const EmuGrid* e, const float* positions, uint32_t n, uint32_t* indices) {
 	GridIO io = {positions, e->n_dims, 1, n, n, 1};
 	grid_indices(nullptr, make_meta(e), io, indices);

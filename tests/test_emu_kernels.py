@@ -58,6 +58,33 @@ def test_grid_forward_bit_exact(case):
         emu.set_grid_forward_lds(0, 4096)
 
 
+@pytest.mark.parametrize("case", GRID_CASES)
+def test_grid_fp32_kernels(case):
+    """k_grid_forward_f32 / k_grid_backward_atomic_f32 / k_grid_backward_input<float> (Encoding<float>, cpp_api.cu:165-168) against the oracle's
+    fp32 restatement: features, dy_dx and the input gradient bit for bit; parameter gradients to the rounding of a running fp32 sum
+    (the emulator adds in thread order, the GPU in whatever order its atomics land); overwrite clears, accumulate adds."""
+    D, L, F, T, base, scale, gtype, interp = case
+    rng = np.random.default_rng(4)
+    og = O.grid_init(D, L, F, T, base, scale, gtype, interp)
+    g = emu.Grid(og)
+    n = 1000
+    pos = rng.random((n, D), dtype=np.float32)
+    pos[0], pos[1] = 0.0, 1.0
+    params = (rng.standard_normal(og.n_params) * 0.3).astype(np.float32)
+    ref, ref_dydx = O.grid_forward_f32(og, params, pos, want_dy_dx=True)
+    out, dydx = emu.grid_forward_f32(g, params, pos, out_stride=L * F + 8, want_dy_dx=True)
+    assert np.array_equal(out[:, :L * F].view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(np.transpose(dydx, (1, 0, 2)), ref_dydx)
+    dy = (rng.standard_normal((n, L * F)) * 1.0e4).astype(np.float32)
+    want, mag = O.grid_backward_f32(og, pos, dy), O.grid_backward_f32(og, pos, np.abs(dy))
+    got = emu.grid_backward_f32(g, pos, dy)
+    assert np.all(np.abs(got - want) <= 8 * n * 2.0 ** -24 * np.maximum(mag, 1e-30)) and not got[mag == 0].any()
+    twice = emu.grid_backward_f32(g, pos, dy, accumulate_into=got.copy())
+    assert np.all(np.abs(twice - 2 * want) <= 16 * n * 2.0 ** -24 * np.maximum(mag, 1e-30))
+    if interp != O.INTERP_NEAREST:
+        assert np.array_equal(emu.grid_backward_input_f32(g, dy, dydx), O.grid_backward_input_f32(og, dy, ref_dydx))
+
+
 @pytest.mark.parametrize("case", GRID_CASES + [(3, 4, 2, 16, 16, 2.0, O.GRID_HASH, O.INTERP_LINEAR)])  # last: > 1 slice per level
 @pytest.mark.parametrize("mode,lds_budget", [(emu.SLICED_F32, 0), (emu.SLICED_F16, 0), (emu.ATOMIC, 0), (emu.ATOMIC, 48 * 1024),
                                              (emu.BUCKETED, 0), (emu.BUCKETED, 1024)])  # 1 KiB slices: every level is bucketed

@@ -212,6 +212,50 @@ def test_grid_backward_input_bit_exact():
 
 
 @pytest.mark.parametrize("case", GRID_CASES)
+def test_grid_fp32_instantiation(case):
+    """GridEncodingTemplated<float> -- what create_encoding(..., Precision::Fp32) builds (cpp_api.cu:165-168): the reference's kernel_grid,
+    kernel_grid_backward and kernel_grid_backward_input instantiated with T = float against the oracle's fp32 restatement.  Features,
+    dy_dx and the input gradient bit for bit; parameter gradients: entries hit once bit for bit, the others to the rounding of the
+    reference's running fp32 atomic sums."""
+    g, R = _grid(case), ref()
+    D, F, L, T, base, pls, gtype, interp = case
+    n = 512 + 3
+    rng = np.random.default_rng(31)
+    params = (rng.standard_normal(g.n_params) * 0.3).astype(np.float32)
+    x = _positions(n, D, seed=6)
+    out, dy_dx = O.grid_forward_f32(g, params, x, want_dy_dx=True)
+    offsets = (C.c_uint32 * (L + 1))(*[g.offsets[l] for l in range(L + 1)])
+    log2_pls = R.ref_log2_per_level_scale(f32(pls))
+    enc = np.zeros((L * F, n), np.float32)
+    dyr = np.zeros((L * F, n, D), np.float32)
+    assert R.ref_grid_forward_f32(D, F, n, L, offsets, base, f32(log2_pls), f32(1.0), _ref_interp(interp), _ref_grid_type(gtype), p(params), p(x), p(enc), p(dyr)) == 0
+    assert np.array_equal(out.view(np.uint32), enc.T.copy().view(np.uint32))
+    assert np.array_equal(dy_dx, dyr.transpose(1, 0, 2))
+    # a gradient far outside the fp16 range: nothing is scaled or rounded to 16 bits on this path
+    dy = (rng.standard_normal((n, L * F)) * 1.0e4).astype(np.float32)
+    want = O.grid_backward_f32(g, x, dy)
+    got = np.zeros(g.n_params, np.float32)
+    assert R.ref_grid_backward_f32(D, F, n, L, offsets, base, f32(log2_pls), f32(1.0), _ref_interp(interp), _ref_grid_type(gtype), p(x), p(np.ascontiguousarray(dy.T)), p(got)) == 0
+    idx = O.grid_indices(g, x)
+    hits = np.zeros(g.n_params // F, np.int64)
+    corners = 1 if interp == O.INTERP_NEAREST else (1 << D)
+    for l in range(L):
+        np.add.at(hits, g.offsets[l] + idx[:, l, :corners].reshape(-1), 1)
+    hits = np.repeat(hits, F)
+    once = hits == 1
+    assert once.sum() > 10 and np.array_equal(got[once], want[once].astype(np.float32))
+    assert not got[hits == 0].any()
+    magnitude = O.grid_backward_f32(g, x, np.abs(dy))
+    many = hits > 1
+    assert np.all(np.abs(got[many] - want[many]) <= hits[many] * 2.0 ** -24 * magnitude[many] * 1.001)
+    if interp != O.INTERP_NEAREST:
+        want_dx = O.grid_backward_input_f32(g, dy, dy_dx)
+        got_dx = np.zeros((n, D), np.float32)
+        assert R.ref_grid_backward_input_f32(D, n, L * F, p(np.ascontiguousarray(dy.T)), p(np.ascontiguousarray(dy_dx.transpose(1, 0, 2))), p(got_dx)) == 0
+        assert np.array_equal(got_dx, want_dx)
+
+
+@pytest.mark.parametrize("case", GRID_CASES)
 def test_grid_second_order_kernels(case):
     """kernel_grid_backward_input_backward_grid / _backward_input / _backward_dLdoutput (grid.h:351-653) as backward_backward_input_impl
     launches them (grid.h:907-1042).  dL_ddLdy is one fp32 dot product per (sample, feature): bit-exact.  dL_dx is an fp32 atomicAdd per

@@ -870,6 +870,59 @@ static void encoding_backward(hipStream_t stream, const Model& md, const Forward
 	}
 }
 
+// ---- Encoding<float> (create_encoding(..., Precision::Fp32), cpp_api.cu:165-168): a bare encoding whose parameters, output and gradients are
+// fp32 and which COMPUTES in fp32, as the reference's instantiation does.  Output sample-major [n][padded] (cpp_api.cu:94-95).
+static void encoding_forward_f32(hipStream_t stream, const Model& md, uint32_t n, const float* input, const float* params, float* out, ForwardCtx* ctx,
+                                 bool prepare_input_gradients) {
+	check_batch(n, widest_matrix(md));
+	if (n == 0) return;
+	const EncodingDesc& e = md.enc;
+	if (ctx) {
+		ctx->stream = stream;
+		ctx->n = n;
+	}
+	const uint32_t stride_k = 1u, stride_i = e.padded_output_width;
+	if (e.is_grid) {
+		float* dy_dx = nullptr;
+		if (ctx && prepare_input_gradients) {
+			ctx->dy_dx = Scratch(stream, (size_t)e.n_output_dims * n * md.n_input_dims * sizeof(float));
+			dy_dx = ctx->dy_dx.as<float>();
+		}
+		GridIO io = {input, in_stride_i(md), in_stride_d(), n, stride_k, stride_i};
+		grid_forward_f32(stream, e.grid, io, params, out, dy_dx);
+		const uint32_t n_to_pad = e.padded_output_width - e.n_output_dims;
+		if (n_to_pad > 0) HIP_CHECK(hipMemset2DAsync(out + e.n_output_dims, (size_t)e.padded_output_width * sizeof(float), 0, (size_t)n_to_pad * sizeof(float), n, stream));
+	} else if (e.is_frequency) {
+		frequency_forward(stream, n, e.n_dims, e.n_frequencies, e.padded_output_width, input, in_stride_i(md), in_stride_d(), out, stride_k, stride_i);
+	} else if (e.is_oneblob) {
+		oneblob_forward(stream, n, e.n_dims, e.n_bins, e.padded_output_width, input, in_stride_i(md), in_stride_d(), out, stride_k, stride_i);
+	} else {
+		identity_forward(stream, n, e.n_dims, e.padded_output_width, e.id_scale, e.id_offset, input, in_stride_i(md), in_stride_d(), out, stride_k, stride_i);
+	}
+}
+static void encoding_backward_f32(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const float* dL_doutput, float* dL_dparams,
+                                  const float* input) {
+	check_batch(n, widest_matrix(md));
+	if (n == 0) return;
+	if (ctx.n != n) throw std::runtime_error("backward: batch size does not match the forward context");
+	const EncodingDesc& e = md.enc;
+	const uint32_t stride_k = 1u, stride_i = e.padded_output_width;
+	if (e.is_grid) {
+		GridIO io = {input, in_stride_i(md), in_stride_d(), n, stride_k, stride_i};
+		if (dL_dparams && e.n_params > 0) grid_backward_f32(stream, e.grid, io, dL_doutput, dL_dparams, /*accumulate=*/false);  // GradientMode::Overwrite, cpp_api.cu:115
+		if (dL_dinput) {
+			if (!ctx.dy_dx.ptr) throw std::runtime_error("backward: dL_dinput requested but forward was not run with prepare_input_gradients");
+			grid_backward_input_f32(stream, md.n_input_dims, e.n_output_dims, io, dL_doutput, ctx.dy_dx.as<float>(), dL_dinput, dx_stride_i(md), dx_stride_d());
+		}
+	} else if (dL_dinput && e.is_frequency) {
+		frequency_backward(stream, n, e.n_dims, e.n_frequencies, dL_doutput, stride_k, stride_i, input, in_stride_i(md), in_stride_d(), dL_dinput, dx_stride_i(md), dx_stride_d());
+	} else if (dL_dinput && e.is_oneblob) {
+		oneblob_backward(stream, n, e.n_dims, e.n_bins, dL_doutput, stride_k, stride_i, input, in_stride_i(md), in_stride_d(), dL_dinput, dx_stride_i(md), dx_stride_d());
+	} else if (dL_dinput) {
+		identity_backward(stream, n, e.n_dims, e.id_scale, dL_doutput, stride_k, stride_i, dL_dinput, dx_stride_i(md), dx_stride_d());
+	}
+}
+
 static Model make_nwie(uint32_t n_input_dims, uint32_t n_output_dims, const Json& encoding, const Json& network) {
 	Model md;
 	md.n_input_dims = n_input_dims;
@@ -891,12 +944,12 @@ struct tcnn_module {
 	Model md;
 	std::string name;
 	uint32_t lds_level_budget = 0;  // 0: default LDS slice size of the sliced grid backward
-	// create_encoding(..., Precision::Fp32) (cpp_api.cu:165-174 -> Encoding<float>): parameters, outputs and gradients cross the
-	// boundary as fp32; the kernels compute in the library's 16-bit type (the caller's loss scale is 1 for fp32, cpp_api.h:77,
-	// so gradients are scaled into that type's range on the way in and back, exactly, on the way out: by the largest power of two
-	// <= FP32_GRADIENT_SCALE that keeps max |dL_doutput| * scale <= FP32_GRADIENT_TARGET (found on the device per call), so a large
-	// fp32 gradient neither overflows fp16 nor turns the result into NaN.  "fp32 I/O, 16-bit compute": values keep the 16-bit type's
-	// resolution; the reference's Encoding<float> computes in fp32.
+	// create_encoding(..., Precision::Fp32) (cpp_api.cu:165-174 -> Encoding<float>): parameters, outputs and gradients are fp32 and the
+	// first-order passes COMPUTE in fp32 (encoding_forward_f32 / encoding_backward_f32: the grid's kernel_grid<float> formulation, fp32
+	// global atomics for its parameter gradients; frequency / one-blob / identity with float values).  Only the second-order pass
+	// (backward_backward_input, grid only) still goes through 16-bit stand-ins of the caller's tensors: incoming gradients are scaled
+	// into that type's range by the largest power of two <= FP32_GRADIENT_SCALE that keeps max |dL_doutput| * scale <=
+	// FP32_GRADIENT_TARGET (found on the device per call) and the results scaled back, exactly.
 	bool fp32_io = false;
 };
 static constexpr float FP32_GRADIENT_SCALE = 1024.0f, FP32_GRADIENT_TARGET = 16384.0f;
@@ -1158,10 +1211,7 @@ int tcnn_module_inference(tcnn_module_t* m, tcnn_stream_t stream_, uint32_t n, c
 	TCNN_API_BEGIN
 	hipStream_t stream = (hipStream_t)stream_;
 	if (m->fp32_io) {
-		const size_t n_out = (size_t)n * m->md.padded_output_width();
-		Scratch p = Fp32Bridge::to_half(stream, params, m->md.n_params()), out(stream, std::max<size_t>(n_out, 1) * sizeof(half_t));
-		model_forward(stream, m->md, n, input, out.as<half_t>(), p.as<half_t>(), nullptr, false);
-		cast_f16_to_f32(stream, n_out, out.as<half_t>(), (float*)output);
+		encoding_forward_f32(stream, m->md, n, input, (const float*)params, (float*)output, nullptr, false);
 		return TCNN_OK;
 	}
 	model_forward(stream, m->md, n, input, (half_t*)output, (const half_t*)params, nullptr, false);
@@ -1174,10 +1224,7 @@ int tcnn_module_forward(tcnn_module_t* m, tcnn_stream_t stream_, uint32_t n, con
 	hipStream_t stream = (hipStream_t)stream_;
 	auto c = std::make_unique<tcnn_context>();
 	if (m->fp32_io) {
-		const size_t n_out = (size_t)n * m->md.padded_output_width();
-		Scratch p = Fp32Bridge::to_half(stream, params, m->md.n_params()), out(stream, std::max<size_t>(n_out, 1) * sizeof(half_t));
-		model_forward(stream, m->md, n, input, out.as<half_t>(), p.as<half_t>(), &c->ctx, prepare_input_gradients != 0);
-		cast_f16_to_f32(stream, n_out, out.as<half_t>(), (float*)output);
+		encoding_forward_f32(stream, m->md, n, input, (const float*)params, (float*)output, &c->ctx, prepare_input_gradients != 0);
 	} else {
 		model_forward(stream, m->md, n, input, (half_t*)output, (const half_t*)params, &c->ctx, prepare_input_gradients != 0);
 	}
@@ -1190,16 +1237,9 @@ int tcnn_module_backward(tcnn_module_t* m, tcnn_stream_t stream, const tcnn_cont
 	(void)output;
 	TCNN_API_BEGIN
 	if (!ctx) throw std::runtime_error("backward: missing forward context");
-	if (m->fp32_io) {  // bare encodings only: `output` is not needed by their backward pass
-		hipStream_t s = (hipStream_t)stream;
-		const size_t n_out = (size_t)n * m->md.padded_output_width(), n_params = m->md.n_params();
-		Scratch gscale;
-		Scratch dy = Fp32Bridge::gradient_to_half(s, dL_doutput, n_out, gscale), p = Fp32Bridge::to_half(s, params, n_params), dp;
-		if (dL_dparams) dp = Scratch(s, std::max<size_t>(n_params, 1) * sizeof(half_t));
-		model_backward(s, m->md, ctx->ctx, n, dL_dinput, dy.as<half_t>(), dL_dparams ? dp.as<half_t>() : nullptr, input, nullptr, p.as<half_t>(),
-		               dL_dparams ? TCNN_GRADIENT_OVERWRITE : TCNN_GRADIENT_IGNORE, m->lds_level_budget);
-		if (dL_dparams) cast_scaled_f16_to_f32(s, n_params, dp.as<half_t>(), (float*)dL_dparams, (const float*)(gscale.as<float>() + 1));
-		if (dL_dinput) scale_f32(s, (size_t)n * m->md.n_input_dims, dL_dinput, (const float*)(gscale.as<float>() + 1));
+	if (m->fp32_io) {  // bare encodings only: neither `output` nor the parameters are needed by their first-order backward pass
+		(void)params;
+		encoding_backward_f32((hipStream_t)stream, m->md, ctx->ctx, n, dL_dinput, (const float*)dL_doutput, (float*)dL_dparams, input);
 		return TCNN_OK;
 	}
 	model_backward((hipStream_t)stream, m->md, ctx->ctx, n, dL_dinput, (const half_t*)dL_doutput, (half_t*)dL_dparams, input, (const half_t*)output,

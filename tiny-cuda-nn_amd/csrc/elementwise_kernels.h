@@ -139,4 +139,19 @@ void oneblob_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n
 void oneblob_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_bins, const half_t* dL_dy, uint32_t stride_k, uint32_t stride_i, const float* in,
                       uint32_t in_stride_i, uint32_t in_stride_j, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j);
 
+// The same three encodings with fp32 values (Encoding<float>: create_encoding(..., Precision::Fp32), cpp_api.cu:165-168): encoded features
+// and incoming gradients are float, nothing is rounded to 16 bits.
+void identity_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t padded, float scale, float offset, const float* in, uint32_t in_stride_i,
+                      uint32_t in_stride_j, float* out, uint32_t stride_k, uint32_t stride_i);
+void identity_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, float scale, const float* dL_dy, uint32_t stride_k, uint32_t stride_i, float* dL_dx,
+                       uint32_t dx_stride_i, uint32_t dx_stride_j);
+void frequency_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_frequencies, uint32_t padded, const float* in, uint32_t in_stride_i,
+                       uint32_t in_stride_j, float* out, uint32_t stride_k, uint32_t stride_i);
+void frequency_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const float* dL_dy, uint32_t stride_k, uint32_t stride_i,
+                        const float* in, uint32_t in_stride_i, uint32_t in_stride_j, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j);
+void oneblob_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_bins, uint32_t padded, const float* in, uint32_t in_stride_i,
+                     uint32_t in_stride_j, float* out, uint32_t stride_k, uint32_t stride_i);
+void oneblob_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_bins, const float* dL_dy, uint32_t stride_k, uint32_t stride_i, const float* in,
+                      uint32_t in_stride_i, uint32_t in_stride_j, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j);
+
 }  // namespace tcnn_hip

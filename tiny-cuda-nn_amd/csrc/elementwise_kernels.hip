@@ -2,6 +2,7 @@
 // 16-byte accesses per lane, grid-stride where it matters, no host synchronisation.
 // Build with -ffp-contract=off (loss / Adam arithmetic is checked against the CPU oracle).
 #include "elementwise_kernels.h"
+#include <type_traits>
 #include "adam_device.h"
 
 #include <cmath>
@@ -555,20 +556,28 @@ void adam_convert_step_representation(hipStream_t stream, uint32_t n, uint32_t s
 	}
 }
 
+// The element-wise encodings write their value type VAL_T: the library's 16-bit type (rounded to nearest even, as the reference's
+// (T) casts do), or float for the fp32 encodings of create_encoding(..., Precision::Fp32) (Encoding<float>, cpp_api.cu:165-168).
+template <typename VAL_T>
+TCNN_DEVICE VAL_T encoded_value(float v) {
+	if constexpr (std::is_same<VAL_T, float>::value) return v;
+	else return to_half_rn(v);
+}
 // ------------------------------------------------------------------------------------------ identity
+template <typename VAL_T>
 __global__ void k_identity_forward(uint32_t n, uint32_t n_dims, uint32_t padded, float scale, float offset, const float* __restrict__ in,
-                                   uint32_t in_stride_i, uint32_t in_stride_j, half_t* __restrict__ out, uint32_t stride_k, uint32_t stride_i) {
+                                   uint32_t in_stride_i, uint32_t in_stride_j, VAL_T* __restrict__ out, uint32_t stride_k, uint32_t stride_i) {
 	// thread -> (k, i) with i fastest: coalesced for the feature-major output the MLP kernels read
 	const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
 	if (e >= n * padded) return;
 	const uint32_t k = e / n, i = e - k * n;
-	half_t v;
+	VAL_T v;
 	if (k >= n_dims) {
-		v = (half_t)1.0f;  // identity.h:62-64
+		v = (VAL_T)1.0f;  // identity.h:62-64
 	} else {
 		float t = in[(size_t)i * in_stride_i + (size_t)k * in_stride_j] * scale;
 		t = t + offset;
-		v = to_half_rn(t);
+		v = encoded_value<VAL_T>(t);
 	}
 	out[(size_t)k * stride_k + (size_t)i * stride_i] = v;
 }
@@ -617,13 +626,14 @@ __global__ void __launch_bounds__(EW_THREADS) k_identity_forward_transpose(uint3
 		}
 	}
 }
-__global__ void k_identity_backward(uint32_t n, uint32_t n_dims, float scale, const half_t* __restrict__ dL_dy, uint32_t stride_k,
+template <typename VAL_T>
+__global__ void k_identity_backward(uint32_t n, uint32_t n_dims, float scale, const VAL_T* __restrict__ dL_dy, uint32_t stride_k,
                                     uint32_t stride_i, float* __restrict__ dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
 	const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
 	if (e >= n * n_dims) return;
 	const uint32_t k = e / n, i = e - k * n;
 	// identity.h:83: (T)((float)dL_dy * scale) -- rounded through half, then widened to the fp32 dL_dx
-	dL_dx[(size_t)i * dx_stride_i + (size_t)k * dx_stride_j] = (float)to_half_rn((float)dL_dy[(size_t)k * stride_k + (size_t)i * stride_i] * scale);
+	dL_dx[(size_t)i * dx_stride_i + (size_t)k * dx_stride_j] = (float)encoded_value<VAL_T>((float)dL_dy[(size_t)k * stride_k + (size_t)i * stride_i] * scale);
 }
 
 void identity_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t padded, float scale, float offset, const float* in,
@@ -635,12 +645,22 @@ void identity_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t 
 		TCNN_LAUNCH(k_identity_forward_transpose, dim3(div_round_up(n, ID_TILE)), dim3(EW_THREADS), lds, stream, n, n_dims, padded, scale, offset, in, out);
 		return;
 	}
-	TCNN_LAUNCH(k_identity_forward, dim3(div_round_up(n * padded, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, padded, scale, offset, in, in_stride_i, in_stride_j, out, stride_k, stride_i);
+	TCNN_LAUNCH(k_identity_forward<half_t>, dim3(div_round_up(n * padded, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, padded, scale, offset, in, in_stride_i, in_stride_j, out, stride_k, stride_i);
+}
+void identity_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t padded, float scale, float offset, const float* in,
+                      uint32_t in_stride_i, uint32_t in_stride_j, float* out, uint32_t stride_k, uint32_t stride_i) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_identity_forward<float>, dim3(div_round_up(n * padded, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, padded, scale, offset, in, in_stride_i, in_stride_j, out, stride_k, stride_i);
 }
 void identity_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, float scale, const half_t* dL_dy, uint32_t stride_k, uint32_t stride_i,
                        float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
 	if (n == 0) return;
-	TCNN_LAUNCH(k_identity_backward, dim3(div_round_up(n * n_dims, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, scale, dL_dy, stride_k, stride_i, dL_dx, dx_stride_i, dx_stride_j);
+	TCNN_LAUNCH(k_identity_backward<half_t>, dim3(div_round_up(n * n_dims, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, scale, dL_dy, stride_k, stride_i, dL_dx, dx_stride_i, dx_stride_j);
+}
+void identity_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, float scale, const float* dL_dy, uint32_t stride_k, uint32_t stride_i,
+                       float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_identity_backward<float>, dim3(div_round_up(n * n_dims, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, scale, dL_dy, stride_k, stride_i, dL_dx, dx_stride_i, dx_stride_j);
 }
 
 // ------------------------------------------------------------------------------------------ frequency
@@ -650,23 +670,25 @@ void identity_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, float sc
 // x 2^f * pi + phase, so parity with the reference is to its intrinsic's accuracy (a fp16 ulp at these magnitudes), parity
 // between kernel and oracle to libm rounding.  One thread per output element (k-major, i fastest).
 #define TCNN_PI_F 3.14159265358979323846f
+template <typename VAL_T>
 __global__ void __launch_bounds__(EW_THREADS) k_frequency_forward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, uint32_t padded, const float* __restrict__ in,
-                                                                  uint32_t in_stride_i, uint32_t in_stride_j, half_t* __restrict__ out, uint32_t stride_k,
+                                                                  uint32_t in_stride_i, uint32_t in_stride_j, VAL_T* __restrict__ out, uint32_t stride_k,
                                                                   uint32_t stride_i) {
 	const uint32_t e = blockIdx.x * EW_THREADS + threadIdx.x;
 	if (e >= n * padded) return;
 	const uint32_t j = e / n, i = e - j * n;
-	half_t v = (half_t)1.0f;
+	VAL_T v = (VAL_T)1.0f;
 	if (j < n_dims * n_frequencies * 2u) {
 		const uint32_t d = j / (n_frequencies * 2u), log2_frequency = (j / 2u) % n_frequencies;
 		const float phase_shift = (float)(j % 2u) * (TCNN_PI_F / 2);
 		const float x = __builtin_scalbnf(in[(size_t)i * in_stride_i + (size_t)d * in_stride_j], (int)log2_frequency);
 		const float input = x * TCNN_PI_F + phase_shift;
-		v = to_half_rn(sinf(input));
+		v = encoded_value<VAL_T>(sinf(input));
 	}
 	out[(size_t)j * stride_k + (size_t)i * stride_i] = v;
 }
-__global__ void __launch_bounds__(EW_THREADS) k_frequency_backward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const half_t* __restrict__ dL_dy,
+template <typename VAL_T>
+__global__ void __launch_bounds__(EW_THREADS) k_frequency_backward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const VAL_T* __restrict__ dL_dy,
                                                                    uint32_t stride_k, uint32_t stride_i, const float* __restrict__ in, uint32_t in_stride_i,
                                                                    uint32_t in_stride_j, float* __restrict__ dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
 	const uint32_t e = blockIdx.x * EW_THREADS + threadIdx.x;
@@ -683,17 +705,35 @@ __global__ void __launch_bounds__(EW_THREADS) k_frequency_backward(uint32_t n, u
 	}
 	dL_dx[(size_t)i * dx_stride_i + (size_t)d * dx_stride_j] = result;
 }
+template <typename VAL_T>
+static void frequency_forward_t(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_frequencies, uint32_t padded, const float* in, uint32_t in_stride_i,
+                                uint32_t in_stride_j, VAL_T* out, uint32_t stride_k, uint32_t stride_i) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_frequency_forward<VAL_T>, dim3(div_round_up(n * padded, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, n_frequencies, padded, in, in_stride_i,
+	            in_stride_j, out, stride_k, stride_i);
+}
+template <typename VAL_T>
+static void frequency_backward_t(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const VAL_T* dL_dy, uint32_t stride_k, uint32_t stride_i,
+                                 const float* in, uint32_t in_stride_i, uint32_t in_stride_j, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
+	if (n == 0) return;
+	TCNN_LAUNCH(k_frequency_backward<VAL_T>, dim3(div_round_up(n * n_dims, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, n_frequencies, dL_dy, stride_k, stride_i, in,
+	            in_stride_i, in_stride_j, dL_dx, dx_stride_i, dx_stride_j);
+}
 void frequency_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_frequencies, uint32_t padded, const float* in, uint32_t in_stride_i,
                        uint32_t in_stride_j, half_t* out, uint32_t stride_k, uint32_t stride_i) {
-	if (n == 0) return;
-	TCNN_LAUNCH(k_frequency_forward, dim3(div_round_up(n * padded, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, n_frequencies, padded, in, in_stride_i,
-	            in_stride_j, out, stride_k, stride_i);
+	frequency_forward_t<half_t>(stream, n, n_dims, n_frequencies, padded, in, in_stride_i, in_stride_j, out, stride_k, stride_i);
+}
+void frequency_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_frequencies, uint32_t padded, const float* in, uint32_t in_stride_i,
+                       uint32_t in_stride_j, float* out, uint32_t stride_k, uint32_t stride_i) {
+	frequency_forward_t<float>(stream, n, n_dims, n_frequencies, padded, in, in_stride_i, in_stride_j, out, stride_k, stride_i);
 }
 void frequency_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const half_t* dL_dy, uint32_t stride_k, uint32_t stride_i,
                         const float* in, uint32_t in_stride_i, uint32_t in_stride_j, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
-	if (n == 0) return;
-	TCNN_LAUNCH(k_frequency_backward, dim3(div_round_up(n * n_dims, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, n_frequencies, dL_dy, stride_k, stride_i, in,
-	            in_stride_i, in_stride_j, dL_dx, dx_stride_i, dx_stride_j);
+	frequency_backward_t<half_t>(stream, n, n_dims, n_frequencies, dL_dy, stride_k, stride_i, in, in_stride_i, in_stride_j, dL_dx, dx_stride_i, dx_stride_j);
+}
+void frequency_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const float* dL_dy, uint32_t stride_k, uint32_t stride_i,
+                        const float* in, uint32_t in_stride_i, uint32_t in_stride_j, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
+	frequency_backward_t<float>(stream, n, n_dims, n_frequencies, dL_dy, stride_k, stride_i, in, in_stride_i, in_stride_j, dL_dx, dx_stride_i, dx_stride_j);
 }
 
 // ------------------------------------------------------------------------------------------ one-blob
@@ -711,8 +751,9 @@ TCNN_DEVICE float quartic_cdf(float x, float inv_radius) {
 	const float u4 = u2 * u2;
 	return __builtin_fmaxf(0.0f, __builtin_fminf(1.0f, ((float)15 / 16) * u * (1 - ((float)2 / 3) * u2 + ((float)1 / 5) * u4) + 0.5f));
 }
+template <typename VAL_T>
 __global__ void __launch_bounds__(EW_THREADS) k_oneblob_forward(uint32_t n, uint32_t n_dims, uint32_t log2_bins, uint32_t padded, const float* __restrict__ in,
-                                                                uint32_t in_stride_i, uint32_t in_stride_j, half_t* __restrict__ out, uint32_t stride_k,
+                                                                uint32_t in_stride_i, uint32_t in_stride_j, VAL_T* __restrict__ out, uint32_t stride_k,
                                                                 uint32_t stride_i) {
 	const uint32_t e = blockIdx.x * EW_THREADS + threadIdx.x;
 	const uint32_t n_bins = 1u << log2_bins, n_out = n_dims * n_bins;
@@ -724,15 +765,16 @@ __global__ void __launch_bounds__(EW_THREADS) k_oneblob_forward(uint32_t n, uint
 		for (uint32_t k = 0; k < n_bins; ++k) {
 			const float right_boundary = (float)(k + 1) * inv_bins;
 			const float right_cdf = quartic_cdf(right_boundary - x, nb) + quartic_cdf(right_boundary - x - 1.0f, nb) + quartic_cdf(right_boundary - x + 1.0f, nb);
-			out[(size_t)(j * n_bins + k) * stride_k + (size_t)i * stride_i] = to_half_rn(right_cdf - left_cdf);
+			out[(size_t)(j * n_bins + k) * stride_k + (size_t)i * stride_i] = encoded_value<VAL_T>(right_cdf - left_cdf);
 			left_cdf = right_cdf;
 		}
 	} else if (e < n * n_dims + n * (padded - n_out)) {  // oneblob.h:214-216, 232-234: padding is 1
 		const uint32_t q = e - n * n_dims, k = n_out + q / n, i = q % n;
-		out[(size_t)k * stride_k + (size_t)i * stride_i] = (half_t)1.0f;
+		out[(size_t)k * stride_k + (size_t)i * stride_i] = (VAL_T)1.0f;
 	}
 }
-__global__ void __launch_bounds__(EW_THREADS) k_oneblob_backward(uint32_t n, uint32_t n_dims, uint32_t log2_bins, const half_t* __restrict__ dL_dy, uint32_t stride_k,
+template <typename VAL_T>
+__global__ void __launch_bounds__(EW_THREADS) k_oneblob_backward(uint32_t n, uint32_t n_dims, uint32_t log2_bins, const VAL_T* __restrict__ dL_dy, uint32_t stride_k,
                                                                  uint32_t stride_i, const float* __restrict__ in, uint32_t in_stride_i, uint32_t in_stride_j,
                                                                  float* __restrict__ dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
 	const uint32_t e = blockIdx.x * EW_THREADS + threadIdx.x;
@@ -752,22 +794,40 @@ __global__ void __launch_bounds__(EW_THREADS) k_oneblob_backward(uint32_t n, uin
 	dL_dx[(size_t)i * dx_stride_i + (size_t)j * dx_stride_j] = result;
 }
 
-void oneblob_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_bins, uint32_t padded, const float* in, uint32_t in_stride_i,
-                     uint32_t in_stride_j, half_t* out, uint32_t stride_k, uint32_t stride_i) {
+template <typename VAL_T>
+static void oneblob_forward_t(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_bins, uint32_t padded, const float* in, uint32_t in_stride_i,
+                              uint32_t in_stride_j, VAL_T* out, uint32_t stride_k, uint32_t stride_i) {
 	if (n == 0) return;
 	uint32_t log2_bins = 0;
 	while ((1u << log2_bins) < n_bins) ++log2_bins;
 	const uint32_t work = n * n_dims + n * (padded - n_dims * n_bins);
-	TCNN_LAUNCH(k_oneblob_forward, dim3(div_round_up(work, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, log2_bins, padded, in, in_stride_i, in_stride_j, out,
+	TCNN_LAUNCH(k_oneblob_forward<VAL_T>, dim3(div_round_up(work, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, log2_bins, padded, in, in_stride_i, in_stride_j, out,
 	            stride_k, stride_i);
 }
-void oneblob_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_bins, const half_t* dL_dy, uint32_t stride_k, uint32_t stride_i, const float* in,
-                      uint32_t in_stride_i, uint32_t in_stride_j, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
+template <typename VAL_T>
+static void oneblob_backward_t(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_bins, const VAL_T* dL_dy, uint32_t stride_k, uint32_t stride_i, const float* in,
+                               uint32_t in_stride_i, uint32_t in_stride_j, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
 	if (n == 0) return;
 	uint32_t log2_bins = 0;
 	while ((1u << log2_bins) < n_bins) ++log2_bins;
-	TCNN_LAUNCH(k_oneblob_backward, dim3(div_round_up(n * n_dims, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, log2_bins, dL_dy, stride_k, stride_i, in,
+	TCNN_LAUNCH(k_oneblob_backward<VAL_T>, dim3(div_round_up(n * n_dims, EW_THREADS)), dim3(EW_THREADS), 0, stream, n, n_dims, log2_bins, dL_dy, stride_k, stride_i, in,
 	            in_stride_i, in_stride_j, dL_dx, dx_stride_i, dx_stride_j);
+}
+void oneblob_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_bins, uint32_t padded, const float* in, uint32_t in_stride_i,
+                     uint32_t in_stride_j, half_t* out, uint32_t stride_k, uint32_t stride_i) {
+	oneblob_forward_t<half_t>(stream, n, n_dims, n_bins, padded, in, in_stride_i, in_stride_j, out, stride_k, stride_i);
+}
+void oneblob_forward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_bins, uint32_t padded, const float* in, uint32_t in_stride_i,
+                     uint32_t in_stride_j, float* out, uint32_t stride_k, uint32_t stride_i) {
+	oneblob_forward_t<float>(stream, n, n_dims, n_bins, padded, in, in_stride_i, in_stride_j, out, stride_k, stride_i);
+}
+void oneblob_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_bins, const half_t* dL_dy, uint32_t stride_k, uint32_t stride_i, const float* in,
+                      uint32_t in_stride_i, uint32_t in_stride_j, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
+	oneblob_backward_t<half_t>(stream, n, n_dims, n_bins, dL_dy, stride_k, stride_i, in, in_stride_i, in_stride_j, dL_dx, dx_stride_i, dx_stride_j);
+}
+void oneblob_backward(hipStream_t stream, uint32_t n, uint32_t n_dims, uint32_t n_bins, const float* dL_dy, uint32_t stride_k, uint32_t stride_i, const float* in,
+                      uint32_t in_stride_i, uint32_t in_stride_j, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_j) {
+	oneblob_backward_t<float>(stream, n, n_dims, n_bins, dL_dy, stride_k, stride_i, in, in_stride_i, in_stride_j, dL_dx, dx_stride_i, dx_stride_j);
 }
 
 }  // namespace tcnn_hip

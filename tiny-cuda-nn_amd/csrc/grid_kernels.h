@@ -117,6 +117,13 @@ void grid_backward_input(hipStream_t stream, uint32_t n_dims, uint32_t n_feature
                          const half_t* dL_dy, const float* dy_dx, float* dL_dx, uint32_t dx_stride_i,
                          uint32_t dx_stride_d);
 
+// ---- fp32 encodings: GridEncodingTemplated<float> (cpp_api.cu:165-168).  Parameters / encoded features / gradients fp32, the reference's
+// formulation (fp32 fma interpolation, one fp32 global atomic per corner and feature); same GridIO addressing as above.
+void grid_forward_f32(hipStream_t stream, const GridMeta& meta, const GridIO& io, const float* params, float* out, float* dy_dx = nullptr);
+void grid_backward_f32(hipStream_t stream, const GridMeta& meta, const GridIO& io, const float* dL_dy, float* grid_gradient, bool accumulate);
+void grid_backward_input_f32(hipStream_t stream, uint32_t n_dims, uint32_t n_features, const GridIO& io, const float* dL_dy, const float* dy_dx, float* dL_dx,
+                             uint32_t dx_stride_i, uint32_t dx_stride_d);
+
 // ---- second order: gradients of dL_dx = sum_k dL_dy[k] * dy_dx[k] (the first backward's input gradient) --------------
 // (grid.h:352-655, 910-1042: what SDF / eikonal losses differentiate through)
 //  * w.r.t. the grid parameters: grid_backward() with io.ddx set -- the same scatter with the corner weight

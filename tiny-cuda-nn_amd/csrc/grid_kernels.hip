@@ -518,6 +518,129 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_backward_atomic(const Gri
 }
 
 // =============================================================================================
+// fp32 encodings: GridEncodingTemplated<float> (what cpp_api.cu:165-168 instantiates for create_encoding(..., Precision::Fp32),
+// tcnn.Encoding(dtype=torch.float32)).  Parameters, encoded features and gradients are fp32; the interpolation is the reference's
+// kernel_grid<float> -- fp32 weights, result = fma(weight, value, result) in fp32 (grid.h:144-163) --, the backward pass its
+// kernel_grid_backward<float, float>: one fp32 global atomic per corner and feature (grid.h:252-255; gradients of any magnitude survive,
+// nothing is scaled).  Not a hot path of the step (the trainer's encoding is 16-bit): one thread per (sample, level), the reference's
+// formulation; same index / weight code as the 16-bit kernels above.
+// =============================================================================================
+template <uint32_t D, uint32_t F, bool DYDX>
+__global__ void __launch_bounds__(GRID_THREADS) k_grid_forward_f32(const GridMeta meta, const GridIO io, const float* __restrict__ params, float* __restrict__ out,
+                                                                    float* __restrict__ dy_dx) {
+	uint32_t level, tile;
+	if (!grid_work_item(meta.n_levels, div_round_up(io.n, GRID_TILE), level, tile)) return;
+	const Level<D> lv = make_level<D>(meta, level);
+	const float* __restrict__ grid = params + (size_t)meta.offset[level] * F;
+	const uint32_t n_features = meta.n_levels * F;
+	const float max_level = (meta.max_level * (float)n_features) / (float)F;  // grid.h:72
+	const bool level_off = (float)level >= max_level + 1e-3f;               // grid.h:75
+	for (uint32_t s = 0; s < GRID_SPT; ++s) {
+		const uint32_t i = tile * GRID_TILE + s * GRID_THREADS + threadIdx.x;
+		if (i >= io.n) continue;
+		float result[F], grads[DYDX ? F : 1][D];
+#pragma unroll
+		for (uint32_t f = 0; f < F; ++f) result[f] = 0.0f;
+#pragma unroll
+		for (uint32_t f = 0; f < (DYDX ? F : 1); ++f)
+#pragma unroll
+			for (uint32_t d = 0; d < D; ++d) grads[f][d] = 0.0f;
+		if (!level_off) {
+			const Cell<D> c = make_cell<D, false>(lv, io, i);
+			if (lv.nearest) {
+				const float* v = grid + (size_t)corner_index<D, false>(lv, c, 0) * F;
+#pragma unroll
+				for (uint32_t f = 0; f < F; ++f) result[f] = v[f];
+			} else {
+				float val[1u << D][F];
+#pragma unroll
+				for (uint32_t idx = 0; idx < (1u << D); ++idx) {
+					const float* v = grid + (size_t)corner_index<D, false>(lv, c, idx) * F;
+#pragma unroll
+					for (uint32_t f = 0; f < F; ++f) val[idx][f] = v[f];
+				}
+#pragma unroll
+				for (uint32_t idx = 0; idx < (1u << D); ++idx) {
+					const float weight = corner_weight<D>(c, idx);
+#pragma unroll
+					for (uint32_t f = 0; f < F; ++f) result[f] = __builtin_fmaf(weight, val[idx][f], result[f]);
+				}
+				if constexpr (DYDX) {  // grid.h:172-211
+#pragma unroll
+					for (uint32_t gd = 0; gd < D; ++gd) {
+#pragma unroll
+						for (uint32_t idx = 0; idx < (1u << (D - 1)); ++idx) {
+							float weight = lv.scale;
+							uint32_t corner = 0;
+#pragma unroll
+							for (uint32_t ngd = 0; ngd < D - 1; ++ngd) {
+								const uint32_t dim = ngd >= gd ? (ngd + 1) : ngd;
+								const uint32_t bit = (idx >> ngd) & 1u;
+								weight *= bit ? c.w[dim][1] : c.w[dim][0];
+								corner |= bit << dim;
+							}
+#pragma unroll
+							for (uint32_t f = 0; f < F; ++f) {
+								const float diff = val[corner | (1u << gd)][f] - val[corner][f];
+								float t = weight * diff;
+								t = t * c.derivative[gd];
+								grads[f][gd] = grads[f][gd] + t;
+							}
+						}
+					}
+				}
+			}
+		}
+#pragma unroll
+		for (uint32_t f = 0; f < F; ++f) {
+			const uint32_t k = level * F + f;
+			if (out) out[(size_t)k * io.stride_k + (size_t)i * io.stride_i] = result[f];
+			if constexpr (DYDX) {
+#pragma unroll
+				for (uint32_t d = 0; d < D; ++d) dy_dx[((size_t)k * io.n + i) * D + d] = grads[f][d];
+			}
+		}
+	}
+}
+
+template <uint32_t D, uint32_t F>
+__global__ void __launch_bounds__(GRID_THREADS) k_grid_backward_atomic_f32(const GridMeta meta, const GridIO io, const float* __restrict__ dL_dy,
+                                                                            float* __restrict__ grid_gradient) {
+	uint32_t level, tile;
+	if (!grid_work_item(meta.n_levels, div_round_up(io.n, GRID_TILE), level, tile)) return;
+	const uint32_t n_features = meta.n_levels * F;
+	const float max_level = (meta.max_level * (float)n_features) / (float)F;
+	if ((float)level > max_level + 1e-3f) return;  // grid.h:242
+	const Level<D> lv = make_level<D>(meta, level);
+	float* __restrict__ grad = grid_gradient + (size_t)meta.offset[level] * F;
+	for (uint32_t s = 0; s < GRID_SPT; ++s) {
+		const uint32_t i = tile * GRID_TILE + s * GRID_THREADS + threadIdx.x;
+		if (i >= io.n) continue;
+		Cell<D> c = make_cell<D, false>(lv, io, i);
+		float g[F];
+#pragma unroll
+		for (uint32_t f = 0; f < F; ++f) g[f] = dL_dy[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i];
+		const bool one_corner = lv.nearest || meta.stochastic != 0u;
+		if (meta.stochastic != 0u && !lv.nearest) {  // grid.h:284-299
+			Pcg32 rng(1337u);
+			rng.advance((int64_t)(uint32_t)(i + level * io.n));
+			const float sample = rng.next_float();
+#pragma unroll
+			for (uint32_t d = 0; d < D; ++d) {
+				if (!(sample >= c.w[d][1])) c.grid[d] += 1u;
+			}
+		}
+		const uint32_t n_corners = one_corner ? 1u : (1u << D);
+		for (uint32_t idx = 0; idx < n_corners; ++idx) {
+			const float weight = one_corner ? 1.0f : corner_weight<D>(c, idx);
+			const uint32_t index = corner_index<D, false>(lv, c, idx);
+#pragma unroll
+			for (uint32_t f = 0; f < F; ++f) atomic_add_f32(grad + (size_t)index * F + f, weight * g[f]);  // (T)weight * grad, T = float (grid.h:254)
+		}
+	}
+}
+
+// =============================================================================================
 // backward, owner-computes form (the default).  No global atomics on the hot path: a workgroup OWNS a
 // contiguous slice of one level's table, keeps it in LDS, walks the samples, recomputes the corner
 // indices (integer ALU is cheap) and accumulates only the corners that fall into its slice; the slice
@@ -1613,7 +1736,8 @@ __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const G
 	}
 }
 
-__global__ void k_grid_backward_input(uint32_t n_dims, uint32_t n_features, GridIO io, const half_t* __restrict__ dL_dy,
+template <typename GRAD_T>
+__global__ void k_grid_backward_input(uint32_t n_dims, uint32_t n_features, GridIO io, const GRAD_T* __restrict__ dL_dy,
                                       const float* __restrict__ dy_dx, float* __restrict__ dL_dx, uint32_t dx_stride_i,
                                       uint32_t dx_stride_d) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
@@ -2216,8 +2340,40 @@ void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, c
 void grid_backward_input(hipStream_t stream, uint32_t n_dims, uint32_t n_features, const GridIO& io, const half_t* dL_dy,
                          const float* dy_dx, float* dL_dx, uint32_t dx_stride_i, uint32_t dx_stride_d) {
 	if (io.n == 0) return;
-	TCNN_LAUNCH(k_grid_backward_input, dim3(div_round_up(io.n, 128u)), dim3(128), 0, stream, n_dims, n_features, io, dL_dy, dy_dx,
+	TCNN_LAUNCH(k_grid_backward_input<half_t>, dim3(div_round_up(io.n, 128u)), dim3(128), 0, stream, n_dims, n_features, io, dL_dy, dy_dx,
 	            dL_dx, dx_stride_i, dx_stride_d);
+}
+
+// ---- fp32 encodings (GridEncodingTemplated<float>) ----
+void grid_forward_f32(hipStream_t stream, const GridMeta& meta, const GridIO& io, const float* params, float* out, float* dy_dx) {
+	if (io.n == 0) return;
+	const uint32_t blocks = grid_n_blocks(meta.n_levels, io.n);
+#define FWD32(D_, F_)                                                                                                              \
+	if (dy_dx) {                                                                                                                   \
+		TCNN_LAUNCH((k_grid_forward_f32<D_, F_, true>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, dy_dx); \
+	} else {                                                                                                                       \
+		TCNN_LAUNCH((k_grid_forward_f32<D_, F_, false>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, params, out, (float*)nullptr); \
+	}
+	TCNN_GRID_DISPATCH(FWD32)
+#undef FWD32
+}
+void grid_backward_f32(hipStream_t stream, const GridMeta& meta, const GridIO& io, const float* dL_dy, float* grid_gradient, bool accumulate) {
+	if (io.n == 0) return;
+	if (!grid_gradient) throw std::runtime_error("grid_backward: missing gradient buffer");
+	const size_t n_params = (size_t)meta.offset[meta.n_levels] * meta.n_feat;
+	if (!accumulate) {  // grid.h:865-867
+		if (hipMemsetAsync(grid_gradient, 0, n_params * sizeof(float), stream) != hipSuccess) throw std::runtime_error("grid_backward: memset failed");
+	}
+	const uint32_t blocks = grid_n_blocks(meta.n_levels, io.n);
+#define BWD32(D_, F_) TCNN_LAUNCH((k_grid_backward_atomic_f32<D_, F_>), dim3(blocks), dim3(GRID_THREADS), 0, stream, meta, io, dL_dy, grid_gradient);
+	TCNN_GRID_DISPATCH(BWD32)
+#undef BWD32
+}
+void grid_backward_input_f32(hipStream_t stream, uint32_t n_dims, uint32_t n_features, const GridIO& io, const float* dL_dy, const float* dy_dx, float* dL_dx,
+                             uint32_t dx_stride_i, uint32_t dx_stride_d) {
+	if (io.n == 0) return;
+	TCNN_LAUNCH(k_grid_backward_input<float>, dim3(div_round_up(io.n, 128u)), dim3(128), 0, stream, n_dims, n_features, io, dL_dy, dy_dx, dL_dx, dx_stride_i,
+	            dx_stride_d);
 }
 
 void grid_backward_backward_dLdoutput(hipStream_t stream, uint32_t n_dims, uint32_t n_features, uint32_t n_to_pad, const GridIO& io,

@@ -45,6 +45,8 @@
 #endif
 #if !defined(TCNN_HAS_NLOHMANN_JSON)
 #include <tiny-cuda-nn/json_mini.h>
+#elif defined(NLOHMANN_JSON_VERSION_MAJOR) && (NLOHMANN_JSON_VERSION_MAJOR > 3 || (NLOHMANN_JSON_VERSION_MAJOR == 3 && NLOHMANN_JSON_VERSION_MINOR >= 8))
+#define TCNN_JSON_HAS_BINARY 1 /* json::binary_t, MessagePack bin: the snapshot document can be a json value (trainer.h: serialize) */
 #endif
 
 namespace tcnn {

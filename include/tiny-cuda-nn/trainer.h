@@ -105,9 +105,9 @@ public:
 	void update_hyperparams(const json& params) { check(tcnn_trainer_update_hyperparams(m_h->tm, json_text(params).c_str())); }
 	json hyperparams() const { return json::parse(std::string(tcnn_trainer_hyperparams_json(m_h->tm))); }
 	// trainer.h:442-481.  The snapshot crosses the C ABI as the MessagePack bytes of the reference's snapshot document
-	// (json::to_msgpack of the reference's serialize()): serialize_msgpack / deserialize_msgpack in every build; with nlohmann::json
-	// present serialize() returns the document itself and deserialize() takes it, exactly as the reference's members do, otherwise
-	// (the bundled json_mini.h has no binary values) they are the byte forms.
+	// (json::to_msgpack of the reference's serialize()): serialize_msgpack / deserialize_msgpack in every build; with an nlohmann::json
+	// that has binary values (3.8 or newer; the reference ships 3.10.4) serialize() returns the document itself and deserialize() takes
+	// it, exactly as the reference's members do, otherwise (older nlohmann, the bundled json_mini.h) they are the byte forms.
 	std::vector<uint8_t> serialize_msgpack(bool serialize_optimizer = false) const {
 		size_t n = 0;
 		check(tcnn_trainer_serialize(m_h->tm, serialize_optimizer, nullptr, 0, &n));
@@ -116,7 +116,7 @@ public:
 		return blob;
 	}
 	void deserialize_msgpack(const std::vector<uint8_t>& blob) { check(tcnn_trainer_deserialize(m_h->tm, blob.data(), blob.size())); }
-#if defined(TCNN_HAS_NLOHMANN_JSON)
+#if defined(TCNN_JSON_HAS_BINARY)
 	json serialize(bool serialize_optimizer = false) const { return json::from_msgpack(serialize_msgpack(serialize_optimizer)); }
 	void deserialize(const json& data) { deserialize_msgpack(json::to_msgpack(data)); }
 #else

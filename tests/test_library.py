@@ -55,15 +55,18 @@ def test_shipped_libraries_are_no_experiment_builds():
     assert r.returncode != 0 and "experiment" in (r.stderr + r.stdout)
 
 
-@pytest.mark.parametrize("json_flag", [[], ["-DTCNN_JSON_HEADER=\"/opt/conda/include/json.hpp\""]], ids=["json_mini", "nlohmann"])
+_JSON_FLAVOURS = [[], ["-DTCNN_JSON_HEADER=\"/opt/conda/include/json.hpp\""], ["-DTCNN_JSON_HEADER=\"/root/reference/dependencies/json/json.hpp\""]]
+
+
+@pytest.mark.parametrize("json_flag", _JSON_FLAVOURS, ids=["json_mini", "nlohmann-3.1", "nlohmann-3.10-of-the-reference"])
 def test_cpp_api_module_header_builds_and_runs_on_the_host(tmp_path, json_flag):
     """include/tiny-cuda-nn/cpp_api.h: `tcnn::cpp::Module` + factories + free functions (reference cpp_api.h:62-123) as a header a binding
     can include in place of the reference's.  Compiled with g++ and RUN here (construction and the accessors need no GPU): the reference's
     own known answers for the grid (tests/test_grid.cu:55-71) come back through the virtual interface; with nlohmann::json present
     Trainer::serialize() has the reference's return type (trainer.h:442)."""
     import subprocess
-    if json_flag and not os.path.exists("/opt/conda/include/json.hpp"):
-        pytest.skip("no nlohmann/json.hpp in this image")
+    if json_flag and not os.path.exists(json_flag[0].split('"')[1]):
+        pytest.skip("this copy of nlohmann/json.hpp is not on this box")
     src = tmp_path / "module_caller.cpp"
     src.write_text(r'''
 #include <tiny-cuda-nn/cpp_api.h>
@@ -71,7 +74,7 @@ def test_cpp_api_module_header_builds_and_runs_on_the_host(tmp_path, json_flag):
 #include <cstdio>
 #include <type_traits>
 using namespace tcnn::cpp;
-#if defined(TCNN_HAS_NLOHMANN_JSON)
+#if defined(TCNN_JSON_HAS_BINARY)
 static_assert(std::is_same<decltype(std::declval<tcnn::Trainer<float, tcnn::precision_t, tcnn::precision_t>&>().serialize(true)), tcnn::json>::value, "Trainer::serialize returns json");
 #endif
 int main() {

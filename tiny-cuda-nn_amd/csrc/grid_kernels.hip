@@ -378,6 +378,11 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward_tiles(const GridM
 		}
 		slot -= n;
 	}
+	if constexpr (EXP_FWD_SAMPLE_MAJOR) {  // experiment builds only (exp_diag.h); needs tiles % 8 == 0 to cover everything
+		level = (blockIdx.x >> 3) % meta.n_levels;
+		tile = (blockIdx.x / (8u * meta.n_levels)) * 8u + (blockIdx.x & 7u);
+		found = tile < plan.tiles;
+	}
 	if (!found) return;
 	const uint32_t first = tile * TILE;
 	float x[SPT][D];

@@ -269,6 +269,12 @@ int tcnn_trainer_set_backward_level_groups(tcnn_trainable_model_t* tm, uint32_t 
  * on the wire; with run_optimizer = 0 the next tcnn_trainer_optimizer_step* call waits for them.  Set the global batch size
  * (tcnn_trainer_set_global_batch_size) so that the sum of the ranks' gradients is the global gradient. */
 int tcnn_trainer_enable_rccl(tcnn_trainable_model_t* tm, void* nccl_comm, int n_ranks);
+/* The same with the SHARDED exchange (ZeRO-1 style, what tinycudann/parallel.py's default does from Python): every ready range is
+ * reduce-scattered (ncclReduceScatter, in place), training_step(run_optimizer = 1) runs Adam on this rank's shard of every range only and
+ * all-gathers the 16-bit parameters (ncclAllGather, in place; the EMA weights too).  `rank` = this process's rank in the communicator.
+ * Both schemes poll ncclCommGetAsyncError before they put the compute stream behind a collective: an asynchronous RCCL error (a dead peer)
+ * surfaces as TCNN_ERROR with the communicator's message instead of a hang. */
+int tcnn_trainer_enable_rccl_sharded(tcnn_trainable_model_t* tm, void* nccl_comm, int n_ranks, int rank);
 /* Adam's state (device pointers, n_params elements each): which = 0 first moments (fp32), 1 second moments (fp32),
  * 2 per-parameter step counters (u32; *steps_are_deficits = 1: the array holds `optimizer steps done - counter`). */
 void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* steps_are_deficits);

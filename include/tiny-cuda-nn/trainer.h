@@ -136,6 +136,7 @@ public:
 	void set_backward_level_groups(uint32_t n_groups) { check(tcnn_trainer_set_backward_level_groups(m_h->tm, n_groups)); }
 	void set_gradient_ready_callback(void (*ready)(void*, size_t, size_t, tcnn_stream_t), void* user) { check(tcnn_trainer_set_gradient_ready_callback(m_h->tm, ready, user)); }
 	void enable_rccl(void* nccl_comm, int n_ranks) { check(tcnn_trainer_enable_rccl(m_h->tm, nccl_comm, n_ranks)); }
+	void enable_rccl_sharded(void* nccl_comm, int n_ranks, int rank) { check(tcnn_trainer_enable_rccl_sharded(m_h->tm, nccl_comm, n_ranks, rank)); }
 	tcnn_trainable_model_t* c_handle() const { return m_h->tm; }
 
 private:

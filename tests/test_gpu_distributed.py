@@ -175,6 +175,24 @@ def test_rccl_all_reduce_inside_the_library_on_one_rank():
         assert tm.optimizer_step_count == STEPS
         assert torch.equal(tm.params_full_precision, plain.params_full_precision), separate_optimizer
         tm.enable_rccl(None, 0)
+    # the sharded exchange inside the library (ncclReduceScatter -> Adam on the rank's shards -> ncclAllGather, ncclCommGetAsyncError polled):
+    # with one rank every shard is the whole range, the trajectory again the plain one -- also with an Ema optimizer, whose averaged weights
+    # travel in the all-gather too; a host-side optimizer step is refused in this mode
+    tm = _model()
+    tm.set_backward_level_groups(3)
+    tm.enable_rccl(comm.value, 1, rank=0)
+    tm.set_global_batch_size(N)
+    for _ in range(STEPS):
+        tm.training_step(x, t)
+    torch.cuda.synchronize()
+    assert tm.optimizer_step_count == STEPS and torch.equal(tm.params_full_precision, plain.params_full_precision)
+    assert torch.equal(tm.inference(x), plain.inference(x))  # the transposed network weights are rebuilt after the gather
+    with pytest.raises(RuntimeError, match="run_optimizer must be true"):
+        tm.training_step(x, t, run_optimizer=False)
+    with pytest.raises(RuntimeError, match="Accumulate"):
+        import tinycudann
+        tm.training_step(x, t, gradient_mode=tinycudann._C.GradientMode.Accumulate)
+    tm.enable_rccl(None, 0)
     assert "librccl" in open("/proc/self/maps").read()
     lib.ncclCommDestroy.argtypes = [type(comm)]
     lib.ncclCommDestroy(comm)

@@ -1039,12 +1039,16 @@ struct tcnn_trainable_model {
 	uint32_t backward_level_groups = getenv("TCNN_BACKWARD_LEVEL_GROUPS") ? (uint32_t)std::max(1, atoi(getenv("TCNN_BACKWARD_LEVEL_GROUPS"))) : 1u;  // env: experiments
 	void* rccl_comm = nullptr;  // ncclComm_t
 	int rccl_ranks = 0;
+	// sharded exchange inside the library (tcnn_trainer_enable_rccl_sharded): reduce-scatter of every ready range -> Adam on this rank's
+	// shards -> all-gather of the 16-bit parameters; -1: the all-reduce scheme
+	int rccl_rank = -1;
 	hipStream_t comm_stream = nullptr;
 	std::vector<hipEvent_t> comm_events;
 	size_t comm_events_used = 0;
 	struct ReducedRange {
 		size_t begin, end;
 		hipEvent_t done;
+		size_t shard = 0;  // sharded scheme: parameters per rank of this range's evenly divided part [begin, begin + shard * ranks); the rest is all-reduced
 	};
 	std::vector<ReducedRange> reduced;  // this step's ranges whose all-reduce is in flight on comm_stream, in issue order
 	hipEvent_t comm_event() {
@@ -1061,6 +1065,11 @@ struct tcnn_trainable_model {
 struct Rccl {
 	void* handle = nullptr;
 	int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+	int (*reduce_scatter)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;  // ncclReduceScatter(send, recv, recvcount, type, op, comm, stream)
+	int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;           // ncclAllGather(send, recv, sendcount, type, comm, stream)
+	int (*group_start)() = nullptr;
+	int (*group_end)() = nullptr;
+	int (*comm_get_async_error)(void*, int*) = nullptr;  // ncclCommGetAsyncError(comm, ncclResult_t*)
 	const char* (*error_string)(int) = nullptr;
 	static Rccl& get() {
 		static Rccl r = [] {
@@ -1071,6 +1080,11 @@ struct Rccl {
 			}
 			if (x.handle) {
 				x.all_reduce = (decltype(x.all_reduce))dlsym(x.handle, "ncclAllReduce");
+				x.reduce_scatter = (decltype(x.reduce_scatter))dlsym(x.handle, "ncclReduceScatter");
+				x.all_gather = (decltype(x.all_gather))dlsym(x.handle, "ncclAllGather");
+				x.group_start = (decltype(x.group_start))dlsym(x.handle, "ncclGroupStart");
+				x.group_end = (decltype(x.group_end))dlsym(x.handle, "ncclGroupEnd");
+				x.comm_get_async_error = (decltype(x.comm_get_async_error))dlsym(x.handle, "ncclCommGetAsyncError");
 				x.error_string = (decltype(x.error_string))dlsym(x.handle, "ncclGetErrorString");
 			}
 			return x;
@@ -1079,6 +1093,24 @@ struct Rccl {
 	}
 };
 constexpr int RCCL_SUM = 0, RCCL_HALF = 6, RCCL_BFLOAT16 = 9;  // rccl.h: ncclSum, ncclFloat16, ncclBfloat16
+constexpr int RCCL_SUCCESS = 0, RCCL_IN_PROGRESS = 7;           // ncclSuccess, ncclInProgress
+static void rccl_check(const Rccl& r, int rc, const char* what) {
+	if (rc != RCCL_SUCCESS) throw std::runtime_error(std::string(what) + " failed: " + (r.error_string ? r.error_string(rc) : "?"));
+}
+// Collectives fail ASYNCHRONOUSLY (a peer that died, a link error): RCCL records the error on the communicator and the kernels already
+// enqueued would wait forever.  Polled at every point where this library is about to put the compute stream behind a collective.
+static void rccl_poll_async_error(tcnn_trainable_model* tm) {
+	if (!tm->rccl_comm) return;
+	const Rccl& r = Rccl::get();
+	if (!r.comm_get_async_error) return;
+	int state = RCCL_SUCCESS;
+	const int rc = r.comm_get_async_error(tm->rccl_comm, &state);
+	if (rc != RCCL_SUCCESS) throw std::runtime_error(std::string("ncclCommGetAsyncError failed: ") + (r.error_string ? r.error_string(rc) : "?"));
+	if (state != RCCL_SUCCESS && state != RCCL_IN_PROGRESS) {
+		throw std::runtime_error(std::string("RCCL reported an asynchronous error on the communicator: ") + (r.error_string ? r.error_string(state) : "?") +
+		                         " (the gradient exchange of this step cannot complete; destroy the communicator and the trainer's rccl hook)");
+	}
+}
 
 // Gradients [begin, end) of this step are final once the work enqueued on `stream` so far has run: tell the host (callback) and /
 // or start their all-reduce on the communication stream, behind an event -- the rest of the backward pass keeps the compute
@@ -1088,13 +1120,24 @@ static void notify_gradients_ready(tcnn_trainable_model* tm, hipStream_t stream,
 	if (tm->gradients_ready) tm->gradients_ready(tm->ready_user, begin, end, stream);
 	if (tm->rccl_comm) {
 		Rccl& r = Rccl::get();
+		rccl_poll_async_error(tm);
 		hipEvent_t ready = tm->comm_event(), done = tm->comm_event();
 		HIP_CHECK(hipEventRecord(ready, stream));
 		HIP_CHECK(hipStreamWaitEvent(tm->comm_stream, ready, 0));
-		const int rc = r.all_reduce(tm->grads + begin, tm->grads + begin, end - begin, HALF_IS_BF16 ? RCCL_BFLOAT16 : RCCL_HALF, RCCL_SUM, tm->rccl_comm, tm->comm_stream);
-		if (rc != 0) throw std::runtime_error(std::string("ncclAllReduce failed: ") + (r.error_string ? r.error_string(rc) : "?"));
+		const int type = HALF_IS_BF16 ? RCCL_BFLOAT16 : RCCL_HALF;
+		size_t shard = 0;
+		if (tm->rccl_rank >= 0) {
+			// sharded: the part of the range that divides evenly over the ranks (shards of a multiple of 8 parameters, what the ranged optimizer
+			// step needs) is reduce-scattered IN PLACE (recv = send + rank * shard: RCCL's in-place form), the remainder all-reduced
+			const size_t P = (size_t)tm->rccl_ranks;
+			shard = ((end - begin) / (8 * P)) * 8;
+			if (shard) rccl_check(r, r.reduce_scatter(tm->grads + begin, tm->grads + begin + (size_t)tm->rccl_rank * shard, shard, type, RCCL_SUM, tm->rccl_comm, tm->comm_stream), "ncclReduceScatter");
+			if (begin + shard * P < end) rccl_check(r, r.all_reduce(tm->grads + begin + shard * P, tm->grads + begin + shard * P, end - begin - shard * P, type, RCCL_SUM, tm->rccl_comm, tm->comm_stream), "ncclAllReduce");
+		} else {
+			rccl_check(r, r.all_reduce(tm->grads + begin, tm->grads + begin, end - begin, type, RCCL_SUM, tm->rccl_comm, tm->comm_stream), "ncclAllReduce");
+		}
 		HIP_CHECK(hipEventRecord(done, tm->comm_stream));
-		tm->reduced.push_back({begin, end, done});
+		tm->reduced.push_back({begin, end, done, shard});
 	}
 }
 
@@ -1849,16 +1892,33 @@ int tcnn_trainer_set_backward_level_groups(tcnn_trainable_model_t* tm, uint32_t 
 // training_step all-reduces (sum) every gradient range on an internal communication stream as soon as it is ready -- RCCL is loaded
 // with dlopen at this point, the library does not link it -- and, with run_optimizer, steps each range when its own collective has
 // finished.  The host sets the global batch size (tcnn_trainer_set_global_batch_size) so that the sum is the global gradient.
-int tcnn_trainer_enable_rccl(tcnn_trainable_model_t* tm, void* nccl_comm, int n_ranks) {
-	TCNN_API_BEGIN
+static void enable_rccl(tcnn_trainable_model_t* tm, void* nccl_comm, int n_ranks, int rank) {
 	if (nccl_comm) {
 		const Rccl& r = Rccl::get();
 		if (!r.handle || !r.all_reduce) throw std::runtime_error("tcnn_trainer_enable_rccl: librccl.so could not be loaded");
+		if (rank >= 0 && (!r.reduce_scatter || !r.all_gather)) throw std::runtime_error("tcnn_trainer_enable_rccl_sharded: librccl.so lacks ncclReduceScatter / ncclAllGather");
+		if (n_ranks < 1 || rank >= n_ranks) throw std::runtime_error("tcnn_trainer_enable_rccl: rank / n_ranks out of range");
 		if (!tm->comm_stream) HIP_CHECK(hipStreamCreateWithFlags(&tm->comm_stream, hipStreamNonBlocking));
 	}
 	tm->rccl_comm = nccl_comm;
 	tm->rccl_ranks = n_ranks;
+	tm->rccl_rank = nccl_comm ? rank : -1;
 	tm->reduced.clear();
+}
+int tcnn_trainer_enable_rccl(tcnn_trainable_model_t* tm, void* nccl_comm, int n_ranks) {
+	TCNN_API_BEGIN
+	enable_rccl(tm, nccl_comm, n_ranks, -1);
+	TCNN_API_END
+}
+// The sharded exchange inside the library (what tinycudann/parallel.py's "pipelined_sharded" does from Python): every ready gradient
+// range is reduce-scattered; training_step(run_optimizer) then runs Adam on this rank's shard of every range only -- the optimizer, the
+// largest HBM consumer of a step, shrinks by the number of ranks; fp32 master weights and Adam's moments of the other shards are never
+// touched on this rank -- and all-gathers the 16-bit parameters (and the EMA weights of an Ema optimizer).  Same bytes on the wire as the
+// all-reduce scheme; replicas cannot drift (everyone receives the same 16-bit parameters).  `rank`: this process's rank in `nccl_comm`.
+int tcnn_trainer_enable_rccl_sharded(tcnn_trainable_model_t* tm, void* nccl_comm, int n_ranks, int rank) {
+	TCNN_API_BEGIN
+	if (nccl_comm && rank < 0) throw std::runtime_error("tcnn_trainer_enable_rccl_sharded: rank must be >= 0");
+	enable_rccl(tm, nccl_comm, n_ranks, rank);
 	TCNN_API_END
 }
 
@@ -1883,11 +1943,53 @@ void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* s
 // stepped as soon as ITS collective has finished (the later ones are still on the wire); otherwise the host's exchange hook, then
 // one optimizer step.
 static int finish_training_step(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale) {
+	if (tm->rccl_comm && !tm->reduced.empty() && tm->rccl_rank >= 0) {
+		TCNN_API_BEGIN
+		const std::vector<tcnn_trainable_model::ReducedRange> ranges = std::move(tm->reduced);
+		tm->reduced.clear();
+		if (ranges.front().begin != 0) throw std::runtime_error("training_step: the reduced gradient ranges do not start at parameter 0");
+		rccl_poll_async_error(tm);
+		const Rccl& r = Rccl::get();
+		const size_t P = (size_t)tm->rccl_ranks, me = (size_t)tm->rccl_rank;
+		// ONE optimizer step over this rank's shards of all ranges (+ the remainders everyone steps), behind all reduce-scatters
+		std::vector<size_t> begins, ends;
+		for (const auto& rr : ranges) {
+			HIP_CHECK(hipStreamWaitEvent(stream, rr.done, 0));
+			if (rr.shard) {
+				begins.push_back(rr.begin + me * rr.shard);
+				ends.push_back(rr.begin + (me + 1) * rr.shard);
+			}
+			if (rr.begin + rr.shard * P < rr.end) {
+				begins.push_back(rr.begin + rr.shard * P);
+				ends.push_back(rr.end);
+			}
+		}
+		optimizer_step_ranges(tm, stream, loss_scale, begins.size(), begins.data(), ends.data(), /*advance=*/true, /*opens_profiled_step=*/true);
+		// all-gather of the stepped 16-bit parameters, in place (send = recv + rank * shard), on the communication stream behind the optimizer
+		hipEvent_t stepped = tm->comm_event(), gathered = tm->comm_event();
+		HIP_CHECK(hipEventRecord(stepped, stream));
+		HIP_CHECK(hipStreamWaitEvent(tm->comm_stream, stepped, 0));
+		const int type = HALF_IS_BF16 ? RCCL_BFLOAT16 : RCCL_HALF;
+		if (r.group_start) rccl_check(r, r.group_start(), "ncclGroupStart");
+		for (half_t* buf : {tm->params, tm->ema ? tm->params_ema : (half_t*)nullptr}) {
+			if (!buf) continue;
+			for (const auto& rr : ranges) {
+				if (rr.shard) rccl_check(r, r.all_gather(buf + rr.begin + me * rr.shard, buf + rr.begin, rr.shard, type, tm->rccl_comm, tm->comm_stream), "ncclAllGather");
+			}
+		}
+		if (r.group_end) rccl_check(r, r.group_end(), "ncclGroupEnd");
+		HIP_CHECK(hipEventRecord(gathered, tm->comm_stream));
+		HIP_CHECK(hipStreamWaitEvent(stream, gathered, 0));  // whatever reads the parameters next on the compute stream sees everybody's shards
+		tm->params_t_valid = false;  // the transposed network weights were maintained for this rank's shard only
+		return TCNN_OK;
+		TCNN_API_END
+	}
 	if (tm->rccl_comm && !tm->reduced.empty()) {
 		TCNN_API_BEGIN
 		const std::vector<tcnn_trainable_model::ReducedRange> ranges = std::move(tm->reduced);
 		tm->reduced.clear();
 		if (ranges.front().begin != 0) throw std::runtime_error("training_step: the reduced gradient ranges do not start at parameter 0");
+		rccl_poll_async_error(tm);
 		for (const auto& r : ranges) {
 			HIP_CHECK(hipStreamWaitEvent(stream, r.done, 0));
 			optimizer_step_ranges(tm, stream, loss_scale, 1, &r.begin, &r.end, /*advance=*/r.begin == 0, r.begin == 0);
@@ -2048,6 +2150,11 @@ int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
 		return TCNN_ERROR;
 	}
 	tm->comm_events_used = 0;
+	if (tm->rccl_comm && tm->rccl_rank >= 0 && !run_optimizer && gradient_mode != TCNN_GRADIENT_IGNORE) {
+		// after the reduce-scatter only this rank's shard of the gradient buffer holds sums: a host-side optimizer_step() over everything would be wrong
+		g_last_error = "training_step: the sharded exchange of tcnn_trainer_enable_rccl_sharded steps the optimizer inside training_step (run_optimizer must be true)";
+		return TCNN_ERROR;
+	}
 	if (tm->rccl_comm && gradient_mode == TCNN_GRADIENT_ACCUMULATE) {
 		// every all-reduce would sum the ranks' ACCUMULATED buffers again: the earlier micro-batches would be counted once per rank and step
 		g_last_error = "training_step: GradientMode::Accumulate cannot be combined with tcnn_trainer_enable_rccl (accumulate locally with the communicator switched off and reduce the buffer once)";

@@ -143,6 +143,7 @@ _sig("tcnn_trainer_set_gradient_exchange", _i, _vp, _vp, _vp)
 _sig("tcnn_trainer_set_gradient_ready_callback", _i, _vp, _vp, _vp)
 _sig("tcnn_trainer_set_backward_level_groups", _i, _vp, C.c_uint32)
 _sig("tcnn_trainer_enable_rccl", _i, _vp, _vp, _i)
+_sig("tcnn_trainer_enable_rccl_sharded", _i, _vp, _vp, _i, _i)
 GRADIENT_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p)  # (user, begin, end, stream)
 _sig("tcnn_trainer_optimizer_state", _vp, _vp, _i, C.POINTER(_i))
 _sig("tcnn_trainer_params_written", _i, _vp)

@@ -255,10 +255,14 @@ class TrainableModel:
         """The encoding's backward pass in n_groups groups of consecutive levels, each reported through the ready callback."""
         _check(_lib.tcnn_trainer_set_backward_level_groups(self._h, int(n_groups)))
 
-    def enable_rccl(self, nccl_comm, n_ranks):
+    def enable_rccl(self, nccl_comm, n_ranks, rank=None):
         """nccl_comm: this rank's ncclComm_t as an integer / c_void_p (None switches it off).  training_step then all-reduces every
-        gradient range inside the library (RCCL loaded with dlopen) and steps each range when its collective has finished."""
-        _check(_lib.tcnn_trainer_enable_rccl(self._h, C.c_void_p(nccl_comm) if nccl_comm else None, int(n_ranks)))
+        gradient range inside the library (RCCL loaded with dlopen) and steps each range when its collective has finished.
+        With `rank` given: the sharded exchange instead (reduce-scatter -> Adam on this rank's shards -> all-gather of the parameters)."""
+        if rank is None or not nccl_comm:
+            _check(_lib.tcnn_trainer_enable_rccl(self._h, C.c_void_p(nccl_comm) if nccl_comm else None, int(n_ranks)))
+        else:
+            _check(_lib.tcnn_trainer_enable_rccl_sharded(self._h, C.c_void_p(nccl_comm), int(n_ranks), int(rank)))
 
     # ---- measurement hooks ---------------------------------------------------------------------
     def set_profiling(self, enable=True, only_stage=None):

@@ -251,8 +251,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="hash")
     ap.add_argument("--precision", choices=["fp16", "bf16"], default="fp16", help="the library build: fp16 (libtcnn_hip.so) or bfloat16 (libtcnn_hip_bf16.so)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: 2^18 samples per GPU (weak) or 2^18 in total (strong)")
-    ap.add_argument("--dp", choices=["sharded", "allreduce", "pipelined", "pipelined_sharded"], default="sharded",
-                    help="N > 1: gradient exchange (tinycudann/parallel.py); pipelined*: collectives started from inside the backward pass, per level group")
+    ap.add_argument("--dp", choices=["sharded", "allreduce", "pipelined", "pipelined_sharded", "direct"], default="sharded",
+                    help="N > 1: gradient exchange (tinycudann/parallel.py); pipelined*: collectives started from inside the backward pass, per level group; "
+                         "direct: peer-mapped buffers read over all xGMI links at once instead of ring collectives (csrc/direct_exchange.h)")
     ap.add_argument("--level-groups", type=int, default=2, help="pipelined exchanges: level groups of the encoding's backward pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--regenerate", dest="regenerate", action="store_true", default=None,
@@ -369,6 +370,8 @@ def main():
     elapsed = par.all_reduce_max(elapsed, device=device)
     dom_ms, dom_cnt = tm.stage_times()[dominant]
     comm = dp.comm_seconds() if dp is not None else None
+    if dp is not None and args.dp == "direct" and tm.direct_status() != 0:
+        raise SystemExit(f"rank {rank}: a wait of the direct exchange timed out (phase {tm.direct_status()}): the measurement is void")
 
     # ---- the same number of steps once more on batches that are resident in HBM (round 1-3's protocol): `value_resident` -------------
     elapsed_resident = None

@@ -248,7 +248,7 @@ uint32_t tcnn_optimizer_step_count(const tcnn_optimizer_t* o);
 int tcnn_optimizer_update_hyperparams(tcnn_optimizer_t* o, const char* optimizer_json);
 void* tcnn_optimizer_state(tcnn_optimizer_t* o, int which); /* 0 first moments, 1 second moments (fp32), 2 step counters (u32) */
 void tcnn_optimizer_destroy(tcnn_optimizer_t* o);
-/* Loss<T>::evaluate on its own (reference loss.h:42-50; losses/*.h): `loss_otype` as in the JSON ("RelativeL2", "L2", "L1", ...).
+/* Loss<T>::evaluate on its own (reference loss.h:42-50 and the headers under losses/): `loss_otype` as in the JSON ("RelativeL2", "L2", "L1", ...).
  * prediction / gradients: column-major `stride` x n matrices of the library's 16-bit type (stride = padded output width, a multiple of
  * 8), target / data_pdf (may be NULL): `dims` x n fp32, values (may be NULL): `stride` x n fp32.  Rows >= dims carry no loss; the
  * normalisation is n * dims as in the reference's kernels. */
@@ -275,6 +275,26 @@ int tcnn_trainer_enable_rccl(tcnn_trainable_model_t* tm, void* nccl_comm, int n_
  * Both schemes poll ncclCommGetAsyncError before they put the compute stream behind a collective: an asynchronous RCCL error (a dead peer)
  * surfaces as TCNN_ERROR with the communicator's message instead of a hang. */
 int tcnn_trainer_enable_rccl_sharded(tcnn_trainable_model_t* tm, void* nccl_comm, int n_ranks, int rank);
+
+/* Gradient exchange over PEER-MAPPED memory instead of ring collectives (csrc/direct_exchange.h; no reference counterpart).  On an MI355X
+ * node every GPU has its own xGMI link to each peer: a rank that reads the P - 1 remote shards of ITS 1/P of the gradient buffer uses all
+ * of its links at once (28.5 MB / 8 = 3.6 MB per link and phase at P = 8) where a ring pushes 7/8 of the buffer through one.
+ *   tcnn_trainer_direct_export   fills `out` (n_bytes bytes; query the size with out == NULL) with IPC handles of this rank's trainer buffer
+ *                                and signal block; the host passes every rank's record to every rank (any channel)
+ *   tcnn_trainer_direct_open     maps the peers (exports: n_ranks records, rank r's at r * bytes_each); the HOST must put a barrier between
+ *                                every rank's open and the first step
+ *   training_step(run_optimizer = 1), or tcnn_trainer_direct_exchange_and_step after training_step(run_optimizer = 0):
+ *                                signal + wait -> fp32 sum of this rank's shard over all ranks in rank order, ONE rounding -> Adam on the
+ *                                shard (+ the < 8 P replicated tail parameters) -> stepped parameters written into every peer's buffer ->
+ *                                signal + wait.  Loss gradients must be normalised by the global batch (tcnn_trainer_set_global_batch_size).
+ *   tcnn_trainer_direct_status   *status = 0, or the phase (1 gradients, 2 parameters) in which a wait for the peers timed out
+ *                                (TCNN_DIRECT_TIMEOUT_MS, default 2000: a dead peer yields an error, not a hung queue); synchronises
+ * Not with Ema-wrapped optimizers, not under TCNN_DEBUG_ALLOC.  At most 16 ranks. */
+int tcnn_trainer_direct_export(tcnn_trainable_model_t* tm, void* out, size_t capacity, size_t* n_bytes);
+int tcnn_trainer_direct_open(tcnn_trainable_model_t* tm, int rank, int n_ranks, const void* exports, size_t bytes_each);
+int tcnn_trainer_direct_close(tcnn_trainable_model_t* tm);
+int tcnn_trainer_direct_exchange_and_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale);
+int tcnn_trainer_direct_status(tcnn_trainable_model_t* tm, tcnn_stream_t stream, int* status);
 /* Adam's state (device pointers, n_params elements each): which = 0 first moments (fp32), 1 second moments (fp32),
  * 2 per-parameter step counters (u32; *steps_are_deficits = 1: the array holds `optimizer steps done - counter`). */
 void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* steps_are_deficits);

@@ -137,6 +137,16 @@ public:
 	void set_gradient_ready_callback(void (*ready)(void*, size_t, size_t, tcnn_stream_t), void* user) { check(tcnn_trainer_set_gradient_ready_callback(m_h->tm, ready, user)); }
 	void enable_rccl(void* nccl_comm, int n_ranks) { check(tcnn_trainer_enable_rccl(m_h->tm, nccl_comm, n_ranks)); }
 	void enable_rccl_sharded(void* nccl_comm, int n_ranks, int rank) { check(tcnn_trainer_enable_rccl_sharded(m_h->tm, nccl_comm, n_ranks, rank)); }
+	// exchange over peer-mapped memory (tcnn_hip.h: tcnn_trainer_direct_*): publish direct_export() to every rank, direct_open() with all of them
+	std::vector<uint8_t> direct_export() const {
+		size_t n = 0;
+		check(tcnn_trainer_direct_export(m_h->tm, nullptr, 0, &n));
+		std::vector<uint8_t> record(n);
+		check(tcnn_trainer_direct_export(m_h->tm, record.data(), record.size(), &n));
+		return record;
+	}
+	void direct_open(int rank, int n_ranks, const std::vector<uint8_t>& all_records) { check(tcnn_trainer_direct_open(m_h->tm, rank, n_ranks, all_records.data(), all_records.size() / (size_t)n_ranks)); }
+	void direct_close() { check(tcnn_trainer_direct_close(m_h->tm)); }
 	tcnn_trainable_model_t* c_handle() const { return m_h->tm; }
 
 private:

@@ -72,7 +72,7 @@ def test_driver_bench_command_in_fresh_processes():
     assert max(values) <= 1.15 * min(values), values  # fresh processes agree
 
 
-@pytest.mark.parametrize("dp", ["sharded", "pipelined_sharded"])
+@pytest.mark.parametrize("dp", ["sharded", "pipelined_sharded", "direct"])
 def test_driver_multi_gpu_command_with_two_ranks_on_one_gpu(dp):
     """The driver's N > 1 form -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
     bench.py --gpus N --steps K --warmup W` -- with N = 2 ranks sharing the one GPU of the test box (gloo transport: RCCL refuses two

@@ -70,7 +70,7 @@ def _worker(rank, world, port, out_path, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", [None, "sharded", "allreduce", "pipelined", "pipelined_sharded"])
+@pytest.mark.parametrize("mode", [None, "sharded", "allreduce", "pipelined", "pipelined_sharded", "direct"])
 def test_two_ranks_on_one_gpu_match_single_process(tmp_path, mode):
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -97,6 +97,85 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path, mode):
     assert losses[-1] < losses[0]
     # same trajectory up to fp16 rounding of the two half-batch gradient sums
     d = (dp["params"] - ref).abs()
+    nm = tm.n_mlp_params
+    assert float(d[:nm].max()) < 2e-2 and float(torch.quantile(d[:nm], 0.99)) < 3e-3
+    assert float((d[nm:] > 0.05 * ref[nm:].abs().max()).float().mean()) < 1e-3
+
+
+def _direct_worker(rank, world, port, out_path):
+    """The exchange over peer-mapped memory (csrc/direct_exchange.h) with `world` ranks sharing the one GPU: IPC handles, signal / wait
+    kernels, the fp32 reduction in rank order and the parameter push are the real ones (only the links are missing)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, os.path.join(ROOT, "tiny-cuda-nn_amd"))
+    import torch.distributed as dist
+    from tinycudann import parallel as par
+    torch.cuda.set_device(0)
+    r, _, w = par.init_from_env(backend="gloo")
+    tm = _model()
+    x, t = _data()
+    b, e = par.shard_rows(N, r, w)
+    xs, ts = x[b:e].cuda(), t[b:e].cuda()
+    dp = par.DataParallel(tm, mode="direct")
+    tm.set_global_batch_size(N)
+    ok = {}
+    for step in range(STEPS):
+        tm.training_step(xs, ts, run_optimizer=False)
+        torch.cuda.synchronize()
+        local = tm.param_gradients.clone()
+        everyone = [torch.empty_like(local.cpu()) for _ in range(w)]
+        dist.all_gather(everyone, local.cpu())
+        # the definition: fp32 sum in rank order, one rounding (the gradients are NOT multiples of anything convenient: real training gradients)
+        want = torch.zeros(local.numel(), dtype=torch.float32)
+        for g in everyone:
+            want = want + g.float()
+        want = want.half()
+        dp.exchange_and_step()
+        torch.cuda.synchronize()
+        sb, se = dp.shard_range()
+        got = tm.param_gradients.cpu()
+        ok[f"own_shard_{step}"] = bool(torch.equal(got[sb:se].view(torch.int16), want[sb:se].view(torch.int16)))
+        ok[f"tail_{step}"] = bool(torch.equal(got[dp.main:].view(torch.int16), want[dp.main:].view(torch.int16)))
+        ok[f"nondyadic_{step}"] = bool((want.float() * 16 != (want.float() * 16).round()).float().mean() > 0.5)
+        # replicas in lock-step: everybody holds the same 16-bit parameters after the push
+        mine = tm.params.clone().cpu()
+        theirs = [torch.empty_like(mine) for _ in range(w)]
+        dist.all_gather(theirs, mine)
+        ok[f"replicas_{step}"] = all(bool(torch.equal(p.view(torch.int16), mine.view(torch.int16))) for p in theirs)
+    ok["status"] = tm.direct_status()
+    ok["steps"] = tm.optimizer_step_count
+    dp.gather_optimizer_state()
+    if r == 0:
+        ok["params"] = tm.params_full_precision.cpu()
+        torch.save(ok, out_path)
+    dist.barrier()
+    tm.direct_close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_direct_exchange_over_peer_mapped_memory(tmp_path, world):
+    """tcnn_trainer_direct_*: every rank's shard of the reduced gradient is, bit for bit, the fp32 sum of all ranks' 16-bit gradients in rank
+    order rounded once (non-dyadic values: real gradients of a training step); every rank ends each step with the same 16-bit parameters;
+    no wait timed out; the trajectory tracks the single-process one as the collective schemes' do."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "direct.pt")
+    mp.spawn(_direct_worker, args=(world, port, out), nprocs=world, join=True)
+    res = torch.load(out)
+    assert res["status"] == 0 and res["steps"] == STEPS
+    for step in range(STEPS):
+        for key in ("own_shard", "tail", "nondyadic", "replicas"):
+            assert res[f"{key}_{step}"], (key, step)
+    tm = _model()
+    x, t = _data()
+    x, t = x.cuda(), t.cuda()
+    for _ in range(STEPS):
+        tm.training_step(x, t)
+    ref = tm.params_full_precision.cpu()
+    d = (res["params"] - ref).abs()
     nm = tm.n_mlp_params
     assert float(d[:nm].max()) < 2e-2 and float(torch.quantile(d[:nm], 0.99)) < 3e-3
     assert float((d[nm:] > 0.05 * ref[nm:].abs().max()).float().mean()) < 1e-3

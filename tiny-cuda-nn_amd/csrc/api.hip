@@ -23,6 +23,7 @@
 #include "adam_device.h"
 #include "device_alloc.h"
 #include "elementwise_kernels.h"
+#include "direct_exchange.h"
 #include "grid_kernels.h"
 #include "../../include/tiny-cuda-nn/json_mini.h"
 #include "mlp_kernels.h"
@@ -1039,6 +1040,8 @@ struct tcnn_trainable_model {
 	uint32_t backward_level_groups = getenv("TCNN_BACKWARD_LEVEL_GROUPS") ? (uint32_t)std::max(1, atoi(getenv("TCNN_BACKWARD_LEVEL_GROUPS"))) : 1u;  // env: experiments
 	void* rccl_comm = nullptr;  // ncclComm_t
 	int rccl_ranks = 0;
+	// gradient exchange over peer-mapped memory (direct_exchange.h; tcnn_trainer_direct_*)
+	DirectExchange direct;
 	// sharded exchange inside the library (tcnn_trainer_enable_rccl_sharded): reduce-scatter of every ready range -> Adam on this rank's
 	// shards -> all-gather of the 16-bit parameters; -1: the all-reduce scheme
 	int rccl_rank = -1;
@@ -1612,6 +1615,8 @@ int tcnn_create_from_config(uint32_t n_input_dims, uint32_t n_output_dims, const
 void tcnn_trainable_model_destroy(tcnn_trainable_model_t* tm) {
 	if (!tm) return;
 	(void)hipDeviceSynchronize();
+	direct_exchange_close(tm->direct);
+	if (tm->direct.own_signals) (void)hipFree(tm->direct.own_signals);
 	device_free(tm->buffer);
 	device_free(tm->m1);
 	device_free(tm->m2);
@@ -1922,6 +1927,49 @@ int tcnn_trainer_enable_rccl_sharded(tcnn_trainable_model_t* tm, void* nccl_comm
 	TCNN_API_END
 }
 
+static void direct_exchange_and_step(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale);
+// ---- gradient exchange over peer-mapped memory (direct_exchange.h): every rank publishes IPC handles of its trainer buffer and of a small
+// signal block, maps its peers', and from then on a step's exchange is: read the peers' shards of the own 1/P of the gradient buffer over all
+// links at once, sum in fp32 in rank order, one rounding -> Adam on that shard -> write the stepped parameters into every peer's buffer.
+int tcnn_trainer_direct_export(tcnn_trainable_model_t* tm, void* out, size_t capacity, size_t* n_bytes) {
+	TCNN_API_BEGIN
+	if (n_bytes) *n_bytes = sizeof(DirectExport);
+	if (!out) return TCNN_OK;
+	if (capacity < sizeof(DirectExport)) throw std::runtime_error("tcnn_trainer_direct_export: buffer too small");
+	if (debug_alloc_mode() != DebugAlloc::Off) throw std::runtime_error("tcnn_trainer_direct_export: not available under TCNN_DEBUG_ALLOC (the trainer buffer must be a plain hipMalloc block)");
+	if (tm->ema) throw std::runtime_error("tcnn_trainer_direct_export: Ema-wrapped optimizers are not supported by the direct exchange (use the sharded collective scheme)");
+	HIP_CHECK(hipDeviceSynchronize());
+	direct_exchange_export(tm->direct, tm->buffer, tm->params, tm->grads, tm->md.n_params(), *(DirectExport*)out);
+	TCNN_API_END
+}
+int tcnn_trainer_direct_open(tcnn_trainable_model_t* tm, int rank, int n_ranks, const void* exports, size_t bytes_each) {
+	TCNN_API_BEGIN
+	if (bytes_each != sizeof(DirectExport) || !exports) throw std::runtime_error("tcnn_trainer_direct_open: exports must be n_ranks records of tcnn_trainer_direct_export's size");
+	HIP_CHECK(hipDeviceSynchronize());
+	direct_exchange_open(tm->direct, rank, n_ranks, (const DirectExport*)exports, tm->params, tm->grads);
+	tm->params_exposed = true;  // peers write this rank's 16-bit parameters from now on: Adam must not re-derive skipped ones from its master weights
+	TCNN_API_END
+}
+int tcnn_trainer_direct_close(tcnn_trainable_model_t* tm) {
+	TCNN_API_BEGIN
+	HIP_CHECK(hipDeviceSynchronize());
+	direct_exchange_close(tm->direct);
+	TCNN_API_END
+}
+// after training_step(run_optimizer = 0): the exchange + optimizer half of the step (training_step(run_optimizer = 1) does the same itself)
+int tcnn_trainer_direct_exchange_and_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale) {
+	TCNN_API_BEGIN
+	if (!tm->direct.active()) throw std::runtime_error("tcnn_trainer_direct_exchange_and_step: tcnn_trainer_direct_open first");
+	direct_exchange_and_step(tm, (hipStream_t)stream, loss_scale);
+	TCNN_API_END
+}
+// 0: every wait of the exchange found its peers in time; 1 / 2: a wait for the peers' gradients / parameters timed out (synchronises)
+int tcnn_trainer_direct_status(tcnn_trainable_model_t* tm, tcnn_stream_t stream, int* status) {
+	TCNN_API_BEGIN
+	*status = direct_exchange_status((hipStream_t)stream, tm->direct);
+	TCNN_API_END
+}
+
 // Adam's state for snapshots / sharded data parallelism: which = 0 first moments (fp32), 1 second moments (fp32),
 // 2 per-parameter step counters (u32; *steps_are_deficits tells their representation, see tcnn_trainer_optimizer_step_range).
 void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* steps_are_deficits) {
@@ -1942,7 +1990,31 @@ void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* s
 // The optimizer half of training_step.  With RCCL enabled every range whose all-reduce was started during the backward pass is
 // stepped as soon as ITS collective has finished (the later ones are still on the wire); otherwise the host's exchange hook, then
 // one optimizer step.
+// reduce over the peers' mapped gradient buffers -> Adam on this rank's shard (+ the replicated tail) -> push the stepped parameters
+static void direct_exchange_and_step(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale) {
+	DirectExchange& dx = tm->direct;
+	direct_exchange_reduce(stream, dx);
+	std::vector<size_t> begins, ends;
+	if (dx.shard) {
+		begins.push_back((size_t)dx.rank * dx.shard);
+		ends.push_back((size_t)(dx.rank + 1) * dx.shard);
+	}
+	if (dx.main < dx.n_params) {
+		begins.push_back(dx.main);
+		ends.push_back((size_t)dx.n_params);
+	}
+	optimizer_step_ranges(tm, stream, loss_scale, begins.size(), begins.data(), ends.data(), /*advance=*/true, /*opens_profiled_step=*/true);
+	direct_exchange_push(stream, dx);
+	tm->params_t_valid = false;  // the transposed network weights were maintained for this rank's shard only
+}
+
 static int finish_training_step(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale) {
+	if (tm->direct.active()) {
+		TCNN_API_BEGIN
+		direct_exchange_and_step(tm, stream, loss_scale);
+		return TCNN_OK;
+		TCNN_API_END
+	}
 	if (tm->rccl_comm && !tm->reduced.empty() && tm->rccl_rank >= 0) {
 		TCNN_API_BEGIN
 		const std::vector<tcnn_trainable_model::ReducedRange> ranges = std::move(tm->reduced);

@@ -1,0 +1,70 @@
+// direct_exchange.h -- gradient exchange of a data-parallel step over PEER-MAPPED memory instead of ring collectives.
+//
+// Why: on an MI355X node every GPU has a direct xGMI link to each of its 7 peers (~153 GB/s per link and direction).
+// A ring reduce-scatter + all-gather pushes (P - 1) / P of the 28.5 MB gradient buffer twice through ONE outgoing link per rank
+// (>= 0.33 ms per step at P = 8 against 0.24 ms of forward + backward); reading the P - 1 remote shards of one's OWN 1/P of the buffer
+// directly moves 1/P of the buffer over EACH of the 7 links at the same time: 28.5 MB / 8 = 3.6 MB per link and phase, ~23 us at link
+// rate, twice per step.
+//
+// Scheme (one process per GPU; every rank maps its peers' trainer buffers with hipIpcOpenMemHandle):
+//   1. after its backward pass a rank tells every peer "my gradients of step s are final" (a 4-byte system-scope store into the peer's
+//      signal block) and waits until it has heard the same from all of them;
+//   2. k_direct_reduce: the rank reads ITS shard of every rank's gradient buffer (own memory + P - 1 peers), adds them in fp32 IN RANK
+//      ORDER and rounds once to the 16-bit type -- deterministic, the same sum on whichever rank computes it, one rounding instead of the
+//      P - 1 a ring's partial sums go through -- and writes the result into its own gradient buffer; the < 8 P parameters that do not
+//      divide are reduced by everyone;
+//   3. Adam on the rank's shard (tcnn_trainer_optimizer_step_ranges: the optimizer shrinks by P, as in the sharded collective scheme);
+//   4. k_direct_push: the rank writes its stepped 16-bit parameters into every peer's parameter buffer, signals "pushed s", and waits for
+//      everybody's push before the next forward pass reads the parameters (which also tells it that nobody still reads its gradients).
+// Signals are step counters (monotonic, never reset); a wait gives up after a timeout (TCNN_DIRECT_TIMEOUT_MS, default 2000) and records
+// an error instead of hanging the queue (direct_exchange_status()).  No collective library is involved.
+//
+// Status: exercised with two and four ranks sharing ONE GPU (tests/test_gpu_distributed.py): handles, signals, the reduction and the
+// push are real; the links are not.  Unmeasured on a multi-GPU node.
+#pragma once
+#include "tcnn_device.h"
+
+#include <vector>
+
+namespace tcnn_hip {
+
+constexpr int DIRECT_MAX_RANKS = 16;
+constexpr size_t DIRECT_HANDLE_BYTES = 64;  // sizeof(hipIpcMemHandle_t)
+
+// what a rank publishes to its peers (plain bytes: travels through any host-side channel)
+struct DirectExport {
+	unsigned char buffer_handle[DIRECT_HANDLE_BYTES];  // the trainer's [master | params | grads] allocation
+	unsigned char signal_handle[DIRECT_HANDLE_BYTES];  // its signal block
+	uint64_t params_offset, grads_offset;              // bytes from the start of the buffer allocation
+	uint64_t n_params;
+};
+
+struct DirectExchange {
+	int rank = -1, n_ranks = 0;
+	uint64_t n_params = 0;
+	size_t shard = 0, main = 0;            // parameters per rank; shard * n_ranks (the rest is the replicated tail)
+	half_t* grads[DIRECT_MAX_RANKS] = {};   // every rank's gradient buffer as mapped HERE (own entry: the trainer's own pointer)
+	half_t* params[DIRECT_MAX_RANKS] = {};
+	uint32_t* signals[DIRECT_MAX_RANKS] = {};  // [2][DIRECT_MAX_RANKS] words per rank: row 0 "gradients of step s final", row 1 "parameters of step s pushed"
+	uint32_t* own_signals = nullptr;           // this rank's block (allocated here, exported)
+	uint32_t* error_flag = nullptr;            // device word: non-zero once a wait timed out
+	void* mapped_buffers[DIRECT_MAX_RANKS] = {};  // bases returned by hipIpcOpenMemHandle (to close)
+	void* mapped_signals[DIRECT_MAX_RANKS] = {};
+	uint32_t step = 0;
+	uint32_t timeout_ms = 2000;
+	bool active() const { return n_ranks > 0; }
+};
+
+// this rank's signal block + error word (idempotent); fills `out` for the trainer buffer at `buffer` (base of its hipMalloc allocation)
+void direct_exchange_export(DirectExchange& dx, void* buffer, const half_t* params, const half_t* grads, uint64_t n_params, DirectExport& out);
+// maps the peers; exports[r] is what rank r published (exports[rank] must be this rank's own)
+void direct_exchange_open(DirectExchange& dx, int rank, int n_ranks, const DirectExport* exports, half_t* own_params, half_t* own_grads);
+void direct_exchange_close(DirectExchange& dx);
+// phase 1 + 2 of a step: signal, wait, reduce this rank's shard (and the tail) into the own gradient buffer
+void direct_exchange_reduce(hipStream_t stream, DirectExchange& dx);
+// phase 4: push the own parameter shard to every peer, signal, wait
+void direct_exchange_push(hipStream_t stream, DirectExchange& dx);
+// 0 while every wait found its signals in time (synchronises the stream)
+int direct_exchange_status(hipStream_t stream, DirectExchange& dx);
+
+}  // namespace tcnn_hip

@@ -1,0 +1,202 @@
+// direct_exchange.hip -- see direct_exchange.h for the scheme and its status.
+#include "direct_exchange.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+namespace tcnn_hip {
+
+static_assert(sizeof(hipIpcMemHandle_t) == DIRECT_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+
+struct PeerBuffers {
+	half_t* p[DIRECT_MAX_RANKS];
+};
+struct PeerSignals {
+	uint32_t* p[DIRECT_MAX_RANKS];
+};
+constexpr uint32_t DX_THREADS = 256;
+
+// "step s of rank `me`, phase `row`, is done": one 4-byte store into every rank's signal block (the own one included), released at
+// system scope -- everything this rank's earlier kernels on the stream wrote is visible to whoever then reads the counter.
+__global__ void k_direct_signal(const PeerSignals peers, const int n_ranks, const int me, const int row, const uint32_t step) {
+	if ((int)threadIdx.x < n_ranks) {
+		__hip_atomic_store(&peers.p[threadIdx.x][row * DIRECT_MAX_RANKS + me], step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+// lane r waits until rank r has signalled `step` in `row` of THIS rank's block; gives up after `timeout_ticks` of the 100 MHz wall
+// clock and records which phase starved (the queue moves on: wrong results, reported by direct_exchange_status, instead of a hung GPU)
+__global__ void k_direct_wait(const uint32_t* own, const int n_ranks, const int row, const uint32_t step, const uint64_t timeout_ticks, uint32_t* error_flag) {
+	if ((int)threadIdx.x < n_ranks) {
+		const uint64_t t0 = wall_clock64();
+		while ((int32_t)(__hip_atomic_load(&own[row * DIRECT_MAX_RANKS + threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) {
+			if (wall_clock64() - t0 > timeout_ticks) {
+				atomicExch(error_flag, (uint32_t)(1 + row));
+				break;
+			}
+			__builtin_amdgcn_s_sleep(64);
+		}
+	}
+}
+// this rank's shard [begin, begin + count) of the summed gradient: fp32 sum over the ranks IN RANK ORDER, one rounding.  8 parameters
+// (16 bytes) per lane and iteration, one load per rank in flight; P - 1 of them cross a link each.
+__global__ void __launch_bounds__(DX_THREADS) k_direct_reduce(const PeerBuffers grads, const int n_ranks, const int me, const size_t begin, const size_t count) {
+	const size_t n8 = count / 8;
+	for (size_t i = (size_t)blockIdx.x * DX_THREADS + threadIdx.x; i < n8; i += (size_t)gridDim.x * DX_THREADS) {
+		float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		h8 v[DIRECT_MAX_RANKS];  // (fully unrolled: registers; every rank's load is issued before the first sum)
+#pragma unroll
+		for (int r = 0; r < DIRECT_MAX_RANKS; ++r) {
+			if (r < n_ranks) v[r] = *(const h8*)(grads.p[r] + begin + 8 * i);
+		}
+#pragma unroll
+		for (int r = 0; r < DIRECT_MAX_RANKS; ++r) {
+			if (r < n_ranks) {
+#pragma unroll
+				for (uint32_t k = 0; k < 8; ++k) acc[k] = acc[k] + (float)v[r][k];
+			}
+		}
+		h8 out;
+#pragma unroll
+		for (uint32_t k = 0; k < 8; ++k) out[k] = to_half_rn(acc[k]);
+		*(h8*)(grads.p[me] + begin + 8 * i) = out;
+	}
+	// what does not fill a 16-byte group (the replicated tail: < 8 P parameters): element by element, by the first workgroup
+	if (blockIdx.x == 0) {
+		for (size_t e = n8 * 8 + threadIdx.x; e < count; e += DX_THREADS) {
+			float acc = 0.0f;
+			for (int r = 0; r < n_ranks; ++r) acc = acc + (float)grads.p[r][begin + e];
+			grads.p[me][begin + e] = to_half_rn(acc);
+		}
+	}
+}
+// the own stepped parameter shard into every peer's parameter buffer
+__global__ void __launch_bounds__(DX_THREADS) k_direct_push(const PeerBuffers params, const int n_ranks, const int me, const size_t begin, const size_t count) {
+	const size_t n8 = count / 8;  // shards are multiples of 8
+	for (size_t i = (size_t)blockIdx.x * DX_THREADS + threadIdx.x; i < n8; i += (size_t)gridDim.x * DX_THREADS) {
+		const h8 v = *(const h8*)(params.p[me] + begin + 8 * i);
+		for (int r = 0; r < n_ranks; ++r) {
+			if (r != me) *(h8*)(params.p[r] + begin + 8 * i) = v;
+		}
+	}
+}
+
+static void hip_ok(hipError_t e, const char* what) {
+	if (e != hipSuccess) throw std::runtime_error(std::string("direct exchange: ") + what + ": " + hipGetErrorString(e));
+}
+
+void direct_exchange_export(DirectExchange& dx, void* buffer, const half_t* params, const half_t* grads, uint64_t n_params, DirectExport& out) {
+	if (!dx.own_signals) {
+		const size_t bytes = (2 * DIRECT_MAX_RANKS + 16) * sizeof(uint32_t);
+		// signal words are polled while peers write them: uncached device memory where the runtime offers it
+		void* p = nullptr;
+		if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+			(void)hipGetLastError();
+			hip_ok(hipMalloc(&p, bytes), "hipMalloc(signals)");
+		}
+		hip_ok(hipMemset(p, 0, bytes), "hipMemset(signals)");
+		hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+		dx.own_signals = (uint32_t*)p;
+		dx.error_flag = dx.own_signals + 2 * DIRECT_MAX_RANKS;
+	}
+	std::memset(&out, 0, sizeof(out));
+	hipIpcMemHandle_t h;
+	hip_ok(hipIpcGetMemHandle(&h, buffer), "hipIpcGetMemHandle(trainer buffer) -- direct exchange needs the plain allocator (no TCNN_DEBUG_ALLOC)");
+	std::memcpy(out.buffer_handle, &h, DIRECT_HANDLE_BYTES);
+	hip_ok(hipIpcGetMemHandle(&h, dx.own_signals), "hipIpcGetMemHandle(signals)");
+	std::memcpy(out.signal_handle, &h, DIRECT_HANDLE_BYTES);
+	out.params_offset = (uint64_t)((const char*)params - (const char*)buffer);
+	out.grads_offset = (uint64_t)((const char*)grads - (const char*)buffer);
+	out.n_params = n_params;
+}
+
+void direct_exchange_open(DirectExchange& dx, int rank, int n_ranks, const DirectExport* exports, half_t* own_params, half_t* own_grads) {
+	if (n_ranks < 1 || n_ranks > DIRECT_MAX_RANKS || rank < 0 || rank >= n_ranks) throw std::runtime_error("direct exchange: rank / n_ranks out of range (at most 16 ranks)");
+	if (!dx.own_signals) throw std::runtime_error("direct exchange: export before open");
+	direct_exchange_close(dx);
+	const uint64_t n = exports[rank].n_params;
+	for (int r = 0; r < n_ranks; ++r) {
+		if (exports[r].n_params != n) throw std::runtime_error("direct exchange: the ranks' models differ in their parameter count");
+	}
+	for (int r = 0; r < n_ranks; ++r) {
+		if (r == rank) {
+			dx.grads[r] = own_grads;
+			dx.params[r] = own_params;
+			dx.signals[r] = dx.own_signals;
+			continue;
+		}
+		hipIpcMemHandle_t h;
+		std::memcpy(&h, exports[r].buffer_handle, DIRECT_HANDLE_BYTES);
+		hip_ok(hipIpcOpenMemHandle(&dx.mapped_buffers[r], h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle(peer trainer buffer)");
+		std::memcpy(&h, exports[r].signal_handle, DIRECT_HANDLE_BYTES);
+		hip_ok(hipIpcOpenMemHandle(&dx.mapped_signals[r], h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle(peer signals)");
+		dx.grads[r] = (half_t*)((char*)dx.mapped_buffers[r] + exports[r].grads_offset);
+		dx.params[r] = (half_t*)((char*)dx.mapped_buffers[r] + exports[r].params_offset);
+		dx.signals[r] = (uint32_t*)dx.mapped_signals[r];
+	}
+	dx.rank = rank;
+	dx.n_ranks = n_ranks;
+	dx.n_params = n;
+	dx.shard = (size_t)(n / (8ull * n_ranks)) * 8;
+	dx.main = dx.shard * n_ranks;
+	dx.step = 0;
+	const char* e = getenv("TCNN_DIRECT_TIMEOUT_MS");
+	dx.timeout_ms = e ? (uint32_t)atoi(e) : 2000u;
+	hip_ok(hipMemset(dx.own_signals, 0, (2 * DIRECT_MAX_RANKS + 16) * sizeof(uint32_t)), "hipMemset(signals)");
+	hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+}
+
+void direct_exchange_close(DirectExchange& dx) {
+	for (int r = 0; r < DIRECT_MAX_RANKS; ++r) {
+		if (dx.mapped_buffers[r]) (void)hipIpcCloseMemHandle(dx.mapped_buffers[r]);
+		if (dx.mapped_signals[r]) (void)hipIpcCloseMemHandle(dx.mapped_signals[r]);
+		dx.mapped_buffers[r] = dx.mapped_signals[r] = nullptr;
+		dx.grads[r] = dx.params[r] = nullptr;
+		dx.signals[r] = nullptr;
+	}
+	dx.n_ranks = 0;
+	dx.rank = -1;
+}
+
+static void signal_and_wait(hipStream_t stream, DirectExchange& dx, int row) {
+	PeerSignals ps;
+	for (int r = 0; r < DIRECT_MAX_RANKS; ++r) ps.p[r] = dx.signals[r];
+	const uint64_t ticks = (uint64_t)dx.timeout_ms * 100000ull;  // wall_clock64: 100 MHz
+	TCNN_LAUNCH(k_direct_signal, dim3(1), dim3(64), 0, stream, ps, dx.n_ranks, dx.rank, row, dx.step);
+	TCNN_LAUNCH(k_direct_wait, dim3(1), dim3(64), 0, stream, (const uint32_t*)dx.own_signals, dx.n_ranks, row, dx.step, ticks, dx.error_flag);
+}
+
+void direct_exchange_reduce(hipStream_t stream, DirectExchange& dx) {
+	if (!dx.active()) throw std::runtime_error("direct exchange: not open");
+	++dx.step;
+	signal_and_wait(stream, dx, 0);  // everybody's gradients of this step are final
+	PeerBuffers g;
+	for (int r = 0; r < DIRECT_MAX_RANKS; ++r) g.p[r] = dx.grads[r];
+	if (dx.shard) {
+		const uint32_t blocks = (uint32_t)std::min<size_t>(div_round_up<size_t>(dx.shard / 8, DX_THREADS), 2048);
+		TCNN_LAUNCH(k_direct_reduce, dim3(blocks), dim3(DX_THREADS), 0, stream, g, dx.n_ranks, dx.rank, (size_t)dx.rank * dx.shard, dx.shard);
+	}
+	if (dx.main < dx.n_params) TCNN_LAUNCH(k_direct_reduce, dim3(1), dim3(DX_THREADS), 0, stream, g, dx.n_ranks, dx.rank, dx.main, (size_t)(dx.n_params - dx.main));
+}
+
+void direct_exchange_push(hipStream_t stream, DirectExchange& dx) {
+	if (!dx.active()) throw std::runtime_error("direct exchange: not open");
+	PeerBuffers p;
+	for (int r = 0; r < DIRECT_MAX_RANKS; ++r) p.p[r] = dx.params[r];
+	if (dx.shard && dx.n_ranks > 1) {
+		const uint32_t blocks = (uint32_t)std::min<size_t>(div_round_up<size_t>(dx.shard / 8, DX_THREADS), 2048);
+		TCNN_LAUNCH(k_direct_push, dim3(blocks), dim3(DX_THREADS), 0, stream, p, dx.n_ranks, dx.rank, (size_t)dx.rank * dx.shard, dx.shard);
+	}
+	signal_and_wait(stream, dx, 1);  // everybody's parameters have arrived here; nobody reads this rank's gradients any more
+}
+
+int direct_exchange_status(hipStream_t stream, DirectExchange& dx) {
+	if (!dx.error_flag) return 0;
+	uint32_t v = 0;
+	hip_ok(hipMemcpyAsync(&v, dx.error_flag, sizeof(v), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(error flag)");
+	hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize");
+	return (int)v;
+}
+
+}  // namespace tcnn_hip

@@ -264,6 +264,31 @@ class TrainableModel:
         else:
             _check(_lib.tcnn_trainer_enable_rccl_sharded(self._h, C.c_void_p(nccl_comm), int(n_ranks), int(rank)))
 
+    # ---- gradient exchange over peer-mapped memory (csrc/direct_exchange.h) ----------------------
+    def direct_export(self):
+        """This rank's IPC record (bytes) for tcnn_trainer_direct_open on every rank."""
+        n = C.c_size_t(0)
+        _check(_lib.tcnn_trainer_direct_export(self._h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        _check(_lib.tcnn_trainer_direct_export(self._h, buf, n.value, C.byref(n)))
+        return buf.raw[:n.value]
+
+    def direct_open(self, rank, records):
+        """records: every rank's direct_export() bytes, in rank order.  Put a barrier between this call and the first step."""
+        blob = b"".join(records)
+        _check(_lib.tcnn_trainer_direct_open(self._h, int(rank), len(records), blob, len(records[0])))
+
+    def direct_close(self):
+        _check(_lib.tcnn_trainer_direct_close(self._h))
+
+    def direct_exchange_and_step(self, loss_scale=128.0):
+        _check(_lib.tcnn_trainer_direct_exchange_and_step(self._h, _stream(), float(loss_scale)))
+
+    def direct_status(self):
+        v = C.c_int(0)
+        _check(_lib.tcnn_trainer_direct_status(self._h, _stream(), C.byref(v)))
+        return v.value
+
     # ---- measurement hooks ---------------------------------------------------------------------
     def set_profiling(self, enable=True, only_stage=None):
         """HIP events around the stages of the training step, on the stream the kernels run on."""

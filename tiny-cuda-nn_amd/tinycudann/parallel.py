@@ -20,6 +20,11 @@ Two exchange schemes (class DataParallel):
     (asynchronously: it waits for exactly the work enqueued so far) and travels while the remaining groups are still being
     computed; exchange_and_step() then only waits range by range and steps the optimizer.  Same sums, same optimizer
     arithmetic: bit-identical to the unpipelined schemes (tests/test_distributed.py).
+  * "direct": no collective at all -- every rank maps its peers' trainer buffers (hipIpc handles exchanged once through the process
+    group) and reads the P - 1 remote shards of ITS 1/P of the gradient buffer itself, over all of its xGMI links at once (a ring moves
+    (P - 1) / P of the buffer through one link per rank), sums them in fp32 in rank order with ONE rounding, runs Adam on that shard and
+    writes the stepped parameters into every peer's buffer; stream-ordered signal / wait kernels stand where the collectives stand
+    (csrc/direct_exchange.h, tcnn_trainer_direct_*).  The process group is only used to hand the handles round and for one barrier.
 Gradients are summed in fp16: every rank's buffer is already normalised by the GLOBAL batch, so the partial sums of a
 ring are bounded by the single-GPU gradient's own magnitude (tests/test_distributed.py checks P = 8 at loss scale 128)."""
 import os
@@ -99,7 +104,7 @@ class DataParallel:
     param_gradients / params / params_inference / n_params / optimizer_step / optimizer_step_range(s) / optimizer_state)."""
 
     def __init__(self, tm, mode="sharded", loss_scale=128.0, n_buckets=None, level_groups=2, single_rank_ok=False):
-        if mode not in ("sharded", "allreduce", "pipelined", "pipelined_sharded"):
+        if mode not in ("sharded", "allreduce", "pipelined", "pipelined_sharded", "direct"):
             raise ValueError(f"unknown data-parallel mode {mode!r}")
         self.tm, self.mode, self.loss_scale, self.n_buckets = tm, mode, loss_scale, n_buckets
         # single_rank_ok: run the collectives even in a process group of ONE rank (tests: the whole exchange on the real backend
@@ -128,6 +133,11 @@ class DataParallel:
         if self.pipelined and self.active:
             tm.set_backward_level_groups(max(1, int(level_groups)))
             tm.set_gradient_ready_callback(self._on_ready)
+        if mode == "direct" and self.active:
+            records = [None] * self.world
+            dist.all_gather_object(records, tm.direct_export())
+            tm.direct_open(self.rank, records)
+            dist.barrier()  # nobody signals before everybody has mapped (and cleared) its signal block
 
     def _fetch_params(self):
         if not self._params_fetched:
@@ -303,6 +313,8 @@ class DataParallel:
         start = self._tic()
         if self.pipelined:
             self._finish_pipelined()
+        elif self.mode == "direct":
+            self.tm.direct_exchange_and_step(self.loss_scale)
         elif self.mode == "allreduce":
             reduce_and_step(self.tm, self.grads, self.n_buckets, self.loss_scale)
         else:
@@ -322,10 +334,10 @@ class DataParallel:
     def gather_optimizer_state(self):
         """Sharded mode: collects the fp32 master weights and Adam's state from their owners so that this rank can write a
         complete snapshot (Trainer::serialize with the optimizer, trainer.h:442-455)."""
-        if not self.active or self.mode not in ("sharded", "pipelined_sharded") or not self.main:
+        if not self.active or self.mode not in ("sharded", "pipelined_sharded", "direct") or not self.main:
             return
         m1, m2, steps, _ = self.tm.optimizer_state()
-        if self.mode == "sharded":
+        if self.mode in ("sharded", "direct"):  # (the snapshot path: ordinary collectives of the process group)
             for buf in (self.tm.params_full_precision, m1, m2, steps):
                 self._all_gather(buf)
             return

@@ -153,7 +153,7 @@ class _CpuTrainer:
 
 def _rank_gradients(n, rank, step, world=2):
     rng = np.random.default_rng(100 * step + rank)
-    if world > 2:  # more than two addends: multiples of 1/16 below 8, so that the fp16 sum is exact in ANY order a backend's ring takes
+    if world > 2 and not os.environ.get("TCNN_TEST_NONDYADIC"):  # more than two addends: multiples of 1/16 below 8, so that the fp16 sum is exact in ANY order a backend's ring takes
         g = (rng.integers(-127, 128, n) / 16.0).astype(np.float16)
     else:
         g = (rng.standard_normal(n) * 4).astype(np.float16)
@@ -181,7 +181,7 @@ def _dp_worker(rank, world, port, n, mode, out_dir):
     before = tm.m1.copy()
     dp.gather_optimizer_state()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), params=tm.params.numpy().view(np.uint16), w32=tm.w32, m1=tm.m1, m2=tm.m2, steps=tm.steps,
-             own=np.array(own), m1_before_gather=before)
+             own=np.array(own), m1_before_gather=before, grads=tm.param_gradients.numpy().view(np.uint16).copy())
     dist.destroy_process_group()
 
 
@@ -210,6 +210,32 @@ def test_data_parallel_exchange_matches_single_process(tmp_path, mode, world):
             other[b:e] = False
             other[(n // (8 * world)) * (8 * world):] = False
             assert np.array_equal(d["m1_before_gather"][b:e], ref.m1[b:e]) and not d["m1_before_gather"][other].any()
+
+
+@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
+def test_four_rank_exchange_of_nondyadic_gradients_within_the_order_tolerance(tmp_path, mode, monkeypatch):
+    """Four ranks, gradients that are NOT exactly summable in fp16 (normal values of magnitude 4): the backend adds them in an order of its own
+    choosing, each partial sum rounded to fp16.  Stated tolerance: |sum_backend - exact| <= (P - 1) x 2^-11 x sum_r |g_r| per parameter (one
+    half-ulp of a partial sum bounded by the sum of the magnitudes, per addition) -- and whatever the order was, every rank ends with the SAME
+    16-bit parameters (the exchange is a collective: replicas cannot drift).  The direct exchange (tests/test_gpu_distributed.py) has no such
+    tolerance: it adds in fp32 in rank order and rounds once."""
+    monkeypatch.setenv("TCNN_TEST_NONDYADIC", "1")
+    world, n = 4, 8 * 4 * 19 + 29
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_worker, args=(world, port, n, mode, str(tmp_path)), nprocs=world, join=True)
+    ranks = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    last = [_rank_gradients(n, r, 2, world).astype(np.float64) for r in range(world)]
+    exact, magnitude = sum(last), sum(np.abs(g) for g in last)
+    assert np.mean(exact * 16 != np.round(exact * 16)) > 0.5  # nothing convenient about these sums
+    main = (n // (8 * world)) * (8 * world)
+    for r, d in enumerate(ranks):
+        got = d["grads"].view(np.float16).astype(np.float64)
+        b, e = (int(d["own"][0]), int(d["own"][1])) if mode == "sharded" else (0, n)
+        for lo, hi in ((b, e), (main, n)):
+            assert np.all(np.abs(got[lo:hi] - exact[lo:hi]) <= (world - 1) * 2.0 ** -11 * magnitude[lo:hi] + 1e-12), (mode, r)
+        assert np.array_equal(d["params"], ranks[0]["params"]), (mode, r)
 
 
 def test_fp16_gradient_sum_over_eight_ranks_does_not_overflow():

@@ -272,5 +272,56 @@ int main() {
 	WRITE("12 B plain stores", 1, rd)
 	WRITE("12 B write-through (sc1) stores", 2, rd)
 	WRITE("8+2 B nt stores", 3, rd10)
+
+	// Does the read side pay for the write side's deferred write-backs?  Alternating launches on one buffer (the scatter -> owner sequence of
+	// the product; the write kernel's stores are line-aligned runs here), the read kernel timed on its own with events around each launch.
+	printf("== read right after the write kernel filled the same queues (the product's sequence) ==\n");
+	{
+		hipEvent_t a, b;
+		CHECK(hipEventCreate(&a));
+		CHECK(hipEventCreate(&b));
+		CHECK(hipFuncSetAttribute((const void*)k_read<512, 0, true, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
+		for (int mode = 0; mode < 3; ++mode) {
+			double read_ms = 0, write_ms = 0;
+			const int reps = 20;
+			for (int i = 0; i < reps + 3; ++i) {
+				uint32_t* q = queues;
+				float ms = 0;
+				CHECK(hipEventRecord(a));
+				if (mode == 0) hipLaunchKernelGGL((k_write<1>), dim3(16 * wgs), dim3(256), 0, 0, q, tiles, wgs);
+				else if (mode == 1) hipLaunchKernelGGL((k_write<0>), dim3(16 * wgs), dim3(256), 0, 0, q, tiles, wgs);
+				else hipLaunchKernelGGL((k_write<2>), dim3(16 * wgs), dim3(256), 0, 0, q, tiles, wgs);
+				CHECK(hipEventRecord(b));
+				CHECK(hipEventSynchronize(b));
+				CHECK(hipEventElapsedTime(&ms, a, b));
+				if (i >= 3) write_ms += ms;
+				CHECK(hipEventRecord(a));
+				hipLaunchKernelGGL((k_read<512, 0, true, 8, false>), dim3(N_QUEUES), dim3(512), LDS64, 0, q, counts, out, slices, N_QUEUES);
+				CHECK(hipEventRecord(b));
+				CHECK(hipEventSynchronize(b));
+				CHECK(hipEventElapsedTime(&ms, a, b));
+				if (i >= 3) read_ms += ms;
+			}
+			printf("%-40s write %7.1f us   read of what was just written %7.1f us\n", mode == 0 ? "plain stores" : (mode == 1 ? "nt stores" : "write-through (sc1) stores"), write_ms * 1e3 / reps,
+			       read_ms * 1e3 / reps);
+		}
+		// the same back to back without a host synchronisation in between (one pair of events around both kernels)
+		for (int mode = 0; mode < 2; ++mode) {
+			float ms = 0;
+			const int reps = 20;
+			CHECK(hipDeviceSynchronize());
+			CHECK(hipEventRecord(a));
+			for (int i = 0; i < reps; ++i) {
+				uint32_t* q = queues;
+				if (mode == 0) hipLaunchKernelGGL((k_write<1>), dim3(16 * wgs), dim3(256), 0, 0, q, tiles, wgs);
+				else hipLaunchKernelGGL((k_write<2>), dim3(16 * wgs), dim3(256), 0, 0, q, tiles, wgs);
+				hipLaunchKernelGGL((k_read<512, 0, true, 8, false>), dim3(N_QUEUES), dim3(512), LDS64, 0, q, counts, out, slices, N_QUEUES);
+			}
+			CHECK(hipEventRecord(b));
+			CHECK(hipEventSynchronize(b));
+			CHECK(hipEventElapsedTime(&ms, a, b));
+			printf("%-40s write + read back to back %7.1f us per pair\n", mode == 0 ? "plain stores" : "write-through (sc1) stores", ms * 1e3 / reps);
+		}
+	}
 	return 0;
 }

@@ -1043,20 +1043,20 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 			const uint32_t b_begin = min(threadIdx.x * per_lane, nb), b_end = min(b_begin + per_lane, nb);
 			uint32_t sum = 0;
 			for (uint32_t b = b_begin; b < b_end; ++b) sum += cnt[b];
-			part[threadIdx.x] = sum;
-			wave_lds_sync();
+			// exclusive prefix over the wave's lanes in registers: sibling blocks of 1, 2, 4, ... lanes merge, a lane in the upper sibling adds
+			// the lower sibling's total (six cross-lane moves; the LDS ladder this replaces cost eighteen LDS round trips while three waves wait)
+			uint32_t block_total = sum, running = 0;
+#pragma unroll
 			for (uint32_t d = 1; d < WAVE; d <<= 1) {
-				const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
-				wave_lds_sync();
-				part[threadIdx.x] += v;
-				wave_lds_sync();
+				const uint32_t sibling = (uint32_t)__shfl_xor((int)block_total, (int)d, 64);
+				if (threadIdx.x & d) running += sibling;
+				block_total += sibling;
 			}
-			uint32_t running = part[threadIdx.x] - sum;
 			for (uint32_t b = b_begin; b < b_end; ++b) {
 				delta[b] = running;
 				running += cnt[b];
 			}
-			if (threadIdx.x == WAVE - 1) total_p[0] = part[WAVE - 1];
+			if (threadIdx.x == WAVE - 1) total_p[0] = block_total;
 		}
 		__syncthreads();
 		const uint32_t total = total_p[0];
@@ -1360,7 +1360,7 @@ TCNN_DEVICE int to_fixed32(float v) {
 #endif
 }
 
-template <uint32_t D, uint32_t F, uint32_t THREADS>
+template <uint32_t D, uint32_t F, uint32_t THREADS, bool FUSED_ADAM>
 TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, uint32_t level, uint32_t j, uint32_t bucket, uint32_t chunk,
                                      const BucketPlan& plan, uint32_t* __restrict__ counters, const uint32_t* queues,
                                      const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient, bool accumulate, unsigned char* lds_raw,
@@ -1523,7 +1523,9 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 	};
 
 	// sole owner of the slice, overwrite: the optimizer step straight from the exact sums (GridFusedAdam), 4 parameters per lane
-	const bool step_here = fused.enabled && n_chunks == 1 && !accumulate;
+	// (a compile-time switch: with the optimizer's arithmetic in the kernel the owner needs 118 registers, without it half as many, and the
+	// register count decides how many waves stream their queues per SIMD)
+	const bool step_here = FUSED_ADAM && fused.enabled && n_chunks == 1 && !accumulate;
 	const size_t p_first = ((size_t)meta.offset[level] + slice_begin) * F;  // relative to the grid's first parameter
 	auto store_quad_and_step = [&](uint32_t q4, h4 g) {
 		*(h4*)(grad + 4 * q4) = g;  // param_gradients stays what the stand-alone path leaves there
@@ -1640,7 +1642,7 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 
 // The workgroups of pass B that own a (bucket, chunk), packed form; block -> item as in k_grid_backward_sliced, whose launch
 // (if the plan holds other kinds of items at all) skips the bucket items when this kernel runs them.
-template <uint32_t D, uint32_t F>
+template <uint32_t D, uint32_t F, bool FUSED_ADAM>
 __global__ void __launch_bounds__(OWNER_THREADS) k_grid_bucket_owner(const GridMeta meta, const SlicePlan plan, const int accumulate, const BucketPlan bplan,
                                                                       uint32_t* __restrict__ counters, const uint32_t* queues,
                                                                       const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient,
@@ -1660,7 +1662,7 @@ __global__ void __launch_bounds__(OWNER_THREADS) k_grid_bucket_owner(const GridM
 	const uint32_t slice = local_block % n_slices, chunk = local_block / n_slices;
 	const Level<D> lv = make_level<D>(meta, level);
 	if constexpr (F % 2 == 0) {  // (never launched for odd F)
-		bucket_level_packed<D, F, OWNER_THREADS>(meta, lv, level, plan.slot[item], slice, chunk, bplan, counters, queues, overflow, grid_gradient,
+		bucket_level_packed<D, F, OWNER_THREADS, FUSED_ADAM>(meta, lv, level, plan.slot[item], slice, chunk, bplan, counters, queues, overflow, grid_gradient,
 		                                         accumulate != 0, lds_raw, lds_bytes, force_wide != 0, fused);
 	}
 }
@@ -2281,9 +2283,15 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 		const int force_wide = owner_mode == 2 ? 1 : 0;
 #define BOWNER(D_, F_)                                                                                                                       \
 	if constexpr (F_ % 2 == 0) {                                                                                                             \
-		TCNN_SET_MAX_DYN_LDS((k_grid_bucket_owner<D_, F_>), owner_lds);                                                                      \
-		TCNN_LAUNCH((k_grid_bucket_owner<D_, F_>), dim3(blocks), dim3(OWNER_THREADS), owner_lds, stream, meta, plan, acc, bk_launch, counters, \
-		            (const uint32_t*)queues, (const uint32_t*)overflow, grid_gradient, owner_lds, force_wide, fused);                        \
+		if (fused.enabled) {                                                                                                                 \
+			TCNN_SET_MAX_DYN_LDS((k_grid_bucket_owner<D_, F_, true>), owner_lds);                                                            \
+			TCNN_LAUNCH((k_grid_bucket_owner<D_, F_, true>), dim3(blocks), dim3(OWNER_THREADS), owner_lds, stream, meta, plan, acc, bk_launch, counters, \
+			            (const uint32_t*)queues, (const uint32_t*)overflow, grid_gradient, owner_lds, force_wide, fused);                    \
+		} else {                                                                                                                             \
+			TCNN_SET_MAX_DYN_LDS((k_grid_bucket_owner<D_, F_, false>), owner_lds);                                                           \
+			TCNN_LAUNCH((k_grid_bucket_owner<D_, F_, false>), dim3(blocks), dim3(OWNER_THREADS), owner_lds, stream, meta, plan, acc, bk_launch, counters, \
+			            (const uint32_t*)queues, (const uint32_t*)overflow, grid_gradient, owner_lds, force_wide, fused);                    \
+		}                                                                                                                                    \
 	}
 		TCNN_GRID_DISPATCH(BOWNER)
 #undef BOWNER

@@ -14,10 +14,33 @@ namespace tcnn_hip {
 constexpr uint32_t EW_THREADS = 256;
 
 // ------------------------------------------------------------------------------------------ rng
-__global__ void k_generate_random_uniform(size_t n_elements, Pcg32 rng, float* __restrict__ out, float lower, float range) {
+// pcg32's skip-ahead by 2^k draws, k = 0 .. 39, as affine maps state -> mult[k] * state + plus[k] (the squarings of Pcg32::advance, done once on
+// the host for the stream's increment).  A thread that has to skip 4 i draws applies the maps of the set bits of 4 i: one 64-bit multiply per
+// set bit instead of the four per bit POSITION of the generic loop -- the same state, bit for bit (the maps are powers of one affine map and
+// commute), at a quarter of the quarter-rate multiplies this kernel consists of (it is what a benchmark step that draws its batch pays first).
+struct Pcg32Skip {
+	uint64_t mult[40], plus[40];
+};
+static Pcg32Skip make_pcg32_skip(const Pcg32& rng) {
+	Pcg32Skip t;
+	uint64_t cur_mult = 0x5851f42d4c957f2dULL, cur_plus = rng.inc;
+	for (int k = 0; k < 40; ++k) {
+		t.mult[k] = cur_mult;
+		t.plus[k] = cur_plus;
+		cur_plus = (cur_mult + 1) * cur_plus;
+		cur_mult *= cur_mult;
+	}
+	return t;
+}
+__global__ void k_generate_random_uniform(size_t n_elements, Pcg32 rng, const Pcg32Skip skip, float* __restrict__ out, float lower, float range) {
 	const size_t i = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
 	const size_t n_threads = (size_t)blockDim.x * gridDim.x;
-	rng.advance((int64_t)(i * 4));
+	{
+		uint64_t delta = (uint64_t)i * 4u;  // < 2^40: the host checked the element count
+		for (uint32_t k = 0; delta != 0; ++k, delta >>= 1) {
+			if (delta & 1u) rng.state = skip.mult[k] * rng.state + skip.plus[k];
+		}
+	}
 #pragma unroll
 	for (size_t j = 0; j < 4; ++j) {
 		const size_t idx = i + n_threads * j;
@@ -30,7 +53,8 @@ void generate_random_uniform(hipStream_t stream, Pcg32& rng, size_t n, float* ou
 	if (n > 0) {
 		const size_t n_threads = div_round_up(n, (size_t)4);
 		const uint32_t blocks = (uint32_t)div_round_up(n_threads, (size_t)128);  // N_THREADS_LINEAR = 128 (common.h:247)
-		TCNN_LAUNCH(k_generate_random_uniform, dim3(blocks), dim3(128), 0, stream, n, rng, out, lower, upper - lower);
+		if (n >= (1ull << 40)) throw std::runtime_error("generate_random_uniform: more than 2^40 elements");
+		TCNN_LAUNCH(k_generate_random_uniform, dim3(blocks), dim3(128), 0, stream, n, rng, make_pcg32_skip(rng), out, lower, upper - lower);
 	}
 	rng.advance((int64_t)n);
 }

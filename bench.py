@@ -251,9 +251,11 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="hash")
     ap.add_argument("--precision", choices=["fp16", "bf16"], default="fp16", help="the library build: fp16 (libtcnn_hip.so) or bfloat16 (libtcnn_hip_bf16.so)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: 2^18 samples per GPU (weak) or 2^18 in total (strong)")
-    ap.add_argument("--dp", choices=["sharded", "allreduce", "pipelined", "pipelined_sharded", "direct"], default="sharded",
+    ap.add_argument("--dp", choices=["auto", "sharded", "allreduce", "pipelined", "pipelined_sharded", "direct"], default="auto",
                     help="N > 1: gradient exchange (tinycudann/parallel.py); pipelined*: collectives started from inside the backward pass, per level group; "
-                         "direct: peer-mapped buffers read over all xGMI links at once instead of ring collectives (csrc/direct_exchange.h)")
+                         "direct: peer-mapped buffers read over all xGMI links at once instead of ring collectives (csrc/direct_exchange.h); "
+                         "auto (default): `direct` (after its link check) and `sharded` are each timed for a few untimed-region steps on throw-away "
+                         "models, the faster one runs the measurement -- the line names it and carries both trial figures")
     ap.add_argument("--level-groups", type=int, default=2, help="pipelined exchanges: level groups of the encoding's backward pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--regenerate", dest="regenerate", action="store_true", default=None,
@@ -291,20 +293,25 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    tm = tcnn.create_from_config(w["n_in"], w["n_out"], w["config"], seed=1337)
-    if args.lds_budget is not None:
-        tm.set_lds_level_budget(args.lds_budget)
     local_batch = BATCH if args.scaling == "weak" else par.shard_rows(BATCH, rank, world)[1] - par.shard_rows(BATCH, rank, world)[0]
     global_batch = int(par.all_reduce_sum(local_batch, device=device)) if world > 1 else local_batch
-    dp = None
-    if world > 1:
-        tm.set_global_batch_size(global_batch)
-        dp = par.DataParallel(tm, mode=args.dp, level_groups=args.level_groups)
+
+    def make_model(dp_mode):
+        model = tcnn.create_from_config(w["n_in"], w["n_out"], w["config"], seed=1337)
+        if args.lds_budget is not None:
+            model.set_lds_level_budget(args.lds_budget)
+        exchange = None
+        if world > 1:
+            model.set_global_batch_size(global_batch)
+            exchange = par.DataParallel(model, mode=dp_mode, level_groups=args.level_groups)  # direct: raises on EVERY rank if any rank cannot map or verify its peers
+        return model, exchange
+
     regenerate = (args.workload != "mlp") if args.regenerate is None else args.regenerate
     rng = tcnn._C.Pcg32(1337 + rank)
     batches = make_batches(w, local_batch, 4, rng, device=device, tcnn=tcnn)
     fresh = make_batches(w, local_batch, 1, rng, device=device, tcnn=tcnn)[0]  # the buffers a regenerated batch is drawn into
     mode = {"regenerate": regenerate}
+    tm = dp = None  # (assigned below; step() reads the current ones)
 
     def step(i):
         if mode["regenerate"]:  # samples/mlp_learning_an_image.cu:263-271: generate_random_uniform(batch), evaluate the target at it, training_step
@@ -319,6 +326,38 @@ def main():
             dp.exchange_and_step()
         else:
             tm.training_step(x, t, want_context=False)
+
+    # ---- N > 1, --dp auto: which exchange?  Both candidates on throw-away models (same seed, same batches), a few steps each, timed the way the
+    # measurement is (barrier + synchronize on both sides, max over ranks).  `direct` must first pass its link check on this node
+    # (tcnn_trainer_direct_selftest inside DataParallel) and finish its trial without a timed-out wait; otherwise `sharded` runs.
+    dp_mode, autotune = args.dp, None
+    if world > 1 and args.dp == "auto":
+        autotune = {"trial_steps": 20, "candidates": {}}
+        for candidate in ("direct", "sharded"):
+            try:
+                tm, dp = make_model(candidate)
+            except RuntimeError as ex:  # raised on every rank alike (parallel.DataParallel._open_direct)
+                autotune["candidates"][candidate] = {"unavailable": str(ex)[:400]}
+                tm = dp = None
+                continue
+            for i in range(5):
+                step(i)
+            par.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(autotune["trial_steps"]):
+                step(i)
+            torch.cuda.synchronize()
+            par.barrier()
+            trial_s = par.all_reduce_max(time.perf_counter() - t0, device=device)
+            bad = par.all_reduce_max(tm.direct_status() if candidate == "direct" else 0, device=device)
+            autotune["candidates"][candidate] = {"ms_per_step": trial_s / autotune["trial_steps"] * 1e3, **({"timed_out_wait": int(bad)} if bad else {})}
+            dp.close()
+            tm = dp = None
+        usable = {k: v["ms_per_step"] for k, v in autotune["candidates"].items() if "ms_per_step" in v and not v.get("timed_out_wait")}
+        dp_mode = par.broadcast_object(min(usable, key=usable.get) if usable else "sharded")
+        autotune["chosen"] = dp_mode
+    tm, dp = make_model(dp_mode)
 
     def breakdown_pass():
         """Fully instrumented steps (HIP events around every stage): the per-stage breakdown of the line; not part of `value`."""
@@ -370,7 +409,7 @@ def main():
     elapsed = par.all_reduce_max(elapsed, device=device)
     dom_ms, dom_cnt = tm.stage_times()[dominant]
     comm = dp.comm_seconds() if dp is not None else None
-    if dp is not None and args.dp == "direct" and tm.direct_status() != 0:
+    if dp is not None and dp_mode == "direct" and tm.direct_status() != 0:
         raise SystemExit(f"rank {rank}: a wait of the direct exchange timed out (phase {tm.direct_status()}): the measurement is void")
 
     # ---- the same number of steps once more on batches that are resident in HBM (round 1-3's protocol): `value_resident` -------------
@@ -463,7 +502,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": ("bf16 (bfloat16" if args.precision == "bf16" else "f16 (fp16") + " params/activations/gradients, fp32 MFMA accumulate, fp32 Adam state)", "data": "synthetic",
             "config": {"workload": w["describe"], "batch_per_gpu": local_batch, "global_batch": global_batch, "n_params": tm.n_params,
-                       "parallelism": f"dp{world} ({args.dp})" if world > 1 else "single"},
+                       "parallelism": f"dp{world} ({dp_mode})" if world > 1 else "single"},
             "roofline": roofline,
             "protocol": {"batches": ("regenerated inside every timed step: positions drawn with the library's pcg32 kernel, targets evaluated at them on the device, then "
                                      "training_step (samples/mlp_learning_an_image.cu:263-271)") if regenerate else "four batches resident in HBM, rotated",
@@ -481,12 +520,16 @@ def main():
             line["ms_per_step_resident"] = elapsed_resident / args.steps * 1e3
         if inference is not None:
             line["inference"] = inference
+        if autotune is not None:
+            line["dp_autotune"] = autotune
         if comm is not None:
             line["comm"] = {"seconds_per_step": comm / args.steps, "share_of_step": comm / elapsed,
                             "note": "GPU event intervals of rank 0 around the exchange: the collectives AND, in the sharded scheme, the optimizer step on the rank's shard that sits between them"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, *batches[0], budget_s=float(os.environ.get("TCNN_BENCH_CPU_BUDGET_S", "12")), bf16=args.precision == "bf16")
         print(json.dumps(line))
+    if dp is not None:
+        dp.close()
     par.barrier()
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -295,6 +295,11 @@ int tcnn_trainer_direct_open(tcnn_trainable_model_t* tm, int rank, int n_ranks, 
 int tcnn_trainer_direct_close(tcnn_trainable_model_t* tm);
 int tcnn_trainer_direct_exchange_and_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream, float loss_scale);
 int tcnn_trainer_direct_status(tcnn_trainable_model_t* tm, tcnn_stream_t stream, int* status);
+/* link check of an opened exchange, to run once before it is trusted (collective: every rank, same rounds and seed, between steps; it
+ * overwrites the gradient buffer and nothing else): rounds x {every rank fills its gradient buffer with a pattern, the shards are reduced
+ * and pushed exactly as a step does it, every rank compares its whole buffer with the sum it must hold}.  *mismatches = elements of this
+ * rank's buffer that were wrong (0 on a working node); *status as above. */
+int tcnn_trainer_direct_selftest(tcnn_trainable_model_t* tm, tcnn_stream_t stream, uint32_t rounds, uint32_t seed, uint64_t* mismatches, int* status);
 /* Adam's state (device pointers, n_params elements each): which = 0 first moments (fp32), 1 second moments (fp32),
  * 2 per-parameter step counters (u32; *steps_are_deficits = 1: the array holds `optimizer steps done - counter`). */
 void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* steps_are_deficits);

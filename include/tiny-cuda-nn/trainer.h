@@ -147,6 +147,14 @@ public:
 	}
 	void direct_open(int rank, int n_ranks, const std::vector<uint8_t>& all_records) { check(tcnn_trainer_direct_open(m_h->tm, rank, n_ranks, all_records.data(), all_records.size() / (size_t)n_ranks)); }
 	void direct_close() { check(tcnn_trainer_direct_close(m_h->tm)); }
+	// link check of the opened exchange (collective, between steps; overwrites the gradient buffer only): wrong elements of this rank's buffer
+	uint64_t direct_selftest(hipStream_t stream, uint32_t rounds = 3, uint32_t seed = 0, int* status = nullptr) {
+		uint64_t bad = 0;
+		int st = 0;
+		check(tcnn_trainer_direct_selftest(m_h->tm, stream, rounds, seed, &bad, &st));
+		if (status) *status = st;
+		return bad;
+	}
 	tcnn_trainable_model_t* c_handle() const { return m_h->tm; }
 
 private:

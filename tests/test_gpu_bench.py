@@ -72,21 +72,29 @@ def test_driver_bench_command_in_fresh_processes():
     assert max(values) <= 1.15 * min(values), values  # fresh processes agree
 
 
-@pytest.mark.parametrize("dp", ["sharded", "pipelined_sharded", "direct"])
+@pytest.mark.parametrize("dp", [None, "sharded", "pipelined_sharded", "direct"])
 def test_driver_multi_gpu_command_with_two_ranks_on_one_gpu(dp):
     """The driver's N > 1 form -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
     bench.py --gpus N --steps K --warmup W` -- with N = 2 ranks sharing the one GPU of the test box (gloo transport: RCCL refuses two
     ranks on a device; TCNN_BENCH_BACKEND / TCNN_BENCH_DEVICE exist for exactly this): launcher environment, barrier + max over ranks,
-    ONE line from rank 0, whole-job value, the communication share."""
+    ONE line from rank 0, whole-job value, the communication share.  Without --dp (the driver's command) the exchange is chosen by
+    trial: `direct` after its link check against `sharded`, the line carries both trial figures and names the choice."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--dp", dp]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"] + (["--dp", dp] if dp else [])
     d = _run(cmd, TCNN_BENCH_BACKEND="gloo", TCNN_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    if dp is None:
+        a = d["dp_autotune"]
+        assert set(a["candidates"]) == {"direct", "sharded"} and all("ms_per_step" in c and "timed_out_wait" not in c for c in a["candidates"].values()), a
+        dp = a["chosen"]
+        assert a["candidates"][dp]["ms_per_step"] == min(c["ms_per_step"] for c in a["candidates"].values())
+    else:
+        assert "dp_autotune" not in d
     assert d["config"]["batch_per_gpu"] == 1 << 18 and d["config"]["global_batch"] == 2 << 18 and dp in d["config"]["parallelism"]
     assert abs(d["value"] - (2 << 18) / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]  # whole-job samples/s
     assert "cpu_baseline" not in d and 0.0 < d["comm"]["share_of_step"] <= 1.0

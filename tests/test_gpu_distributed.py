@@ -144,11 +144,20 @@ def _direct_worker(rank, world, port, out_path):
     ok["status"] = tm.direct_status()
     ok["steps"] = tm.optimizer_step_count
     dp.gather_optimizer_state()
+    params = tm.params_full_precision.cpu()
+    # the link check (DataParallel ran it once before the first step): clean between steps, and NOT vacuous -- ranks that disagree about the
+    # pattern (a seed of their own) must all see wrong sums
+    before = tm.params.clone()
+    ok["selftest"] = tm.direct_selftest(rounds=2, seed=3)
+    ok["selftest_disagreeing"] = tm.direct_selftest(rounds=1, seed=100 + r)
+    ok["selftest_leaves_parameters_alone"] = bool(torch.equal(before.view(torch.int16), tm.params.view(torch.int16)))
+    everyone = [None] * w
+    dist.all_gather_object(everyone, (ok["selftest"], ok["selftest_disagreeing"], ok["selftest_leaves_parameters_alone"]))
     if r == 0:
-        ok["params"] = tm.params_full_precision.cpu()
+        ok["selftest_all"] = everyone
+        ok["params"] = params
         torch.save(ok, out_path)
-    dist.barrier()
-    tm.direct_close()
+    dp.close()
     dist.destroy_process_group()
 
 
@@ -156,7 +165,8 @@ def _direct_worker(rank, world, port, out_path):
 def test_direct_exchange_over_peer_mapped_memory(tmp_path, world):
     """tcnn_trainer_direct_*: every rank's shard of the reduced gradient is, bit for bit, the fp32 sum of all ranks' 16-bit gradients in rank
     order rounded once (non-dyadic values: real gradients of a training step); every rank ends each step with the same 16-bit parameters;
-    no wait timed out; the trajectory tracks the single-process one as the collective schemes' do."""
+    no wait timed out; the trajectory tracks the single-process one as the collective schemes' do.  tcnn_trainer_direct_selftest (the link
+    check DataParallel runs before the first step) reports a clean exchange and catches ranks that disagree about the pattern."""
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -169,6 +179,8 @@ def test_direct_exchange_over_peer_mapped_memory(tmp_path, world):
     for step in range(STEPS):
         for key in ("own_shard", "tail", "nondyadic", "replicas"):
             assert res[f"{key}_{step}"], (key, step)
+    for clean, disagreeing, untouched in res["selftest_all"]:  # every rank
+        assert tuple(clean) == (0, 0) and disagreeing[0] > 0 and disagreeing[1] == 0 and untouched
     tm = _model()
     x, t = _data()
     x, t = x.cuda(), t.cuda()

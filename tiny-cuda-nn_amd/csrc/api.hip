@@ -1970,6 +1970,15 @@ int tcnn_trainer_direct_status(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
 	TCNN_API_END
 }
 
+// Link check of an opened exchange (collective: same rounds and seed on every rank, between steps; overwrites the gradient buffer only).
+// *mismatches: elements of this rank's buffer that did not hold the expected sum; *status as tcnn_trainer_direct_status.
+int tcnn_trainer_direct_selftest(tcnn_trainable_model_t* tm, tcnn_stream_t stream, uint32_t rounds, uint32_t seed, uint64_t* mismatches, int* status) {
+	TCNN_API_BEGIN
+	if (!tm->direct.active()) throw std::runtime_error("tcnn_trainer_direct_selftest: tcnn_trainer_direct_open first");
+	direct_exchange_selftest((hipStream_t)stream, tm->direct, rounds, seed, mismatches, status);
+	TCNN_API_END
+}
+
 // Adam's state for snapshots / sharded data parallelism: which = 0 first moments (fp32), 1 second moments (fp32),
 // 2 per-parameter step counters (u32; *steps_are_deficits tells their representation, see tcnn_trainer_optimizer_step_range).
 void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* steps_are_deficits) {

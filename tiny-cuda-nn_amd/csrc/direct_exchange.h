@@ -64,6 +64,8 @@ void direct_exchange_close(DirectExchange& dx);
 void direct_exchange_reduce(hipStream_t stream, DirectExchange& dx);
 // phase 4: push the own parameter shard to every peer, signal, wait
 void direct_exchange_push(hipStream_t stream, DirectExchange& dx);
+// link check (collective; clobbers the gradient buffers): rounds x {pattern -> reduce -> push the reduced shards -> compare the whole buffer}
+void direct_exchange_selftest(hipStream_t stream, DirectExchange& dx, uint32_t rounds, uint32_t seed, uint64_t* mismatches, int* status);
 // 0 while every wait found its signals in time (synchronises the stream)
 int direct_exchange_status(hipStream_t stream, DirectExchange& dx);
 

@@ -82,6 +82,26 @@ __global__ void __launch_bounds__(DX_THREADS) k_direct_push(const PeerBuffers pa
 	}
 }
 
+// ---- link check (direct_exchange_selftest): a pattern only (rank, element, round, seed) determine; multiples of 1/16 below 1/2, so that the
+// sum over up to 16 ranks (< 8: seven bits) is exact in fp16 AND bfloat16 whatever the order
+TCNN_HOST_DEVICE float selftest_pattern(uint32_t rank, uint64_t i, uint32_t round, uint32_t seed) {
+	return (float)((uint32_t)((i * 7ull + rank * 13ull + round * 29ull + seed * 5ull) % 8ull)) * 0.0625f;
+}
+__global__ void __launch_bounds__(DX_THREADS) k_direct_selftest_fill(half_t* grads, const size_t n, const uint32_t rank, const uint32_t round, const uint32_t seed) {
+	for (size_t i = (size_t)blockIdx.x * DX_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * DX_THREADS) grads[i] = (half_t)selftest_pattern(rank, i, round, seed);
+}
+// after reduce + push every element of the own buffer must hold the sum of all ranks' patterns of THIS round
+__global__ void __launch_bounds__(DX_THREADS) k_direct_selftest_check(const half_t* grads, const size_t n, const uint32_t n_ranks, const uint32_t round, const uint32_t seed,
+                                                                      unsigned long long* mismatches) {
+	unsigned long long bad = 0;
+	for (size_t i = (size_t)blockIdx.x * DX_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * DX_THREADS) {
+		float expected = 0.0f;
+		for (uint32_t r = 0; r < n_ranks; ++r) expected += selftest_pattern(r, i, round, seed);
+		if ((float)grads[i] != expected) ++bad;
+	}
+	if (bad) atomicAdd(mismatches, bad);
+}
+
 static void hip_ok(hipError_t e, const char* what) {
 	if (e != hipSuccess) throw std::runtime_error(std::string("direct exchange: ") + what + ": " + hipGetErrorString(e));
 }
@@ -189,6 +209,40 @@ void direct_exchange_push(hipStream_t stream, DirectExchange& dx) {
 		TCNN_LAUNCH(k_direct_push, dim3(blocks), dim3(DX_THREADS), 0, stream, p, dx.n_ranks, dx.rank, (size_t)dx.rank * dx.shard, dx.shard);
 	}
 	signal_and_wait(stream, dx, 1);  // everybody's parameters have arrived here; nobody reads this rank's gradients any more
+}
+
+// Link check before the exchange is trusted with a training run: `rounds` times every rank fills its GRADIENT buffer with a pattern of the
+// round, the ranks reduce their shards exactly as a step does (signal, wait, read the peers), push the reduced shard into every peer's
+// gradient buffer exactly as a step pushes parameters (peer writes, signal, wait), and every rank compares its whole buffer with the sum it
+// must hold.  A stale line anywhere (a poll that never sees the peer's store, a remote read served from a cache that kept last round's
+// data, a push that had not landed when the signal did) shows up as mismatches or as a timed-out wait.  Collective: every rank must call it
+// with the same rounds and seed, between steps; it clobbers the gradient buffer and nothing else.
+void direct_exchange_selftest(hipStream_t stream, DirectExchange& dx, uint32_t rounds, uint32_t seed, uint64_t* mismatches, int* status) {
+	if (!dx.active()) throw std::runtime_error("direct exchange: not open");
+	unsigned long long* counter = nullptr;
+	hip_ok(hipMalloc((void**)&counter, sizeof(*counter)), "hipMalloc(self-test counter)");
+	hip_ok(hipMemsetAsync(counter, 0, sizeof(*counter), stream), "hipMemsetAsync");
+	PeerBuffers g;
+	for (int r = 0; r < DIRECT_MAX_RANKS; ++r) g.p[r] = dx.grads[r];
+	half_t* own = dx.grads[dx.rank];
+	const size_t n = (size_t)dx.n_params;
+	const uint32_t blocks = (uint32_t)std::min<size_t>(div_round_up<size_t>(n, DX_THREADS), 4096);
+	for (uint32_t round = 0; round < rounds; ++round) {
+		TCNN_LAUNCH(k_direct_selftest_fill, dim3(blocks), dim3(DX_THREADS), 0, stream, own, n, (uint32_t)dx.rank, round, seed);
+		direct_exchange_reduce(stream, dx);
+		if (dx.shard && dx.n_ranks > 1) {
+			const uint32_t pb = (uint32_t)std::min<size_t>(div_round_up<size_t>(dx.shard / 8, DX_THREADS), 2048);
+			TCNN_LAUNCH(k_direct_push, dim3(pb), dim3(DX_THREADS), 0, stream, g, dx.n_ranks, dx.rank, (size_t)dx.rank * dx.shard, dx.shard);
+		}
+		signal_and_wait(stream, dx, 1);
+		TCNN_LAUNCH(k_direct_selftest_check, dim3(blocks), dim3(DX_THREADS), 0, stream, (const half_t*)own, n, (uint32_t)dx.n_ranks, round, seed, counter);
+	}
+	unsigned long long bad = 0;
+	hip_ok(hipMemcpyAsync(&bad, counter, sizeof(bad), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(self-test counter)");
+	hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize");
+	(void)hipFree(counter);
+	if (mismatches) *mismatches = (uint64_t)bad;
+	if (status) *status = direct_exchange_status(stream, dx);
 }
 
 int direct_exchange_status(hipStream_t stream, DirectExchange& dx) {

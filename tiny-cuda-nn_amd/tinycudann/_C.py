@@ -149,6 +149,7 @@ _sig("tcnn_trainer_direct_open", _i, _vp, _i, _i, _vp, _sz)
 _sig("tcnn_trainer_direct_close", _i, _vp)
 _sig("tcnn_trainer_direct_exchange_and_step", _i, _vp, _vp, _f)
 _sig("tcnn_trainer_direct_status", _i, _vp, _vp, C.POINTER(_i))
+_sig("tcnn_trainer_direct_selftest", _i, _vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(_i))
 GRADIENT_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p)  # (user, begin, end, stream)
 _sig("tcnn_trainer_optimizer_state", _vp, _vp, _i, C.POINTER(_i))
 _sig("tcnn_trainer_params_written", _i, _vp)

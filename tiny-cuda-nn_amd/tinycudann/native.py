@@ -289,6 +289,13 @@ class TrainableModel:
         _check(_lib.tcnn_trainer_direct_status(self._h, _stream(), C.byref(v)))
         return v.value
 
+    def direct_selftest(self, rounds=3, seed=0):
+        """Link check of an opened exchange (collective: every rank, same arguments, between steps; overwrites the gradient buffer):
+        returns (mismatching elements of this rank's buffer, status as direct_status())."""
+        bad, st = C.c_uint64(0), C.c_int(0)
+        _check(_lib.tcnn_trainer_direct_selftest(self._h, _stream(), int(rounds), int(seed), C.byref(bad), C.byref(st)))
+        return bad.value, st.value
+
     # ---- measurement hooks ---------------------------------------------------------------------
     def set_profiling(self, enable=True, only_stage=None):
         """HIP events around the stages of the training step, on the stream the kernels run on."""

@@ -103,7 +103,7 @@ class DataParallel:
     """Gradient exchange + optimizer of one data-parallel rank.  `tm`: a tinycudann.native.TrainableModel (or anything with
     param_gradients / params / params_inference / n_params / optimizer_step / optimizer_step_range(s) / optimizer_state)."""
 
-    def __init__(self, tm, mode="sharded", loss_scale=128.0, n_buckets=None, level_groups=2, single_rank_ok=False):
+    def __init__(self, tm, mode="sharded", loss_scale=128.0, n_buckets=None, level_groups=2, single_rank_ok=False, verify_direct=True):
         if mode not in ("sharded", "allreduce", "pipelined", "pipelined_sharded", "direct"):
             raise ValueError(f"unknown data-parallel mode {mode!r}")
         self.tm, self.mode, self.loss_scale, self.n_buckets = tm, mode, loss_scale, n_buckets
@@ -134,10 +134,57 @@ class DataParallel:
             tm.set_backward_level_groups(max(1, int(level_groups)))
             tm.set_gradient_ready_callback(self._on_ready)
         if mode == "direct" and self.active:
-            records = [None] * self.world
-            dist.all_gather_object(records, tm.direct_export())
-            tm.direct_open(self.rank, records)
-            dist.barrier()  # nobody signals before everybody has mapped (and cleared) its signal block
+            self._open_direct(verify_direct)
+
+    def _agree(self, failure):
+        """Every rank learns whether ANY rank failed (and why): set-up errors must take all ranks down the same path, or the survivors
+        wait in a collective the failed rank never enters."""
+        reports = [None] * self.world
+        dist.all_gather_object(reports, failure)
+        return [f"rank {r}: {f}" for r, f in enumerate(reports) if f]
+
+    def _open_direct(self, verify):
+        tm = self.tm
+        failure, record = None, None
+        try:
+            record = tm.direct_export()
+        except Exception as ex:  # (e.g. the checking allocator, an Ema wrapper: see tcnn_trainer_direct_export)
+            failure = f"export: {ex}"
+        records = [None] * self.world
+        dist.all_gather_object(records, record)
+        if failure is None and any(r is None for r in records):
+            failure = "a peer could not export its buffers"
+        if failure is None:
+            try:
+                tm.direct_open(self.rank, records)
+            except Exception as ex:  # hipIpcOpenMemHandle: no peer access between the two devices, IPC disabled, ...
+                failure = f"open: {ex}"
+        failed = self._agree(failure)  # doubles as the barrier: nobody signals before everybody has mapped (and cleared) its signal block
+        if not failed and verify:
+            # the link check (tcnn_trainer_direct_selftest): the exchange itself on known patterns, three rounds, before gradients depend on it
+            try:
+                bad, status = tm.direct_selftest(rounds=3, seed=0)
+                if bad or status:
+                    failure = f"self-test: {bad} wrong elements" + (f", a wait timed out in phase {status}" if status else "")
+            except Exception as ex:
+                failure = f"self-test: {ex}"
+            failed = self._agree(failure)
+        if failed:
+            try:
+                tm.direct_close()
+            except Exception:
+                pass
+            dist.barrier()
+            raise RuntimeError("direct exchange unavailable on this node (fall back to mode='sharded'): " + "; ".join(failed))
+
+    def close(self):
+        """Direct mode: unmaps the peers' buffers (collective; call before a model that was opened for the direct exchange is dropped)."""
+        if self.mode == "direct" and self.active:
+            torch.cuda.synchronize()
+            dist.barrier()  # nobody unmaps while a peer's last step still reads or writes
+            self.tm.direct_close()
+            dist.barrier()
+            self.active = False
 
     def _fetch_params(self):
         if not self._params_fetched:

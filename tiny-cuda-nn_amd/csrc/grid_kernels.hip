@@ -1416,7 +1416,11 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 	constexpr bool PIPELINED = false;
 #endif
 	typedef uint32_t rec3_t __attribute__((ext_vector_type(3)));
-	rec3_t half_a[4], half_b[4];
+#ifndef TCNN_OWNER_GROUPS
+#define TCNN_OWNER_GROUPS 2
+#endif
+	constexpr uint32_t NG = TCNN_OWNER_GROUPS;  // groups of 4 records in flight per lane
+	rec3_t grp[NG][4];
 	uint32_t first_round[PIPELINED ? 1 : STREAM_U][PWP];
 #if !defined(TCNN_HOST_EMU)
 	const uint64_t q_address = (uint64_t)(uintptr_t)q;  // wave-uniform: into a scalar register pair, the loads' base
@@ -1430,13 +1434,16 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 			asm volatile("global_load_dwordx3 %0, %1, %2 nt" : "=v"(h[u]) : "v"(byte_offset), "s"(q_scalar) : "memory");
 		}
 	};
-	auto await_older_half = [&](rec3_t (&h)[4]) { asm volatile("s_waitcnt vmcnt(4)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3])::"memory"); };
+	// (all NG groups outstanding: "at most 4 (NG - 1) loads outstanding" means the oldest group has landed)
+	auto await_oldest_group = [&](rec3_t (&h)[4]) {
+		asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]) : [n] "n"(4 * (NG - 1)) : "memory");
+	};
 #endif
 	if constexpr (PIPELINED) {
 #if !defined(TCNN_HOST_EMU)
 		if (safe) {  // (only the packed pass consumes them -- and nothing the compiler does not know of may stay in flight otherwise)
-			issue_half(half_a, threadIdx.x, cap - 1u);
-			issue_half(half_b, threadIdx.x + 4u * THREADS, cap - 1u);
+#pragma unroll
+			for (uint32_t k = 0; k < NG; ++k) issue_half(grp[k], threadIdx.x + 4u * k * THREADS, cap - 1u);
 		}
 #endif
 	} else {
@@ -1493,17 +1500,24 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 			}
 		};
 		const uint32_t last = count ? count - 1u : 0u;
-		for (uint32_t round = 0; round < count; round += 8u * THREADS) {  // workgroup-uniform trip count: every wave issues the same loads
+		// every round but the last re-requests its groups (workgroup-uniform trip count: every wave issues the same loads); the last
+		// one only drains -- a request beyond the queue's end is a load instruction and a round trip the lane then has to wait out
+		uint32_t round = 0;
+		for (; round + 4u * NG * THREADS < count; round += 4u * NG * THREADS) {
 			const uint32_t first = round + threadIdx.x;
-			await_older_half(half_a);
-			add_half(first, half_a);
-			issue_half(half_a, first + 8u * THREADS, last);
-			await_older_half(half_b);
-			add_half(first + 4u * THREADS, half_b);
-			issue_half(half_b, first + 12u * THREADS, last);
+#pragma unroll
+			for (uint32_t k = 0; k < NG; ++k) {
+				await_oldest_group(grp[k]);
+				add_half(first + 4u * k * THREADS, grp[k]);
+				issue_half(grp[k], first + 4u * (NG + k) * THREADS, last);
+			}
 		}
 		// nothing of this lane's may still be on its way into registers the compiler is about to reuse
-		asm volatile("s_waitcnt vmcnt(0)" : "+v"(half_a[0]), "+v"(half_a[1]), "+v"(half_a[2]), "+v"(half_a[3]), "+v"(half_b[0]), "+v"(half_b[1]), "+v"(half_b[2]), "+v"(half_b[3])::"memory");
+#pragma unroll
+		for (uint32_t k = 0; k < NG; ++k) {
+			asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(grp[k][0]), "+v"(grp[k][1]), "+v"(grp[k][2]), "+v"(grp[k][3]) : [n] "n"(4 * (NG - 1 - k)) : "memory");
+			if (round < count) add_half(round + threadIdx.x + 4u * k * THREADS, grp[k]);
+		}
 #endif
 		if (inline_overflow && chunk == 0u) {
 			for (uint32_t t = threadIdx.x; t < n_over; t += THREADS) {

@@ -1,0 +1,24 @@
+import ctypes as C, os, sys, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tiny-cuda-nn_amd"))
+import bench, tinycudann as tcnn
+w = bench.WORKLOADS["hash"]
+tm = tcnn.create_from_config(w["n_in"], w["n_out"], w["config"], seed=1337)
+rng = tcnn._C.Pcg32(1337)
+batches = bench.make_batches(w, bench.BATCH, 4, rng, device=torch.device("cuda", 0), tcnn=tcnn)
+for i in range(30): tm.training_step(*batches[i % 4], want_context=False)
+torch.cuda.synchronize()
+buf = np.zeros((4096, 8), dtype=np.uint64)
+assert tcnn._C._lib.tcnn_experiment_read_owner_stamps(C.c_void_p(buf.ctypes.data), C.c_size_t(buf.nbytes)) == 0
+live = buf[:, 5] > 0
+s = buf[live].astype(np.int64); idx = np.nonzero(live)[0]
+rel = (s[:, :6] - s[:, 0].min()) * 0.01
+lvl = s[:, 7]
+print("workgroups", live.sum(), "span %.1f us" % rel[:, 5].max())
+d = np.diff(rel, axis=1)
+print("phase means: entry->first tile loaded %.2f, tiles %s" % (d[:, 0].mean(), np.round(d[:, 1:].mean(axis=0), 2)))
+for l in range(16):
+    m = lvl == l
+    if m.any(): print("level %2d: n %4d entry mean %5.1f (min %5.1f max %5.1f)  per tile %s  life %5.2f  end max %5.1f" % (l, m.sum(), rel[m, 0].mean(), rel[m, 0].min(), rel[m, 0].max(), np.round(d[m, 1:].mean(axis=0), 2), (rel[m, 5] - rel[m, 0]).mean(), rel[m, 5].max()))
+ts = np.arange(0, rel[:, 5].max(), 3.0)
+print("resident at t:", "  ".join("%d:%d" % (t, ((rel[:, 0] <= t) & (rel[:, 5] > t)).sum()) for t in ts))

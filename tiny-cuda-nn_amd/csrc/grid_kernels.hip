@@ -901,7 +901,10 @@ constexpr uint32_t BUCKET_INVALID_INDEX = 0xFFFFFFFFu;  // second record of a pa
 TCNN_DEVICE uint32_t h2_bits(h2 v) { return __builtin_bit_cast(uint32_t, v); }
 TCNN_DEVICE h2 bits_h2(uint32_t v) { return __builtin_bit_cast(h2, v); }
 
-template <uint32_t D, uint32_t F>
+// SECOND_ORDER: scatter d(dL_dx)/d(grid) instead of dy/d(grid) (backward_backward_input's parameter part) -- a compile-time switch: as a
+// run-time select the corner weight of the second-order form (three products per dimension and corner) sits next to the first-order one in
+// every training step's instruction stream and register budget
+template <uint32_t D, uint32_t F, bool SECOND_ORDER>
 __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const GridMeta meta, const GridIO io, const BucketPlan plan,
                                                                          const half_t* __restrict__ dL_dy, uint32_t* __restrict__ counters,
                                                                          uint32_t* __restrict__ queues, uint32_t* __restrict__ overflow,
@@ -964,7 +967,7 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 
 	float x[SPT][D], x_next[SPT][D];
 	half_t g[SPT][F], g_next[SPT][F];
-	const bool second_order = io.ddx != nullptr;  // scatter d(dL_dx)/d(grid) instead of dy/d(grid)
+	constexpr bool second_order = SECOND_ORDER;
 	if (first_tile < plan.tiles) load_tile(first_tile, x, g);
 	__syncthreads();
 
@@ -983,10 +986,12 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 				float dd[D];
 #pragma unroll
 				for (uint32_t d = 0; d < D; ++d) dd[d] = 0.0f;
-				if (second_order) load_ddx<D>(io, min(tile * TILE + s * BUCKET_THREADS + threadIdx.x, io.n - 1u), dd);
+				if constexpr (second_order) load_ddx<D>(io, min(tile * TILE + s * BUCKET_THREADS + threadIdx.x, io.n - 1u), dd);
 #pragma unroll
 				for (uint32_t idx = 0; idx < N_CORNERS; ++idx) {
-					const float weight = second_order ? corner_weight_second_order<D>(lv, c, idx, dd) : (lv.nearest ? 1.0f : corner_weight<D>(c, idx));
+					float weight;
+					if constexpr (second_order) weight = corner_weight_second_order<D>(lv, c, idx, dd);
+					else weight = lv.nearest ? 1.0f : corner_weight<D>(c, idx);
 					if constexpr (F == 1) {
 						pay[s][idx][0] = __builtin_bit_cast(uint32_t, weight * (float)g[s][0]);
 					} else {
@@ -2246,9 +2251,15 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 	{                                                                                                                                         \
 		const uint32_t lds = bucket_spt(D_, F_) * BUCKET_THREADS * ((1u << D_) / 2u) * BucketRecord<F_>::PAIR_WORDS * 4u +                          \
 		                     (2u * max_buckets + WAVE + 4u) * 4u;                                                                             \
-		TCNN_SET_MAX_DYN_LDS((k_grid_bucket_scatter<D_, F_>), lds);                                                                           \
-		TCNN_LAUNCH((k_grid_bucket_scatter<D_, F_>), dim3(scatter_blocks), dim3(BUCKET_THREADS), lds, stream, meta, io, bk, dL_dy, counters,  \
-		            queues, overflow, grid_gradient);                                                                                         \
+		if (io.ddx) {                                                                                                                         \
+			TCNN_SET_MAX_DYN_LDS((k_grid_bucket_scatter<D_, F_, true>), lds);                                                                 \
+			TCNN_LAUNCH((k_grid_bucket_scatter<D_, F_, true>), dim3(scatter_blocks), dim3(BUCKET_THREADS), lds, stream, meta, io, bk, dL_dy,  \
+			            counters, queues, overflow, grid_gradient);                                                                           \
+		} else {                                                                                                                              \
+			TCNN_SET_MAX_DYN_LDS((k_grid_bucket_scatter<D_, F_, false>), lds);                                                                \
+			TCNN_LAUNCH((k_grid_bucket_scatter<D_, F_, false>), dim3(scatter_blocks), dim3(BUCKET_THREADS), lds, stream, meta, io, bk, dL_dy, \
+			            counters, queues, overflow, grid_gradient);                                                                           \
+		}                                                                                                                                     \
 	}
 		TCNN_GRID_DISPATCH(BSCATTER)
 #undef BSCATTER

@@ -294,8 +294,10 @@ def test_headline_kernels_keep_the_occupancy_design_md_states(tmp_path):
 
     for name, k in one("k_grid_forward_tilesILj3ELj2ELj2E").items():
         assert k["vgpr"] <= 64 and k["lds"] == 0 and k["spill"] == 0, (name, k)
-    for name, k in one("k_grid_bucket_scatterILj3ELj2E").items():
+    for name, k in one("k_grid_bucket_scatterILj3ELj2ELb0E").items():  # the training step's instance (Lb1: second-order gradients)
         assert k["vgpr"] <= 96 and k["spill"] == 0, (name, k)
+    for name, k in one("k_grid_bucket_scatterILj3ELj2ELb1E").items():
+        assert k["vgpr"] <= 102 and k["spill"] == 0, (name, k)  # five waves per SIMD, as the first-order instance
     for name, k in one("k_grid_bucket_ownerILj3ELj2E").items():
         assert k["vgpr"] <= 128 and k["spill"] == 0, (name, k)
     for name, k in one("k_mlp_train_waveILj64ELj32ELj1ELb0E").items():  # the headline network: loss and external-gradient instances

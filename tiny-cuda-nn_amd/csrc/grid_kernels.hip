@@ -1002,6 +1002,16 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 					}
 					ridx[s][idx] = corner_index<D, FAST>(lv, c, idx);
 				}
+				// Hashed levels (prime[0] == 1): the two entries of EVERY pair of a sample differ by the same low bits, x ^ (x + 1) under the table's
+				// mask -- whether a pair's second record can ride with the first (same bucket; derivable from word 0 by construction) and the
+				// flip count t are properties of the sample, not of the pair
+				uint32_t fast_tag = 0;
+				bool fast_together = true;
+				if constexpr (FAST) {
+					const uint32_t flips = c.hlo[0] ^ c.hhi[0];
+					fast_together = ((flips & lv.mask) >> shift) == 0u;
+					fast_tag = fast_together ? ((((uint32_t)__builtin_popcount(flips) - 1u) << PAIR_INDEX_BITS) | PAIR_HAS_SECOND) : 0u;
+				}
 #pragma unroll
 				for (uint32_t pr = 0; pr < N_PAIRS_PER_SAMPLE; ++pr) {
 					const bool live = valid && (pr == 0u || !lv.nearest);
@@ -1011,6 +1021,12 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 						ridx[s][2 * pr + 1] = INVALID;
 					} else if (lv.nearest) {
 						ridx[s][2 * pr + 1] = INVALID;
+					} else if constexpr (FAST) {
+						if (!fast_together) {
+							push_overflow(ridx[s][2 * pr + 1], pay[s][2 * pr + 1]);
+							ridx[s][2 * pr + 1] = INVALID;
+						}
+						ridx[s][2 * pr] |= fast_tag;
 					} else {
 						// word 0 of the pair; the second entry must be derivable from it AND live in the same bucket,
 						// otherwise (about one pair in 2^shift) it travels through the overflow list

@@ -125,7 +125,7 @@ bool mlp_train_supported(const MlpMeta& m);
 // (Relative)L2 loss.  mlp_train() picks them
 // when available (TCNN_MLP_TRAIN_WAVE=0 in the environment disables them); same contract as mlp_train().
 bool mlp_train_wave_supported(const MlpMeta& m, uint32_t n, LossType loss);
-uint32_t mlp_train_wave_n_partials(uint32_t n);
+uint32_t mlp_train_wave_n_partials(const MlpMeta& m, uint32_t n);
 void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
                     const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums);
 

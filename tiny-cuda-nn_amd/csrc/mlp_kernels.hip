@@ -1184,7 +1184,7 @@ static void dispatch_train(hipStream_t stream, const MlpMeta& m, uint32_t n, con
 }
 
 uint32_t mlp_train_n_partials(const MlpMeta& m, uint32_t n, LossType loss) {
-	if (mlp_train_wave_supported(m, n, loss)) return mlp_train_wave_n_partials(n);
+	if (mlp_train_wave_supported(m, n, loss)) return mlp_train_wave_n_partials(m, n);
 	if (mlp_train_wide_supported(m, n)) return mlp_train_wide_n_partials(n);
 	return mlp_backward_n_partials(m, n);
 }

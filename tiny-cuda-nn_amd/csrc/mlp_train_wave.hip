@@ -566,15 +566,24 @@ bool mlp_train_wave_supported(const MlpMeta& m, uint32_t n, LossType loss) {
 	return (m.width == 64 && m.n_hidden_matmuls <= 1) || (m.width == 32 && m.n_hidden_matmuls <= 2);
 }
 
-uint32_t mlp_train_wave_n_partials(uint32_t n) {
+// The 64-input, two-hidden-layer instance has a SIMD to itself (its 144 accumulators): ONE workgroup per CU is all that is resident, so 256 of
+// them are one generation -- with 512 the second generation pays the weight staging, the ramp and the 144-register reduction again
+// (mlp_train_fused stage at N = 2^18: 0.0646 -> 0.0562 ms; carrying 64 instead of 32 samples per wave and iteration into the same
+// accumulators, for more independent MFMA -> convert chains in the one wave, measured 0.0591 at 256 and 0.0683 at 512 blocks: not kept)
+#ifndef TCNN_MLP_WAVE_WIDE_BLOCKS
+#define TCNN_MLP_WAVE_WIDE_BLOCKS 256
+#endif
+uint32_t mlp_train_wave_n_partials(const MlpMeta& m, uint32_t n) {
+	const bool one_wave_per_simd = m.in_width == 64 && m.width == 64 && m.n_hidden_matmuls == 1;
 	const uint32_t wanted = div_round_up(n / MLP_WAVE_STRIP, MLP_WAVE_THREADS / 64u);
-	return wanted < TCNN_MLP_WAVE_BLOCKS ? wanted : TCNN_MLP_WAVE_BLOCKS;
+	const uint32_t most = one_wave_per_simd ? TCNN_MLP_WAVE_WIDE_BLOCKS : TCNN_MLP_WAVE_BLOCKS;
+	return wanted < most ? wanted : most;
 }
 
 template <uint32_t WIDTH, uint32_t IN, uint32_t HM, uint32_t MIN_WAVES = TCNN_MLP_WAVE_MIN_BLOCKS>
 static void launch_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
                               const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
-	const uint32_t blocks = mlp_train_wave_n_partials(n);  // (one-wave-per-SIMD instances: one resident workgroup per CU holds half of them at a time)
+	const uint32_t blocks = mlp_train_wave_n_partials(m, n);
 	if (la.external_dL_doutput) {
 		TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, true, MIN_WAVES>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la, output,
 		            dL_doutput, dL_dinput, partials, block_sums);

@@ -1212,3 +1212,43 @@ def test_cpp_sample_learns_an_image(tmp_path):
     psnr = float(r.stdout.split("psnr=")[1].split()[0])
     assert psnr > 25.0, r.stdout
     assert (tmp_path / "learned_image.ppm").read_bytes().startswith(b"P6\n512 512\n255\n")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("out_dims", [3, 16])
+def test_inference_writes_the_callers_matrix_in_every_layout(out_dims):
+    """Network::inference (object.h:214-271) into a GPUMatrixDynamic<float> of either layout and any stride (tcnn_network_inference_matrices).
+    Where the register-resident inference kernel runs the network it stores the fp32 elements itself instead of a padded 16-bit matrix that
+    trim_and_cast would read back: the elements must be bit for bit the cast of the 16-bit outputs the training pass's forward produces,
+    in the dense column-major form, row-major, and with padded leading dimensions whose padding stays untouched."""
+    import ctypes as C
+    T = tcnn()
+    tm = T.create_from_config(3, out_dims, config_hash(), seed=1337)
+    n = 1024
+    pos = positions(n, 3, seed=3)
+    x = torch.from_numpy(pos).cuda()
+    tgt = torch.zeros((n, out_dims), dtype=torch.float32, device="cuda")
+    ctx = tm.training_step(x, tgt, run_optimizer=False)  # its context holds the padded 16-bit prediction of the same parameters
+    want = ctx.output[:, :out_dims].float()
+
+    class Matrix(C.Structure):
+        _fields_ = [("data", C.c_void_p), ("m", C.c_uint32), ("n", C.c_uint32), ("stride", C.c_uint32), ("layout", C.c_int)]
+
+    lib = T._C._lib
+    fn = lib.tcnn_network_inference_matrices
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Matrix), C.POINTER(Matrix), C.c_int]
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    inp = Matrix(x.data_ptr(), 3, n, 3, 1)  # the batch as the library's callers hold it: column-major n_dims x batch
+    dense = tm.inference(x)
+    assert torch.equal(dense, want)
+    for layout, stride in ((1, out_dims), (1, out_dims + 5), (0, n), (0, n + 24)):
+        rows, cols = (n, stride) if layout == 1 else (out_dims, stride)
+        buf = torch.full((rows, cols), -7.0, dtype=torch.float32, device="cuda")
+        out = Matrix(buf.data_ptr(), out_dims, n, stride, layout)
+        assert fn(tm._h, stream, C.byref(inp), C.byref(out), 0) == 0, lib.tcnn_last_error().decode()
+        torch.cuda.synchronize()
+        got = buf[:, :out_dims] if layout == 1 else buf[:, :n].t()
+        assert torch.equal(got, want), (layout, stride)
+        pad = buf[:, out_dims:] if layout == 1 else buf[:, n:]
+        assert bool((pad == -7.0).all()), (layout, stride)

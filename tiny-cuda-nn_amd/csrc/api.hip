@@ -672,7 +672,7 @@ static bool backward_recomputes(const Model& md) { return g_fused_network_passes
 
 // NetworkWithInputEncoding::forward_impl / inference_mixed_precision_impl (:60-81).  ctx == nullptr: inference.
 static void model_forward(hipStream_t stream, const Model& md, uint32_t n, const float* input, half_t* output, const half_t* params,
-                          ForwardCtx* ctx, bool prepare_input_gradients) {
+                          ForwardCtx* ctx, bool prepare_input_gradients, const MlpF32Output* f32 = nullptr) {
 	check_batch(n, widest_matrix(md));
 	if (n == 0) return;
 	if (ctx) {
@@ -698,7 +698,25 @@ static void model_forward(hipStream_t stream, const Model& md, uint32_t n, const
 		hidden = ctx->hidden.as<half_t>();
 	}
 	ProfScope prof(stream, STAGE_MLP_FWD);
+	if (f32) {  // (inference_to_f32 below checked that the register-resident inference kernel takes this network)
+		mlp_infer_wave(stream, md.net.mlp, n, params, enc.as<half_t>(), nullptr, *f32);
+		return;
+	}
 	mlp_forward(stream, md.net.mlp, n, params, enc.as<half_t>(), hidden, output);
+}
+
+// network->inference into the caller's fp32 matrix (object.h:214-271).  Where the register-resident inference kernel runs the network it
+// writes the fp32 elements itself; otherwise the padded 16-bit result goes through trim_and_cast as in the reference.
+static void inference_to_f32(hipStream_t stream, const Model& md, uint32_t n, const float* input, const half_t* params, float* out, uint32_t stride_i, uint32_t stride_j) {
+	const uint32_t padded = md.padded_output_width(), width = md.output_width();
+	if (md.has_network && n > 0 && mlp_infer_wave_supported(md.net.mlp, n)) {
+		const MlpF32Output f32 = {out, width, stride_i, stride_j};
+		model_forward(stream, md, n, input, nullptr, params, nullptr, false, &f32);
+		return;
+	}
+	Scratch tmp(stream, (size_t)padded * n * sizeof(half_t));  // object.h:260
+	model_forward(stream, md, n, input, tmp.as<half_t>(), params, nullptr, false);
+	trim_and_cast(stream, n, padded, width, tmp.as<half_t>(), out, stride_i, stride_j);  // object.h:269-270
 }
 
 // The grid's parameter gradients in groups of consecutive levels, each reported as soon as its kernels are enqueued (data-parallel
@@ -2290,10 +2308,7 @@ const void* tcnn_train_context_dL_doutput(const tcnn_train_context_t* ctx) { ret
 int tcnn_network_inference(tcnn_trainable_model_t* tm, tcnn_stream_t stream_, uint32_t n, const float* input, float* output, int use_inference_params) {
 	TCNN_API_BEGIN
 	hipStream_t stream = (hipStream_t)stream_;
-	const uint32_t padded = tm->md.padded_output_width();
-	Scratch tmp(stream, (size_t)padded * n * sizeof(half_t));  // object.h:260
-	model_forward(stream, tm->md, n, input, tmp.as<half_t>(), use_inference_params ? tm->inference_params() : tm->params, nullptr, false);
-	trim_and_cast(stream, n, padded, tm->md.output_width(), tmp.as<half_t>(), output, tm->md.output_width(), 1u);  // object.h:269-270
+	inference_to_f32(stream, tm->md, n, input, use_inference_params ? tm->inference_params() : tm->params, output, tm->md.output_width(), 1u);
 	TCNN_API_END
 }
 
@@ -2378,14 +2393,13 @@ int tcnn_network_inference_matrices(tcnn_trainable_model_t* tm, tcnn_stream_t st
 	TCNN_API_BEGIN
 	if (!input || !output) throw std::runtime_error("inference: input and output are required");
 	hipStream_t stream = (hipStream_t)stream_;
-	const uint32_t n = input->n, padded = tm->md.padded_output_width(), width = tm->md.output_width();
+	const uint32_t n = input->n, width = tm->md.output_width();
 	const IoLayoutGuard guard(layout_of(input, nullptr, tm->md.n_input_dims, n));
 	if (output->m != width || output->n != n) throw std::runtime_error("inference: output must be n_output_dims x batch_size");  // object.h:221-222
 	const bool cm = output->layout == TCNN_LAYOUT_COLUMN_MAJOR;
 	if (output->stride < (cm ? output->m : output->n)) throw std::runtime_error("inference: output stride smaller than its leading dimension");
-	Scratch tmp(stream, (size_t)padded * n * sizeof(half_t));  // object.h:260
-	model_forward(stream, tm->md, n, (const float*)input->data, tmp.as<half_t>(), use_inference_params ? tm->inference_params() : tm->params, nullptr, false);
-	trim_and_cast(stream, n, padded, width, tmp.as<half_t>(), (float*)output->data, cm ? output->stride : 1u, cm ? 1u : output->stride);  // object.h:269-270
+	inference_to_f32(stream, tm->md, n, (const float*)input->data, use_inference_params ? tm->inference_params() : tm->params, (float*)output->data,
+	                 cm ? output->stride : 1u, cm ? 1u : output->stride);
 	TCNN_API_END
 }
 

@@ -141,7 +141,13 @@ void mlp_train_wide(hipStream_t stream, const MlpMeta& m, uint32_t n, const half
 // Inference (no saved activations) of the same shapes, also with 64 inputs, with up to 3 (64 neurons) / 4 (32 neurons) hidden layers: the forward
 // half of the register-resident kernel.  mlp_forward() picks it when `hidden` is null.
 bool mlp_infer_wave_supported(const MlpMeta& m, uint32_t n);
-void mlp_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output);
+// where an inference call wants its result as the caller's fp32 matrix (object.h:269-270: the first `dims` of the padded outputs, cast):
+// element (sample i, output j) at out[i * stride_i + j * stride_j].  The kernel then stores that instead of the padded 16-bit matrix.
+struct MlpF32Output {
+	float* out = nullptr;
+	uint32_t dims = 0, stride_i = 0, stride_j = 0;
+};
+void mlp_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output, const MlpF32Output& f32 = {});
 
 // number of fp32 slabs / loss partial sums mlp_train() writes for this shape and batch (<= mlp_backward_n_partials)
 uint32_t mlp_train_n_partials(const MlpMeta& m, uint32_t n, LossType loss);

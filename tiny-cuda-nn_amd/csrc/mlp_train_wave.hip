@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 #endif
 template <uint32_t WIDTH, uint32_t IN, uint32_t HM>
 __global__ void __launch_bounds__(MLP_WAVE_THREADS) k_mlp_infer_wave(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
-                                                                     const half_t* __restrict__ input, half_t* __restrict__ output) {
+                                                                     const half_t* __restrict__ input, half_t* __restrict__ output, const MlpF32Output f32) {
 	constexpr uint32_t NB = WIDTH / 16, NP = WIDTH / 32, FB = IN / 16, FP = IN / 32, NWAVES = MLP_WAVE_THREADS / 64;
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
 	const uint32_t out_act = m.output_activation;
@@ -538,7 +538,14 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS) k_mlp_infer_wave(const MlpMe
 			for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(wfrag[F_WOUTA + p][lane], pack8(hp[s][2 * p], hp[s][2 * p + 1]), acc);
 			const h4 o = h4{(half_t)act_forward<false>(out_act, acc[0]), (half_t)act_forward<false>(out_act, acc[1]), (half_t)act_forward<false>(out_act, acc[2]),
 			                (half_t)act_forward<false>(out_act, acc[3])};
-			*(h4*)(output + ((base + perm32(s, lr)) * 16 + 4 * g)) = o;
+			if (f32.out) {  // the caller's fp32 matrix straight from the registers (the same exact conversion trim_and_cast does)
+				const size_t at = (size_t)(base + perm32(s, lr)) * f32.stride_i;
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r)
+					if (4 * g + r < f32.dims) f32.out[at + (size_t)(4 * g + r) * f32.stride_j] = (float)o[r];
+			} else {
+				*(h4*)(output + ((base + perm32(s, lr)) * 16 + 4 * g)) = o;
+			}
 		}
 	}
 }
@@ -617,25 +624,25 @@ bool mlp_infer_wave_supported(const MlpMeta& m, uint32_t n) {
 }
 
 template <uint32_t WIDTH, uint32_t IN, uint32_t HM>
-static void launch_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output) {
+static void launch_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output, const MlpF32Output& f32) {
 	const uint32_t wanted = div_round_up(n / MLP_WAVE_STRIP, MLP_WAVE_THREADS / 64u);
 	const uint32_t blocks = wanted < TCNN_MLP_INFER_BLOCKS ? wanted : TCNN_MLP_INFER_BLOCKS;
-	TCNN_LAUNCH((k_mlp_infer_wave<WIDTH, IN, HM>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, input, output);
+	TCNN_LAUNCH((k_mlp_infer_wave<WIDTH, IN, HM>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, input, output, f32);
 }
 
-void mlp_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output) {
+void mlp_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output, const MlpF32Output& f32) {
 	if (!mlp_infer_wave_supported(m, n)) throw std::runtime_error("mlp_infer_wave: unsupported shape or activation (check mlp_infer_wave_supported first)");
 	switch (m.width * 1000u + m.in_width * 10u + m.n_hidden_matmuls) {
-		case 64320: launch_infer_wave<64, 32, 0>(stream, m, n, params, input, output); break;
-		case 64321: launch_infer_wave<64, 32, 1>(stream, m, n, params, input, output); break;
-		case 64322: launch_infer_wave<64, 32, 2>(stream, m, n, params, input, output); break;
-		case 64640: launch_infer_wave<64, 64, 0>(stream, m, n, params, input, output); break;
-		case 64641: launch_infer_wave<64, 64, 1>(stream, m, n, params, input, output); break;
-		case 64642: launch_infer_wave<64, 64, 2>(stream, m, n, params, input, output); break;
-		case 32320: launch_infer_wave<32, 32, 0>(stream, m, n, params, input, output); break;
-		case 32321: launch_infer_wave<32, 32, 1>(stream, m, n, params, input, output); break;
-		case 32322: launch_infer_wave<32, 32, 2>(stream, m, n, params, input, output); break;
-		case 32323: launch_infer_wave<32, 32, 3>(stream, m, n, params, input, output); break;
+		case 64320: launch_infer_wave<64, 32, 0>(stream, m, n, params, input, output, f32); break;
+		case 64321: launch_infer_wave<64, 32, 1>(stream, m, n, params, input, output, f32); break;
+		case 64322: launch_infer_wave<64, 32, 2>(stream, m, n, params, input, output, f32); break;
+		case 64640: launch_infer_wave<64, 64, 0>(stream, m, n, params, input, output, f32); break;
+		case 64641: launch_infer_wave<64, 64, 1>(stream, m, n, params, input, output, f32); break;
+		case 64642: launch_infer_wave<64, 64, 2>(stream, m, n, params, input, output, f32); break;
+		case 32320: launch_infer_wave<32, 32, 0>(stream, m, n, params, input, output, f32); break;
+		case 32321: launch_infer_wave<32, 32, 1>(stream, m, n, params, input, output, f32); break;
+		case 32322: launch_infer_wave<32, 32, 2>(stream, m, n, params, input, output, f32); break;
+		case 32323: launch_infer_wave<32, 32, 3>(stream, m, n, params, input, output, f32); break;
 		default: throw std::runtime_error("mlp_infer_wave: no instance for this shape");
 	}
 }

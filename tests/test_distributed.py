@@ -256,3 +256,75 @@ def test_fp16_gradient_sum_over_eight_ranks_does_not_overflow():
     assert np.isfinite(acc).all() and np.abs(full).max() < 6.0e4
     scale = np.abs(full).max()
     assert np.abs(acc.astype(np.float64) - full).max() < 4e-3 * scale
+
+
+class _DirectStub:
+    """What DataParallel(mode="direct") asks of a trainer, with a failure injected on chosen ranks at a chosen stage."""
+
+    def __init__(self, rank, fail):
+        self.param_gradients = torch.zeros(64, dtype=torch.half)
+        self.rank, self.fail, self.closed, self.opened = rank, fail, 0, 0
+
+    def _maybe(self, stage):
+        if self.fail.get(stage) is not None and self.rank in self.fail[stage]:
+            raise RuntimeError(f"injected at {stage}")
+
+    def direct_export(self):
+        self._maybe("export")
+        return bytes([self.rank]) * 8
+
+    def direct_open(self, rank, records):
+        assert rank == self.rank and [r[0] for r in records] == list(range(len(records)))
+        self._maybe("open")
+        self.opened += 1
+
+    def direct_selftest(self, rounds=3, seed=0):
+        self._maybe("selftest")
+        return (5 if self.rank in self.fail.get("mismatch", ()) else 0), (2 if self.rank in self.fail.get("timeout", ()) else 0)
+
+    def direct_close(self):
+        self.closed += 1
+
+
+def _direct_setup_worker(rank, world, port, fail, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    par = _load_parallel()
+    par.init_from_env(backend="gloo")
+    tm = _DirectStub(rank, fail)
+    try:
+        par.DataParallel(tm, mode="direct")
+        outcome = "ok"
+    except RuntimeError as ex:
+        outcome = str(ex)
+    # every rank is still in step with the others afterwards: a collective completes
+    t = torch.tensor([1.0])
+    dist.all_reduce(t)
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(f"{outcome}\n{tm.closed}\n{int(t.item())}\n")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail,expect", [
+    ({}, None),
+    ({"export": (1,)}, "rank 1: export: injected at export"),
+    ({"open": (0, 2)}, "rank 0: open: injected at open; rank 2: open: injected at open"),
+    ({"selftest": (2,)}, "rank 2: self-test: injected at selftest"),
+    ({"mismatch": (1,)}, "rank 1: self-test: 5 wrong elements"),
+    ({"timeout": (0,)}, "rank 0: self-test: 0 wrong elements, a wait timed out in phase 2"),
+])
+def test_direct_exchange_setup_fails_on_every_rank_or_on_none(tmp_path, fail, expect):
+    """DataParallel(mode="direct"): a rank that cannot export, cannot map a peer, or whose link check reports wrong sums or a timed-out wait must
+    take EVERY rank down the same path (close the mapping, raise the same error) -- the survivors would otherwise wait in a collective the
+    failed rank never enters.  bench.py's --dp auto relies on it to fall back to the sharded collectives on all ranks alike."""
+    world = 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_direct_setup_worker, args=(world, port, fail, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        outcome, closed, after = open(os.path.join(str(tmp_path), f"rank{rank}.txt")).read().splitlines()
+        assert int(after) == world
+        if expect is None:
+            assert outcome == "ok" and int(closed) == 0
+        else:
+            assert expect in outcome and "fall back" in outcome and int(closed) == 1, (rank, outcome)

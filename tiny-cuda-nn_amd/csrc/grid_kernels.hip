@@ -2040,7 +2040,10 @@ void grid_forward(hipStream_t stream, const GridMeta& meta, const GridIO& io, co
 	if (io.n == 0) return;
 	static const bool per_sample_form = getenv("TCNN_GRID_FWD") && atoi(getenv("TCNN_GRID_FWD")) == 0;  // A/B switch: the first implementation
 	if (!dy_dx && out && !per_sample_form) {
-#define FWD_TILES(D_, F_) launch_forward_tiles<D_, F_, 2>(stream, meta, io, params, out);
+#ifndef TCNN_FWD_SPT
+#define TCNN_FWD_SPT 2  // samples per thread of the tiled gather (a workgroup: 256 x SPT samples of one level)
+#endif
+#define FWD_TILES(D_, F_) launch_forward_tiles<D_, F_, TCNN_FWD_SPT>(stream, meta, io, params, out);
 		TCNN_GRID_DISPATCH(FWD_TILES)
 #undef FWD_TILES
 		return;

@@ -249,3 +249,22 @@ def test_wave_rows_transpose_on_the_chip(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "wave_rows_transpose4: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_multi_gpu_auto_falls_back_to_the_collectives_when_the_direct_exchange_is_unavailable():
+    """--dp auto on a node where the direct exchange cannot be set up (here: the checking allocator is on, under which the trainer buffer is no
+    plain hipMalloc block and tcnn_trainer_direct_export refuses): every rank takes the same way out, the sharded collectives run the
+    measurement, and the line says why `direct` was not a candidate."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"]
+    d = _run(cmd, TCNN_BENCH_BACKEND="gloo", TCNN_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", TCNN_DEBUG_ALLOC="canary")
+    a = d["dp_autotune"]
+    assert a["chosen"] == "sharded" and "sharded" in d["config"]["parallelism"]
+    assert "unavailable" in a["candidates"]["direct"] and "TCNN_DEBUG_ALLOC" in a["candidates"]["direct"]["unavailable"]
+    assert "ms_per_step" in a["candidates"]["sharded"] and math.isfinite(d["final_loss"])

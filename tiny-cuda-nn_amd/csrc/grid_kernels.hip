@@ -1941,20 +1941,24 @@ static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t 
 		for (uint32_t l = 0; l < meta.n_levels; ++l) {
 			const size_t table_bytes = (size_t)(meta.offset[l + 1] - meta.offset[l]) * meta.n_feat * sizeof(half_t);
 			const uint32_t entries = meta.offset[l + 1] - meta.offset[l];
-			const bool pow2 = (entries & (entries - 1u)) == 0u;
-			// densely indexed levels measure dearer per sample than hashed ones (grid_index's stride arithmetic instead of two xors): 11 against 8
-			// where the resolution is no power of two (round 2); where it is one (base resolution 16, scale 2: the headline's levels 0-2) the table
-			// has a power-of-two size like a hashed level's, and per-workgroup clock stamps (profiles/r04_exp_notes.txt section 18) put a 128 KiB
-			// level at 1.04 and a 1 MiB level at 1.26 of a hashed level's cost -- with all of them at 8 the XCDs that hold the dense levels
-			// finished 8 us after the others
+			// What a (level, 512-sample tile) item costs, from per-workgroup clock stamps of this kernel on the headline and the T = 2^22 stress shape
+			// (scripts/exp_forward_stamps.*, profiles/r04_exp_notes.txt sections 18 and 20; microseconds of workgroup life, halved):
+			//   tables that fit the L1 (<= 24 KiB)                                   4
+			//   hashed levels: no locality at all                                    8 while the table fits the L2, x (1 + 2.5 miss) beyond it (16 MiB: 24)
+			//   dense levels: grid_index's stride arithmetic, but the corners of a   4.6 + 1.15 log2(table bytes / 24 KiB), the table capped at the L2's
+			//   cell are neighbours in y and z too                                   3 MiB, x (1 + 0.8 miss) beyond it  (55 KiB: 6, 1 MiB: 11, 7 MiB: 21)
+			// miss = share of the line fetches that miss the XCD's 4 MiB L2 (about 3 MiB of it hold the table while outputs stream through).
+			// Round 2's weights (dense 11 whatever the size, told from hashed by "no power-of-two size"; miss x 1.5 for both kinds) had the XCDs that
+			// hold the dense levels finish 8 us late on the headline (its dense levels ARE powers of two) and 40-87 us EARLY on the stress shape.
 			uint64_t dense_entries = 1;  // resolution^D, saturated
 			for (uint32_t d = 0; d < meta.n_dims; ++d) dense_entries = std::min<uint64_t>(dense_entries * meta.resolution[l], 1ull << 40);
 			const bool hashed = meta.grid_type == (uint32_t)GridType::Hash && (uint64_t)entries < dense_entries;
-			// share of the line fetches that miss the XCD's 4 MiB L2 (about 3 MiB of it hold the table while outputs stream through)
 			const double miss = std::max(0.0, 1.0 - 3.0 * 1048576.0 / (double)table_bytes);
-			const double dense_pow2 = 8.0 * (1.0 + 0.25 * std::min(1.0, (double)table_bytes / 1048576.0));
-			const double base = table_bytes <= 24u * 1024u ? 4.0 : (hashed ? 8.0 : (pow2 ? dense_pow2 : 11.0));
-			cost[l] = uniform ? 16u : (uint32_t)(2.0 * base * (1.0 + 1.5 * miss) + 0.5);
+			const double in_l2 = std::min((double)table_bytes, 3.0 * 1048576.0);
+			const double base = table_bytes <= 24u * 1024u ? 4.0
+			                    : hashed ? 8.0 * (1.0 + 2.5 * miss)
+			                             : (4.6 + 1.15 * std::log2(in_l2 / (24.0 * 1024.0))) * (1.0 + 0.8 * miss);
+			cost[l] = uniform ? 16u : (uint32_t)(4.0 * base + 0.5);  // (quarter-microsecond units: the cuts fall on whole tiles)
 			if (skip_level && skip_level[l]) continue;  // gathered out of LDS by k_grid_forward_lds
 			total += (uint64_t)cost[l] * plan.tiles;
 		}

@@ -23,7 +23,7 @@ batches = bench.make_batches(w, bench.BATCH, 4, rng, device=torch.device("cuda",
 for i in range(30):
     tm.training_step(*batches[i % 4], want_context=False)
 torch.cuda.synchronize()
-buf = np.zeros((16384, 4), dtype=np.uint64)
+buf = np.zeros((32768, 4), dtype=np.uint64)
 assert tcnn._C._lib.tcnn_experiment_read_owner_stamps(C.c_void_p(buf.ctypes.data), C.c_size_t(buf.nbytes)) == 0
 live = buf[:, 1] > 0
 s = buf[live].astype(np.int64)

@@ -1440,7 +1440,7 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 #ifndef TCNN_OWNER_GROUPS
 #define TCNN_OWNER_GROUPS 2
 #endif
-	constexpr uint32_t NG = TCNN_OWNER_GROUPS;  // groups of 4 records in flight per lane
+	constexpr uint32_t NG = TCNN_OWNER_GROUPS;  // groups of 4 records in flight per lane (3 / 4 / 6 / 8 groups measured 0.0524 / 0.0538 / 0.0574 / 0.0710 ms against 0.0510: profiles/r04_exp_notes.txt 14d)
 	rec3_t grp[NG][4];
 	uint32_t first_round[PIPELINED ? 1 : STREAM_U][PWP];
 #if !defined(TCNN_HOST_EMU)

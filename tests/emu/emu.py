@@ -101,6 +101,18 @@ def grid_forward(g, params_h, positions, soa=True, out_stride=None, want_dy_dx=F
     return (out, dy_dx) if want_dy_dx else out
 
 
+def grid_forward_plan(g, n, tile_samples=512):
+    """The tiled gather's work plan: (tiles per level, [[(level, tile_begin, tile_end), ...] for each of the 8 XCDs])."""
+    max_segments = 32
+    n_seg = np.zeros(8, dtype=np.uint32)
+    out = np.zeros((8, max_segments, 3), dtype=np.uint32)
+    fn = lib().emu_grid_forward_plan
+    fn.restype = C.c_uint32
+    tiles = fn(C.byref(g.c), C.c_uint32(n), C.c_uint32(tile_samples), _p(n_seg), _p(out), C.c_uint32(max_segments))
+    assert tiles > 0
+    return int(tiles), [[tuple(int(v) for v in out[x, k]) for k in range(int(n_seg[x]))] for x in range(8)]
+
+
 def grid_forward_f32(g, params, positions, out_stride=None, want_dy_dx=False):
     """k_grid_forward_f32: fp32 parameters -> fp32 features [n][out_stride] (+ dy_dx [k][n][D])."""
     og = g.og

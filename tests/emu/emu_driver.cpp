@@ -50,6 +50,26 @@ int emu_grid_forward(const EmuGrid* e, const float* positions, uint32_t n, const
 	return 0;
 }
 
+// The tiled gather's work plan (make_forward_plan, host code of the library): segments[x][k] = {level, tile_begin, tile_end} for XCD x.
+// out: [8][FWD_MAX_SEGMENTS][3] u32, n_segments: [8]; returns the sample tiles per level (0 on failure).
+uint32_t emu_grid_forward_plan(const EmuGrid* e, uint32_t n, uint32_t tile_samples, uint32_t* n_segments, uint32_t* out, uint32_t max_segments) {
+	try {
+		const ForwardPlan plan = make_forward_plan(make_meta(e), n, tile_samples);
+		for (uint32_t x = 0; x < 8; ++x) {
+			n_segments[x] = plan.n_segments[x];
+			for (uint32_t k = 0; k < plan.n_segments[x] && k < max_segments; ++k) {
+				out[(x * max_segments + k) * 3 + 0] = plan.segments[x][k].level;
+				out[(x * max_segments + k) * 3 + 1] = plan.segments[x][k].tile_begin;
+				out[(x * max_segments + k) * 3 + 2] = plan.segments[x][k].tile_end;
+			}
+		}
+		return plan.tiles;
+	} catch (const std::exception& ex) {
+		fprintf(stderr, "emu_grid_forward_plan: %s\n", ex.what());
+		return 0;
+	}
+}
+
 void emu_set_grid_owner_mode(int mode) { grid_owner_mode() = mode; }
 void emu_set_grid_forward_lds(uint32_t limit_bytes, uint32_t min_samples) {
 	grid_forward_lds_limit() = limit_bytes;

@@ -607,3 +607,56 @@ def test_network_kernels_against_the_reference_kernels_run_live(case):
     assert nr(f64(grads), want) < (5e-3 if smooth else 8e-2)
     if ref_dinput is not None:
         assert nr(f64(dx).T, f64(ref_dinput)) < (5e-3 if smooth else 8e-2)
+
+
+# item costs of make_forward_plan's model in quarter-microseconds per 512-sample tile (profiles/r04_exp_notes.txt sections 18, 20)
+def _plan_cost(og, level):
+    entries = int(og.offsets[level + 1] - og.offsets[level])
+    table = entries * og.n_features_per_level * 2
+    dense = min(int(og.resolution[level]) ** og.n_dims, 1 << 40)
+    hashed = og.grid_type == O.GRID_HASH and entries < dense
+    miss = max(0.0, 1.0 - 3.0 * 1048576.0 / table)
+    if table <= 24 * 1024:
+        base = 4.0
+    elif hashed:
+        base = 8.0 * (1.0 + 2.5 * miss)
+    else:
+        base = (4.6 + 1.15 * np.log2(min(table, 3.0 * 1048576.0) / (24.0 * 1024.0))) * (1.0 + 0.8 * miss)
+    return int(4.0 * base + 0.5)
+
+
+@pytest.mark.parametrize("case", [
+    (3, 16, 2, 19, 16, 2.0, O.GRID_HASH, O.INTERP_LINEAR),   # the headline: dense levels with power-of-two resolutions, hashed levels within the L2
+    (3, 16, 2, 22, 16, 1.5, O.GRID_HASH, O.INTERP_LINEAR),   # the stress shape: dense levels of 16 KiB .. 7 MiB, hashed levels of 16 MiB
+    (2, 16, 2, 15, 16, 1.5, O.GRID_HASH, O.INTERP_LINEAR),   # the shipped 2-D configuration: everything small
+    (3, 5, 2, 19, 4, 1.4, O.GRID_DENSE, O.INTERP_LINEAR),
+    (3, 3, 2, 19, 16, 2.0, O.GRID_HASH, O.INTERP_LINEAR),    # fewer levels than XCDs
+])
+@pytest.mark.parametrize("n", [1 << 18, 1000])
+def test_forward_work_plan_covers_every_tile_once_and_levels_the_xcds(case, n):
+    """make_forward_plan (host code of the tiled gather): the (level, tile) items laid end to end and cut into eight runs, one per XCD.  Every tile
+    of every level belongs to exactly one run, the runs are contiguous in (level, tile) order, and with the cost model of the plan no XCD's
+    share differs from an eighth of the total by more than one item of its dearest level -- the property the per-XCD clock stamps of round 4
+    were after (the two XCDs holding the headline's dense levels finished 8 us late while those were priced like hashed levels)."""
+    D, L, F, T, base, scale, gtype, interp = case
+    og = O.grid_init(D, L, F, T, base, scale, gtype, interp)
+    tiles, runs = emu.grid_forward_plan(emu.Grid(og), n)
+    assert tiles == -(-n // 512)
+    seen = np.zeros((L, tiles), dtype=np.int32)
+    order = []
+    for x, run in enumerate(runs):
+        for level, begin, end in run:
+            assert 0 <= level < L and 0 <= begin < end <= tiles
+            seen[level, begin:end] += 1
+            order.append((level, begin, end, x))
+    assert np.all(seen == 1)
+    assert order == sorted(order) and all(a[3] <= b[3] for a, b in zip(order[:-1], order[1:]))  # level-major, XCDs in order
+    cost = [_plan_cost(og, l) for l in range(L)]
+    share = [sum(cost[level] * (end - begin) for level, begin, end in run) for run in runs]
+    total = sum(cost) * tiles
+    assert sum(share) == total
+    for x, run in enumerate(runs[:7]):
+        if run:  # a cut falls on a whole tile: the share is an eighth of the total up to the items at the run's two ends
+            assert abs(share[x] - total / 8.0) <= 2 * max(cost[level] for level, _, _ in run), (x, share, total / 8.0)
+    # the last run takes what is left: never more than an eighth plus the rounding of the seven cuts before it
+    assert share[7] <= total / 8.0 + 7 * max(cost)

@@ -151,7 +151,14 @@ int tcnn_network_inference(tcnn_trainable_model_t* tm, tcnn_stream_t stream, uin
 
 /* parameter access, trainer.h:389-440 */
 size_t tcnn_trainer_n_params(const tcnn_trainable_model_t* tm);
+/* Mutable pointers (trainer.h:423-440 hands out T*): the library must assume the caller writes through them, now or later.  From the
+ * first call on, the optimizer reads the 16-bit weights back instead of re-deriving skipped ones from its master weights, and the
+ * transposed copy of the network weights is rebuilt before every pass -- a few per cent of a step -- until tcnn_trainer_params_written()
+ * (after writes through _params / _params_inference: the 16-bit buffer is authoritative, the master weights are re-derived from it where
+ * the two disagree) or tcnn_trainer_set_params_full_precision() (after writes to the master weights).  A host that only READS the master
+ * weights (logging, checkpoints) uses tcnn_trainer_params_full_precision_view(): same memory, no change of mode. */
 float* tcnn_trainer_params_full_precision(tcnn_trainable_model_t* tm);
+const float* tcnn_trainer_params_full_precision_view(const tcnn_trainable_model_t* tm);
 void* tcnn_trainer_params(tcnn_trainable_model_t* tm);
 void* tcnn_trainer_params_inference(tcnn_trainable_model_t* tm);
 void* tcnn_trainer_param_gradients(tcnn_trainable_model_t* tm);

@@ -111,6 +111,8 @@ class _CpuTrainer:
     def params_full_precision(self):
         return torch.from_numpy(self.w32)
 
+    params_full_precision_mutable = params_full_precision
+
     # the gradient-ready interface of tinycudann.native.TrainableModel (tcnn_trainer_set_gradient_ready_callback): a "backward pass"
     # that fills the gradient buffer range by range -- network weights, then the encoding's level groups -- and reports each
     def set_backward_level_groups(self, n_groups):

@@ -218,11 +218,41 @@ def test_parameters_written_through_the_exposed_pointers_survive_the_optimizer()
     # (2) a caller holds the MASTER pointer and writes it (no params_written yet): skipped 16-bit weights stay what they were
     p16_before = h_np(tm.params).copy()
     tm.params_written()  # the shortcut is trusted again (this call leaves the 16-bit buffer as it is) ...
-    pm = tm.params_full_precision  # ... and the master pointer is the only one out
+    pm = tm.params_full_precision_mutable  # ... and the master pointer is the only one out
     pm[torch.from_numpy(written).cuda()] = torch.from_numpy((new16.astype(np.float32) * 3.0)).cuda()
     g = step_with_sparse_gradient()
     skipped = written[g[written] == 0]
     assert len(skipped) > 100 and np.array_equal(h_np(tm.params)[skipped], p16_before[skipped])
+
+
+def test_reading_the_master_weights_does_not_change_the_trainer_s_mode():
+    """tcnn_trainer_params_full_precision_view: a host that only reads the master weights -- logging, a checkpoint -- must not
+    switch off Adam's "16-bit weights follow the master weights" shortcut for good.  Observable: with the shortcut ON the 16-bit weight of a
+    skipped entry is re-derived from the master weight, so a master weight changed behind the library's back (through the mutable pointer of
+    ANOTHER handle on the same memory: here a raw view made before) shows up in the 16-bit buffer of a skipped entry; with it OFF it would not."""
+    T = tcnn()
+    tm = T.create_from_config(3, 4, config_hash(log2_hashmap_size=12, per_level_scale=1.5))
+    n, nm = tm.n_params, tm.n_mlp_params
+    tm.set_global_batch_size(1 << 20)
+    rng = np.random.default_rng(4)
+    view = tm.params_full_precision  # read-only accessor: same memory, no mode change
+    assert view.data_ptr() == tm.params_full_precision.data_ptr()
+    before = view.cpu().numpy().copy()
+    g = (rng.standard_normal(n) * 0.1).astype(np.float16)
+    g[nm:][rng.random(n - nm) < 0.5] = 0
+    tm.param_gradients.copy_(h_t(g.view(np.uint16)))
+    probe = nm + np.flatnonzero(g[nm:] == 0)[:64]
+    # lanes of four that mix stepped and skipped parameters re-derive the skipped ones: find probes whose lane is mixed
+    lane = (probe // 4) * 4
+    mixed = np.array([np.any(g[l:l + 4] != 0) for l in lane])
+    probe = probe[mixed]
+    assert len(probe) > 8
+    view[torch.from_numpy(probe).cuda()] = 0.75  # (torch lets us write through the view; the library was told nothing)
+    tm.optimizer_step()
+    torch.cuda.synchronize()
+    got = h_np(tm.params)[probe]
+    assert np.array_equal(got, np.full(len(probe), np.float16(0.75)).view(np.uint16)), "the shortcut is off: the read-only view changed the trainer's mode"
+    assert not np.array_equal(before[probe], np.full(len(probe), 0.75, np.float32))
 
 
 def test_optimizer_object_on_its_own_bit_level():

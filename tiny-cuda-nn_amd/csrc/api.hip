@@ -200,9 +200,16 @@ enum Stage : int {
 	STAGE_GRID_BWD_SCATTER,     // bucketed backward pass A: derive the corner records once, bin them by owning slice
 	STAGE_GRID_BWD,             // pass B (owners accumulate + store, overflow records included) -- or the whole backward in the sliced / atomic modes
 	STAGE_ADAM,
+	// the direct exchange's phases (direct_exchange.h); recorded whenever a profiler is on, whatever `only_stage` says: they exist on N > 1 only,
+	// where a step is long and the first node run has to explain itself
+	STAGE_DX_WAIT_GRADS,   // signal "my gradients are final" + wait for every peer's
+	STAGE_DX_REDUCE,       // read the peers' shards over the links, fp32 sum, one rounding
+	STAGE_DX_PUSH,         // write the stepped shard into every peer's parameter buffer
+	STAGE_DX_WAIT_PARAMS,  // signal "pushed" + wait for every peer's push
 	N_STAGES
 };
-static const char* const STAGE_NAMES[N_STAGES] = {"grid_forward", "mlp_forward", "loss", "mlp_backward", "mlp_train_fused", "grid_backward_scatter", "grid_backward", "adam"};
+static const char* const STAGE_NAMES[N_STAGES] = {"grid_forward", "mlp_forward", "loss", "mlp_backward", "mlp_train_fused", "grid_backward_scatter", "grid_backward", "adam",
+                                                  "exchange_wait_gradients", "exchange_reduce", "exchange_push", "exchange_wait_parameters"};
 
 struct Profiler {
 	int only_stage = -1;  // -1: all stages
@@ -260,7 +267,7 @@ struct ProfScope {
 	bool counts;  // false: a further piece of a stage that is launched in several parts per step (time adds up, the launch count does not)
 	hipEvent_t a = nullptr;
 	ProfScope(hipStream_t s, int st, bool counts_ = true) : stream(s), stage(st), counts(counts_) {
-		if (g_profiler && (g_profiler->only_stage < 0 || g_profiler->only_stage == st)) {
+		if (g_profiler && (g_profiler->only_stage < 0 || g_profiler->only_stage == st || st >= STAGE_DX_WAIT_GRADS)) {
 			a = g_profiler->get();
 			HIP_CHECK(hipEventRecord(a, stream));
 		}
@@ -1635,6 +1642,7 @@ void tcnn_trainable_model_destroy(tcnn_trainable_model_t* tm) {
 	(void)hipDeviceSynchronize();
 	direct_exchange_close(tm->direct);
 	if (tm->direct.own_signals) (void)hipFree(tm->direct.own_signals);
+	if (tm->direct.host_error) (void)hipHostFree((void*)tm->direct.host_error);
 	device_free(tm->buffer);
 	device_free(tm->m1);
 	device_free(tm->m2);
@@ -2017,21 +2025,35 @@ void* tcnn_trainer_optimizer_state(tcnn_trainable_model_t* tm, int which, int* s
 // The optimizer half of training_step.  With RCCL enabled every range whose all-reduce was started during the backward pass is
 // stepped as soon as ITS collective has finished (the later ones are still on the wire); otherwise the host's exchange hook, then
 // one optimizer step.
-// reduce over the peers' mapped gradient buffers -> Adam on this rank's shard (+ the replicated tail) -> push the stepped parameters
+// reduce over the peers' mapped gradient buffers -> Adam on this rank's shard (the last rank's carries the remainder) -> push the stepped parameters
 static void direct_exchange_and_step(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale) {
 	DirectExchange& dx = tm->direct;
-	direct_exchange_reduce(stream, dx);
-	std::vector<size_t> begins, ends;
-	if (dx.shard) {
-		begins.push_back((size_t)dx.rank * dx.shard);
-		ends.push_back((size_t)(dx.rank + 1) * dx.shard);
+	direct_exchange_begin_step(dx);
+	{
+		ProfilerGuard pg(tm->profiler.get());
+		{
+			ProfScope prof(stream, STAGE_DX_WAIT_GRADS);
+			direct_exchange_signal_wait(stream, dx, 0);
+		}
+		ProfScope prof(stream, STAGE_DX_REDUCE);
+		direct_exchange_reduce_own(stream, dx);
 	}
-	if (dx.main < dx.n_params) {
-		begins.push_back(dx.main);
-		ends.push_back((size_t)dx.n_params);
+	std::vector<size_t> begins, ends;
+	if (dx.own_count()) {
+		begins.push_back(dx.own_begin);
+		ends.push_back(dx.own_end);
 	}
 	optimizer_step_ranges(tm, stream, loss_scale, begins.size(), begins.data(), ends.data(), /*advance=*/true, /*opens_profiled_step=*/true);
-	direct_exchange_push(stream, dx);
+	{
+		ProfilerGuard pg(tm->profiler.get());
+		{
+			ProfScope prof(stream, STAGE_DX_PUSH);
+			direct_exchange_push_own(stream, dx);
+		}
+		ProfScope prof(stream, STAGE_DX_WAIT_PARAMS);
+		direct_exchange_signal_wait(stream, dx, 1);
+	}
+	direct_exchange_finish_step(stream, dx);
 	tm->params_t_valid = false;  // the transposed network weights were maintained for this rank's shard only
 }
 
@@ -2191,7 +2213,7 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 	bool optimizer_opened = false;
 	if (need_denc) {
 		const size_t n_mlp = md.n_mlp_params();
-		const bool fuse = run_optimizer && tm->fused_optimizer && want_grads && !accumulate && e.is_grid && e.n_params > 0 && !tm->ema && !tm->exchange && !wants_ready_ranges(tm) && !grouped_backward &&
+		const bool fuse = run_optimizer && tm->fused_optimizer && want_grads && !accumulate && e.is_grid && e.n_params > 0 && !tm->ema && !tm->exchange && !tm->direct.active() && !wants_ready_ranges(tm) && !grouped_backward &&
 		                  tm->global_batch == 0 && !use_inference_params && e.grid.stochastic == 0u &&
 		                  (GridBackwardMode)g_grid_backward_mode.load() == GridBackwardMode::Bucketed;
 		AdamCore core;
@@ -2410,6 +2432,9 @@ float* tcnn_trainer_params_full_precision(tcnn_trainable_model_t* tm) {
 	tm->params_exposed = true;
 	return tm->master;
 }
+// read-only view of the same memory: the trainer's mode does not change (a logging / checkpointing host must not switch
+// Adam's "16-bit weights follow the master weights" shortcut off for good)
+const float* tcnn_trainer_params_full_precision_view(const tcnn_trainable_model_t* tm) { return tm->master; }
 void* tcnn_trainer_params(tcnn_trainable_model_t* tm) {
 	tm->params_exposed = true;  // a mutable pointer leaves the library: assume the caller writes through it, now or later
 	return tm->params;

@@ -62,7 +62,8 @@ __global__ void __launch_bounds__(DX_THREADS) k_direct_reduce(const PeerBuffers 
 		for (uint32_t k = 0; k < 8; ++k) out[k] = to_half_rn(acc[k]);
 		*(h8*)(grads.p[me] + begin + 8 * i) = out;
 	}
-	// what does not fill a 16-byte group (the replicated tail: < 8 P parameters): element by element, by the first workgroup
+	// what does not fill a 16-byte group (only the LAST rank's shard can end off a multiple of 8: it carries the remainder of the
+	// buffer): element by element, by the first workgroup.  Nobody else writes -- or steps -- these elements.
 	if (blockIdx.x == 0) {
 		for (size_t e = n8 * 8 + threadIdx.x; e < count; e += DX_THREADS) {
 			float acc = 0.0f;
@@ -73,11 +74,19 @@ __global__ void __launch_bounds__(DX_THREADS) k_direct_reduce(const PeerBuffers 
 }
 // the own stepped parameter shard into every peer's parameter buffer
 __global__ void __launch_bounds__(DX_THREADS) k_direct_push(const PeerBuffers params, const int n_ranks, const int me, const size_t begin, const size_t count) {
-	const size_t n8 = count / 8;  // shards are multiples of 8
+	const size_t n8 = count / 8;  // shards begin on multiples of 8; only the last rank's may end off one
 	for (size_t i = (size_t)blockIdx.x * DX_THREADS + threadIdx.x; i < n8; i += (size_t)gridDim.x * DX_THREADS) {
 		const h8 v = *(const h8*)(params.p[me] + begin + 8 * i);
 		for (int r = 0; r < n_ranks; ++r) {
 			if (r != me) *(h8*)(params.p[r] + begin + 8 * i) = v;
+		}
+	}
+	if (blockIdx.x == 0) {
+		for (size_t e = n8 * 8 + threadIdx.x; e < count; e += DX_THREADS) {
+			const half_t v = params.p[me][begin + e];
+			for (int r = 0; r < n_ranks; ++r) {
+				if (r != me) params.p[r][begin + e] = v;
+			}
 		}
 	}
 }
@@ -119,6 +128,9 @@ void direct_exchange_export(DirectExchange& dx, void* buffer, const half_t* para
 		hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
 		dx.own_signals = (uint32_t*)p;
 		dx.error_flag = dx.own_signals + 2 * DIRECT_MAX_RANKS;
+		void* h = nullptr;
+		hip_ok(hipHostMalloc(&h, sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc(error word)");
+		dx.host_error = (volatile uint32_t*)h;
 	}
 	std::memset(&out, 0, sizeof(out));
 	hipIpcMemHandle_t h;
@@ -158,13 +170,18 @@ void direct_exchange_open(DirectExchange& dx, int rank, int n_ranks, const Direc
 	dx.rank = rank;
 	dx.n_ranks = n_ranks;
 	dx.n_params = n;
+	// rank r owns [r * shard, (r + 1) * shard); the LAST rank's shard runs to the end of the buffer (the < 8 P parameters that do not divide
+	// are its own too).  Every parameter has exactly one owner: one rank reads the peers' gradients of it, writes its sum, steps it and
+	// pushes it -- nothing is reduced in place by several ranks at once (round 4 had everyone reduce a replicated tail: a cross-rank race).
 	dx.shard = (size_t)(n / (8ull * n_ranks)) * 8;
-	dx.main = dx.shard * n_ranks;
+	dx.own_begin = (size_t)rank * dx.shard;
+	dx.own_end = rank == n_ranks - 1 ? (size_t)n : (size_t)(rank + 1) * dx.shard;
 	dx.step = 0;
 	const char* e = getenv("TCNN_DIRECT_TIMEOUT_MS");
 	dx.timeout_ms = e ? (uint32_t)atoi(e) : 2000u;
 	hip_ok(hipMemset(dx.own_signals, 0, (2 * DIRECT_MAX_RANKS + 16) * sizeof(uint32_t)), "hipMemset(signals)");
 	hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+	*dx.host_error = 0;
 }
 
 void direct_exchange_close(DirectExchange& dx) {
@@ -187,28 +204,43 @@ static void signal_and_wait(hipStream_t stream, DirectExchange& dx, int row) {
 	TCNN_LAUNCH(k_direct_wait, dim3(1), dim3(64), 0, stream, (const uint32_t*)dx.own_signals, dx.n_ranks, row, dx.step, ticks, dx.error_flag);
 }
 
-void direct_exchange_reduce(hipStream_t stream, DirectExchange& dx) {
+// ---- a step's exchange, phase by phase (the trainer brackets each with profiler events so that a node run explains itself) ------------
+void direct_exchange_begin_step(DirectExchange& dx) {
 	if (!dx.active()) throw std::runtime_error("direct exchange: not open");
+	// the error word as of the last finished step (pinned copy, no synchronisation): a wait that gave up means this replica stepped on
+	// unreduced gradients or stale parameters -- fail here instead of training on
+	if (dx.host_error && *dx.host_error) {
+		throw std::runtime_error("direct exchange: a wait for the peers' " + std::string(*dx.host_error == 1 ? "gradients" : "parameters") +
+		                         " timed out in an earlier step (TCNN_DIRECT_TIMEOUT_MS): the replicas are no longer in lock-step");
+	}
 	++dx.step;
-	signal_and_wait(stream, dx, 0);  // everybody's gradients of this step are final
+}
+void direct_exchange_signal_wait(hipStream_t stream, DirectExchange& dx, int row) { signal_and_wait(stream, dx, row); }
+void direct_exchange_reduce_own(hipStream_t stream, DirectExchange& dx) {
 	PeerBuffers g;
 	for (int r = 0; r < DIRECT_MAX_RANKS; ++r) g.p[r] = dx.grads[r];
-	if (dx.shard) {
-		const uint32_t blocks = (uint32_t)std::min<size_t>(div_round_up<size_t>(dx.shard / 8, DX_THREADS), 2048);
-		TCNN_LAUNCH(k_direct_reduce, dim3(blocks), dim3(DX_THREADS), 0, stream, g, dx.n_ranks, dx.rank, (size_t)dx.rank * dx.shard, dx.shard);
-	}
-	if (dx.main < dx.n_params) TCNN_LAUNCH(k_direct_reduce, dim3(1), dim3(DX_THREADS), 0, stream, g, dx.n_ranks, dx.rank, dx.main, (size_t)(dx.n_params - dx.main));
+	if (dx.own_count()) TCNN_LAUNCH(k_direct_reduce, dim3(dx.blocks()), dim3(DX_THREADS), 0, stream, g, dx.n_ranks, dx.rank, dx.own_begin, dx.own_count());
+}
+void direct_exchange_push_own(hipStream_t stream, DirectExchange& dx) {
+	PeerBuffers p;
+	for (int r = 0; r < DIRECT_MAX_RANKS; ++r) p.p[r] = dx.params[r];
+	if (dx.own_count() && dx.n_ranks > 1) TCNN_LAUNCH(k_direct_push, dim3(dx.blocks()), dim3(DX_THREADS), 0, stream, p, dx.n_ranks, dx.rank, dx.own_begin, dx.own_count());
+}
+void direct_exchange_finish_step(hipStream_t stream, DirectExchange& dx) {
+	if (dx.host_error) hip_ok(hipMemcpyAsync((void*)dx.host_error, dx.error_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(error word)");
+}
+
+void direct_exchange_reduce(hipStream_t stream, DirectExchange& dx) {
+	direct_exchange_begin_step(dx);
+	signal_and_wait(stream, dx, 0);  // everybody's gradients of this step are final
+	direct_exchange_reduce_own(stream, dx);
 }
 
 void direct_exchange_push(hipStream_t stream, DirectExchange& dx) {
 	if (!dx.active()) throw std::runtime_error("direct exchange: not open");
-	PeerBuffers p;
-	for (int r = 0; r < DIRECT_MAX_RANKS; ++r) p.p[r] = dx.params[r];
-	if (dx.shard && dx.n_ranks > 1) {
-		const uint32_t blocks = (uint32_t)std::min<size_t>(div_round_up<size_t>(dx.shard / 8, DX_THREADS), 2048);
-		TCNN_LAUNCH(k_direct_push, dim3(blocks), dim3(DX_THREADS), 0, stream, p, dx.n_ranks, dx.rank, (size_t)dx.rank * dx.shard, dx.shard);
-	}
+	direct_exchange_push_own(stream, dx);
 	signal_and_wait(stream, dx, 1);  // everybody's parameters have arrived here; nobody reads this rank's gradients any more
+	direct_exchange_finish_step(stream, dx);
 }
 
 // Link check before the exchange is trusted with a training run: `rounds` times every rank fills its GRADIENT buffer with a pattern of the
@@ -230,10 +262,7 @@ void direct_exchange_selftest(hipStream_t stream, DirectExchange& dx, uint32_t r
 	for (uint32_t round = 0; round < rounds; ++round) {
 		TCNN_LAUNCH(k_direct_selftest_fill, dim3(blocks), dim3(DX_THREADS), 0, stream, own, n, (uint32_t)dx.rank, round, seed);
 		direct_exchange_reduce(stream, dx);
-		if (dx.shard && dx.n_ranks > 1) {
-			const uint32_t pb = (uint32_t)std::min<size_t>(div_round_up<size_t>(dx.shard / 8, DX_THREADS), 2048);
-			TCNN_LAUNCH(k_direct_push, dim3(pb), dim3(DX_THREADS), 0, stream, g, dx.n_ranks, dx.rank, (size_t)dx.rank * dx.shard, dx.shard);
-		}
+		if (dx.own_count() && dx.n_ranks > 1) TCNN_LAUNCH(k_direct_push, dim3(dx.blocks()), dim3(DX_THREADS), 0, stream, g, dx.n_ranks, dx.rank, dx.own_begin, dx.own_count());
 		signal_and_wait(stream, dx, 1);
 		TCNN_LAUNCH(k_direct_selftest_check, dim3(blocks), dim3(DX_THREADS), 0, stream, (const half_t*)own, n, (uint32_t)dx.n_ranks, round, seed, counter);
 	}

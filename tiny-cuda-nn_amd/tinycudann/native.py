@@ -187,6 +187,14 @@ class TrainableModel:
 
     @property
     def params_full_precision(self):
+        """The fp32 master weights, to READ (tcnn_trainer_params_full_precision_view: the trainer's mode does not change).  To write them:
+        set_params_full_precision(), or `params_full_precision_mutable` followed by set_params_full_precision / params_written."""
+        return self._tensor(_lib.tcnn_trainer_params_full_precision_view(self._h), "<f4")
+
+    @property
+    def params_full_precision_mutable(self):
+        """Trainer::params_full_precision() as a pointer the caller may write through (tcnn_hip.h: from now on the optimizer reads the 16-bit
+        weights back and the transposed network weights are rebuilt before every pass, until params_written())."""
         return self._tensor(_lib.tcnn_trainer_params_full_precision(self._h), "<f4")
 
     @property

@@ -204,7 +204,12 @@ class DataParallel:
         return self._params_inference
 
     def shard_range(self, rank=None):
+        """[begin, end) of the parameters `rank` owns.  Collective schemes: equal shards of [0, main), the tail [main, n) is replicated
+        (all-reduced and stepped by everyone).  Direct exchange: the LAST rank's shard runs to n -- every parameter has exactly one owner
+        (csrc/direct_exchange.hip: nothing is ever reduced in place by several ranks at once)."""
         r = self.rank if rank is None else rank
+        if self.mode == "direct" and r == self.world - 1:
+            return r * self.shard, self.n
         return r * self.shard, (r + 1) * self.shard
 
     # ---- timing of the communication share (bench.py) ----------------------------------------------------------------
@@ -247,7 +252,7 @@ class DataParallel:
 
     def _reduce_scatter(self, buf):
         """Sum over ranks; afterwards this rank's shard of buf[:main] holds the reduced values."""
-        b, e = self.shard_range()
+        b, e = self.rank * self.shard, (self.rank + 1) * self.shard
         if self._has_reduce_scatter:
             try:
                 out = self._staging(buf)
@@ -259,8 +264,10 @@ class DataParallel:
         dist.all_reduce(buf[: self.main], op=dist.ReduceOp.SUM)  # twice the bytes, same result in the own shard
 
     def _all_gather(self, buf):
-        """Every rank's shard of buf[:main] -> all ranks."""
-        b, e = self.shard_range()
+        """Every rank's (equal) shard of buf[:main] -> all ranks."""
+        if not self.main:
+            return
+        b, e = self.rank * self.shard, (self.rank + 1) * self.shard
         own = self._staging(buf)
         own.copy_(buf[b:e])
         if self._has_all_gather_into:
@@ -381,14 +388,18 @@ class DataParallel:
     def gather_optimizer_state(self):
         """Sharded mode: collects the fp32 master weights and Adam's state from their owners so that this rank can write a
         complete snapshot (Trainer::serialize with the optimizer, trainer.h:442-455)."""
-        if not self.active or self.mode not in ("sharded", "pipelined_sharded", "direct") or not self.main:
+        if not self.active or self.mode not in ("sharded", "pipelined_sharded", "direct") or not (self.main or self.mode == "direct"):
             return
         m1, m2, steps, _ = self.tm.optimizer_state()
         if self.mode in ("sharded", "direct"):  # (the snapshot path: ordinary collectives of the process group)
-            for buf in (self.tm.params_full_precision, m1, m2, steps):
+            for buf in (self.tm.params_full_precision_mutable, m1, m2, steps):
                 self._all_gather(buf)
+                if self.mode == "direct" and self.main < self.n:  # the remainder lives on the last rank alone
+                    tail = buf[self.main:].clone()
+                    dist.broadcast(tail, src=self.world - 1)
+                    buf[self.main:].copy_(tail)
             return
-        for buf in (self.tm.params_full_precision, m1, m2, steps):  # the owners' shards of every segment of the last step
+        for buf in (self.tm.params_full_precision_mutable, m1, m2, steps):  # the owners' shards of every segment of the last step
             for begin, end, shard in self._last_segments:
                 if shard:
                     dist.all_gather([buf[begin + r * shard:begin + (r + 1) * shard] for r in range(self.world)],

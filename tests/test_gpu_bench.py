@@ -33,6 +33,12 @@ def _run(cmd, **env):
     return json.loads(lines[0])
 
 
+def r_adam_moved(d):
+    """profiles/traffic.json rides along per stage: what the kernel MOVED (PMC passes) against the clock of this run."""
+    st = d["roofline"]["stages"]["adam"]
+    return "moved_frac" not in st or (0.0 < st["moved_frac"] < 1.2 and st["moved_bytes_per_launch"] > 0)
+
+
 def test_driver_bench_command_in_fresh_processes():
     """`python3 bench.py --gpus 1 --steps 20 --warmup 5`, three times, each in a process of its own: exit code 0, one JSON line
     with the contract's fields, `roofline` and `cpu_baseline` present, a loss that went down, no faulted worker."""
@@ -48,6 +54,15 @@ def test_driver_bench_command_in_fresh_processes():
         assert d["value_resident"] >= 0.97 * d["value"] and abs(d["value_resident"] - (1 << 18) / (d["ms_per_step_resident"] * 1e-3)) <= 1e-6 * d["value_resident"]
         assert 0.9 < p["adam_touched_fraction"] <= 1.0  # N 2^D = 4 T at the fine levels: nearly every entry sees a sample
         assert p["adam_algorithmic_bytes"]["touched"] <= p["adam_algorithmic_bytes"]["dense_upper_bound"] == d["config"]["n_params"] * 36
+        # "touched" is counted from the batch and the table (unit-gradient encoding backward), not from the training gradients, whose fp16 values
+        # underflow as the fit converges: it cannot be smaller than what the last training gradient still shows
+        assert p["adam_touched_parameters"] >= p["nonzero_training_gradients_at_end_of_run"] > 0
+        assert r_adam_moved(d)
+        # the same step through the PyTorch binding, with its ratio to the native step (README.md:208-210)
+        tb = d["torch_binding"]
+        assert "error" not in tb, tb
+        assert tb["steps_timed"] == 20 and math.isfinite(tb["final_loss"]) and 1.0 <= tb["ratio_to_native_step"] < 4.0
+        assert math.isclose(tb["samples_per_s"], (1 << 18) / (tb["ms_per_step"] * 1e-3), rel_tol=1e-9)
         # network->inference on the same batch, with its own roofline: 4 D_in + L 2^D F 2 + 4 D_out = 540 B per sample
         inf = d["inference"]
         assert inf["batch"] == 1 << 18 and inf["roofline"]["algorithmic_bytes_per_call"] == (1 << 18) * 540
@@ -102,8 +117,15 @@ def test_driver_multi_gpu_command_with_two_ranks_on_one_gpu(dp):
 
 
 def test_bench_other_workloads_print_their_line():
-    for workload, kernel in (("mlp", "mlp_train_fused"), ("stress", "adam")):
+    for workload, kernel in (("mlp", "mlp_train_fused"), ("stress", "adam"), ("hash_shipped", None)):
         d = _run(DRIVER_COMMAND + ["--workload", workload, "--no-cpu-baseline"])
+        if workload == "hash_shipped":  # data/config_hash.json as the reference ships it (2-D -> 3, T = 2^15): the one configuration it publishes a figure for
+            assert d["config"]["n_params"] == 708368 + 7168 and "2D->3" in d["config"]["workload"]  # SURVEY 8 (derived sizes)
+            v = d["vs_reference_readme"]
+            assert math.isclose(v["ratio"], d["value"] / 2.4e8, rel_tol=1e-9) and d["vs_baseline"] is None
+            assert math.isfinite(d["final_loss"]) and d["roofline"]["kernel"] == "grid_forward" and "torch_binding" in d
+            assert d["roofline"]["algorithmic_bytes_per_launch"] == (1 << 18) * (8 + 16 * 4 * 2 * 2 + 64)
+            continue
         assert d["roofline"]["kernel"] == kernel and math.isfinite(d["final_loss"]) and "mfma" in d["roofline"]
         p = d["protocol"]
         if workload == "stress":
@@ -113,6 +135,26 @@ def test_bench_other_workloads_print_their_line():
             assert d["roofline"]["algorithmic_bytes_per_launch"] == p["adam_algorithmic_bytes"]["touched"] < 0.85 * p["adam_algorithmic_bytes"]["dense_upper_bound"]
         else:
             assert p["regenerate"] is False and "value_resident" not in d  # benchmarks/mlp generates its input once
+
+
+def test_bench_launches_its_own_ranks_when_no_launcher_is_around_it():
+    """`python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment (the form the N = 1 command has): bench.py re-executes itself
+    under torch.distributed.run and relays rank 0's line (it used to exit without a JSON line).  Two ranks share
+    the one GPU of the test box (gloo); the line carries the exchange's phases."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    for dp, phases in (("sharded", {"reduce_scatter", "adam_shard", "all_gather"}),
+                       ("direct", {"signal+wait_gradients", "reduce", "adam_shard", "push", "signal+wait_parameters"})):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--dp", dp]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                           env=dict(env, TCNN_BENCH_BACKEND="gloo", TCNN_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["steps"] == 6 and "torch.distributed.run" in d["launched_by"] and dp in d["config"]["parallelism"]
+        ph = d["comm"]["phases_ms_per_step_max_over_ranks"]
+        assert set(ph) == phases and all(v > 0 for v in ph.values()), ph
+        assert sum(ph.values()) <= 1.5 * d["comm"]["seconds_per_step"] * 1e3 + 0.05  # the phases are what the exchange consists of
 
 
 def test_bench_resident_batches_on_request():
@@ -178,7 +220,8 @@ def test_stage_profiling_all_stages_and_single_stage():
     with pytest.raises(RuntimeError, match="profiling is not enabled"):
         tm.stage_times()
     names = tm.stage_names()
-    assert names == ["grid_forward", "mlp_forward", "loss", "mlp_backward", "mlp_train_fused", "grid_backward_scatter", "grid_backward", "adam"]
+    assert names == ["grid_forward", "mlp_forward", "loss", "mlp_backward", "mlp_train_fused", "grid_backward_scatter", "grid_backward", "adam",
+                     "exchange_wait_gradients", "exchange_reduce", "exchange_push", "exchange_wait_parameters"]  # the last four: the direct exchange's phases (N > 1 only)
 
     tm.set_profiling(True)
     for _ in range(7):

@@ -261,13 +261,14 @@ static std::atomic<int> g_grid_backward_mode{initial_grid_backward_mode()};
 // TCNN_GRID_LDS_SLICE_BYTES: LDS bytes per table slice of the grid backward (tuning; 0 / unset = built-in default)
 static const uint32_t g_default_lds_slice_bytes = getenv("TCNN_GRID_LDS_SLICE_BYTES") ? (uint32_t)atoi(getenv("TCNN_GRID_LDS_SLICE_BYTES")) : 0u;
 
+static thread_local bool g_prof_every_stage = false;  // inside the direct exchange: its Adam is one of the exchange's phases
 struct ProfScope {
 	hipStream_t stream;
 	int stage;
 	bool counts;  // false: a further piece of a stage that is launched in several parts per step (time adds up, the launch count does not)
 	hipEvent_t a = nullptr;
 	ProfScope(hipStream_t s, int st, bool counts_ = true) : stream(s), stage(st), counts(counts_) {
-		if (g_profiler && (g_profiler->only_stage < 0 || g_profiler->only_stage == st || st >= STAGE_DX_WAIT_GRADS)) {
+		if (g_profiler && (g_profiler->only_stage < 0 || g_profiler->only_stage == st || st >= STAGE_DX_WAIT_GRADS || g_prof_every_stage)) {
 			a = g_profiler->get();
 			HIP_CHECK(hipEventRecord(a, stream));
 		}
@@ -2043,7 +2044,14 @@ static void direct_exchange_and_step(tcnn_trainable_model_t* tm, hipStream_t str
 		begins.push_back(dx.own_begin);
 		ends.push_back(dx.own_end);
 	}
-	optimizer_step_ranges(tm, stream, loss_scale, begins.size(), begins.data(), ends.data(), /*advance=*/true, /*opens_profiled_step=*/true);
+	g_prof_every_stage = true;
+	try {
+		optimizer_step_ranges(tm, stream, loss_scale, begins.size(), begins.data(), ends.data(), /*advance=*/true, /*opens_profiled_step=*/true);
+	} catch (...) {
+		g_prof_every_stage = false;
+		throw;
+	}
+	g_prof_every_stage = false;
 	{
 		ProfilerGuard pg(tm->profiler.get());
 		{

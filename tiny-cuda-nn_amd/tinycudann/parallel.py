@@ -215,6 +215,29 @@ class DataParallel:
     # ---- timing of the communication share (bench.py) ----------------------------------------------------------------
     def reset_timers(self):
         self._comm_s, self._events = 0.0, []
+        self._phase_s, self._phase_events = {}, []
+
+    def phase_seconds(self):
+        """Per-phase totals of the sharded scheme since reset_timers(): {"reduce_scatter", "adam_shard", "all_gather"} -> seconds (GPU event
+        intervals on the step's stream; host wall time for CPU tensors).  The direct exchange's phases are timed inside the library
+        (tm.stage_times(): exchange_wait_gradients / exchange_reduce / adam / exchange_push / exchange_wait_parameters)."""
+        if getattr(self, "_phase_events", None):
+            torch.cuda.synchronize()
+            for name, a, b in self._phase_events:
+                self._phase_s[name] = self._phase_s.get(name, 0.0) + a.elapsed_time(b) * 1e-3
+            self._phase_events = []
+        return dict(getattr(self, "_phase_s", {}))
+
+    def _phase(self, name, start):
+        """Closes a phase opened with _tic()."""
+        if not hasattr(self, "_phase_s"):
+            self._phase_s, self._phase_events = {}, []
+        if self.grads.is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._phase_events.append((name, start, e))
+        else:
+            self._phase_s[name] = self._phase_s.get(name, 0.0) + time.perf_counter() - start
 
     def comm_seconds(self):
         """Time between issuing a step's collectives and their completion, summed: GPU time between events recorded on the
@@ -372,17 +395,23 @@ class DataParallel:
         elif self.mode == "allreduce":
             reduce_and_step(self.tm, self.grads, self.n_buckets, self.loss_scale)
         else:
+            t = self._tic()
             if self.main:
                 self._reduce_scatter(self.grads)
             ranges = [self.shard_range()] if self.main else []
             if self.main < self.n:
                 dist.all_reduce(self.grads[self.main:], op=dist.ReduceOp.SUM)
                 ranges.append((self.main, self.n))
+            self._phase("reduce_scatter", t)
+            t = self._tic()
             self.tm.optimizer_step_ranges(ranges, self.loss_scale)
+            self._phase("adam_shard", t)
+            t = self._tic()
             if self.main:
                 self._all_gather(self.params)
                 if self.params_inference is not None:
                     self._all_gather(self.params_inference)
+            self._phase("all_gather", t)
         self._toc(start)
 
     def gather_optimizer_state(self):

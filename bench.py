@@ -355,6 +355,8 @@ def main():
                     help="the fully instrumented per-stage pass (min(steps, 50) untimed steps) runs before the warm-up steps (default) or after the timed region")
     ap.add_argument("--dominant", default="fixed", help="stage timed with HIP events inside the timed region (fixed: the workload's dominant kernel per rocprof, see DOMINANT; auto: the slowest stage of a short probe pass)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--resident-first", action="store_true", help="diagnostic: time the resident-batch region BEFORE the regenerated one (which of two back-to-back regions is faster "
+                                                                   "is a property of their order on this device, see DESIGN.md section 3)")
     ap.add_argument("--lds-budget", type=int, default=None, help="grid backward: LDS bytes per level table (tuning knob)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.worker:
@@ -484,6 +486,25 @@ def main():
         dominant = max(probe, key=lambda k: probe[k][0] / max(probe[k][1], 1))
         dominant = par.broadcast_object(dominant)
 
+    def resident_region():
+        """The same number of steps on batches that are resident in HBM (round 1-3's protocol): `value_resident`."""
+        mode["regenerate"] = False
+        tm.set_profiling(False)
+        for i in range(min(args.warmup, 10)):
+            step(i)
+        par.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        par.barrier()
+        out = par.all_reduce_max(time.perf_counter() - t0, device=device)
+        mode["regenerate"] = True
+        return out
+
+    elapsed_resident = resident_region() if regenerate and args.resident_first else None
+
     # ---- timed region: EXACTLY --steps steps, barrier + synchronize on both sides -----------------------
     tm.set_profiling(True, only_stage=dominant)  # 2 HIP events per step around the dominant kernel only
     if dp is not None:
@@ -512,22 +533,8 @@ def main():
     if dp is not None and dp_mode == "direct" and tm.direct_status() != 0:
         raise SystemExit(f"rank {rank}: a wait of the direct exchange timed out (phase {tm.direct_status()}): the measurement is void")
 
-    # ---- the same number of steps once more on batches that are resident in HBM (round 1-3's protocol): `value_resident` -------------
-    elapsed_resident = None
-    if regenerate:
-        mode["regenerate"] = False
-        tm.set_profiling(False)
-        for i in range(min(args.warmup, 10)):
-            step(i)
-        par.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
-        torch.cuda.synchronize()
-        par.barrier()
-        elapsed_resident = par.all_reduce_max(time.perf_counter() - t0, device=device)
-        mode["regenerate"] = True
+    if regenerate and not args.resident_first:
+        elapsed_resident = resident_region()
 
     # ---- network->inference on the same batch (north_star names it; the reference publishes inference curves, README.md:7-8) ----------
     inference = None

@@ -270,6 +270,11 @@ int tcnn_loss_evaluate(const char* loss_otype, tcnn_stream_t stream, uint32_t n,
  * tcnn_trainer_optimizer_step_range(s).  ready == NULL removes the hook. */
 int tcnn_trainer_set_gradient_ready_callback(tcnn_trainable_model_t* tm, void (*ready)(void* user, size_t begin, size_t end, tcnn_stream_t stream), void* user);
 int tcnn_trainer_set_backward_level_groups(tcnn_trainable_model_t* tm, uint32_t n_groups);
+/* One GPU, training_step(run_optimizer = 1): the encoding's backward pass and the optimizer step as a pipeline over three HIP streams in
+ * `n_groups` groups of consecutive levels -- record scatter of group g+2 | owner pass of group g+1 | Adam on group g's parameters (the three
+ * kernels are bound by instruction issue, memory latency and HBM bandwidth respectively).  Same kernels on sub-ranges: bit for bit the
+ * one-stream step.  The caller's stream continues behind the whole pipeline.  1 = one stream. */
+int tcnn_trainer_set_backward_overlap(tcnn_trainable_model_t* tm, uint32_t n_groups);
 /* Data parallelism inside the library: `nccl_comm` is this rank's ncclComm_t (RCCL; NULL switches it off).  training_step then
  * all-reduces (sum) every ready range on an internal communication stream -- librccl.so is dlopen'ed by this call, the library does
  * not link it -- and, with run_optimizer = 1, steps each range as soon as ITS collective has finished while the later ones are still

@@ -820,6 +820,21 @@ static GridMeta grid_levels(const GridMeta& g, uint32_t a, uint32_t b) {
 	return s;
 }
 
+// consecutive levels in `n_groups` groups, cut where the running parameter count passes k / n_groups of the total
+static std::vector<std::pair<uint32_t, uint32_t>> split_levels(const GridMeta& g, uint32_t n_groups) {
+	const uint32_t L = g.n_levels;
+	std::vector<std::pair<uint32_t, uint32_t>> level_ranges;
+	for (uint32_t k = 1, a = 0; k <= n_groups && a < L; ++k) {
+		uint32_t b = a + 1;
+		const uint64_t target = (uint64_t)g.offset[L] * k / n_groups;
+		while (b < L && (k == n_groups || g.offset[b] < target)) ++b;
+		if (k == n_groups) b = L;
+		level_ranges.push_back({a, b});
+		a = b;
+	}
+	return level_ranges;
+}
+
 static void encoding_backward(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const half_t* dL_denc,
                               uint32_t stride_k, uint32_t stride_i, half_t* dL_dparams, bool want_grads, bool accumulate, const float* input,
                               uint32_t lds_level_budget, const GridFusedAdam* fused_adam, const LevelGroups* groups) {
@@ -837,16 +852,7 @@ static void encoding_backward(hipStream_t stream, const Model& md, const Forward
 			const uint32_t L = e.grid.n_levels, F = e.grid.n_feat;
 			uint32_t n_groups = groups ? std::min(std::max(groups->n_groups, 1u), L) : 1u;
 			if (e.grid.max_level < 1.0f || e.grid.stochastic != 0u || fused_adam) n_groups = 1;
-			// consecutive levels, cut where the running parameter count passes k / n_groups of the total
-			std::vector<std::pair<uint32_t, uint32_t>> level_ranges;
-			for (uint32_t k = 1, a = 0; k <= n_groups && a < L; ++k) {
-				uint32_t b = a + 1;
-				const uint64_t target = (uint64_t)e.grid.offset[L] * k / n_groups;
-				while (b < L && (k == n_groups || e.grid.offset[b] < target)) ++b;
-				if (k == n_groups) b = L;
-				level_ranges.push_back({a, b});
-				a = b;
-			}
+			const std::vector<std::pair<uint32_t, uint32_t>> level_ranges = split_levels(e.grid, n_groups);
 			// one workspace for all groups: the largest any of them asks for (a group of later levels can bucket levels that the plan of
 			// the whole grid, which takes the first MAX_BUCKET_LEVELS eligible ones, left to the other kinds)
 			GridBackwardWorkspace ws = grid_backward_workspace_size(e.grid, n, mode, lds_level_budget);
@@ -1064,6 +1070,12 @@ struct tcnn_trainable_model {
 	void (*gradients_ready)(void* user, size_t begin, size_t end, tcnn_stream_t stream) = nullptr;
 	void* ready_user = nullptr;
 	uint32_t backward_level_groups = getenv("TCNN_BACKWARD_LEVEL_GROUPS") ? (uint32_t)std::max(1, atoi(getenv("TCNN_BACKWARD_LEVEL_GROUPS"))) : 1u;  // env: experiments
+	// training_step(run_optimizer = true) on one GPU: the encoding's backward in `backward_overlap` groups of consecutive levels, PIPELINED over
+	// three streams -- record scatter of group g+2 | owner pass of group g+1 | Adam on group g's parameters -- see overlapped_backward_and_step.
+	// 1 = off (one stream).  TCNN_BACKWARD_OVERLAP / tcnn_trainer_set_backward_overlap.
+	uint32_t backward_overlap = getenv("TCNN_BACKWARD_OVERLAP") ? (uint32_t)std::max(1, atoi(getenv("TCNN_BACKWARD_OVERLAP"))) : 1u;
+	struct OverlapLanes;
+	std::shared_ptr<OverlapLanes> lanes;
 	void* rccl_comm = nullptr;  // ncclComm_t
 	int rccl_ranks = 0;
 	// gradient exchange over peer-mapped memory (direct_exchange.h; tcnn_trainer_direct_*)
@@ -1854,6 +1866,19 @@ static void await_reduced_gradients(tcnn_trainable_model_t* tm, hipStream_t stre
 	tm->reduced.clear();
 }
 
+// Adam over [begin, end) of the current optimizer step (optimizer_advance opened it), on `stream`
+static void adam_range(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale, size_t begin, size_t end, bool counts) {
+	// the trainer's 16-bit parameters are its rounded master weights unless a caller holds a pointer to them (params_exposed): Adam need
+	// not read the skipped ones back (AdamCore::half_follows_master).  TCNN_ADAM_HALF_FROM_MASTER=0: always read them back (A/B runs)
+	static const bool half_from_master = !(getenv("TCNN_ADAM_HALF_FROM_MASTER") && atoi(getenv("TCNN_ADAM_HALF_FROM_MASTER")) == 0);
+	const size_t n = tm->md.n_params();
+	ProfScope prof(stream, STAGE_ADAM, counts);  // a ranged (bucketed) step is ONE optimizer step
+	adam_step(stream, tm->adam, (uint32_t)n, (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master, tm->params, tm->grads,
+	          tm->m1, tm->m2, tm->steps, tm->params_t_valid ? tm->params_t : nullptr, tm->md.has_network ? &tm->md.net.mlp : nullptr, (uint32_t)begin,
+	          (uint32_t)end, tm->steps_form, tm->step_deficits8, /*half_follows_master=*/half_from_master && !tm->params_exposed);
+	if (tm->ema) ema_step(stream, (uint32_t)n, tm->ema_decay, tm->optimizer_step, tm->params, tm->params_ema, tm->ema_tmp, (uint32_t)begin, (uint32_t)end);
+}
+
 static void optimizer_step_ranges(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale, size_t n_ranges, const size_t* begins, const size_t* ends,
                                   bool advance, bool opens_profiled_step) {
 	const size_t n = tm->md.n_params();
@@ -1863,17 +1888,10 @@ static void optimizer_step_ranges(tcnn_trainable_model_t* tm, hipStream_t stream
 	}
 	if (advance) optimizer_advance(tm, stream);
 	ProfilerGuard pg(tm->profiler.get());
-	// the trainer's 16-bit parameters are its rounded master weights unless a caller holds a pointer to them (params_exposed): Adam need
-	// not read the skipped ones back (AdamCore::half_follows_master).  TCNN_ADAM_HALF_FROM_MASTER=0: always read them back (A/B runs)
-	static const bool half_from_master = !(getenv("TCNN_ADAM_HALF_FROM_MASTER") && atoi(getenv("TCNN_ADAM_HALF_FROM_MASTER")) == 0);
 	for (size_t r = 0; r < n_ranges; ++r) {
 		const size_t begin = begins[r], end = std::min(ends[r], n);
 		if (begin == end) continue;
-		ProfScope prof(stream, STAGE_ADAM, /*counts=*/opens_profiled_step && r == 0);  // a ranged (bucketed) step is ONE optimizer step
-		adam_step(stream, tm->adam, (uint32_t)n, (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master, tm->params, tm->grads,
-		          tm->m1, tm->m2, tm->steps, tm->params_t_valid ? tm->params_t : nullptr, tm->md.has_network ? &tm->md.net.mlp : nullptr, (uint32_t)begin,
-		          (uint32_t)end, tm->steps_form, tm->step_deficits8, /*half_follows_master=*/half_from_master && !tm->params_exposed);
-		if (tm->ema) ema_step(stream, (uint32_t)n, tm->ema_decay, tm->optimizer_step, tm->params, tm->params_ema, tm->ema_tmp, (uint32_t)begin, (uint32_t)end);
+		adam_range(tm, stream, loss_scale, begin, end, /*counts=*/opens_profiled_step && r == 0);
 	}
 }
 
@@ -1914,6 +1932,12 @@ int tcnn_trainer_set_gradient_exchange(tcnn_trainable_model_t* tm, void (*exchan
 int tcnn_trainer_set_gradient_ready_callback(tcnn_trainable_model_t* tm, void (*ready)(void* user, size_t begin, size_t end, tcnn_stream_t stream), void* user) {
 	tm->gradients_ready = ready;
 	tm->ready_user = user;
+	return TCNN_OK;
+}
+// Single-GPU training_step(run_optimizer = 1): the encoding's backward pass and the optimizer pipelined over three streams in `n_groups` groups
+// of levels (overlapped_backward_and_step; bit for bit the one-stream step).  1 (the default unless TCNN_BACKWARD_OVERLAP is set): one stream.
+int tcnn_trainer_set_backward_overlap(tcnn_trainable_model_t* tm, uint32_t n_groups) {
+	tm->backward_overlap = n_groups ? n_groups : 1u;
 	return TCNN_OK;
 }
 int tcnn_trainer_set_backward_level_groups(tcnn_trainable_model_t* tm, uint32_t n_groups) {
@@ -2146,6 +2170,116 @@ struct ReadyTrampoline {
 };
 static bool wants_ready_ranges(const tcnn_trainable_model_t* tm) { return tm->gradients_ready || tm->rccl_comm; }
 
+// ------------------------------------------------------------------------------------------------
+// Backward + optimizer of a single-GPU training step as a PIPELINE over three streams (tcnn_trainer_set_backward_overlap).
+//
+// The three kernels behind the network's backward pass are bound by three different things (per-workgroup
+// clock stamps and PMC passes of round 4): the record scatter by what a CU can ISSUE (18.6 M VALU instructions), the owner pass by the
+// LATENCY of its queue stream (~8 us of non-streaming phases per workgroup life), Adam by HBM bandwidth.  Run one after the other they
+// leave two of the three resources idle at any time.  Their dependencies are per LEVEL: the owners of a level need that level's queues,
+// Adam needs that level's gradients.  So the levels go through in G groups (consecutive levels, about equal parameter counts --
+// the same split, the same kernels on sub-ranges and therefore bit for bit the same gradients and parameters as the one-stream pass):
+//
+//     compute stream : scatter(g0) scatter(g1) scatter(g2) ...                      [+ the join at the end]
+//     owner lane     :             owner(g0)   owner(g1)   owner(g2) ...            each behind its group's scatter (event)
+//     adam lane      : adam(net)               adam(g0)    adam(g1)    adam(g2) ... each behind its group's owners (event)
+//
+// Separate launches cost their ramp and tail (two groups one after the other: +26 us, round 3) -- here another lane's kernel fills them.
+// Every group has its own queues and counters (the lanes overlap in time).
+// ------------------------------------------------------------------------------------------------
+struct tcnn_trainable_model::OverlapLanes {
+	hipStream_t owner = nullptr, adam = nullptr;
+	std::vector<hipEvent_t> events;
+	size_t next = 0;
+	OverlapLanes() {
+		HIP_CHECK(hipStreamCreateWithFlags(&owner, hipStreamNonBlocking));
+		HIP_CHECK(hipStreamCreateWithFlags(&adam, hipStreamNonBlocking));
+	}
+	hipEvent_t event() {
+		if (next == events.size()) {
+			hipEvent_t e;
+			HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+			events.push_back(e);
+		}
+		return events[next++];
+	}
+	// `to` continues behind everything enqueued on `from` so far
+	void order(hipStream_t from, hipStream_t to) {
+		hipEvent_t e = event();
+		HIP_CHECK(hipEventRecord(e, from));
+		HIP_CHECK(hipStreamWaitEvent(to, e, 0));
+	}
+	~OverlapLanes() {
+		for (auto e : events) (void)hipEventDestroy(e);
+		if (owner) (void)hipStreamDestroy(owner);
+		if (adam) (void)hipStreamDestroy(adam);
+	}
+};
+
+static void overlapped_backward_and_step(tcnn_trainable_model_t* tm, hipStream_t stream, uint32_t n, const float* input, const half_t* dL_denc, float loss_scale,
+                                         uint32_t n_groups) {
+	const Model& md = tm->md;
+	const EncodingDesc& e = md.enc;
+	if (!tm->lanes) tm->lanes = std::make_shared<tcnn_trainable_model::OverlapLanes>();
+	tcnn_trainable_model::OverlapLanes& lanes = *tm->lanes;
+	lanes.next = 0;
+	const uint32_t F = e.grid.n_feat;
+	const size_t n_mlp = md.n_mlp_params();
+	const GridBackwardMode mode = GridBackwardMode::Bucketed;
+	const uint32_t budget = tm->lds_level_budget ? tm->lds_level_budget : g_default_lds_slice_bytes;
+	const std::vector<std::pair<uint32_t, uint32_t>> level_ranges = split_levels(e.grid, std::min(n_groups, e.grid.n_levels));
+	const size_t G = level_ranges.size();
+	// a workspace per group, carved out of one scratch block and one counter block of the compute stream
+	std::vector<GridBackwardWorkspace> ws(G);
+	std::vector<size_t> scratch_at(G), counters_at(G);
+	size_t scratch_bytes = 0, n_counters = 0;
+	for (size_t g = 0; g < G; ++g) {
+		ws[g] = grid_backward_workspace_size(grid_levels(e.grid, level_ranges[g].first, level_ranges[g].second), n, mode, budget);
+		scratch_at[g] = scratch_bytes;
+		counters_at[g] = n_counters;
+		scratch_bytes += next_multiple<size_t>(ws[g].scratch_bytes, 256);
+		n_counters += next_multiple<size_t>(ws[g].n_counters, 64);
+	}
+	Scratch queues;
+	uint32_t* counters = nullptr;
+	if (scratch_bytes) {
+		queues = Scratch(stream, scratch_bytes);
+		counters = ZeroedCounters::get(stream, n_counters);
+	}
+	optimizer_advance(tm, stream);
+	lanes.order(stream, lanes.owner);  // both lanes start behind the network's backward pass (and whatever else the compute stream holds)
+	lanes.order(stream, lanes.adam);
+	adam_range(tm, lanes.adam, loss_scale, 0, n_mlp, /*counts=*/true);  // the network's weights: their gradients are final already
+	half_t* grid_grads = tm->grads + n_mlp;
+	struct CountsGuard {
+		~CountsGuard() { g_phase_hook_counts = true; }
+	} counts_guard;
+	GridIO io = {input, in_stride_i(md), in_stride_d(), n, n, 1u};
+	for (size_t g = 0; g < G; ++g) {
+		const uint32_t a = level_ranges[g].first, b = level_ranges[g].second;
+		const GridMeta sub = grid_levels(e.grid, a, b);
+		GridBackwardWorkspace w = ws[g];
+		if (w.scratch_bytes) {
+			w.scratch = (unsigned char*)queues.ptr + scratch_at[g];
+			w.counters = counters + counters_at[g];
+		}
+		w.phase_hook = grid_backward_phase_hook;
+		g_phase_hook_counts = g == 0;  // one backward pass per step, however many launches it takes
+		const half_t* dy = dL_denc + (size_t)a * F * io.stride_k;
+		half_t* grads = grid_grads + (size_t)e.grid.offset[a] * F;
+		w.phases = 1u;  // pass A on the compute stream
+		w.hook_user = (void*)stream;
+		grid_backward(stream, sub, io, dy, grads, /*accumulate=*/false, mode, budget, w);
+		lanes.order(stream, lanes.owner);
+		w.phases = 2u;  // pass B on the owner lane
+		w.hook_user = (void*)lanes.owner;
+		grid_backward(lanes.owner, sub, io, dy, grads, /*accumulate=*/false, mode, budget, w);
+		lanes.order(lanes.owner, lanes.adam);
+		adam_range(tm, lanes.adam, loss_scale, n_mlp + (size_t)e.grid.offset[a] * F, n_mlp + (size_t)e.grid.offset[b] * F, /*counts=*/false);
+	}
+	lanes.order(lanes.adam, stream);  // the step is complete (the adam lane is behind every owner) before anything else runs on the compute stream
+}
+
 // training_step fast path (g_fused_network_passes): encoding forward, ONE kernel for the network's forward + loss + backward, encoding
 // backward.  Same results as forward() + backward() (tests/test_emu_kernels.py); the returned context carries the
 // prediction, dL_doutput, the loss and the encoded input, but no hidden activations.
@@ -2219,6 +2353,15 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 	// step: one GPU, gradients overwritten, plain Adam (no EMA copy to maintain), parameters the trainer's own.
 	bool fused_level[MAX_N_LEVELS] = {};
 	bool optimizer_opened = false;
+	// the pipelined form (overlapped_backward_and_step): this call owns the whole step on one GPU and every level runs the bucketed pass
+	const bool overlap = run_optimizer && tm->backward_overlap > 1 && !tm->fused_optimizer && want_grads && !accumulate && !dL_dinput && e.is_grid && e.n_params > 0 && !tm->ema &&
+	                     !tm->exchange && !tm->direct.active() && !wants_ready_ranges(tm) && !grouped_backward && !use_inference_params && e.grid.stochastic == 0u &&
+	                     e.grid.max_level >= 1.0f && (GridBackwardMode)g_grid_backward_mode.load() == GridBackwardMode::Bucketed;
+	if (overlap) {
+		overlapped_backward_and_step(tm, stream, n, input, denc.as<half_t>(), loss_scale, tm->backward_overlap);
+		*ctx_out = c.release();
+		return TCNN_OK;
+	}
 	if (need_denc) {
 		const size_t n_mlp = md.n_mlp_params();
 		const bool fuse = run_optimizer && tm->fused_optimizer && want_grads && !accumulate && e.is_grid && e.n_params > 0 && !tm->ema && !tm->exchange && !tm->direct.active() && !wants_ready_ranges(tm) && !grouped_backward &&

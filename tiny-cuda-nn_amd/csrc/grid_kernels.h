@@ -96,6 +96,10 @@ struct GridBackwardWorkspace {
 	void (*phase_hook)(void* user, int phase, int begin) = nullptr;
 	void* hook_user = nullptr;
 	const GridFusedAdam* fused_adam = nullptr;  // Bucketed mode, accumulate == false, first-order scatter only
+	// Bucketed mode: which half of the pass this call launches -- bit 0: pass A (record scatter), bit 1: pass B (owners + the other kinds
+	// of levels).  A caller that pipelines groups of levels over several streams (api.hip: overlapped backward) launches the halves
+	// separately, on different streams, with an event between them; both calls must see the same meta / io / workspace.
+	uint32_t phases = 3;
 };
 GridBackwardWorkspace grid_backward_workspace_size(const GridMeta& meta, uint32_t n, GridBackwardMode mode, uint32_t lds_slice_bytes);
 void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient, bool accumulate,

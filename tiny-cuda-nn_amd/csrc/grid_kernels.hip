@@ -2274,6 +2274,8 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 		counters = ws.counters;  // zero on entry (contract); the kernels below leave them zeroed again
 		queues = (uint32_t*)ws.scratch;
 		overflow = (uint32_t*)((unsigned char*)ws.scratch + bp.overflow_offset);
+	}
+	if (bk.n_levels && (ws.phases & 1u)) {
 		if (ws.phase_hook) ws.phase_hook(ws.hook_user, 0, 1);
 		// pass A: derive every corner once, bin by owner (+ zero the gradients of chunked levels)
 		const uint32_t scatter_blocks = bk.scatter_blocks + bk.zero_block_begin[bk.n_levels];
@@ -2297,6 +2299,7 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 #undef BSCATTER
 		if (ws.phase_hook) ws.phase_hook(ws.hook_user, 0, 0);
 	}
+	if (!(ws.phases & 2u)) return;
 	if (ws.phase_hook) ws.phase_hook(ws.hook_user, 1, 1);
 	for (uint32_t p = 0; p < plan.n_items; ++p) {
 		struct { uint32_t level, kind, n_chunks; } it = {plan.level[p], plan.kind[p], bp.n_chunks[p]};

@@ -263,6 +263,11 @@ class TrainableModel:
         """The encoding's backward pass in n_groups groups of consecutive levels, each reported through the ready callback."""
         _check(_lib.tcnn_trainer_set_backward_level_groups(self._h, int(n_groups)))
 
+    def set_backward_overlap(self, n_groups):
+        """Single-GPU training_step: backward scatter | owner pass | Adam pipelined over three streams in `n_groups` level groups
+        (tcnn_trainer_set_backward_overlap; bit for bit the one-stream step).  1: one stream."""
+        _check(_lib.tcnn_trainer_set_backward_overlap(self._h, int(n_groups)))
+
     def enable_rccl(self, nccl_comm, n_ranks, rank=None):
         """nccl_comm: this rank's ncclComm_t as an integer / c_void_p (None switches it off).  training_step then all-reduces every
         gradient range inside the library (RCCL loaded with dlopen) and steps each range when its collective has finished.

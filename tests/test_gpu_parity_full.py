@@ -421,7 +421,7 @@ def test_backward_and_optimizer_pipelined_over_three_streams_equal_the_one_strea
         else:
             assert (ga.float() - gb.float()).abs().max() <= 2.0 ** -7 * gb.float().abs().max()
             assert (a.params_full_precision[lo:hi] - b.params_full_precision[lo:hi]).abs().max() <= 2.5e-2
-    assert exact_levels >= 13, exact_levels  # the network's weights and every level with a sole owner per slice
+    assert exact_levels >= 12, exact_levels  # the network's weights and every level with a sole owner per slice
     # further steps: both trajectories keep learning at the same rate (the next step's forward pass reads what the adam lane wrote)
     la = [a.loss(a.training_step(x, t)) for _ in range(5)]
     lb = [b.loss(b.training_step(x, t)) for _ in range(5)]

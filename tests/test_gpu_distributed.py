@@ -127,10 +127,11 @@ def _direct_worker(rank, world, port, out_path, cfg, need_remainder):
     r, _, w = par.init_from_env(backend="gloo")
     tm = _model_of(cfg)
     x, t = _data()
-    b, e = par.shard_rows(N, r, w)
+    nt = _batch_for(w)
+    b, e = par.shard_rows(nt, r, w)
     xs, ts = x[b:e].cuda(), t[b:e].cuda()
     dp = par.DataParallel(tm, mode="direct")
-    tm.set_global_batch_size(N)
+    tm.set_global_batch_size(nt)
     ok = {"remainder": dp.n - dp.main}
     assert not need_remainder or dp.main < dp.n, "this case is about parameters that do not divide by 8 * world"
     # every parameter has exactly ONE owner: the ranks' shards tile [0, n) (the last one carries the remainder)
@@ -187,6 +188,11 @@ def _direct_worker(rank, world, port, out_path, cfg, need_remainder):
     dist.destroy_process_group()
 
 
+def _batch_for(world):
+    """the first rows of _data() that split into `world` shards of whole 256-sample tiles"""
+    return (N // (256 * world)) * 256 * world
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -219,7 +225,7 @@ def test_direct_exchange_over_peer_mapped_memory(tmp_path, world, which):
         assert tuple(clean) == (0, 0) and disagreeing[0] > 0 and disagreeing[1] == 0 and untouched
     tm = _model_of(cfg)
     x, t = _data()
-    x, t = x.cuda(), t.cuda()
+    x, t = x[:_batch_for(world)].cuda(), t[:_batch_for(world)].cuda()
     for _ in range(STEPS):
         tm.training_step(x, t)
     ref = tm.params_full_precision.cpu()

@@ -930,6 +930,54 @@ def test_bucketed_grid_backward_full_size(clustered):
                 assert np.mean(out[3][lo:hi].astype(np.float32) == O.h2f(O.f2h(ref[lo:hi].astype(np.float32)))) > 0.998, f"level {l}"
 
 
+@pytest.mark.parametrize("log2_t,scale", [(15, 1.5), (19, 2.0)])
+def test_owner_pass_hand_pipelined_stream_at_every_queue_length(log2_t, scale):
+    """The packed owner pass streams its queues through loads the compiler does not see (inline asm into registers that keep their
+    identity, counted s_waitcnt: csrc/grid_kernels.hip bucket_level_packed).  That path is compiled out of the host
+    emulator, so it is pinned here: batch sizes from 256 to 2^17 + 768 give the queues of the sixteen levels every kind of length -- empty
+    (fine levels at small batches), shorter than one round of a lane, a few records more or less than whole rounds of 4 x NG x 512
+    records -- and the gradients must equal, BIT FOR BIT, the 64-bit-per-value owner kernel's (mode 1: plain C++ loads, no pipelining)
+    and the packed kernel's own 64-bit redo of every slice (mode 2) wherever a slice has a sole owner (chunked coarse levels sum the
+    owners' results with fp16 atomics in either form and are compared within that rounding); the sole-owner levels are also exact
+    against the oracle's sum rounded once."""
+    C = tcnn()._C
+    enc = dict(HASH_ENCODING, log2_hashmap_size=log2_t, per_level_scale=scale)
+    m = C.create_encoding(3, enc)
+    og = oracle_grid(enc, 3)
+    rng = np.random.default_rng(5)
+    default_owner = C.get_grid_owner_mode()
+    try:
+        for n in (256, 512, 1024, 3840, 4096 + 256, 1 << 14, (1 << 16) - 256, (1 << 17) + 768):
+            pos = positions(n, 3, seed=100 + n % 97)
+            dy = O.f2h((rng.standard_normal((n, m.n_output_dims())) * 0.05).astype(np.float32))
+            x = torch.from_numpy(pos).cuda()
+            p = torch.zeros(og.n_params, dtype=torch.half, device="cuda").requires_grad_(True)
+            ctx, y = m.fwd(x, p)
+            out = {}
+            for owner in (0, 1, 2):
+                C.set_grid_owner_mode(owner)
+                _, dp = m.bwd(ctx, x, p, y, h_t(dy))
+                torch.cuda.synchronize()
+                out[owner] = dp.cpu().view(torch.int16).numpy().view(np.uint16).copy()
+            ref = O.grid_backward(og, pos, dy)
+            n_exact = 0
+            for l in range(og.n_levels):
+                lo, hi = og.offsets[l] * 2, og.offsets[l + 1] * 2
+                same = np.array_equal(out[0][lo:hi], out[1][lo:hi]) and np.array_equal(out[0][lo:hi], out[2][lo:hi])
+                if og.offsets[l + 1] - og.offsets[l] > 65536 or same:
+                    assert same, (n, l)
+                    n_exact += 1
+                else:  # several owners per slice: fp16 atomics between them
+                    a, b = O.h2f(out[0][lo:hi]).astype(np.float64), O.h2f(out[1][lo:hi]).astype(np.float64)
+                    assert np.all(np.abs(a - b) <= 2.0 ** -7 * np.maximum(np.abs(a), np.abs(b)) + 1e-4), (n, l)
+            assert n_exact >= 10, (n, n_exact)
+            got = O.h2f(out[0]).astype(np.float64)
+            absacc = O.grid_backward(og, pos, O.f2h(np.abs(O.h2f(dy))))
+            assert np.all(np.abs(got - ref) <= absacc * 2.0 ** -8 + 1e-3), n
+    finally:
+        C.set_grid_owner_mode(default_owner)
+
+
 @pytest.mark.parametrize("act,out_act", [("LeakyReLU", "None"), ("Exponential", "Sigmoid"), ("Sigmoid", "Exponential"), ("Squareplus", "Tanh"),
                                          ("Softplus", "Softplus"), ("Tanh", "Squareplus"), ("None", "ReLU")])
 def test_network_activations(act, out_act):

@@ -342,3 +342,60 @@ def test_no_mfma_result_is_read_too_soon_after_a_taken_branch(tmp_path, build):
     assert set(flagged) == {"_Z21fixture_padded_pathPf", "_Z23fixture_unpadded_pathPf", "_Z20fixture_cured_pathPf"}
     assert flagged["_Z21fixture_padded_pathPf"] == [] and flagged["_Z20fixture_cured_pathPf"] == []
     assert len(flagged["_Z23fixture_unpadded_pathPf"]) == 1 and "after 1 wait states" in flagged["_Z23fixture_unpadded_pathPf"][0]
+
+
+@pytest.mark.parametrize("lib_name", ["libtcnn_hip.so", "libtcnn_hip_bf16.so"])
+def test_no_register_of_a_hand_issued_load_is_touched_before_its_wait(tmp_path, lib_name):
+    """The owner pass of the grid backward streams its queues through loads issued from inline asm and awaited with counted
+    `s_waitcnt vmcnt(N)` statements (csrc/grid_kernels.hip, bucket_level_packed): the compiler's wait-count insertion does not know these
+    loads, so a register copy, spill or reuse between issue and wait would read data that is still in flight -- silently wrong gradients on the
+    GPU, invisible to the emulator, which compiles the path out.  scripts/check_asm_load_hazard.py follows EVERY
+    control-flow path of the SHIPPED code object from each such load and demands a sufficient wait before anything names its destination
+    registers; the positive controls (a copy on the loop's back edge, a wait that allows too many loads in flight, a path that skips the
+    wait) must be flagged."""
+    import shutil
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import check_asm_load_hazard as chk
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(tools, "llvm-objdump")):
+        pytest.skip("no llvm-objdump")
+    lib = shutil.copy(os.path.join(ROOT, "tiny-cuda-nn_amd", "lib", lib_name), str(tmp_path / lib_name))
+    subprocess.run([os.path.join(tools, "llvm-objdump"), "--offloading", lib], capture_output=True, text=True, check=True, cwd=str(tmp_path))
+    n_loads, n_kernels = 0, 0
+    for f in sorted(os.listdir(str(tmp_path))):
+        if "gfx950" not in f:
+            continue
+        dis = subprocess.run([os.path.join(tools, "llvm-objdump"), "-d", "--no-show-raw-insn", str(tmp_path / f)], capture_output=True, text=True, check=True).stdout
+        for name, insts in chk.parse(dis.splitlines()).items():
+            if "k_grid_bucket_owner" not in name:
+                continue
+            findings, n = chk.check_kernel(name, insts)
+            assert findings == [], findings[:3]
+            n_loads += n
+            n_kernels += 1
+    assert n_kernels >= 6 and n_loads >= 8 * 6  # every F = 2 instance carries the eight hand-issued loads of a lane's first round
+
+    def kernel(body):
+        lines = ["0000000000001000 <k_fixture>:"]
+        for i, (text, target) in enumerate(body):
+            lines.append(f"\t{text}    // {0x1000 + 4 * i:012X}: 00000000" + (f" <k_fixture+{hex(4 * target)}>" if target is not None else ""))
+        return chk.parse(lines)["k_fixture"]
+
+    ok = kernel([("global_load_dwordx3 v[10:12], v2, s[4:5] nt", None), ("global_load_dwordx3 v[14:16], v3, s[4:5] nt", None),
+                 ("s_waitcnt vmcnt(1)", None), ("v_add_u32_e32 v20, v10, v11", None), ("s_waitcnt vmcnt(0)", None), ("v_add_u32_e32 v21, v14, v15", None), ("s_endpgm", None)])
+    assert chk.check_kernel("ok", ok) == ([], 2)
+    too_many_in_flight = kernel([("global_load_dwordx3 v[10:12], v2, s[4:5] nt", None), ("global_load_dwordx3 v[14:16], v3, s[4:5] nt", None),
+                                 ("s_waitcnt vmcnt(2)", None), ("v_add_u32_e32 v20, v10, v11", None), ("s_waitcnt vmcnt(0)", None), ("s_endpgm", None)])
+    assert len(chk.check_kernel("f", too_many_in_flight)[0]) == 1
+    copy_on_the_back_edge = kernel([("global_load_dwordx3 v[10:12], v2, s[4:5] nt", None),            # 0
+                                    ("s_waitcnt vmcnt(0)", None),                                    # 1  loop head
+                                    ("v_add_u32_e32 v20, v10, v11", None),                           # 2
+                                    ("global_load_dwordx3 v[10:12], v2, s[4:5] nt", None),            # 3  re-request
+                                    ("v_mov_b32_e32 v30, v12", None),                                # 4  the compiler's rotation copy: in flight
+                                    ("s_cbranch_scc1 65532", 1),                                     # 5
+                                    ("s_waitcnt vmcnt(0)", None), ("s_endpgm", None)])
+    assert any("v_mov_b32_e32 v30, v12" in f for f in chk.check_kernel("f", copy_on_the_back_edge)[0])
+    path_around_the_wait = kernel([("global_load_dwordx3 v[10:12], v2, s[4:5] nt", None), ("s_cbranch_vccnz 2", 3), ("s_waitcnt vmcnt(0)", None),
+                                   ("v_mov_b32_e32 v11, 0", None), ("s_endpgm", None)])
+    assert len(chk.check_kernel("f", path_around_the_wait)[0]) == 1

@@ -2205,6 +2205,7 @@ struct tcnn_trainable_model::OverlapLanes {
 	}
 	// `to` continues behind everything enqueued on `from` so far
 	void order(hipStream_t from, hipStream_t to) {
+		if (from == to) return;
 		hipEvent_t e = event();
 		HIP_CHECK(hipEventRecord(e, from));
 		HIP_CHECK(hipStreamWaitEvent(to, e, 0));
@@ -2223,6 +2224,10 @@ static void overlapped_backward_and_step(tcnn_trainable_model_t* tm, hipStream_t
 	if (!tm->lanes) tm->lanes = std::make_shared<tcnn_trainable_model::OverlapLanes>();
 	tcnn_trainable_model::OverlapLanes& lanes = *tm->lanes;
 	lanes.next = 0;
+	// TCNN_BACKWARD_OVERLAP_LANES (diagnostics): bit 0 = the owner passes on a lane of their own, bit 1 = Adam on a lane of its own; a lane that is
+	// switched off runs on the compute stream (3 = both, the design; 0 = the same launches, one stream: what grouping alone costs)
+	static const int lane_mask = getenv("TCNN_BACKWARD_OVERLAP_LANES") ? atoi(getenv("TCNN_BACKWARD_OVERLAP_LANES")) : 3;
+	const hipStream_t owner_lane = (lane_mask & 1) ? lanes.owner : stream, adam_lane = (lane_mask & 2) ? lanes.adam : stream;
 	const uint32_t F = e.grid.n_feat;
 	const size_t n_mlp = md.n_mlp_params();
 	const GridBackwardMode mode = GridBackwardMode::Bucketed;
@@ -2247,9 +2252,9 @@ static void overlapped_backward_and_step(tcnn_trainable_model_t* tm, hipStream_t
 		counters = ZeroedCounters::get(stream, n_counters);
 	}
 	optimizer_advance(tm, stream);
-	lanes.order(stream, lanes.owner);  // both lanes start behind the network's backward pass (and whatever else the compute stream holds)
-	lanes.order(stream, lanes.adam);
-	adam_range(tm, lanes.adam, loss_scale, 0, n_mlp, /*counts=*/true);  // the network's weights: their gradients are final already
+	lanes.order(stream, owner_lane);  // both lanes start behind the network's backward pass (and whatever else the compute stream holds)
+	lanes.order(stream, adam_lane);
+	adam_range(tm, adam_lane, loss_scale, 0, n_mlp, /*counts=*/true);  // the network's weights: their gradients are final already
 	half_t* grid_grads = tm->grads + n_mlp;
 	struct CountsGuard {
 		~CountsGuard() { g_phase_hook_counts = true; }
@@ -2270,14 +2275,15 @@ static void overlapped_backward_and_step(tcnn_trainable_model_t* tm, hipStream_t
 		w.phases = 1u;  // pass A on the compute stream
 		w.hook_user = (void*)stream;
 		grid_backward(stream, sub, io, dy, grads, /*accumulate=*/false, mode, budget, w);
-		lanes.order(stream, lanes.owner);
+		lanes.order(stream, owner_lane);
 		w.phases = 2u;  // pass B on the owner lane
-		w.hook_user = (void*)lanes.owner;
-		grid_backward(lanes.owner, sub, io, dy, grads, /*accumulate=*/false, mode, budget, w);
-		lanes.order(lanes.owner, lanes.adam);
-		adam_range(tm, lanes.adam, loss_scale, n_mlp + (size_t)e.grid.offset[a] * F, n_mlp + (size_t)e.grid.offset[b] * F, /*counts=*/false);
+		w.hook_user = (void*)owner_lane;
+		grid_backward(owner_lane, sub, io, dy, grads, /*accumulate=*/false, mode, budget, w);
+		lanes.order(owner_lane, adam_lane);
+		adam_range(tm, adam_lane, loss_scale, n_mlp + (size_t)e.grid.offset[a] * F, n_mlp + (size_t)e.grid.offset[b] * F, /*counts=*/false);
 	}
-	lanes.order(lanes.adam, stream);  // the step is complete (the adam lane is behind every owner) before anything else runs on the compute stream
+	lanes.order(owner_lane, stream);
+	lanes.order(adam_lane, stream);  // the step is complete (the adam lane is behind every owner) before anything else runs on the compute stream
 }
 
 // training_step fast path (g_fused_network_passes): encoding forward, ONE kernel for the network's forward + loss + backward, encoding

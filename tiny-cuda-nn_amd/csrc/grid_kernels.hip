@@ -1421,9 +1421,8 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 	bool safe = !force_wide;
 	// the packed table is cleared first (LDS only), the first round requested behind it: nothing then stands between the loads and
 	// their use but the barrier (cleared after the loads, the compiler parks part of a record in other registers and waits for it)
-	if (safe && !(diag_owner & 1u)) {
-		for (uint32_t e = threadIdx.x; e < slice_count * PW / 2; e += THREADS) ((u4*)lds_raw)[e] = u4{0u, 0u, 0u, 0u};  // slice_count is a multiple of 8
-	}
+	// (both happen at the top of the `if (safe)` block below -- ONE block from the issue of the hand-made loads to their last use, so that no
+	// control-flow path of the compiled code leads from an issued load to anything but its wait: scripts/check_asm_load_hazard.py checks that)
 	// Three-word records (F <= 2) on the GPU: the stream is PIPELINED BY HAND, two half-rounds of STREAM_U / 2 records per lane that are
 	// consumed and re-requested in turn -- while the records of one half go through the conversions and LDS atomics (45 VALU
 	// instructions each; the four waves of a SIMD all want the ALU when their loads arrive), the other half's loads are on their
@@ -1460,17 +1459,6 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 		asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]) : [n] "n"(4 * (NG - 1)) : "memory");
 	};
 #endif
-	if constexpr (PIPELINED) {
-#if !defined(TCNN_HOST_EMU)
-		if (safe) {  // (only the packed pass consumes them -- and nothing the compiler does not know of may stay in flight otherwise)
-#pragma unroll
-			for (uint32_t k = 0; k < NG; ++k) issue_half(grp[k], threadIdx.x + 4u * k * THREADS, cap - 1u);
-		}
-#endif
-	} else {
-		load_round(threadIdx.x, cap - 1u, first_round);
-	}
-
 	// streams the queue (and this slice's share of the overflow list) through `add(index, payload)`; `first`: the lane's first
 	// round if it is in registers already (the first pass over the queue), null to load it here (the 64-bit redo)
 	auto stream = [&](const uint32_t (*first)[PWP], auto&& add) {
@@ -1569,6 +1557,18 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 	};
 
 	if (safe) {
+		if (!(diag_owner & 1u)) {
+			for (uint32_t e = threadIdx.x; e < slice_count * PW / 2; e += THREADS) ((u4*)lds_raw)[e] = u4{0u, 0u, 0u, 0u};  // slice_count is a multiple of 8
+		}
+		if constexpr (PIPELINED) {
+#if !defined(TCNN_HOST_EMU)
+			// (only the packed pass consumes them -- and nothing the compiler does not know of may stay in flight otherwise)
+#pragma unroll
+			for (uint32_t k = 0; k < NG; ++k) issue_half(grp[k], threadIdx.x + 4u * k * THREADS, cap - 1u);
+#endif
+		} else {
+			load_round(threadIdx.x, cap - 1u, first_round);
+		}
 		unsigned long long* tab = (unsigned long long*)lds_raw;  // [entries][PW]: features 2p (low word) and 2p + 1 (high word)
 		__syncthreads();  // the table is clear
 		float bound[F];

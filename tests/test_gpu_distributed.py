@@ -256,10 +256,10 @@ def _direct_soak_worker(rank, world, port, out_path, n_steps):
         tm.training_step(x.cuda(), t.cuda(), run_optimizer=False)
         dp.exchange_and_step()
         torch.cuda.synchronize()
-        mine = tm.params.clone().cpu().view(torch.int16)
+        mine = tm.params.clone().cpu()  # (gloo has no int16: the 16-bit weights travel as they are and are compared as bit patterns)
         theirs = [torch.empty_like(mine) for _ in range(w)]
         dist.all_gather(theirs, mine)
-        if not all(bool(torch.equal(p, mine)) for p in theirs):
+        if not all(bool(torch.equal(p.view(torch.int16), mine.view(torch.int16))) for p in theirs):
             diverged.append(step)
     status = tm.direct_status()
     if r == 0:

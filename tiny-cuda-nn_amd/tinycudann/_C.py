@@ -359,6 +359,23 @@ class Context:
             self._h = None
 
 
+class _DeviceGuard:
+    """`with torch.cuda.device(d)` only when `d` is not the current device already (bindings.cpp:95: a device guard per call; the context
+    manager costs ~10 us of host time per entry, which the binding's loop at batch 2^18 cannot hide on small tables)."""
+
+    def __init__(self, device):
+        self._cm = None if device.index is None or device.index == torch.cuda.current_device() else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self._cm is not None:
+            self._cm.__enter__()
+
+    def __exit__(self, *exc):
+        if self._cm is not None:
+            return self._cm.__exit__(*exc)
+        return False
+
+
 class Module:
     """Mirror of the pybind `Module` (bindings.cpp:75-248)."""
 
@@ -371,10 +388,10 @@ class Module:
             self._h = None
 
     def _torch_param_dtype(self):
-        return TORCH_DTYPE[Precision(self.param_precision())]
+        return self._fixed("_param_dtype", lambda: TORCH_DTYPE[Precision(self.param_precision())])
 
     def _torch_output_dtype(self):
-        return TORCH_DTYPE[Precision(self.output_precision())]
+        return self._fixed("_output_dtype", lambda: TORCH_DTYPE[Precision(self.output_precision())])
 
     def fwd(self, input, params):
         _check_input(input)
@@ -387,7 +404,7 @@ class Module:
             raise RuntimeError("input / params have the wrong size")
         if input.device != params.device:
             raise RuntimeError("input and params must be on the same device")
-        with torch.cuda.device(input.device):
+        with _DeviceGuard(input.device):
             batch_size = input.shape[0]
             output = torch.empty((batch_size, self.n_output_dims()), dtype=self._torch_output_dtype(), device=input.device)
             if not input.requires_grad and not params.requires_grad:
@@ -409,7 +426,7 @@ class Module:
         if input.shape[1] != self.n_input_dims() or output.shape[1] != self.n_output_dims() or \
                 params.shape[0] != self.n_params() or output.shape[0] != input.shape[0] or dL_doutput.shape[0] != input.shape[0]:
             raise RuntimeError("bwd: wrong tensor size")
-        with torch.cuda.device(input.device):
+        with _DeviceGuard(input.device):
             batch_size = input.shape[0]
             dL_dinput = torch.empty((batch_size, input.shape[1]), dtype=torch.float32, device=input.device) if input.requires_grad else None
             dL_dparams = torch.empty((self.n_params(),), dtype=self._torch_param_dtype(), device=input.device) if params.requires_grad else None
@@ -429,7 +446,7 @@ class Module:
         if input.shape[1] != self.n_input_dims() or dL_doutput.shape[1] != self.n_output_dims() or dL_ddLdinput.shape != input.shape or \
                 params.shape[0] != self.n_params() or dL_doutput.shape[0] != input.shape[0]:
             raise RuntimeError("bwd_bwd_input: wrong tensor size")
-        with torch.cuda.device(input.device):
+        with _DeviceGuard(input.device):
             batch_size = input.shape[0]
             dL_ddLdoutput = torch.zeros((batch_size, self.n_output_dims()), dtype=self._torch_output_dtype(), device=input.device) if dL_doutput.requires_grad else None
             dL_dparams = torch.zeros((self.n_params(),), dtype=self._torch_param_dtype(), device=input.device) if params.requires_grad else None
@@ -444,20 +461,27 @@ class Module:
         _check(_lib.tcnn_module_initialize_params(self._h, int(seed), _ptr(out), 1.0))
         return out
 
+    # (fixed for the lifetime of a module: asked once -- fwd / bwd check them on every call)
+    def _fixed(self, name, fn):
+        v = self.__dict__.get(name)
+        if v is None:
+            v = self.__dict__[name] = fn()
+        return v
+
     def n_input_dims(self):
-        return int(_lib.tcnn_module_n_input_dims(self._h))
+        return self._fixed("_n_input_dims", lambda: int(_lib.tcnn_module_n_input_dims(self._h)))
 
     def n_params(self):
-        return int(_lib.tcnn_module_n_params(self._h))
+        return self._fixed("_n_params", lambda: int(_lib.tcnn_module_n_params(self._h)))
 
     def param_precision(self):
-        return Precision(_lib.tcnn_module_param_precision(self._h))
+        return self._fixed("_param_precision", lambda: Precision(_lib.tcnn_module_param_precision(self._h)))
 
     def n_output_dims(self):
-        return int(_lib.tcnn_module_n_output_dims(self._h))
+        return self._fixed("_n_output_dims", lambda: int(_lib.tcnn_module_n_output_dims(self._h)))
 
     def output_precision(self):
-        return Precision(_lib.tcnn_module_output_precision(self._h))
+        return self._fixed("_output_precision", lambda: Precision(_lib.tcnn_module_output_precision(self._h)))
 
     def hyperparams(self):
         return json.loads(_lib.tcnn_module_hyperparams_json(self._h).decode())

@@ -61,6 +61,13 @@ class _NativeFunction(torch.autograd.Function):
             warnings.warn("doutput must be a GPU tensor, but isn't. This indicates suboptimal performance.")
             dy = dy.cuda()
         x, params, y = ctx.saved_tensors
+        if not torch.is_grad_enabled():
+            # the ordinary backward pass (no create_graph): nothing will differentiate this again, so the native call is made right here -- the
+            # differentiable wrapper below costs a second autograd node and its bookkeeping per step, which at batch 2^18 is host time the GPU
+            # waits for (profiles/r05_exp_notes.txt: the binding's loop is bound by the host's launch rate on small tables)
+            scale = ctx.loss_scale
+            dx, dparams = ctx.native_module.bwd(ctx.native_ctx, x, params, y, (dy * scale).to(y.dtype).contiguous())
+            return None, (None if dx is None else dx / scale), (None if dparams is None else dparams / scale), None
         # a Function of its own, so that the input gradient can be differentiated again (eikonal / SDF losses)
         dx, dparams = _NativeBackwardFunction.apply(ctx, dy, x, params, y)
         return None, _none_if_scalar(dx), _none_if_scalar(dparams), None

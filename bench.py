@@ -669,6 +669,10 @@ def main():
         if elapsed_resident is not None:
             line["value_resident"] = global_batch * args.steps / elapsed_resident
             line["ms_per_step_resident"] = elapsed_resident / args.steps * 1e3
+            # which of two back-to-back timed regions is faster depends on their ORDER once they are long (profiles/r05_exp_notes.txt 2: whichever
+            # 1000-step region runs second is 4-10 % slower -- the device has lowered its clock by then); `value` is always the first region's
+            line["resident_region_order"] = ("before the timed region (--resident-first)" if args.resident_first else
+                                             "after the timed region: in runs of several hundred steps it runs at the lower clock the device has settled to by then")
         if "reference_readme_samples_per_s" in w:
             line["vs_reference_readme"] = {"ratio": value / w["reference_readme_samples_per_s"], "reference_samples_per_s": w["reference_readme_samples_per_s"],
                                            "note": "README.md:151-153, RTX 4090, derived from 'a bit over 1 second per 1000 steps' (BASELINE.md section 1): other hardware, "

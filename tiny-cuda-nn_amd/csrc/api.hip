@@ -2332,12 +2332,17 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 
 	const bool need_denc = (want_grads && e.n_params > 0) || dL_dinput;
 	Scratch denc;
+	// The weight-gradient finalize (a 5 us kernel that is all launch latency: 14.7 MB of slabs -> 7168 sums) beside the encoding's backward
+	// instead of in front of it: on a lane of its own behind the network kernel, joined before anything reads the gradients.  Only where
+	// nobody is told "the network's gradients are ready" before the join (the data-parallel hooks) -- TCNN_FINALIZE_ASIDE=1 (experiment).
+	static const bool finalize_aside_enabled = getenv("TCNN_FINALIZE_ASIDE") && atoi(getenv("TCNN_FINALIZE_ASIDE")) != 0;
+	const bool finalize_aside = finalize_aside_enabled && want_grads && need_denc && e.is_grid && e.n_params > 0 && !wants_ready_ranges(tm);
+	Scratch partials;  // (lives until the join below: the lane reads it while the compute stream moves on)
 	{
 		ProfScope prof(stream, STAGE_MLP_TRAIN);
 		Scratch params_t_local;
 		const half_t* params_t = trainer_params_t(tm, stream, params, params_t_local);
 		const uint32_t n_partials = mlp_train_n_partials(md.net.mlp, n, external_dL_dy ? LossType::L2 : tm->loss);
-		Scratch partials;
 		if (want_grads) partials = Scratch(stream, (size_t)n_partials * md.n_mlp_params() * sizeof(float));
 		if (need_denc) denc = Scratch(stream, (size_t)e.padded_output_width * n * sizeof(half_t));
 		MlpLossArgs la = {tm->loss, target, data_pdf, md.output_width(), loss_scale, (uint32_t)n_total};
@@ -2349,8 +2354,29 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 		const SlabOrder order = mlp_train(stream, md.net.mlp, n, params, params_t, fc.enc.as<half_t>(), la, c->output.as<half_t>(),
 		                                  external_dL_dy ? nullptr : c->dL_doutput.as<half_t>(), need_denc ? denc.as<half_t>() : nullptr,
 		                                  want_grads ? partials.as<float>() : nullptr, external_dL_dy ? nullptr : c->block_sums.as<float>());
-		if (want_grads) mlp_finalize_gradients(stream, md.net.mlp, n_partials, partials.as<float>(), tm->grads, accumulate, order);
+		if (want_grads && !finalize_aside) mlp_finalize_gradients(stream, md.net.mlp, n_partials, partials.as<float>(), tm->grads, accumulate, order);
+		if (finalize_aside) {
+			if (!tm->lanes) tm->lanes = std::make_shared<tcnn_trainable_model::OverlapLanes>();
+			tm->lanes->next = 0;
+			tm->lanes->order(stream, tm->lanes->owner);
+			mlp_finalize_gradients(tm->lanes->owner, md.net.mlp, n_partials, partials.as<float>(), tm->grads, accumulate, order);
+		}
 	}
+	struct JoinLane {  // the compute stream continues behind the lane wherever this function leaves (also by exception)
+		tcnn_trainable_model_t* tm;
+		hipStream_t stream;
+		bool armed;
+		void join() {
+			if (armed) tm->lanes->order(tm->lanes->owner, stream);
+			armed = false;
+		}
+		~JoinLane() {
+			try {
+				join();
+			} catch (...) {
+			}
+		}
+	} finalize_join = {tm, stream, finalize_aside};
 	ReadyTrampoline tramp = {tm, stream};
 	LevelGroups level_groups = {tm->backward_level_groups, want_grads && wants_ready_ranges(tm) ? &ReadyTrampoline::call : nullptr, &tramp};
 	const bool grouped_backward = level_groups.n_groups > 1;
@@ -2364,6 +2390,7 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 	                     !tm->exchange && !tm->direct.active() && !wants_ready_ranges(tm) && !grouped_backward && !use_inference_params && e.grid.stochastic == 0u &&
 	                     e.grid.max_level >= 1.0f && (GridBackwardMode)g_grid_backward_mode.load() == GridBackwardMode::Bucketed;
 	if (overlap) {
+		finalize_join.join();
 		overlapped_backward_and_step(tm, stream, n, input, denc.as<half_t>(), loss_scale, tm->backward_overlap);
 		*ctx_out = c.release();
 		return TCNN_OK;
@@ -2392,6 +2419,7 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 		encoding_backward(stream, md, fc, n, dL_dinput, denc.as<half_t>(), n, 1u, tm->grads, want_grads, accumulate, input, tm->lds_level_budget,
 		                  fuse ? &fa : nullptr, &level_groups);
 	}
+	finalize_join.join();  // the network's gradients are final on the compute stream from here on
 	*ctx_out = c.release();
 	if (run_optimizer && optimizer_opened) {  // the rest of the step: network weights and the levels the backward did not step
 		std::vector<size_t> begins, ends;

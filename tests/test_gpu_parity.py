@@ -960,6 +960,7 @@ def test_owner_pass_hand_pipelined_stream_at_every_queue_length(log2_t, scale):
                 torch.cuda.synchronize()
                 out[owner] = dp.cpu().view(torch.int16).numpy().view(np.uint16).copy()
             ref = O.grid_backward(og, pos, dy)
+            absacc = O.grid_backward(og, pos, O.f2h(np.abs(O.h2f(dy))))
             n_exact = 0
             for l in range(og.n_levels):
                 lo, hi = og.offsets[l] * 2, og.offsets[l + 1] * 2
@@ -967,12 +968,11 @@ def test_owner_pass_hand_pipelined_stream_at_every_queue_length(log2_t, scale):
                 if og.offsets[l + 1] - og.offsets[l] > 65536 or same:
                     assert same, (n, l)
                     n_exact += 1
-                else:  # several owners per slice: fp16 atomics between them
+                else:  # several owners per slice (sample chunks of a small table): their exact sums meet in fp16 atomics, one rounding per owner
                     a, b = O.h2f(out[0][lo:hi]).astype(np.float64), O.h2f(out[1][lo:hi]).astype(np.float64)
-                    assert np.all(np.abs(a - b) <= 2.0 ** -7 * np.maximum(np.abs(a), np.abs(b)) + 1e-4), (n, l)
+                    assert np.all(np.abs(a - b) <= absacc[lo:hi] * 2.0 ** -8 + 1e-3), (n, l)
             assert n_exact >= 10, (n, n_exact)
             got = O.h2f(out[0]).astype(np.float64)
-            absacc = O.grid_backward(og, pos, O.f2h(np.abs(O.h2f(dy))))
             assert np.all(np.abs(got - ref) <= absacc * 2.0 ** -8 + 1e-3), n
     finally:
         C.set_grid_owner_mode(default_owner)

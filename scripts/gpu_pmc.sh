@@ -8,7 +8,7 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 cd /tmp
 run_pass () {  # name, counters...
   local name=$1; shift
-  timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$name -o pmc -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-inference --dominant grid_forward > $OUT/pmc_$name.log 2>&1
+  timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$name -o pmc -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-inference --api native --dominant grid_forward > $OUT/pmc_$name.log 2>&1
   echo "pass $name exit $?"
 }
 run_pass fetch FETCH_SIZE

@@ -591,12 +591,17 @@ def main():
     # (97 % non-zero after 20 steps, 57 % after 1000 on the headline, while the kernel takes the same time).
     g_nz = tm.param_gradients != 0
     nonzero_training_gradients = int(g_nz.sum().item())
+    touched_counted_by = "the library's encoding backward on the first batch with unit output gradients (entries a sample's corner lands on) + all network weights: a property of batch and table, independent of the state of training"
     if w["config"]["encoding"]["otype"] == "HashGrid":
-        enc_only = tcnn.Encoding(w["n_in"], w["config"]["encoding"])
-        y = enc_only(batches[0][0])
-        y.backward(torch.ones_like(y))
-        touched = tm.n_mlp_params + int(torch.count_nonzero(enc_only.params.grad).item())
-        del enc_only, y
+        try:
+            enc_only = tcnn.Encoding(w["n_in"], w["config"]["encoding"])
+            y = enc_only(batches[0][0])
+            y.backward(torch.ones_like(y))
+            touched = tm.n_mlp_params + int(torch.count_nonzero(enc_only.params.grad).item())
+            del enc_only, y
+        except Exception as ex:  # (the count is accounting, not measurement: never worth the line)
+            touched = nonzero_training_gradients
+            touched_counted_by = f"non-zero training gradients at the end of the run (the unit-gradient count failed: {type(ex).__name__}: {ex})"[:300]
     else:
         touched = tm.n_params  # network weights: every one of them, every step
     # the granularity the kernel is BUILT for: whole 128-byte lines of fp32 state (32 consecutive parameters vote, `dense_store`)
@@ -655,8 +660,7 @@ def main():
                                      "training_step (samples/mlp_learning_an_image.cu:263-271)") if regenerate else "four batches resident in HBM, rotated",
                          "regenerate": regenerate, "timed_steps": args.steps,
                          "adam_touched_parameters": touched, "adam_touched_fraction": touched / tm.n_params,
-                         "adam_touched_counted_by": "the library's encoding backward on the first batch with unit output gradients (entries a sample's corner lands on) "
-                                                    "+ all network weights: a property of batch and table, independent of the state of training",
+                         "adam_touched_counted_by": touched_counted_by,
                          "nonzero_training_gradients_at_end_of_run": nonzero_training_gradients,
                          "adam_algorithmic_bytes": {"touched": ab["adam"], "dense_upper_bound": adam_dense,
                                                     "whole_128B_state_lines_with_a_stepped_parameter": params_in_touched_lines * 36 + (tm.n_params - params_in_touched_lines) * 2}},

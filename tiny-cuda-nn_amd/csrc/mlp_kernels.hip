@@ -94,11 +94,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_forward(const MlpMeta m
 			// accumulator (neuron 16w+4g+r, sample 16t+lr) -> activation -> sample-major store
 #pragma unroll
 			for (uint32_t t = 0; t < NT; ++t) {
-				h4 o;
-#pragma unroll
-				for (uint32_t r = 0; r < 4; ++r) {
-					o[r] = (half_t)act_forward<GENERAL>(act, acc[t][r]);
-				}
+				const h4 o = act_forward4<GENERAL>(act, acc[t]);
 				*(h4*)(nxt + (16 * t + lr) * ld + 16 * w + 4 * g) = o;
 			}
 			__syncthreads();
@@ -134,8 +130,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_forward(const MlpMeta m
 				const h4 b = *(const h4*)(cur + (16 * t + lr) * ld + k0 + 4 * g);
 				acc = mfma_16x16x16(a, b, acc);
 			}
-			const h4 o = h4{(half_t)act_forward<GENERAL>(out_act, acc[0]), (half_t)act_forward<GENERAL>(out_act, acc[1]), (half_t)act_forward<GENERAL>(out_act, acc[2]),
-			                (half_t)act_forward<GENERAL>(out_act, acc[3])};
+			const h4 o = act_forward4<GENERAL>(out_act, acc);
 			*(h4*)(output + ((size_t)tile * S + 16 * t + lr) * OUTP + 16 * ob + 4 * g) = o;  // (output 16ob+4g+r, sample 16t+lr)
 		}
 		__syncthreads();
@@ -227,11 +222,9 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 				const h4 a = *(const h4*)(dL_doutput + ((size_t)tile * S + 16 * t + lr) * 16 + 4 * g);
 				const f4 acc = mfma_16x16x16(a, bw, zero4());
 				const h4 hv = *(const h4*)(hlast + (16 * w + lr) * SP + ft_col16(w, 16 * t) + lane_c4);
+				da[t] = act_backward4<GENERAL>(act, acc, hv);  // transfer on post-activation values (common_device.h:363-418)
 #pragma unroll
-				for (uint32_t r = 0; r < 4; ++r) {
-					da[t][r] = (half_t)act_backward<GENERAL>(act, acc[r], hv[r]);  // transfer on post-activation values (common_device.h:363-418)
-					dact0[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
-				}
+				for (uint32_t r = 0; r < 4; ++r) dact0[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
 			}
 			if (want_grads) {  // dW_out^T[k][o] += sum_s A_last[k][s] dY[o][s]
 #pragma unroll
@@ -289,11 +282,9 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward(const MlpMeta 
 #pragma unroll
 			for (uint32_t t = 0; t < NT; ++t) {
 				const h4 hv = *(const h4*)(hj + (16 * w + lr) * SP + ft_col16(w, 16 * t) + lane_c4);
+				da[t] = act_backward4<GENERAL>(act, acc[t], hv);
 #pragma unroll
-				for (uint32_t r = 0; r < 4; ++r) {
-					da[t][r] = (half_t)act_backward<GENERAL>(act, acc[t][r], hv[r]);
-					nxt[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
-				}
+				for (uint32_t r = 0; r < 4; ++r) nxt[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
 			}
 			__syncthreads();
 			half_t* tmp = cur;
@@ -436,8 +427,9 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward_chain(const Ml
 					acc = mfma_16x16x16(a, bw, acc);
 				}
 				const h4 hv = *(const h4*)(hT + (16 * w + lr) * SP + 16 * t + 4 * g);
+				const h4 dv = act_backward4<GENERAL>(act, acc, hv);
 #pragma unroll
-				for (uint32_t r = 0; r < 4; ++r) dact0[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = (half_t)act_backward<GENERAL>(act, acc[r], hv[r]);
+				for (uint32_t r = 0; r < 4; ++r) dact0[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = dv[r];
 			}
 		}
 		__syncthreads();
@@ -472,8 +464,9 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64) k_mlp_backward_chain(const Ml
 #pragma unroll
 			for (uint32_t t = 0; t < NT; ++t) {
 				const h4 hv = *(const h4*)(hT + (16 * w + lr) * SP + 16 * t + 4 * g);
+				const h4 dv = act_backward4<GENERAL>(act, acc[t], hv);
 #pragma unroll
-				for (uint32_t r = 0; r < 4; ++r) nxt[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = (half_t)act_backward<GENERAL>(act, acc[t][r], hv[r]);
+				for (uint32_t r = 0; r < 4; ++r) nxt[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = dv[r];
 			}
 			__syncthreads();
 			store_dact((uint32_t)j, tile, nxt);
@@ -719,12 +712,9 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, WIDTH == 128 ? 1 : TCNN_MLP_T
 				half_t* hl = hT + layer * WIDTH * SP;
 #pragma unroll
 				for (uint32_t t = 0; t < NT; ++t) {
-					h4 o;
+					const h4 o = act_forward4<GENERAL>(act, acc[t]);
 #pragma unroll
-					for (uint32_t r = 0; r < 4; ++r) {
-						o[r] = (half_t)act_forward<GENERAL>(act, acc[t][r]);
-						hl[(16 * w + 4 * g + r) * SP + 16 * t + lr] = o[r];
-					}
+					for (uint32_t r = 0; r < 4; ++r) hl[(16 * w + 4 * g + r) * SP + 16 * t + lr] = o[r];
 					*(h4*)(nxt + (16 * t + lr) * LDW + 16 * w + 4 * g) = o;
 				}
 				__syncthreads();
@@ -753,8 +743,7 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, WIDTH == 128 ? 1 : TCNN_MLP_T
 					const h4 b = *(const h4*)(cur + (16 * t + lr) * LDW + k0 + 4 * g);
 					acc = mfma_16x16x16(a, b, acc);
 				}
-				const h4 o = h4{(half_t)act_forward<GENERAL>(out_act, acc[0]), (half_t)act_forward<GENERAL>(out_act, acc[1]), (half_t)act_forward<GENERAL>(out_act, acc[2]),
-				                (half_t)act_forward<GENERAL>(out_act, acc[3])};
+				const h4 o = act_forward4<GENERAL>(out_act, acc);
 				const size_t i = (size_t)tile * S + 16 * t + lr;
 				h4 gy;
 				if (la.external_dL_doutput) {
@@ -773,11 +762,9 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, WIDTH == 128 ? 1 : TCNN_MLP_T
 				}
 				if (output) *(h4*)(output + i * 16 + 4 * g) = o;
 				if (dL_doutput) *(h4*)(dL_doutput + i * 16 + 4 * g) = gy;  // the caller's context holds dL/doutput ...
+				gy = act_backward4<GENERAL>(out_act, f4{(float)gy[0], (float)gy[1], (float)gy[2], (float)gy[3]}, o);  // ... the backward pass continues from dL/d(pre-activation) (fully_fused_mlp.cu:760-763)
 #pragma unroll
-				for (uint32_t r = 0; r < 4; ++r) {  // ... the backward pass continues from dL/d(pre-activation) (fully_fused_mlp.cu:760-763)
-					gy[r] = (half_t)act_backward<GENERAL>(out_act, (float)gy[r], o[r]);
-					dyT[(4 * g + r) * SP + 16 * t + lr] = gy[r];
-				}
+				for (uint32_t r = 0; r < 4; ++r) dyT[(4 * g + r) * SP + 16 * t + lr] = gy[r];
 				*(h4*)(dys + (16 * t + lr) * LDY + 4 * g) = gy;
 			}
 			__syncthreads();
@@ -795,11 +782,9 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, WIDTH == 128 ? 1 : TCNN_MLP_T
 				const h4 a = *(const h4*)(dys + (16 * t + lr) * LDY + 4 * g);
 				const f4 acc = mfma_16x16x16(a, bw, zero4());
 				const h4 hv = *(const h4*)(hlast + (16 * w + lr) * SP + 16 * t + 4 * g);
+				da[t] = act_backward4<GENERAL>(act, acc, hv);
 #pragma unroll
-				for (uint32_t r = 0; r < 4; ++r) {
-					da[t][r] = (half_t)act_backward<GENERAL>(act, acc[r], hv[r]);
-					dact0[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
-				}
+				for (uint32_t r = 0; r < 4; ++r) dact0[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
 			}
 			if (want_grads) {
 #pragma unroll
@@ -854,11 +839,9 @@ __global__ void __launch_bounds__(WIDTH / 16 * 64, WIDTH == 128 ? 1 : TCNN_MLP_T
 #pragma unroll
 			for (uint32_t t = 0; t < NT; ++t) {
 				const h4 hv = *(const h4*)(hj + (16 * w + lr) * SP + 16 * t + 4 * g);
+				da[t] = act_backward4<GENERAL>(act, acc[t], hv);
 #pragma unroll
-				for (uint32_t r = 0; r < 4; ++r) {
-					da[t][r] = (half_t)act_backward<GENERAL>(act, acc[t][r], hv[r]);
-					nxt[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
-				}
+				for (uint32_t r = 0; r < 4; ++r) nxt[(16 * t + 4 * g + r) * LDW + 16 * w + lr] = da[t][r];
 			}
 			__syncthreads();
 			half_t* tmp = cur;
@@ -962,7 +945,11 @@ __global__ void __launch_bounds__(256) k_mlp_output_activation_backward(uint32_t
 	const h8 o = *(const h8*)(output + (size_t)i * 8), d = *(const h8*)(dL_doutput + (size_t)i * 8);
 	h8 r;
 #pragma unroll
-	for (uint32_t j = 0; j < 8; ++j) r[j] = (half_t)act_backward<true>(act, (float)d[j], o[j]);
+	for (uint32_t q = 0; q < 2; ++q) {
+		const h4 v = act_backward4<true>(act, f4{(float)d[4 * q], (float)d[4 * q + 1], (float)d[4 * q + 2], (float)d[4 * q + 3]}, h4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]});
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j) r[4 * q + j] = v[j];
+	}
 	*(h8*)(dL_dpreact + (size_t)i * 8) = r;
 }
 

@@ -136,9 +136,7 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 			}
 #pragma unroll
 			for (uint32_t t = 0; t < NT; ++t) {
-				h4 o;
-#pragma unroll
-				for (uint32_t r = 0; r < 4; ++r) o[r] = (half_t)act_forward<GENERAL>(act, acc[t][r]);
+				const h4 o = act_forward4<GENERAL>(act, acc[t]);
 				*(h4*)(hT + (16 * t + lr) * LDA + 16 * w + 4 * g) = o;  // (neurons 16w+4g.., sample 16t+lr)
 			}
 		}
@@ -157,9 +155,7 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 			half_t* nxt = hT + l * S * LDA;
 #pragma unroll
 			for (uint32_t t = 0; t < NT; ++t) {
-				h4 o;
-#pragma unroll
-				for (uint32_t r = 0; r < 4; ++r) o[r] = (half_t)act_forward<GENERAL>(act, acc[t][r]);
+				const h4 o = act_forward4<GENERAL>(act, acc[t]);
 				*(h4*)(nxt + (16 * t + lr) * LDA + 16 * w + 4 * g) = o;
 			}
 			__syncthreads();
@@ -170,8 +166,7 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 			f4 acc = zero4();
 #pragma unroll
 			for (uint32_t kb = 0; kb < KB; ++kb) acc = mfma_16x16x32(wof[kb], *(const h8*)(hlast + (16 * t + lr) * LDA + 32 * kb + 8 * g), acc);
-			const h4 o = h4{(half_t)act_forward<GENERAL>(out_act, acc[0]), (half_t)act_forward<GENERAL>(out_act, acc[1]), (half_t)act_forward<GENERAL>(out_act, acc[2]),
-			                (half_t)act_forward<GENERAL>(out_act, acc[3])};
+			const h4 o = act_forward4<GENERAL>(out_act, acc);
 			const size_t i = (size_t)tile * S + 16 * t + lr;
 			h4 gy;
 			if (la.external_dL_doutput) {
@@ -190,8 +185,7 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 			}
 			if (output) *(h4*)(output + i * 16 + 4 * g) = o;
 			if (dL_doutput) *(h4*)(dL_doutput + i * 16 + 4 * g) = gy;
-#pragma unroll
-			for (uint32_t r = 0; r < 4; ++r) gy[r] = (half_t)act_backward<GENERAL>(out_act, (float)gy[r], o[r]);  // fully_fused_mlp.cu:760-763
+			gy = act_backward4<GENERAL>(out_act, f4{(float)gy[0], (float)gy[1], (float)gy[2], (float)gy[3]}, o);  // fully_fused_mlp.cu:760-763
 			*(h4*)(dys + (16 * t + lr) * LDY + 4 * g) = gy;
 		}
 		__syncthreads();
@@ -202,11 +196,9 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 		for (uint32_t t = 0; t < NT; ++t) {
 			const f4 acc = mfma_16x16x16(*(const h4*)(dys + (16 * t + lr) * LDY + 4 * g), wob, zero4());
 			const h4 hv = tr4(hlast, 16 * t + 4 * g, 16 * w, LDA, lane);
+			da[t] = act_backward4<GENERAL>(act, acc, hv);
 #pragma unroll
-			for (uint32_t r = 0; r < 4; ++r) {
-				da[t][r] = (half_t)act_backward<GENERAL>(act, acc[r], hv[r]);
-				d0[(16 * t + 4 * g + r) * LDA + 16 * w + lr] = da[t][r];
-			}
+			for (uint32_t r = 0; r < 4; ++r) d0[(16 * t + 4 * g + r) * LDA + 16 * w + lr] = da[t][r];
 		}
 		if (want_grads)  // dW_out^T[neuron][o] += sum_s A_last[neuron][s] dY[o][s]; both operands transposed out of sample-major tiles
 			accO = mfma_16x16x32(tr8(hlast, 8 * g, 16 * w, LDA, lane), tr8(dys, 8 * g, 0, LDY, lane), accO);
@@ -235,11 +227,9 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 #pragma unroll
 			for (uint32_t t = 0; t < NT; ++t) {
 				const h4 hv = tr4(hj, 16 * t + 4 * g, 16 * w, LDA, lane);
+				da[t] = act_backward4<GENERAL>(act, acc[t], hv);
 #pragma unroll
-				for (uint32_t r = 0; r < 4; ++r) {
-					da[t][r] = (half_t)act_backward<GENERAL>(act, acc[t][r], hv[r]);
-					nxt[(16 * t + 4 * g + r) * LDA + 16 * w + lr] = da[t][r];
-				}
+				for (uint32_t r = 0; r < 4; ++r) nxt[(16 * t + 4 * g + r) * LDA + 16 * w + lr] = da[t][r];
 			}
 			__syncthreads();
 			half_t* tmp = cur;

@@ -971,7 +971,10 @@ def test_owner_pass_hand_pipelined_stream_at_every_queue_length(log2_t, scale):
                 else:  # several owners per slice (sample chunks of a small table): their exact sums meet in fp16 atomics, one rounding per owner
                     a, b = O.h2f(out[0][lo:hi]).astype(np.float64), O.h2f(out[1][lo:hi]).astype(np.float64)
                     assert np.all(np.abs(a - b) <= absacc[lo:hi] * 2.0 ** -8 + 1e-3), (n, l)
-            assert n_exact >= 10, (n, n_exact)
+            # (a small table at a large batch splits the SAMPLES of a slice over several owners -- per-bucket records beyond 65536 -- and no level is
+            # exact then; the sole-owner regime is what the other cases pin bit for bit)
+            if log2_t == 19 or n <= (1 << 14):
+                assert n_exact >= 10, (n, n_exact)
             got = O.h2f(out[0]).astype(np.float64)
             assert np.all(np.abs(got - ref) <= absacc * 2.0 ** -8 + 1e-3), n
     finally:

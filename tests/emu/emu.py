@@ -151,11 +151,6 @@ def set_grid_forward_lds(limit_bytes, min_samples):
     lib().emu_set_grid_forward_lds(C.c_uint32(limit_bytes), C.c_uint32(min_samples))
 
 
-def set_grid_forward_tail_tiles(tiles):
-    """Tiles at the end of every XCD's run that the tiled gather processes as two workgroups of one sample per thread (-1: default, 0: none)."""
-    lib().emu_set_grid_forward_tail_tiles(C.c_int(tiles))
-
-
 SLICED_F32, SLICED_F16, ATOMIC, BUCKETED = 0, 1, 2, 3
 
 

@@ -71,7 +71,6 @@ uint32_t emu_grid_forward_plan(const EmuGrid* e, uint32_t n, uint32_t tile_sampl
 }
 
 void emu_set_grid_owner_mode(int mode) { grid_owner_mode() = mode; }
-void emu_set_grid_forward_tail_tiles(int tiles) { grid_forward_tail_tiles() = tiles; }
 void emu_set_grid_forward_lds(uint32_t limit_bytes, uint32_t min_samples) {
 	grid_forward_lds_limit() = limit_bytes;
 	grid_forward_lds_min_samples() = min_samples;

@@ -58,31 +58,6 @@ def test_grid_forward_bit_exact(case):
         emu.set_grid_forward_lds(0, 4096)
 
 
-@pytest.mark.parametrize("case", [GRID_CASES[0], GRID_CASES[-1], GRID_CASES[-2]])
-def test_grid_forward_tail_workgroups_gather_the_same_bits(case):
-    """The tiled gather ends every XCD's run with workgroups of half the work -- the last tiles go to two workgroups of one sample per thread
-    each (ForwardPlan::n_full; the kernel's tail of half a workgroup life shrinks with the workgroups' lives).  Whatever the number of tail
-    tiles (none, one, a few, the default, all), and for a ragged batch whose last tile is mostly empty, every sample of every level is
-    gathered exactly once and to the same bits as the oracle's."""
-    D, L, F, T, base, scale, gtype, interp = case
-    rng = np.random.default_rng(11)
-    og = O.grid_init(D, L, F, T, base, scale, gtype, interp)
-    g = emu.Grid(og)
-    n = 512 * 9 + 300 + 7  # ten 512-sample tiles per level, the last one ragged in its first half... and not a multiple of anything
-    pos = rng.random((n, D), dtype=np.float32)
-    params = O.f2h((rng.random(og.n_params, dtype=np.float32) * 2 - 1) * 0.5)
-    ref = O.grid_forward(og, params, pos)
-    try:
-        for tail in (0, 1, 3, -1, 1000):
-            emu.set_grid_forward_tail_tiles(tail)
-            out = emu.grid_forward(g, params, pos, soa=True)
-            assert np.array_equal(out.T, ref), tail
-            out_aos = emu.grid_forward(g, params, pos, soa=False, out_stride=L * F + 8)
-            assert np.array_equal(out_aos[:, :L * F], ref), tail
-    finally:
-        emu.set_grid_forward_tail_tiles(-1)
-
-
 @pytest.mark.parametrize("case", GRID_CASES)
 def test_grid_fp32_kernels(case):
     """k_grid_forward_f32 / k_grid_backward_atomic_f32 / k_grid_backward_input<float> (Encoding<float>, cpp_api.cu:165-168) against the oracle's

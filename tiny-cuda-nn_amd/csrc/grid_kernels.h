@@ -55,9 +55,6 @@ void grid_forward(hipStream_t stream, const GridMeta& meta, const GridIO& io, co
 // least `grid_forward_lds_min_samples()` samples; same bits either way.
 uint32_t& grid_forward_lds_limit();
 uint32_t& grid_forward_lds_min_samples();
-// The tiled gather ends every XCD's run with workgroups of half the work (one sample per thread instead of two): tiles per XCD treated that
-// way; -1 = default (one resident generation), 0 = whole tiles throughout.  Same bits either way.  TCNN_GRID_FWD_TAIL_TILES.
-int& grid_forward_tail_tiles();
 
 // Backward into grid_gradient (half).  accumulate == false overwrites (GradientMode::Overwrite: any zeroing
 // the chosen mode needs is done here, the caller does not memset), true adds to what is there.

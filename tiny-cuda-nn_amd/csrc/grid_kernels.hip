@@ -321,10 +321,6 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward(const GridMeta me
 constexpr uint32_t FWD_MAX_SEGMENTS = 20;  // per XCD: ceil(MAX_N_LEVELS / 8) + the two cut levels at the ends of a run
 struct ForwardPlan {
 	uint32_t tiles;  // sample tiles per level
-	// The LAST `half` tiles of an XCD's run are processed by two workgroups each (one sample per thread instead of SPT): the kernel ends with
-	// a tail in which the workgroups that are left no longer fill the chip -- about half a workgroup life (round 4's clock stamps: 65 us of
-	// steady state + 10 us of tail on the headline) -- and workgroups with half the work have half the life.  n_full[x] = whole-tile slots of XCD x.
-	uint32_t n_full[8];
 	uint32_t n_segments[8];
 	struct Segment {
 		uint32_t level, tile_begin, tile_end;
@@ -370,12 +366,6 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward_tiles(const GridM
 	// block -> (segment of its XCD's run, tile): level-major, so an XCD walks one table at a time
 	const uint32_t xcd = blockIdx.x & 7u;
 	uint32_t slot = blockIdx.x >> 3, level = 0, tile = 0;
-	uint32_t half = SPT;  // SPT: the whole tile; s < SPT: only the tile's samples s * GRID_THREADS + thread (a tail workgroup)
-	if (SPT > 1 && slot >= plan.n_full[xcd]) {
-		const uint32_t q = slot - plan.n_full[xcd];
-		slot = plan.n_full[xcd] + q / SPT;
-		half = q % SPT;
-	}
 	bool found = false;
 	for (uint32_t k = 0; k < plan.n_segments[xcd]; ++k) {
 		const ForwardPlan::Segment seg = plan.segments[xcd][k];
@@ -395,6 +385,9 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward_tiles(const GridM
 	}
 	if (!found) return;
 	const uint32_t first = tile * TILE;
+	float x[SPT][D];
+#pragma unroll
+	for (uint32_t s = 0; s < SPT; ++s) load_position<D, true>(io, min(first + s * GRID_THREADS + threadIdx.x, io.n - 1u), x[s]);
 	const Level<D> lv = make_level<D>(meta, level);
 	const half_t* __restrict__ grid = params + (size_t)meta.offset[level] * F;
 	const uint32_t n_features = meta.n_levels * F;
@@ -402,25 +395,10 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward_tiles(const GridM
 	const bool level_off = (float)level >= max_level + 1e-3f;               // grid.h:75
 	if (level_off || lv.nearest) {  // rare forms: one sample at a time
 		for (uint32_t s = 0; s < SPT; ++s) {
-			if (half != SPT && s != half) continue;
 			const uint32_t i = first + s * GRID_THREADS + threadIdx.x;
 			if (i < io.n) grid_forward_sample<D, F, false, false>(lv, io, grid, level, i, level_off, out, nullptr);
 		}
-		return;
-	}
-	if (SPT > 1 && half != SPT) {  // a tail workgroup: one sample per thread, the same arithmetic on the same samples
-		const uint32_t first1 = first + half * GRID_THREADS;
-		if (first1 >= io.n) return;
-		float x1[1][D];
-		load_position<D, true>(io, min(first1 + threadIdx.x, io.n - 1u), x1[0]);
-		if (lv.fast) grid_forward_tile<D, F, 1, true>(lv, io, grid, level, first1, x1, out);
-		else grid_forward_tile<D, F, 1, false>(lv, io, grid, level, first1, x1, out);
-		return;
-	}
-	float x[SPT][D];
-#pragma unroll
-	for (uint32_t s = 0; s < SPT; ++s) load_position<D, true>(io, min(first + s * GRID_THREADS + threadIdx.x, io.n - 1u), x[s]);
-	if (lv.fast) {  // wave-uniform: one lean code path per level kind
+	} else if (lv.fast) {  // wave-uniform: one lean code path per level kind
 		grid_forward_tile<D, F, SPT, true>(lv, io, grid, level, first, x, out);
 	} else {
 		grid_forward_tile<D, F, SPT, false>(lv, io, grid, level, first, x, out);
@@ -2019,12 +1997,6 @@ uint32_t& grid_forward_lds_limit() {
 	static uint32_t limit = getenv("TCNN_GRID_FWD_LDS_BYTES") ? (uint32_t)atoi(getenv("TCNN_GRID_FWD_LDS_BYTES")) : 0u;
 	return limit;
 }
-// tiles at the end of every XCD's run that the tiled gather processes with one sample per thread (ForwardPlan::n_full); -1 = the default
-// (one resident generation), 0 = whole tiles throughout.  TCNN_GRID_FWD_TAIL_TILES sets the initial value.
-int& grid_forward_tail_tiles() {
-	static int tiles = getenv("TCNN_GRID_FWD_TAIL_TILES") ? atoi(getenv("TCNN_GRID_FWD_TAIL_TILES")) : -1;
-	return tiles;
-}
 // batch sizes below this stay in the tiled kernel altogether (a table copy per workgroup needs samples to pay for it)
 uint32_t& grid_forward_lds_min_samples() {
 	static uint32_t n = 4096u;
@@ -2058,18 +2030,12 @@ static void launch_forward_tiles(hipStream_t stream, const GridMeta& meta, const
 		TCNN_LAUNCH((k_grid_forward_lds<D, F>), dim3(div_round_up(io.n, per_block)), dim3(FWD_LDS_THREADS), table_bytes, lds_stream, meta, io, l, per_block, params, out);
 	}
 	if (!any_left) return;
-	ForwardPlan plan = make_forward_plan(meta, io.n, GRID_THREADS * SPT, in_lds);
-	// the last tiles of every XCD's run as SPT workgroups of one sample per thread each (ForwardPlan::n_full).  TCNN_GRID_FWD_TAIL_TILES tiles per XCD
-	// (default: one resident generation -- 32 CUs x 8 workgroups of 256 threads -- divided by SPT; 0 = whole tiles throughout)
-	const int tail_set = grid_forward_tail_tiles();
-	const uint32_t tail_tiles = SPT > 1 ? (tail_set >= 0 ? (uint32_t)tail_set : 256u / SPT) : 0u;
+	const ForwardPlan plan = make_forward_plan(meta, io.n, GRID_THREADS * SPT, in_lds);
 	uint32_t slots = 0;
 	for (uint32_t x = 0; x < 8; ++x) {
 		uint32_t n = 0;
 		for (uint32_t k = 0; k < plan.n_segments[x]; ++k) n += plan.segments[x][k].tile_end - plan.segments[x][k].tile_begin;
-		const uint32_t tail = std::min(n, tail_tiles);
-		plan.n_full[x] = n - tail;
-		slots = std::max(slots, plan.n_full[x] + SPT * tail);
+		slots = std::max(slots, n);
 	}
 	TCNN_LAUNCH((k_grid_forward_tiles<D, F, SPT>), dim3(8u * slots), dim3(GRID_THREADS), 0, stream, meta, io, plan, params, out);
 }

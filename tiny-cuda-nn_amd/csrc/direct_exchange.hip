@@ -18,6 +18,50 @@ struct PeerSignals {
 };
 constexpr uint32_t DX_THREADS = 256;
 
+// Accesses to a PEER's memory carry system scope (sc0 sc1 on gfx950): a load is served by the memory it names, not by a line this GPU's
+// L2s kept from the step before, and a store is written through to the peer instead of resting in an L2 here.  The trainer buffers are
+// ordinary (coarse-grained) hipMalloc memory, for which the caches are only reconciled at kernel boundaries -- and which of the eight
+// XCD-private L2s a boundary's fences reach is the runtime's business; with the scope on the instruction itself the data path does not
+// depend on it (the signal words' release / acquire order the accesses, the self-test checks the whole arrangement on the node).
+// 8-byte relaxed atomics: what the scope builtins offer; a lane's 16 bytes are two of them.
+TCNN_DEVICE h8 peer_load16(const half_t* p) {
+#if defined(TCNN_HOST_EMU)
+	return *(const h8*)p;
+#else
+	const unsigned long long* q = (const unsigned long long*)p;
+	const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+	return __builtin_bit_cast(h8, (ull2){lo, hi});
+#endif
+}
+TCNN_DEVICE void peer_store16(half_t* p, h8 v) {
+#if defined(TCNN_HOST_EMU)
+	*(h8*)p = v;
+#else
+	typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+	const ull2 w = __builtin_bit_cast(ull2, v);
+	unsigned long long* q = (unsigned long long*)p;
+	__hip_atomic_store(q, w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	__hip_atomic_store(q + 1, w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+TCNN_DEVICE half_t peer_load2(const half_t* p) {
+#if defined(TCNN_HOST_EMU)
+	return *p;
+#else
+	const unsigned short w = __hip_atomic_load((const unsigned short*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	return __builtin_bit_cast(half_t, w);
+#endif
+}
+TCNN_DEVICE void peer_store2(half_t* p, half_t v) {
+#if defined(TCNN_HOST_EMU)
+	*p = v;
+#else
+	__hip_atomic_store((unsigned short*)p, __builtin_bit_cast(unsigned short, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+
 // "step s of rank `me`, phase `row`, is done": one 4-byte store into every rank's signal block (the own one included), released at
 // system scope -- everything this rank's earlier kernels on the stream wrote is visible to whoever then reads the counter.
 __global__ void k_direct_signal(const PeerSignals peers, const int n_ranks, const int me, const int row, const uint32_t step) {
@@ -48,7 +92,7 @@ __global__ void __launch_bounds__(DX_THREADS) k_direct_reduce(const PeerBuffers 
 		h8 v[DIRECT_MAX_RANKS];  // (fully unrolled: registers; every rank's load is issued before the first sum)
 #pragma unroll
 		for (int r = 0; r < DIRECT_MAX_RANKS; ++r) {
-			if (r < n_ranks) v[r] = *(const h8*)(grads.p[r] + begin + 8 * i);
+			if (r < n_ranks) v[r] = r == me ? *(const h8*)(grads.p[r] + begin + 8 * i) : peer_load16(grads.p[r] + begin + 8 * i);
 		}
 #pragma unroll
 		for (int r = 0; r < DIRECT_MAX_RANKS; ++r) {
@@ -67,7 +111,7 @@ __global__ void __launch_bounds__(DX_THREADS) k_direct_reduce(const PeerBuffers 
 	if (blockIdx.x == 0) {
 		for (size_t e = n8 * 8 + threadIdx.x; e < count; e += DX_THREADS) {
 			float acc = 0.0f;
-			for (int r = 0; r < n_ranks; ++r) acc = acc + (float)grads.p[r][begin + e];
+			for (int r = 0; r < n_ranks; ++r) acc = acc + (float)(r == me ? grads.p[r][begin + e] : peer_load2(grads.p[r] + begin + e));
 			grads.p[me][begin + e] = to_half_rn(acc);
 		}
 	}
@@ -78,14 +122,14 @@ __global__ void __launch_bounds__(DX_THREADS) k_direct_push(const PeerBuffers pa
 	for (size_t i = (size_t)blockIdx.x * DX_THREADS + threadIdx.x; i < n8; i += (size_t)gridDim.x * DX_THREADS) {
 		const h8 v = *(const h8*)(params.p[me] + begin + 8 * i);
 		for (int r = 0; r < n_ranks; ++r) {
-			if (r != me) *(h8*)(params.p[r] + begin + 8 * i) = v;
+			if (r != me) peer_store16(params.p[r] + begin + 8 * i, v);
 		}
 	}
 	if (blockIdx.x == 0) {
 		for (size_t e = n8 * 8 + threadIdx.x; e < count; e += DX_THREADS) {
 			const half_t v = params.p[me][begin + e];
 			for (int r = 0; r < n_ranks; ++r) {
-				if (r != me) params.p[r][begin + e] = v;
+				if (r != me) peer_store2(params.p[r] + begin + e, v);
 			}
 		}
 	}

@@ -429,6 +429,13 @@ def main():
         else:
             tm.training_step(x, t, want_context=False)
 
+    def replicas_identical(model):
+        """N > 1: do all ranks hold the same 16-bit parameters?  (a 64-bit sum of their bit patterns, min == max over the ranks)"""
+        if world == 1:
+            return True
+        h = float(model.params_view.view(torch.int16).to(torch.int64).sum().item() % (1 << 52))  # (exact in a double)
+        return par.all_reduce_max(h, device=device) == -par.all_reduce_max(-h, device=device)
+
     # ---- N > 1, --dp auto: which exchange?  Both candidates on throw-away models (same seed, same batches), a few steps each, timed the way the
     # measurement is (barrier + synchronize on both sides, max over ranks).  `direct` must first pass its link check on this node
     # (tcnn_trainer_direct_selftest inside DataParallel) and finish its trial without a timed-out wait; otherwise `sharded` runs.
@@ -453,10 +460,12 @@ def main():
             par.barrier()
             trial_s = par.all_reduce_max(time.perf_counter() - t0, device=device)
             bad = par.all_reduce_max(tm.direct_status() if candidate == "direct" else 0, device=device)
-            autotune["candidates"][candidate] = {"ms_per_step": trial_s / autotune["trial_steps"] * 1e3, **({"timed_out_wait": int(bad)} if bad else {})}
+            same = replicas_identical(tm)  # every rank must hold the same 16-bit parameters after the trial: an exchange that lets them drift is no candidate
+            autotune["candidates"][candidate] = {"ms_per_step": trial_s / autotune["trial_steps"] * 1e3, **({"timed_out_wait": int(bad)} if bad else {}),
+                                                 **({} if same else {"replicas_diverged": True})}
             dp.close()
             tm = dp = None
-        usable = {k: v["ms_per_step"] for k, v in autotune["candidates"].items() if "ms_per_step" in v and not v.get("timed_out_wait")}
+        usable = {k: v["ms_per_step"] for k, v in autotune["candidates"].items() if "ms_per_step" in v and not v.get("timed_out_wait") and not v.get("replicas_diverged")}
         dp_mode = par.broadcast_object(min(usable, key=usable.get) if usable else "sharded")
         autotune["chosen"] = dp_mode
     tm, dp = make_model(dp_mode)
@@ -542,6 +551,9 @@ def main():
         comm_phases = {k: par.all_reduce_max(v, device=device) for k, v in sorted(comm_phases.items())}
     if dp is not None and dp_mode == "direct" and tm.direct_status() != 0:
         raise SystemExit(f"rank {rank}: a wait of the direct exchange timed out (phase {tm.direct_status()}): the measurement is void")
+    replicas_same = replicas_identical(tm) if dp is not None else None
+    if replicas_same is False:
+        raise SystemExit(f"rank {rank}: the replicas' parameters differ after the timed region ({dp_mode} exchange): the measurement is void")
 
     if regenerate and not args.resident_first:
         elapsed_resident = resident_region()
@@ -687,6 +699,8 @@ def main():
             line["torch_binding"] = torch_binding
         if autotune is not None:
             line["dp_autotune"] = autotune
+        if replicas_same is not None:
+            line["replicas_identical_after_timed_region"] = replicas_same
         if comm is not None:
             line["comm"] = {"seconds_per_step": comm / args.steps, "share_of_step": comm / elapsed, "phases_ms_per_step_max_over_ranks": comm_phases,
                             "note": "GPU event intervals of rank 0 around the exchange: the collectives AND, in the sharded scheme, the optimizer step on the rank's shard that sits between them"}

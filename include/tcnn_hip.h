@@ -159,6 +159,7 @@ size_t tcnn_trainer_n_params(const tcnn_trainable_model_t* tm);
  * weights (logging, checkpoints) uses tcnn_trainer_params_full_precision_view(): same memory, no change of mode. */
 float* tcnn_trainer_params_full_precision(tcnn_trainable_model_t* tm);
 const float* tcnn_trainer_params_full_precision_view(const tcnn_trainable_model_t* tm);
+const void* tcnn_trainer_params_view(const tcnn_trainable_model_t* tm);   /* the 16-bit parameters, to read: no change of mode either */
 void* tcnn_trainer_params(tcnn_trainable_model_t* tm);
 void* tcnn_trainer_params_inference(tcnn_trainable_model_t* tm);
 void* tcnn_trainer_param_gradients(tcnn_trainable_model_t* tm);

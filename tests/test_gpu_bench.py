@@ -113,6 +113,7 @@ def test_driver_multi_gpu_command_with_two_ranks_on_one_gpu(dp):
     assert d["config"]["batch_per_gpu"] == 1 << 18 and d["config"]["global_batch"] == 2 << 18 and dp in d["config"]["parallelism"]
     assert abs(d["value"] - (2 << 18) / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]  # whole-job samples/s
     assert "cpu_baseline" not in d and 0.0 < d["comm"]["share_of_step"] <= 1.0
+    assert d["replicas_identical_after_timed_region"] is True  # every rank holds the same 16-bit parameters (a drifting exchange voids the run)
     assert math.isfinite(d["final_loss"]) and d["final_loss"] < 5.0
 
 

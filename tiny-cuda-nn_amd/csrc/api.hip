@@ -2620,6 +2620,7 @@ float* tcnn_trainer_params_full_precision(tcnn_trainable_model_t* tm) {
 // read-only view of the same memory: the trainer's mode does not change (a logging / checkpointing host must not switch
 // Adam's "16-bit weights follow the master weights" shortcut off for good)
 const float* tcnn_trainer_params_full_precision_view(const tcnn_trainable_model_t* tm) { return tm->master; }
+const void* tcnn_trainer_params_view(const tcnn_trainable_model_t* tm) { return tm->params; }
 void* tcnn_trainer_params(tcnn_trainable_model_t* tm) {
 	tm->params_exposed = true;  // a mutable pointer leaves the library: assume the caller writes through it, now or later
 	return tm->params;

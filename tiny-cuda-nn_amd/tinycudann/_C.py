@@ -125,6 +125,7 @@ _sig("tcnn_network_inference", _i, _vp, _vp, _u32, _vp, _vp, _i)
 _sig("tcnn_trainer_n_params", _sz, _vp)
 _sig("tcnn_trainer_params_full_precision", _vp, _vp)
 _sig("tcnn_trainer_params_full_precision_view", _vp, _vp)
+_sig("tcnn_trainer_params_view", _vp, _vp)
 _sig("tcnn_trainer_params", _vp, _vp)
 _sig("tcnn_trainer_params_inference", _vp, _vp)
 _sig("tcnn_trainer_param_gradients", _vp, _vp)

@@ -201,6 +201,12 @@ class TrainableModel:
     def params(self):
         return self._tensor(_lib.tcnn_trainer_params(self._h), "<f2")
 
+    @property
+    def params_view(self):
+        """The 16-bit parameters, to READ (tcnn_trainer_params_view): unlike `params`, asking for it does not put the trainer into its
+        "a caller may write my parameters" mode."""
+        return self._tensor(_lib.tcnn_trainer_params_view(self._h), "<f2")
+
     def params_written(self):
         """Done writing through `params` / `params_inference`: the trainer rebuilds its transposed weight copy once and trusts it again."""
         _check(_lib.tcnn_trainer_params_written(self._h))

@@ -344,6 +344,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="hash")
+    ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU and step (default 2^18, the batch BASELINE.json's metric is quoted on; other sizes are "
+                                                               "exploration -- e.g. 65536, where the reference quotes its PyTorch binding at ~2x the native step -- and say so in `config`)")
     ap.add_argument("--precision", choices=["fp16", "bf16"], default="fp16", help="the library build: fp16 (libtcnn_hip.so) or bfloat16 (libtcnn_hip_bf16.so)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: 2^18 samples per GPU (weak) or 2^18 in total (strong)")
     ap.add_argument("--dp", choices=["auto", "sharded", "allreduce", "pipelined", "pipelined_sharded", "direct"], default="auto",
@@ -395,7 +397,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    local_batch = BATCH if args.scaling == "weak" else par.shard_rows(BATCH, rank, world)[1] - par.shard_rows(BATCH, rank, world)[0]
+    if args.batch <= 0 or args.batch % (256 * world) != 0:
+        raise SystemExit(f"--batch must be a positive multiple of 256 x the number of ranks (got {args.batch})")
+    local_batch = args.batch if args.scaling == "weak" else par.shard_rows(args.batch, rank, world)[1] - par.shard_rows(args.batch, rank, world)[0]
     global_batch = int(par.all_reduce_sum(local_batch, device=device)) if world > 1 else local_batch
 
     def make_model(dp_mode):
@@ -665,7 +669,8 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": ("bf16 (bfloat16" if args.precision == "bf16" else "f16 (fp16") + " params/activations/gradients, fp32 MFMA accumulate, fp32 Adam state)", "data": "synthetic",
-            "config": {"workload": w["describe"], "batch_per_gpu": local_batch, "global_batch": global_batch, "n_params": tm.n_params,
+            "config": {"workload": w["describe"] + ("" if args.batch == BATCH else f" -- at a NON-DEFAULT batch of {args.batch} (exploration; the metric's batch is 2^18)"),
+                       "batch_per_gpu": local_batch, "global_batch": global_batch, "n_params": tm.n_params,
                        "parallelism": f"dp{world} ({dp_mode})" if world > 1 else "single"},
             "roofline": roofline,
             "protocol": {"batches": ("regenerated inside every timed step: positions drawn with the library's pcg32 kernel, targets evaluated at them on the device, then "

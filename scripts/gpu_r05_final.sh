@@ -16,6 +16,7 @@ for W in mlp stress hash_shipped; do
 done
 timeout 300 python bench.py --workload stress --precision bf16 --steps 200 --warmup 30 --no-cpu-baseline > $OUT/bench_stress_bf16.json 2>> $OUT/bench.err
 timeout 300 python bench.py --precision bf16 --steps 200 --warmup 30 --no-cpu-baseline > $OUT/bench_hash_bf16.json 2>> $OUT/bench.err
+for B in 65536 16384; do timeout 200 python bench.py --batch $B --steps 500 --warmup 50 --no-cpu-baseline > $OUT/bench_batch_$B.json 2>> $OUT/bench.err; python3 -c "import json; d=json.load(open('$OUT/bench_batch_$B.json')); print('batch $B: native', round(d['ms_per_step'],4), 'ms; torch binding', round(d['torch_binding']['ms_per_step'],4), 'ratio', round(d['torch_binding']['ratio_to_native_step'],2), 'fused adam', d['torch_binding'].get('with_fused_adam',{}).get('ratio_to_native_step'))"; done
 timeout 300 python scripts/exp_spilling_instances.py > $OUT/spilling_instances.txt 2>&1; cat $OUT/spilling_instances.txt | cut -c1-200
 bash scripts/soak_first_steps.sh ${SOAK_N:-15} $OUT/soak_first_steps.txt
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" $OUT/pytest.log | tail -2; grep -E "^FAILED|^ERROR" $OUT/pytest.log | head

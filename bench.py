@@ -371,7 +371,7 @@ def main():
                                                                    "is a property of their order on this device, see DESIGN.md section 3)")
     ap.add_argument("--lds-budget", type=int, default=None, help="grid backward: LDS bytes per level table (tuning knob)")
     args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.worker:
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.worker:  # no launcher around this command (or a stale WORLD_SIZE=1)
         return launch_ranks(sys.argv[1:], args.gpus)
     if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.worker:
         return supervise(sys.argv[1:])

@@ -40,6 +40,9 @@ def free_temporary_memory():
     _C.free_temporary_memory()
 
 
+_BATCH_GRANULARITY = int(_C.batch_size_granularity())  # (a constant of the library: 256)
+
+
 class _NativeFunction(torch.autograd.Function):
     """forward/backward through the native module; `params` arrive already in native precision."""
 
@@ -130,17 +133,15 @@ class Module(torch.nn.Module):
             warnings.warn("input must be a GPU tensor, but isn't. This indicates suboptimal performance.")
             x = x.cuda()
         batch_size = x.shape[0]
-        g = int(_C.batch_size_granularity())
+        g = _BATCH_GRANULARITY
         padded = (batch_size + g - 1) // g * g
         if padded != batch_size:
             x = torch.nn.functional.pad(x, [0, 0, 0, padded - batch_size])
-        y = _NativeFunction.apply(
-            self.native_tcnn_module,
-            x.to(torch.float).contiguous(),
-            self.params.to(_torch_precision(self.native_tcnn_module.param_precision())).contiguous(),
-            self.loss_scale,
-        )
-        return y[:batch_size, : self.n_output_dims]
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.to(torch.float).contiguous()
+        y = _NativeFunction.apply(self.native_tcnn_module, x, self.params.to(self.dtype).contiguous(), self.loss_scale)
+        # (one slicing node in the graph where the batch needed no padding: the common case at training batch sizes)
+        return y[:, : self.n_output_dims] if padded == batch_size else y[:batch_size, : self.n_output_dims]
 
     def __getstate__(self):
         state = self.__dict__.copy()

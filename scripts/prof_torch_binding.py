@@ -8,10 +8,10 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tiny-cuda-nn_amd"))
+sys.path.insert(0, os.environ.get("TCNN_PKG_DIR") or os.path.join(ROOT, "tiny-cuda-nn_amd"))  # (TCNN_PKG_DIR: A/B against another copy of the Python package)
 import torch  # noqa: E402
+import tinycudann as tcnn  # noqa: E402  (before bench: bench.py puts the in-tree package first on sys.path)
 import bench  # noqa: E402
-import tinycudann as tcnn  # noqa: E402
 
 w = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "hash"]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200

@@ -336,6 +336,10 @@ int tcnn_trainer_set_fused_optimizer(tcnn_trainable_model_t* tm, int enable);
  * consumed under the same setting. */
 int tcnn_get_fused_network_passes(void);
 int tcnn_set_fused_network_passes(int enable);
+/* training_step with an Identity encoding that pads nothing (n_input_dims a multiple of 16; identity.h:46-66): the network kernel reads the
+ * caller's fp32 matrix itself where an instance offers it (64 inputs, 64 neurons, two hidden layers: the benchmarks/mlp shape) instead of
+ * running the encoding as a kernel of its own; same bits.  Process-wide, default on; 0 restores the separate kernel (A/B runs). */
+int tcnn_set_fused_identity_input(int enable);
 /* Tuning knob: bytes of LDS one grid-backward workgroup uses for the table slice it owns (default 64 KiB). */
 int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes);
 /* Grid backward formulation, process-wide: 0 = owner-computes LDS slices with fp32 accumulation on hashed levels,

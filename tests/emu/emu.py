@@ -266,6 +266,27 @@ def mlp_train(om, params_h, input_soa_h, loss_type, target, dims, loss_scale=128
     return out, dy, dinput, grads, float(s[0])
 
 
+def mlp_train_f32_input(om, params_h, x, scale, offset, loss_type, target, dims, loss_scale=128.0, data_pdf=None, n_total=None, want_dinput=True, want_enc=True):
+    """mlp_train with the network kernel loading the fp32 sample-major input of an unpadded Identity encoding itself (MlpF32Input).
+    Returns (output, dL_doutput, dL_dinput, grads, loss_sum, enc_out) or None where no instance offers it."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n = x.shape[0]
+    out = np.zeros((n, om.padded_out), dtype=np.uint16)
+    dy = np.zeros((n, om.padded_out), dtype=np.uint16)
+    dinput = np.zeros((om.in_width, n), dtype=np.uint16) if want_dinput else None
+    enc = np.full((om.in_width, n), 0x7E00, dtype=np.uint16) if want_enc else None
+    grads = np.full(om.n_params, 0x3C00, dtype=np.uint16)
+    s = np.zeros(1, dtype=np.float32)
+    m = mlp_meta(om)
+    r = lib().emu_mlp_train_f32_input(C.byref(m), C.c_uint32(n), _p(params_h), _p(x), C.c_float(scale), C.c_float(offset), C.c_int(loss_type),
+                                      _p(np.ascontiguousarray(target, dtype=np.float32)), _p(data_pdf), C.c_uint32(dims), C.c_float(loss_scale),
+                                      C.c_uint32(n_total if n_total is not None else n * dims), _p(out), _p(dy), _p(dinput), _p(grads), _p(s), _p(enc))
+    if r == 2:
+        return None
+    assert r == 0
+    return out, dy, dinput, grads, float(s[0]), enc
+
+
 def loss(loss_type, prediction_h, target, dims, loss_scale=128.0, data_pdf=None, n_total=None):
     prediction_h = np.ascontiguousarray(prediction_h, dtype=np.uint16)
     n, stride = prediction_h.shape

@@ -242,6 +242,35 @@ int emu_mlp_train(const EmuMlp* e, uint32_t n, const uint16_t* params, const uin
 	return 0;
 }
 
+// the same with the network kernel loading an unpadded Identity encoding's fp32 input itself (MlpF32Input); 2: no instance offers it.
+// enc_out [in_width][n] receives the encoded input the kernel leaves behind.
+int emu_mlp_train_f32_input(const EmuMlp* e, uint32_t n, const uint16_t* params, const float* x, float scale, float offset, int loss_type, const float* target,
+                            const float* data_pdf, uint32_t dims, float loss_scale, uint32_t n_total, uint16_t* output, uint16_t* dL_doutput,
+                            uint16_t* dL_dinput_soa, uint16_t* grads, float* loss_sum, uint16_t* enc_out) {
+	try {
+		const MlpMeta m = make_mlp(e);
+		if (!mlp_train_supported(m) || !mlp_train_f32_input_supported(m, n, (LossType)loss_type)) return 2;
+		std::vector<uint16_t> params_t(m.n_params());
+		mlp_transpose_weights(nullptr, m, (const half_t*)params, (half_t*)params_t.data());
+		const uint32_t np = mlp_train_n_partials(m, n, (LossType)loss_type);
+		std::vector<float> partials(grads ? (size_t)np * m.n_params() : 0, -12345.0f), block_sums(np, -777.0f), ws(1024);
+		MlpLossArgs la = {(LossType)loss_type, target, data_pdf, dims, loss_scale, n_total};
+		MlpF32Input fin;
+		fin.x = x;
+		fin.scale = scale;
+		fin.offset = offset;
+		fin.enc_out = (half_t*)enc_out;
+		const SlabOrder order = mlp_train(nullptr, m, n, (const half_t*)params, (const half_t*)params_t.data(), nullptr, la, (half_t*)output, (half_t*)dL_doutput,
+		                                  (half_t*)dL_dinput_soa, grads ? partials.data() : nullptr, block_sums.data(), &fin);
+		if (grads) mlp_finalize_gradients(nullptr, m, np, partials.data(), (half_t*)grads, false, order);
+		if (loss_sum) reduce_sum(nullptr, block_sums.data(), block_sums.size(), ws.data(), loss_sum);
+	} catch (const std::exception& ex) {
+		fprintf(stderr, "emu_mlp_train_f32_input: %s\n", ex.what());
+		return 1;
+	}
+	return 0;
+}
+
 int emu_loss(int type, uint32_t n, uint32_t stride, uint32_t dims, float loss_scale, const uint16_t* prediction, const float* target,
              const float* data_pdf, float* values, uint16_t* gradients, float* loss_sum, uint32_t n_total) {
 	std::vector<float> block_sums(loss_n_blocks(n, stride));

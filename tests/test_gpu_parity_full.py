@@ -428,3 +428,50 @@ def test_backward_and_optimizer_pipelined_over_three_streams_equal_the_one_strea
     assert np.allclose(la, lb, rtol=2e-2) and la[-1] < la[0]
     # inference right behind a pipelined step (same stream: it must wait for the adam lane)
     assert torch.isfinite(a.inference(x)).all()
+
+
+@pytest.mark.parametrize("scale,offset,loss", [(1.0, 0.0, "L2"), (0.5, 0.25, "RelativeL2")])
+def test_network_kernel_reading_the_fp32_input_of_an_identity_encoding_itself(scale, offset, loss):
+    """BASELINE configs[1] (64 inputs -> 64 x 2 -> 16, Identity encoding): training_step lets the register-resident network kernel load the
+    caller's fp32 matrix itself (MlpF32Input, tcnn_set_fused_identity_input) instead of running the encoding as a transpose kernel in front of
+    it.  Prediction, loss, gradients, parameters and optimizer state after several steps must equal the two-kernel path's BIT FOR BIT, the
+    returned context must still carry what `loss()` and a later `backward()` need, and the kernel that ran must be the fused one (no encoding
+    stage in the profile)."""
+    T = tcnn()
+    C = T._C
+    cfg = {"loss": {"otype": loss}, "optimizer": {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6},
+           "encoding": {"otype": "Identity", "scale": scale, "offset": offset},
+           "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2}}
+    n = (1 << 16) + 256
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand((n, 64), generator=g) * 2 - 1).cuda()
+    t = torch.rand((n, 16), generator=g).cuda()
+    results = {}
+    try:
+        for fused in (True, False):
+            C.set_fused_identity_input(fused)
+            tm = T.create_from_config(64, 16, cfg, seed=9)
+            tm.set_profiling(True)
+            losses = []
+            for _ in range(4):
+                ctx = tm.training_step(x, t)
+                losses.append(tm.loss(ctx))
+            stages = {k for k, (ms, c) in tm.stage_times().items() if c}
+            tm.set_profiling(False)
+            ctx = tm.training_step(x, t, run_optimizer=False)
+            pred = ctx.output.clone()
+            grads_step = tm.param_gradients.clone()
+            tm.backward(ctx, x)  # the context's encoded input, whoever wrote it, feeds the recomputing backward pass
+            torch.cuda.synchronize()
+            m1, m2, steps, _ = tm.optimizer_state()
+            results[fused] = (losses, pred, grads_step, tm.param_gradients.clone(), tm.params_full_precision.clone(), m1.clone(), m2.clone(), steps.clone(), stages)
+    finally:
+        C.set_fused_identity_input(True)
+    a, b = results[True], results[False]
+    assert a[0] == b[0] and a[0][-1] < a[0][0]
+    for u, v in zip(a[1:8], b[1:8]):
+        assert torch.equal(u.view(torch.int16) if u.dtype == torch.half else u, v.view(torch.int16) if v.dtype == torch.half else v)
+    # (a[3] == b[3] above: backward(ctx) recomputes from the context's encoded input, which the network kernel left behind in one case and the
+    # encoding kernel wrote in the other)
+    assert float((a[2].float() - a[3].float()).abs().max()) <= 2.0 ** -9 * float(a[2].float().abs().max())  # and reproduces the step's gradients
+    assert "grid_forward" in b[8] and "grid_forward" not in a[8] and "mlp_train_fused" in a[8]  # (the encoding stage is named after its first user)

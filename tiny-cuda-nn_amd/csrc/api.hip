@@ -675,6 +675,9 @@ static void encoding_forward(hipStream_t stream, const Model& md, uint32_t n, co
 //     kernel with the caller's dL/doutput in place of the loss -- it RECOMPUTES the hidden activations (three small matrix products)
 //     instead of reading back what the forward pass would have had to write (2 B x width x layers per sample each way).
 // Off: k_mlp_forward (saves the activations) -> k_loss -> k_mlp_backward.  Same results either way (tests/test_emu_kernels.py).
+// training_step: an unpadded Identity encoding is evaluated by the network kernel's own input loads (MlpF32Input) where an instance offers it;
+// TCNN_MLP_F32_INPUT=0 / tcnn_set_fused_identity_input(0): always the separate encoding kernel (A/B runs, tests)
+static std::atomic<int> g_fused_identity_input{1};
 static std::atomic<int> g_fused_network_passes{!(getenv("TCNN_FUSED_MLP_TRAINING") && std::string(getenv("TCNN_FUSED_MLP_TRAINING")) == "0") ? 1 : 0};
 static bool backward_recomputes(const Model& md) { return g_fused_network_passes.load() != 0 && md.has_network && mlp_train_supported(md.net.mlp); }
 
@@ -2328,7 +2331,12 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 		dy_dx = fc.dy_dx.as<float>();
 	}
 	fc.enc = Scratch(stream, (size_t)e.padded_output_width * n * sizeof(half_t));
-	encoding_forward(stream, md, n, input, params + md.n_mlp_params(), fc.enc.as<half_t>(), /*soa=*/true, dy_dx);
+	// An Identity encoding that pads nothing is `(T)(x * scale + offset)` per element: the register-resident network kernel reads the caller's
+	// fp32 matrix itself (MlpF32Input) and leaves the encoded matrix behind for the context -- no transpose kernel, no second pass over the input
+	const bool plain_identity = !e.is_grid && !e.is_frequency && !e.is_oneblob && e.n_dims == e.padded_output_width && in_stride_i(md) == e.n_dims && in_stride_d() == 1u;
+	const bool input_by_network = plain_identity && !external_dL_dy && g_fused_identity_input.load() != 0 && n <= (1u << 25) &&
+	                              mlp_train_f32_input_supported(md.net.mlp, n, tm->loss);
+	if (!input_by_network) encoding_forward(stream, md, n, input, params + md.n_mlp_params(), fc.enc.as<half_t>(), /*soa=*/true, dy_dx);
 
 	const bool need_denc = (want_grads && e.n_params > 0) || dL_dinput;
 	Scratch denc;
@@ -2351,9 +2359,15 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 			c->n_block_sums = n_partials;
 			c->block_sums = Scratch(stream, (size_t)n_partials * sizeof(float));
 		}
+		MlpF32Input f32_input;
+		f32_input.x = input;
+		f32_input.scale = e.id_scale;
+		f32_input.offset = e.id_offset;
+		f32_input.enc_out = fc.enc.as<half_t>();  // (the returned context holds the encoded input, whoever computed it)
 		const SlabOrder order = mlp_train(stream, md.net.mlp, n, params, params_t, fc.enc.as<half_t>(), la, c->output.as<half_t>(),
 		                                  external_dL_dy ? nullptr : c->dL_doutput.as<half_t>(), need_denc ? denc.as<half_t>() : nullptr,
-		                                  want_grads ? partials.as<float>() : nullptr, external_dL_dy ? nullptr : c->block_sums.as<float>());
+		                                  want_grads ? partials.as<float>() : nullptr, external_dL_dy ? nullptr : c->block_sums.as<float>(),
+		                                  input_by_network ? &f32_input : nullptr);
 		if (want_grads && !finalize_aside) mlp_finalize_gradients(stream, md.net.mlp, n_partials, partials.as<float>(), tm->grads, accumulate, order);
 		if (finalize_aside) {
 			if (!tm->lanes) tm->lanes = std::make_shared<tcnn_trainable_model::OverlapLanes>();
@@ -2830,6 +2844,10 @@ int tcnn_trainer_set_fused_optimizer(tcnn_trainable_model_t* tm, int enable) {
 }
 int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes) {
 	tm->lds_level_budget = bytes;
+	return TCNN_OK;
+}
+int tcnn_set_fused_identity_input(int enable) {
+	g_fused_identity_input.store(enable != 0 ? 1 : 0);
 	return TCNN_OK;
 }
 int tcnn_get_fused_network_passes(void) { return g_fused_network_passes.load(); }

@@ -119,6 +119,17 @@ struct MlpLossArgs {
 	// the three matrix products cost less than writing and re-reading every hidden activation).  targets / data_pdf unused.
 	const half_t* external_dL_doutput = nullptr;
 };
+// The network kernel reads the caller's fp32 matrix itself: an Identity encoding without padding (encodings/identity.h:46-66) is
+// `(T)(x * scale + offset)` per element, and the register-resident training kernel loads its input one 32-sample strip ahead anyway -- so it
+// can load x[i][k] (sample-major, x[i * in_width + k]) instead of the encoded half matrix, convert with k_identity_forward's arithmetic, and, if
+// `enc_out` is given, leave the encoded input [in_width][n] there for the caller's context (what encoding_forward would have written).
+// Saves the transpose kernel and its 100 MB of traffic on BASELINE configs[1].  Same bits as the two-kernel path.
+struct MlpF32Input {
+	const float* x = nullptr;
+	float scale = 1.0f, offset = 0.0f;
+	half_t* enc_out = nullptr;
+};
+bool mlp_train_f32_input_supported(const MlpMeta& m, uint32_t n, LossType loss);
 bool mlp_train_supported(const MlpMeta& m);
 // The register-resident instances of the training pass (mlp_train_wave.hip): one wavefront per strip of 32 samples, for
 // 32 inputs x {64 neurons, 1-2 hidden layers | 32 neurons, 1-3 hidden layers} x 16 padded outputs, ReLU / None activations,
@@ -127,7 +138,8 @@ bool mlp_train_supported(const MlpMeta& m);
 bool mlp_train_wave_supported(const MlpMeta& m, uint32_t n, LossType loss);
 uint32_t mlp_train_wave_n_partials(const MlpMeta& m, uint32_t n);
 void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
-                    const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums);
+                    const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums,
+                    const MlpF32Input* f32_input = nullptr);
 
 // The fused training pass of 128-neuron networks (mlp_train_wide.hip): hidden weights resident in LDS (one copy, the backward
 // operands come out of it through the hardware transpose read), sample-major activation tiles of 32 samples, weight gradients
@@ -152,7 +164,8 @@ void mlp_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half
 // number of fp32 slabs / loss partial sums mlp_train() writes for this shape and batch (<= mlp_backward_n_partials)
 uint32_t mlp_train_n_partials(const MlpMeta& m, uint32_t n, LossType loss);
 SlabOrder mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
-               const MlpLossArgs& loss, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums);
+               const MlpLossArgs& loss, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums,
+               const MlpF32Input* f32_input = nullptr);  // f32_input: only where mlp_train_f32_input_supported (then `input` is ignored)
 
 // grads[i] = (accumulate ? grads[i] : 0) + sum_b partials[b][i]   (fully_fused_mlp.cu:770 beta)
 // `order`: how the slabs are laid out -- what mlp_train() returned for them (mlp_backward writes parameter order)

@@ -1184,13 +1184,17 @@ bool mlp_train_supported(const MlpMeta& m) {
 }
 
 SlabOrder mlp_train(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
-                    const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
+                    const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums,
+                    const MlpF32Input* f32_input) {
 	check_meta(m, n);
 	if (n == 0) return SlabOrder::Params;
 	if (!mlp_train_supported(m)) throw std::runtime_error("mlp_train: unsupported network shape (check mlp_train_supported first)");
 	if (!la.external_dL_doutput && !loss_is_elementwise(la.type)) throw std::runtime_error("mlp_train: this loss needs whole output rows; use the stand-alone loss kernel");
+	if (f32_input && (la.external_dL_doutput || !mlp_train_f32_input_supported(m, n, la.type))) {
+		throw std::runtime_error("mlp_train: no instance reads an fp32 input for this shape (check mlp_train_f32_input_supported first)");
+	}
 	if (mlp_train_wave_supported(m, n, la.external_dL_doutput ? LossType::L2 : la.type)) {
-		mlp_train_wave(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums);
+		mlp_train_wave(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums, f32_input);
 		return SlabOrder::WaveRegisters;
 	}
 	if (m.width == 128) {

@@ -106,12 +106,17 @@ constexpr uint32_t MLP_WAVE_STRIP = 32, MLP_WAVE_THREADS = 256;
 
 // EXTERNAL: no loss -- dL/doutput comes from la.external_dL_doutput (the backward pass of a module recomputing its forward pass).  A
 // compile-time switch: the loss instance is at the register limit (256 of 256 at two waves per SIMD), a run-time branch around the loss spills.
-template <uint32_t WIDTH, uint32_t IN, uint32_t HM, bool GENERAL, bool EXTERNAL, uint32_t MIN_WAVES = TCNN_MLP_WAVE_MIN_BLOCKS>
+// F32IN: the input is the caller's fp32 sample-major matrix (MlpF32Input: an unpadded Identity encoding folded into the strip loads).  A
+// lane's fragment -- eight consecutive samples of one feature -- is eight 4-byte loads then (sample stride IN floats; the four lanes of a quad
+// read 16 contiguous bytes, a strip's 8 KiB are fetched once and hit the L1 for the other fragment of the pair), held as fp32 until the
+// strip is used so that the loads stay a whole strip ahead, converted with k_identity_forward's arithmetic, and stored once as the encoded
+// matrix if the caller wants it for its context.
+template <uint32_t WIDTH, uint32_t IN, uint32_t HM, bool GENERAL, bool EXTERNAL, uint32_t MIN_WAVES = TCNN_MLP_WAVE_MIN_BLOCKS, bool F32IN = false>
 __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
                                                                         const half_t* __restrict__ params_t, const half_t* __restrict__ input,
                                                                         const MlpLossArgs la, half_t* __restrict__ output, half_t* __restrict__ dL_doutput,
                                                                         half_t* __restrict__ dL_dinput, float* __restrict__ partials,
-                                                                        float* __restrict__ block_sums) {
+                                                                        float* __restrict__ block_sums, const MlpF32Input fin) {
 	constexpr uint32_t NB = WIDTH / 16, NP = WIDTH / 32, FB = IN / 16, FP = IN / 32, NWAVES = MLP_WAVE_THREADS / 64, HMX = HM > 0 ? HM : 1;
 	constexpr uint32_t N_PARAMS = WIDTH * IN + HM * WIDTH * WIDTH + 16 * WIDTH;
 	static_assert(NWAVES == 4 && WIDTH % 32 == 0 && IN % 32 == 0, "the final reduction pairs waves (0,2) and (1,3); operands are built from pairs of 16-row tiles");
@@ -148,9 +153,19 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	const uint32_t n_strips = n / MLP_WAVE_STRIP, stride = gridDim.x * NWAVES;
 	uint32_t strip = blockIdx.x * NWAVES + w;
 	h8 xq_next[FB];
+	float xraw_next[F32IN ? FB : 1][8];  // F32IN: the next strip's fragments as they arrive (fp32)
+	auto request_strip = [&](uint32_t strip_) {
+		if constexpr (F32IN) {
 #pragma unroll
-	for (uint32_t f = 0; f < FB; ++f)
-		if (strip < n_strips) xq_next[f] = *(const h8*)(input + (perm32(f, lr) * n + strip * MLP_WAVE_STRIP + 8 * g));
+			for (uint32_t f = 0; f < FB; ++f)
+#pragma unroll
+				for (uint32_t j = 0; j < 8; ++j) xraw_next[f][j] = fin.x[(strip_ * MLP_WAVE_STRIP + 8 * g + j) * IN + perm32(f, lr)];  // (element offsets fit 32 bits: the host checks n)
+		} else {
+#pragma unroll
+			for (uint32_t f = 0; f < FB; ++f) xq_next[f] = *(const h8*)(input + (perm32(f, lr) * n + strip_ * MLP_WAVE_STRIP + 8 * g));
+		}
+	};
+	if (strip < n_strips) request_strip(strip);
 	auto fragment_source = [&](uint32_t f) -> const half_t* {
 		if (f < F_WHIDA) {
 			const uint32_t b = (f - F_WINA) / FP, p = (f - F_WINA) % FP;
@@ -226,12 +241,22 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 		asm volatile("" ::: "memory");  // the weight fragments are re-read from LDS where they are used, not hoisted into registers for the whole loop
 		const uint32_t base = strip * MLP_WAVE_STRIP;  // element offsets fit 32 bits (the host checks n): scalar base + 32-bit lane offset addressing
 		h8 xq[FB];  // lane lr <-> feature perm32(f, lr), k = sample 8g+j
+		if constexpr (F32IN) {
 #pragma unroll
-		for (uint32_t f = 0; f < FB; ++f) xq[f] = xq_next[f];
-		if (strip + stride < n_strips) {
+			for (uint32_t f = 0; f < FB; ++f) {
 #pragma unroll
-			for (uint32_t f = 0; f < FB; ++f) xq_next[f] = *(const h8*)(input + (perm32(f, lr) * n + (strip + stride) * MLP_WAVE_STRIP + 8 * g));
+				for (uint32_t j = 0; j < 8; ++j) {  // identity.h:60: (T)(x * scale + offset), the two roundings of k_identity_forward
+					float t = xraw_next[f][j] * fin.scale;
+					t = t + fin.offset;
+					xq[f][j] = to_half_rn(t);
+				}
+				if (fin.enc_out) *(h8*)(fin.enc_out + (perm32(f, lr) * n + base + 8 * g)) = xq[f];
+			}
+		} else {
+#pragma unroll
+			for (uint32_t f = 0; f < FB; ++f) xq[f] = xq_next[f];
 		}
+		if (strip + stride < n_strips) request_strip(strip + stride);
 		// this lane's targets: output 4r+g of sample perm32(s, lr)
 		float tgt[2][4];
 #pragma unroll
@@ -589,29 +614,45 @@ uint32_t mlp_train_wave_n_partials(const MlpMeta& m, uint32_t n) {
 
 template <uint32_t WIDTH, uint32_t IN, uint32_t HM, uint32_t MIN_WAVES = TCNN_MLP_WAVE_MIN_BLOCKS>
 static void launch_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
-                              const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
+                              const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums,
+                              const MlpF32Input* f32_input) {
 	const uint32_t blocks = mlp_train_wave_n_partials(m, n);
-	if (la.external_dL_doutput) {
+	const MlpF32Input fin = f32_input ? *f32_input : MlpF32Input();
+	if (f32_input) {
+		if constexpr (IN == 64 && HM == 1) {  // the instances mlp_train_f32_input_supported names
+			TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, false, MIN_WAVES, true>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la,
+			            output, dL_doutput, dL_dinput, partials, block_sums, fin);
+		} else {
+			throw std::runtime_error("mlp_train_wave: no fp32-input instance for this shape");
+		}
+	} else if (la.external_dL_doutput) {
 		TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, true, MIN_WAVES>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la, output,
-		            dL_doutput, dL_dinput, partials, block_sums);
+		            dL_doutput, dL_dinput, partials, block_sums, fin);
 	} else {
 		TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, false, MIN_WAVES>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la, output,
-		            dL_doutput, dL_dinput, partials, block_sums);
+		            dL_doutput, dL_dinput, partials, block_sums, fin);
 	}
+}
+// fp32 sample-major input (MlpF32Input): the 64-input, two-hidden-layer instance -- the benchmarks/mlp shape, which has a SIMD's registers to
+// itself (room for a strip of fp32 fragments in flight); the other instances are at their register limit
+bool mlp_train_f32_input_supported(const MlpMeta& m, uint32_t n, LossType loss) {
+	static const bool enabled = !(getenv("TCNN_MLP_F32_INPUT") && atoi(getenv("TCNN_MLP_F32_INPUT")) == 0);
+	return enabled && m.in_width == 64 && m.width == 64 && m.n_hidden_matmuls == 1 && n <= (1u << 25) && mlp_train_wave_supported(m, n, loss);
 }
 
 void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
-                    const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums) {
+                    const MlpLossArgs& la, half_t* output, half_t* dL_doutput, half_t* dL_dinput, float* partials, float* block_sums,
+                    const MlpF32Input* f32_input) {
 	if (!mlp_train_wave_supported(m, n, la.external_dL_doutput ? LossType::L2 : la.type)) throw std::runtime_error("mlp_train_wave: unsupported shape, activation or loss (check mlp_train_wave_supported first)");
 	const uint32_t key = (m.in_width == 64 ? 10000u : 0u) + m.width * 10u + m.n_hidden_matmuls;
 	switch (key) {
-		case 10640: launch_train_wave<64, 64, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
-		case 10641: launch_train_wave<64, 64, 1, 1>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;  // one wave per SIMD
-		case 640: launch_train_wave<64, 32, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
-		case 641: launch_train_wave<64, 32, 1>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
-		case 320: launch_train_wave<32, 32, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
-		case 321: launch_train_wave<32, 32, 1>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
-		case 322: launch_train_wave<32, 32, 2>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums); break;
+		case 10640: launch_train_wave<64, 64, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums, f32_input); break;
+		case 10641: launch_train_wave<64, 64, 1, 1>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums, f32_input); break;  // one wave per SIMD
+		case 640: launch_train_wave<64, 32, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums, f32_input); break;
+		case 641: launch_train_wave<64, 32, 1>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums, f32_input); break;
+		case 320: launch_train_wave<32, 32, 0>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums, f32_input); break;
+		case 321: launch_train_wave<32, 32, 1>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums, f32_input); break;
+		case 322: launch_train_wave<32, 32, 2>(stream, m, n, params, params_t, input, la, output, dL_doutput, dL_dinput, partials, block_sums, f32_input); break;
 		default: throw std::runtime_error("mlp_train: no register-resident instance for this shape");
 	}
 }

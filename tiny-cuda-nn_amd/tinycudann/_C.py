@@ -164,6 +164,7 @@ _sig("tcnn_trainer_set_lds_level_budget", _i, _vp, _u32)
 _sig("tcnn_trainer_set_fused_optimizer", _i, _vp, _i)
 _sig("tcnn_get_fused_network_passes", _i)
 _sig("tcnn_set_fused_network_passes", _i, _i)
+_sig("tcnn_set_fused_identity_input", _i, _i)
 _sig("tcnn_set_grid_backward_mode", _i, _i)
 _sig("tcnn_get_grid_backward_mode", _i)
 _sig("tcnn_set_grid_owner_mode", _i, _i)
@@ -300,6 +301,11 @@ def grid_owner_wide_slices():
 
 def get_fused_network_passes():
     return bool(_lib.tcnn_get_fused_network_passes())
+
+
+def set_fused_identity_input(enable):
+    """training_step with an unpadded Identity encoding: the network kernel loads the fp32 input itself (default) / the encoding runs as its own kernel."""
+    _check(_lib.tcnn_set_fused_identity_input(int(bool(enable))))
 
 
 def set_fused_network_passes(enable):

@@ -266,6 +266,22 @@ def mlp_train(om, params_h, input_soa_h, loss_type, target, dims, loss_scale=128
     return out, dy, dinput, grads, float(s[0])
 
 
+def mlp_infer_f32_input(om, params_h, x, scale=1.0, offset=0.0, dims=None):
+    """k_mlp_infer_wave reading an unpadded Identity encoding's fp32 input itself.  dims=None: the padded 16-bit output [n][16];
+    otherwise the caller's fp32 matrix [n][dims].  None where no instance takes the shape."""
+    x = np.require(x, dtype=np.float32, requirements=["C", "ALIGNED"])
+    n = x.shape[0]
+    out_h = np.zeros((n, om.padded_out), dtype=np.uint16) if dims is None else None
+    out_f = np.zeros((n, dims), dtype=np.float32) if dims is not None else None
+    m = mlp_meta(om)
+    r = lib().emu_mlp_infer_f32_input(C.byref(m), C.c_uint32(n), _p(params_h), _p(x), C.c_float(scale), C.c_float(offset), _p(out_h), _p(out_f),
+                                      C.c_uint32(dims or 0))
+    if r == 2:
+        return None
+    assert r == 0
+    return out_h if dims is None else out_f
+
+
 def mlp_train_f32_input(om, params_h, x, scale, offset, loss_type, target, dims, loss_scale=128.0, data_pdf=None, n_total=None, want_dinput=True, want_enc=True):
     """mlp_train with the network kernel loading the fp32 sample-major input of an unpadded Identity encoding itself (MlpF32Input).
     Returns (output, dL_doutput, dL_dinput, grads, loss_sum, enc_out) or None where no instance offers it."""

@@ -190,6 +190,27 @@ int emu_mlp_forward(const EmuMlp* e, uint32_t n, const uint16_t* params, const u
 	return 0;
 }
 
+// the register-resident inference kernel reading an unpadded Identity encoding's fp32 input itself (MlpF32Input); out_half [n][16] or, if
+// out_f32 is given, the caller's fp32 matrix [n][dims].  2: no instance.
+int emu_mlp_infer_f32_input(const EmuMlp* e, uint32_t n, const uint16_t* params, const float* x, float scale, float offset, uint16_t* out_half, float* out_f32,
+                            uint32_t dims) {
+	try {
+		const MlpMeta m = make_mlp(e);
+		if (!mlp_infer_f32_input_supported(m, n)) return 2;
+		MlpF32Input fin;
+		fin.x = x;
+		fin.scale = scale;
+		fin.offset = offset;
+		MlpF32Output f32;
+		if (out_f32) f32 = {out_f32, dims, dims, 1u};
+		mlp_infer_wave(nullptr, m, n, (const half_t*)params, nullptr, (half_t*)out_half, f32, &fin);
+	} catch (const std::exception& ex) {
+		fprintf(stderr, "emu_mlp_infer_f32_input: %s\n", ex.what());
+		return 1;
+	}
+	return 0;
+}
+
 // grads: half [n_params] (Overwrite unless accumulate); scratch sizes are handled here.
 int emu_mlp_backward(const EmuMlp* e, uint32_t n, const uint16_t* params, const uint16_t* input_soa, const uint16_t* hidden,
                      const uint16_t* dL_doutput, uint16_t* dL_dinput_soa, uint16_t* grads, int accumulate, const uint16_t* output) {

@@ -385,6 +385,27 @@ def test_network_kernel_loads_an_unpadded_identity_encoding_itself(loss_type, sc
         assert emu.mlp_train_f32_input(other, O.f2h(O.mlp_init_params(other, O.pcg32(5))), x[:, :shape[0]].copy(), 1.0, 0.0, loss_type, target, 16) is None
 
 
+@pytest.mark.parametrize("shape", [(64, 64, 16, 2), (64, 64, 16, 1), (64, 64, 16, 3), (32, 64, 16, 2), (32, 32, 16, 4)])
+def test_inference_kernel_loads_an_unpadded_identity_encoding_itself(shape):
+    """MlpF32Input in the register-resident inference kernel: the first layer's B operand (eight consecutive features of a sample per lane) is 32
+    contiguous bytes of the caller's fp32 sample-major matrix -- two 16-byte loads and the Identity encoding's arithmetic replace the encoding
+    kernel AND the selection MFMAs that turn the feature-major fragments around.  Same bits as encoding kernel + inference kernel, into the
+    padded 16-bit output and into the caller's fp32 matrix."""
+    IN, W, OUT, H = shape
+    rng = np.random.default_rng(23)
+    om = O.mlp_init(IN, W, OUT, H)
+    ph = O.f2h(O.mlp_init_params(om, O.pcg32(7)))
+    n = 1024 + 512
+    x = (rng.random((n, IN), dtype=np.float32) * 2 - 1).astype(np.float32)
+    for scale, offset in ((1.0, 0.0), (1.5, -0.25)):
+        enc = O.f2h((x * np.float32(scale) + np.float32(offset)).astype(np.float32)).T.copy()
+        _, want = emu.mlp_forward(om, ph, enc, save_hidden=False)
+        got = emu.mlp_infer_f32_input(om, ph, x, scale, offset)
+        assert got is not None and np.array_equal(got, want)
+        got32 = emu.mlp_infer_f32_input(om, ph, x, scale, offset, dims=3)
+        assert np.array_equal(got32, O.h2f(want[:, :3]))
+
+
 @pytest.mark.parametrize("loss_type", range(len(O.LOSS_NAMES)))
 def test_loss_bit_exact(loss_type):
     """Every elementwise loss of src/loss.cu:57-65 (all but RelativeL2Luminance): the gradients are the oracle's bits."""

@@ -458,13 +458,15 @@ def test_network_kernel_reading_the_fp32_input_of_an_identity_encoding_itself(sc
                 losses.append(tm.loss(ctx))
             stages = {k for k, (ms, c) in tm.stage_times().items() if c}
             tm.set_profiling(False)
+            tm.training_step(x, t, want_context=False)  # (no context asked for: the kernel does not write the encoded matrix at all)
+            inferred = tm.inference(x).clone()  # the inference kernel reads the fp32 input itself as well (no encoding kernel, no encoded matrix)
             ctx = tm.training_step(x, t, run_optimizer=False)
             pred = ctx.output.clone()
             grads_step = tm.param_gradients.clone()
             tm.backward(ctx, x)  # the context's encoded input, whoever wrote it, feeds the recomputing backward pass
             torch.cuda.synchronize()
             m1, m2, steps, _ = tm.optimizer_state()
-            results[fused] = (losses, pred, grads_step, tm.param_gradients.clone(), tm.params_full_precision.clone(), m1.clone(), m2.clone(), steps.clone(), stages)
+            results[fused] = (losses, pred, grads_step, tm.param_gradients.clone(), tm.params_full_precision.clone(), m1.clone(), m2.clone(), steps.clone(), stages, inferred)
     finally:
         C.set_fused_identity_input(True)
     a, b = results[True], results[False]
@@ -475,3 +477,4 @@ def test_network_kernel_reading_the_fp32_input_of_an_identity_encoding_itself(sc
     # encoding kernel wrote in the other)
     assert float((a[2].float() - a[3].float()).abs().max()) <= 2.0 ** -9 * float(a[2].float().abs().max())  # and reproduces the step's gradients
     assert "grid_forward" in b[8] and "grid_forward" not in a[8] and "mlp_train_fused" in a[8]  # (the encoding stage is named after its first user)
+    assert torch.equal(a[9], b[9]) and torch.isfinite(a[9]).all()

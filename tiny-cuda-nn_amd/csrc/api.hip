@@ -699,6 +699,19 @@ static void model_forward(hipStream_t stream, const Model& md, uint32_t n, const
 		encoding_forward(stream, md, n, input, params, output, /*soa=*/false, dy_dx);
 		return;
 	}
+	// inference into the caller's fp32 matrix with an Identity encoding that pads nothing: the inference kernel reads the fp32 input itself
+	// (MlpF32Input; no encoding kernel, no encoded matrix)
+	const EncodingDesc& e = md.enc;
+	if (f32 && !ctx && !e.is_grid && !e.is_frequency && !e.is_oneblob && e.n_dims == e.padded_output_width && in_stride_i(md) == e.n_dims && in_stride_d() == 1u &&
+	    ((uintptr_t)input & 15u) == 0u && g_fused_identity_input.load() != 0 && mlp_infer_f32_input_supported(md.net.mlp, n)) {
+		MlpF32Input f32_input;
+		f32_input.x = input;
+		f32_input.scale = e.id_scale;
+		f32_input.offset = e.id_offset;
+		ProfScope prof(stream, STAGE_MLP_FWD);
+		mlp_infer_wave(stream, md.net.mlp, n, params, nullptr, nullptr, *f32, &f32_input);
+		return;
+	}
 	Scratch enc_local;
 	Scratch& enc = ctx ? ctx->enc : enc_local;
 	enc = Scratch(stream, (size_t)md.enc.padded_output_width * n * sizeof(half_t));
@@ -2294,7 +2307,7 @@ static void overlapped_backward_and_step(tcnn_trainable_model_t* tm, hipStream_t
 // prediction, dL_doutput, the loss and the encoded input, but no hidden activations.
 static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale, uint32_t n, const float* input, const float* target,
                                const float* data_pdf, float* dL_dinput, int use_inference_params, int gradient_mode, bool run_optimizer,
-                               const half_t* external_dL_dy, tcnn_train_context_t** ctx_out) {
+                               const half_t* external_dL_dy, tcnn_train_context_t** ctx_out, bool context_wanted) {
 	TCNN_API_BEGIN
 	const half_t* params = use_inference_params ? tm->inference_params() : tm->params;
 	ProfilerGuard pg(tm->profiler.get());
@@ -2363,7 +2376,7 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 		f32_input.x = input;
 		f32_input.scale = e.id_scale;
 		f32_input.offset = e.id_offset;
-		f32_input.enc_out = fc.enc.as<half_t>();  // (the returned context holds the encoded input, whoever computed it)
+		f32_input.enc_out = context_wanted ? fc.enc.as<half_t>() : nullptr;  // (a context that is handed out holds the encoded input, whoever computed it)
 		const SlabOrder order = mlp_train(stream, md.net.mlp, n, params, params_t, fc.enc.as<half_t>(), la, c->output.as<half_t>(),
 		                                  external_dL_dy ? nullptr : c->dL_doutput.as<half_t>(), need_denc ? denc.as<half_t>() : nullptr,
 		                                  want_grads ? partials.as<float>() : nullptr, external_dL_dy ? nullptr : c->block_sums.as<float>(),
@@ -2483,7 +2496,7 @@ int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
 	tcnn_train_context_t* ctx = nullptr;
 	if (g_fused_network_passes.load() && tm->md.has_network && mlp_train_supported(tm->md.net.mlp) && (external_dL_dy || (target && loss_is_elementwise(tm->loss)))) {
 		int r = training_step_fused(tm, (hipStream_t)stream, loss_scale, n, input, target, data_pdf, dL_dinput, use_inference_params, gradient_mode,
-		                            run_optimizer != 0, (const half_t*)external_dL_dy, &ctx);
+		                            run_optimizer != 0, (const half_t*)external_dL_dy, &ctx, /*context_wanted=*/ctx_out != nullptr);
 		if (r == TCNN_OK) r = settle_unstepped_reductions(tm, (hipStream_t)stream, run_optimizer != 0);
 		if (ctx_out && r == TCNN_OK) {
 			*ctx_out = ctx;

@@ -159,7 +159,9 @@ struct MlpF32Output {
 	float* out = nullptr;
 	uint32_t dims = 0, stride_i = 0, stride_j = 0;
 };
-void mlp_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output, const MlpF32Output& f32 = {});
+void mlp_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output, const MlpF32Output& f32 = {},
+                    const MlpF32Input* f32_input = nullptr);  // f32_input (16-byte aligned, mlp_infer_f32_input_supported): `input` is ignored
+bool mlp_infer_f32_input_supported(const MlpMeta& m, uint32_t n);
 
 // number of fp32 slabs / loss partial sums mlp_train() writes for this shape and batch (<= mlp_backward_n_partials)
 uint32_t mlp_train_n_partials(const MlpMeta& m, uint32_t n, LossType loss);

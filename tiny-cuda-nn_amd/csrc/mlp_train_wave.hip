@@ -483,9 +483,13 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 #ifndef TCNN_MLP_INFER_BLOCKS
 #define TCNN_MLP_INFER_BLOCKS 1024  // four workgroups per CU; the instance needs < 128 registers and 8-12 KiB of LDS
 #endif
-template <uint32_t WIDTH, uint32_t IN, uint32_t HM>
+// F32IN: the input is the caller's fp32 sample-major matrix (MlpF32Input).  Inference needs the input in ONE orientation only -- the first
+// layer's B operand, eight consecutive features of a sample per lane -- which is 32 contiguous bytes of that matrix: two 16-byte loads, the
+// Identity encoding's arithmetic, and neither the encoding kernel nor the selection MFMAs that turn the feature-major fragments around.
+template <uint32_t WIDTH, uint32_t IN, uint32_t HM, bool F32IN = false>
 __global__ void __launch_bounds__(MLP_WAVE_THREADS) k_mlp_infer_wave(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
-                                                                     const half_t* __restrict__ input, half_t* __restrict__ output, const MlpF32Output f32) {
+                                                                     const half_t* __restrict__ input, half_t* __restrict__ output, const MlpF32Output f32,
+                                                                     const MlpF32Input fin) {
 	constexpr uint32_t NB = WIDTH / 16, NP = WIDTH / 32, FB = IN / 16, FP = IN / 32, NWAVES = MLP_WAVE_THREADS / 64;
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
 	const uint32_t out_act = m.output_activation;
@@ -516,18 +520,34 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS) k_mlp_infer_wave(const MlpMe
 	const uint32_t n_strips = n / MLP_WAVE_STRIP, stride = gridDim.x * NWAVES;
 	for (uint32_t strip = blockIdx.x * NWAVES + w; strip < n_strips; strip += stride) {
 		const uint32_t base = strip * MLP_WAVE_STRIP;
-		h8 xq[FB];
-#pragma unroll
-		for (uint32_t f = 0; f < FB; ++f) xq[f] = *(const h8*)(input + (perm32(f, lr) * n + base + 8 * g));
 		h4 hp[2][NB];
 		{
-			h8 xb[2][FP];
+			h8 xb[2][FP];  // first layer's B operand: k = feature 32p + 8g + j, n = sample perm32(s, lr)
+			if constexpr (F32IN) {
 #pragma unroll
-			for (uint32_t s = 0; s < 2; ++s) {
-				const h8 sel = wfrag[F_SEL + s][lane];
+				for (uint32_t s = 0; s < 2; ++s)
 #pragma unroll
-				for (uint32_t p = 0; p < FP; ++p)
-					xb[s][p] = pack8(to_h4(mfma_16x16x32(xq[2 * p], sel, zero4())), to_h4(mfma_16x16x32(xq[2 * p + 1], sel, zero4())));
+					for (uint32_t p = 0; p < FP; ++p) {
+						const float* src = fin.x + ((base + perm32(s, lr)) * IN + 32 * p + 8 * g);  // (element offsets fit 32 bits: the host checks n)
+						const f4 lo = *(const f4*)src, hi = *(const f4*)(src + 4);
+#pragma unroll
+						for (uint32_t j = 0; j < 8; ++j) {  // identity.h:60: (T)(x * scale + offset), the two roundings of k_identity_forward
+							float t = (j < 4 ? lo[j & 3u] : hi[j & 3u]) * fin.scale;
+							t = t + fin.offset;
+							xb[s][p][j] = to_half_rn(t);
+						}
+					}
+			} else {
+				h8 xq[FB];
+#pragma unroll
+				for (uint32_t f = 0; f < FB; ++f) xq[f] = *(const h8*)(input + (perm32(f, lr) * n + base + 8 * g));
+#pragma unroll
+				for (uint32_t s = 0; s < 2; ++s) {
+					const h8 sel = wfrag[F_SEL + s][lane];
+#pragma unroll
+					for (uint32_t p = 0; p < FP; ++p)
+						xb[s][p] = pack8(to_h4(mfma_16x16x32(xq[2 * p], sel, zero4())), to_h4(mfma_16x16x32(xq[2 * p + 1], sel, zero4())));
+				}
 			}
 #pragma unroll
 			for (uint32_t s = 0; s < 2; ++s)
@@ -665,25 +685,38 @@ bool mlp_infer_wave_supported(const MlpMeta& m, uint32_t n) {
 }
 
 template <uint32_t WIDTH, uint32_t IN, uint32_t HM>
-static void launch_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output, const MlpF32Output& f32) {
+static void launch_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output, const MlpF32Output& f32,
+                              const MlpF32Input* f32_input) {
 	const uint32_t wanted = div_round_up(n / MLP_WAVE_STRIP, MLP_WAVE_THREADS / 64u);
 	const uint32_t blocks = wanted < TCNN_MLP_INFER_BLOCKS ? wanted : TCNN_MLP_INFER_BLOCKS;
-	TCNN_LAUNCH((k_mlp_infer_wave<WIDTH, IN, HM>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, input, output, f32);
+	if (f32_input) {
+		TCNN_LAUNCH((k_mlp_infer_wave<WIDTH, IN, HM, true>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, input, output, f32, *f32_input);
+	} else {
+		TCNN_LAUNCH((k_mlp_infer_wave<WIDTH, IN, HM, false>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, input, output, f32, MlpF32Input());
+	}
 }
 
-void mlp_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output, const MlpF32Output& f32) {
+// every inference instance reads an fp32 sample-major input (16-byte aligned rows: in_width is 32 or 64)
+bool mlp_infer_f32_input_supported(const MlpMeta& m, uint32_t n) {
+	static const bool enabled = !(getenv("TCNN_MLP_F32_INPUT") && atoi(getenv("TCNN_MLP_F32_INPUT")) == 0);
+	return enabled && n <= (1u << 25) && mlp_infer_wave_supported(m, n);
+}
+
+void mlp_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output, const MlpF32Output& f32,
+                    const MlpF32Input* f32_input) {
 	if (!mlp_infer_wave_supported(m, n)) throw std::runtime_error("mlp_infer_wave: unsupported shape or activation (check mlp_infer_wave_supported first)");
+	if (f32_input && (!mlp_infer_f32_input_supported(m, n) || ((uintptr_t)f32_input->x & 15u) != 0u)) throw std::runtime_error("mlp_infer_wave: the fp32 input needs 16-byte alignment and n <= 2^25");
 	switch (m.width * 1000u + m.in_width * 10u + m.n_hidden_matmuls) {
-		case 64320: launch_infer_wave<64, 32, 0>(stream, m, n, params, input, output, f32); break;
-		case 64321: launch_infer_wave<64, 32, 1>(stream, m, n, params, input, output, f32); break;
-		case 64322: launch_infer_wave<64, 32, 2>(stream, m, n, params, input, output, f32); break;
-		case 64640: launch_infer_wave<64, 64, 0>(stream, m, n, params, input, output, f32); break;
-		case 64641: launch_infer_wave<64, 64, 1>(stream, m, n, params, input, output, f32); break;
-		case 64642: launch_infer_wave<64, 64, 2>(stream, m, n, params, input, output, f32); break;
-		case 32320: launch_infer_wave<32, 32, 0>(stream, m, n, params, input, output, f32); break;
-		case 32321: launch_infer_wave<32, 32, 1>(stream, m, n, params, input, output, f32); break;
-		case 32322: launch_infer_wave<32, 32, 2>(stream, m, n, params, input, output, f32); break;
-		case 32323: launch_infer_wave<32, 32, 3>(stream, m, n, params, input, output, f32); break;
+		case 64320: launch_infer_wave<64, 32, 0>(stream, m, n, params, input, output, f32, f32_input); break;
+		case 64321: launch_infer_wave<64, 32, 1>(stream, m, n, params, input, output, f32, f32_input); break;
+		case 64322: launch_infer_wave<64, 32, 2>(stream, m, n, params, input, output, f32, f32_input); break;
+		case 64640: launch_infer_wave<64, 64, 0>(stream, m, n, params, input, output, f32, f32_input); break;
+		case 64641: launch_infer_wave<64, 64, 1>(stream, m, n, params, input, output, f32, f32_input); break;
+		case 64642: launch_infer_wave<64, 64, 2>(stream, m, n, params, input, output, f32, f32_input); break;
+		case 32320: launch_infer_wave<32, 32, 0>(stream, m, n, params, input, output, f32, f32_input); break;
+		case 32321: launch_infer_wave<32, 32, 1>(stream, m, n, params, input, output, f32, f32_input); break;
+		case 32322: launch_infer_wave<32, 32, 2>(stream, m, n, params, input, output, f32, f32_input); break;
+		case 32323: launch_infer_wave<32, 32, 3>(stream, m, n, params, input, output, f32, f32_input); break;
 		default: throw std::runtime_error("mlp_infer_wave: no instance for this shape");
 	}
 }

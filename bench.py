@@ -627,10 +627,14 @@ def main():
     if tcnn._C.debug_alloc_mode() != 0:
         tcnn._C.debug_check_allocations()  # raises if any block of the checking allocator was written out of bounds
 
+    is_grid_workload = w["config"]["encoding"]["otype"] == "HashGrid"
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = global_batch * args.steps / elapsed
         ab = algorithmic_bytes(w, local_batch, tm.n_params, tm.n_mlp_params)
+        if not is_grid_workload and stages and not stages.get("grid_forward"):
+            # the Identity encoding ran inside the network kernel (MlpF32Input): that stage's minimum input is the caller's fp32 matrix then
+            ab["mlp_train_fused"] += local_batch * (4 * w["n_in"] - 2 * (-(-w["n_in"] // 16) * 16))
         adam_dense = ab["adam"]
         # Adam's algorithmic bytes from the parameters it actually steps: 36 B each, 2 B (the gradient read) for a skipped one.  The dense
         # figure (SURVEY 8d's upper bound) overstates the rate wherever a batch leaves table entries untouched (T = 2^22: most of them)

@@ -469,6 +469,17 @@ def test_network_kernel_reading_the_fp32_input_of_an_identity_encoding_itself(sc
             results[fused] = (losses, pred, grads_step, tm.param_gradients.clone(), tm.params_full_precision.clone(), m1.clone(), m2.clone(), steps.clone(), stages, inferred)
     finally:
         C.set_fused_identity_input(True)
+    # a PyTorch module's inference (no_grad: tcnn_module_inference, padded 16-bit output) takes the same way in
+    net_out = {}
+    try:
+        for fused in (True, False):
+            C.set_fused_identity_input(fused)
+            net = T.Network(64, 16, cfg["network"], seed=3)
+            with torch.no_grad():
+                net_out[fused] = net(x).clone()
+    finally:
+        C.set_fused_identity_input(True)
+    assert net_out[True].dtype == torch.half and torch.equal(net_out[True].view(torch.int16), net_out[False].view(torch.int16)) and torch.isfinite(net_out[True].float()).all()
     a, b = results[True], results[False]
     assert a[0] == b[0] and a[0][-1] < a[0][0]
     for u, v in zip(a[1:8], b[1:8]):

@@ -702,14 +702,15 @@ static void model_forward(hipStream_t stream, const Model& md, uint32_t n, const
 	// inference into the caller's fp32 matrix with an Identity encoding that pads nothing: the inference kernel reads the fp32 input itself
 	// (MlpF32Input; no encoding kernel, no encoded matrix)
 	const EncodingDesc& e = md.enc;
-	if (f32 && !ctx && !e.is_grid && !e.is_frequency && !e.is_oneblob && e.n_dims == e.padded_output_width && in_stride_i(md) == e.n_dims && in_stride_d() == 1u &&
+	if (!ctx && !e.is_grid && !e.is_frequency && !e.is_oneblob && e.n_dims == e.padded_output_width && in_stride_i(md) == e.n_dims && in_stride_d() == 1u &&
 	    ((uintptr_t)input & 15u) == 0u && g_fused_identity_input.load() != 0 && mlp_infer_f32_input_supported(md.net.mlp, n)) {
 		MlpF32Input f32_input;
 		f32_input.x = input;
 		f32_input.scale = e.id_scale;
 		f32_input.offset = e.id_offset;
 		ProfScope prof(stream, STAGE_MLP_FWD);
-		mlp_infer_wave(stream, md.net.mlp, n, params, nullptr, nullptr, *f32, &f32_input);
+		// into the caller's fp32 matrix (network->inference) or into the padded 16-bit matrix (a module's inference, cpp_api.h:97)
+		mlp_infer_wave(stream, md.net.mlp, n, params, nullptr, f32 ? nullptr : output, f32 ? *f32 : MlpF32Output(), &f32_input);
 		return;
 	}
 	Scratch enc_local;

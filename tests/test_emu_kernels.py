@@ -352,16 +352,17 @@ def test_mlp_fused_training_pass_equals_the_unfused_kernels(case, loss_type):
     assert close(g_e, g_u) and close(dx_e, dx_u)
 
 
+@pytest.mark.parametrize("hidden_layers", [2, 1])
 @pytest.mark.parametrize("loss_type", [O.LOSS_L2, O.LOSS_RELATIVE_L2])
 @pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (0.75, -0.125)])
-def test_network_kernel_loads_an_unpadded_identity_encoding_itself(loss_type, scale, offset):
-    """MlpF32Input: on the benchmarks/mlp shape (64 inputs, 64 neurons, two hidden layers: BASELINE configs[1]) the register-resident
+def test_network_kernel_loads_an_unpadded_identity_encoding_itself(loss_type, scale, offset, hidden_layers):
+    """MlpF32Input: on the benchmarks/mlp shape (64 inputs, 64 neurons, two hidden layers: BASELINE configs[1]; also with one) the register-resident
     training kernel reads the caller's fp32 sample-major matrix, applies the Identity encoding's `(T)(x * scale + offset)`
     (identity.h:60) to the fragments it loads a strip ahead anyway, and leaves the encoded matrix behind for the context.  Prediction,
     dL/doutput, dL/dinput, the weight gradients, the loss and the encoded matrix must be, BIT FOR BIT, what the encoding kernel followed by the
     same network kernel on its half-precision output gives; other shapes have no such instance."""
     rng = np.random.default_rng(17)
-    om = O.mlp_init(64, 64, 16, 2)
+    om = O.mlp_init(64, 64, 16, hidden_layers)
     ph = O.f2h(O.mlp_init_params(om, O.pcg32(5)))
     n = 1024 + 256  # 40 strips over the persistent workgroups: some waves take two strips, some one, some none
     x = (rng.random((n, 64), dtype=np.float32) * 2 - 1).astype(np.float32)
@@ -379,8 +380,8 @@ def test_network_kernel_loads_an_unpadded_identity_encoding_itself(loss_type, sc
     # without a context to fill and without input gradients
     lean = emu.mlp_train_f32_input(om, ph, x, scale, offset, loss_type, target, 16, data_pdf=pdf, n_total=2 * n * 16, want_dinput=False, want_enc=False)
     assert lean[2] is None and lean[5] is None and np.array_equal(lean[3], want[3]) and np.array_equal(lean[0], want[0])
-    # no instance: one hidden layer, 32 inputs, 32 neurons
-    for shape in ((64, 64, 16, 1), (32, 64, 16, 2), (64, 32, 16, 2)):
+    # no instance: three hidden layers, 32 inputs, 32 neurons
+    for shape in ((64, 64, 16, 3), (32, 64, 16, 2), (64, 32, 16, 2)):
         other = O.mlp_init(*shape)
         assert emu.mlp_train_f32_input(other, O.f2h(O.mlp_init_params(other, O.pcg32(5))), x[:, :shape[0]].copy(), 1.0, 0.0, loss_type, target, 16) is None
 

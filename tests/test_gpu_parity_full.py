@@ -430,8 +430,8 @@ def test_backward_and_optimizer_pipelined_over_three_streams_equal_the_one_strea
     assert torch.isfinite(a.inference(x)).all()
 
 
-@pytest.mark.parametrize("scale,offset,loss", [(1.0, 0.0, "L2"), (0.5, 0.25, "RelativeL2")])
-def test_network_kernel_reading_the_fp32_input_of_an_identity_encoding_itself(scale, offset, loss):
+@pytest.mark.parametrize("scale,offset,loss,hidden_layers", [(1.0, 0.0, "L2", 2), (0.5, 0.25, "RelativeL2", 2), (1.0, 0.0, "RelativeL2", 1)])
+def test_network_kernel_reading_the_fp32_input_of_an_identity_encoding_itself(scale, offset, loss, hidden_layers):
     """BASELINE configs[1] (64 inputs -> 64 x 2 -> 16, Identity encoding): training_step lets the register-resident network kernel load the
     caller's fp32 matrix itself (MlpF32Input, tcnn_set_fused_identity_input) instead of running the encoding as a transpose kernel in front of
     it.  Prediction, loss, gradients, parameters and optimizer state after several steps must equal the two-kernel path's BIT FOR BIT, the
@@ -441,7 +441,7 @@ def test_network_kernel_reading_the_fp32_input_of_an_identity_encoding_itself(sc
     C = T._C
     cfg = {"loss": {"otype": loss}, "optimizer": {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6},
            "encoding": {"otype": "Identity", "scale": scale, "offset": offset},
-           "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2}}
+           "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": hidden_layers}}
     n = (1 << 16) + 256
     g = torch.Generator().manual_seed(5)
     x = (torch.rand((n, 64), generator=g) * 2 - 1).cuda()

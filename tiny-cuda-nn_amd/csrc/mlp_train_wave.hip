@@ -639,7 +639,7 @@ static void launch_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, 
 	const uint32_t blocks = mlp_train_wave_n_partials(m, n);
 	const MlpF32Input fin = f32_input ? *f32_input : MlpF32Input();
 	if (f32_input) {
-		if constexpr (IN == 64 && HM == 1) {  // the instances mlp_train_f32_input_supported names
+		if constexpr (IN == 64) {  // the instances mlp_train_f32_input_supported names
 			TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, false, MIN_WAVES, true>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la,
 			            output, dL_doutput, dL_dinput, partials, block_sums, fin);
 		} else {
@@ -653,11 +653,12 @@ static void launch_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, 
 		            dL_doutput, dL_dinput, partials, block_sums, fin);
 	}
 }
-// fp32 sample-major input (MlpF32Input): the 64-input, two-hidden-layer instance -- the benchmarks/mlp shape, which has a SIMD's registers to
-// itself (room for a strip of fp32 fragments in flight); the other instances are at their register limit
+// fp32 sample-major input (MlpF32Input): the 64-input instances -- two hidden layers (the benchmarks/mlp shape, which has a SIMD's registers to
+// itself) and one hidden layer (246 registers at two waves per SIMD with a strip of fp32 fragments in flight, no scratch); the 32-input
+// instances serve grid encodings and stay as they are
 bool mlp_train_f32_input_supported(const MlpMeta& m, uint32_t n, LossType loss) {
 	static const bool enabled = !(getenv("TCNN_MLP_F32_INPUT") && atoi(getenv("TCNN_MLP_F32_INPUT")) == 0);
-	return enabled && m.in_width == 64 && m.width == 64 && m.n_hidden_matmuls == 1 && n <= (1u << 25) && mlp_train_wave_supported(m, n, loss);
+	return enabled && m.in_width == 64 && m.width == 64 && m.n_hidden_matmuls <= 1 && n <= (1u << 25) && mlp_train_wave_supported(m, n, loss);
 }
 
 void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,

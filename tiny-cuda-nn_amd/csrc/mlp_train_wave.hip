@@ -46,6 +46,7 @@ TCNN_DEVICE h4 to_h4(f4 v) { return h4{(half_t)v[0], (half_t)v[1], (half_t)v[2],
 //   backward (half)(h > 0 ? v : 0): the fp16 bits of (half)v ANDed with 0xFFFF where h != +-0 and with 0 elsewhere
 //            (h >= 0 after ReLU; +0 for masked entries); "None" forces the mask to ones
 typedef int16_t ss2 __attribute__((ext_vector_type(2)));
+typedef uint16_t us2 __attribute__((ext_vector_type(2)));
 struct PackedAct {
 	h2 floor2;            // forward: {0, 0} for ReLU, {-inf, -inf} for None
 	uint32_t keep_bits;   // backward: 0 for ReLU, 0x00010001 for None
@@ -65,9 +66,27 @@ TCNN_DEVICE h4 act_forward4(uint32_t act, const PackedAct& pa, f4 x) {
 	}
 }
 TCNN_DEVICE h2 relu_mask(h2 d, h2 forward_value, uint32_t keep_bits) {
+#if defined(TCNN_WAVE_OLD_MASK)
 	const uint32_t t = (__builtin_bit_cast(uint32_t, forward_value) & 0x7FFF7FFFu) | keep_bits;
 	const ss2 keep = (ss2)(-__builtin_bit_cast(ss2, t)) >> 15;  // 0xFFFF where the (sign-stripped) forward value is not zero
 	return __builtin_bit_cast(h2, __builtin_bit_cast(uint32_t, d) & __builtin_bit_cast(uint32_t, keep));
+#else
+	// three instructions per pair (v_and_or_b32: strip the sign, force "keep"; v_pk_min_u16; v_pk_mul_lo_u16) where the sign-extending form took
+	// five: the sign-stripped forward value, as an unsigned 16-bit integer, is clamped to {0, 1} and multiplies the gradient's BITS
+#if defined(TCNN_HOST_EMU)
+	const uint32_t t = (__builtin_bit_cast(uint32_t, forward_value) & 0x7FFF7FFFu) | keep_bits;
+	const us2 pass = __builtin_elementwise_min(__builtin_bit_cast(us2, t), us2{1, 1});
+	return __builtin_bit_cast(h2, (us2)(__builtin_bit_cast(us2, d) * pass));
+#else
+	// (as instructions: told that the factor is 0 or 1, the compiler rewrites minimum and product as compares and selects on unpacked halves;
+	// and it does not form v_and_or_b32 out of a literal and a scalar register -- one of the two has to be a vector register)
+	uint32_t t, pass, masked;
+	asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(t) : "v"(__builtin_bit_cast(uint32_t, forward_value)), "s"(0x7FFF7FFFu), "v"(keep_bits));
+	asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(pass) : "v"(t));
+	asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(masked) : "v"(__builtin_bit_cast(uint32_t, d)), "v"(pass));
+	return __builtin_bit_cast(h2, masked);
+#endif
+#endif
 }
 template <bool GENERAL>
 TCNN_DEVICE h4 act_backward4(uint32_t act, const PackedAct& pa, f4 v, h4 forward_value) {
@@ -111,7 +130,10 @@ constexpr uint32_t MLP_WAVE_STRIP = 32, MLP_WAVE_THREADS = 256;
 // read 16 contiguous bytes, a strip's 8 KiB are fetched once and hit the L1 for the other fragment of the pair), held as fp32 until the
 // strip is used so that the loads stay a whole strip ahead, converted with k_identity_forward's arithmetic, and stored once as the encoded
 // matrix if the caller wants it for its context.
-template <uint32_t WIDTH, uint32_t IN, uint32_t HM, bool GENERAL, bool EXTERNAL, uint32_t MIN_WAVES = TCNN_MLP_WAVE_MIN_BLOCKS, bool F32IN = false>
+// FEW_DIMS: at most four (unpadded) outputs -- accumulator row 4g + r holds output 4r + g, so only element r = 0 of a lane carries a target, a
+// loss and a pdf then.  A compile-time switch: the other three elements' loads, branches and registers (six target registers live through the
+// whole forward pass at the 256-register limit) leave the instruction stream of the usual case; wider outputs run the FEW_DIMS = false instance.
+template <uint32_t WIDTH, uint32_t IN, uint32_t HM, bool GENERAL, bool EXTERNAL, uint32_t MIN_WAVES = TCNN_MLP_WAVE_MIN_BLOCKS, bool F32IN = false, bool FEW_DIMS = true>
 __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
                                                                         const half_t* __restrict__ params_t, const half_t* __restrict__ input,
                                                                         const MlpLossArgs la, half_t* __restrict__ output, half_t* __restrict__ dL_doutput,
@@ -121,7 +143,21 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	constexpr uint32_t N_PARAMS = WIDTH * IN + HM * WIDTH * WIDTH + 16 * WIDTH;
 	static_assert(NWAVES == 4 && WIDTH % 32 == 0 && IN % 32 == 0, "the final reduction pairs waves (0,2) and (1,3); operands are built from pairs of 16-row tiles");
 	constexpr uint32_t N_TILES = NB * FB + HM * NB * NB + NB;  // accumulator tiles per wave
-	__shared__ f4 exchange[N_TILES * 64];
+	// Transposes through LDS (TR_LDS): the weight-gradient MFMAs need their factors with the SAMPLES in the k slots.  A 16 x 16 tile as the
+	// accumulators hold it (lane (g, lr): neurons 4g .. 4g+3 of sample lr) is one 8-byte LDS store per lane into a sample-major image, and
+	// gfx950's transposing read (ds_read_b64_tr_b16, lds_read_tr4) hands lane (g, c) the four samples 4g .. 4g+3 of neuron c out of it --
+	// exactly what the MFMA against the identity + two conversions produced, on the LDS pipe, which this kernel otherwise leaves idle,
+	// instead of on the matrix and vector pipes, which bound it (34 of 126 MFMAs and 68 conversions per strip for the 64-neuron instance).
+	// The tiles of a wave are its own: no barrier, the LDS executes a wave's requests in order.  Layer j's activations are stored as soon as
+	// the forward pass has them; dL/d(pre-activation) of layer j reuses the region of layer j's activations once those have been read.
+#if defined(TCNN_WAVE_MFMA_TRANSPOSE)
+	constexpr bool TR_LDS = false;
+#else
+	constexpr bool TR_LDS = true;
+#endif
+	constexpr uint32_t TR_TILES = (HM + 1) * 2 * NB + 2;  // per wave: every layer's activations + the two dL/doutput tiles, 512 bytes each
+	constexpr uint32_t EXCH_F4 = N_TILES * 64, TR_F4 = TR_LDS ? NWAVES * TR_TILES * 32 : 0;
+	__shared__ f4 exchange[EXCH_F4 > TR_F4 ? EXCH_F4 : TR_F4];
 	__shared__ float red[MLP_WAVE_THREADS];
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
 	const uint32_t act = m.activation, out_act = m.output_activation;
@@ -214,9 +250,28 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	auto woutA = [&](uint32_t p) { return wfrag[F_WOUTA + p][lane]; };
 	auto winB = [&](uint32_t b, uint32_t p) { return wfrag[F_WINB + b * NP + p][lane]; };
 	auto woutT = [&](uint32_t b) { return wfrag_out_t[b][lane]; };
-	h4 eye;  // identity (16x16x16 B operand)
+	h4 eye;  // identity (16x16x16 B operand; the MFMA form of the transposes)
 #pragma unroll
 	for (uint32_t j = 0; j < 4; ++j) eye[j] = (half_t)(4 * g + j == lr ? 1.0f : 0.0f);
+	half_t* const tr = (half_t*)exchange + w * (TR_TILES * 256u);
+	// A tile's 64 words (sample s, neuron quad q; 8 bytes each) are laid out for the LDS banks, not row-major: the transposing read only
+	// cares which word a lane addresses.  Word (s, q) at 8-byte slot 32 (s >> 3) + 8 ((q + (s >> 3)) & 3) + (s & 7): the 16 lanes of a
+	// ds_write_b64 group (one q, all s) and the 32 lanes of a ds_read_b64_tr_b16 group (all q, eight s) each cover their bank window
+	// exactly once (row-major, 32-byte rows: four-way conflicts on the stores -- 3.3 M conflict cycles per launch, 2 us slower than the MFMA form).
+	auto tr_slot = [](uint32_t s_, uint32_t q_) { return 32u * (s_ >> 3) + 8u * ((q_ + (s_ >> 3)) & 3u) + (s_ & 7u); };
+	const uint32_t tr_store_at = 4u * tr_slot(lr, g);                        // lane (g, lr) holds neurons 4g .. 4g+3 of sample lr
+	const uint32_t tr_load_at = 4u * tr_slot(4u * g + (lr >> 2), lr & 3u);    // lds_read_tr4: lane i of group g addresses word (sample 4g + (i >> 2), quad i & 3)
+	auto tr_put = [&](uint32_t tile, h4 v) { *(h4*)(tr + tile * 256u + tr_store_at) = v; };
+	auto tr_get = [&](uint32_t tile) -> h4 {
+#if defined(TCNN_WAVE_MFMA_TRANSPOSE)
+		return h4{};
+#else
+		return lds_read_tr4(tr + tile * 256u + tr_load_at);
+#endif
+	};
+	auto tile_h = [&](uint32_t layer, uint32_t s_, uint32_t b_) { return (layer * 2u + s_) * NB + b_; };
+	constexpr uint32_t TILE_DY = (HM + 1) * 2 * NB;
+	const PackedAct pa_out = packed_act(out_act);
 
 	f4 accI[NB][FB], accH[HMX][NB][NB], accO[NB];
 #pragma unroll
@@ -258,21 +313,50 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 		}
 		if (strip + stride < n_strips) request_strip(strip + stride);
 		// this lane's targets: output 4r+g of sample perm32(s, lr)
-		float tgt[2][4];
+		constexpr bool few_dims = FEW_DIMS;
+		float tgt[2][4], pdf0[2];
+		h4 gy_external[2];
 #pragma unroll
 		for (uint32_t s = 0; s < 2; ++s) {
+			pdf0[s] = 1.0f;
+			gy_external[s] = h4{};
+			if constexpr (external) {  // one 8-byte load of outputs 4g .. 4g + 3 (transposed where it is used)
+				gy_external[s] = *(const h4*)(la.external_dL_doutput + ((base + perm32(s, lr)) * 16 + 4 * g));
+			} else if (has_pdf && g < la.dims) {
+				pdf0[s] = la.data_pdf[(base + perm32(s, lr)) * la.dims + g];
+			}
 #pragma unroll
 			for (uint32_t r = 0; r < 4; ++r) {
 				const uint32_t dim = 4 * r + g;
-				const bool live = !external && dim < la.dims;
-				const uint32_t target_idx = (base + perm32(s, lr)) * la.dims + dim;
-				tgt[s][r] = live ? la.targets[target_idx] : 0.0f;
+				tgt[s][r] = 0.0f;
+				if (!external && (r == 0 || !few_dims)) {
+					const bool live = dim < la.dims;
+					const uint32_t target_idx = (base + perm32(s, lr)) * la.dims + dim;
+					tgt[s][r] = live ? la.targets[target_idx] : 0.0f;
+				}
 			}
 		}
 
 		// ================= forward =================
+		// The weight fragments of a phase are requested from LDS at the start of the phase BEFORE (WF_AHEAD): read where they are used, every
+		// phase opened with a wait on the LDS -- 46 % of a wave's cycles were spent parked in s_waitcnt (profiles/r06_exp_notes.txt).
+		// (not in the wide-output instances: with four targets per lane live through the forward pass they are at the 256-register limit)
+#if defined(TCNN_WAVE_NO_PREFETCH)
+		constexpr bool WF_AHEAD = false;
+#else
+		constexpr bool WF_AHEAD = FEW_DIMS;
+#endif
 		h4 hp[HM + 1][2][NB];  // layer, sample block, neuron block: (neuron perm32(b, 4g+r), sample perm32(s, lr))
+		h8 w_hid[NB][NP];      // the next hidden layer's fragments (forward: whidA, backward: whidT), a phase ahead
+		h8 w_out[NP];
 		{
+			h8 w_in[NB][FP];
+			if constexpr (WF_AHEAD) {
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+					for (uint32_t p = 0; p < FP; ++p) w_in[b][p] = winA(b, p);
+			}
 			h8 xb[2][FP];  // first layer's B operand: k = feature 32p + 8g + j, n = sample perm32(s, lr)
 #pragma unroll
 			for (uint32_t s = 0; s < 2; ++s) {
@@ -282,50 +366,109 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 					xb[s][p] = pack8(to_h4(mfma_16x16x32(xq[2 * p], sel, zero4())), to_h4(mfma_16x16x32(xq[2 * p + 1], sel, zero4())));
 			}
 			sched_fence();
+			if constexpr (WF_AHEAD) {
+				if constexpr (HM > 0) {
+#pragma unroll
+					for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+						for (uint32_t p = 0; p < NP; ++p) w_hid[b][p] = whidA(0, b, p);
+				} else {
+#pragma unroll
+					for (uint32_t p = 0; p < NP; ++p) w_out[p] = woutA(p);
+				}
+			}
 #pragma unroll
 			for (uint32_t s = 0; s < 2; ++s)
 #pragma unroll
 				for (uint32_t b = 0; b < NB; ++b) {
 					f4 acc = zero4();
 #pragma unroll
-					for (uint32_t p = 0; p < FP; ++p) acc = mfma_16x16x32(winA(b, p), xb[s][p], acc);
+					for (uint32_t p = 0; p < FP; ++p) acc = mfma_16x16x32(WF_AHEAD ? w_in[b][p] : winA(b, p), xb[s][p], acc);
 					hp[0][s][b] = act_forward4<GENERAL>(act, pa, acc);
+					if constexpr (TR_LDS) tr_put(tile_h(0, s, b), hp[0][s][b]);
 				}
 			sched_fence();
 		}
 #pragma unroll
 		for (uint32_t j = 0; j < HM; ++j) {
+			h8 w_cur[NB][NP];
+			if constexpr (WF_AHEAD) {
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+					for (uint32_t p = 0; p < NP; ++p) w_cur[b][p] = w_hid[b][p];
+				if (j + 1 < HM) {
+#pragma unroll
+					for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+						for (uint32_t p = 0; p < NP; ++p) w_hid[b][p] = whidA(j + 1, b, p);
+				} else {
+#pragma unroll
+					for (uint32_t p = 0; p < NP; ++p) w_out[p] = woutA(p);
+				}
+			}
 #pragma unroll
 			for (uint32_t s = 0; s < 2; ++s)
 #pragma unroll
 				for (uint32_t b = 0; b < NB; ++b) {
 					f4 acc = zero4();
 #pragma unroll
-					for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(whidA(j, b, p), pack8(hp[j][s][2 * p], hp[j][s][2 * p + 1]), acc);
+					for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(WF_AHEAD ? w_cur[b][p] : whidA(j, b, p), pack8(hp[j][s][2 * p], hp[j][s][2 * p + 1]), acc);
 					hp[j + 1][s][b] = act_forward4<GENERAL>(act, pa, acc);
+					if constexpr (TR_LDS) tr_put(tile_h(j + 1, s, b), hp[j + 1][s][b]);
 				}
 			sched_fence();
 		}
+		// the backward pass's first fragments travel during the output layer and the loss
+		h4 w_out_t[NB];
+		if constexpr (WF_AHEAD && TR_LDS) {
+#pragma unroll
+			for (uint32_t b = 0; b < NB; ++b) w_out_t[b] = woutT(b);
+			if constexpr (HM > 0) {
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+					for (uint32_t p = 0; p < NP; ++p) w_hid[b][p] = whidT(HM - 1, b, p);
+			}
+		}
 		// ---- output layer + loss: (output 4r+g, sample perm32(s, lr))
-		h4 dyp[2];
+		// Every load of the strip has landed BEFORE its first store is issued, and no load follows the stores.  gfx9 counts loads and stores
+		// in ONE counter (vmcnt), and a register a load MAY still be writing -- on any path, taken or not: the targets of outputs 4 .. 15, the
+		// pdf -- is only reused behind "s_waitcnt vmcnt(0)".  With the loss of sample block 1 (and the backward pass's first register reuse)
+		// behind sample block 0's stores, those waits sat out the stores' round trip to HBM twice per strip: 47 % of a wave's cycles were spent
+		// parked in s_waitcnt, whatever the instruction count (profiles/r06_exp_notes.txt).
+#pragma unroll
+		for (uint32_t s = 0; s < 2; ++s) {
+#if !defined(TCNN_HOST_EMU)
+			asm volatile("" : "+v"(pdf0[s]));
+			if constexpr (external) asm volatile("" : "+v"(gy_external[s]));
+#pragma unroll
+			for (uint32_t r = 0; r < 4; ++r) asm volatile("" : "+v"(tgt[s][r]));
+#endif
+		}
+		h4 dyp[2], o_[2], gy_[2];
 #pragma unroll
 		for (uint32_t s = 0; s < 2; ++s) {
 			f4 acc = zero4();
 #pragma unroll
-			for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(woutA(p), pack8(hp[HM][s][2 * p], hp[HM][s][2 * p + 1]), acc);
-			const h4 o = h4{(half_t)act_forward<GENERAL>(out_act, acc[0]), (half_t)act_forward<GENERAL>(out_act, acc[1]), (half_t)act_forward<GENERAL>(out_act, acc[2]),
-			                (half_t)act_forward<GENERAL>(out_act, acc[3])};
+			for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(WF_AHEAD ? w_out[p] : woutA(p), pack8(hp[HM][s][2 * p], hp[HM][s][2 * p + 1]), acc);
+			o_[s] = act_forward4<GENERAL>(out_act, pa_out, acc);
+		}
+#pragma unroll
+		for (uint32_t s = 0; s < 2; ++s) {
+			const h4 o = o_[s];
 			const uint32_t i = base + perm32(s, lr);
 			h4 gy;
-			if (external) {  // one 8-byte load of outputs 4g .. 4g + 3, then the same 4 x 4 transpose as the stores below (it is its own inverse)
-				gy = wave_rows_transpose4(*(const h4*)(la.external_dL_doutput + (i * 16 + 4 * g)));
+			if (external) {  // the same 4 x 4 transpose as the stores below (it is its own inverse)
+				gy = wave_rows_transpose4(gy_external[s]);
 			} else {
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
 					const uint32_t dim = 4 * r + g;
 					gy[r] = (half_t)0.0f;
-					if (dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
-						const float pdf = has_pdf ? la.data_pdf[i * la.dims + dim] : 1.0f;  // rare: fetched where it is used
+					if ((r == 0 || !few_dims) && dim < la.dims) {  // relative_l2.h:57-61: padding outputs carry no loss
+						float pdf = pdf0[s];
+						if (r > 0 && has_pdf) pdf = la.data_pdf[i * la.dims + dim];  // (more than four outputs with a pdf: rare, fetched where it is used)
 						float value;
 						if constexpr (GENERAL) gy[r] = loss_element<true>(la.type, (float)o[r], tgt[s][r], pdf, n_total, la.loss_scale, value);
 						else gy[r] = loss_gradient_simple(relative, has_pdf, (float)o[r], tgt[s][r], pdf, n_total, inv_n_total, la.loss_scale, value);
@@ -333,17 +476,130 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 					}
 				}
 			}
-			// Lane (g, lr) holds outputs 4r + g of its sample.  Stored as they lie that is four 2-byte stores per matrix whose 64 lanes
-			// touch 64 different 32-byte sectors -- measured: 6 us of the kernel's 34 (profiles/r03_exp_notes.txt).  A 4 x 4 transpose
-			// over the four lane groups (register moves, no LDS) gives every lane outputs 4g .. 4g + 3: ONE 8-byte store.
-			if (output) *(h4*)(output + (i * 16 + 4 * g)) = wave_rows_transpose4(o);
-			if (dL_doutput) *(h4*)(dL_doutput + (i * 16 + 4 * g)) = wave_rows_transpose4(gy);
+			gy_[s] = gy;
+			// fully_fused_mlp.cu:760-763 (an fp16 value through fp32 and back is itself: the packed mask is the scalar form's select)
+			if constexpr (GENERAL) {
 #pragma unroll
-			for (uint32_t r = 0; r < 4; ++r) dyp[s][r] = (half_t)act_backward<GENERAL>(out_act, (float)gy[r], o[r]);  // fully_fused_mlp.cu:760-763
-			sched_fence();
+				for (uint32_t r = 0; r < 4; ++r) dyp[s][r] = (half_t)act_backward<GENERAL>(out_act, (float)gy[r], o[r]);
+			} else {
+				dyp[s] = pack4(relu_mask(__builtin_shufflevector(gy, gy, 0, 1), __builtin_shufflevector(o, o, 0, 1), pa_out.keep_bits),
+				               relu_mask(__builtin_shufflevector(gy, gy, 2, 3), __builtin_shufflevector(o, o, 2, 3), pa_out.keep_bits));
+			}
+			if constexpr (TR_LDS) tr_put(TILE_DY + s, dyp[s]);
+		}
+		sched_fence();
+		// Lane (g, lr) holds outputs 4r + g of its sample.  Stored as they lie that is four 2-byte stores per matrix whose 64 lanes
+		// touch 64 different 32-byte sectors -- measured: 6 us of the kernel's 34 (profiles/r03_exp_notes.txt).  A 4 x 4 transpose
+		// over the four lane groups (register moves, no LDS) gives every lane outputs 4g .. 4g + 3: ONE 8-byte store.
+#pragma unroll
+		for (uint32_t s = 0; s < 2; ++s) {
+			const uint32_t i = base + perm32(s, lr);
+			if (output) *(h4*)(output + (i * 16 + 4 * g)) = wave_rows_transpose4(o_[s]);
+			if (dL_doutput) *(h4*)(dL_doutput + (i * 16 + 4 * g)) = wave_rows_transpose4(gy_[s]);
 		}
 
 		sched_fence();
+		// ================= backward =================
+		if constexpr (TR_LDS) {
+			wave_lds_sync();  // this wave's tiles are in LDS
+			{  // dW_out[output][neuron] += dY * H_last^T  (accumulated unconditionally: a branch around the MFMAs costs the in-place accumulators)
+				const h8 dyq = pack8(tr_get(TILE_DY), tr_get(TILE_DY + 1));
+				h8 hq[NB];  // the layer's activations with the samples in k: lane lr <-> neuron perm32(b, lr), k = sample 8g+j
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b) hq[b] = pack8(tr_get(tile_h(HM, 0, b)), tr_get(tile_h(HM, 1, b)));
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b) accO[b] = mfma_16x16x32(dyq, hq[b], accO[b]);
+			}
+			h4 dap[2][NB];  // dL/d(pre-activation) of the current layer, same tile layout as hp
+#pragma unroll
+			for (uint32_t s = 0; s < 2; ++s)
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b) dap[s][b] = act_backward4<GENERAL>(act, pa, mfma_16x16x16(WF_AHEAD ? w_out_t[b] : woutT(b), dyp[s], zero4()), hp[HM][s][b]);
+			wave_lds_sync();  // the activations' region has been read: it takes the layer's dL/d(pre-activation)
+#pragma unroll
+			for (uint32_t s = 0; s < 2; ++s)
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b) tr_put(tile_h(HM, s, b), dap[s][b]);
+			sched_fence();
+#pragma unroll
+			for (int j = (int)HM - 1; j >= 0; --j) {
+				// the previous layer's dL/d(pre-activation) first (it needs nothing from LDS): the tiles just stored travel meanwhile
+				h4 prev[2][NB];
+				h8 w_cur[NB][NP];
+				if constexpr (WF_AHEAD) {
+#pragma unroll
+					for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+						for (uint32_t p = 0; p < NP; ++p) w_cur[b][p] = w_hid[b][p];
+					if (j > 0) {
+#pragma unroll
+						for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+							for (uint32_t p = 0; p < NP; ++p) w_hid[b][p] = whidT(j - 1, b, p);
+					}
+				}
+#pragma unroll
+				for (uint32_t s = 0; s < 2; ++s)
+#pragma unroll
+					for (uint32_t b = 0; b < NB; ++b) {
+						f4 acc = zero4();
+#pragma unroll
+						for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(WF_AHEAD ? w_cur[b][p] : whidT(j, b, p), pack8(dap[s][2 * p], dap[s][2 * p + 1]), acc);
+						prev[s][b] = act_backward4<GENERAL>(act, pa, acc, hp[j][s][b]);
+					}
+				sched_fence();
+				wave_lds_sync();
+				{  // dW_hid_j[out][in] += dA_{j+1} * H_j^T
+					h8 daq[NB], hq[NB];
+#pragma unroll
+					for (uint32_t b = 0; b < NB; ++b) {
+						daq[b] = pack8(tr_get(tile_h(j + 1, 0, b)), tr_get(tile_h(j + 1, 1, b)));
+						hq[b] = pack8(tr_get(tile_h(j, 0, b)), tr_get(tile_h(j, 1, b)));
+					}
+#pragma unroll
+					for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+						for (uint32_t i = 0; i < NB; ++i) accH[j][b][i] = mfma_16x16x32(daq[b], hq[i], accH[j][b][i]);
+				}
+				wave_lds_sync();
+#pragma unroll
+				for (uint32_t s = 0; s < 2; ++s)
+#pragma unroll
+					for (uint32_t b = 0; b < NB; ++b) {
+						dap[s][b] = prev[s][b];
+						tr_put(tile_h(j, s, b), dap[s][b]);
+					}
+				sched_fence();
+			}
+			if (want_dx) {  // dX^T = dA_0^T * W_in (below) needs nothing from LDS either: ahead of the last transposes
+#pragma unroll
+				for (uint32_t f = 0; f < FB; ++f) {
+					h4 d[2];
+#pragma unroll
+					for (uint32_t s = 0; s < 2; ++s) {
+						f4 acc = zero4();
+#pragma unroll
+						for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(pack8(dap[s][2 * p], dap[s][2 * p + 1]), winB(f, p), acc);
+						d[s] = to_h4(acc);
+					}
+					*(h8*)(dL_dinput + ((16 * f + lr) * n + base + 8 * g)) = pack8(d[0], d[1]);
+				}
+			}
+			sched_fence();
+			wave_lds_sync();
+			{  // dW_in[out][feature] += dA_0 * X^T
+				h8 daq[NB];
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b) daq[b] = pack8(tr_get(tile_h(0, 0, b)), tr_get(tile_h(0, 1, b)));
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+					for (uint32_t f = 0; f < FB; ++f) accI[b][f] = mfma_16x16x32(daq[b], xq[f], accI[b][f]);
+			}
+			wave_lds_sync();  // (the next strip's forward pass overwrites the tiles)
+			sched_fence();
+			continue;
+		}
 		// ================= backward =================
 		{  // dW_out[output][neuron] += dY * H_last^T  (accumulated unconditionally: a branch around the MFMAs costs the in-place accumulators)
 			const h8 dyq = pack8(to_h4(mfma_16x16x16(dyp[0], eye, zero4())), to_h4(mfma_16x16x16(dyp[1], eye, zero4())));
@@ -638,20 +894,24 @@ static void launch_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, 
                               const MlpF32Input* f32_input) {
 	const uint32_t blocks = mlp_train_wave_n_partials(m, n);
 	const MlpF32Input fin = f32_input ? *f32_input : MlpF32Input();
+	const bool few = la.external_dL_doutput != nullptr || la.dims <= 4u;  // (no loss, no targets with an external dL/doutput)
+#define TCNN_WAVE_LAUNCH(EXTERNAL_, F32IN_, FEW_)                                                                                                              \
+	TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, EXTERNAL_, MIN_WAVES, F32IN_, FEW_>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, \
+	            input, la, output, dL_doutput, dL_dinput, partials, block_sums, fin)
 	if (f32_input) {
 		if constexpr (IN == 64) {  // the instances mlp_train_f32_input_supported names
-			TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, false, MIN_WAVES, true>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la,
-			            output, dL_doutput, dL_dinput, partials, block_sums, fin);
+			if (few) TCNN_WAVE_LAUNCH(false, true, true); else TCNN_WAVE_LAUNCH(false, true, false);
 		} else {
 			throw std::runtime_error("mlp_train_wave: no fp32-input instance for this shape");
 		}
 	} else if (la.external_dL_doutput) {
-		TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, true, MIN_WAVES>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la, output,
-		            dL_doutput, dL_dinput, partials, block_sums, fin);
+		TCNN_WAVE_LAUNCH(true, false, true);
+	} else if (few) {
+		TCNN_WAVE_LAUNCH(false, false, true);
 	} else {
-		TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, false, MIN_WAVES>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, input, la, output,
-		            dL_doutput, dL_dinput, partials, block_sums, fin);
+		TCNN_WAVE_LAUNCH(false, false, false);
 	}
+#undef TCNN_WAVE_LAUNCH
 }
 // fp32 sample-major input (MlpF32Input): the 64-input instances -- two hidden layers (the benchmarks/mlp shape, which has a SIMD's registers to
 // itself) and one hidden layer (246 registers at two waves per SIMD with a strip of fp32 fragments in flight, no scratch); the 32-input

@@ -107,6 +107,11 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 	const uint32_t chunk_k = tid % IN, chunk_cc = tid / IN;
 	h8 pf = h8{};
 	if (tid < N_CHUNKS && blockIdx.x < n_tiles) pf = *(const h8*)(input + (size_t)chunk_k * n + (size_t)blockIdx.x * S + 8 * chunk_cc);
+#if !defined(TCNN_HOST_EMU)
+	// (waited for HERE: left pending into the loop, the staging store at the loop's top -- one block for the first and for every later
+	// iteration -- carries the wait for it, and on the later iterations that wait sits out dL/dinput's stores, see below)
+	asm volatile("" : "+v"(pf));
+#endif
 
 	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		if (tid < N_CHUNKS) *(h8*)(xT + chunk_k * SPX + 8 * chunk_cc) = pf;
@@ -116,6 +121,8 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 		}
 		// this lane's targets (output 4g+r of sample 16w+lr; waves 0..NT-1 own the output tiles)
 		float tgt[4], pdf[4];
+		h4 gy_external = h4{};
+		if (w < NT && la.external_dL_doutput) gy_external = *(const h4*)(la.external_dL_doutput + ((size_t)tile * S + 16 * w + lr) * 16 + 4 * g);
 #pragma unroll
 		for (uint32_t r = 0; r < 4; ++r) {
 			const uint32_t dim = 4 * g + r;
@@ -161,6 +168,16 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 			__syncthreads();
 		}
 		const half_t* hlast = hT + HM * S * LDA;
+		// Every load of the tile -- the next tile's input chunk, the targets, the pdf -- has landed BEFORE the tile's first store is issued, and
+		// no load follows the stores.  gfx9 counts loads and stores in ONE counter (vmcnt); a register that a load MAY still be writing on some
+		// path (the conditional target loads) is only reused behind "s_waitcnt vmcnt(0)", and the staging of the next tile's chunk at the
+		// loop's top sat directly behind dL/dinput's stores: three to five waits per tile that sat out a store's round trip to HBM (one of
+		// them between the prediction's store and dL/doutput's) with the workgroup's other waves waiting at the next barrier.
+#if !defined(TCNN_HOST_EMU)
+		asm volatile("" : "+v"(pf), "+v"(gy_external));
+#pragma unroll
+		for (uint32_t r = 0; r < 4; ++r) asm volatile("" : "+v"(tgt[r]), "+v"(pdf[r]));
+#endif
 		if (w < NT) {  // output layer + loss: (output 4g+r, sample 16w+lr)
 			const uint32_t t = w;
 			f4 acc = zero4();
@@ -170,7 +187,7 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 			const size_t i = (size_t)tile * S + 16 * t + lr;
 			h4 gy;
 			if (la.external_dL_doutput) {
-				gy = *(const h4*)(la.external_dL_doutput + i * 16 + 4 * g);
+				gy = gy_external;
 			} else {
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {

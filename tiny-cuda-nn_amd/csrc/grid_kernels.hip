@@ -969,6 +969,19 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 	half_t g[SPT][F], g_next[SPT][F];
 	constexpr bool second_order = SECOND_ORDER;
 	if (first_tile < plan.tiles) load_tile(first_tile, x, g);
+#if !defined(TCNN_HOST_EMU)
+	// The first tile's inputs are waited for HERE, not at the loop's top.  gfx9 counts loads and stores in one counter (vmcnt); the waits
+	// the compiler places in the loop header serve the first iteration (inputs still on their way) and every later one (inputs long there:
+	// the wait for the reservation atomics covered them) alike, and on the later ones "s_waitcnt vmcnt(0)" sits out the round trip of the
+	// queue stores the previous tile's append loop has just issued -- once per tile and workgroup.
+#pragma unroll
+	for (uint32_t s = 0; s < SPT; ++s) {
+#pragma unroll
+		for (uint32_t d = 0; d < D; ++d) asm volatile("" : "+v"(x[s][d]));
+#pragma unroll
+		for (uint32_t f = 0; f < F; ++f) asm volatile("" : "+v"(g[s][f]));
+	}
+#endif
 	__syncthreads();
 
 	for (uint32_t tile = first_tile; tile < plan.tiles; tile += plan.wgs_per_level) {
@@ -1100,6 +1113,17 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 			}
 		}
 		__syncthreads();
+#if !defined(TCNN_HOST_EMU)
+		// (the next tile's inputs, requested before the ranking barrier, are waited for here -- ahead of this tile's queue stores, see the
+		// note at the first tile's loads: nothing of this lane's is in flight when the stores go out, and nothing waits behind them)
+#pragma unroll
+		for (uint32_t s = 0; s < SPT; ++s) {
+#pragma unroll
+			for (uint32_t d = 0; d < D; ++d) asm volatile("" : "+v"(x_next[s][d]));
+#pragma unroll
+			for (uint32_t f = 0; f < F; ++f) asm volatile("" : "+v"(g_next[s][f]));
+		}
+#endif
 		// delta[b] := (position of the run in bucket b's queue) - (position of the run in the staging area);
 		// the counts are dead from here on: clear them for the next tile
 		if (nb <= BUCKET_THREADS) {

@@ -271,11 +271,6 @@ int tcnn_loss_evaluate(const char* loss_otype, tcnn_stream_t stream, uint32_t n,
  * tcnn_trainer_optimizer_step_range(s).  ready == NULL removes the hook. */
 int tcnn_trainer_set_gradient_ready_callback(tcnn_trainable_model_t* tm, void (*ready)(void* user, size_t begin, size_t end, tcnn_stream_t stream), void* user);
 int tcnn_trainer_set_backward_level_groups(tcnn_trainable_model_t* tm, uint32_t n_groups);
-/* One GPU, training_step(run_optimizer = 1): the encoding's backward pass and the optimizer step as a pipeline over three HIP streams in
- * `n_groups` groups of consecutive levels -- record scatter of group g+2 | owner pass of group g+1 | Adam on group g's parameters (the three
- * kernels are bound by instruction issue, memory latency and HBM bandwidth respectively).  Same kernels on sub-ranges: bit for bit the
- * one-stream step.  The caller's stream continues behind the whole pipeline.  1 = one stream. */
-int tcnn_trainer_set_backward_overlap(tcnn_trainable_model_t* tm, uint32_t n_groups);
 /* Data parallelism inside the library: `nccl_comm` is this rank's ncclComm_t (RCCL; NULL switches it off).  training_step then
  * all-reduces (sum) every ready range on an internal communication stream -- librccl.so is dlopen'ed by this call, the library does
  * not link it -- and, with run_optimizer = 1, steps each range as soon as ITS collective has finished while the later ones are still
@@ -324,12 +319,7 @@ int tcnn_trainer_set_profiling(tcnn_trainable_model_t* tm, int enable, int only_
 int tcnn_trainer_n_stages(void);
 const char* tcnn_trainer_stage_name(int stage);
 int tcnn_trainer_get_stage_times(tcnn_trainable_model_t* tm, double* total_ms, uint64_t* counts);
-/* training_step(run_optimizer = 1) on one GPU lets the bucket owners of the grid backward apply Adam to the table slices whose
- * exact gradient sums they hold in LDS (the rest of the parameters are stepped by the optimizer kernel as usual): same
- * arithmetic and results, bit for bit, as backward followed by optimizer_step.  Off by default (measured no faster: the
- * owner pass's own queue streaming leaves the optimizer's traffic nothing to hide behind); 1 turns it on. */
-int tcnn_trainer_set_fused_optimizer(tcnn_trainable_model_t* tm, int enable);
-/* Process-wide (default 1; TCNN_FUSED_MLP_TRAINING=0 in the environment starts with 0): training_step runs the network's forward +
+/* Process-wide (default 1): training_step runs the network's forward +
  * loss + backward as one kernel, and forward() / backward() -- of a Trainer and of a module -- keep only the encoded input in
  * the context: the backward pass recomputes the hidden activations inside the same kernel instead of reading saved ones.
  * 0: separate forward (saving activations), loss and backward kernels.  Same results; contexts made under one setting must be
@@ -351,8 +341,7 @@ int tcnn_set_grid_backward_mode(int mode);
 int tcnn_get_grid_backward_mode(void);
 /* Accumulator form of the bucket owners in mode 3, process-wide (same bits from all three): 0 = packed (default: both features of a
  * payload word in one 64-bit LDS word, half the LDS atomics and half the LDS; slices whose sums could leave int32 are redone wide),
- * 1 = 64-bit fixed point per value throughout, 2 = the packed kernel with every slice through its wide redo (tests).
- * Also selectable with TCNN_GRID_OWNER=packed|fixed64|wide. */
+ * 1 = 64-bit fixed point per value throughout, 2 = the packed kernel with every slice through its wide redo (tests). */
 int tcnn_set_grid_owner_mode(int mode);
 int tcnn_get_grid_owner_mode(void);
 /* Table slices the packed owners had to redo with 64 bits per value since the process started (their gradients failed the int32 bound:

@@ -146,11 +146,6 @@ def grid_backward_input_f32(g, dL_dy, dy_dx):
     return out
 
 
-def set_grid_forward_lds(limit_bytes, min_samples):
-    """Levels with tables up to limit_bytes are gathered out of LDS (k_grid_forward_lds) for batches of at least min_samples."""
-    lib().emu_set_grid_forward_lds(C.c_uint32(limit_bytes), C.c_uint32(min_samples))
-
-
 SLICED_F32, SLICED_F16, ATOMIC, BUCKETED = 0, 1, 2, 3
 
 

@@ -71,10 +71,6 @@ uint32_t emu_grid_forward_plan(const EmuGrid* e, uint32_t n, uint32_t tile_sampl
 }
 
 void emu_set_grid_owner_mode(int mode) { grid_owner_mode() = mode; }
-void emu_set_grid_forward_lds(uint32_t limit_bytes, uint32_t min_samples) {
-	grid_forward_lds_limit() = limit_bytes;
-	grid_forward_lds_min_samples() = min_samples;
-}
 // slices the packed owner kernel finished from its packed table / redid with 64 bits per value, since the last call
 void emu_grid_owner_stats(unsigned long* packed_wide) {
 	for (int i = 0; i < 2; ++i) {

@@ -47,15 +47,6 @@ def test_grid_forward_bit_exact(case):
     assert np.array_equal(np.transpose(dydx, (1, 0, 2)), ref_dydx)
     out_aos = emu.grid_forward(g, params, pos, soa=False, out_stride=L * F + 8)
     assert np.array_equal(out_aos[:, :L * F], ref)
-    # the same through the LDS-resident kernel for every level that fits (off by default), and with it switched off again
-    try:
-        emu.set_grid_forward_lds(152 * 1024, 0)
-        assert np.array_equal(emu.grid_forward(g, params, pos, soa=True).T, ref)
-        assert np.array_equal(emu.grid_forward(g, params, pos, soa=False, out_stride=L * F + 8)[:, :L * F], ref)
-        emu.set_grid_forward_lds(0, 0)
-        assert np.array_equal(emu.grid_forward(g, params, pos, soa=True).T, ref)
-    finally:
-        emu.set_grid_forward_lds(0, 4096)
 
 
 @pytest.mark.parametrize("case", GRID_CASES)

@@ -391,99 +391,6 @@ def test_training_step_data_pdf_external_gradient_and_input_gradient():
         tm.loss(ctx)
 
 
-@pytest.mark.parametrize("n,log2_t,min_exact_levels", [(4096, 15, 12), (512, 15, 12), (1 << 18, 19, 13)])
-def test_optimizer_inside_the_grid_backward_equals_the_separate_step(n, log2_t, min_exact_levels):
-    """training_step(run_optimizer=True) applies Adam to the bucketed levels inside the owner pass of the grid backward
-    (GridFusedAdam); results must equal backward + optimizer_step BIT FOR BIT: 16-bit and fp32 weights, both moments, the
-    per-parameter step counters, the gradients left behind -- in the deficit form (large batch), the counter form (small batch:
-    most hash entries untouched and skipped) and at the bench size.  The coarse levels whose gradients are summed by several
-    owners with fp16 atomics (not fused, and not reproducible from run to run) are compared within that rounding."""
-    T = tcnn()
-    cfg = config_hash(log2_hashmap_size=log2_t, per_level_scale=2.0 if log2_t == 19 else 1.5)
-    a, b = T.create_from_config(3, 4, cfg, seed=3), T.create_from_config(3, 4, cfg, seed=3)
-    a.set_fused_optimizer(True)
-    b.set_fused_optimizer(False)
-    for tm in (a, b):
-        w = tm.params_full_precision.clone()
-        w[tm.n_mlp_params:] *= 1.0e3
-        tm.set_params_full_precision(w)
-    og = O.grid_init(3, 16, 2, log2_t, 16, 2.0 if log2_t == 19 else 1.5)
-    nm = a.n_mlp_params
-    bounds = [(0, nm)] + [(nm + og.offsets[l] * 2, nm + og.offsets[l + 1] * 2) for l in range(16)]
-    pos = positions(n, 3, seed=41)
-    x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(targets_for(pos, 4)).cuda()
-    exact_levels = 0
-    ctx_a, ctx_b = a.training_step(x, t), b.training_step(x, t)  # one step from identical states
-    assert a.loss(ctx_a) == b.loss(ctx_b)
-    sa, sb = a.optimizer_state(), b.optimizer_state()
-    # the fused step keeps 32-bit deficits at large batches; the separate kernel keeps them as bytes, which hosts see as counters
-    assert sa[3] == (n >= 4096) and sb[3] is False and a.optimizer_step_count == b.optimizer_step_count == 1
-    as_counters = lambda st: (st[0], st[1], (1 - st[2]) if st[3] else st[2])
-    sa, sb = as_counters(sa), as_counters(sb)
-    for lo, hi in bounds:
-        ga, gb = a.param_gradients[lo:hi], b.param_gradients[lo:hi]
-        if torch.equal(ga.view(torch.int16), gb.view(torch.int16)):  # exactly accumulated part: everything downstream is identical
-            exact_levels += 1
-            assert torch.equal(a.params[lo:hi].view(torch.int16), b.params[lo:hi].view(torch.int16))
-            assert torch.equal(a.params_full_precision[lo:hi], b.params_full_precision[lo:hi])
-            for u, v in zip(sa[:3], sb[:3]):
-                assert torch.equal(u[lo:hi], v[lo:hi])
-        else:
-            assert (ga.float() - gb.float()).abs().max() <= 2.0 ** -7 * gb.float().abs().max()
-            assert (a.params_full_precision[lo:hi] - b.params_full_precision[lo:hi]).abs().max() <= 2.5e-2  # first Adam step: +-lr
-    assert exact_levels >= min_exact_levels, exact_levels
-    for _ in range(3):  # a few more steps: both keep training
-        la, lb = a.loss(a.training_step(x, t)), b.loss(b.training_step(x, t))
-    assert np.isfinite(la) and abs(la - lb) <= 0.05 * abs(lb)
-
-
-@pytest.mark.parametrize("n,log2_t,groups", [(1 << 18, 19, 2), (1 << 18, 19, 4), (1 << 18, 19, 16), (4096, 15, 3), (1 << 16, 19, 40)])
-def test_backward_and_optimizer_pipelined_over_three_streams_equal_the_one_stream_step(n, log2_t, groups):
-    """tcnn_trainer_set_backward_overlap: record scatter | owner pass | Adam of a single-GPU training step as a pipeline over three HIP
-    streams in groups of consecutive levels (csrc/api.hip: overlapped_backward_and_step).  The same kernels on sub-ranges of the level table,
-    each group with queues and counters of its own: gradients, 16-bit and fp32 weights, both moments and the per-parameter step counters
-    must equal the one-stream step's BIT FOR BIT wherever the one-stream step is itself reproducible (the coarse levels whose gradients
-    several owners sum with fp16 atomics are compared within that rounding, as in the fused-optimizer test above) -- after one step from
-    identical states, and the work that follows on the caller's stream (the next step, a loss read-back) sees the finished step."""
-    T = tcnn()
-    scale = 2.0 if log2_t == 19 else 1.5
-    cfg = config_hash(log2_hashmap_size=log2_t, per_level_scale=scale)
-    a, b = T.create_from_config(3, 4, cfg, seed=3), T.create_from_config(3, 4, cfg, seed=3)
-    a.set_backward_overlap(groups)
-    for tm in (a, b):
-        w = tm.params_full_precision.clone()
-        w[tm.n_mlp_params:] *= 1.0e3
-        tm.set_params_full_precision(w)
-    og = O.grid_init(3, 16, 2, log2_t, 16, scale)
-    nm = a.n_mlp_params
-    bounds = [(0, nm)] + [(nm + og.offsets[l] * 2, nm + og.offsets[l + 1] * 2) for l in range(16)]
-    pos = positions(n, 3, seed=43)
-    x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(targets_for(pos, 4)).cuda()
-    ctx_a, ctx_b = a.training_step(x, t), b.training_step(x, t)
-    assert a.loss(ctx_a) == b.loss(ctx_b) and a.optimizer_step_count == b.optimizer_step_count == 1
-    sa, sb = a.optimizer_state(), b.optimizer_state()
-    assert sa[3] == sb[3]
-    exact_levels = 0
-    for lo, hi in bounds:
-        ga, gb = a.param_gradients[lo:hi], b.param_gradients[lo:hi]
-        if torch.equal(ga.view(torch.int16), gb.view(torch.int16)):
-            exact_levels += 1
-            assert torch.equal(a.params[lo:hi].view(torch.int16), b.params[lo:hi].view(torch.int16))
-            assert torch.equal(a.params_full_precision[lo:hi], b.params_full_precision[lo:hi])
-            for u, v in zip(sa[:3], sb[:3]):
-                assert torch.equal(u[lo:hi], v[lo:hi])
-        else:
-            assert (ga.float() - gb.float()).abs().max() <= 2.0 ** -7 * gb.float().abs().max()
-            assert (a.params_full_precision[lo:hi] - b.params_full_precision[lo:hi]).abs().max() <= 2.5e-2
-    assert exact_levels >= 12, exact_levels  # the network's weights and every level with a sole owner per slice
-    # further steps: both trajectories keep learning at the same rate (the next step's forward pass reads what the adam lane wrote)
-    la = [a.loss(a.training_step(x, t)) for _ in range(5)]
-    lb = [b.loss(b.training_step(x, t)) for _ in range(5)]
-    assert np.allclose(la, lb, rtol=2e-2) and la[-1] < la[0]
-    # inference right behind a pipelined step (same stream: it must wait for the adam lane)
-    assert torch.isfinite(a.inference(x)).all()
-
-
 @pytest.mark.parametrize("scale,offset,loss,hidden_layers", [(1.0, 0.0, "L2", 2), (0.5, 0.25, "RelativeL2", 2), (1.0, 0.0, "RelativeL2", 1)])
 def test_network_kernel_reading_the_fp32_input_of_an_identity_encoding_itself(scale, offset, loss, hidden_layers):
     """BASELINE configs[1] (64 inputs -> 64 x 2 -> 16, Identity encoding): training_step lets the register-resident network kernel load the

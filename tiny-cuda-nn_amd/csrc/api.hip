@@ -258,8 +258,7 @@ static int initial_grid_backward_mode() {
 	return (int)GridBackwardMode::Bucketed;  // default: derive each corner once, bin by owner, exact fixed-point accumulation
 }
 static std::atomic<int> g_grid_backward_mode{initial_grid_backward_mode()};
-// TCNN_GRID_LDS_SLICE_BYTES: LDS bytes per table slice of the grid backward (tuning; 0 / unset = built-in default)
-static const uint32_t g_default_lds_slice_bytes = getenv("TCNN_GRID_LDS_SLICE_BYTES") ? (uint32_t)atoi(getenv("TCNN_GRID_LDS_SLICE_BYTES")) : 0u;
+static const uint32_t g_default_lds_slice_bytes = 0u;  // LDS bytes per table slice of the grid backward: 0 = the kernels' default (tcnn_trainer_set_lds_level_budget overrides)
 
 static thread_local bool g_prof_every_stage = false;  // inside the direct exchange: its Adam is one of the exchange's phases
 struct ProfScope {
@@ -676,9 +675,9 @@ static void encoding_forward(hipStream_t stream, const Model& md, uint32_t n, co
 //     instead of reading back what the forward pass would have had to write (2 B x width x layers per sample each way).
 // Off: k_mlp_forward (saves the activations) -> k_loss -> k_mlp_backward.  Same results either way (tests/test_emu_kernels.py).
 // training_step: an unpadded Identity encoding is evaluated by the network kernel's own input loads (MlpF32Input) where an instance offers it;
-// TCNN_MLP_F32_INPUT=0 / tcnn_set_fused_identity_input(0): always the separate encoding kernel (A/B runs, tests)
+// tcnn_set_fused_identity_input(0): always the separate encoding kernel (A/B runs, tests)
 static std::atomic<int> g_fused_identity_input{1};
-static std::atomic<int> g_fused_network_passes{!(getenv("TCNN_FUSED_MLP_TRAINING") && std::string(getenv("TCNN_FUSED_MLP_TRAINING")) == "0") ? 1 : 0};
+static std::atomic<int> g_fused_network_passes{1};
 static bool backward_recomputes(const Model& md) { return g_fused_network_passes.load() != 0 && md.has_network && mlp_train_supported(md.net.mlp); }
 
 // NetworkWithInputEncoding::forward_impl / inference_mixed_precision_impl (:60-81).  ctx == nullptr: inference.
@@ -754,7 +753,7 @@ struct LevelGroups {
 };
 static void encoding_backward(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const half_t* dL_denc,
                               uint32_t stride_k, uint32_t stride_i, half_t* dL_dparams, bool want_grads, bool accumulate, const float* input,
-                              uint32_t lds_level_budget, const GridFusedAdam* fused_adam = nullptr, const LevelGroups* groups = nullptr);
+                              uint32_t lds_level_budget, const LevelGroups* groups = nullptr);
 static uint32_t widest_matrix(const Model& md) {
 	uint32_t w = std::max(md.enc.padded_output_width, md.n_input_dims);
 	if (md.has_network) w = std::max(w, std::max(md.net.mlp.width * md.net.n_hidden_layers, md.net.mlp.padded_out));
@@ -854,7 +853,7 @@ static std::vector<std::pair<uint32_t, uint32_t>> split_levels(const GridMeta& g
 
 static void encoding_backward(hipStream_t stream, const Model& md, const ForwardCtx& ctx, uint32_t n, float* dL_dinput, const half_t* dL_denc,
                               uint32_t stride_k, uint32_t stride_i, half_t* dL_dparams, bool want_grads, bool accumulate, const float* input,
-                              uint32_t lds_level_budget, const GridFusedAdam* fused_adam, const LevelGroups* groups) {
+                              uint32_t lds_level_budget, const LevelGroups* groups) {
 	const EncodingDesc& e = md.enc;
 	if (e.is_grid) {
 		GridIO io = {input, in_stride_i(md), in_stride_d(), n, stride_k, stride_i};
@@ -868,7 +867,7 @@ static void encoding_backward(hipStream_t stream, const Model& md, const Forward
 			// no per-level random stream) and nothing else rides on the pass
 			const uint32_t L = e.grid.n_levels, F = e.grid.n_feat;
 			uint32_t n_groups = groups ? std::min(std::max(groups->n_groups, 1u), L) : 1u;
-			if (e.grid.max_level < 1.0f || e.grid.stochastic != 0u || fused_adam) n_groups = 1;
+			if (e.grid.max_level < 1.0f || e.grid.stochastic != 0u) n_groups = 1;
 			const std::vector<std::pair<uint32_t, uint32_t>> level_ranges = split_levels(e.grid, n_groups);
 			// one workspace for all groups: the largest any of them asks for (a group of later levels can bucket levels that the plan of
 			// the whole grid, which takes the first MAX_BUCKET_LEVELS eligible ones, left to the other kinds)
@@ -890,7 +889,6 @@ static void encoding_backward(hipStream_t stream, const Model& md, const Forward
 			}
 			ws.phase_hook = grid_backward_phase_hook;  // per-kernel timing when a profiler is attached
 			ws.hook_user = (void*)stream;
-			ws.fused_adam = mode == GridBackwardMode::Bucketed ? fused_adam : nullptr;
 			if (level_ranges.size() <= 1) {
 				grid_backward(stream, e.grid, io, dL_denc, grid_grads, accumulate, mode, lds_level_budget, ws);
 				if (groups && groups->ready) groups->ready(groups->ctx, md.n_mlp_params(), md.n_mlp_params() + (size_t)e.grid.offset[L] * F);
@@ -1074,11 +1072,6 @@ struct tcnn_trainable_model {
 	std::string hyper_json;
 	float* loss_scratch = nullptr;  // 1024 + 1 floats
 	std::unique_ptr<Profiler> profiler;  // null unless tcnn_trainer_set_profiling enabled it
-	// training_step(run_optimizer = true): the bucket owners of the grid backward apply Adam to their slices (GridFusedAdam).
-	// Off by default: measured, the owner pass then takes as long as owner pass + optimizer kernel together (0.153 vs 0.068 +
-	// 0.080 ms, step 0.362 vs 0.346 ms; no better with two owners per CU) -- its queue streaming already keeps HBM busy, so the
-	// optimizer's traffic finds nothing to hide behind (profiles/r02_exp_notes.txt).  TCNN_FUSED_OPTIMIZER=1 / the setter turn it on.
-	bool fused_optimizer = getenv("TCNN_FUSED_OPTIMIZER") && atoi(getenv("TCNN_FUSED_OPTIMIZER")) != 0;
 	// data-parallel hosts: called between backward and the optimizer (tcnn_trainer_set_gradient_exchange)
 	void (*exchange)(void* user, void* gradients_fp16, size_t n_params, tcnn_stream_t stream) = nullptr;
 	void* exchange_user = nullptr;
@@ -1086,13 +1079,7 @@ struct tcnn_trainable_model {
 	// tcnn_trainer_set_backward_level_groups, tcnn_trainer_enable_rccl)
 	void (*gradients_ready)(void* user, size_t begin, size_t end, tcnn_stream_t stream) = nullptr;
 	void* ready_user = nullptr;
-	uint32_t backward_level_groups = getenv("TCNN_BACKWARD_LEVEL_GROUPS") ? (uint32_t)std::max(1, atoi(getenv("TCNN_BACKWARD_LEVEL_GROUPS"))) : 1u;  // env: experiments
-	// training_step(run_optimizer = true) on one GPU: the encoding's backward in `backward_overlap` groups of consecutive levels, PIPELINED over
-	// three streams -- record scatter of group g+2 | owner pass of group g+1 | Adam on group g's parameters -- see overlapped_backward_and_step.
-	// 1 = off (one stream).  TCNN_BACKWARD_OVERLAP / tcnn_trainer_set_backward_overlap.
-	uint32_t backward_overlap = getenv("TCNN_BACKWARD_OVERLAP") ? (uint32_t)std::max(1, atoi(getenv("TCNN_BACKWARD_OVERLAP"))) : 1u;
-	struct OverlapLanes;
-	std::shared_ptr<OverlapLanes> lanes;
+	uint32_t backward_level_groups = 1u;
 	void* rccl_comm = nullptr;  // ncclComm_t
 	int rccl_ranks = 0;
 	// gradient exchange over peer-mapped memory (direct_exchange.h; tcnn_trainer_direct_*)
@@ -1839,12 +1826,7 @@ int tcnn_trainer_backward(tcnn_trainable_model_t* tm, tcnn_stream_t stream, cons
 // parameter instead of four; the 32-bit deficit form remains for the optimizer step fused into the grid backward and for
 // TCNN_ADAM_STEP_DEFICITS=1 (=0: counters, =2: bytes).
 static int choose_step_representation(const tcnn_trainable_model* tm) {
-	static const int forced = [] {
-		const char* e = getenv("TCNN_ADAM_STEP_DEFICITS");
-		return e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : -1;
-	}();
-	if (forced >= 0) return forced;
-	const int deficits = tm->fused_optimizer ? ADAM_STEPS_DEFICITS32 : ADAM_STEPS_DEFICITS8;
+	const int deficits = ADAM_STEPS_DEFICITS8;
 	if (!tm->md.enc.is_grid) return deficits;  // network weights are stepped every time
 	const auto& g = tm->md.enc.grid;
 	uint32_t largest = 0;
@@ -1886,13 +1868,12 @@ static void await_reduced_gradients(tcnn_trainable_model_t* tm, hipStream_t stre
 // Adam over [begin, end) of the current optimizer step (optimizer_advance opened it), on `stream`
 static void adam_range(tcnn_trainable_model_t* tm, hipStream_t stream, float loss_scale, size_t begin, size_t end, bool counts) {
 	// the trainer's 16-bit parameters are its rounded master weights unless a caller holds a pointer to them (params_exposed): Adam need
-	// not read the skipped ones back (AdamCore::half_follows_master).  TCNN_ADAM_HALF_FROM_MASTER=0: always read them back (A/B runs)
-	static const bool half_from_master = !(getenv("TCNN_ADAM_HALF_FROM_MASTER") && atoi(getenv("TCNN_ADAM_HALF_FROM_MASTER")) == 0);
+	// not read the skipped ones back (AdamCore::half_follows_master)
 	const size_t n = tm->md.n_params();
 	ProfScope prof(stream, STAGE_ADAM, counts);  // a ranged (bucketed) step is ONE optimizer step
 	adam_step(stream, tm->adam, (uint32_t)n, (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master, tm->params, tm->grads,
 	          tm->m1, tm->m2, tm->steps, tm->params_t_valid ? tm->params_t : nullptr, tm->md.has_network ? &tm->md.net.mlp : nullptr, (uint32_t)begin,
-	          (uint32_t)end, tm->steps_form, tm->step_deficits8, /*half_follows_master=*/half_from_master && !tm->params_exposed);
+	          (uint32_t)end, tm->steps_form, tm->step_deficits8, /*half_follows_master=*/!tm->params_exposed);
 	if (tm->ema) ema_step(stream, (uint32_t)n, tm->ema_decay, tm->optimizer_step, tm->params, tm->params_ema, tm->ema_tmp, (uint32_t)begin, (uint32_t)end);
 }
 
@@ -1949,12 +1930,6 @@ int tcnn_trainer_set_gradient_exchange(tcnn_trainable_model_t* tm, void (*exchan
 int tcnn_trainer_set_gradient_ready_callback(tcnn_trainable_model_t* tm, void (*ready)(void* user, size_t begin, size_t end, tcnn_stream_t stream), void* user) {
 	tm->gradients_ready = ready;
 	tm->ready_user = user;
-	return TCNN_OK;
-}
-// Single-GPU training_step(run_optimizer = 1): the encoding's backward pass and the optimizer pipelined over three streams in `n_groups` groups
-// of levels (overlapped_backward_and_step; bit for bit the one-stream step).  1 (the default unless TCNN_BACKWARD_OVERLAP is set): one stream.
-int tcnn_trainer_set_backward_overlap(tcnn_trainable_model_t* tm, uint32_t n_groups) {
-	tm->backward_overlap = n_groups ? n_groups : 1u;
 	return TCNN_OK;
 }
 int tcnn_trainer_set_backward_level_groups(tcnn_trainable_model_t* tm, uint32_t n_groups) {
@@ -2187,122 +2162,6 @@ struct ReadyTrampoline {
 };
 static bool wants_ready_ranges(const tcnn_trainable_model_t* tm) { return tm->gradients_ready || tm->rccl_comm; }
 
-// ------------------------------------------------------------------------------------------------
-// Backward + optimizer of a single-GPU training step as a PIPELINE over three streams (tcnn_trainer_set_backward_overlap).
-//
-// The three kernels behind the network's backward pass are bound by three different things (per-workgroup
-// clock stamps and PMC passes of round 4): the record scatter by what a CU can ISSUE (18.6 M VALU instructions), the owner pass by the
-// LATENCY of its queue stream (~8 us of non-streaming phases per workgroup life), Adam by HBM bandwidth.  Run one after the other they
-// leave two of the three resources idle at any time.  Their dependencies are per LEVEL: the owners of a level need that level's queues,
-// Adam needs that level's gradients.  So the levels go through in G groups (consecutive levels, about equal parameter counts --
-// the same split, the same kernels on sub-ranges and therefore bit for bit the same gradients and parameters as the one-stream pass):
-//
-//     compute stream : scatter(g0) scatter(g1) scatter(g2) ...                      [+ the join at the end]
-//     owner lane     :             owner(g0)   owner(g1)   owner(g2) ...            each behind its group's scatter (event)
-//     adam lane      : adam(net)               adam(g0)    adam(g1)    adam(g2) ... each behind its group's owners (event)
-//
-// Separate launches cost their ramp and tail (two groups one after the other: +26 us, round 3) -- here another lane's kernel fills them.
-// Every group has its own queues and counters (the lanes overlap in time).
-// ------------------------------------------------------------------------------------------------
-struct tcnn_trainable_model::OverlapLanes {
-	hipStream_t owner = nullptr, adam = nullptr;
-	std::vector<hipEvent_t> events;
-	size_t next = 0;
-	OverlapLanes() {
-		HIP_CHECK(hipStreamCreateWithFlags(&owner, hipStreamNonBlocking));
-		HIP_CHECK(hipStreamCreateWithFlags(&adam, hipStreamNonBlocking));
-	}
-	hipEvent_t event() {
-		if (next == events.size()) {
-			hipEvent_t e;
-			HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-			events.push_back(e);
-		}
-		return events[next++];
-	}
-	// `to` continues behind everything enqueued on `from` so far
-	void order(hipStream_t from, hipStream_t to) {
-		if (from == to) return;
-		hipEvent_t e = event();
-		HIP_CHECK(hipEventRecord(e, from));
-		HIP_CHECK(hipStreamWaitEvent(to, e, 0));
-	}
-	~OverlapLanes() {
-		for (auto e : events) (void)hipEventDestroy(e);
-		if (owner) (void)hipStreamDestroy(owner);
-		if (adam) (void)hipStreamDestroy(adam);
-	}
-};
-
-static void overlapped_backward_and_step(tcnn_trainable_model_t* tm, hipStream_t stream, uint32_t n, const float* input, const half_t* dL_denc, float loss_scale,
-                                         uint32_t n_groups) {
-	const Model& md = tm->md;
-	const EncodingDesc& e = md.enc;
-	if (!tm->lanes) tm->lanes = std::make_shared<tcnn_trainable_model::OverlapLanes>();
-	tcnn_trainable_model::OverlapLanes& lanes = *tm->lanes;
-	lanes.next = 0;
-	// TCNN_BACKWARD_OVERLAP_LANES (diagnostics): bit 0 = the owner passes on a lane of their own, bit 1 = Adam on a lane of its own; a lane that is
-	// switched off runs on the compute stream (3 = both, the design; 0 = the same launches, one stream: what grouping alone costs)
-	static const int lane_mask = getenv("TCNN_BACKWARD_OVERLAP_LANES") ? atoi(getenv("TCNN_BACKWARD_OVERLAP_LANES")) : 3;
-	const hipStream_t owner_lane = (lane_mask & 1) ? lanes.owner : stream, adam_lane = (lane_mask & 2) ? lanes.adam : stream;
-	const uint32_t F = e.grid.n_feat;
-	const size_t n_mlp = md.n_mlp_params();
-	const GridBackwardMode mode = GridBackwardMode::Bucketed;
-	const uint32_t budget = tm->lds_level_budget ? tm->lds_level_budget : g_default_lds_slice_bytes;
-	const std::vector<std::pair<uint32_t, uint32_t>> level_ranges = split_levels(e.grid, std::min(n_groups, e.grid.n_levels));
-	const size_t G = level_ranges.size();
-	// a workspace per group, carved out of one scratch block and one counter block of the compute stream
-	std::vector<GridBackwardWorkspace> ws(G);
-	std::vector<size_t> scratch_at(G), counters_at(G);
-	size_t scratch_bytes = 0, n_counters = 0;
-	for (size_t g = 0; g < G; ++g) {
-		ws[g] = grid_backward_workspace_size(grid_levels(e.grid, level_ranges[g].first, level_ranges[g].second), n, mode, budget);
-		scratch_at[g] = scratch_bytes;
-		counters_at[g] = n_counters;
-		scratch_bytes += next_multiple<size_t>(ws[g].scratch_bytes, 256);
-		n_counters += next_multiple<size_t>(ws[g].n_counters, 64);
-	}
-	Scratch queues;
-	uint32_t* counters = nullptr;
-	if (scratch_bytes) {
-		queues = Scratch(stream, scratch_bytes);
-		counters = ZeroedCounters::get(stream, n_counters);
-	}
-	optimizer_advance(tm, stream);
-	lanes.order(stream, owner_lane);  // both lanes start behind the network's backward pass (and whatever else the compute stream holds)
-	lanes.order(stream, adam_lane);
-	adam_range(tm, adam_lane, loss_scale, 0, n_mlp, /*counts=*/true);  // the network's weights: their gradients are final already
-	half_t* grid_grads = tm->grads + n_mlp;
-	struct CountsGuard {
-		~CountsGuard() { g_phase_hook_counts = true; }
-	} counts_guard;
-	GridIO io = {input, in_stride_i(md), in_stride_d(), n, n, 1u};
-	for (size_t g = 0; g < G; ++g) {
-		const uint32_t a = level_ranges[g].first, b = level_ranges[g].second;
-		const GridMeta sub = grid_levels(e.grid, a, b);
-		GridBackwardWorkspace w = ws[g];
-		if (w.scratch_bytes) {
-			w.scratch = (unsigned char*)queues.ptr + scratch_at[g];
-			w.counters = counters + counters_at[g];
-		}
-		w.phase_hook = grid_backward_phase_hook;
-		g_phase_hook_counts = g == 0;  // one backward pass per step, however many launches it takes
-		const half_t* dy = dL_denc + (size_t)a * F * io.stride_k;
-		half_t* grads = grid_grads + (size_t)e.grid.offset[a] * F;
-		w.phases = 1u;  // pass A on the compute stream
-		w.hook_user = (void*)stream;
-		grid_backward(stream, sub, io, dy, grads, /*accumulate=*/false, mode, budget, w);
-		lanes.order(stream, owner_lane);
-		w.phases = 2u;  // pass B on the owner lane
-		w.hook_user = (void*)owner_lane;
-		grid_backward(owner_lane, sub, io, dy, grads, /*accumulate=*/false, mode, budget, w);
-		lanes.order(owner_lane, adam_lane);
-		adam_range(tm, adam_lane, loss_scale, n_mlp + (size_t)e.grid.offset[a] * F, n_mlp + (size_t)e.grid.offset[b] * F, /*counts=*/false);
-	}
-	lanes.order(owner_lane, stream);
-	lanes.order(adam_lane, stream);  // the step is complete (the adam lane is behind every owner) before anything else runs on the compute stream
-}
-
 // training_step fast path (g_fused_network_passes): encoding forward, ONE kernel for the network's forward + loss + backward, encoding
 // backward.  Same results as forward() + backward() (tests/test_emu_kernels.py); the returned context carries the
 // prediction, dL_doutput, the loss and the encoded input, but no hidden activations.
@@ -2354,12 +2213,7 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 
 	const bool need_denc = (want_grads && e.n_params > 0) || dL_dinput;
 	Scratch denc;
-	// The weight-gradient finalize (a 5 us kernel that is all launch latency: 14.7 MB of slabs -> 7168 sums) beside the encoding's backward
-	// instead of in front of it: on a lane of its own behind the network kernel, joined before anything reads the gradients.  Only where
-	// nobody is told "the network's gradients are ready" before the join (the data-parallel hooks) -- TCNN_FINALIZE_ASIDE=1 (experiment).
-	static const bool finalize_aside_enabled = getenv("TCNN_FINALIZE_ASIDE") && atoi(getenv("TCNN_FINALIZE_ASIDE")) != 0;
-	const bool finalize_aside = finalize_aside_enabled && want_grads && need_denc && e.is_grid && e.n_params > 0 && !wants_ready_ranges(tm);
-	Scratch partials;  // (lives until the join below: the lane reads it while the compute stream moves on)
+	Scratch partials;
 	{
 		ProfScope prof(stream, STAGE_MLP_TRAIN);
 		Scratch params_t_local;
@@ -2382,91 +2236,16 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 		                                  external_dL_dy ? nullptr : c->dL_doutput.as<half_t>(), need_denc ? denc.as<half_t>() : nullptr,
 		                                  want_grads ? partials.as<float>() : nullptr, external_dL_dy ? nullptr : c->block_sums.as<float>(),
 		                                  input_by_network ? &f32_input : nullptr);
-		if (want_grads && !finalize_aside) mlp_finalize_gradients(stream, md.net.mlp, n_partials, partials.as<float>(), tm->grads, accumulate, order);
-		if (finalize_aside) {
-			if (!tm->lanes) tm->lanes = std::make_shared<tcnn_trainable_model::OverlapLanes>();
-			tm->lanes->next = 0;
-			tm->lanes->order(stream, tm->lanes->owner);
-			mlp_finalize_gradients(tm->lanes->owner, md.net.mlp, n_partials, partials.as<float>(), tm->grads, accumulate, order);
-		}
+		if (want_grads) mlp_finalize_gradients(stream, md.net.mlp, n_partials, partials.as<float>(), tm->grads, accumulate, order);
 	}
-	struct JoinLane {  // the compute stream continues behind the lane wherever this function leaves (also by exception)
-		tcnn_trainable_model_t* tm;
-		hipStream_t stream;
-		bool armed;
-		void join() {
-			if (armed) tm->lanes->order(tm->lanes->owner, stream);
-			armed = false;
-		}
-		~JoinLane() {
-			try {
-				join();
-			} catch (...) {
-			}
-		}
-	} finalize_join = {tm, stream, finalize_aside};
 	ReadyTrampoline tramp = {tm, stream};
 	LevelGroups level_groups = {tm->backward_level_groups, want_grads && wants_ready_ranges(tm) ? &ReadyTrampoline::call : nullptr, &tramp};
-	const bool grouped_backward = level_groups.n_groups > 1;
 	if (level_groups.ready) level_groups.ready(&tramp, 0, md.n_mlp_params());  // the network's gradients: the first range of the step
-	// The optimizer step of the bucketed levels happens inside the grid backward (GridFusedAdam) when this call owns the whole
-	// step: one GPU, gradients overwritten, plain Adam (no EMA copy to maintain), parameters the trainer's own.
-	bool fused_level[MAX_N_LEVELS] = {};
-	bool optimizer_opened = false;
-	// the pipelined form (overlapped_backward_and_step): this call owns the whole step on one GPU and every level runs the bucketed pass
-	const bool overlap = run_optimizer && tm->backward_overlap > 1 && !tm->fused_optimizer && want_grads && !accumulate && !dL_dinput && e.is_grid && e.n_params > 0 && !tm->ema &&
-	                     !tm->exchange && !tm->direct.active() && !wants_ready_ranges(tm) && !grouped_backward && !use_inference_params && e.grid.stochastic == 0u &&
-	                     e.grid.max_level >= 1.0f && (GridBackwardMode)g_grid_backward_mode.load() == GridBackwardMode::Bucketed;
-	if (overlap) {
-		finalize_join.join();
-		overlapped_backward_and_step(tm, stream, n, input, denc.as<half_t>(), loss_scale, tm->backward_overlap);
-		*ctx_out = c.release();
-		return TCNN_OK;
-	}
 	if (need_denc) {
-		const size_t n_mlp = md.n_mlp_params();
-		const bool fuse = run_optimizer && tm->fused_optimizer && want_grads && !accumulate && e.is_grid && e.n_params > 0 && !tm->ema && !tm->exchange && !tm->direct.active() && !wants_ready_ranges(tm) && !grouped_backward &&
-		                  tm->global_batch == 0 && !use_inference_params && e.grid.stochastic == 0u &&
-		                  (GridBackwardMode)g_grid_backward_mode.load() == GridBackwardMode::Bucketed;
-		AdamCore core;
-		GridFusedAdam fa;
-		if (fuse) {
-			optimizer_advance(tm, stream);
-			optimizer_opened = true;
-			if (tm->steps_form == ADAM_STEPS_DEFICITS8) throw std::runtime_error("fused optimizer: unexpected byte form of the step deficits");
-			core = make_adam_core(tm->adam, (uint32_t)n_mlp, loss_scale, tm->optimizer_step, tm->steps_form);
-			fa.core = &core;
-			fa.master = tm->master + n_mlp;
-			fa.params = tm->params + n_mlp;
-			fa.m1 = tm->m1 + n_mlp;
-			fa.m2 = tm->m2 + n_mlp;
-			fa.steps = tm->steps + n_mlp;
-			fa.stream_state = adam_streams_its_state((uint32_t)md.n_params());
-			fa.fused_level = fused_level;
-		}
-		encoding_backward(stream, md, fc, n, dL_dinput, denc.as<half_t>(), n, 1u, tm->grads, want_grads, accumulate, input, tm->lds_level_budget,
-		                  fuse ? &fa : nullptr, &level_groups);
+		encoding_backward(stream, md, fc, n, dL_dinput, denc.as<half_t>(), n, 1u, tm->grads, want_grads, accumulate, input, tm->lds_level_budget, &level_groups);
 	}
-	finalize_join.join();  // the network's gradients are final on the compute stream from here on
 	*ctx_out = c.release();
-	if (run_optimizer && optimizer_opened) {  // the rest of the step: network weights and the levels the backward did not step
-		std::vector<size_t> begins, ends;
-		const size_t n_mlp = md.n_mlp_params(), F = e.grid.n_feat;
-		begins.push_back(0);
-		ends.push_back(n_mlp);
-		for (uint32_t l = 0; l < e.grid.n_levels; ++l) {
-			if (fused_level[l]) continue;
-			const size_t b = n_mlp + (size_t)e.grid.offset[l] * F, en = n_mlp + (size_t)e.grid.offset[l + 1] * F;
-			if (ends.back() == b) ends.back() = en;
-			else {
-				begins.push_back(b);
-				ends.push_back(en);
-			}
-		}
-		optimizer_step_ranges(tm, stream, loss_scale, begins.size(), begins.data(), ends.data(), /*advance=*/false, /*opens_profiled_step=*/true);
-	} else if (run_optimizer) {
-		return finish_training_step(tm, stream, loss_scale);
-	}
+	if (run_optimizer) return finish_training_step(tm, stream, loss_scale);
 	TCNN_API_END
 }
 
@@ -2851,10 +2630,6 @@ int tcnn_trainer_get_stage_times(tcnn_trainable_model_t* tm, double* total_ms, u
 		counts[i] = tm->profiler->count[i];
 	}
 	TCNN_API_END
-}
-int tcnn_trainer_set_fused_optimizer(tcnn_trainable_model_t* tm, int enable) {
-	tm->fused_optimizer = enable != 0;
-	return TCNN_OK;
 }
 int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes) {
 	tm->lds_level_budget = bytes;

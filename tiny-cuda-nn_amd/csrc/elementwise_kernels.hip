@@ -517,8 +517,7 @@ AdamCore make_adam_core(const AdamHyper& h, uint32_t n_matrix_weights, float los
 	a.non_matrix_l2_reg = h.non_matrix_l2_reg;
 	a.steps_done = current_step - 1u;
 	a.deficit = steps_form;
-	static const bool dense = !(getenv("TCNN_ADAM_DENSE_STORE") && atoi(getenv("TCNN_ADAM_DENSE_STORE")) == 0);  // =0: the sparse form, for A/B runs
-	a.dense_store = dense ? 1 : 0;
+	a.dense_store = 1;
 	a.half_follows_master = 0;
 	return a;
 }

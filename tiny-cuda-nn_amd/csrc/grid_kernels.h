@@ -50,11 +50,6 @@ struct GridIO {
 void grid_forward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* params, half_t* out,
                   float* dy_dx);
 
-// Tuning knobs of the forward pass (process-wide): a level whose table is at most `grid_forward_lds_limit()` bytes (TCNN_GRID_FWD_LDS_BYTES;
-// default 0 = never: measured slower on MI355X) is gathered out of LDS by its own launch (k_grid_forward_lds) when the batch has at
-// least `grid_forward_lds_min_samples()` samples; same bits either way.
-uint32_t& grid_forward_lds_limit();
-uint32_t& grid_forward_lds_min_samples();
 
 // Backward into grid_gradient (half).  accumulate == false overwrites (GradientMode::Overwrite: any zeroing
 // the chosen mode needs is done here, the caller does not memset), true adds to what is there.
@@ -70,22 +65,6 @@ uint32_t& grid_forward_lds_min_samples();
 //                          keeps one such buffer per stream and never clears it again.
 // lds_slice_bytes: LDS bytes one workgroup devotes to its table slice (0 = default 128 KiB).
 enum class GridBackwardMode : int { SlicedF32 = 0, SlicedF16 = 1, Atomic = 2, Bucketed = 3 };
-// Optimizer step inside the bucketed backward (optional).  The owner of a table slice holds the slice's exact gradient sums in
-// LDS; instead of only storing them for a later optimizer kernel to read back, it applies Adam (adam_device.h: the arithmetic
-// of the stand-alone kernel, bit for bit) to the slice's parameters right there -- the optimizer's HBM streaming then overlaps
-// the LDS-bound accumulation of the other owners instead of following it.  Only levels whose slices have a single owner
-// (bucketed, not split over sample chunks) are stepped here; `fused_level[l]` tells the caller which, the rest is its job.
-// Gradients are still stored (param_gradients stays valid).  Array pointers are indexed from the GRID's first parameter.
-struct AdamCore;
-struct GridFusedAdam {
-	const AdamCore* core = nullptr;  // host copy; n_matrix_weights = parameters that precede the grid's in the trainer's arrays
-	float* master = nullptr;         // fp32 weights
-	half_t* params = nullptr;        // 16-bit weights
-	float *m1 = nullptr, *m2 = nullptr;
-	uint32_t* steps = nullptr;
-	bool stream_state = false;       // non-temporal accesses to the optimizer state (elementwise_kernels.h: adam_streams_its_state)
-	bool* fused_level = nullptr;     // out, [n_levels]
-};
 struct GridBackwardWorkspace {
 	void* scratch = nullptr;
 	size_t scratch_bytes = 0;
@@ -95,20 +74,15 @@ struct GridBackwardWorkspace {
 	// phase 0: record scatter (bucketed mode only), 1: accumulation + stores (every mode)
 	void (*phase_hook)(void* user, int phase, int begin) = nullptr;
 	void* hook_user = nullptr;
-	const GridFusedAdam* fused_adam = nullptr;  // Bucketed mode, accumulate == false, first-order scatter only
-	// Bucketed mode: which half of the pass this call launches -- bit 0: pass A (record scatter), bit 1: pass B (owners + the other kinds
-	// of levels).  A caller that pipelines groups of levels over several streams (api.hip: overlapped backward) launches the halves
-	// separately, on different streams, with an event between them; both calls must see the same meta / io / workspace.
-	uint32_t phases = 3;
 };
 GridBackwardWorkspace grid_backward_workspace_size(const GridMeta& meta, uint32_t n, GridBackwardMode mode, uint32_t lds_slice_bytes);
 void grid_backward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* dL_dy, half_t* grid_gradient, bool accumulate,
                    GridBackwardMode mode, uint32_t lds_slice_bytes, const GridBackwardWorkspace& workspace = GridBackwardWorkspace());
 
-// Accumulator form of the bucket owners (pass B of the Bucketed mode), process-wide; initial value from TCNN_GRID_OWNER=packed|fixed64|wide:
+// Accumulator form of the bucket owners (pass B of the Bucketed mode), process-wide (tcnn_set_grid_owner_mode):
 //   0 packed  -- the two features of a payload word share one 64-bit LDS word (one ds_add_u64 per table entry at F = 2, 8 bytes of
 //                LDS per entry, two workgroups per CU); a slice whose gradients could leave int32 is redone with 64 bits per value
-//   1 fixed64 -- 64 bits per value throughout (k_grid_backward_sliced; also what odd F and the fused optimizer step run)
+//   1 fixed64 -- 64 bits per value throughout (k_grid_backward_sliced; also what odd F runs)
 //   2 wide    -- the packed kernel, every slice through its 64-bit redo (tests of that path)
 // All three produce the same bits.
 int& grid_owner_mode();

@@ -3,7 +3,6 @@
 // that indices AND interpolated features are bit-identical to the CPU oracle.
 #include "grid_kernels.h"
 #include "elementwise_kernels.h"  // Pcg32 (stochastic interpolation)
-#include "adam_device.h"          // the optimizer step of the owner pass (GridFusedAdam)
 #include "exp_diag.h"             // experiment switches: compile-time zeros in the product build
 
 #include <algorithm>
@@ -403,67 +402,6 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward_tiles(const GridM
 	} else {
 		grid_forward_tile<D, F, SPT, false>(lv, io, grid, level, first, x, out);
 	}
-}
-
-// ---------------------------------------------------------------------------------------------
-// forward for the levels whose whole table fits a CU's LDS (the coarse levels of every configuration; all levels of the small
-// hash-table configurations): the workgroup copies the table into LDS once (coalesced 16-byte loads) and gathers its share of the
-// samples from there -- a random 4-byte LDS gather costs ~16 clk per wave instruction where the L2-resident gather above pays
-// ~148 (a quarter of that when the table happens to sit in the CU's L1), and none of it touches the L2's line rate, which is what
-// bounds the levels that stay in the tiled kernel.  One launch per such level (dynamic LDS = that table), 1024 threads, one
-// contiguous share of the samples per workgroup; same index / weight / fma-chain code as above: bit-identical output.
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t FWD_LDS_THREADS = 1024;
-template <uint32_t D, uint32_t F, bool FAST>
-TCNN_DEVICE void grid_forward_lds_samples(const Level<D>& lv, const GridIO& io, const half_t* lds_grid, uint32_t level, uint32_t begin, uint32_t end,
-                                          half_t* __restrict__ out) {
-	constexpr uint32_t NP = (F + 1) / 2, NC = 1u << D, U = 2;  // U samples in flight per lane
-	for (uint32_t base = begin + threadIdx.x; base < end; base += FWD_LDS_THREADS * U) {
-		float x[U][D];
-#pragma unroll
-		for (uint32_t u = 0; u < U; ++u) load_position<D, true>(io, min(base + u * FWD_LDS_THREADS, end - 1u), x[u]);
-		Cell<D> c[U];
-		h2 val[U][NC][NP];
-#pragma unroll
-		for (uint32_t u = 0; u < U; ++u) {
-			c[u] = make_cell<D, FAST>(lv, x[u]);
-#pragma unroll
-			for (uint32_t idx = 0; idx < NC; ++idx) load_features<F>(lds_grid + (size_t)corner_index<D, FAST>(lv, c[u], idx) * F, val[u][idx]);
-		}
-#pragma unroll
-		for (uint32_t u = 0; u < U; ++u) {
-			h2 result[NP];
-#pragma unroll
-			for (uint32_t p = 0; p < NP; ++p) result[p] = h2{(half_t)0.0f, (half_t)0.0f};
-#pragma unroll
-			for (uint32_t idx = 0; idx < NC; ++idx) {  // corner order and fp16 fma chain of grid.h:144-163
-				const half_t wh = to_half_rn(corner_weight<D>(c[u], idx));
-				const h2 w2 = h2{wh, wh};
-#pragma unroll
-				for (uint32_t p = 0; p < NP; ++p) result[p] = fma_h2(w2, val[u][idx][p], result[p]);
-			}
-			const uint32_t i = base + u * FWD_LDS_THREADS;
-			if (i < end) {
-#pragma unroll
-				for (uint32_t f = 0; f < F; ++f) out[(size_t)(level * F + f) * io.stride_k + (size_t)i * io.stride_i] = result[f / 2][f % 2];
-			}
-		}
-	}
-}
-
-template <uint32_t D, uint32_t F>
-__global__ void __launch_bounds__(FWD_LDS_THREADS) k_grid_forward_lds(const GridMeta meta, const GridIO io, const uint32_t level, const uint32_t samples_per_block,
-                                                                       const half_t* __restrict__ params, half_t* __restrict__ out) {
-	TCNN_DYN_LDS(lds_raw);
-	const Level<D> lv = make_level<D>(meta, level);
-	const half_t* __restrict__ grid = params + (size_t)meta.offset[level] * F;
-	const uint32_t n_vec = lv.hashmap_size * F / 8u;  // 16-byte pieces: level sizes are multiples of 8 entries, the host checked the alignment
-	for (uint32_t e = threadIdx.x; e < n_vec; e += FWD_LDS_THREADS) ((u4*)lds_raw)[e] = ((const u4*)grid)[e];
-	__syncthreads();
-	const uint32_t begin = blockIdx.x * samples_per_block, end = min(begin + samples_per_block, io.n);
-	if (begin >= end) return;
-	if (lv.fast) grid_forward_lds_samples<D, F, true>(lv, io, (const half_t*)lds_raw, level, begin, end, out);
-	else grid_forward_lds_samples<D, F, false>(lv, io, (const half_t*)lds_raw, level, begin, end, out);
 }
 
 // =============================================================================================
@@ -1170,59 +1108,6 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 	}
 }
 
-// GridFusedAdam as the kernel sees it
-struct FusedAdamArgs {
-	AdamCore core;
-	float* master;
-	half_t* params;
-	float *m1, *m2;
-	uint32_t* steps;
-	int enabled, stream;
-};
-
-// Adam on 4 consecutive parameters of a slice whose exact gradients `g` were just read out of the LDS table: the body of
-// k_adam_step's four-parameter path (elementwise_kernels.hip), same arithmetic (adam_one), same step-counter forms
-template <bool STREAM>
-TCNN_DEVICE void fused_adam4(const FusedAdamArgs& fa, size_t p, h4 g) {
-	const AdamCore& a = fa.core;
-	f4 w = adam_load<STREAM>((const f4*)(fa.master + p));
-	f4 m1 = adam_load<STREAM>((const f4*)(fa.m1 + p));
-	f4 m2 = adam_load<STREAM>((const f4*)(fa.m2 + p));
-	u4 st = adam_load<STREAM>((const u4*)(fa.steps + p));
-	h4 wh = h4{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
-	uint32_t updated = 0;
-#pragma unroll
-	for (uint32_t j = 0; j < 4; ++j) {
-		float wj = w[j], m1j = m1[j], m2j = m2[j];
-		uint32_t sj = a.deficit ? a.steps_done - st[j] : st[j];
-		if (adam_one(a, a.n_matrix_weights + (uint32_t)p + j, (float)g[j], wj, m1j, m2j, sj)) {
-			w[j] = wj;
-			m1[j] = m1j;
-			m2[j] = m2j;
-			if (!a.deficit) st[j] = sj;
-			wh[j] = to_half_rn(wj);
-			updated |= 1u << j;
-		} else if (a.deficit) {
-			st[j] += 1u;
-		}
-	}
-	if (a.deficit && updated != 0xFu) adam_store<STREAM>((u4*)(fa.steps + p), st);
-	if (updated != 0u || a.dense_store) {
-		if (updated != 0xFu) {  // keep the 16-bit weights of the parameters that were skipped
-			const h4 old = *(const h4*)(fa.params + p);
-#pragma unroll
-			for (uint32_t j = 0; j < 4; ++j) {
-				if (!((updated >> j) & 1u)) wh[j] = old[j];
-			}
-		}
-		adam_store<STREAM>((f4*)(fa.master + p), w);
-		adam_store<STREAM>((f4*)(fa.m1 + p), m1);
-		adam_store<STREAM>((f4*)(fa.m2 + p), m2);
-		if (!a.deficit) adam_store<STREAM>((u4*)(fa.steps + p), st);
-		*(h4*)(fa.params + p) = wh;
-	}
-}
-
 // What every owner of a (bucket, chunk) does last.  Every thread read the counters before the barriers of the caller: they end
 // the call zeroed.  The last owner to get here (all owners have read the overflow count by then) resets the two bookkeeping
 // counters -- after draining a long overflow list with the reference's global atomics.
@@ -1273,8 +1158,7 @@ TCNN_DEVICE void bucket_owner_epilogue(const GridMeta& meta, const BucketPlan& p
 template <uint32_t D, uint32_t F>
 TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t level, uint32_t j, uint32_t bucket, uint32_t chunk,
                               const BucketPlan& plan, uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues,
-                              const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient, bool accumulate, unsigned char* lds_raw,
-                              const FusedAdamArgs& fused) {
+                              const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient, bool accumulate, unsigned char* lds_raw) {
 	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, PWP = BucketRecord<F>::PAIR_WORDS, OW = BucketRecord<F>::WORDS + 1;
 	// records that did not fit their queue (or whose x-neighbour lives in another bucket: about one pair in 2^shift).  Up to
 	// OVERFLOW_INLINE_MAX of them every owner picks its own out of the list -- exact, no atomics, no extra launch; beyond
@@ -1335,18 +1219,6 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 
 	half_t* __restrict__ grad = grid_gradient + ((size_t)meta.offset[level] + slice_begin) * F;
 	const uint32_t n_halves = slice_count * F;  // a multiple of 8: level sizes are multiples of 8
-	if (fused.enabled && n_chunks == 1 && !accumulate) {
-		// sole owner of the slice: the optimizer step straight from the exact sums (GridFusedAdam), 4 parameters per lane
-		const size_t p_first = ((size_t)meta.offset[level] + slice_begin) * F;  // relative to the grid's first parameter
-		for (uint32_t q = threadIdx.x; q < n_halves / 4; q += SLICED_THREADS) {
-			h4 g;
-#pragma unroll
-			for (uint32_t jj = 0; jj < 4; ++jj) g[jj] = (half_t)(float)((double)((const long long*)lds_raw)[4 * q + jj] * (1.0 / FIXED_SCALE));
-			*(h4*)(grad + 4 * q) = g;  // param_gradients stays what the stand-alone path leaves there
-			if (fused.stream) fused_adam4<true>(fused, p_first + 4 * q, g);
-			else fused_adam4<false>(fused, p_first + 4 * q, g);
-		}
-	} else
 	for (uint32_t e2 = threadIdx.x; e2 < n_halves / 2; e2 += SLICED_THREADS) {
 		const long long q0 = ((const long long*)lds_raw)[2 * e2], q1 = ((const long long*)lds_raw)[2 * e2 + 1];
 		h2 v = h2{(half_t)(float)((double)q0 * (1.0 / FIXED_SCALE)), (half_t)(float)((double)q1 * (1.0 / FIXED_SCALE))};
@@ -1361,7 +1233,7 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// pass B, packed form (even F; what the bucketed backward runs unless TCNN_GRID_OWNER=fixed64).
+// pass B, packed form (even F; what the bucketed backward runs unless grid_owner_mode() == 1).
 //
 // The form above spends one ds_add_u64 per VALUE (two per table entry at F = 2) and 16 bytes of LDS per entry, so a
 // 8192-entry slice takes 128 KiB: one workgroup per CU, whose clear / stream / convert phases cannot overlap anything.
@@ -1405,11 +1277,11 @@ TCNN_DEVICE int to_fixed32(float v) {
 #endif
 }
 
-template <uint32_t D, uint32_t F, uint32_t THREADS, bool FUSED_ADAM>
+template <uint32_t D, uint32_t F, uint32_t THREADS>
 TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, uint32_t level, uint32_t j, uint32_t bucket, uint32_t chunk,
                                      const BucketPlan& plan, uint32_t* __restrict__ counters, const uint32_t* queues,
                                      const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient, bool accumulate, unsigned char* lds_raw,
-                                     uint32_t lds_bytes, bool force_wide, const FusedAdamArgs& fused) {
+                                     uint32_t lds_bytes, bool force_wide) {
 	static_assert(F % 2 == 0, "the packed owner pairs the features of a payload word");
 	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, PWP = BucketRecord<F>::PAIR_WORDS, OW = BucketRecord<F>::WORDS + 1;
 	constexpr uint32_t N_WAVES = THREADS / WAVE;
@@ -1569,16 +1441,6 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 		}
 	};
 
-	// sole owner of the slice, overwrite: the optimizer step straight from the exact sums (GridFusedAdam), 4 parameters per lane
-	// (a compile-time switch: with the optimizer's arithmetic in the kernel the owner needs 118 registers, without it half as many, and the
-	// register count decides how many waves stream their queues per SIMD)
-	const bool step_here = FUSED_ADAM && fused.enabled && n_chunks == 1 && !accumulate;
-	const size_t p_first = ((size_t)meta.offset[level] + slice_begin) * F;  // relative to the grid's first parameter
-	auto store_quad_and_step = [&](uint32_t q4, h4 g) {
-		*(h4*)(grad + 4 * q4) = g;  // param_gradients stays what the stand-alone path leaves there
-		if (fused.stream) fused_adam4<true>(fused, p_first + 4 * q4, g);
-		else fused_adam4<false>(fused, p_first + 4 * q4, g);
-	};
 
 	if (safe) {
 		if (!(diag_owner & 1u)) {
@@ -1635,12 +1497,7 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 				// int32 -> fp32 rounds to nearest even exactly as the fp64 -> fp32 conversion of the wide form does
 				return h2{(half_t)((float)s0 * (1.0f / 16777216.0f)), (half_t)((float)s1 * (1.0f / 16777216.0f))};
 			};
-			if (step_here) {
-				for (uint32_t q4 = threadIdx.x; q4 < slice_count * PW / 2; q4 += THREADS) {
-					const h2 a = unpack(2 * q4), b = unpack(2 * q4 + 1);
-					store_quad_and_step(q4, h4{a[0], a[1], b[0], b[1]});
-				}
-			} else if (n_chunks == 1 && !accumulate && ((uintptr_t)grad & 15u) == 0u) {  // sole owner, overwrite: 16 bytes per lane (slice_count * PW is a multiple of 8)
+			if (n_chunks == 1 && !accumulate && ((uintptr_t)grad & 15u) == 0u) {  // sole owner, overwrite: 16 bytes per lane (slice_count * PW is a multiple of 8)
 				for (uint32_t e8 = threadIdx.x; e8 < slice_count * PW / 4; e8 += THREADS) {
 					const h2 a = unpack(4 * e8), b = unpack(4 * e8 + 1), c = unpack(4 * e8 + 2), d = unpack(4 * e8 + 3);
 					*(h8*)(grad + 8 * e8) = h8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
@@ -1675,14 +1532,6 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 				}
 			});
 			__syncthreads();
-			if (step_here) {
-				for (uint32_t q4 = threadIdx.x; q4 < sub_count * PW / 2; q4 += THREADS) {
-					h4 g;
-#pragma unroll
-					for (uint32_t jj = 0; jj < 4; ++jj) g[jj] = (half_t)(float)((double)((const long long*)lds_raw)[4 * q4 + jj] * (1.0 / FIXED_SCALE));
-					store_quad_and_step(sub_begin * PW / 2 + q4, g);
-				}
-			} else
 			for (uint32_t e2 = threadIdx.x; e2 < sub_count * PW; e2 += THREADS) {
 				const long long q0 = ((const long long*)lds_raw)[2 * e2], q1 = ((const long long*)lds_raw)[2 * e2 + 1];
 				store_pair(sub_begin * PW + e2, h2{(half_t)(float)((double)q0 * (1.0 / FIXED_SCALE)), (half_t)(float)((double)q1 * (1.0 / FIXED_SCALE))});
@@ -1701,11 +1550,11 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 
 // The workgroups of pass B that own a (bucket, chunk), packed form; block -> item as in k_grid_backward_sliced, whose launch
 // (if the plan holds other kinds of items at all) skips the bucket items when this kernel runs them.
-template <uint32_t D, uint32_t F, bool FUSED_ADAM>
+template <uint32_t D, uint32_t F>
 __global__ void __launch_bounds__(OWNER_THREADS) k_grid_bucket_owner(const GridMeta meta, const SlicePlan plan, const int accumulate, const BucketPlan bplan,
                                                                       uint32_t* __restrict__ counters, const uint32_t* queues,
                                                                       const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient,
-                                                                      const uint32_t lds_bytes, const int force_wide, const FusedAdamArgs fused) {
+                                                                      const uint32_t lds_bytes, const int force_wide) {
 	TCNN_DYN_LDS(lds_raw);
 	uint32_t item = 0, local_block;
 	if (plan.blocks_per_item) {
@@ -1721,8 +1570,8 @@ __global__ void __launch_bounds__(OWNER_THREADS) k_grid_bucket_owner(const GridM
 	const uint32_t slice = local_block % n_slices, chunk = local_block / n_slices;
 	const Level<D> lv = make_level<D>(meta, level);
 	if constexpr (F % 2 == 0) {  // (never launched for odd F)
-		bucket_level_packed<D, F, OWNER_THREADS, FUSED_ADAM>(meta, lv, level, plan.slot[item], slice, chunk, bplan, counters, queues, overflow, grid_gradient,
-		                                         accumulate != 0, lds_raw, lds_bytes, force_wide != 0, fused);
+		bucket_level_packed<D, F, OWNER_THREADS>(meta, lv, level, plan.slot[item], slice, chunk, bplan, counters, queues, overflow, grid_gradient,
+		                                         accumulate != 0, lds_raw, lds_bytes, force_wide != 0);
 	}
 }
 
@@ -1731,7 +1580,7 @@ __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const G
                                                                            const half_t* __restrict__ dL_dy, half_t* __restrict__ grid_gradient,
                                                                            const int accumulate, const BucketPlan bplan,
                                                                            uint32_t* __restrict__ counters, const uint32_t* __restrict__ queues,
-                                                                           const uint32_t* __restrict__ overflow, const FusedAdamArgs fused) {
+                                                                           const uint32_t* __restrict__ overflow) {
 	TCNN_DYN_LDS(lds_raw);
 	uint32_t item = 0, local_block;
 	if (plan.blocks_per_item) {
@@ -1757,7 +1606,7 @@ __global__ void __launch_bounds__(SLICED_THREADS) k_grid_backward_sliced(const G
 
 	if (kind == SLICE_BUCKET) {
 		if (bplan.packed_owner) return;  // k_grid_bucket_owner runs them
-		bucket_level<D, F>(meta, lv, level, plan.slot[item], slice, chunk, bplan, counters, queues, overflow, grid_gradient, accumulate != 0, lds_raw, fused);
+		bucket_level<D, F>(meta, lv, level, plan.slot[item], slice, chunk, bplan, counters, queues, overflow, grid_gradient, accumulate != 0, lds_raw);
 		return;
 	}
 	if (kind == SLICE_GLOBAL_ATOMIC) {
@@ -1956,7 +1805,7 @@ __global__ void k_grid_indices(const GridMeta meta, const GridIO io, uint32_t* _
 // (<= 24 KiB), 8 for a hashed level (one L2 line per corner pair), 11 for a larger densely indexed level, each times
 // (1 + 1.5 x the share of fetches that miss the L2) for tables beyond the L2 (T = 2^22: 16 MiB per level, 2.4x the
 // time of a 2 MiB level).  Falls back to uniform costs if a run would need more than FWD_MAX_SEGMENTS segments.
-static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t tile_samples, const bool* skip_level = nullptr) {
+static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t tile_samples) {
 	for (int uniform = 0; uniform < 2; ++uniform) {
 		ForwardPlan plan = {};
 		plan.tiles = div_round_up(n, tile_samples);
@@ -1983,7 +1832,6 @@ static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t 
 			                    : hashed ? 8.0 * (1.0 + 2.5 * miss)
 			                             : (4.6 + 1.15 * std::log2(in_l2 / (24.0 * 1024.0))) * (1.0 + 0.8 * miss);
 			cost[l] = uniform ? 16u : (uint32_t)(4.0 * base + 0.5);  // (quarter-microsecond units: the cuts fall on whole tiles)
-			if (skip_level && skip_level[l]) continue;  // gathered out of LDS by k_grid_forward_lds
 			total += (uint64_t)cost[l] * plan.tiles;
 		}
 		bool ok = true;
@@ -1991,7 +1839,6 @@ static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t 
 		uint32_t xcd = 0;
 		for (uint32_t l = 0; l < meta.n_levels && ok; ++l) {
 			uint32_t t = 0;
-			if (skip_level && skip_level[l]) continue;
 			while (t < plan.tiles) {
 				// XCD `xcd` takes items while the cost assigned so far stays below its cumulative share
 				const uint64_t limit = (total * (xcd + 1) + 7) / 8;
@@ -2015,46 +1862,11 @@ static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t 
 	throw std::runtime_error("grid_forward: could not build the work plan");
 }
 
-// LDS bytes up to which a level's table is gathered out of LDS (k_grid_forward_lds); TCNN_GRID_FWD_LDS_BYTES sets it, 0 = never (default:
-// on MI355X the path measures slower than the tiled kernel for every level it could take, see launch_forward_tiles)
-uint32_t& grid_forward_lds_limit() {
-	static uint32_t limit = getenv("TCNN_GRID_FWD_LDS_BYTES") ? (uint32_t)atoi(getenv("TCNN_GRID_FWD_LDS_BYTES")) : 0u;
-	return limit;
-}
-// batch sizes below this stay in the tiled kernel altogether (a table copy per workgroup needs samples to pay for it)
-uint32_t& grid_forward_lds_min_samples() {
-	static uint32_t n = 4096u;
-	return n;
-}
-
 template <uint32_t D, uint32_t F, uint32_t SPT>
 static void launch_forward_tiles(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* params, half_t* out) {
-	// levels that fit LDS first, one launch each; the tiled kernel takes the rest
-	bool in_lds[MAX_N_LEVELS] = {};
-	bool any_left = false;
-	const uint32_t limit = std::min(grid_forward_lds_limit(), 160u * 1024u);
-	const float max_level = (meta.max_level * (float)(meta.n_levels * F)) / (float)F;
-	const bool plain = meta.interp != (uint32_t)InterpolationType::Nearest && ((uintptr_t)params & 15u) == 0u && io.n >= grid_forward_lds_min_samples();
-	for (uint32_t l = 0; l < meta.n_levels; ++l) {
-		const size_t table_bytes = (size_t)(meta.offset[l + 1] - meta.offset[l]) * F * sizeof(half_t);
-		const bool level_off = (float)l >= max_level + 1e-3f;  // grid.h:75: the tiled kernel's rare-form path writes the zeros
-		in_lds[l] = plain && !level_off && table_bytes <= limit && ((size_t)meta.offset[l] * F * sizeof(half_t)) % 16u == 0u;
-		any_left = any_left || !in_lds[l];
-	}
-	// (Measured, profiles/r03_exp_notes.txt: these launches AHEAD of the tiled kernel cost more than the L1 / L2 gathers they replace,
-	// and BESIDE it -- a side stream forked and joined with events -- the event hand-offs alone add ~25 us per call.  Hence off by default.)
-	hipStream_t lds_stream = stream;
-	for (uint32_t l = 0; l < meta.n_levels; ++l) {
-		if (!in_lds[l]) continue;
-		const uint32_t table_bytes = (meta.offset[l + 1] - meta.offset[l]) * F * (uint32_t)sizeof(half_t);
-		// at most one workgroup per CU and launch (256), each with at least two samples per thread (the loop's unroll)
-		const uint32_t blocks = std::min(div_round_up(io.n, 2u * FWD_LDS_THREADS), 256u);
-		const uint32_t per_block = next_multiple(div_round_up(io.n, blocks), 64u);
-		TCNN_SET_MAX_DYN_LDS((k_grid_forward_lds<D, F>), table_bytes);
-		TCNN_LAUNCH((k_grid_forward_lds<D, F>), dim3(div_round_up(io.n, per_block)), dim3(FWD_LDS_THREADS), table_bytes, lds_stream, meta, io, l, per_block, params, out);
-	}
-	if (!any_left) return;
-	const ForwardPlan plan = make_forward_plan(meta, io.n, GRID_THREADS * SPT, in_lds);
+	// (Gathering the levels whose table fits a CU's LDS out of LDS -- one launch per level, the table copied in by every workgroup -- was
+	// built in round 3 and measured slower in every arrangement: scripts/exp_grid_forward_lds.patch, profiles/r03_exp_notes.txt.)
+	const ForwardPlan plan = make_forward_plan(meta, io.n, GRID_THREADS * SPT);
 	uint32_t slots = 0;
 	for (uint32_t x = 0; x < 8; ++x) {
 		uint32_t n = 0;
@@ -2066,8 +1878,7 @@ static void launch_forward_tiles(hipStream_t stream, const GridMeta& meta, const
 
 void grid_forward(hipStream_t stream, const GridMeta& meta, const GridIO& io, const half_t* params, half_t* out, float* dy_dx) {
 	if (io.n == 0) return;
-	static const bool per_sample_form = getenv("TCNN_GRID_FWD") && atoi(getenv("TCNN_GRID_FWD")) == 0;  // A/B switch: the first implementation
-	if (!dy_dx && out && !per_sample_form) {
+	if (!dy_dx && out) {
 #ifndef TCNN_FWD_SPT
 #define TCNN_FWD_SPT 2  // samples per thread of the tiled gather (a workgroup: 256 x SPT samples of one level)
 #endif
@@ -2110,10 +1921,7 @@ unsigned long long grid_owner_wide_slices() {
 }
 
 int& grid_owner_mode() {
-	static int mode = [] {
-		const char* e = getenv("TCNN_GRID_OWNER");
-		return !e ? 0 : (std::string(e) == "fixed64" ? 1 : (std::string(e) == "wide" ? 2 : 0));
-	}();
+	static int mode = 0;
 	return mode;
 }
 
@@ -2299,7 +2107,7 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 		queues = (uint32_t*)ws.scratch;
 		overflow = (uint32_t*)((unsigned char*)ws.scratch + bp.overflow_offset);
 	}
-	if (bk.n_levels && (ws.phases & 1u)) {
+	if (bk.n_levels) {
 		if (ws.phase_hook) ws.phase_hook(ws.hook_user, 0, 1);
 		// pass A: derive every corner once, bin by owner (+ zero the gradients of chunked levels)
 		const uint32_t scatter_blocks = bk.scatter_blocks + bk.zero_block_begin[bk.n_levels];
@@ -2323,7 +2131,6 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 #undef BSCATTER
 		if (ws.phase_hook) ws.phase_hook(ws.hook_user, 0, 0);
 	}
-	if (!(ws.phases & 2u)) return;
 	if (ws.phase_hook) ws.phase_hook(ws.hook_user, 1, 1);
 	for (uint32_t p = 0; p < plan.n_items; ++p) {
 		struct { uint32_t level, kind, n_chunks; } it = {plan.level[p], plan.kind[p], bp.n_chunks[p]};
@@ -2335,28 +2142,8 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 		}
 	}
 	const int acc = accumulate ? 1 : 0;
-	FusedAdamArgs fused = {};
-	if (ws.fused_adam && ws.fused_adam->core && bucketed && !accumulate && !io.ddx) {
-		const GridFusedAdam& fa = *ws.fused_adam;
-		fused.core = *fa.core;
-		fused.master = fa.master;
-		fused.params = fa.params;
-		fused.m1 = fa.m1;
-		fused.m2 = fa.m2;
-		fused.steps = fa.steps;
-		fused.enabled = 1;
-		fused.stream = fa.stream_state ? 1 : 0;
-		if (fa.fused_level) {
-			for (uint32_t l = 0; l < meta.n_levels; ++l) fa.fused_level[l] = false;
-			for (uint32_t p = 0; p < plan.n_items; ++p) {
-				if (plan.kind[p] == SLICE_BUCKET && bp.n_chunks[p] == 1) fa.fused_level[plan.level[p]] = true;
-			}
-		}
-	} else if (ws.fused_adam && ws.fused_adam->fused_level) {
-		for (uint32_t l = 0; l < meta.n_levels; ++l) ws.fused_adam->fused_level[l] = false;
-	}
-	// bucket items: the packed owner kernel (even F) unless the optimizer step rides along or TCNN_GRID_OWNER=fixed64 asks for the
-	// 64-bit-per-value form; TCNN_GRID_OWNER=wide runs the packed kernel's own 64-bit redo on every slice (tests)
+	// bucket items: the packed owner kernel (even F) unless grid_owner_mode() asks for the 64-bit-per-value form; mode "wide" runs the
+	// packed kernel's own 64-bit redo on every slice (tests)
 	const int owner_mode = grid_owner_mode();
 	BucketPlan bk_launch = bk;
 	bk_launch.packed_owner = (bk.n_levels && F % 2 == 0 && owner_mode != 1) ? 1u : 0u;
@@ -2367,15 +2154,9 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 		const int force_wide = owner_mode == 2 ? 1 : 0;
 #define BOWNER(D_, F_)                                                                                                                       \
 	if constexpr (F_ % 2 == 0) {                                                                                                             \
-		if (fused.enabled) {                                                                                                                 \
-			TCNN_SET_MAX_DYN_LDS((k_grid_bucket_owner<D_, F_, true>), owner_lds);                                                            \
-			TCNN_LAUNCH((k_grid_bucket_owner<D_, F_, true>), dim3(blocks), dim3(OWNER_THREADS), owner_lds, stream, meta, plan, acc, bk_launch, counters, \
-			            (const uint32_t*)queues, (const uint32_t*)overflow, grid_gradient, owner_lds, force_wide, fused);                    \
-		} else {                                                                                                                             \
-			TCNN_SET_MAX_DYN_LDS((k_grid_bucket_owner<D_, F_, false>), owner_lds);                                                           \
-			TCNN_LAUNCH((k_grid_bucket_owner<D_, F_, false>), dim3(blocks), dim3(OWNER_THREADS), owner_lds, stream, meta, plan, acc, bk_launch, counters, \
-			            (const uint32_t*)queues, (const uint32_t*)overflow, grid_gradient, owner_lds, force_wide, fused);                    \
-		}                                                                                                                                    \
+		TCNN_SET_MAX_DYN_LDS((k_grid_bucket_owner<D_, F_>), owner_lds);                                                                      \
+		TCNN_LAUNCH((k_grid_bucket_owner<D_, F_>), dim3(blocks), dim3(OWNER_THREADS), owner_lds, stream, meta, plan, acc, bk_launch, counters, \
+		            (const uint32_t*)queues, (const uint32_t*)overflow, grid_gradient, owner_lds, force_wide);                               \
 	}
 		TCNN_GRID_DISPATCH(BOWNER)
 #undef BOWNER
@@ -2385,12 +2166,12 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 		if constexpr (F_ % 2 == 0) {                                                                                                   \
 			TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, true>), lds_slice_bytes);                                             \
 			TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, true>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io, \
-			            plan, dL_dy, grid_gradient, acc, bk_launch, counters, (const uint32_t*)queues, (const uint32_t*)overflow, fused); \
+			            plan, dL_dy, grid_gradient, acc, bk_launch, counters, (const uint32_t*)queues, (const uint32_t*)overflow); \
 		}                                                                                                                              \
 	} else {                                                                                                                           \
 		TCNN_SET_MAX_DYN_LDS((k_grid_backward_sliced<D_, F_, false>), lds_slice_bytes);                                                \
 		TCNN_LAUNCH((k_grid_backward_sliced<D_, F_, false>), dim3(blocks), dim3(SLICED_THREADS), lds_slice_bytes, stream, meta, io,    \
-		            plan, dL_dy, grid_gradient, acc, bk_launch, counters, (const uint32_t*)queues, (const uint32_t*)overflow, fused);     \
+		            plan, dL_dy, grid_gradient, acc, bk_launch, counters, (const uint32_t*)queues, (const uint32_t*)overflow);     \
 	}
 	if (!bk_launch.packed_owner || other_items) {
 		TCNN_GRID_DISPATCH(BWDS)

@@ -134,7 +134,7 @@ bool mlp_train_supported(const MlpMeta& m);
 // The register-resident instances of the training pass (mlp_train_wave.hip): one wavefront per strip of 32 samples, for
 // 32 inputs x {64 neurons, 1-2 hidden layers | 32 neurons, 1-3 hidden layers} x 16 padded outputs, ReLU / None activations,
 // (Relative)L2 loss.  mlp_train() picks them
-// when available (TCNN_MLP_TRAIN_WAVE=0 in the environment disables them); same contract as mlp_train().
+// when available; same contract as mlp_train().
 bool mlp_train_wave_supported(const MlpMeta& m, uint32_t n, LossType loss);
 uint32_t mlp_train_wave_n_partials(const MlpMeta& m, uint32_t n);
 void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
@@ -144,7 +144,7 @@ void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half
 // The fused training pass of 128-neuron networks (mlp_train_wide.hip): hidden weights resident in LDS (one copy, the backward
 // operands come out of it through the hardware transpose read), sample-major activation tiles of 32 samples, weight gradients
 // in registers.  32 or 64 inputs, up to 4 hidden layers, 16 padded outputs, any activation / element-wise loss.  mlp_train()
-// picks it (TCNN_MLP_TRAIN_WIDE=0 disables it: 128-wide networks then train through forward / loss / backward kernels).
+// picks it.
 bool mlp_train_wide_supported(const MlpMeta& m, uint32_t n);
 uint32_t mlp_train_wide_n_partials(uint32_t n);
 void mlp_train_wide(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,

@@ -45,7 +45,6 @@ TCNN_DEVICE h4 to_h4(f4 v) { return h4{(half_t)v[0], (half_t)v[1], (half_t)v[2],
 //   forward  (half)(x > 0 ? x : 0) == max((half)x, 0)   rounding is monotonic; "None" takes the maximum with -inf
 //   backward (half)(h > 0 ? v : 0): the fp16 bits of (half)v ANDed with 0xFFFF where h != +-0 and with 0 elsewhere
 //            (h >= 0 after ReLU; +0 for masked entries); "None" forces the mask to ones
-typedef int16_t ss2 __attribute__((ext_vector_type(2)));
 typedef uint16_t us2 __attribute__((ext_vector_type(2)));
 struct PackedAct {
 	h2 floor2;            // forward: {0, 0} for ReLU, {-inf, -inf} for None
@@ -66,11 +65,6 @@ TCNN_DEVICE h4 act_forward4(uint32_t act, const PackedAct& pa, f4 x) {
 	}
 }
 TCNN_DEVICE h2 relu_mask(h2 d, h2 forward_value, uint32_t keep_bits) {
-#if defined(TCNN_WAVE_OLD_MASK)
-	const uint32_t t = (__builtin_bit_cast(uint32_t, forward_value) & 0x7FFF7FFFu) | keep_bits;
-	const ss2 keep = (ss2)(-__builtin_bit_cast(ss2, t)) >> 15;  // 0xFFFF where the (sign-stripped) forward value is not zero
-	return __builtin_bit_cast(h2, __builtin_bit_cast(uint32_t, d) & __builtin_bit_cast(uint32_t, keep));
-#else
 	// three instructions per pair (v_and_or_b32: strip the sign, force "keep"; v_pk_min_u16; v_pk_mul_lo_u16) where the sign-extending form took
 	// five: the sign-stripped forward value, as an unsigned 16-bit integer, is clamped to {0, 1} and multiplies the gradient's BITS
 #if defined(TCNN_HOST_EMU)
@@ -85,7 +79,6 @@ TCNN_DEVICE h2 relu_mask(h2 d, h2 forward_value, uint32_t keep_bits) {
 	asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(pass) : "v"(t));
 	asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(masked) : "v"(__builtin_bit_cast(uint32_t, d)), "v"(pass));
 	return __builtin_bit_cast(h2, masked);
-#endif
 #endif
 }
 template <bool GENERAL>
@@ -143,20 +136,15 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	constexpr uint32_t N_PARAMS = WIDTH * IN + HM * WIDTH * WIDTH + 16 * WIDTH;
 	static_assert(NWAVES == 4 && WIDTH % 32 == 0 && IN % 32 == 0, "the final reduction pairs waves (0,2) and (1,3); operands are built from pairs of 16-row tiles");
 	constexpr uint32_t N_TILES = NB * FB + HM * NB * NB + NB;  // accumulator tiles per wave
-	// Transposes through LDS (TR_LDS): the weight-gradient MFMAs need their factors with the SAMPLES in the k slots.  A 16 x 16 tile as the
+	// Transposes through LDS: the weight-gradient MFMAs need their factors with the SAMPLES in the k slots.  A 16 x 16 tile as the
 	// accumulators hold it (lane (g, lr): neurons 4g .. 4g+3 of sample lr) is one 8-byte LDS store per lane into a sample-major image, and
 	// gfx950's transposing read (ds_read_b64_tr_b16, lds_read_tr4) hands lane (g, c) the four samples 4g .. 4g+3 of neuron c out of it --
 	// exactly what the MFMA against the identity + two conversions produced, on the LDS pipe, which this kernel otherwise leaves idle,
 	// instead of on the matrix and vector pipes, which bound it (34 of 126 MFMAs and 68 conversions per strip for the 64-neuron instance).
 	// The tiles of a wave are its own: no barrier, the LDS executes a wave's requests in order.  Layer j's activations are stored as soon as
 	// the forward pass has them; dL/d(pre-activation) of layer j reuses the region of layer j's activations once those have been read.
-#if defined(TCNN_WAVE_MFMA_TRANSPOSE)
-	constexpr bool TR_LDS = false;
-#else
-	constexpr bool TR_LDS = true;
-#endif
 	constexpr uint32_t TR_TILES = (HM + 1) * 2 * NB + 2;  // per wave: every layer's activations + the two dL/doutput tiles, 512 bytes each
-	constexpr uint32_t EXCH_F4 = N_TILES * 64, TR_F4 = TR_LDS ? NWAVES * TR_TILES * 32 : 0;
+	constexpr uint32_t EXCH_F4 = N_TILES * 64, TR_F4 = NWAVES * TR_TILES * 32;
 	__shared__ f4 exchange[EXCH_F4 > TR_F4 ? EXCH_F4 : TR_F4];
 	__shared__ float red[MLP_WAVE_THREADS];
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
@@ -250,9 +238,6 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	auto woutA = [&](uint32_t p) { return wfrag[F_WOUTA + p][lane]; };
 	auto winB = [&](uint32_t b, uint32_t p) { return wfrag[F_WINB + b * NP + p][lane]; };
 	auto woutT = [&](uint32_t b) { return wfrag_out_t[b][lane]; };
-	h4 eye;  // identity (16x16x16 B operand; the MFMA form of the transposes)
-#pragma unroll
-	for (uint32_t j = 0; j < 4; ++j) eye[j] = (half_t)(4 * g + j == lr ? 1.0f : 0.0f);
 	half_t* const tr = (half_t*)exchange + w * (TR_TILES * 256u);
 	// A tile's 64 words (sample s, neuron quad q; 8 bytes each) are laid out for the LDS banks, not row-major: the transposing read only
 	// cares which word a lane addresses.  Word (s, q) at 8-byte slot 32 (s >> 3) + 8 ((q + (s >> 3)) & 3) + (s & 7): the 16 lanes of a
@@ -262,13 +247,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	const uint32_t tr_store_at = 4u * tr_slot(lr, g);                        // lane (g, lr) holds neurons 4g .. 4g+3 of sample lr
 	const uint32_t tr_load_at = 4u * tr_slot(4u * g + (lr >> 2), lr & 3u);    // lds_read_tr4: lane i of group g addresses word (sample 4g + (i >> 2), quad i & 3)
 	auto tr_put = [&](uint32_t tile, h4 v) { *(h4*)(tr + tile * 256u + tr_store_at) = v; };
-	auto tr_get = [&](uint32_t tile) -> h4 {
-#if defined(TCNN_WAVE_MFMA_TRANSPOSE)
-		return h4{};
-#else
-		return lds_read_tr4(tr + tile * 256u + tr_load_at);
-#endif
-	};
+	auto tr_get = [&](uint32_t tile) -> h4 { return lds_read_tr4(tr + tile * 256u + tr_load_at); };
 	auto tile_h = [&](uint32_t layer, uint32_t s_, uint32_t b_) { return (layer * 2u + s_) * NB + b_; };
 	constexpr uint32_t TILE_DY = (HM + 1) * 2 * NB;
 	const PackedAct pa_out = packed_act(out_act);
@@ -285,12 +264,6 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 			for (uint32_t i = 0; i < NB; ++i) accH[j][b][i] = zero4();
 	}
 	float loss_sum = 0.0f;
-
-	// transposes NB tiles (rows 4g+r of block b, sample perm32(s, lr)) of both sample blocks into "samples in k" operands
-	auto transpose = [&](const h4 (&p)[2][NB], h8 (&q)[NB]) {
-#pragma unroll
-		for (uint32_t b = 0; b < NB; ++b) q[b] = pack8(to_h4(mfma_16x16x16(p[0][b], eye, zero4())), to_h4(mfma_16x16x16(p[1][b], eye, zero4())));
-	};
 
 	for (; strip < n_strips; strip += stride) {
 		asm volatile("" ::: "memory");  // the weight fragments are re-read from LDS where they are used, not hoisted into registers for the whole loop
@@ -341,11 +314,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 		// The weight fragments of a phase are requested from LDS at the start of the phase BEFORE (WF_AHEAD): read where they are used, every
 		// phase opened with a wait on the LDS -- 46 % of a wave's cycles were spent parked in s_waitcnt (profiles/r06_exp_notes.txt).
 		// (not in the wide-output instances: with four targets per lane live through the forward pass they are at the 256-register limit)
-#if defined(TCNN_WAVE_NO_PREFETCH)
-		constexpr bool WF_AHEAD = false;
-#else
 		constexpr bool WF_AHEAD = FEW_DIMS;
-#endif
 		h4 hp[HM + 1][2][NB];  // layer, sample block, neuron block: (neuron perm32(b, 4g+r), sample perm32(s, lr))
 		h8 w_hid[NB][NP];      // the next hidden layer's fragments (forward: whidA, backward: whidT), a phase ahead
 		h8 w_out[NP];
@@ -385,7 +354,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 #pragma unroll
 					for (uint32_t p = 0; p < FP; ++p) acc = mfma_16x16x32(WF_AHEAD ? w_in[b][p] : winA(b, p), xb[s][p], acc);
 					hp[0][s][b] = act_forward4<GENERAL>(act, pa, acc);
-					if constexpr (TR_LDS) tr_put(tile_h(0, s, b), hp[0][s][b]);
+					tr_put(tile_h(0, s, b), hp[0][s][b]);
 				}
 			sched_fence();
 		}
@@ -415,13 +384,13 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 #pragma unroll
 					for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(WF_AHEAD ? w_cur[b][p] : whidA(j, b, p), pack8(hp[j][s][2 * p], hp[j][s][2 * p + 1]), acc);
 					hp[j + 1][s][b] = act_forward4<GENERAL>(act, pa, acc);
-					if constexpr (TR_LDS) tr_put(tile_h(j + 1, s, b), hp[j + 1][s][b]);
+					tr_put(tile_h(j + 1, s, b), hp[j + 1][s][b]);
 				}
 			sched_fence();
 		}
 		// the backward pass's first fragments travel during the output layer and the loss
 		h4 w_out_t[NB];
-		if constexpr (WF_AHEAD && TR_LDS) {
+		if constexpr (WF_AHEAD) {
 #pragma unroll
 			for (uint32_t b = 0; b < NB; ++b) w_out_t[b] = woutT(b);
 			if constexpr (HM > 0) {
@@ -485,7 +454,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 				dyp[s] = pack4(relu_mask(__builtin_shufflevector(gy, gy, 0, 1), __builtin_shufflevector(o, o, 0, 1), pa_out.keep_bits),
 				               relu_mask(__builtin_shufflevector(gy, gy, 2, 3), __builtin_shufflevector(o, o, 2, 3), pa_out.keep_bits));
 			}
-			if constexpr (TR_LDS) tr_put(TILE_DY + s, dyp[s]);
+			tr_put(TILE_DY + s, dyp[s]);
 		}
 		sched_fence();
 		// Lane (g, lr) holds outputs 4r + g of its sample.  Stored as they lie that is four 2-byte stores per matrix whose 64 lanes
@@ -500,111 +469,12 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 
 		sched_fence();
 		// ================= backward =================
-		if constexpr (TR_LDS) {
-			wave_lds_sync();  // this wave's tiles are in LDS
-			{  // dW_out[output][neuron] += dY * H_last^T  (accumulated unconditionally: a branch around the MFMAs costs the in-place accumulators)
-				const h8 dyq = pack8(tr_get(TILE_DY), tr_get(TILE_DY + 1));
-				h8 hq[NB];  // the layer's activations with the samples in k: lane lr <-> neuron perm32(b, lr), k = sample 8g+j
-#pragma unroll
-				for (uint32_t b = 0; b < NB; ++b) hq[b] = pack8(tr_get(tile_h(HM, 0, b)), tr_get(tile_h(HM, 1, b)));
-#pragma unroll
-				for (uint32_t b = 0; b < NB; ++b) accO[b] = mfma_16x16x32(dyq, hq[b], accO[b]);
-			}
-			h4 dap[2][NB];  // dL/d(pre-activation) of the current layer, same tile layout as hp
-#pragma unroll
-			for (uint32_t s = 0; s < 2; ++s)
-#pragma unroll
-				for (uint32_t b = 0; b < NB; ++b) dap[s][b] = act_backward4<GENERAL>(act, pa, mfma_16x16x16(WF_AHEAD ? w_out_t[b] : woutT(b), dyp[s], zero4()), hp[HM][s][b]);
-			wave_lds_sync();  // the activations' region has been read: it takes the layer's dL/d(pre-activation)
-#pragma unroll
-			for (uint32_t s = 0; s < 2; ++s)
-#pragma unroll
-				for (uint32_t b = 0; b < NB; ++b) tr_put(tile_h(HM, s, b), dap[s][b]);
-			sched_fence();
-#pragma unroll
-			for (int j = (int)HM - 1; j >= 0; --j) {
-				// the previous layer's dL/d(pre-activation) first (it needs nothing from LDS): the tiles just stored travel meanwhile
-				h4 prev[2][NB];
-				h8 w_cur[NB][NP];
-				if constexpr (WF_AHEAD) {
-#pragma unroll
-					for (uint32_t b = 0; b < NB; ++b)
-#pragma unroll
-						for (uint32_t p = 0; p < NP; ++p) w_cur[b][p] = w_hid[b][p];
-					if (j > 0) {
-#pragma unroll
-						for (uint32_t b = 0; b < NB; ++b)
-#pragma unroll
-							for (uint32_t p = 0; p < NP; ++p) w_hid[b][p] = whidT(j - 1, b, p);
-					}
-				}
-#pragma unroll
-				for (uint32_t s = 0; s < 2; ++s)
-#pragma unroll
-					for (uint32_t b = 0; b < NB; ++b) {
-						f4 acc = zero4();
-#pragma unroll
-						for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(WF_AHEAD ? w_cur[b][p] : whidT(j, b, p), pack8(dap[s][2 * p], dap[s][2 * p + 1]), acc);
-						prev[s][b] = act_backward4<GENERAL>(act, pa, acc, hp[j][s][b]);
-					}
-				sched_fence();
-				wave_lds_sync();
-				{  // dW_hid_j[out][in] += dA_{j+1} * H_j^T
-					h8 daq[NB], hq[NB];
-#pragma unroll
-					for (uint32_t b = 0; b < NB; ++b) {
-						daq[b] = pack8(tr_get(tile_h(j + 1, 0, b)), tr_get(tile_h(j + 1, 1, b)));
-						hq[b] = pack8(tr_get(tile_h(j, 0, b)), tr_get(tile_h(j, 1, b)));
-					}
-#pragma unroll
-					for (uint32_t b = 0; b < NB; ++b)
-#pragma unroll
-						for (uint32_t i = 0; i < NB; ++i) accH[j][b][i] = mfma_16x16x32(daq[b], hq[i], accH[j][b][i]);
-				}
-				wave_lds_sync();
-#pragma unroll
-				for (uint32_t s = 0; s < 2; ++s)
-#pragma unroll
-					for (uint32_t b = 0; b < NB; ++b) {
-						dap[s][b] = prev[s][b];
-						tr_put(tile_h(j, s, b), dap[s][b]);
-					}
-				sched_fence();
-			}
-			if (want_dx) {  // dX^T = dA_0^T * W_in (below) needs nothing from LDS either: ahead of the last transposes
-#pragma unroll
-				for (uint32_t f = 0; f < FB; ++f) {
-					h4 d[2];
-#pragma unroll
-					for (uint32_t s = 0; s < 2; ++s) {
-						f4 acc = zero4();
-#pragma unroll
-						for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(pack8(dap[s][2 * p], dap[s][2 * p + 1]), winB(f, p), acc);
-						d[s] = to_h4(acc);
-					}
-					*(h8*)(dL_dinput + ((16 * f + lr) * n + base + 8 * g)) = pack8(d[0], d[1]);
-				}
-			}
-			sched_fence();
-			wave_lds_sync();
-			{  // dW_in[out][feature] += dA_0 * X^T
-				h8 daq[NB];
-#pragma unroll
-				for (uint32_t b = 0; b < NB; ++b) daq[b] = pack8(tr_get(tile_h(0, 0, b)), tr_get(tile_h(0, 1, b)));
-#pragma unroll
-				for (uint32_t b = 0; b < NB; ++b)
-#pragma unroll
-					for (uint32_t f = 0; f < FB; ++f) accI[b][f] = mfma_16x16x32(daq[b], xq[f], accI[b][f]);
-			}
-			wave_lds_sync();  // (the next strip's forward pass overwrites the tiles)
-			sched_fence();
-			continue;
-		}
-		// ================= backward =================
+		wave_lds_sync();  // this wave's tiles are in LDS
 		{  // dW_out[output][neuron] += dY * H_last^T  (accumulated unconditionally: a branch around the MFMAs costs the in-place accumulators)
-			const h8 dyq = pack8(to_h4(mfma_16x16x16(dyp[0], eye, zero4())), to_h4(mfma_16x16x16(dyp[1], eye, zero4())));
+			const h8 dyq = pack8(tr_get(TILE_DY), tr_get(TILE_DY + 1));
 			h8 hq[NB];  // the layer's activations with the samples in k: lane lr <-> neuron perm32(b, lr), k = sample 8g+j
-			transpose(hp[HM], hq);
+#pragma unroll
+			for (uint32_t b = 0; b < NB; ++b) hq[b] = pack8(tr_get(tile_h(HM, 0, b)), tr_get(tile_h(HM, 1, b)));
 #pragma unroll
 			for (uint32_t b = 0; b < NB; ++b) accO[b] = mfma_16x16x32(dyq, hq[b], accO[b]);
 		}
@@ -612,48 +482,64 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 #pragma unroll
 		for (uint32_t s = 0; s < 2; ++s)
 #pragma unroll
-			for (uint32_t b = 0; b < NB; ++b) {
-				dap[s][b] = act_backward4<GENERAL>(act, pa, mfma_16x16x16(woutT(b), dyp[s], zero4()), hp[HM][s][b]);
-			}
+			for (uint32_t b = 0; b < NB; ++b) dap[s][b] = act_backward4<GENERAL>(act, pa, mfma_16x16x16(WF_AHEAD ? w_out_t[b] : woutT(b), dyp[s], zero4()), hp[HM][s][b]);
+		wave_lds_sync();  // the activations' region has been read: it takes the layer's dL/d(pre-activation)
+#pragma unroll
+		for (uint32_t s = 0; s < 2; ++s)
+#pragma unroll
+			for (uint32_t b = 0; b < NB; ++b) tr_put(tile_h(HM, s, b), dap[s][b]);
 		sched_fence();
 #pragma unroll
 		for (int j = (int)HM - 1; j >= 0; --j) {
-			{  // dW_hid_j[out][in] += dA_{j+1} * H_j^T
-				h8 daq[NB], hq[NB];
-				transpose(dap, daq);
-				transpose(hp[j], hq);
+			// the previous layer's dL/d(pre-activation) first (it needs nothing from LDS): the tiles just stored travel meanwhile
+			h4 prev[2][NB];
+			h8 w_cur[NB][NP];
+			if constexpr (WF_AHEAD) {
 #pragma unroll
 				for (uint32_t b = 0; b < NB; ++b)
 #pragma unroll
-					for (uint32_t i = 0; i < NB; ++i) accH[j][b][i] = mfma_16x16x32(daq[b], hq[i], accH[j][b][i]);
+					for (uint32_t p = 0; p < NP; ++p) w_cur[b][p] = w_hid[b][p];
+				if (j > 0) {
+#pragma unroll
+					for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+						for (uint32_t p = 0; p < NP; ++p) w_hid[b][p] = whidT(j - 1, b, p);
+				}
 			}
-			sched_fence();
-			h4 prev[2][NB];
 #pragma unroll
 			for (uint32_t s = 0; s < 2; ++s)
 #pragma unroll
 				for (uint32_t b = 0; b < NB; ++b) {
 					f4 acc = zero4();
 #pragma unroll
-					for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(whidT(j, b, p), pack8(dap[s][2 * p], dap[s][2 * p + 1]), acc);
+					for (uint32_t p = 0; p < NP; ++p) acc = mfma_16x16x32(WF_AHEAD ? w_cur[b][p] : whidT(j, b, p), pack8(dap[s][2 * p], dap[s][2 * p + 1]), acc);
 					prev[s][b] = act_backward4<GENERAL>(act, pa, acc, hp[j][s][b]);
 				}
+			sched_fence();
+			wave_lds_sync();
+			{  // dW_hid_j[out][in] += dA_{j+1} * H_j^T
+				h8 daq[NB], hq[NB];
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b) {
+					daq[b] = pack8(tr_get(tile_h(j + 1, 0, b)), tr_get(tile_h(j + 1, 1, b)));
+					hq[b] = pack8(tr_get(tile_h(j, 0, b)), tr_get(tile_h(j, 1, b)));
+				}
+#pragma unroll
+				for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+					for (uint32_t i = 0; i < NB; ++i) accH[j][b][i] = mfma_16x16x32(daq[b], hq[i], accH[j][b][i]);
+			}
+			wave_lds_sync();
 #pragma unroll
 			for (uint32_t s = 0; s < 2; ++s)
 #pragma unroll
-				for (uint32_t b = 0; b < NB; ++b) dap[s][b] = prev[s][b];
+				for (uint32_t b = 0; b < NB; ++b) {
+					dap[s][b] = prev[s][b];
+					tr_put(tile_h(j, s, b), dap[s][b]);
+				}
 			sched_fence();
 		}
-		{  // dW_in[out][feature] += dA_0 * X^T
-			h8 daq[NB];
-			transpose(dap, daq);
-#pragma unroll
-			for (uint32_t b = 0; b < NB; ++b)
-#pragma unroll
-				for (uint32_t f = 0; f < FB; ++f) accI[b][f] = mfma_16x16x32(daq[b], xq[f], accI[b][f]);
-		}
-		sched_fence();
-		if (want_dx) {  // dX^T = dA_0^T * W_in: (sample perm32(s, 4g+r) = 8g + 4s + r, feature 16f + lr) -> eight consecutive samples per lane
+		if (want_dx) {  // dX^T = dA_0^T * W_in (below) needs nothing from LDS either: ahead of the last transposes
 #pragma unroll
 			for (uint32_t f = 0; f < FB; ++f) {
 				h4 d[2];
@@ -667,6 +553,19 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 				*(h8*)(dL_dinput + ((16 * f + lr) * n + base + 8 * g)) = pack8(d[0], d[1]);
 			}
 		}
+		sched_fence();
+		wave_lds_sync();
+		{  // dW_in[out][feature] += dA_0 * X^T
+			h8 daq[NB];
+#pragma unroll
+			for (uint32_t b = 0; b < NB; ++b) daq[b] = pack8(tr_get(tile_h(0, 0, b)), tr_get(tile_h(0, 1, b)));
+#pragma unroll
+			for (uint32_t b = 0; b < NB; ++b)
+#pragma unroll
+				for (uint32_t f = 0; f < FB; ++f) accI[b][f] = mfma_16x16x32(daq[b], xq[f], accI[b][f]);
+		}
+		wave_lds_sync();  // (the next strip's forward pass overwrites the tiles)
+		sched_fence();
 	}
 
 	// ---- this workgroup's share of the loss
@@ -852,25 +751,15 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS) k_mlp_infer_wave(const MlpMe
 }
 
 // ---- the register-resident wave-per-strip variant: instantiated for the shapes whose operands fit one wave's registers
-static bool mlp_train_wave_enabled() {
-	static const bool enabled = [] {
-		const char* e = getenv("TCNN_MLP_TRAIN_WAVE");
-		return !(e && e[0] == '0');
-	}();
-	return enabled;
-}
-
 bool mlp_train_wave_supported(const MlpMeta& m, uint32_t n, LossType loss) {
-	if (!mlp_train_wave_enabled() || m.padded_out != 16 || (m.in_width != 32 && m.in_width != 64)) return false;
+	if (m.padded_out != 16 || (m.in_width != 32 && m.in_width != 64)) return false;
 	// ReLU / None and (Relative)L2 only: the instances with out-of-line activation / loss calls gain nothing here
 	if (!act_is_simple(m.activation) || !act_is_simple(m.output_activation) || !loss_is_simple(loss)) return false;
 	if (n > (1u << 26)) return false;  // 32-bit element offsets inside the kernel
 	// 64 inputs with two hidden layers (the benchmarks/mlp shape, BASELINE configs[1]): the 144 fp32 weight-gradient accumulators per
 	// lane spill at two waves per SIMD (0.077 vs 0.068 ms for the workgroup-tiled kernel, profiles/r02_exp_notes.txt); that instance is
-	// built for ONE wave per SIMD instead (174 VGPRs + 164 AGPRs holding the accumulators, no spill): 0.0679 vs 0.0716 ms for the stage
-	// (profiles/r03_exp_notes.txt).  TCNN_MLP_WAVE_64_64_1=0 restores the tiled kernel for it.
-	static const bool wide_regs = !(getenv("TCNN_MLP_WAVE_64_64_1") && atoi(getenv("TCNN_MLP_WAVE_64_64_1")) == 0);
-	if (m.in_width == 64) return m.width == 64 && (m.n_hidden_matmuls == 0 || (wide_regs && m.n_hidden_matmuls == 1));
+	// built for ONE wave per SIMD instead (VGPRs + AGPRs holding the accumulators, no spill: profiles/r03_exp_notes.txt)
+	if (m.in_width == 64) return m.width == 64 && m.n_hidden_matmuls <= 1;
 	return (m.width == 64 && m.n_hidden_matmuls <= 1) || (m.width == 32 && m.n_hidden_matmuls <= 2);
 }
 
@@ -917,8 +806,7 @@ static void launch_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, 
 // itself) and one hidden layer (246 registers at two waves per SIMD with a strip of fp32 fragments in flight, no scratch); the 32-input
 // instances serve grid encodings and stay as they are
 bool mlp_train_f32_input_supported(const MlpMeta& m, uint32_t n, LossType loss) {
-	static const bool enabled = !(getenv("TCNN_MLP_F32_INPUT") && atoi(getenv("TCNN_MLP_F32_INPUT")) == 0);
-	return enabled && m.in_width == 64 && m.width == 64 && m.n_hidden_matmuls <= 1 && n <= (1u << 25) && mlp_train_wave_supported(m, n, loss);
+	return m.in_width == 64 && m.width == 64 && m.n_hidden_matmuls <= 1 && n <= (1u << 25) && mlp_train_wave_supported(m, n, loss);
 }
 
 void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* params_t, const half_t* input,
@@ -940,7 +828,7 @@ void mlp_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half
 
 // ---- inference instances
 bool mlp_infer_wave_supported(const MlpMeta& m, uint32_t n) {
-	if (!mlp_train_wave_enabled() || m.padded_out != 16 || (m.in_width != 32 && m.in_width != 64) || n > (1u << 25)) return false;
+	if (m.padded_out != 16 || (m.in_width != 32 && m.in_width != 64) || n > (1u << 25)) return false;
 	if (!act_is_simple(m.activation) || !act_is_simple(m.output_activation)) return false;
 	return (m.width == 64 && m.n_hidden_matmuls <= 2) || (m.width == 32 && m.n_hidden_matmuls <= 3 && m.in_width == 32);
 }
@@ -959,8 +847,7 @@ static void launch_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, 
 
 // every inference instance reads an fp32 sample-major input (16-byte aligned rows: in_width is 32 or 64)
 bool mlp_infer_f32_input_supported(const MlpMeta& m, uint32_t n) {
-	static const bool enabled = !(getenv("TCNN_MLP_F32_INPUT") && atoi(getenv("TCNN_MLP_F32_INPUT")) == 0);
-	return enabled && n <= (1u << 25) && mlp_infer_wave_supported(m, n);
+	return n <= (1u << 25) && mlp_infer_wave_supported(m, n);
 }
 
 void mlp_infer_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, const half_t* params, const half_t* input, half_t* output, const MlpF32Output& f32,

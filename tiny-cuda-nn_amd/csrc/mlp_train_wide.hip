@@ -321,14 +321,6 @@ __global__ void __launch_bounds__(WIDE_THREADS, 1) k_mlp_train_wide(const MlpMet
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-static bool mlp_train_wide_enabled() {
-	static const bool enabled = [] {
-		const char* e = getenv("TCNN_MLP_TRAIN_WIDE");
-		return !(e && e[0] == '0');
-	}();
-	return enabled;
-}
-
 static uint32_t mlp_train_wide_lds_bytes(const MlpMeta& m) {
 	const uint32_t HM = m.n_hidden_matmuls;
 	const uint32_t lda = wide_tile_ld(m.in_width / 32u);
@@ -336,7 +328,7 @@ static uint32_t mlp_train_wide_lds_bytes(const MlpMeta& m) {
 }
 
 bool mlp_train_wide_supported(const MlpMeta& m, uint32_t n) {
-	return mlp_train_wide_enabled() && m.width == WIDE && m.padded_out == 16 && (m.in_width == 32 || m.in_width == 64) &&
+	return m.width == WIDE && m.padded_out == 16 && (m.in_width == 32 || m.in_width == 64) &&
 	       m.n_hidden_matmuls <= MLP_MAX_HIDDEN_MATMULS_TRAIN && n % WIDE_S == 0 && mlp_train_wide_lds_bytes(m) <= 160u * 1024u;
 }
 

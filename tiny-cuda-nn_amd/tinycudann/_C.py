@@ -144,7 +144,6 @@ _sig("tcnn_trainer_optimizer_step_ranges", _i, _vp, _vp, _f, _sz, C.POINTER(_sz)
 _sig("tcnn_trainer_set_gradient_exchange", _i, _vp, _vp, _vp)
 _sig("tcnn_trainer_set_gradient_ready_callback", _i, _vp, _vp, _vp)
 _sig("tcnn_trainer_set_backward_level_groups", _i, _vp, C.c_uint32)
-_sig("tcnn_trainer_set_backward_overlap", _i, _vp, C.c_uint32)
 _sig("tcnn_trainer_enable_rccl", _i, _vp, _vp, _i)
 _sig("tcnn_trainer_enable_rccl_sharded", _i, _vp, _vp, _i, _i)
 _sig("tcnn_trainer_direct_export", _i, _vp, _vp, _sz, C.POINTER(_sz))
@@ -161,7 +160,6 @@ _sig("tcnn_trainer_n_stages", _i)
 _sig("tcnn_trainer_stage_name", _cp, _i)
 _sig("tcnn_trainer_get_stage_times", _i, _vp, _vp, _vp)
 _sig("tcnn_trainer_set_lds_level_budget", _i, _vp, _u32)
-_sig("tcnn_trainer_set_fused_optimizer", _i, _vp, _i)
 _sig("tcnn_get_fused_network_passes", _i)
 _sig("tcnn_set_fused_network_passes", _i, _i)
 _sig("tcnn_set_fused_identity_input", _i, _i)

@@ -269,11 +269,6 @@ class TrainableModel:
         """The encoding's backward pass in n_groups groups of consecutive levels, each reported through the ready callback."""
         _check(_lib.tcnn_trainer_set_backward_level_groups(self._h, int(n_groups)))
 
-    def set_backward_overlap(self, n_groups):
-        """Single-GPU training_step: backward scatter | owner pass | Adam pipelined over three streams in `n_groups` level groups
-        (tcnn_trainer_set_backward_overlap; bit for bit the one-stream step).  1: one stream."""
-        _check(_lib.tcnn_trainer_set_backward_overlap(self._h, int(n_groups)))
-
     def enable_rccl(self, nccl_comm, n_ranks, rank=None):
         """nccl_comm: this rank's ncclComm_t as an integer / c_void_p (None switches it off).  training_step then all-reduces every
         gradient range inside the library (RCCL loaded with dlopen) and steps each range when its collective has finished.
@@ -332,10 +327,6 @@ class TrainableModel:
         cnt = (C.c_uint64 * n)()
         _check(_lib.tcnn_trainer_get_stage_times(self._h, ms, cnt))
         return {name: (ms[i], cnt[i]) for i, name in enumerate(self.stage_names())}
-
-    def set_fused_optimizer(self, enable=True):
-        """Adam inside the grid backward's owner pass for training_step(run_optimizer=True) on one GPU (default off: measured no faster)."""
-        _check(_lib.tcnn_trainer_set_fused_optimizer(self._h, int(enable)))
 
     def set_lds_level_budget(self, n_bytes):
         _check(_lib.tcnn_trainer_set_lds_level_budget(self._h, int(n_bytes)))

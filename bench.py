@@ -380,6 +380,8 @@ def main():
         os.environ["TCNN_PRECISION"] = "bf16"  # read by tinycudann._C at import: selects the bfloat16 build of the library
 
     import tinycudann as tcnn  # fails loudly if the native library is missing
+    if os.environ.get("TCNN_FINALIZE_SEPARATE") == "1":  # A/B runs: the weight-gradient finalize as a launch of its own (scripts/gpu_r06_e.sh)
+        tcnn._C.set_finalize_in_optimizer(False)
     from tinycudann import parallel as par
 
     # TCNN_BENCH_BACKEND / TCNN_BENCH_DEVICE: dry runs of the multi-rank branch on a one-GPU box (gloo, every rank on one

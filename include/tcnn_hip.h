@@ -330,6 +330,11 @@ int tcnn_set_fused_network_passes(int enable);
  * caller's fp32 matrix itself where an instance offers it (64 inputs, 64 neurons, two hidden layers: the benchmarks/mlp shape) instead of
  * running the encoding as a kernel of its own; same bits.  Process-wide, default on; 0 restores the separate kernel (A/B runs). */
 int tcnn_set_fused_identity_input(int enable);
+/* training_step(run_optimizer = 1) that runs the whole step itself (one GPU: no gradient exchange, no ready callback, GradientMode::Overwrite):
+ * the fp32 weight-gradient slabs of the network kernel are summed by the first workgroups of the optimizer's launch -- the same additions in
+ * the same order as the stand-alone finalize kernel, the same bits -- instead of by a launch of their own (fully_fused_mlp.cu:776-835 runs
+ * split-K GEMMs there).  Process-wide, default on; 0 restores the separate kernel (A/B runs, tests). */
+int tcnn_set_finalize_in_optimizer(int enable);
 /* Tuning knob: bytes of LDS one grid-backward workgroup uses for the table slice it owns (default 64 KiB). */
 int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes);
 /* Grid backward formulation, process-wide: 0 = owner-computes LDS slices with fp32 accumulation on hashed levels,

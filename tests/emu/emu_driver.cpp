@@ -335,7 +335,7 @@ int emu_adam_step(const EmuAdam* e, uint32_t n, uint32_t n_matrix, float loss_sc
 	h.optimize_matrix_params = e->optimize_matrix_params != 0;
 	h.optimize_non_matrix_params = e->optimize_non_matrix_params != 0;
 	h.skip_zero_grad_non_matrix_params = e->skip_zero_grad_non_matrix_params != 0;
-	adam_step(nullptr, h, n, n_matrix, loss_scale, current_step, w32, (half_t*)w16, (const half_t*)grads, m1, m2, steps, nullptr, nullptr, 0, 0xFFFFFFFFu,
+	adam_step(nullptr, h, n, n_matrix, loss_scale, current_step, w32, (half_t*)w16, (half_t*)grads, m1, m2, steps, nullptr, nullptr, 0, 0xFFFFFFFFu,
 	          steps_form, deficits8, g_adam_half_follows_master);
 	return 0;
 }

@@ -391,6 +391,46 @@ def test_training_step_data_pdf_external_gradient_and_input_gradient():
         tm.loss(ctx)
 
 
+@pytest.mark.parametrize("n,log2_t,cfg_kw", [(1 << 18, 19, {}), (4096, 15, {"per_level_scale": 1.5}), (1 << 16, 17, {"n_neurons": 128, "n_hidden_layers": 4}),
+                                             (8192, 15, {"n_neurons": 32, "n_hidden_layers": 3})])
+def test_weight_gradient_slabs_summed_inside_the_optimizer_launch_equal_the_separate_kernel(n, log2_t, cfg_kw):
+    """tcnn_set_finalize_in_optimizer: training_step(run_optimizer = True) sums the network kernel's fp32 weight-gradient slabs in the first
+    workgroups of k_adam_step's launch (AdamFinalize) -- the same additions in the same order as k_mlp_finalize_gradients -- and steps those
+    parameters there.  From identical states a step with and a step without it leave bit-identical network gradients, 16-bit and master
+    weights and optimizer state (the register-order slabs of the wave kernels, the parameter-order slabs of the 128-wide kernel); also after
+    a step that did NOT run the optimizer (run_optimizer = False falls back to the kernel of its own).  The encoding's part is the same
+    code either way and is compared as the run-to-run spread of its coarse levels' packed-half atomics allows (chunked small tables)."""
+    T = tcnn()
+    cfg = config_hash(log2_hashmap_size=log2_t, **cfg_kw)
+    a, b = T.create_from_config(3, 4, cfg, seed=11), T.create_from_config(3, 4, cfg, seed=12)
+    w = a.params_full_precision.cpu().numpy().copy()
+    nm = a.n_mlp_params
+    w[nm:] *= 1.0e3
+    a.set_params_full_precision(torch.from_numpy(w))
+    try:
+        for step in range(5):
+            b.deserialize(a.serialize(serialize_optimizer=True))  # identical weights and optimizer state
+            b.set_params_full_precision(a.params_full_precision.clone())  # (snapshots carry the 16-bit weights: the master weights as well)
+            pos = positions(n, 3, seed=100 + step)
+            x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(targets_for(pos, 4)).cuda()
+            run = step != 3  # one step without the optimizer in between
+            T._C.set_finalize_in_optimizer(True)
+            a.training_step(x, t, run_optimizer=run)
+            T._C.set_finalize_in_optimizer(False)
+            b.training_step(x, t, run_optimizer=run)
+            ga, gb = a.param_gradients, b.param_gradients
+            assert torch.equal(ga[:nm].view(torch.int16), gb[:nm].view(torch.int16)), step
+            assert ga[:nm].float().abs().max() > 0
+            assert torch.equal(a.params[:nm].view(torch.int16), b.params[:nm].view(torch.int16)), step
+            assert torch.equal(a.params_full_precision[:nm].view(torch.int32), b.params_full_precision[:nm].view(torch.int32)), step
+            for u, v in zip(_optimizer_state(a)[:3], _optimizer_state(b)[:3]):
+                assert np.array_equal(u[:nm], v[:nm]), step
+            d = (ga[nm:].float() - gb[nm:].float()).abs()
+            assert float(d.max()) <= 2.0 ** -8 * float(ga[nm:].float().abs().max()) and float((d > 0).float().mean()) < 0.05, step
+    finally:
+        T._C.set_finalize_in_optimizer(True)
+
+
 @pytest.mark.parametrize("scale,offset,loss,hidden_layers", [(1.0, 0.0, "L2", 2), (0.5, 0.25, "RelativeL2", 2), (1.0, 0.0, "RelativeL2", 1)])
 def test_network_kernel_reading_the_fp32_input_of_an_identity_encoding_itself(scale, offset, loss, hidden_layers):
     """BASELINE configs[1] (64 inputs -> 64 x 2 -> 16, Identity encoding): training_step lets the register-resident network kernel load the

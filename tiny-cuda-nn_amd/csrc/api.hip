@@ -668,7 +668,7 @@ static void encoding_forward(hipStream_t stream, const Model& md, uint32_t n, co
 	}
 }
 
-// Single-kernel network passes (process-wide; TCNN_FUSED_MLP_TRAINING=0 or tcnn_set_fused_network_passes(0) turn them off):
+// Single-kernel network passes (process-wide; tcnn_set_fused_network_passes(0) turns them off):
 //   * training_step: encoding forward, ONE kernel for the network's forward + loss + backward, encoding backward;
 //   * forward() + backward() (Trainer and modules): the forward pass saves only the encoded input; the backward pass runs the same
 //     kernel with the caller's dL/doutput in place of the loss -- it RECOMPUTES the hidden activations (three small matrix products)
@@ -678,6 +678,9 @@ static void encoding_forward(hipStream_t stream, const Model& md, uint32_t n, co
 // tcnn_set_fused_identity_input(0): always the separate encoding kernel (A/B runs, tests)
 static std::atomic<int> g_fused_identity_input{1};
 static std::atomic<int> g_fused_network_passes{1};
+// training_step(run_optimizer = 1) on one GPU sums the network kernel's weight-gradient slabs inside the optimizer's launch (AdamFinalize);
+// tcnn_set_finalize_in_optimizer(0): always k_mlp_finalize_gradients, a launch of its own behind the network kernel (A/B runs, tests)
+static std::atomic<int> g_finalize_in_optimizer{1};
 static bool backward_recomputes(const Model& md) { return g_fused_network_passes.load() != 0 && md.has_network && mlp_train_supported(md.net.mlp); }
 
 // NetworkWithInputEncoding::forward_impl / inference_mixed_precision_impl (:60-81).  ctx == nullptr: inference.
@@ -1072,6 +1075,9 @@ struct tcnn_trainable_model {
 	std::string hyper_json;
 	float* loss_scratch = nullptr;  // 1024 + 1 floats
 	std::unique_ptr<Profiler> profiler;  // null unless tcnn_trainer_set_profiling enabled it
+	// training_step on one GPU: the network kernel's fp32 weight-gradient slabs of THIS step, summed inside the optimizer's launch instead
+	// of by a kernel of their own (AdamFinalize); set by training_step_fused for the optimizer step it runs itself, empty otherwise
+	AdamFinalize pending_finalize;
 	// data-parallel hosts: called between backward and the optimizer (tcnn_trainer_set_gradient_exchange)
 	void (*exchange)(void* user, void* gradients_fp16, size_t n_params, tcnn_stream_t stream) = nullptr;
 	void* exchange_user = nullptr;
@@ -1742,7 +1748,7 @@ int tcnn_optimizer_step(tcnn_optimizer_t* o, tcnn_stream_t stream, float loss_sc
 	if (!o->n) return TCNN_OK;
 	if (!weights_full_precision || !weights || !gradients) throw std::runtime_error("Optimizer::step: missing buffer");
 	++o->step;  // adam.h:159
-	adam_step((hipStream_t)stream, o->adam, o->n, o->n_matrix, loss_scale, o->step, weights_full_precision, (half_t*)weights, (const half_t*)gradients, o->m1, o->m2, o->steps);
+	adam_step((hipStream_t)stream, o->adam, o->n, o->n_matrix, loss_scale, o->step, weights_full_precision, (half_t*)weights, (half_t*)gradients /* read only: no finalize rides along */, o->m1, o->m2, o->steps);
 	TCNN_API_END
 }
 uint32_t tcnn_optimizer_step_count(const tcnn_optimizer_t* o) { return o->step; }
@@ -1873,7 +1879,9 @@ static void adam_range(tcnn_trainable_model_t* tm, hipStream_t stream, float los
 	ProfScope prof(stream, STAGE_ADAM, counts);  // a ranged (bucketed) step is ONE optimizer step
 	adam_step(stream, tm->adam, (uint32_t)n, (uint32_t)tm->md.n_mlp_params(), loss_scale, tm->optimizer_step, tm->master, tm->params, tm->grads,
 	          tm->m1, tm->m2, tm->steps, tm->params_t_valid ? tm->params_t : nullptr, tm->md.has_network ? &tm->md.net.mlp : nullptr, (uint32_t)begin,
-	          (uint32_t)end, tm->steps_form, tm->step_deficits8, /*half_follows_master=*/!tm->params_exposed);
+	          (uint32_t)end, tm->steps_form, tm->step_deficits8, /*half_follows_master=*/!tm->params_exposed,
+	          begin == 0 && tm->pending_finalize.partials ? &tm->pending_finalize : nullptr);
+	if (begin == 0) tm->pending_finalize = AdamFinalize();
 	if (tm->ema) ema_step(stream, (uint32_t)n, tm->ema_decay, tm->optimizer_step, tm->params, tm->params_ema, tm->ema_tmp, (uint32_t)begin, (uint32_t)end);
 }
 
@@ -2236,8 +2244,22 @@ static int training_step_fused(tcnn_trainable_model_t* tm, hipStream_t stream, f
 		                                  external_dL_dy ? nullptr : c->dL_doutput.as<half_t>(), need_denc ? denc.as<half_t>() : nullptr,
 		                                  want_grads ? partials.as<float>() : nullptr, external_dL_dy ? nullptr : c->block_sums.as<float>(),
 		                                  input_by_network ? &f32_input : nullptr);
-		if (want_grads) mlp_finalize_gradients(stream, md.net.mlp, n_partials, partials.as<float>(), tm->grads, accumulate, order);
+		// The slabs' sums: by the first workgroups of the optimizer's launch when this call runs the whole step itself on one GPU (nobody reads
+		// the network's gradients between here and there: no exchange, no ready callback, no accumulation) -- by their own kernel otherwise.
+		const bool sum_in_optimizer = want_grads && run_optimizer && !accumulate && !tm->exchange && !tm->direct.active() && !wants_ready_ranges(tm) &&
+		                              md.n_mlp_params() % 4 == 0 && g_finalize_in_optimizer.load() != 0;
+		if (sum_in_optimizer) {
+			tm->pending_finalize.partials = partials.as<float>();
+			tm->pending_finalize.n_partials = n_partials;
+			tm->pending_finalize.order = (uint32_t)order;
+		} else if (want_grads) {
+			mlp_finalize_gradients(stream, md.net.mlp, n_partials, partials.as<float>(), tm->grads, accumulate, order);
+		}
 	}
+	struct DropPendingFinalize {  // (an exception between here and the optimizer must not leave a dangling slab pointer behind)
+		tcnn_trainable_model_t* tm;
+		~DropPendingFinalize() { tm->pending_finalize = AdamFinalize(); }
+	} drop_pending_finalize = {tm};
 	ReadyTrampoline tramp = {tm, stream};
 	LevelGroups level_groups = {tm->backward_level_groups, want_grads && wants_ready_ranges(tm) ? &ReadyTrampoline::call : nullptr, &tramp};
 	if (level_groups.ready) level_groups.ready(&tramp, 0, md.n_mlp_params());  // the network's gradients: the first range of the step
@@ -2637,6 +2659,10 @@ int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes
 }
 int tcnn_set_fused_identity_input(int enable) {
 	g_fused_identity_input.store(enable != 0 ? 1 : 0);
+	return TCNN_OK;
+}
+int tcnn_set_finalize_in_optimizer(int enable) {
+	g_finalize_in_optimizer.store(enable != 0 ? 1 : 0);
 	return TCNN_OK;
 }
 int tcnn_get_fused_network_passes(void) { return g_fused_network_passes.load(); }

@@ -107,10 +107,19 @@ bool adam_streams_its_state(uint32_t n_params);  // optimizer state too large fo
 
 // weights_t (nullable) + mlp: also keep the transposed copy of the network weights (mlp_transposed_index) current, so
 // that the next training step does not need a transposition pass.
+// finalize (nullable): the network's weight gradients are still fp32 slabs of the training kernel (mlp_train's `partials`, `order` as it
+// returned them): the first workgroups of THIS launch sum them -- the same additions in the same order as mlp_finalize_gradients --, write the
+// 16-bit gradients into `gradients` and step those parameters; only for a step over the whole network (begin == 0, GradientMode::Overwrite).
+struct AdamFinalize {
+	const float* partials = nullptr;
+	uint32_t n_partials = 0, order = 0;
+	uint32_t blocks = 0;  // (set by adam_step)
+};
 void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale,
-               uint32_t current_step, float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2,
+               uint32_t current_step, float* weights_fp32, half_t* weights, half_t* gradients, float* m1, float* m2,
                uint32_t* param_steps, half_t* weights_t = nullptr, const MlpMeta* mlp = nullptr, uint32_t begin = 0, uint32_t end = 0xFFFFFFFFu,
-               int steps_form = ADAM_STEPS_COUNTERS, uint8_t* deficits8 = nullptr, bool half_follows_master = false);  // AdamCore::half_follows_master
+               int steps_form = ADAM_STEPS_COUNTERS, uint8_t* deficits8 = nullptr, bool half_follows_master = false,  // AdamCore::half_follows_master
+               const AdamFinalize* finalize = nullptr);
 // param_steps holds either the per-parameter step counters (adam.h:84) or, with steps_are_deficits, their deficit
 // steps_done - counter (steps_done = current_step - 1): a stepped parameter then reads its 4 bytes and writes nothing, a
 // skipped one is incremented -- cheaper when most parameters are stepped every time (the headline table: 98 %), dearer

@@ -377,14 +377,100 @@ TCNN_DEVICE uint32_t adam_next8(const AdamCore& a, uint32_t d, bool stepped, uin
 	return d < 255u ? d + 1u : 255u;
 }
 
+// one parameter on its own (the ragged end of a range; the network weights a finalize block has just summed)
+TCNN_DEVICE void adam_single(const AdamArgs& a, uint32_t i, half_t gradient, float* __restrict__ weights_fp32, half_t* __restrict__ weights,
+                             float* __restrict__ first_moments, float* __restrict__ second_moments, uint32_t* __restrict__ param_steps,
+                             half_t* __restrict__ weights_t, uint8_t* __restrict__ deficits8) {
+	float wj = weights_fp32[i], m1j = first_moments[i], m2j = second_moments[i];
+	const bool bytes = a.deficit == 2;
+	const uint32_t dj = bytes ? deficits8[i] : 0u;
+	uint32_t sj = bytes ? adam_count8(a, dj, param_steps, i) : (a.deficit ? a.steps_done - param_steps[i] : param_steps[i]);
+	const bool stepped = adam_one(a, i, (float)gradient, wj, m1j, m2j, sj);
+	if (bytes) deficits8[i] = (uint8_t)adam_next8(a, dj, stepped, sj, param_steps, i);
+	if (stepped) {
+		weights_fp32[i] = wj;
+		first_moments[i] = m1j;
+		second_moments[i] = m2j;
+		if (!a.deficit) param_steps[i] = sj;
+		weights[i] = to_half_rn(wj);
+		if (weights_t && i < a.n_matrix_weights) weights_t[mlp_transposed_index(a.mlp, i)] = weights[i];
+	} else if (a.deficit == 1) {
+		param_steps[i] += 1u;
+	}
+}
+
+// The network's weight-gradient slabs summed INSIDE the optimizer's launch (AdamFinalize): the first `blocks` workgroups of the launch each
+// take 32 slab positions, add up the training kernel's fp32 slabs exactly as k_mlp_finalize_gradients does -- 32 groups of slabs, group g
+// sums slabs g, g + 32, ... in that order, then the groups in order: the same bits -- store the 16-bit gradient and step the parameter
+// right there; the other workgroups step the encoding's parameters as always.  One launch (and its dependent boundary) less per training
+// step, and the 14.7 MB of slabs travel beside the optimizer's state stream instead of in a 224-workgroup kernel that is all latency.
+// 256 threads: lane = thread & 31 (slab position), the thread's group of 32 = G = thread >> 5, which carries groups G, G + 8, G + 16, G + 24
+// in separate accumulators, four loads of each in flight.
+TCNN_DEVICE void adam_finalize_block(const AdamArgs& a, const AdamFinalize& fin, float* __restrict__ weights_fp32, half_t* __restrict__ weights,
+                                     half_t* __restrict__ gradients, float* __restrict__ first_moments, float* __restrict__ second_moments,
+                                     uint32_t* __restrict__ param_steps, half_t* __restrict__ weights_t, uint8_t* __restrict__ deficits8) {
+	constexpr uint32_t GROUPS = 32, PER_THREAD = GROUPS / (EW_THREADS / 32), U = 16, CHUNK = 4;
+	static_assert(EW_THREADS % 32 == 0 && GROUPS % (EW_THREADS / 32) == 0 && U % CHUNK == 0, "finalize geometry");
+	__shared__ float red[GROUPS][32];
+	const uint32_t lane = threadIdx.x & 31u, G = threadIdx.x >> 5;
+	const uint32_t i = blockIdx.x * 32u + lane, n_params = a.n_matrix_weights;
+	float s[PER_THREAD];
+#pragma unroll
+	for (uint32_t k = 0; k < PER_THREAD; ++k) s[k] = 0.0f;
+	if (i < n_params) {
+		// (PER_THREAD x CHUNK loads in flight and no more -- the loops are NOT unrolled further: this role shares its kernel, and with it its
+		// register allocation, with the optimizer's streaming workgroups, whose eight waves per SIMD are what keeps HBM busy)
+		const float* __restrict__ column = fin.partials + i;  // element offsets of a slab fit 32 bits (the host checks n_partials * n_params)
+		for (uint32_t b0 = 0; b0 < fin.n_partials; b0 += GROUPS * U) {
+#pragma clang loop unroll(disable)
+			for (uint32_t c = 0; c < U; c += CHUNK) {
+				float v[PER_THREAD][CHUNK];
+#pragma unroll
+				for (uint32_t k = 0; k < PER_THREAD; ++k) {
+#pragma unroll
+					for (uint32_t u = 0; u < CHUNK; ++u) {
+						const uint32_t bb = b0 + (G + (EW_THREADS / 32) * k) + (c + u) * GROUPS;
+						v[k][u] = bb < fin.n_partials ? column[bb * n_params] : 0.0f;
+					}
+				}
+#pragma unroll
+				for (uint32_t k = 0; k < PER_THREAD; ++k) {
+#pragma unroll
+					for (uint32_t u = 0; u < CHUNK; ++u) s[k] += v[k][u];
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (uint32_t k = 0; k < PER_THREAD; ++k) red[G + (EW_THREADS / 32) * k][lane] = s[k];
+	__syncthreads();
+	if (G == 0 && i < n_params) {
+		float t = red[0][lane];
+#pragma unroll
+		for (uint32_t k = 1; k < GROUPS; ++k) t += red[k][lane];
+		const uint32_t param = fin.order == (uint32_t)SlabOrder::WaveRegisters ? mlp_wave_slab_param(a.mlp, i) : i;
+		const half_t g = to_half_rn(t);
+		gradients[param] = g;
+		adam_single(a, param, g, weights_fp32, weights, first_moments, second_moments, param_steps, weights_t, deficits8);
+	}
+}
+
 // 4 parameters per lane: 8 B of gradients decide whether the 16-byte state loads happen at all, so
 // untouched stretches of a hash table cost 2 B/param as in the reference (adam.h:79-82).
-template <bool STREAM>
+template <bool STREAM, bool FINALIZE>
 __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, float* __restrict__ weights_fp32, half_t* __restrict__ weights,
-                                                           const half_t* __restrict__ gradients, float* __restrict__ first_moments,
+                                                           half_t* __restrict__ gradients, float* __restrict__ first_moments,
                                                            float* __restrict__ second_moments, uint32_t* __restrict__ param_steps,
-                                                           half_t* __restrict__ weights_t, uint8_t* __restrict__ deficits8) {
-	const uint32_t i0 = a.begin + (blockIdx.x * EW_THREADS + threadIdx.x) * 4;
+                                                           half_t* __restrict__ weights_t, uint8_t* __restrict__ deficits8, const AdamFinalize fin) {
+	uint32_t block = blockIdx.x;
+	if constexpr (FINALIZE) {  // (a.begin == the first parameter behind the network's: the host checked)
+		if (block < fin.blocks) {
+			adam_finalize_block(a, fin, weights_fp32, weights, gradients, first_moments, second_moments, param_steps, weights_t, deficits8);
+			return;
+		}
+		block -= fin.blocks;
+	}
+	const uint32_t i0 = a.begin + (block * EW_THREADS + threadIdx.x) * 4;
 	const bool four = i0 < a.n_elements && i0 + 3 < a.n_elements;
 	h4 g = h4{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
 	if (four) g = *(const h4*)(gradients + i0);
@@ -468,24 +554,7 @@ __global__ void __launch_bounds__(EW_THREADS) k_adam_step(const AdamArgs a, floa
 			*(h4*)(weights + i0) = wh;
 		}
 	} else {
-		for (uint32_t i = i0; i < a.n_elements; ++i) {
-			float wj = weights_fp32[i], m1j = first_moments[i], m2j = second_moments[i];
-			const bool bytes = a.deficit == 2;
-			const uint32_t dj = bytes ? deficits8[i] : 0u;
-			uint32_t sj = bytes ? adam_count8(a, dj, param_steps, i) : (a.deficit ? a.steps_done - param_steps[i] : param_steps[i]);
-			const bool stepped = adam_one(a, i, (float)gradients[i], wj, m1j, m2j, sj);
-			if (bytes) deficits8[i] = (uint8_t)adam_next8(a, dj, stepped, sj, param_steps, i);
-			if (stepped) {
-				weights_fp32[i] = wj;
-				first_moments[i] = m1j;
-				second_moments[i] = m2j;
-				if (!a.deficit) param_steps[i] = sj;
-				weights[i] = to_half_rn(wj);
-				if (weights_t && i < a.n_matrix_weights) weights_t[mlp_transposed_index(a.mlp, i)] = weights[i];
-			} else if (a.deficit == 1) {
-				param_steps[i] += 1u;
-			}
-		}
+		for (uint32_t i = i0; i < a.n_elements; ++i) adam_single(a, i, gradients[i], weights_fp32, weights, first_moments, second_moments, param_steps, weights_t, deficits8);
 	}
 }
 
@@ -524,8 +593,8 @@ AdamCore make_adam_core(const AdamHyper& h, uint32_t n_matrix_weights, float los
 bool adam_streams_its_state(uint32_t n) { return (size_t)n * 32u > ADAM_STREAM_THRESHOLD_BYTES; }
 
 void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_matrix_weights, float loss_scale, uint32_t current_step,
-               float* weights_fp32, half_t* weights, const half_t* gradients, float* m1, float* m2, uint32_t* param_steps, half_t* weights_t,
-               const MlpMeta* mlp, uint32_t begin, uint32_t end, int steps_form, uint8_t* deficits8, bool half_follows_master) {
+               float* weights_fp32, half_t* weights, half_t* gradients, float* m1, float* m2, uint32_t* param_steps, half_t* weights_t,
+               const MlpMeta* mlp, uint32_t begin, uint32_t end, int steps_form, uint8_t* deficits8, bool half_follows_master, const AdamFinalize* finalize) {
 	if (end > n) end = n;
 	if (begin >= end) return;
 	if (begin % 4u != 0u) throw std::runtime_error("adam_step: a parameter range must start at a multiple of 4");
@@ -537,12 +606,26 @@ void adam_step(hipStream_t stream, const AdamHyper& h, uint32_t n, uint32_t n_ma
 	a.begin = begin;
 	a.n_elements = end;
 	a.mlp = mlp ? *mlp : MlpMeta{};
-	const dim3 grid(div_round_up(div_round_up(end - begin, 4u), EW_THREADS));
-	if (adam_streams_its_state(n)) {
-		TCNN_LAUNCH(k_adam_step<true>, grid, dim3(EW_THREADS), 0, stream, a, weights_fp32, weights, gradients, m1, m2, param_steps, weights_t, deficits8);
-	} else {
-		TCNN_LAUNCH(k_adam_step<false>, grid, dim3(EW_THREADS), 0, stream, a, weights_fp32, weights, gradients, m1, m2, param_steps, weights_t, deficits8);
+	AdamFinalize fin;
+	if (finalize && finalize->partials) {
+		// the finalize workgroups sum AND step the network's weights; the others start behind them
+		if (begin != 0 || !mlp || mlp->n_params() != n_matrix_weights || n_matrix_weights % 4u != 0u || end < n_matrix_weights || finalize->n_partials == 0 ||
+		    (uint64_t)finalize->n_partials * n_matrix_weights >= (1ull << 32)) {
+			throw std::runtime_error("adam_step: the weight-gradient slabs can only be summed inside an optimizer step over the whole network");
+		}
+		fin = *finalize;
+		fin.blocks = div_round_up(n_matrix_weights, 32u);
+		a.begin = n_matrix_weights;
 	}
+	const dim3 grid(fin.blocks + div_round_up(div_round_up(end - a.begin, 4u), EW_THREADS));
+#define TCNN_ADAM_LAUNCH(STREAM_, FINALIZE_) \
+	TCNN_LAUNCH((k_adam_step<STREAM_, FINALIZE_>), grid, dim3(EW_THREADS), 0, stream, a, weights_fp32, weights, gradients, m1, m2, param_steps, weights_t, deficits8, fin)
+	if (adam_streams_its_state(n)) {
+		if (fin.blocks) TCNN_ADAM_LAUNCH(true, true); else TCNN_ADAM_LAUNCH(true, false);
+	} else {
+		if (fin.blocks) TCNN_ADAM_LAUNCH(false, true); else TCNN_ADAM_LAUNCH(false, false);
+	}
+#undef TCNN_ADAM_LAUNCH
 }
 
 // counters <-> deficits: x -> steps_done - x is its own inverse (mod 2^32)

@@ -162,6 +162,7 @@ _sig("tcnn_trainer_get_stage_times", _i, _vp, _vp, _vp)
 _sig("tcnn_trainer_set_lds_level_budget", _i, _vp, _u32)
 _sig("tcnn_get_fused_network_passes", _i)
 _sig("tcnn_set_fused_network_passes", _i, _i)
+_sig("tcnn_set_finalize_in_optimizer", _i, _i)
 _sig("tcnn_set_fused_identity_input", _i, _i)
 _sig("tcnn_set_grid_backward_mode", _i, _i)
 _sig("tcnn_get_grid_backward_mode", _i)
@@ -304,6 +305,11 @@ def get_fused_network_passes():
 def set_fused_identity_input(enable):
     """training_step with an unpadded Identity encoding: the network kernel loads the fp32 input itself (default) / the encoding runs as its own kernel."""
     _check(_lib.tcnn_set_fused_identity_input(int(bool(enable))))
+
+
+def set_finalize_in_optimizer(enable):
+    """Process-wide: training_step sums the network's weight-gradient slabs inside the optimizer's launch (default) / in a kernel of their own."""
+    _check(_lib.tcnn_set_finalize_in_optimizer(int(bool(enable))))
 
 
 def set_fused_network_passes(enable):

@@ -13,7 +13,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REFERENCE = "/root/reference/samples/mlp_learning_an_image.cu"
+REFERENCE = os.path.join(os.environ.get("REFERENCE_DIR", "/root/reference"), "samples", "mlp_learning_an_image.cu")
 TEMPLATE = os.path.join(ROOT, "samples", "mlp_learning_an_image.hip.in")
 OUT_DIR = os.path.join(ROOT, "samples", "_generated")
 OUT = os.path.join(OUT_DIR, "mlp_learning_an_image.hip")
@@ -66,5 +66,5 @@ def generate():
 
 if __name__ == "__main__":
     p = generate()
-    print(p if p else "no /root/reference here: nothing generated (the prebuilt binary is used)")
+    print(p if p else f"{REFERENCE} not found: nothing generated (a binary built earlier, e.g. the one that travelled to the GPU box, keeps working)")
     sys.exit(0)

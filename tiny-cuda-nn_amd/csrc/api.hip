@@ -2068,14 +2068,13 @@ static void direct_exchange_and_step(tcnn_trainable_model_t* tm, hipStream_t str
 		begins.push_back(dx.own_begin);
 		ends.push_back(dx.own_end);
 	}
-	g_prof_every_stage = true;
-	try {
+	{
+		struct EveryStage {  // the exchange's Adam is one of its phases: timed whatever the profiler's stage filter says
+			EveryStage() { g_prof_every_stage = true; }
+			~EveryStage() { g_prof_every_stage = false; }
+		} every_stage;
 		optimizer_step_ranges(tm, stream, loss_scale, begins.size(), begins.data(), ends.data(), /*advance=*/true, /*opens_profiled_step=*/true);
-	} catch (...) {
-		g_prof_every_stage = false;
-		throw;
 	}
-	g_prof_every_stage = false;
 	{
 		ProfilerGuard pg(tm->profiler.get());
 		{

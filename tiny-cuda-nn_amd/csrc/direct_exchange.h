@@ -55,6 +55,8 @@ struct DirectExchange {
 	uint32_t* own_signals = nullptr;           // this rank's block (allocated here, exported)
 	uint32_t* error_flag = nullptr;            // device word: non-zero once a wait timed out
 	volatile uint32_t* host_error = nullptr;   // pinned host copy of it, refreshed behind every step's push: the NEXT step fails instead of training on
+	void* step_done = nullptr;                 // hipEvent_t recorded behind that refresh: begin_step waits for the step before, so the copy it reads is that step's
+	bool step_recorded = false;
 	void* mapped_buffers[DIRECT_MAX_RANKS] = {};  // bases returned by hipIpcOpenMemHandle (to close)
 	void* mapped_signals[DIRECT_MAX_RANKS] = {};
 	uint32_t step = 0;

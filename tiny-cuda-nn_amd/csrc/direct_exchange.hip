@@ -226,9 +226,16 @@ void direct_exchange_open(DirectExchange& dx, int rank, int n_ranks, const Direc
 	hip_ok(hipMemset(dx.own_signals, 0, (2 * DIRECT_MAX_RANKS + 16) * sizeof(uint32_t)), "hipMemset(signals)");
 	hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
 	*dx.host_error = 0;
+	dx.step_recorded = false;
 }
 
 void direct_exchange_close(DirectExchange& dx) {
+	if (dx.step_done) {
+		(void)hipEventSynchronize((hipEvent_t)dx.step_done);
+		(void)hipEventDestroy((hipEvent_t)dx.step_done);
+		dx.step_done = nullptr;
+		dx.step_recorded = false;
+	}
 	for (int r = 0; r < DIRECT_MAX_RANKS; ++r) {
 		if (dx.mapped_buffers[r]) (void)hipIpcCloseMemHandle(dx.mapped_buffers[r]);
 		if (dx.mapped_signals[r]) (void)hipIpcCloseMemHandle(dx.mapped_signals[r]);
@@ -251,8 +258,11 @@ static void signal_and_wait(hipStream_t stream, DirectExchange& dx, int row) {
 // ---- a step's exchange, phase by phase (the trainer brackets each with profiler events so that a node run explains itself) ------------
 void direct_exchange_begin_step(DirectExchange& dx) {
 	if (!dx.active()) throw std::runtime_error("direct exchange: not open");
-	// the error word as of the last finished step (pinned copy, no synchronisation): a wait that gave up means this replica stepped on
-	// unreduced gradients or stale parameters -- fail here instead of training on
+	// The error word as of the step before: a wait that gave up means this replica stepped on unreduced gradients or stale parameters -- fail
+	// here instead of training on.  The pinned copy is refreshed by a copy queued behind every step, and the host runs ahead of the GPU: the
+	// event behind that copy is waited for here, so that the word read IS the previous step's (every step is serialised against the peers
+	// anyway; the host keeps one step of lead, not several steps on gradients nobody reduced).
+	if (dx.step_done && dx.step_recorded) hip_ok(hipEventSynchronize((hipEvent_t)dx.step_done), "hipEventSynchronize(previous step of the direct exchange)");
 	if (dx.host_error && *dx.host_error) {
 		throw std::runtime_error("direct exchange: a wait for the peers' " + std::string(*dx.host_error == 1 ? "gradients" : "parameters") +
 		                         " timed out in an earlier step (TCNN_DIRECT_TIMEOUT_MS): the replicas are no longer in lock-step");
@@ -272,6 +282,13 @@ void direct_exchange_push_own(hipStream_t stream, DirectExchange& dx) {
 }
 void direct_exchange_finish_step(hipStream_t stream, DirectExchange& dx) {
 	if (dx.host_error) hip_ok(hipMemcpyAsync((void*)dx.host_error, dx.error_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(error word)");
+	if (!dx.step_done) {
+		hipEvent_t e;
+		hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+		dx.step_done = (void*)e;
+	}
+	hip_ok(hipEventRecord((hipEvent_t)dx.step_done, stream), "hipEventRecord");
+	dx.step_recorded = true;
 }
 
 void direct_exchange_reduce(hipStream_t stream, DirectExchange& dx) {
@@ -315,7 +332,9 @@ void direct_exchange_selftest(hipStream_t stream, DirectExchange& dx, uint32_t r
 	hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize");
 	(void)hipFree(counter);
 	if (mismatches) *mismatches = (uint64_t)bad;
-	if (status) *status = direct_exchange_status(stream, dx);
+	const int st = direct_exchange_status(stream, dx);
+	if (dx.host_error) *dx.host_error = (uint32_t)st;  // (the stream is idle: what the first step's begin_step reads is the self-test's outcome)
+	if (status) *status = st;
 }
 
 int direct_exchange_status(hipStream_t stream, DirectExchange& dx) {

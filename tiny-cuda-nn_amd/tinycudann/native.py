@@ -187,8 +187,16 @@ class TrainableModel:
 
     @property
     def params_full_precision(self):
-        """The fp32 master weights, to READ (tcnn_trainer_params_full_precision_view: the trainer's mode does not change).  To write them:
-        set_params_full_precision(), or `params_full_precision_mutable` followed by set_params_full_precision / params_written."""
+        """The fp32 master weights as a COPY (a snapshot of tcnn_trainer_params_full_precision_view: the trainer's mode does not change, and
+        writing into the returned tensor changes nothing in the trainer -- visibly, instead of leaving 16-bit weights behind that the
+        optimizer no longer re-derives).  To write them: set_params_full_precision(), or `params_full_precision_mutable` followed by
+        params_written().  `params_full_precision_view` is the zero-copy form for readers that keep their hands off it."""
+        return self.params_full_precision_view.clone()
+
+    @property
+    def params_full_precision_view(self):
+        """The fp32 master weights in place, to READ ONLY (tcnn_trainer_params_full_precision_view): no copy, no change of the trainer's mode;
+        a write through it would bypass the trainer's bookkeeping (the 16-bit weights of parameters whose gradient is zero would go stale)."""
         return self._tensor(_lib.tcnn_trainer_params_full_precision_view(self._h), "<f4")
 
     @property

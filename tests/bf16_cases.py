@@ -215,11 +215,18 @@ def test_stress_shape_training_step_at_its_stated_size():
     for l in range(16):
         a, b = gq[nm + off[l]:nm + off[l + 1]], gref[nm + off[l]:nm + off[l + 1]]
         assert rel(a, b) < 5e-2, (l, rel(a, b))
-        # untouched entries stay exactly zero (the optimizer skips them).  The owner pass sums records in 2^-24 fixed point -- the
-        # resolution of the fp16 type it was built for -- so bfloat16 records below 2^-25 vanish where the oracle keeps them
-        # (and a coarse level's bf16 partial sums of ~45 records each can cancel to an exact zero where the exact sum is ~1e-3 of a typical entry)
-        floor = max(2.0 ** -20, 2e-2 * float(np.sqrt(np.mean(b.astype(np.float64) ** 2))))
-        assert np.mean((a != 0) & (b == 0)) < 1e-4 and np.mean((a == 0) & (np.abs(b) > floor)) < 1e-4, l
+        # Untouched entries stay exactly zero on both sides (the optimizer skips them, adam.h:79-82).  Touched ones: the owner pass sums bfloat16
+        # records in fixed point at an exponent chosen per slice from the level's own |dL/dy| (OwnerScale, grid_kernels.hip) -- 2^-28 on the
+        # hashed levels of this step, so a sum survives unless it is below 2^-29 = 2.5e-5 of the level's rms (round 5: 2^-24 for every level,
+        # i.e. everything below 8e-4 of the rms vanished, and the test accepted zeros up to 2 % of it).  Tables of 2^19 entries and more have
+        # one owner per slice: a zero where the oracle holds more than 1e-4 of the rms is a sample whose dL/dy differs between the two sides
+        # (a ReLU mask that flips on a pre-activation next to zero) -- fewer than one entry in 10^5.  The smaller tables are split over sample
+        # chunks whose partial sums (~45 records each) meet in bfloat16 atomics: two of them can cancel to an exact zero where the exact sum
+        # is a percent of a typical entry -- the 8-bit mantissa, not the fixed point.
+        rms = float(np.sqrt(np.mean(b.astype(np.float64) ** 2)))
+        assert np.mean((a != 0) & (b == 0)) < 1e-4 and np.mean((a == 0) != (b == 0)) < 1.5e-3, l
+        floor = (1e-4 if off[l + 1] - off[l] >= 2 * (1 << 19) else 2e-2) * rms
+        assert np.mean((a == 0) & (np.abs(b) > floor)) < 1e-5, (l, np.mean((a == 0) & (np.abs(b) > floor)))
 
     # one optimizer step (the streaming Adam variant) from the GPU's own gradients
     ref = O.TrainState(md, init)

@@ -584,11 +584,25 @@ def test_full_size_training_converges():
     assert torch.equal(a, b)
 
 
-def test_torch_modules_autograd_and_padding():
+@pytest.fixture(params=["compiled", "ctypes"])
+def binding(request, monkeypatch):
+    """Both bindings behind the tinycudann modules: the compiled extension (tinycudann/ext/bindings.cpp -> _tcnn_ext.so: pybind11 Module + the
+    autograd function pair in C++, what the reference ships) and the ctypes classes of _C.py (the fallback when the extension is not built)."""
+    C = tcnn()._C
+    if request.param == "compiled":
+        assert C.EXT is not None, "the compiled binding is missing: __graft_entry__.build() builds tiny-cuda-nn_amd/tinycudann/_tcnn_ext.so"
+        assert "_tcnn_ext" in open("/proc/self/maps").read()
+    else:
+        monkeypatch.setattr(C, "EXT", None)
+    return request.param
+
+
+def test_torch_modules_autograd_and_padding(binding):
     """modules.py surface: batch padding to 256, output slicing, loss-scale handling, two forwards then one
     backward (scripts/test_torch_bindings.py), pickling."""
     T = tcnn()
     model = T.NetworkWithInputEncoding(3, 4, HASH_ENCODING_SMALL, MLP_64x2, seed=1337)
+    assert type(model.native_tcnn_module).__name__ == ("ExtModule" if binding == "compiled" else "Module")
     assert model.params.dtype == torch.float32 and model.params.shape[0] == model.native_tcnn_module.n_params()
     with torch.no_grad():
         model.params[7168:] *= 1.0e3  # lift the U(-1e-4, 1e-4) grid init out of the fp16 subnormal range
@@ -628,7 +642,7 @@ def test_torch_modules_autograd_and_padding():
     assert torch.equal(clone(x), y1)
 
 
-def test_fp32_encoding_module():
+def test_fp32_encoding_module(binding):
     """tcnn.Encoding(..., dtype=torch.float32) = create_encoding(Precision::Fp32) -> Encoding<float> (cpp_api.cu:165-174): fp32 parameters,
     features and gradients, COMPUTED in fp32 as the reference's instantiation does -- against the oracle's fp32 restatement (pinned to the
     reference's kernel_grid<float> / kernel_grid_backward<float, float> / kernel_grid_backward_input<float>, tests/test_oracle_ref.py).
@@ -1165,7 +1179,7 @@ def test_deep_network_trains():
 
 
 @pytest.mark.parametrize("interp", ["Linear", "Smoothstep"])
-def test_grid_second_order_through_c_abi_and_double_backward(interp):
+def test_grid_second_order_through_c_abi_and_double_backward(interp, binding):
     """backward_backward_input of the grid encoding (grid.h:352-655, 910-1042): the three native outputs against the
     oracle, and torch double backward (an eikonal-style loss on d(encoding)/dx) against torch.autograd.gradcheck-free
     finite differences."""

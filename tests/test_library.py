@@ -401,3 +401,29 @@ def test_no_register_of_a_hand_issued_load_is_touched_before_its_wait(tmp_path, 
     path_around_the_wait = kernel([("global_load_dwordx3 v[10:12], v2, s[4:5] nt", None), ("s_cbranch_vccnz 2", 3), ("s_waitcnt vmcnt(0)", None),
                                    ("v_mov_b32_e32 v11, 0", None), ("s_endpgm", None)])
     assert len(chk.check_kernel("f", path_around_the_wait)[0]) == 1
+
+
+def test_compiled_torch_binding_builds_and_mirrors_the_reference_module():
+    """tinycudann/ext/bindings.cpp -> _tcnn_ext.so (built by __graft_entry__.build(); g++ against torch's headers, no device code): importable
+    without a GPU, bound to the library _C.py loaded, `Module` with the reference's method names (bindings.cpp:322-335), the three factories
+    (bindings.cpp:337-341) -- and the modules of the package pick it up."""
+    sys.path.insert(0, os.path.join(ROOT, "tiny-cuda-nn_amd"))
+    from tinycudann.ext import build_ext
+    assert os.path.exists(build_ext.build())  # (a no-op when the file is newer than its source)
+    import tinycudann as T
+    ext = T._C.EXT
+    assert ext is not None and ext.library_path() == T._C.library_path()
+    for name in ("fwd", "bwd", "bwd_bwd_input", "initial_params", "n_input_dims", "n_params", "param_precision", "n_output_dims", "output_precision", "name"):
+        assert hasattr(ext.Module, name), name
+    for name in ("create_network_with_input_encoding", "create_network", "create_encoding", "batch_size_granularity", "default_loss_scale", "apply"):
+        assert hasattr(ext, name), name
+    assert ext.batch_size_granularity() == 256 and ext.default_loss_scale(1) == 128.0
+    enc = {"otype": "HashGrid", "n_levels": 4, "n_features_per_level": 2, "log2_hashmap_size": 12, "base_resolution": 4, "per_level_scale": 1.5}
+    m = T._C.create_encoding(3, enc)
+    assert type(m).__name__ == "ExtModule" and m.n_input_dims() == 3 and m.n_output_dims() == 8 and m.hyperparams()["n_levels"] == 4
+    with pytest.raises(RuntimeError):
+        T._C.create_network(3, 4, {"otype": "FullyFusedMLP", "n_neurons": 48, "n_hidden_layers": 2})  # the library's message, as a RuntimeError
+    # the extension links neither precision of the library: it resolves the C ABI from the one that is loaded
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", os.path.join(ROOT, "tiny-cuda-nn_amd", "tinycudann", "_tcnn_ext.so")], capture_output=True, text=True).stdout
+    assert "libtcnn_hip" not in needed and "libc10_hip" in needed

@@ -783,6 +783,7 @@ struct BucketPlan {
 	uint32_t wgs_per_level;      // persistent pass-A workgroups per level (each walks tiles wg, wg + wgs_per_level, ...)
 	uint32_t scatter_blocks;     // n_levels * wgs_per_level: pass-A blocks beyond these zero the gradients of chunked levels
 	uint32_t overflow_counter;   // index of the overflow counter (== total number of queues); the one after it counts finished pass-C blocks
+	uint32_t level_sum_base;     // (even) index of slot 0's 64-bit sums (LEVEL_SUM_PARTS per level) of |dL/dy| over the batch, 2^-32 units (OwnerScale; bfloat16 build only)
 	uint32_t overflow_capacity;  // records
 	uint32_t n_owner_blocks;     // workgroups of pass B that own a bucket (the last one to finish resets the bookkeeping counters)
 	uint32_t packed_owner;       // pass B's bucket items run in k_grid_bucket_owner (packed accumulators), not in k_grid_backward_sliced
@@ -838,6 +839,47 @@ TCNN_DEVICE uint32_t queue_load(const uint32_t* p) { return __builtin_nontempora
 constexpr uint32_t BUCKET_INVALID_INDEX = 0xFFFFFFFFu;  // second record of a pair that has none
 TCNN_DEVICE uint32_t h2_bits(h2 v) { return __builtin_bit_cast(uint32_t, v); }
 TCNN_DEVICE h2 bits_h2(uint32_t v) { return __builtin_bit_cast(h2, v); }
+
+// Fixed-point exponent of a bucket owner's accumulators (pass B): a record v is accumulated as the integer round(v * 2^k).
+//   IEEE half: k = 24 for every slice -- a half times 2^24 is an integer already (11 significant bits, exponent >= -24): exact sums.
+//   bfloat16 (-DTCNN_BF16): the type reaches down to 2^-133, and at a fixed 2^-24 records below 2^-25 vanished and small ones lost most of
+//   their eight bits (round 5's stress-shape test had to tolerate entries that the oracle touched and the GPU left at zero).  k is chosen per
+//   slice from what pass A measured: the level's sum of |dL/dy| over the batch (a 64-bit integer sum, so the same k every run) divided by
+//   the level's slices, with a factor 8 of headroom over that uniform share -- k = 30 - ceil(log2(8 * share)), 20 <= k <= 40.  At the
+//   stress shape: k = 31 - 34 for the hashed levels, resolution 2^-31 and finer against records of 1e-7 and up.  A slice whose records
+//   exceed the headroom (clustered samples) fails the int32 bound test as before and is redone with 64 bits per value at the same k.
+struct OwnerScale {
+	int k;
+	TCNN_DEVICE float up(float v) const { return HALF_IS_BF16 ? __builtin_ldexpf(v, k) : v * 16777216.0f; }
+	TCNN_DEVICE float down(float v) const { return HALF_IS_BF16 ? __builtin_ldexpf(v, -k) : v * (1.0f / 16777216.0f); }
+	TCNN_DEVICE float safe_abs_sum() const { return HALF_IS_BF16 ? __builtin_ldexpf(0.9375f, 31 - k) : 120.0f; }  // < 2^31 / 2^k, with room for the bound's own rounding
+	TCNN_DEVICE double up64() const { return HALF_IS_BF16 ? __builtin_ldexp(1.0, k) : 16777216.0; }
+	TCNN_DEVICE double down64() const { return HALF_IS_BF16 ? __builtin_ldexp(1.0, -k) : 1.0 / 16777216.0; }
+};
+constexpr uint32_t LEVEL_SUM_PARTS = 8;  // words a level's sum is spread over (the scatter's workgroups add into word blockIdx % 8)
+constexpr float LEVEL_SUM_CLAMP = 4096.0f;  // per sample: 2^18 .. 2^20 samples of it stay inside 64 bits at 2^-32 units
+template <typename PLAN>
+TCNN_DEVICE OwnerScale owner_scale(const PLAN& plan, const uint32_t* counters, uint32_t j) {
+	if constexpr (!HALF_IS_BF16) return OwnerScale{24};
+	unsigned long long sum = 0;
+#pragma unroll
+	for (uint32_t p = 0; p < LEVEL_SUM_PARTS; ++p) sum += *(const unsigned long long*)(counters + plan.level_sum_base + 2u * (j * LEVEL_SUM_PARTS + p));
+	if (sum == 0ull) return OwnerScale{40};
+	const float share = (float)sum * (8.0f / 4294967296.0f) / (float)(plan.n_buckets[j] * plan.n_chunks[j]);
+	int e;
+	(void)__builtin_frexpf(share, &e);  // share < 2^e
+	const int k = 30 - e;
+	return OwnerScale{k < 20 ? 20 : (k > 40 ? 40 : k)};
+}
+
+// the 64-bit-per-value forms: IEEE half through to_fixed() (fp32 / int32 operations only); bfloat16 at the slice's exponent
+TCNN_DEVICE long long to_fixed64(float v, const OwnerScale& sc) {
+	if constexpr (!HALF_IS_BF16) return to_fixed(v);
+	const double s = (double)v * sc.up64();
+	if (!(__builtin_fabs(s) < 9.0e18)) return 0;  // beyond 64 bits, infinite or NaN: gradients no sum can represent (the reference's atomics would carry NaN / Inf on)
+	return (long long)__builtin_rint(s);
+}
+TCNN_DEVICE half_t from_fixed64(long long q, const OwnerScale& sc) { return (half_t)(float)((double)q * sc.down64()); }
 
 // SECOND_ORDER: scatter d(dL_dx)/d(grid) instead of dy/d(grid) (backward_backward_input's parameter part) -- a compile-time switch: as a
 // run-time select the corner weight of the second-order form (three products per dimension and corner) sits next to the first-order one in
@@ -922,10 +964,20 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 #endif
 	__syncthreads();
 
+	float level_abs_sum = 0.0f;  // (bfloat16 build)
 	for (uint32_t tile = first_tile; tile < plan.tiles; tile += plan.wgs_per_level) {
 		const uint32_t chunk = tile / plan.tiles_per_chunk[j];
 		uint32_t* __restrict__ my_counters = counters + plan.counter_base[j] + chunk * nb;
 
+#if defined(TCNN_BF16)  // the level's sum of |dL/dy| (OwnerScale), gathered per thread over the workgroup's tiles
+#pragma unroll
+		for (uint32_t s = 0; s < SPT; ++s) {
+			float m = 0.0f;
+#pragma unroll
+			for (uint32_t f = 0; f < F; ++f) m = __builtin_fmaxf(m, __builtin_fabsf((float)g[s][f]));
+			if (tile * TILE + s * BUCKET_THREADS + threadIdx.x < io.n) level_abs_sum += __builtin_fminf(m, LEVEL_SUM_CLAMP);  // (NaN -> the other operand: the bound test sees it)
+		}
+#endif
 		// ---- derive the records of my samples; rank each pair within its bucket
 		uint32_t ridx[SPT][N_CORNERS], rank[SPT][N_PAIRS_PER_SAMPLE], pay[SPT][N_CORNERS][PW];
 		auto derive = [&](auto fast_tag) {
@@ -1106,6 +1158,24 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 			for (uint32_t f = 0; f < F; ++f) g[s][f] = g_next[s][f];
 		}
 	}
+#if defined(TCNN_BF16)
+	{  // ONE 64-bit integer atomic per workgroup, into one of the level's LEVEL_SUM_PARTS words (per wave and tile -- 2048 same-address atomics per
+	   // level -- the atomics serialised in their L2 channel and the pass took five times as long)
+		const float wave_total = wave_sum_f32(level_abs_sum);
+		if (lane_id() == 0) part[threadIdx.x / WAVE] = __builtin_bit_cast(uint32_t, wave_total);
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			float total = 0.0f;
+			for (uint32_t w = 0; w < BUCKET_THREADS / WAVE; ++w) total += __builtin_bit_cast(float, part[w]);
+			if (total > 0.0f) {
+				atomicAdd((unsigned long long*)(counters + plan.level_sum_base + 2u * (j * LEVEL_SUM_PARTS + (blockIdx.x % LEVEL_SUM_PARTS))),
+				          (unsigned long long)((double)total * 4294967296.0));
+			}
+		}
+	}
+#else
+	(void)level_abs_sum;
+#endif
 }
 
 // What every owner of a (bucket, chunk) does last.  Every thread read the counters before the barriers of the caller: they end
@@ -1151,6 +1221,9 @@ TCNN_DEVICE void bucket_owner_epilogue(const GridMeta& meta, const BucketPlan& p
 			counters[plan.overflow_counter] = 0u;
 			counters[plan.overflow_counter + 1] = 0u;
 		}
+		if constexpr (HALF_IS_BF16) {  // (every owner read its level's sum before it signed off)
+			for (uint32_t t = threadIdx.x; t < 2u * LEVEL_SUM_PARTS * plan.n_levels; t += THREADS) counters[plan.level_sum_base + t] = 0u;
+		}
 	}
 }
 
@@ -1169,6 +1242,7 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 	const uint32_t slice_begin = bucket * entries_per_bucket;
 	const uint32_t slice_count = slice_begin < lv.hashmap_size ? min(entries_per_bucket, lv.hashmap_size - slice_begin) : 0u;
 	unsigned long long* tab = (unsigned long long*)lds_raw;  // [entries][F]
+	const OwnerScale sc = owner_scale(plan, counters, j);
 	const uint32_t cap = plan.capacity[j], n_chunks = plan.n_chunks[j];
 	const uint32_t queue = chunk * plan.n_buckets[j] + bucket;
 	const uint32_t count = min(counters[plan.counter_base[j] + queue], cap);  // in flight while the table is cleared
@@ -1179,13 +1253,13 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 	auto add_record = [&](uint32_t index, const uint32_t* payload) {
 		const uint32_t rel = index & (entries_per_bucket - 1u);
 		if constexpr (F == 1) {
-			lds_atomic_add_u64(&tab[rel], (unsigned long long)to_fixed(__builtin_bit_cast(float, payload[0])));
+			lds_atomic_add_u64(&tab[rel], (unsigned long long)to_fixed64(__builtin_bit_cast(float, payload[0]), sc));
 		} else {
 #pragma unroll
 			for (uint32_t p = 0; p < PW; ++p) {
 				const h2 v = bits_h2(payload[p]);
-				lds_atomic_add_u64(&tab[rel * F + 2 * p], (unsigned long long)to_fixed((float)v[0]));
-				lds_atomic_add_u64(&tab[rel * F + 2 * p + 1], (unsigned long long)to_fixed((float)v[1]));
+				lds_atomic_add_u64(&tab[rel * F + 2 * p], (unsigned long long)to_fixed64((float)v[0], sc));
+				lds_atomic_add_u64(&tab[rel * F + 2 * p + 1], (unsigned long long)to_fixed64((float)v[1], sc));
 			}
 		}
 	};
@@ -1221,7 +1295,7 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 	const uint32_t n_halves = slice_count * F;  // a multiple of 8: level sizes are multiples of 8
 	for (uint32_t e2 = threadIdx.x; e2 < n_halves / 2; e2 += SLICED_THREADS) {
 		const long long q0 = ((const long long*)lds_raw)[2 * e2], q1 = ((const long long*)lds_raw)[2 * e2 + 1];
-		h2 v = h2{(half_t)(float)((double)q0 * (1.0 / FIXED_SCALE)), (half_t)(float)((double)q1 * (1.0 / FIXED_SCALE))};
+		h2 v = h2{from_fixed64(q0, sc), from_fixed64(q1, sc)};
 		if (n_chunks == 1) {  // sole owner of the slice: plain stores
 			if (accumulate) v += *(const h2*)(grad + 2 * e2);
 			*(h2*)(grad + 2 * e2) = v;
@@ -1251,7 +1325,6 @@ TCNN_DEVICE void bucket_level(const GridMeta& meta, const Level<D>& lv, uint32_t
 #define TCNN_OWNER_THREADS 512
 #endif
 constexpr uint32_t OWNER_THREADS = TCNN_OWNER_THREADS;
-constexpr float OWNER_SAFE_ABS_SUM = 120.0f;  // < 128 = 2^31 / 2^24, with room for the fp32 rounding of the bound's own summation
 
 #if defined(TCNN_HOST_EMU)
 inline unsigned long owner_slice_stats[2] = {0, 0};  // emulator only: slices finished from the packed table / redone wide
@@ -1261,22 +1334,21 @@ inline unsigned long owner_slice_stats[2] = {0, 0};  // emulator only: slices fi
 __device__ unsigned long long g_owner_wide_slices = 0ull;
 #endif
 
-// round(v * 2^24) for |v| < 128; saturates beyond (such a slice fails the bound and is redone in 64 bits).  A 16-bit float times
-// 2^24 is an integer already when the type is IEEE half (11 significant bits, exponent >= -24): the conversion instruction alone
-// (v_cvt_i32_f32 saturates and maps NaN to 0 -- written as asm because the C++ conversion is undefined out of range).
-TCNN_DEVICE int to_fixed32(float v) {
+// round(v * 2^k) (OwnerScale; IEEE half: k = 24, |v| < 128); saturates beyond (such a slice fails the bound and is redone in 64 bits).  A
+// 16-bit float times 2^24 is an integer already when the type is IEEE half (11 significant bits, exponent >= -24): the conversion
+// instruction alone (v_cvt_i32_f32 saturates and maps NaN to 0 -- written as asm because the C++ conversion is undefined out of range).
+TCNN_DEVICE int to_fixed32(float v, const OwnerScale& sc) {
 #if defined(TCNN_HOST_EMU)
 	v = __builtin_fminf(__builtin_fmaxf(v, -127.0f), 127.0f);
 	return (int)__builtin_rintf(v * 16777216.0f);
 #else
-	float s = v * 16777216.0f;
-	if constexpr (HALF_IS_BF16) s = __builtin_rintf(s);  // bfloat16 products reach below 2^-24
+	float s = sc.up(v);
+	if constexpr (HALF_IS_BF16) s = __builtin_rintf(s);  // bfloat16 records reach below 2^-k
 	int r;
 	asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(s));
 	return r;
 #endif
 }
-
 template <uint32_t D, uint32_t F, uint32_t THREADS>
 TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, uint32_t level, uint32_t j, uint32_t bucket, uint32_t chunk,
                                      const BucketPlan& plan, uint32_t* __restrict__ counters, const uint32_t* queues,
@@ -1314,6 +1386,7 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 	const bool inline_overflow = n_over <= OVERFLOW_INLINE_MAX;
 	const uint32_t count = min(counters[plan.counter_base[j] + queue], cap);  // in flight while the table is cleared
 	constexpr uint32_t diag_owner = EXP_DIAG_OWNER;  // 0 in the product build (exp_diag.h)
+	const OwnerScale sc = owner_scale(plan, counters, j);
 	bool safe = !force_wide;
 	// the packed table is cleared first (LDS only), the first round requested behind it: nothing then stands between the loads and
 	// their use but the barrier (cleared after the loads, the compiler parks part of a record in other registers and waits for it)
@@ -1468,7 +1541,7 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 				const float f0 = (float)v[0], f1 = (float)v[1];
 				bound[2 * p] += __builtin_fabsf(f0);
 				bound[2 * p + 1] += __builtin_fabsf(f1);
-				const int v0 = to_fixed32(f0), v1 = to_fixed32(f1);
+				const int v0 = to_fixed32(f0, sc), v1 = to_fixed32(f1, sc);
 				const unsigned long long x = ((unsigned long long)(uint32_t)(v1 + (v0 >> 31)) << 32) | (unsigned long long)(uint32_t)v0;
 				if (!(diag_owner & 2u) || x == 0x123456789ull) lds_atomic_add_u64(&tab[rel * PW + p], x);
 			}
@@ -1487,7 +1560,7 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 			float total = 0.0f;
 #pragma unroll
 			for (uint32_t w = 0; w < N_WAVES; ++w) total += bound_parts[w][f];
-			safe = safe && total < OWNER_SAFE_ABS_SUM;
+			safe = safe && total < sc.safe_abs_sum();
 		}
 		if (safe && !(diag_owner & 4u)) {
 			auto unpack = [&](uint32_t e2) {
@@ -1495,7 +1568,7 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 				const int s0 = (int)(uint32_t)(unsigned long long)x;
 				const int s1 = (int)((x - (long long)s0) >> 32);
 				// int32 -> fp32 rounds to nearest even exactly as the fp64 -> fp32 conversion of the wide form does
-				return h2{(half_t)((float)s0 * (1.0f / 16777216.0f)), (half_t)((float)s1 * (1.0f / 16777216.0f))};
+				return h2{(half_t)sc.down((float)s0), (half_t)sc.down((float)s1)};
 			};
 			if (n_chunks == 1 && !accumulate && ((uintptr_t)grad & 15u) == 0u) {  // sole owner, overwrite: 16 bytes per lane (slice_count * PW is a multiple of 8)
 				for (uint32_t e8 = threadIdx.x; e8 < slice_count * PW / 4; e8 += THREADS) {
@@ -1527,14 +1600,14 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 #pragma unroll
 				for (uint32_t p = 0; p < PW; ++p) {
 					const h2 v = bits_h2(payload[p]);
-					lds_atomic_add_u64(&tab[rel * F + 2 * p], (unsigned long long)to_fixed((float)v[0]));
-					lds_atomic_add_u64(&tab[rel * F + 2 * p + 1], (unsigned long long)to_fixed((float)v[1]));
+					lds_atomic_add_u64(&tab[rel * F + 2 * p], (unsigned long long)to_fixed64((float)v[0], sc));
+					lds_atomic_add_u64(&tab[rel * F + 2 * p + 1], (unsigned long long)to_fixed64((float)v[1], sc));
 				}
 			});
 			__syncthreads();
 			for (uint32_t e2 = threadIdx.x; e2 < sub_count * PW; e2 += THREADS) {
 				const long long q0 = ((const long long*)lds_raw)[2 * e2], q1 = ((const long long*)lds_raw)[2 * e2 + 1];
-				store_pair(sub_begin * PW + e2, h2{(half_t)(float)((double)q0 * (1.0 / FIXED_SCALE)), (half_t)(float)((double)q1 * (1.0 / FIXED_SCALE))});
+				store_pair(sub_begin * PW + e2, h2{from_fixed64(q0, sc), from_fixed64(q1, sc)});
 			}
 		}
 	}
@@ -2023,7 +2096,8 @@ static BackwardPlan make_backward_plan(const GridMeta& meta, uint32_t n, bool pa
 	bk.zero_block_begin[bk.n_levels] = n_zero_blocks;
 	bk.overflow_counter = n_counters;
 	bk.overflow_capacity = (uint32_t)n_records;
-	bp.n_counters = bk.n_levels ? n_counters + 2 : 0;
+	bk.level_sum_base = (n_counters + 2u + 1u) & ~1u;
+	bp.n_counters = bk.n_levels ? bk.level_sum_base + 2u * LEVEL_SUM_PARTS * MAX_BUCKET_LEVELS : 0;
 	bp.overflow_offset = next_multiple<size_t>(n_queue_records * (2 * record_words - 1) * sizeof(uint32_t), 256);  // n_queue_records counts pairs
 	bp.workspace_bytes = bk.n_levels ? bp.overflow_offset + next_multiple<size_t>(n_records * (record_words + 1) * sizeof(uint32_t), 256) : 0;
 

@@ -25,6 +25,14 @@ if not os.path.exists(_LIB_PATH):
 
 _lib = C.CDLL(_LIB_PATH)
 
+# The compiled binding (ext/bindings.cpp -> _tcnn_ext.so: the reference's pybind11 module over the same C ABI, with the autograd function pair
+# in C++): used for the module path when it has been built (__graft_entry__.build() builds it); TCNN_TORCH_EXT=0 forces the ctypes classes
+# below, which remain the fallback and the surface of everything but the modules (trainer, generators, debugging aids).
+EXT = None
+if os.environ.get("TCNN_TORCH_EXT", "1") != "0" and os.path.exists(os.path.join(_HERE, "_tcnn_ext.so")):
+    from . import _tcnn_ext as EXT  # noqa: E402
+    EXT.bind_library(_LIB_PATH)
+
 OK = 0
 
 
@@ -555,13 +563,56 @@ def _dumps(cfg):
     return json.dumps(cfg).encode()
 
 
+class ExtModule:
+    """The compiled binding's Module (ext/bindings.cpp) behind the surface of the ctypes `Module` above: fwd / bwd / bwd_bwd_input / initial_params and
+    the accessors are the C++ methods; the parity helpers go through ctypes on the same native handle."""
+
+    def __init__(self, m):
+        self._m = m
+        self._h = C.c_void_p(m.handle())
+        for name in ("fwd", "bwd", "bwd_bwd_input", "initial_params", "n_input_dims", "n_params", "n_output_dims", "name"):
+            setattr(self, name, getattr(m, name))
+        self._param_precision = Precision(m.param_precision())
+        self._output_precision = Precision(m.output_precision())
+
+    def param_precision(self):
+        return self._param_precision
+
+    def output_precision(self):
+        return self._output_precision
+
+    def hyperparams(self):
+        return json.loads(self._m.hyperparams_json())
+
+    @property
+    def jit_fusion(self):
+        return self._m.jit_fusion
+
+    @jit_fusion.setter
+    def jit_fusion(self, val):
+        self._m.jit_fusion = bool(val)
+
+    grid_indices = Module.grid_indices
+    grid_level_n_params = Module.grid_level_n_params
+    grid_level_params_offset = Module.grid_level_params_offset
+
+
+def ext_apply(module, x, params, loss_scale):
+    """y = module(x, params) as ONE C++ autograd node (first and second order); `module` an ExtModule."""
+    return EXT.apply(module._m, x, params, float(loss_scale))
+
+
 def create_network_with_input_encoding(n_input_dims, n_output_dims, encoding, network):
+    if EXT is not None:
+        return ExtModule(EXT.create_network_with_input_encoding(n_input_dims, n_output_dims, _dumps(encoding).decode(), _dumps(network).decode()))
     h = C.c_void_p()
     _check(_lib.tcnn_create_network_with_input_encoding(n_input_dims, n_output_dims, _dumps(encoding), _dumps(network), C.byref(h)))
     return Module(h.value)
 
 
 def create_network(n_input_dims, n_output_dims, network):
+    if EXT is not None:
+        return ExtModule(EXT.create_network(n_input_dims, n_output_dims, _dumps(network).decode()))
     h = C.c_void_p()
     _check(_lib.tcnn_create_network(n_input_dims, n_output_dims, _dumps(network), C.byref(h)))
     return Module(h.value)
@@ -570,6 +621,8 @@ def create_network(n_input_dims, n_output_dims, network):
 def create_encoding(n_input_dims, encoding, precision=None):
     if precision is None:
         precision = preferred_precision()
+    if EXT is not None:
+        return ExtModule(EXT.create_encoding(n_input_dims, _dumps(encoding).decode(), int(precision)))
     h = C.c_void_p()
     _check(_lib.tcnn_create_encoding(n_input_dims, _dumps(encoding), int(precision), C.byref(h)))
     return Module(h.value)

@@ -139,7 +139,10 @@ class Module(torch.nn.Module):
             x = torch.nn.functional.pad(x, [0, 0, 0, padded - batch_size])
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.to(torch.float).contiguous()
-        y = _NativeFunction.apply(self.native_tcnn_module, x, self.params.to(self.dtype).contiguous(), self.loss_scale)
+        if _C.EXT is not None:  # the compiled binding: one C++ autograd node (ext/bindings.cpp NativeFunction)
+            y = _C.ext_apply(self.native_tcnn_module, x, self.params.to(self.dtype).contiguous(), self.loss_scale)
+        else:
+            y = _NativeFunction.apply(self.native_tcnn_module, x, self.params.to(self.dtype).contiguous(), self.loss_scale)
         # (one slicing node in the graph where the batch needed no padding: the common case at training batch sizes)
         return y[:, : self.n_output_dims] if padded == batch_size else y[:batch_size, : self.n_output_dims]
 

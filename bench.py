@@ -255,6 +255,49 @@ def launch_ranks(argv, n):
     return r.returncode or 1
 
 
+# ---- what a multi-GPU run of the headline workload SHOULD measure (nothing here has been timed on more than one GPU) ----
+# Single-GPU stage sums of this round (profiles/r06_bench_batches.txt, ms per step at the per-GPU batch; "compute" = the step without its
+# optimizer kernel, with the weight-gradient finalize as a kernel of its own -- the data-parallel step cannot sum the slabs inside Adam's
+# launch, the gradients are exchanged in between) and the link model: one xGMI link per peer, ~153 GB/s per link and direction (SURVEY
+# section 5), the 28.5 MB fp16 gradient buffer (and as many bytes of 16-bit parameters back).
+PREDICTION_INPUTS = {
+    "compute_ms_by_batch": {262144: 0.2223 + 0.005, 131072: 0.1300 + 0.005, 65536: 0.0917 + 0.005, 32768: 0.0720 + 0.005},
+    "adam_full_ms": 0.0705,         # 14.2 M parameters, 416 MB at 6 TB/s: shrinks by P when every rank steps its own shard
+    "exchange_bytes": 28.5e6,       # fp16 gradients out, 16-bit parameters back: the same count twice per step
+    "link_GBps": 153.0,             # per link and direction
+    "ring_GBps": (100.0, 153.0),    # what ring collectives usually reach per link .. the link rate
+    "signal_round_ms": 0.010,       # direct exchange: one signal + wait round (two small kernels, a cross-GPU store's latency); two per step
+}
+
+
+def predicted_step(world, per_gpu_batch, mode):
+    """Model of one data-parallel step of the headline workload, ms: compute at the per-GPU batch + the exchange + Adam on 1/P of the
+    parameters.  `direct` (peer-mapped buffers, every link at once): each rank READS its shard of P - 1 peers' gradients, one link each
+    (bytes / P per link), steps it, and PUSHES its shard of the parameters to P - 1 peers, one link each.  `sharded` / `allreduce` (RCCL
+    rings): reduce-scatter and all-gather each move (P - 1) / P of the buffer through ONE link per rank.  Returns None where the model has
+    no inputs (other workloads, batch sizes it was not measured at)."""
+    pi = PREDICTION_INPUTS
+    compute = pi["compute_ms_by_batch"].get(int(per_gpu_batch))
+    if compute is None or world < 1:
+        return None
+    if world == 1:
+        return {"ms_per_step": compute - 0.005 + pi["adam_full_ms"], "mode": "single GPU (measured, not a model)"}
+    shard_ms = pi["exchange_bytes"] / world / (pi["link_GBps"] * 1e9) * 1e3
+    if mode.startswith("direct"):
+        exchange = 2 * shard_ms + 2 * pi["signal_round_ms"]
+        adam = pi["adam_full_ms"] / world
+        lo = hi = compute + exchange + adam
+        parts = {"compute": compute, "reduce_over_links": shard_ms, "adam_on_shard": adam, "push_over_links": shard_ms, "signal_rounds": 2 * pi["signal_round_ms"]}
+    else:
+        ring = [2 * (world - 1) / world * pi["exchange_bytes"] / (g * 1e9) * 1e3 for g in pi["ring_GBps"]]
+        adam = pi["adam_full_ms"] / world if "sharded" in mode else pi["adam_full_ms"]
+        lo, hi = compute + min(ring) + adam, compute + max(ring) + adam
+        parts = {"compute": compute, "ring_reduce_scatter_plus_all_gather": [min(ring), max(ring)], "adam": adam}
+    return {"ms_per_step": [lo, hi] if hi != lo else lo, "parts_ms": parts, "mode": mode,
+            "note": "a MODEL (bench.py PREDICTION_INPUTS: single-GPU stage times of round 6 + the xGMI link rate), written down before any multi-GPU run: "
+                    "DESIGN.md section 6 holds the table this line is to be judged against"}
+
+
 def torch_binding_leg(w, tcnn, batches, fresh, rng, regenerate, steps, warmup, native_ms):
     """The same training step through the PyTorch surface (the largest user population): tcnn.NetworkWithInputEncoding ->
     RelativeL2 written in torch -> loss.backward() -> torch.optim.Adam, exactly the loop of samples/mlp_learning_an_image_pytorch.py; same
@@ -708,6 +751,12 @@ def main():
             line["inference"] = inference
         if torch_binding is not None:
             line["torch_binding"] = torch_binding
+        if world > 1 and args.workload == "hash":
+            pred = predicted_step(world, local_batch, dp_mode)
+            if pred is not None:
+                ms = pred["ms_per_step"]
+                line["predicted_ms_per_step"] = ms if not isinstance(ms, list) else ms
+                line["prediction"] = pred
         if autotune is not None:
             line["dp_autotune"] = autotune
         if replicas_same is not None:

@@ -156,6 +156,9 @@ def test_bench_launches_its_own_ranks_when_no_launcher_is_around_it():
         ph = d["comm"]["phases_ms_per_step_max_over_ranks"]
         assert set(ph) == phases and all(v > 0 for v in ph.values()), ph
         assert sum(ph.values()) <= 1.5 * d["comm"]["seconds_per_step"] * 1e3 + 0.05  # the phases are what the exchange consists of
+        # the model a node run is to be held against rides along (two ranks on ONE GPU are not what it describes)
+        pred = d["prediction"]
+        assert d["predicted_ms_per_step"] == pred["ms_per_step"] and pred["parts_ms"]["compute"] > 0 and "MODEL" in pred["note"]
 
 
 def test_bench_resident_batches_on_request():

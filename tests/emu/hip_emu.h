@@ -182,8 +182,9 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> fn
 		for (size_t i = old; i < g.n_threads; ++i) g.fibers[i].stack = (char*)malloc(STACK_BYTES);
 	}
 	g.waves.assign((g.n_threads + 63) / 64, Wave());
-	for (unsigned bx = 0; bx < grid.x; ++bx) {
-		g.bidx = dim3(bx, 0, 0);
+	for (unsigned linear = 0; linear < grid.x * grid.y; ++linear) {  // (two-dimensional grids: x fastest, as the hardware dispatches them)
+		const unsigned bx = linear % grid.x;
+		g.bidx = dim3(bx, linear / grid.x, 0);
 		g.block_gen = 0;
 		g.block_arrived = 0;
 		for (unsigned w = 0; w < g.waves.size(); ++w) {

@@ -69,6 +69,18 @@ TCNN_DEVICE Level<D> make_level(const GridMeta& meta, uint32_t level) {
 	return lv;
 }
 
+// make_level's `fast` on the host (the owner kernel's item descriptors carry it)
+static inline bool level_is_fast(const GridMeta& meta, uint32_t level) {
+	constexpr uint32_t MAX_BASES[11] = {0x0, 0xFFFFFFFF, 0xFFFF, 0x659, 0xFF, 0x54, 0x28, 0x17, 0xF, 0xB, 0x9};
+	const uint32_t hashmap_size = meta.offset[level + 1] - meta.offset[level], resolution = meta.resolution[level];
+	uint32_t stride = 0xFFFFFFFFu;
+	if (meta.n_dims < 11 && resolution <= MAX_BASES[meta.n_dims]) {
+		stride = 1;
+		for (uint32_t d = 0; d < meta.n_dims; ++d) stride *= resolution;
+	}
+	return meta.grid_type == (uint32_t)GridType::Hash && hashmap_size < stride && (hashmap_size & (hashmap_size - 1u)) == 0u;
+}
+
 TCNN_DEVICE float smoothstep(float v) { return v * v * (3.0f - 2.0f * v); }
 TCNN_DEVICE float smoothstep_derivative(float v) { return 6 * v * (1.0f - v); }
 
@@ -783,6 +795,8 @@ struct BucketPlan {
 	uint32_t wgs_per_level;      // persistent pass-A workgroups per level (each walks tiles wg, wg + wgs_per_level, ...)
 	uint32_t scatter_blocks;     // n_levels * wgs_per_level: pass-A blocks beyond these zero the gradients of chunked levels
 	uint32_t overflow_counter;   // index of the overflow counter (== total number of queues); the one after it counts finished pass-C blocks
+	TCNN_HOST_DEVICE uint32_t sum_slot(uint32_t j) const { return j; }
+	TCNN_HOST_DEVICE uint32_t table_offset(const GridMeta& meta, uint32_t level) const { return meta.offset[level]; }
 	uint32_t level_sum_base;     // (even) index of slot 0's 64-bit sums (LEVEL_SUM_PARTS per level) of |dL/dy| over the batch, 2^-32 units (OwnerScale; bfloat16 build only)
 	uint32_t overflow_capacity;  // records
 	uint32_t n_owner_blocks;     // workgroups of pass B that own a bucket (the last one to finish resets the bookkeeping counters)
@@ -863,7 +877,7 @@ TCNN_DEVICE OwnerScale owner_scale(const PLAN& plan, const uint32_t* counters, u
 	if constexpr (!HALF_IS_BF16) return OwnerScale{24};
 	unsigned long long sum = 0;
 #pragma unroll
-	for (uint32_t p = 0; p < LEVEL_SUM_PARTS; ++p) sum += *(const unsigned long long*)(counters + plan.level_sum_base + 2u * (j * LEVEL_SUM_PARTS + p));
+	for (uint32_t p = 0; p < LEVEL_SUM_PARTS; ++p) sum += *(const unsigned long long*)(counters + plan.level_sum_base + 2u * (plan.sum_slot(j) * LEVEL_SUM_PARTS + p));
 	if (sum == 0ull) return OwnerScale{40};
 	const float share = (float)sum * (8.0f / 4294967296.0f) / (float)(plan.n_buckets[j] * plan.n_chunks[j]);
 	int e;
@@ -1181,8 +1195,8 @@ __global__ void __launch_bounds__(BUCKET_THREADS) k_grid_bucket_scatter(const Gr
 // What every owner of a (bucket, chunk) does last.  Every thread read the counters before the barriers of the caller: they end
 // the call zeroed.  The last owner to get here (all owners have read the overflow count by then) resets the two bookkeeping
 // counters -- after draining a long overflow list with the reference's global atomics.
-template <uint32_t F, uint32_t THREADS>
-TCNN_DEVICE void bucket_owner_epilogue(const GridMeta& meta, const BucketPlan& plan, uint32_t j, uint32_t queue, bool inline_overflow, uint32_t n_over,
+template <uint32_t F, uint32_t THREADS, typename PLAN>
+TCNN_DEVICE void bucket_owner_epilogue(const GridMeta& meta, const PLAN& plan, uint32_t j, uint32_t queue, bool inline_overflow, uint32_t n_over,
                                        uint32_t* __restrict__ counters, const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient) {
 	constexpr uint32_t PW = BucketRecord<F>::PAYLOAD_WORDS, OW = BucketRecord<F>::WORDS + 1;
 	__shared__ uint32_t last_owner;
@@ -1349,9 +1363,9 @@ TCNN_DEVICE int to_fixed32(float v, const OwnerScale& sc) {
 	return r;
 #endif
 }
-template <uint32_t D, uint32_t F, uint32_t THREADS>
+template <uint32_t D, uint32_t F, uint32_t THREADS, typename PLAN>
 TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, uint32_t level, uint32_t j, uint32_t bucket, uint32_t chunk,
-                                     const BucketPlan& plan, uint32_t* __restrict__ counters, const uint32_t* queues,
+                                     const PLAN& plan, uint32_t* __restrict__ counters, const uint32_t* queues,
                                      const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient, bool accumulate, unsigned char* lds_raw,
                                      uint32_t lds_bytes, bool force_wide) {
 	static_assert(F % 2 == 0, "the packed owner pairs the features of a payload word");
@@ -1366,7 +1380,7 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 	// (not __restrict__, and neither is `queues`: loads the compiler may treat as invariant are moved wherever it likes -- it sank
 	// the first round below the barrier, next to its use)
 	const uint32_t* q = queues + (plan.queue_base[j] + (size_t)queue * cap) * PWP;  // `count` PAIRS of records
-	half_t* __restrict__ grad = grid_gradient + ((size_t)meta.offset[level] + slice_begin) * F;
+	half_t* __restrict__ grad = grid_gradient + ((size_t)plan.table_offset(meta, level) + slice_begin) * F;
 
 	// U pair records (12 bytes each for F == 2) in flight per lane.  The FIRST round is requested right here, before the queue's
 	// length is known (a queue holds `cap` records of memory whatever its count; what lies beyond the count is never used): it
@@ -1621,30 +1635,62 @@ TCNN_DEVICE void bucket_level_packed(const GridMeta& meta, const Level<D>& lv, u
 	bucket_owner_epilogue<F, THREADS>(meta, plan, j, queue, inline_overflow, n_over, counters, overflow, grid_gradient);
 }
 
-// The workgroups of pass B that own a (bucket, chunk), packed form; block -> item as in k_grid_backward_sliced, whose launch
-// (if the plan holds other kinds of items at all) skips the bucket items when this kernel runs them.
+// The workgroups of pass B that own a (bucket, chunk), packed form.  Launched as a 2-D grid -- blockIdx.y = the plan's item, blockIdx.x = the
+// workgroup within it -- with everything a workgroup needs to know about its item in ONE descriptor in the kernel arguments: a single
+// scalar load round before the queue's first records are requested.  (Round 5 looked the item up through the sliced kernel's plan: blocks per
+// item -> block_begin[item] -> kind[item] -> level[item] -> n_slices[item] -> the level's table size -> the slot's queue geometry, six
+// dependent loads, 1.6 us of a workgroup's 18.7 by the clock stamps of round 4 -- twice per launch, there are two generations of owners.)
+// k_grid_backward_sliced (the other kinds of items, if the plan holds any) skips the bucket items when this kernel runs them.
+struct OwnerItem {
+	uint32_t level, slot, n_slices, n_blocks;      // n_blocks = n_slices x n_chunks workgroups belong to the item
+	uint32_t hashmap_size, fast, offset, capacity;  // the level's table: entries, hashed power-of-two table?, first entry; pairs per queue
+	uint32_t n_chunks, n_buckets, counter_base, pad;
+	uint64_t queue_base;
+};
+struct OwnerItems {
+	OwnerItem item[MAX_BUCKET_LEVELS];
+};
+// what bucket_level_packed and the epilogue read of a BucketPlan, for ONE slot (j == 0 indexes it), out of the descriptor
+struct OwnerPlanView {
+	uint32_t shift, overflow_counter, overflow_capacity, n_owner_blocks, level_sum_base, n_levels, slot;
+	uint32_t capacity[1], n_chunks[1], n_buckets[1], counter_base[1];
+	uint64_t queue_base[1];
+	uint32_t offset;
+	TCNN_HOST_DEVICE uint32_t sum_slot(uint32_t) const { return slot; }
+	TCNN_HOST_DEVICE uint32_t table_offset(const GridMeta&, uint32_t) const { return offset; }
+};
 template <uint32_t D, uint32_t F>
-__global__ void __launch_bounds__(OWNER_THREADS) k_grid_bucket_owner(const GridMeta meta, const SlicePlan plan, const int accumulate, const BucketPlan bplan,
-                                                                      uint32_t* __restrict__ counters, const uint32_t* queues,
-                                                                      const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient,
+__global__ void __launch_bounds__(OWNER_THREADS) k_grid_bucket_owner(const GridMeta meta, const OwnerItems items, const int accumulate, const uint32_t shift,
+                                                                      const uint32_t overflow_counter, const uint32_t overflow_capacity, const uint32_t n_owner_blocks,
+                                                                      const uint32_t level_sum_base, const uint32_t n_bucket_levels, uint32_t* __restrict__ counters,
+                                                                      const uint32_t* queues, const uint32_t* __restrict__ overflow, half_t* __restrict__ grid_gradient,
                                                                       const uint32_t lds_bytes, const int force_wide) {
 	TCNN_DYN_LDS(lds_raw);
-	uint32_t item = 0, local_block;
-	if (plan.blocks_per_item) {
-		item = blockIdx.x / plan.blocks_per_item;
-		local_block = blockIdx.x % plan.blocks_per_item;
-		if (local_block >= plan.block_begin[item + 1] - plan.block_begin[item]) return;
-	} else {
-		while (item + 1 < plan.n_items && blockIdx.x >= plan.block_begin[item + 1]) ++item;
-		local_block = blockIdx.x - plan.block_begin[item];
-	}
-	if (plan.kind[item] != SLICE_BUCKET) return;
-	const uint32_t level = plan.level[item], n_slices = plan.n_slices[item];
-	const uint32_t slice = local_block % n_slices, chunk = local_block / n_slices;
-	const Level<D> lv = make_level<D>(meta, level);
+	const OwnerItem it = items.item[blockIdx.y];
+	const uint32_t local_block = blockIdx.x;
+	if (local_block >= it.n_blocks) return;
+	const uint32_t slice = local_block % it.n_slices, chunk = local_block / it.n_slices;
+	Level<D> lv = {};  // (what the owner reads of it: the table's size and kind -- pair_second_index, the slice's extent)
+	lv.hashmap_size = it.hashmap_size;
+	lv.mask = it.hashmap_size - 1u;
+	lv.fast = it.fast != 0u;
+	OwnerPlanView view;
+	view.shift = shift;
+	view.overflow_counter = overflow_counter;
+	view.overflow_capacity = overflow_capacity;
+	view.n_owner_blocks = n_owner_blocks;
+	view.level_sum_base = level_sum_base;
+	view.n_levels = n_bucket_levels;
+	view.slot = it.slot;
+	view.offset = it.offset;
+	view.capacity[0] = it.capacity;
+	view.n_chunks[0] = it.n_chunks;
+	view.n_buckets[0] = it.n_buckets;
+	view.counter_base[0] = it.counter_base;
+	view.queue_base[0] = it.queue_base;
 	if constexpr (F % 2 == 0) {  // (never launched for odd F)
-		bucket_level_packed<D, F, OWNER_THREADS>(meta, lv, level, plan.slot[item], slice, chunk, bplan, counters, queues, overflow, grid_gradient,
-		                                         accumulate != 0, lds_raw, lds_bytes, force_wide != 0);
+		bucket_level_packed<D, F, OWNER_THREADS>(meta, lv, it.level, 0u, slice, chunk, view, counters, queues, overflow, grid_gradient, accumulate != 0, lds_raw, lds_bytes,
+		                                         force_wide != 0);
 	}
 }
 
@@ -2226,11 +2272,33 @@ static void grid_backward_sliced_launches(hipStream_t stream, const GridMeta& me
 	if (bk_launch.packed_owner) {
 		const uint32_t owner_lds = std::max((1u << bk.shift) * F * 4u, 8u * F * 8u);
 		const int force_wide = owner_mode == 2 ? 1 : 0;
-#define BOWNER(D_, F_)                                                                                                                       \
-	if constexpr (F_ % 2 == 0) {                                                                                                             \
-		TCNN_SET_MAX_DYN_LDS((k_grid_bucket_owner<D_, F_>), owner_lds);                                                                      \
-		TCNN_LAUNCH((k_grid_bucket_owner<D_, F_>), dim3(blocks), dim3(OWNER_THREADS), owner_lds, stream, meta, plan, acc, bk_launch, counters, \
-		            (const uint32_t*)queues, (const uint32_t*)overflow, grid_gradient, owner_lds, force_wide);                               \
+		// one descriptor per bucket item, in plan order; the grid is (workgroups of the largest item) x (items)
+		OwnerItems owner_items = {};
+		uint32_t n_owner_items = 0, owner_width = 0;
+		for (uint32_t p = 0; p < plan.n_items; ++p) {
+			if (plan.kind[p] != SLICE_BUCKET) continue;
+			const uint32_t l = plan.level[p], j = plan.slot[p];
+			OwnerItem& it = owner_items.item[n_owner_items++];
+			it.level = l;
+			it.slot = j;
+			it.n_slices = plan.n_slices[p];
+			it.n_blocks = plan.block_begin[p + 1] - plan.block_begin[p];
+			it.hashmap_size = meta.offset[l + 1] - meta.offset[l];
+			it.fast = level_is_fast(meta, l) ? 1u : 0u;
+			it.offset = meta.offset[l];
+			it.capacity = bk.capacity[j];
+			it.n_chunks = bk.n_chunks[j];
+			it.n_buckets = bk.n_buckets[j];
+			it.counter_base = bk.counter_base[j];
+			it.queue_base = bk.queue_base[j];
+			owner_width = std::max(owner_width, it.n_blocks);
+		}
+#define BOWNER(D_, F_)                                                                                                                                  \
+	if constexpr (F_ % 2 == 0) {                                                                                                                        \
+		TCNN_SET_MAX_DYN_LDS((k_grid_bucket_owner<D_, F_>), owner_lds);                                                                                 \
+		TCNN_LAUNCH((k_grid_bucket_owner<D_, F_>), dim3(owner_width, n_owner_items), dim3(OWNER_THREADS), owner_lds, stream, meta, owner_items, acc, bk.shift, \
+		            bk.overflow_counter, bk.overflow_capacity, bk.n_owner_blocks, bk.level_sum_base, bk.n_levels, counters, (const uint32_t*)queues,    \
+		            (const uint32_t*)overflow, grid_gradient, owner_lds, force_wide);                                                                   \
 	}
 		TCNN_GRID_DISPATCH(BOWNER)
 #undef BOWNER

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6, GPU call I: owner kernel with one descriptor load round (2-D grid) vs the previous lookup chain
+# Round 6, GPU call I: grid kernels with one load round in their prologues (owner: item descriptor; gather: four segments at once) vs the previous commit
 OUT=$PWD/gpurun_out/r06i; mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_full.py -m gpu -x -q -k "bucket or grid or backward or headline or owner or stress or second_order" > $OUT/pytest_grid.log 2>&1

@@ -14,7 +14,7 @@
 #if defined(TCNN_EXPERIMENT)
 extern "C" __attribute__((weak, visibility("default"))) int tcnn_experiment_build_marker = 1;
 #else
-#if defined(TCNN_EXP_DIAG_SCATTER) || defined(TCNN_EXP_DIAG_OWNER) || defined(TCNN_EXP_FWD_SAMPLE_MAJOR)
+#if defined(TCNN_EXP_DIAG_SCATTER) || defined(TCNN_EXP_DIAG_OWNER)
 #error "TCNN_EXP_* switches exist in experiment builds only: add -DTCNN_EXPERIMENT (scripts/build_variant_one.sh does)"
 #endif
 #endif
@@ -31,13 +31,5 @@ constexpr uint32_t EXP_DIAG_SCATTER = 0u;
 constexpr uint32_t EXP_DIAG_OWNER = TCNN_EXP_DIAG_OWNER;
 #else
 constexpr uint32_t EXP_DIAG_OWNER = 0u;
-#endif
-// k_grid_forward_tiles: the (level, tile) items in SAMPLE-major order per XCD -- every XCD walks all levels of a tile before it moves to its
-// next tile, the order in which a fused gather -> network kernel would touch the tables (same output; what the level <-> XCD affinity of
-// the ForwardPlan is worth, profiles/r04_exp_notes.txt)
-#if defined(TCNN_EXP_FWD_SAMPLE_MAJOR)
-constexpr bool EXP_FWD_SAMPLE_MAJOR = true;
-#else
-constexpr bool EXP_FWD_SAMPLE_MAJOR = false;
 #endif
 }  // namespace tcnn_hip

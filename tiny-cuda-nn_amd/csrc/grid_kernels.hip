@@ -333,10 +333,28 @@ constexpr uint32_t FWD_MAX_SEGMENTS = 20;  // per XCD: ceil(MAX_N_LEVELS / 8) + 
 struct ForwardPlan {
 	uint32_t tiles;  // sample tiles per level
 	uint32_t n_segments[8];
+	// a run of one level's tiles with what the workgroup needs of that level (make_level's inputs): the workgroup's whole "what am I?" is ONE
+	// round of scalar loads -- the XCD's first four segments at once, searched in registers -- instead of a loop of dependent loads over the
+	// segments followed by a round for the level's table geometry (a workgroup lives a few microseconds: every round trip ahead of its first
+	// gather is occupancy the L2's line rate does not get)
 	struct Segment {
-		uint32_t level, tile_begin, tile_end;
+		uint32_t level, tile_begin, tile_end, hashmap_size, resolution, scale_bits, offset, fast;
 	} segments[8][FWD_MAX_SEGMENTS];
 };
+constexpr uint32_t FWD_SEGMENTS_AT_ONCE = 4;
+template <uint32_t D>
+TCNN_DEVICE Level<D> level_of_segment(const GridMeta& meta, const ForwardPlan::Segment& seg) {
+	Level<D> lv;
+	lv.hashmap_size = seg.hashmap_size;
+	lv.resolution = seg.resolution;
+	lv.mask = seg.hashmap_size - 1u;
+	lv.scale = __builtin_bit_cast(float, seg.scale_bits);
+	lv.is_hash = meta.grid_type == (uint32_t)GridType::Hash;
+	lv.smooth = meta.interp == (uint32_t)InterpolationType::Smoothstep;
+	lv.nearest = meta.interp == (uint32_t)InterpolationType::Nearest;
+	lv.fast = seg.fast != 0u;
+	return lv;
+}
 
 template <uint32_t D, uint32_t F, uint32_t SPT, bool FAST>
 TCNN_DEVICE void grid_forward_tile(const Level<D>& lv, const GridIO& io, const half_t* __restrict__ grid, uint32_t level, uint32_t first,
@@ -376,31 +394,64 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward_tiles(const GridM
 	constexpr uint32_t TILE = GRID_THREADS * SPT;
 	// block -> (segment of its XCD's run, tile): level-major, so an XCD walks one table at a time
 	const uint32_t xcd = blockIdx.x & 7u;
-	uint32_t slot = blockIdx.x >> 3, level = 0, tile = 0;
+	uint32_t slot = blockIdx.x >> 3, tile = 0;
 	bool found = false;
-	for (uint32_t k = 0; k < plan.n_segments[xcd]; ++k) {
-		const ForwardPlan::Segment seg = plan.segments[xcd][k];
-		const uint32_t n = seg.tile_end - seg.tile_begin;
-		if (slot < n) {
-			level = seg.level;
-			tile = seg.tile_begin + slot;
-			found = true;
-			break;
+	ForwardPlan::Segment mine = {};
+	{
+		ForwardPlan::Segment head[FWD_SEGMENTS_AT_ONCE];  // (rows are zero-padded: an unused segment holds no tiles and never matches)
+#pragma unroll
+		for (uint32_t k = 0; k < FWD_SEGMENTS_AT_ONCE; ++k) head[k] = plan.segments[xcd][k];
+#if !defined(TCNN_HOST_EMU)
+		{  // (all of it now, in ONE round -- the four segments and what the position loads need of the other kernel arguments)
+			uint64_t positions = (uint64_t)(uintptr_t)io.positions;
+			uint32_t a = io.pos_stride_i, b = io.pos_stride_d, c = io.n, d = meta.grid_type, e = meta.interp;
+			asm volatile("" : "+s"(positions), "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e), "+s"(head[0].level), "+s"(head[0].tile_begin), "+s"(head[0].tile_end),
+			             "+s"(head[0].hashmap_size), "+s"(head[0].resolution), "+s"(head[0].scale_bits), "+s"(head[0].offset), "+s"(head[0].fast));
+#pragma unroll
+			for (uint32_t k = 1; k < FWD_SEGMENTS_AT_ONCE; ++k) {
+				asm volatile("" : "+s"(head[k].level), "+s"(head[k].tile_begin), "+s"(head[k].tile_end), "+s"(head[k].hashmap_size), "+s"(head[k].resolution),
+				             "+s"(head[k].scale_bits), "+s"(head[k].offset), "+s"(head[k].fast));
+			}
 		}
-		slot -= n;
+#endif
+		// branch-free (selects): written with branches the compiler sinks each segment's loads into "the segments before it did not match"
+		// and the one round of loads becomes up to four
+#pragma unroll
+		for (uint32_t k = 0; k < FWD_SEGMENTS_AT_ONCE; ++k) {
+			const uint32_t n = head[k].tile_end - head[k].tile_begin;
+			const bool here = !found && slot < n;
+			mine.level = here ? head[k].level : mine.level;
+			mine.hashmap_size = here ? head[k].hashmap_size : mine.hashmap_size;
+			mine.resolution = here ? head[k].resolution : mine.resolution;
+			mine.scale_bits = here ? head[k].scale_bits : mine.scale_bits;
+			mine.offset = here ? head[k].offset : mine.offset;
+			mine.fast = here ? head[k].fast : mine.fast;
+			tile = here ? head[k].tile_begin + slot : tile;
+			slot -= (found || here) ? 0u : n;
+			found = found || here;
+		}
 	}
-	if constexpr (EXP_FWD_SAMPLE_MAJOR) {  // experiment builds only (exp_diag.h); needs tiles % 8 == 0 to cover everything
-		level = (blockIdx.x >> 3) % meta.n_levels;
-		tile = (blockIdx.x / (8u * meta.n_levels)) * 8u + (blockIdx.x & 7u);
-		found = tile < plan.tiles;
+	if (!found) {  // (more than 32 levels: the rest of the run, one segment at a time)
+		for (uint32_t k = FWD_SEGMENTS_AT_ONCE; k < plan.n_segments[xcd]; ++k) {
+			const ForwardPlan::Segment seg = plan.segments[xcd][k];
+			const uint32_t n = seg.tile_end - seg.tile_begin;
+			if (slot < n) {
+				mine = seg;
+				tile = seg.tile_begin + slot;
+				found = true;
+				break;
+			}
+			slot -= n;
+		}
 	}
+	const uint32_t level = mine.level;
 	if (!found) return;
 	const uint32_t first = tile * TILE;
 	float x[SPT][D];
 #pragma unroll
 	for (uint32_t s = 0; s < SPT; ++s) load_position<D, true>(io, min(first + s * GRID_THREADS + threadIdx.x, io.n - 1u), x[s]);
-	const Level<D> lv = make_level<D>(meta, level);
-	const half_t* __restrict__ grid = params + (size_t)meta.offset[level] * F;
+	const Level<D> lv = level_of_segment<D>(meta, mine);
+	const half_t* __restrict__ grid = params + (size_t)mine.offset * F;
 	const uint32_t n_features = meta.n_levels * F;
 	const float max_level = (meta.max_level * (float)n_features) / (float)F;  // grid.h:72
 	const bool level_off = (float)level >= max_level + 1e-3f;               // grid.h:75
@@ -1969,7 +2020,8 @@ static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t 
 						ok = false;
 						break;
 					}
-					plan.segments[xcd][ns++] = {l, t, t + take};
+					plan.segments[xcd][ns++] = {l, t, t + take, meta.offset[l + 1] - meta.offset[l], meta.resolution[l], __builtin_bit_cast(uint32_t, meta.scale[l]),
+					                            meta.offset[l], level_is_fast(meta, l) ? 1u : 0u};
 					t += take;
 					done += (uint64_t)take * cost[l];
 				}

@@ -289,8 +289,9 @@ def test_reading_the_master_weights_does_not_change_the_trainer_s_mode():
     n, nm = tm.n_params, tm.n_mlp_params
     tm.set_global_batch_size(1 << 20)
     rng = np.random.default_rng(4)
-    view = tm.params_full_precision  # read-only accessor: same memory, no mode change
-    assert view.data_ptr() == tm.params_full_precision.data_ptr()
+    view = tm.params_full_precision_view  # read-only accessor: same memory, no mode change
+    assert view.data_ptr() == tm.params_full_precision_view.data_ptr()
+    assert tm.params_full_precision.data_ptr() != view.data_ptr()  # (the plain accessor hands out a copy: ADVICE round 5)
     before = view.cpu().numpy().copy()
     g = (rng.standard_normal(n) * 0.1).astype(np.float16)
     g[nm:][rng.random(n - nm) < 0.5] = 0

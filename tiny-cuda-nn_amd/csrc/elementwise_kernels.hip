@@ -49,12 +49,43 @@ __global__ void k_generate_random_uniform(size_t n_elements, Pcg32 rng, const Pc
 	}
 }
 
+// The same element <-> draw mapping (element i + n_threads * j is draw 4 i + j of the stream, n_threads the reference's launch width), four i per
+// thread: one skip-ahead per 16 consecutive draws instead of per 4, and the four elements of one j are adjacent, so they leave as one 16-byte store.
+__global__ void k_generate_random_uniform_x4(size_t n_elements, size_t n_threads, Pcg32 rng, const Pcg32Skip skip, float* __restrict__ out, float lower, float range) {
+	const size_t i = (threadIdx.x + (size_t)blockIdx.x * blockDim.x) * 4;
+	if (i >= n_threads) return;
+	{
+		uint64_t delta = (uint64_t)i * 4u;
+		for (uint32_t k = 0; delta != 0; ++k, delta >>= 1) {
+			if (delta & 1u) rng.state = skip.mult[k] * rng.state + skip.plus[k];
+		}
+	}
+	float draw[16];
+#pragma unroll
+	for (int k = 0; k < 16; ++k) draw[k] = __builtin_fmaf(rng.next_float(), range, lower);
+#pragma unroll
+	for (size_t j = 0; j < 4; ++j) {
+		const size_t idx = i + n_threads * j;
+		if (idx + 3 < n_elements) {
+			*(f4*)(out + idx) = f4{draw[j], draw[4 + j], draw[8 + j], draw[12 + j]};
+		} else {
+			for (size_t a = 0; a < 4 && idx + a < n_elements; ++a) out[idx + a] = draw[4 * a + j];
+		}
+	}
+}
+
 void generate_random_uniform(hipStream_t stream, Pcg32& rng, size_t n, float* out, float lower, float upper) {
 	if (n > 0) {
 		const size_t n_threads = div_round_up(n, (size_t)4);
 		const uint32_t blocks = (uint32_t)div_round_up(n_threads, (size_t)128);  // N_THREADS_LINEAR = 128 (common.h:247)
 		if (n >= (1ull << 40)) throw std::runtime_error("generate_random_uniform: more than 2^40 elements");
-		TCNN_LAUNCH(k_generate_random_uniform, dim3(blocks), dim3(128), 0, stream, n, rng, make_pcg32_skip(rng), out, lower, upper - lower);
+		if (((uintptr_t)out & 15u) == 0) {
+			const size_t width = (size_t)blocks * 128;  // the launch width the mapping is defined on
+			TCNN_LAUNCH(k_generate_random_uniform_x4, dim3((uint32_t)div_round_up(width / 4, (size_t)64)), dim3(64), 0, stream, n, width, rng, make_pcg32_skip(rng), out, lower,
+			            upper - lower);
+		} else {
+			TCNN_LAUNCH(k_generate_random_uniform, dim3(blocks), dim3(128), 0, stream, n, rng, make_pcg32_skip(rng), out, lower, upper - lower);
+		}
 	}
 	rng.advance((int64_t)n);
 }

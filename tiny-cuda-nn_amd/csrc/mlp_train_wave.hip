@@ -109,12 +109,19 @@ TCNN_DEVICE half_t loss_gradient_simple(bool relative, bool has_pdf, float predi
 }
 
 #ifndef TCNN_MLP_WAVE_BLOCKS
-#define TCNN_MLP_WAVE_BLOCKS 512  // two workgroups of four waves per CU (256 registers per wave): the second wave of a SIMD fills the first one's stalls
+#define TCNN_MLP_WAVE_BLOCKS 512  // in units of four waves -- two per SIMD (256 registers per wave): the second wave of a SIMD fills the first one's stalls
 #endif
 #ifndef TCNN_MLP_WAVE_MIN_BLOCKS
 #define TCNN_MLP_WAVE_MIN_BLOCKS 2
 #endif
 constexpr uint32_t MLP_WAVE_STRIP = 32, MLP_WAVE_THREADS = 256;
+// Waves per training workgroup.  The instances that run two waves per SIMD put all EIGHT waves of a CU into one workgroup (round 6): the weights
+// are staged once per CU instead of twice, and the launch leaves 256 weight-gradient slabs behind instead of 512 -- half the write burst at the
+// kernel's end, half of what the optimizer's launch has to sum (AdamFinalize).  The instance that has a SIMD's registers to itself stays at four.
+#ifndef TCNN_MLP_WAVE_WAVES
+#define TCNN_MLP_WAVE_WAVES 8  // (4: the geometry of rounds 3-5, two workgroups per CU; kept as a build-time knob for A/B runs)
+#endif
+constexpr uint32_t mlp_train_wave_waves(uint32_t min_waves) { return min_waves >= 2u ? (uint32_t)TCNN_MLP_WAVE_WAVES : 4u; }
 
 // EXTERNAL: no loss -- dL/doutput comes from la.external_dL_doutput (the backward pass of a module recomputing its forward pass).  A
 // compile-time switch: the loss instance is at the register limit (256 of 256 at two waves per SIMD), a run-time branch around the loss spills.
@@ -127,14 +134,14 @@ constexpr uint32_t MLP_WAVE_STRIP = 32, MLP_WAVE_THREADS = 256;
 // loss and a pdf then.  A compile-time switch: the other three elements' loads, branches and registers (six target registers live through the
 // whole forward pass at the 256-register limit) leave the instruction stream of the usual case; wider outputs run the FEW_DIMS = false instance.
 template <uint32_t WIDTH, uint32_t IN, uint32_t HM, bool GENERAL, bool EXTERNAL, uint32_t MIN_WAVES = TCNN_MLP_WAVE_MIN_BLOCKS, bool F32IN = false, bool FEW_DIMS = true>
-__global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
+__global__ void __launch_bounds__(64 * mlp_train_wave_waves(MIN_WAVES), MIN_WAVES) k_mlp_train_wave(const MlpMeta m, const uint32_t n, const half_t* __restrict__ params,
                                                                         const half_t* __restrict__ params_t, const half_t* __restrict__ input,
                                                                         const MlpLossArgs la, half_t* __restrict__ output, half_t* __restrict__ dL_doutput,
                                                                         half_t* __restrict__ dL_dinput, float* __restrict__ partials,
                                                                         float* __restrict__ block_sums, const MlpF32Input fin) {
-	constexpr uint32_t NB = WIDTH / 16, NP = WIDTH / 32, FB = IN / 16, FP = IN / 32, NWAVES = MLP_WAVE_THREADS / 64, HMX = HM > 0 ? HM : 1;
+	constexpr uint32_t NB = WIDTH / 16, NP = WIDTH / 32, FB = IN / 16, FP = IN / 32, NWAVES = mlp_train_wave_waves(MIN_WAVES), THREADS = 64 * NWAVES, HMX = HM > 0 ? HM : 1;
 	constexpr uint32_t N_PARAMS = WIDTH * IN + HM * WIDTH * WIDTH + 16 * WIDTH;
-	static_assert(NWAVES == 4 && WIDTH % 32 == 0 && IN % 32 == 0, "the final reduction pairs waves (0,2) and (1,3); operands are built from pairs of 16-row tiles");
+	static_assert((NWAVES == 4 || NWAVES == 8) && WIDTH % 32 == 0 && IN % 32 == 0, "the final reduction halves the waves down to two; operands are built from pairs of 16-row tiles");
 	constexpr uint32_t N_TILES = NB * FB + HM * NB * NB + NB;  // accumulator tiles per wave
 	// Transposes through LDS: the weight-gradient MFMAs need their factors with the SAMPLES in the k slots.  A 16 x 16 tile as the
 	// accumulators hold it (lane (g, lr): neurons 4g .. 4g+3 of sample lr) is one 8-byte LDS store per lane into a sample-major image, and
@@ -144,9 +151,9 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 	// The tiles of a wave are its own: no barrier, the LDS executes a wave's requests in order.  Layer j's activations are stored as soon as
 	// the forward pass has them; dL/d(pre-activation) of layer j reuses the region of layer j's activations once those have been read.
 	constexpr uint32_t TR_TILES = (HM + 1) * 2 * NB + 2;  // per wave: every layer's activations + the two dL/doutput tiles, 512 bytes each
-	constexpr uint32_t EXCH_F4 = N_TILES * 64, TR_F4 = NWAVES * TR_TILES * 32;
+	constexpr uint32_t EXCH_F4 = (NWAVES / 2 - 1) * N_TILES * 64, TR_F4 = NWAVES * TR_TILES * 32;  // (the last exchange buffer is the weights' region)
 	__shared__ f4 exchange[EXCH_F4 > TR_F4 ? EXCH_F4 : TR_F4];
-	__shared__ float red[MLP_WAVE_THREADS];
+	__shared__ float red[THREADS];
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, lr = lane & 15u, g = lane >> 4;
 	const uint32_t act = m.activation, out_act = m.output_activation;
 	const bool want_grads = partials != nullptr, want_dx = dL_dinput != nullptr;
@@ -573,19 +580,19 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 		if constexpr (!GENERAL) loss_sum = loss_sum * 0.5f / n_total;  // see loss_gradient_simple
 		red[tid] = loss_sum;
 		__syncthreads();
-		for (uint32_t k = MLP_WAVE_THREADS / 2; k > 0; k >>= 1) {
+		for (uint32_t k = THREADS / 2; k > 0; k >>= 1) {
 			if (tid < k) red[tid] += red[tid + k];
 			__syncthreads();
 		}
 		if (tid == 0) block_sums[blockIdx.x] = red[0];
 	}
 
-	// ---- fp32 partial weight gradients: (wave 0 + wave 2) + (wave 1 + wave 3), exchanged through LDS in register order
-	// (tile t of lane l at [t][l]: conflict-free 16-byte accesses; all waves share the lane <-> element map).  The second round
-	// splits the tiles between waves 0 and 1, and each writes its half of the workgroup's slab IN REGISTER ORDER (slab position
-	// 256 t + 4 lane + r: one coalesced 16-byte store per tile; k_mlp_finalize_gradients knows the position -> parameter map,
-	// mlp_wave_slab_param).  The parameter-layout slab of rounds 1-2 was 112 scattered 4-byte store instructions issued by
-	// wave 0 alone: 3.7 us of the kernel's fixed cost (profiles/r03_exp_notes.txt).
+	// ---- fp32 partial weight gradients: the waves are halved down to two -- w += w + NWAVES/2, ..., w += w + 2, i.e. ((0+4)+(2+6)) + ((1+5)+(3+7))
+	// for eight waves, (0+2) + (1+3) for four -- exchanged through LDS in register order (tile t of lane l at [t][l]: conflict-free 16-byte
+	// accesses; all waves share the lane <-> element map).  The last round splits the tiles between waves 0 and 1, and each writes its half of
+	// the workgroup's slab IN REGISTER ORDER (slab position 256 t + 4 lane + r: one coalesced 16-byte store per tile; the summation knows the
+	// position -> parameter map, mlp_wave_slab_param).  The parameter-layout slab of rounds 1-2 was 112 scattered 4-byte store instructions
+	// issued by wave 0 alone: 3.7 us of the kernel's fixed cost (profiles/r03_exp_notes.txt).
 	if (want_grads) {
 		auto for_each_tile = [&](auto&& fn) {
 			uint32_t t = 0;
@@ -601,17 +608,22 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 			}
 		};
 		constexpr uint32_t HALF_TILES = N_TILES / 2;  // wave 0 finishes tiles [0, HALF_TILES), wave 1 the rest
-		f4* ex0 = (f4*)exchange;
-		f4* ex1 = (f4*)wfrag;  // the weights are not needed any more
-		__syncthreads();
-		if (w >= 2) {
-			f4* ex = w == 2 ? ex0 : ex1;
-			for_each_tile([&](uint32_t t, f4& a) { ex[t * 64 + lane] = a; });
-		}
-		__syncthreads();
-		if (w < 2) {
-			const f4* ex = w == 0 ? ex0 : ex1;
-			for_each_tile([&](uint32_t t, f4& a) { a += ex[t * 64 + lane]; });
+		constexpr uint32_t N_BUF = NWAVES / 2;
+		auto buffer = [&](uint32_t k) -> f4* { return k + 1 < N_BUF ? (f4*)exchange + k * (N_TILES * 64u) : (f4*)wfrag; };  // (the weights are not needed any more)
+		f4* ex0 = buffer(0);
+		f4* ex1 = buffer(N_BUF - 1);
+#pragma unroll
+		for (uint32_t half = NWAVES / 2; half >= 2; half >>= 1) {
+			__syncthreads();
+			if (w >= half && w < 2 * half) {
+				f4* ex = buffer(w - half);
+				for_each_tile([&](uint32_t t, f4& a) { ex[t * 64 + lane] = a; });
+			}
+			__syncthreads();
+			if (w < half) {
+				const f4* ex = buffer(w);
+				for_each_tile([&](uint32_t t, f4& a) { a += ex[t * 64 + lane]; });
+			}
 		}
 		__syncthreads();
 		if (w == 1) for_each_tile([&](uint32_t t, f4& a) { if (t < HALF_TILES) ex0[t * 64 + lane] = a; });
@@ -624,7 +636,7 @@ __global__ void __launch_bounds__(MLP_WAVE_THREADS, MIN_WAVES) k_mlp_train_wave(
 			});
 		} else if (w == 1) {
 			for_each_tile([&](uint32_t t, f4& a) {
-				if (t >= HALF_TILES) *(f4*)(P + (t * 256u + lane * 4u)) = ex1[t * 64 + lane] + a;  // (wave 0 + wave 2) + (wave 1 + wave 3) here too
+				if (t >= HALF_TILES) *(f4*)(P + (t * 256u + lane * 4u)) = ex1[t * 64 + lane] + a;  // (even waves) + (odd waves) here too
 			});
 		}
 	}
@@ -772,8 +784,9 @@ bool mlp_train_wave_supported(const MlpMeta& m, uint32_t n, LossType loss) {
 #endif
 uint32_t mlp_train_wave_n_partials(const MlpMeta& m, uint32_t n) {
 	const bool one_wave_per_simd = m.in_width == 64 && m.width == 64 && m.n_hidden_matmuls == 1;
-	const uint32_t wanted = div_round_up(n / MLP_WAVE_STRIP, MLP_WAVE_THREADS / 64u);
-	const uint32_t most = one_wave_per_simd ? TCNN_MLP_WAVE_WIDE_BLOCKS : TCNN_MLP_WAVE_BLOCKS;
+	const uint32_t n_waves = mlp_train_wave_waves(one_wave_per_simd ? 1u : TCNN_MLP_WAVE_MIN_BLOCKS);
+	const uint32_t wanted = div_round_up(n / MLP_WAVE_STRIP, n_waves);
+	const uint32_t most = one_wave_per_simd ? TCNN_MLP_WAVE_WIDE_BLOCKS : div_round_up((uint32_t)TCNN_MLP_WAVE_BLOCKS * 4u, n_waves);
 	return wanted < most ? wanted : most;
 }
 
@@ -785,7 +798,7 @@ static void launch_train_wave(hipStream_t stream, const MlpMeta& m, uint32_t n, 
 	const MlpF32Input fin = f32_input ? *f32_input : MlpF32Input();
 	const bool few = la.external_dL_doutput != nullptr || la.dims <= 4u;  // (no loss, no targets with an external dL/doutput)
 #define TCNN_WAVE_LAUNCH(EXTERNAL_, F32IN_, FEW_)                                                                                                              \
-	TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, EXTERNAL_, MIN_WAVES, F32IN_, FEW_>), dim3(blocks), dim3(MLP_WAVE_THREADS), 0, stream, m, n, params, params_t, \
+	TCNN_LAUNCH((k_mlp_train_wave<WIDTH, IN, HM, false, EXTERNAL_, MIN_WAVES, F32IN_, FEW_>), dim3(blocks), dim3(64 * mlp_train_wave_waves(MIN_WAVES)), 0, stream, m, n, params, params_t, \
 	            input, la, output, dL_doutput, dL_dinput, partials, block_sums, fin)
 	if (f32_input) {
 		if constexpr (IN == 64) {  // the instances mlp_train_f32_input_supported names

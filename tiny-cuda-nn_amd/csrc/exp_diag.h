@@ -14,7 +14,7 @@
 #if defined(TCNN_EXPERIMENT)
 extern "C" __attribute__((weak, visibility("default"))) int tcnn_experiment_build_marker = 1;
 #else
-#if defined(TCNN_EXP_DIAG_SCATTER) || defined(TCNN_EXP_DIAG_OWNER)
+#if defined(TCNN_EXP_DIAG_SCATTER) || defined(TCNN_EXP_DIAG_OWNER) || defined(TCNN_EXP_FWD_REGION_LOG2)
 #error "TCNN_EXP_* switches exist in experiment builds only: add -DTCNN_EXPERIMENT (scripts/build_variant_one.sh does)"
 #endif
 #endif
@@ -31,5 +31,20 @@ constexpr uint32_t EXP_DIAG_SCATTER = 0u;
 constexpr uint32_t EXP_DIAG_OWNER = TCNN_EXP_DIAG_OWNER;
 #else
 constexpr uint32_t EXP_DIAG_OWNER = 0u;
+#endif
+// k_grid_forward_tiles, region passes: a hashed level whose table has more than 2^TCNN_EXP_FWD_REGION_LOG2 entries is
+// walked once per slice of that many entries; every pass fetches only the corners that fall inside its slice (the other lanes' loads are
+// masked off), so that an XCD works on a slice its L2 can hold.  A TIMING build: every pass overwrites the level's features with its own
+// partial sums (an exact version would have to stage the raw corners -- the fp16 fma chain of grid.h:144-163 is order-dependent).
+// TCNN_EXP_FWD_REGION_COST: what the work plan charges a (slice, tile) item, in the units of make_forward_plan (a 2 MiB hashed level: 8).
+#if defined(TCNN_EXP_FWD_REGION_LOG2)
+constexpr uint32_t EXP_FWD_REGION_LOG2 = TCNN_EXP_FWD_REGION_LOG2;
+#else
+constexpr uint32_t EXP_FWD_REGION_LOG2 = 0u;
+#endif
+#if defined(TCNN_EXP_FWD_REGION_COST)
+constexpr double EXP_FWD_REGION_COST = TCNN_EXP_FWD_REGION_COST;
+#else
+constexpr double EXP_FWD_REGION_COST = 4.0;
 #endif
 }  // namespace tcnn_hip

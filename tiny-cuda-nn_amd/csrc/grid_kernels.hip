@@ -352,13 +352,13 @@ TCNN_DEVICE Level<D> level_of_segment(const GridMeta& meta, const ForwardPlan::S
 	lv.is_hash = meta.grid_type == (uint32_t)GridType::Hash;
 	lv.smooth = meta.interp == (uint32_t)InterpolationType::Smoothstep;
 	lv.nearest = meta.interp == (uint32_t)InterpolationType::Nearest;
-	lv.fast = seg.fast != 0u;
+	lv.fast = (seg.fast & 1u) != 0u;  // (an experiment build keeps a region of the table in the upper bits: exp_diag.h, EXP_FWD_REGION_LOG2)
 	return lv;
 }
 
 template <uint32_t D, uint32_t F, uint32_t SPT, bool FAST>
 TCNN_DEVICE void grid_forward_tile(const Level<D>& lv, const GridIO& io, const half_t* __restrict__ grid, uint32_t level, uint32_t first,
-                                   const float (&x)[SPT][D], half_t* __restrict__ out) {
+                                   const float (&x)[SPT][D], half_t* __restrict__ out, uint32_t region_begin = 0u, uint32_t region_end = 0xffffffffu) {
 	constexpr uint32_t NP = (F + 1) / 2, NC = 1u << D;
 	Cell<D> c[SPT];
 	h2 val[SPT][NC][NP];
@@ -366,7 +366,16 @@ TCNN_DEVICE void grid_forward_tile(const Level<D>& lv, const GridIO& io, const h
 	for (uint32_t s = 0; s < SPT; ++s) {
 		c[s] = make_cell<D, FAST>(lv, x[s]);
 #pragma unroll
-		for (uint32_t idx = 0; idx < NC; ++idx) load_features<F>(grid + (size_t)corner_index<D, FAST>(lv, c[s], idx) * F, val[s][idx]);
+		for (uint32_t idx = 0; idx < NC; ++idx) {
+			const uint32_t index = corner_index<D, FAST>(lv, c[s], idx);
+			if constexpr (EXP_FWD_REGION_LOG2 != 0u) {  // region-pass timing build: only the corners inside this pass's slice of the table are fetched
+#pragma unroll
+				for (uint32_t p = 0; p < NP; ++p) val[s][idx][p] = h2{(half_t)0.0f, (half_t)0.0f};
+				if (index >= region_begin && index < region_end) load_features<F>(grid + (size_t)index * F, val[s][idx]);
+			} else {
+				load_features<F>(grid + (size_t)index * F, val[s][idx]);
+			}
+		}
 	}
 #pragma unroll
 	for (uint32_t s = 0; s < SPT; ++s) {
@@ -461,7 +470,13 @@ __global__ void __launch_bounds__(GRID_THREADS) k_grid_forward_tiles(const GridM
 			if (i < io.n) grid_forward_sample<D, F, false, false>(lv, io, grid, level, i, level_off, out, nullptr);
 		}
 	} else if (lv.fast) {  // wave-uniform: one lean code path per level kind
-		grid_forward_tile<D, F, SPT, true>(lv, io, grid, level, first, x, out);
+		if constexpr (EXP_FWD_REGION_LOG2 != 0u) {
+			const uint32_t n_regions = mine.fast >> 16, region = (mine.fast >> 8) & 0xffu;
+			if (n_regions > 1u) grid_forward_tile<D, F, SPT, true>(lv, io, grid, level, first, x, out, region << EXP_FWD_REGION_LOG2, (region + 1u) << EXP_FWD_REGION_LOG2);
+			else grid_forward_tile<D, F, SPT, true>(lv, io, grid, level, first, x, out);
+		} else {
+			grid_forward_tile<D, F, SPT, true>(lv, io, grid, level, first, x, out);
+		}
 	} else {
 		grid_forward_tile<D, F, SPT, false>(lv, io, grid, level, first, x, out);
 	}
@@ -1980,7 +1995,7 @@ static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t 
 		ForwardPlan plan = {};
 		plan.tiles = div_round_up(n, tile_samples);
 		uint64_t total = 0;
-		uint32_t cost[MAX_N_LEVELS];
+		uint32_t cost[MAX_N_LEVELS], n_regions[MAX_N_LEVELS];
 		for (uint32_t l = 0; l < meta.n_levels; ++l) {
 			const size_t table_bytes = (size_t)(meta.offset[l + 1] - meta.offset[l]) * meta.n_feat * sizeof(half_t);
 			const uint32_t entries = meta.offset[l + 1] - meta.offset[l];
@@ -2002,30 +2017,39 @@ static ForwardPlan make_forward_plan(const GridMeta& meta, uint32_t n, uint32_t 
 			                    : hashed ? 8.0 * (1.0 + 2.5 * miss)
 			                             : (4.6 + 1.15 * std::log2(in_l2 / (24.0 * 1024.0))) * (1.0 + 0.8 * miss);
 			cost[l] = uniform ? 16u : (uint32_t)(4.0 * base + 0.5);  // (quarter-microsecond units: the cuts fall on whole tiles)
-			total += (uint64_t)cost[l] * plan.tiles;
+			n_regions[l] = 1u;
+			if (EXP_FWD_REGION_LOG2 != 0u && hashed && level_is_fast(meta, l) && entries > (1u << EXP_FWD_REGION_LOG2)) {
+				// region-pass timing build (exp_diag.h): the level is walked once per 2^EXP_FWD_REGION_LOG2-entry slice of its table, every pass
+				// fetching only the corners inside its slice -- priced like a pass over an L2-resident table with a fraction of the lanes active
+				n_regions[l] = entries >> EXP_FWD_REGION_LOG2;
+				cost[l] = (uint32_t)(4.0 * EXP_FWD_REGION_COST + 0.5);
+			}
+			total += (uint64_t)cost[l] * plan.tiles * n_regions[l];
 		}
 		bool ok = true;
 		uint64_t done = 0;  // cost of the items already assigned
 		uint32_t xcd = 0;
 		for (uint32_t l = 0; l < meta.n_levels && ok; ++l) {
-			uint32_t t = 0;
-			while (t < plan.tiles) {
-				// XCD `xcd` takes items while the cost assigned so far stays below its cumulative share
-				const uint64_t limit = (total * (xcd + 1) + 7) / 8;
-				uint32_t take = (uint32_t)std::min<uint64_t>(plan.tiles - t, (limit - done + cost[l] - 1) / cost[l]);
-				if (xcd == 7) take = plan.tiles - t;
-				if (take > 0) {
-					uint32_t& ns = plan.n_segments[xcd];
-					if (ns == FWD_MAX_SEGMENTS) {
-						ok = false;
-						break;
+			for (uint32_t region = 0; region < n_regions[l] && ok; ++region) {
+				uint32_t t = 0;
+				while (t < plan.tiles) {
+					// XCD `xcd` takes items while the cost assigned so far stays below its cumulative share
+					const uint64_t limit = (total * (xcd + 1) + 7) / 8;
+					uint32_t take = (uint32_t)std::min<uint64_t>(plan.tiles - t, (limit - done + cost[l] - 1) / cost[l]);
+					if (xcd == 7) take = plan.tiles - t;
+					if (take > 0) {
+						uint32_t& ns = plan.n_segments[xcd];
+						if (ns == FWD_MAX_SEGMENTS) {
+							ok = false;
+							break;
+						}
+						plan.segments[xcd][ns++] = {l, t, t + take, meta.offset[l + 1] - meta.offset[l], meta.resolution[l], __builtin_bit_cast(uint32_t, meta.scale[l]),
+						                            meta.offset[l], (level_is_fast(meta, l) ? 1u : 0u) | (EXP_FWD_REGION_LOG2 != 0u ? (region << 8) | (n_regions[l] << 16) : 0u)};
+						t += take;
+						done += (uint64_t)take * cost[l];
 					}
-					plan.segments[xcd][ns++] = {l, t, t + take, meta.offset[l + 1] - meta.offset[l], meta.resolution[l], __builtin_bit_cast(uint32_t, meta.scale[l]),
-					                            meta.offset[l], level_is_fast(meta, l) ? 1u : 0u};
-					t += take;
-					done += (uint64_t)take * cost[l];
+					if (done >= limit && xcd < 7) ++xcd;
 				}
-				if (done >= limit && xcd < 7) ++xcd;
 			}
 		}
 		if (ok) return plan;

@@ -108,7 +108,8 @@ WORKLOADS["hash_shipped"] = {
 # stage (HIP-event span inside the library) -> the kernel it brackets, as it appears in the rocprofv3 kernel stats
 STAGE_KERNEL = {"grid_forward": "tcnn_hip::k_grid_forward_tiles", "mlp_forward": "tcnn_hip::k_mlp_forward", "loss": "tcnn_hip::k_loss",
                 "mlp_backward": "tcnn_hip::k_mlp_transpose_weights + k_mlp_backward + k_mlp_finalize_gradients",
-                "mlp_train_fused": "tcnn_hip::k_mlp_train_wave (128 neurons: k_mlp_train_wide; else k_mlp_train) + k_mlp_finalize_gradients",
+                "mlp_train_fused": "tcnn_hip::k_mlp_train_wave (128 neurons: k_mlp_train_wide; else k_mlp_train); its weight-gradient slabs are summed inside k_adam_step's launch "
+                                   "(k_mlp_finalize_gradients only where the optimizer does not run in the same call)",
                 "grid_backward_scatter": "tcnn_hip::k_grid_bucket_scatter", "grid_backward": "tcnn_hip::k_grid_bucket_owner",
                 "adam": "tcnn_hip::k_adam_step"}
 # the kernel with the largest share of a step in the rocprofv3 kernel statistics of each workload (profiles/r03_kernel_stats*.csv)
@@ -712,7 +713,7 @@ def main():
         if "mfma" not in roofline and net_ms > 0:  # the network stages against the matrix-core roof, whichever stage dominates the step
             tflops = network_flops_per_sample(w) * local_batch / (net_ms * 1e-3) / 1e12
             roofline["mfma"] = {"achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
-                                "stages": "mlp_forward + mlp_backward + mlp_train_fused (incl. k_mlp_finalize_gradients)", "ms": net_ms}
+                                "stages": "mlp_forward + mlp_backward + mlp_train_fused (the slab summation rides in the adam stage)", "ms": net_ms}
         line = {
             "metric": w["metric"] + (", 1/2/4/8 GPU" if args.workload == "hash" else ""),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

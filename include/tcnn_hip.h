@@ -327,8 +327,8 @@ int tcnn_trainer_get_stage_times(tcnn_trainable_model_t* tm, double* total_ms, u
 int tcnn_get_fused_network_passes(void);
 int tcnn_set_fused_network_passes(int enable);
 /* training_step with an Identity encoding that pads nothing (n_input_dims a multiple of 16; identity.h:46-66): the network kernel reads the
- * caller's fp32 matrix itself where an instance offers it (64 inputs, 64 neurons, two hidden layers: the benchmarks/mlp shape) instead of
- * running the encoding as a kernel of its own; same bits.  Process-wide, default on; 0 restores the separate kernel (A/B runs). */
+ * caller's fp32 matrix itself where an instance offers it (training_step: 64 inputs, 64 neurons, one or two hidden layers -- the second is the
+ * benchmarks/mlp shape; inference: every register-resident instance with 64 inputs) instead of running the encoding as a kernel of its own; same bits.  Process-wide, default on; 0 restores the separate kernel (A/B runs). */
 int tcnn_set_fused_identity_input(int enable);
 /* training_step(run_optimizer = 1) that runs the whole step itself (one GPU: no gradient exchange, no ready callback, GradientMode::Overwrite):
  * the fp32 weight-gradient slabs of the network kernel are summed by the first workgroups of the optimizer's launch -- the same additions in

@@ -335,6 +335,15 @@ int tcnn_set_fused_identity_input(int enable);
  * the same order as the stand-alone finalize kernel, the same bits -- instead of by a launch of their own (fully_fused_mlp.cu:776-835 runs
  * split-K GEMMs there).  Process-wide, default on; 0 restores the separate kernel (A/B runs, tests). */
 int tcnn_set_finalize_in_optimizer(int enable);
+/* training_step as one graph launch (Trainer::training_step runs its passes under CudaGraph::capture_guard, trainer.h:343-350,
+ * cuda_graph.h:65-155): with capture on, every training_step on a non-null stream that is not already capturing re-records its launches
+ * into a graph, patches the instantiated graph with it (hipGraphExecUpdate; a changed topology re-instantiates) and launches that.  The first
+ * step of a shape (batch size, which optional arguments are present) runs plainly so that the stream's scratch cache holds every block the
+ * capture will ask for; steps with a gradient exchange, a ready callback, a direct exchange or profiling run plainly too.  Default OFF: on
+ * MI355X a replayed step measures the same as the plain one at every batch size, the switch exists for hosts that want
+ * the reference's behaviour.  _stats: graph launches and instantiations so far. */
+int tcnn_trainer_set_graph_capture(tcnn_trainable_model_t* tm, int enable);
+int tcnn_trainer_graph_capture_stats(const tcnn_trainable_model_t* tm, uint64_t* launches, uint64_t* instantiations);
 /* Tuning knob: bytes of LDS one grid-backward workgroup uses for the table slice it owns (default 64 KiB). */
 int tcnn_trainer_set_lds_level_budget(tcnn_trainable_model_t* tm, uint32_t bytes);
 /* Grid backward formulation, process-wide: 0 = owner-computes LDS slices with fp32 accumulation on hashed levels,

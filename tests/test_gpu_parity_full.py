@@ -16,6 +16,7 @@ Bars (the fp16 tolerance of BASELINE.json's north_star, stated here):
   * Adam: first / second moments and step counters bit-exact, fp32 master weights within 4 ulp (powf of the bias
     correction is not correctly rounded on either side), fp16 weights = RNE of the GPU's own master weights.
 """
+import math
 import msgpack
 import numpy as np
 import pytest
@@ -430,6 +431,72 @@ def test_weight_gradient_slabs_summed_inside_the_optimizer_launch_equal_the_sepa
             assert float(d.max()) <= 2.0 ** -8 * float(ga[nm:].float().abs().max()) and float((d > 0).float().mean()) < 0.05, step
     finally:
         T._C.set_finalize_in_optimizer(True)
+
+
+def test_training_step_as_one_graph_launch_leaves_the_plain_steps_bits():
+    """tcnn_trainer_set_graph_capture (trainer.h:343-350, cuda_graph.h:65-155: the reference records its passes into a CUDA graph on every
+    call, patches the instantiated graph and launches it): on a non-null stream every training_step after the first of a shape is ONE graph
+    launch.  From identical states a captured and a plain step leave bit-identical network gradients, weights and optimizer state and the same
+    prediction in the context (the encoding's part within the run-to-run spread of its coarse levels' packed-half atomics); a new batch size
+    runs plainly once and is captured again; the null stream and profiled steps are never captured."""
+    T = tcnn()
+    cfg = config_hash(log2_hashmap_size=15, per_level_scale=1.5)
+    a, b = T.create_from_config(3, 4, cfg, seed=21), T.create_from_config(3, 4, cfg, seed=22)
+    nm = a.n_mlp_params
+    side = torch.cuda.Stream()
+    a.set_graph_capture(True)
+    expected_launches = 0
+    seen_shapes = set()
+    with torch.cuda.stream(side):
+        for step, n in enumerate([4096, 4096, 4096, 1024, 1024, 4096, 4096]):
+            b.deserialize(a.serialize(serialize_optimizer=True))
+            b.set_params_full_precision(a.params_full_precision.clone())
+            pos = positions(n, 3, seed=300 + step)
+            x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(targets_for(pos, 4)).cuda()
+            side.synchronize()
+            want_ctx = n == 4096
+            ca = a.training_step(x, t, want_context=want_ctx)
+            cb = b.training_step(x, t, want_context=want_ctx)
+            side.synchronize()
+            # the first step of a shape runs plainly (it fills the stream's scratch cache); a step of another shape forgets the previous one
+            shape = (n, want_ctx)
+            if seen_shapes == {shape}:
+                expected_launches += 1
+            seen_shapes = {shape}
+            assert a.graph_capture_stats()[0] == expected_launches, (step, a.graph_capture_stats())
+            if want_ctx:
+                assert torch.equal(ca.output.view(torch.int16), cb.output.view(torch.int16)), step
+                assert abs(a.loss(ca) - b.loss(cb)) <= 1e-6 * abs(b.loss(cb)), step
+            ga, gb = a.param_gradients, b.param_gradients
+            assert torch.equal(ga[:nm].view(torch.int16), gb[:nm].view(torch.int16)), step
+            assert torch.equal(a.params[:nm].view(torch.int16), b.params[:nm].view(torch.int16)), step
+            assert torch.equal(a.params_full_precision[:nm].view(torch.int32), b.params_full_precision[:nm].view(torch.int32)), step
+            for u, v in zip(_optimizer_state(a)[:3], _optimizer_state(b)[:3]):
+                assert np.array_equal(u[:nm], v[:nm]), step
+            d = (ga[nm:].float() - gb[nm:].float()).abs()
+            assert float(d.max()) <= 2.0 ** -8 * float(ga[nm:].float().abs().max()) and float((d > 0).float().mean()) < 0.05, step
+    launches, instantiations = a.graph_capture_stats()
+    assert launches == expected_launches and launches >= 2 and 1 <= instantiations <= launches
+    assert b.graph_capture_stats() == (0, 0)
+    # the null stream is never captured (cuda_graph.h:67-69), a profiled step neither (its events would be recorded into the graph)
+    pos = positions(4096, 3, seed=99)
+    x, t = torch.from_numpy(pos).cuda(), torch.from_numpy(targets_for(pos, 4)).cuda()
+    for _ in range(3):
+        a.training_step(x, t)
+    assert a.graph_capture_stats()[0] == launches
+    a.set_profiling(True)
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            a.training_step(x, t)
+    a.set_profiling(False)
+    torch.cuda.synchronize()
+    assert a.graph_capture_stats()[0] == launches
+    a.set_graph_capture(False)
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            a.training_step(x, t)
+    torch.cuda.synchronize()
+    assert a.graph_capture_stats()[0] == launches and math.isfinite(a.loss(a.training_step(x, t)))
 
 
 @pytest.mark.parametrize("scale,offset,loss,hidden_layers", [(1.0, 0.0, "L2", 2), (0.5, 0.25, "RelativeL2", 2), (1.0, 0.0, "RelativeL2", 1)])

@@ -1078,6 +1078,14 @@ struct tcnn_trainable_model {
 	// training_step on one GPU: the network kernel's fp32 weight-gradient slabs of THIS step, summed inside the optimizer's launch instead
 	// of by a kernel of their own (AdamFinalize); set by training_step_fused for the optimizer step it runs itself, empty otherwise
 	AdamFinalize pending_finalize;
+	// training_step as ONE graph launch (tcnn_trainer_set_graph_capture; Trainer::training_step runs its passes under CudaGraph::capture_guard,
+	// trainer.h:343-350, cuda_graph.h:65-155): every call re-records its launches into a graph, patches the instantiated graph with it and
+	// launches that.  `graph_warm`: the shape (batch size and the flags that decide which scratch blocks a step takes) whose step has run
+	// once outside a capture, so that the capture finds every block in the stream's cache and allocates nothing.
+	bool graph_capture = false;
+	hipGraphExec_t graph_exec = nullptr;
+	uint64_t graph_warm = ~0ull;
+	uint64_t graph_launches = 0, graph_instantiations = 0;
 	// data-parallel hosts: called between backward and the optimizer (tcnn_trainer_set_gradient_exchange)
 	void (*exchange)(void* user, void* gradients_fp16, size_t n_params, tcnn_stream_t stream) = nullptr;
 	void* exchange_user = nullptr;
@@ -1677,6 +1685,7 @@ void tcnn_trainable_model_destroy(tcnn_trainable_model_t* tm) {
 	device_free(tm->loss_scratch);
 	for (hipEvent_t e : tm->comm_events) (void)hipEventDestroy(e);
 	if (tm->comm_stream) (void)hipStreamDestroy(tm->comm_stream);
+	if (tm->graph_exec) (void)hipGraphExecDestroy(tm->graph_exec);
 	delete tm;
 }
 
@@ -2296,8 +2305,62 @@ int tcnn_trainer_training_step(tcnn_trainable_model_t* tm, tcnn_stream_t stream,
 	}
 	tcnn_train_context_t* ctx = nullptr;
 	if (g_fused_network_passes.load() && tm->md.has_network && mlp_train_supported(tm->md.net.mlp) && (external_dL_dy || (target && loss_is_elementwise(tm->loss)))) {
+		// The step as one graph launch (opt-in; the reference's capture_guard).  Not on the null stream (cuda_graph.h:67-69), not inside a
+		// capture of the caller's (:72-76), not with an exchange / ready callback (their collectives live on other streams) or a profiler
+		// (its events would be recorded into the graph), and not before a plain step of the same shape has filled the stream's scratch cache.
+		const uint64_t shape = (uint64_t)n | ((uint64_t)(dL_dinput != nullptr) << 32) | ((uint64_t)(gradient_mode & 3) << 33) | ((uint64_t)(use_inference_params != 0) << 35) |
+		                       ((uint64_t)(external_dL_dy != nullptr) << 36) | ((uint64_t)(ctx_out != nullptr) << 37) | ((uint64_t)(run_optimizer != 0) << 38) |
+		                       ((uint64_t)(data_pdf != nullptr) << 39);
+		bool capture = tm->graph_capture && stream != nullptr && !tm->profiler && !tm->exchange && !tm->direct.active() && !wants_ready_ranges(tm) && n > 0 &&
+		               tm->graph_warm == shape && (debug_launch_flags() & 1) == 0;
+		if (capture) {
+			hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+			if (hipStreamIsCapturing((hipStream_t)stream, &status) != hipSuccess || status != hipStreamCaptureStatusNone) capture = false;
+		}
+		if (capture && hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+			(void)hipGetLastError();
+			capture = false;
+		}
 		int r = training_step_fused(tm, (hipStream_t)stream, loss_scale, n, input, target, data_pdf, dL_dinput, use_inference_params, gradient_mode,
 		                            run_optimizer != 0, (const half_t*)external_dL_dy, &ctx, /*context_wanted=*/ctx_out != nullptr);
+		if (capture) {
+			hipGraph_t graph = nullptr;
+			const hipError_t ended = hipStreamEndCapture((hipStream_t)stream, &graph);  // (always: the stream must leave capture mode, whatever happened)
+			if (r == TCNN_OK && (ended != hipSuccess || !graph)) {
+				(void)hipGetLastError();
+				tm->graph_capture = false;  // the step was recorded, not run, and its host-side effects (step count) have happened: say so loudly, once
+				g_last_error = std::string("training_step: capturing the step into a graph failed (") + hipGetErrorString(ended) + "); graph capture is switched off, this step did not run";
+				r = TCNN_ERROR;
+			}
+			if (r == TCNN_OK) {
+				if (tm->graph_exec) {  // patch the instantiated graph with this step's arguments (cuda_graph.h:118-138); a new topology re-instantiates
+					hipGraphNode_t error_node = nullptr;
+					hipGraphExecUpdateResult result = hipGraphExecUpdateSuccess;
+					if (hipGraphExecUpdate(tm->graph_exec, graph, &error_node, &result) != hipSuccess || result != hipGraphExecUpdateSuccess) {
+						(void)hipGetLastError();
+						(void)hipGraphExecDestroy(tm->graph_exec);
+						tm->graph_exec = nullptr;
+					}
+				}
+				hipError_t e = hipSuccess;
+				if (!tm->graph_exec) {
+					e = hipGraphInstantiate(&tm->graph_exec, graph, nullptr, nullptr, 0);
+					++tm->graph_instantiations;
+				}
+				if (e == hipSuccess) e = hipGraphLaunch(tm->graph_exec, (hipStream_t)stream);
+				if (e != hipSuccess) {
+					(void)hipGetLastError();
+					tm->graph_capture = false;
+					g_last_error = std::string("training_step: launching the captured step failed (") + hipGetErrorString(e) + "); graph capture is switched off, this step did not run";
+					r = TCNN_ERROR;
+				} else {
+					++tm->graph_launches;
+				}
+			}
+			if (graph) (void)hipGraphDestroy(graph);
+		} else if (r == TCNN_OK) {
+			tm->graph_warm = shape;
+		}
 		if (r == TCNN_OK) r = settle_unstepped_reductions(tm, (hipStream_t)stream, run_optimizer != 0);
 		if (ctx_out && r == TCNN_OK) {
 			*ctx_out = ctx;
@@ -2665,6 +2728,24 @@ int tcnn_set_finalize_in_optimizer(int enable) {
 	return TCNN_OK;
 }
 int tcnn_get_fused_network_passes(void) { return g_fused_network_passes.load(); }
+int tcnn_trainer_set_graph_capture(tcnn_trainable_model_t* tm, int enable) {
+	TCNN_API_BEGIN
+	if (!tm) throw std::runtime_error("tcnn_trainer_set_graph_capture: null model");
+	tm->graph_capture = enable != 0;
+	if (!enable && tm->graph_exec) {
+		HIP_CHECK(hipDeviceSynchronize());
+		(void)hipGraphExecDestroy(tm->graph_exec);
+		tm->graph_exec = nullptr;
+	}
+	TCNN_API_END
+}
+int tcnn_trainer_graph_capture_stats(const tcnn_trainable_model_t* tm, uint64_t* launches, uint64_t* instantiations) {
+	TCNN_API_BEGIN
+	if (!tm) throw std::runtime_error("tcnn_trainer_graph_capture_stats: null model");
+	if (launches) *launches = tm->graph_launches;
+	if (instantiations) *instantiations = tm->graph_instantiations;
+	TCNN_API_END
+}
 int tcnn_set_fused_network_passes(int enable) {
 	g_fused_network_passes.store(enable != 0 ? 1 : 0);
 	return TCNN_OK;

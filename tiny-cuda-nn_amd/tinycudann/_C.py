@@ -168,6 +168,8 @@ _sig("tcnn_trainer_n_stages", _i)
 _sig("tcnn_trainer_stage_name", _cp, _i)
 _sig("tcnn_trainer_get_stage_times", _i, _vp, _vp, _vp)
 _sig("tcnn_trainer_set_lds_level_budget", _i, _vp, _u32)
+_sig("tcnn_trainer_set_graph_capture", _i, _vp, _i)
+_sig("tcnn_trainer_graph_capture_stats", _i, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 _sig("tcnn_get_fused_network_passes", _i)
 _sig("tcnn_set_fused_network_passes", _i, _i)
 _sig("tcnn_set_finalize_in_optimizer", _i, _i)

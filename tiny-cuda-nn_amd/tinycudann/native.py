@@ -318,6 +318,16 @@ class TrainableModel:
         _check(_lib.tcnn_trainer_direct_selftest(self._h, _stream(), int(rounds), int(seed), C.byref(bad), C.byref(st)))
         return bad.value, st.value
 
+    def set_graph_capture(self, enable=True):
+        """training_step as one graph launch on non-null streams (trainer.h:343-350: the reference captures its passes into a CUDA graph)."""
+        _check(_lib.tcnn_trainer_set_graph_capture(self._h, int(enable)))
+
+    def graph_capture_stats(self):
+        """(graph launches, graph instantiations) so far."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(_lib.tcnn_trainer_graph_capture_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     # ---- measurement hooks ---------------------------------------------------------------------
     def set_profiling(self, enable=True, only_stage=None):
         """HIP events around the stages of the training step, on the stream the kernels run on."""

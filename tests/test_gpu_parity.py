@@ -586,7 +586,7 @@ def test_full_size_training_converges():
 
 @pytest.fixture(params=["compiled", "ctypes"])
 def binding(request, monkeypatch):
-    """Both bindings behind the tinycudann modules: the compiled extension (tinycudann/ext/bindings.cpp -> _tcnn_ext.so: pybind11 Module + the
+    """Both bindings behind the tinycudann modules: the compiled extension (tinycudann/ext/torch_module.cpp -> _tcnn_ext.so: pybind11 Module + the
     autograd function pair in C++, what the reference ships) and the ctypes classes of _C.py (the fallback when the extension is not built)."""
     C = tcnn()._C
     if request.param == "compiled":

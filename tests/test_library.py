@@ -404,7 +404,7 @@ def test_no_register_of_a_hand_issued_load_is_touched_before_its_wait(tmp_path, 
 
 
 def test_compiled_torch_binding_builds_and_mirrors_the_reference_module():
-    """tinycudann/ext/bindings.cpp -> _tcnn_ext.so (built by __graft_entry__.build(); g++ against torch's headers, no device code): importable
+    """tinycudann/ext/torch_module.cpp -> _tcnn_ext.so (built by __graft_entry__.build(); g++ against torch's headers, no device code): importable
     without a GPU, bound to the library _C.py loaded, `Module` with the reference's method names (bindings.cpp:322-335), the three factories
     (bindings.cpp:337-341) -- and the modules of the package pick it up."""
     sys.path.insert(0, os.path.join(ROOT, "tiny-cuda-nn_amd"))

@@ -25,7 +25,7 @@ if not os.path.exists(_LIB_PATH):
 
 _lib = C.CDLL(_LIB_PATH)
 
-# The compiled binding (ext/bindings.cpp -> _tcnn_ext.so: the reference's pybind11 module over the same C ABI, with the autograd function pair
+# The compiled binding (ext/torch_module.cpp -> _tcnn_ext.so: the reference's pybind11 module over the same C ABI, with the autograd function pair
 # in C++): used for the module path when it has been built (__graft_entry__.build() builds it); TCNN_TORCH_EXT=0 forces the ctypes classes
 # below, which remain the fallback and the surface of everything but the modules (trainer, generators, debugging aids).
 EXT = None
@@ -566,7 +566,7 @@ def _dumps(cfg):
 
 
 class ExtModule:
-    """The compiled binding's Module (ext/bindings.cpp) behind the surface of the ctypes `Module` above: fwd / bwd / bwd_bwd_input / initial_params and
+    """The compiled binding's Module (ext/torch_module.cpp) behind the surface of the ctypes `Module` above: fwd / bwd / bwd_bwd_input / initial_params and
     the accessors are the C++ methods; the parity helpers go through ctypes on the same native handle."""
 
     def __init__(self, m):

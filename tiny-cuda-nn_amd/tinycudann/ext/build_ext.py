@@ -1,12 +1,12 @@
 """Builds the compiled PyTorch binding in-tree: tinycudann/_tcnn_ext.so (g++ against torch's headers; no device code, nothing hipified --
-ext/bindings.cpp is plain C++ over the C ABI).  Called by __graft_entry__.build(); `python -m tinycudann.ext.build_ext` from tiny-cuda-nn_amd/ works too."""
+ext/torch_module.cpp is plain C++ over the C ABI).  Called by __graft_entry__.build(); `python -m tinycudann.ext.build_ext` from tiny-cuda-nn_amd/ works too."""
 import os
 import subprocess
 import sys
 import sysconfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "bindings.cpp")
+SRC = os.path.join(HERE, "torch_module.cpp")
 OUT = os.path.join(os.path.dirname(HERE), "_tcnn_ext.so")
 
 

@@ -139,7 +139,7 @@ class Module(torch.nn.Module):
             x = torch.nn.functional.pad(x, [0, 0, 0, padded - batch_size])
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.to(torch.float).contiguous()
-        if _C.EXT is not None:  # the compiled binding: one C++ autograd node (ext/bindings.cpp NativeFunction)
+        if _C.EXT is not None:  # the compiled binding: one C++ autograd node (ext/torch_module.cpp NativeFunction)
             y = _C.ext_apply(self.native_tcnn_module, x, self.params.to(self.dtype).contiguous(), self.loss_scale)
         else:
             y = _NativeFunction.apply(self.native_tcnn_module, x, self.params.to(self.dtype).contiguous(), self.loss_scale)

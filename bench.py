@@ -262,7 +262,7 @@ def launch_ranks(argv, n):
 # launch, the gradients are exchanged in between) and the link model: one xGMI link per peer, ~153 GB/s per link and direction (SURVEY
 # section 5), the 28.5 MB fp16 gradient buffer (and as many bytes of 16-bit parameters back).
 PREDICTION_INPUTS = {
-    "compute_ms_by_batch": {262144: 0.2223 + 0.005, 131072: 0.1300 + 0.005, 65536: 0.0917 + 0.005, 32768: 0.0720 + 0.005},
+    "compute_ms_by_batch": {262144: 0.2166 + 0.004, 131072: 0.1278 + 0.004, 65536: 0.0877 + 0.004, 32768: 0.0718 + 0.004},
     "adam_full_ms": 0.0705,         # 14.2 M parameters, 416 MB at 6 TB/s: shrinks by P when every rank steps its own shard
     "exchange_bytes": 28.5e6,       # fp16 gradients out, 16-bit parameters back: the same count twice per step
     "link_GBps": 153.0,             # per link and direction
@@ -282,7 +282,7 @@ def predicted_step(world, per_gpu_batch, mode):
     if compute is None or world < 1:
         return None
     if world == 1:
-        return {"ms_per_step": compute - 0.005 + pi["adam_full_ms"], "mode": "single GPU (measured, not a model)"}
+        return {"ms_per_step": compute - 0.004 + pi["adam_full_ms"], "mode": "single GPU (measured, not a model)"}
     shard_ms = pi["exchange_bytes"] / world / (pi["link_GBps"] * 1e9) * 1e3
     if mode.startswith("direct"):
         exchange = 2 * shard_ms + 2 * pi["signal_round_ms"]
